@@ -1,0 +1,226 @@
+/*
+ * similari_assoc.h — C ABI of the MI355X-native association engine.
+ *
+ * This is the drop-in boundary for ONE hot path of insight-platform/Similari:
+ * the per-frame  N_candidates x T_tracks  cost matrices (cosine / euclidean /
+ * IoU / Mahalanobis, pair pre-filter) and the assignment solve (BestFit visual
+ * vote + max-weight "Hungarian" vote).  In the reference that path is the pair
+ * of statements
+ *
+ *     store.foreign_track_distances(tracks, 0, false);  voting.winners(dists)
+ *
+ * inside  Sort::predict_with_scene          src/trackers/sort/simple_api.rs:147-162
+ *         VisualSort::predict_with_scene    src/trackers/visual_sort/simple_api.rs:172-187
+ *         BatchSort::predict / voting_thread        src/trackers/sort/batch_api.rs:269-288, 83-98
+ *         BatchVisualSort::predict / voting_thread  src/trackers/visual_sort/batch_api.rs:296-315, 92-100
+ *
+ * Everything here is plain C: pointers, sizes, POD structs, int status codes.
+ * A Rust `extern "C"` block (or cgo / ctypes) binds it 1:1 — see INTEGRATION.md.
+ *
+ * Ownership: the caller owns every buffer passed in or out.  The engine copies
+ * inputs to device-resident structure-of-arrays storage; track state (boxes,
+ * Kalman projection, feature banks) persists on the device across frames, the
+ * way the reference keeps it inside TrackStore.  Handles are freed only by the
+ * matching *_destroy.  No callbacks.
+ *
+ * Threading: calls on one handle are not re-entrant (the reference's predict
+ * takes &mut self).  Distinct handles (one per GPU / process) are independent.
+ *
+ * Errors: every function returns an sa_status (0 = ok, < 0 = error) and never
+ * aborts; sa_last_error() returns a human-readable message for the last error
+ * on that handle.  The reference's assert!s (aspect/height > 0 bbox.rs:453-456,
+ * confidence in [0,1] bbox.rs:123-126, ids > 0 sort/voting.rs:57) become
+ * SA_ERR_BAD_ARG.
+ */
+#ifndef SIMILARI_ASSOC_H
+#define SIMILARI_ASSOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_API_VERSION 1u
+
+typedef enum sa_status {
+  SA_OK = 0,
+  SA_ERR_BAD_ARG = -1,     /* null pointer, bad size, reference assert! violated */
+  SA_ERR_OOM = -2,         /* host or device allocation failed                   */
+  SA_ERR_HIP = -3,         /* a HIP runtime call failed (message has the code)   */
+  SA_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve              */
+  SA_ERR_NOT_FOUND = -5,   /* unknown scene / track id                           */
+  SA_ERR_STATE = -6,       /* call sequence violated (e.g. fetch before run)     */
+  SA_ERR_NO_DEVICE = -7    /* no gfx950 device visible: the engine has NO CPU fallback */
+} sa_status;
+
+/* PositionalMetricType  src/trackers/sort.rs:366-371 */
+typedef enum sa_positional_kind { SA_POS_IOU = 0, SA_POS_MAHALANOBIS = 1 } sa_positional_kind;
+/* VisualSortMetricType  src/trackers/visual_sort/metric.rs:20-24 */
+typedef enum sa_visual_kind { SA_VIS_NONE = 0, SA_VIS_COSINE = 1, SA_VIS_EUCLIDEAN = 2 } sa_visual_kind;
+/* VotingType  src/trackers/sort.rs:360-364 ; 0 = no winner (candidate starts a new track) */
+typedef enum sa_voting_type { SA_VOTE_NONE = 0, SA_VOTE_VISUAL = 1, SA_VOTE_POSITIONAL = 2 } sa_voting_type;
+
+/* Universal2DBox  src/utils/bbox.rs:78-87  (angle: Option<f32> -> has_angle + angle). */
+typedef struct sa_box {
+  float xc, yc;
+  float angle;       /* radians; ignored when has_angle == 0                 */
+  float aspect;      /* width / height, must be > 0                          */
+  float height;      /* must be > 0                                          */
+  float confidence;  /* must lie in [0, 1]                                   */
+  int32_t has_angle; /* Option::is_some                                      */
+  int32_t reserved;  /* must be 0                                            */
+} sa_box;            /* 32 bytes */
+
+/* Engine configuration = the option structs the reference's trackers are built from:
+ * Sort::new args (sort/simple_api.rs:41-50), VisualSortOptions (visual_sort/options.rs:10-205),
+ * VisualMetricBuilder defaults (visual_sort/metric/builder.rs:26-42). */
+typedef struct sa_config {
+  uint32_t struct_size;  /* = sizeof(sa_config), for ABI evolution */
+  int32_t device;        /* HIP device ordinal, -1 = current device */
+  void* stream;          /* hipStream_t to launch on; NULL = engine creates its own */
+
+  int32_t positional_kind;          /* sa_positional_kind */
+  float positional_threshold;       /* IoU(t); ignored for Mahalanobis (new-track threshold is 1.0, sort.rs:379) */
+  float positional_min_confidence;  /* SortMetric min_confidence / VisualMetric positional_min_confidence */
+
+  int32_t visual_kind;              /* sa_visual_kind; SA_VIS_NONE = plain SORT */
+  float visual_threshold;           /* Cosine(t): keep d >= t ; Euclidean(t): keep d <= t */
+  uint32_t feature_len;             /* D, floats per feature vector (un-padded) */
+  uint32_t max_observations;        /* K = visual_max_observations (feature bank depth per track) */
+  uint32_t visual_min_votes;
+  uint32_t visual_minimal_track_length;
+  float visual_minimal_area;
+  float visual_minimal_quality_use;
+  float visual_minimal_own_area_percentage_use;
+
+  uint64_t max_idle_epochs;
+  /* SpatioTemporalConstraints (spatio_temporal_constraints.rs:15-59): pairs (epoch_delta, max_dist). */
+  uint32_t n_constraints;
+  const uint64_t* constraint_epoch_delta;
+  const float* constraint_max_dist;
+
+  float kf_position_weight;         /* 1/20  by default (kalman_2d_box.rs:26)  */
+  float kf_velocity_weight;         /* 1/160 by default                        */
+
+  uint32_t flags;                   /* SA_FLAG_* */
+} sa_config;
+
+#define SA_FLAG_NO_GRAPH 0x1u       /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define SA_FLAG_PROFILE 0x2u        /* bracket every kernel with hipEvents (implies eager launches)    */
+
+/* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,
+ * max_idle_epochs 5? -> no: caller must set it; KF weights 1/20, 1/160). */
+void sa_config_default(sa_config* cfg);
+
+typedef struct sa_engine sa_engine;
+
+int sa_engine_create(const sa_config* cfg, sa_engine** out);
+void sa_engine_destroy(sa_engine* e);
+const char* sa_last_error(const sa_engine* e); /* e may be NULL: last create() error of this thread */
+uint32_t sa_api_version(void);
+
+/* ---- track state (what TrackStore holds for this path) ------------------------------------
+ * One row per stored track.  `boxes` = the track's last predicted box, i.e. the bbox of
+ * observation[0] and predicted_boxes.back() (sort.rs:252-253).  `kf_mean`/`kf_cov` =
+ * rows 0..5 of the Kalman state mean and the top-left 5x5 block of its covariance, row-major
+ * (all `distance` reads through the identity update matrix, kalman_2d_box.rs:104-120,150-170);
+ * may be NULL for IoU engines.  `feats` = n x K x D feature bank in observation order
+ * (slot 0 = newest observation), `feat_present` = n x K flags; may be NULL for SORT engines.
+ * Upserting an id that exists replaces its row in place; new ids are appended, so a caller that
+ * hands out increasing ids (gen_track_id) keeps columns in ascending-id order. */
+typedef struct sa_tracks {
+  uint32_t n;
+  const uint64_t* ids;        /* > 0 */
+  const sa_box* boxes;
+  const uint64_t* epochs;     /* last_updated_epoch */
+  const float* kf_mean;       /* n x 5  or NULL */
+  const float* kf_cov;        /* n x 25 or NULL */
+  const float* feats;         /* n x K x D or NULL */
+  const uint8_t* feat_present;/* n x K or NULL (NULL with feats != NULL means all present) */
+} sa_tracks;
+
+int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t);
+int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids);
+int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n);
+/* Column order of the scene's track table (= column order of every matrix tap below). */
+int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t cap, uint32_t* out_n);
+
+/* ---- one frame of detections of one scene ------------------------------------------------- */
+typedef struct sa_detections {
+  uint32_t n;
+  const sa_box* boxes;
+  const float* feats;          /* n x D or NULL (no features at all)                         */
+  const uint8_t* feat_present; /* n or NULL (= all present when feats != NULL)                */
+  const float* feat_quality;   /* n or NULL (= 1.0, visual_sort/simple_api.rs:146)            */
+  const float* own_area;       /* n or NULL; NaN = None (own-area percentage of the detection) */
+} sa_detections;
+
+/* Association of one scene-frame: replaces foreign_track_distances + winners.
+ * out_track_id[i] = id of the winning stored track, or 0 when candidate i starts a new track
+ * (winner == self or no winner).  out_voting_type[i] = sa_voting_type.  Host buffers in, host
+ * buffers out; the call stages, launches, synchronises and copies back. */
+int sa_associate(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d,
+                 uint64_t* out_track_id, uint8_t* out_voting_type);
+
+/* Batched scenes (BatchSort / BatchVisualSort): all scenes of one request go through ONE set
+ * of kernel launches (grid.z = scene).  Split form, so a caller can keep inputs resident and
+ * time only the device work:
+ *   sa_batch_begin  — waits for the previous batch (the reference's "busy monitor",
+ *                     sort/batch_api.rs:233-241), clears the staged list
+ *   sa_batch_add    — stage one scene's detections (async H2D); returns its slot in *out_slot
+ *   sa_batch_run    — enqueue the whole pipeline on the engine's stream; does not synchronise
+ *   sa_batch_sync   — wait for the stream
+ *   sa_batch_fetch  — copy one scene's result back (synchronises if needed)
+ * sa_batch_run may be called repeatedly on the same staged inputs (benchmark loop). */
+int sa_batch_begin(sa_engine* e);
+int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, uint32_t* out_slot);
+int sa_batch_run(sa_engine* e);
+int sa_batch_sync(sa_engine* e);
+int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type);
+
+typedef struct sa_scene_request {
+  uint64_t scene_id;
+  uint64_t epoch;
+  sa_detections detections;
+} sa_scene_request;
+typedef struct sa_scene_result {
+  uint64_t* out_track_id;   /* detections.n entries */
+  uint8_t* out_voting_type; /* detections.n entries */
+} sa_scene_result;
+int sa_associate_batch(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, const sa_scene_result* res);
+
+/* ---- parity taps (debug / test): the matrices of the last run of batch slot `slot` --------
+ * Row = candidate in input order, column = track in sa_tracks_order() order.
+ *   positional: N x T f32, NaN = absent (SortMetric::metric / VisualMetric::positional_metric)
+ *   visual    : N x T x K f32, NaN = absent (VisualMetric::visual_metric after distance_to_weight)
+ *   quantised : N x T i64 = (w * 1e6f) as i64 of the positional value, 0 where absent
+ *               (SortVoting::winners sort/voting.rs:59; the diagonal/self columns are implicit) */
+int sa_tap_dims(sa_engine* e, uint32_t slot, uint32_t* n, uint32_t* t, uint32_t* k);
+int sa_tap_positional(sa_engine* e, uint32_t slot, float* out);
+int sa_tap_visual(sa_engine* e, uint32_t slot, float* out);
+int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+typedef struct sa_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double total_ms;   /* sum of hipEvent-bracketed durations on the engine's stream */
+} sa_kernel_stat;
+int sa_profile_reset(sa_engine* e);
+int sa_profile_read(sa_engine* e, sa_kernel_stat* out, uint32_t cap, uint32_t* out_n);
+/* hipEvent-timed wall time of `iters` back-to-back sa_batch_run()s on the engine's stream. */
+int sa_batch_time(sa_engine* e, uint32_t iters, double* out_ms_total);
+
+/* Standalone cost-matrix entry point (config C5 / MFMA roofline): out[n x t] f32 of
+ * cosine (kind 1) or euclidean (kind 2) distance between device-resident?  No: host pointers;
+ * the call copies, runs the contraction kernel `iters` times, reports the hipEvent time of the
+ * kernel alone, and copies the matrix back when out != NULL. */
+int sa_feature_distance_matrix(sa_engine* e, int32_t visual_kind, uint32_t n, uint32_t t, uint32_t d,
+                               const float* a, const float* b, float* out, uint32_t iters, double* out_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMILARI_ASSOC_H */

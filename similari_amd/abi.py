@@ -1,0 +1,311 @@
+"""ctypes mirror of include/similari_assoc.h (the C ABI of the association engine).
+
+Only POD layouts and function prototypes live here; nothing in this module computes anything.
+The shared library is built in-tree by `__graft_entry__.build()` / `similari_amd.build`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libsimilari_assoc.so"
+
+SA_OK = 0
+SA_ERR_BAD_ARG = -1
+SA_ERR_OOM = -2
+SA_ERR_HIP = -3
+SA_ERR_UNSUPPORTED = -4
+SA_ERR_NOT_FOUND = -5
+SA_ERR_STATE = -6
+SA_ERR_NO_DEVICE = -7
+
+SA_POS_IOU = 0
+SA_POS_MAHALANOBIS = 1
+SA_VIS_NONE = 0
+SA_VIS_COSINE = 1
+SA_VIS_EUCLIDEAN = 2
+SA_VOTE_NONE = 0
+SA_VOTE_VISUAL = 1
+SA_VOTE_POSITIONAL = 2
+
+SA_FLAG_NO_GRAPH = 0x1
+SA_FLAG_PROFILE = 0x2
+
+
+class sa_box(C.Structure):
+    _fields_ = [
+        ("xc", C.c_float),
+        ("yc", C.c_float),
+        ("angle", C.c_float),
+        ("aspect", C.c_float),
+        ("height", C.c_float),
+        ("confidence", C.c_float),
+        ("has_angle", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+BOX_DTYPE = np.dtype(
+    [
+        ("xc", "<f4"),
+        ("yc", "<f4"),
+        ("angle", "<f4"),
+        ("aspect", "<f4"),
+        ("height", "<f4"),
+        ("confidence", "<f4"),
+        ("has_angle", "<i4"),
+        ("reserved", "<i4"),
+    ]
+)
+assert BOX_DTYPE.itemsize == C.sizeof(sa_box) == 32
+
+
+class sa_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("stream", C.c_void_p),
+        ("positional_kind", C.c_int32),
+        ("positional_threshold", C.c_float),
+        ("positional_min_confidence", C.c_float),
+        ("visual_kind", C.c_int32),
+        ("visual_threshold", C.c_float),
+        ("feature_len", C.c_uint32),
+        ("max_observations", C.c_uint32),
+        ("visual_min_votes", C.c_uint32),
+        ("visual_minimal_track_length", C.c_uint32),
+        ("visual_minimal_area", C.c_float),
+        ("visual_minimal_quality_use", C.c_float),
+        ("visual_minimal_own_area_percentage_use", C.c_float),
+        ("max_idle_epochs", C.c_uint64),
+        ("n_constraints", C.c_uint32),
+        ("constraint_epoch_delta", C.POINTER(C.c_uint64)),
+        ("constraint_max_dist", C.POINTER(C.c_float)),
+        ("kf_position_weight", C.c_float),
+        ("kf_velocity_weight", C.c_float),
+        ("flags", C.c_uint32),
+    ]
+
+
+class sa_tracks(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("ids", C.POINTER(C.c_uint64)),
+        ("boxes", C.POINTER(sa_box)),
+        ("epochs", C.POINTER(C.c_uint64)),
+        ("kf_mean", C.POINTER(C.c_float)),
+        ("kf_cov", C.POINTER(C.c_float)),
+        ("feats", C.POINTER(C.c_float)),
+        ("feat_present", C.POINTER(C.c_uint8)),
+    ]
+
+
+class sa_detections(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("boxes", C.POINTER(sa_box)),
+        ("feats", C.POINTER(C.c_float)),
+        ("feat_present", C.POINTER(C.c_uint8)),
+        ("feat_quality", C.POINTER(C.c_float)),
+        ("own_area", C.POINTER(C.c_float)),
+    ]
+
+
+class sa_scene_request(C.Structure):
+    _fields_ = [("scene_id", C.c_uint64), ("epoch", C.c_uint64), ("detections", sa_detections)]
+
+
+class sa_scene_result(C.Structure):
+    _fields_ = [("out_track_id", C.POINTER(C.c_uint64)), ("out_voting_type", C.POINTER(C.c_uint8))]
+
+
+class sa_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+def _ptr(arr, ctype):
+    if arr is None:
+        return C.cast(None, C.POINTER(ctype))
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def make_boxes(xc, yc, aspect, height, confidence=None, angle=None) -> np.ndarray:
+    """Build an sa_box array (numpy structured, C-contiguous). angle=None -> Option::None."""
+    n = len(xc)
+    b = np.zeros(n, dtype=BOX_DTYPE)
+    b["xc"] = np.asarray(xc, np.float32)
+    b["yc"] = np.asarray(yc, np.float32)
+    b["aspect"] = np.asarray(aspect, np.float32)
+    b["height"] = np.asarray(height, np.float32)
+    b["confidence"] = 1.0 if confidence is None else np.asarray(confidence, np.float32)
+    if angle is not None:
+        b["angle"] = np.asarray(angle, np.float32)
+        b["has_angle"] = 1
+    return b
+
+
+def ltwh(l, t, w, h, confidence=1.0) -> np.ndarray:
+    """BoundingBox(left, top, width, height) -> Universal2DBox (bbox.rs:246-257), f32 arithmetic."""
+    l, t, w, h = (np.atleast_1d(np.asarray(v, np.float32)) for v in (l, t, w, h))
+    two = np.float32(2.0)
+    return make_boxes(l + w / two, t + h / two, w / h, h, confidence=np.float32(confidence))
+
+
+class Keep:
+    """Holds numpy arrays alive for the lifetime of a ctypes struct that points into them."""
+
+    def __init__(self):
+        self.refs = []
+
+    def arr(self, a, dtype, shape=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if shape is not None:
+            a = a.reshape(shape)
+        self.refs.append(a)
+        return a
+
+
+def make_config(
+    positional="iou",
+    positional_threshold=0.3,
+    positional_min_confidence=0.05,
+    visual=None,
+    visual_threshold=0.0,
+    feature_len=0,
+    max_observations=1,
+    visual_min_votes=1,
+    visual_minimal_track_length=1,
+    visual_minimal_area=0.0,
+    visual_minimal_quality_use=0.0,
+    visual_minimal_own_area_percentage_use=0.0,
+    max_idle_epochs=5,
+    constraints=(),
+    kf_position_weight=1.0 / 20.0,
+    kf_velocity_weight=1.0 / 160.0,
+    device=-1,
+    stream=None,
+    flags=0,
+):
+    """sa_config with the reference's defaults; returns (cfg, keepalive)."""
+    keep = Keep()
+    cfg = sa_config()
+    cfg.struct_size = C.sizeof(sa_config)
+    cfg.device = device
+    cfg.stream = stream
+    cfg.positional_kind = SA_POS_IOU if positional == "iou" else SA_POS_MAHALANOBIS
+    cfg.positional_threshold = positional_threshold
+    cfg.positional_min_confidence = positional_min_confidence
+    cfg.visual_kind = {None: SA_VIS_NONE, "cosine": SA_VIS_COSINE, "euclidean": SA_VIS_EUCLIDEAN}[visual]
+    cfg.visual_threshold = visual_threshold
+    cfg.feature_len = feature_len
+    cfg.max_observations = max_observations
+    cfg.visual_min_votes = visual_min_votes
+    cfg.visual_minimal_track_length = visual_minimal_track_length
+    cfg.visual_minimal_area = visual_minimal_area
+    cfg.visual_minimal_quality_use = visual_minimal_quality_use
+    cfg.visual_minimal_own_area_percentage_use = visual_minimal_own_area_percentage_use
+    cfg.max_idle_epochs = max_idle_epochs
+    # SpatioTemporalConstraints::add_constraints sorts by delta and dedups (first wins after a stable sort)
+    cons = sorted(constraints, key=lambda c: c[0])
+    dedup = []
+    for d, m in cons:
+        if not dedup or dedup[-1][0] != d:
+            dedup.append((d, m))
+    cfg.n_constraints = len(dedup)
+    deltas = keep.arr([d for d, _ in dedup], np.uint64) if dedup else None
+    dists = keep.arr([m for _, m in dedup], np.float32) if dedup else None
+    cfg.constraint_epoch_delta = _ptr(deltas, C.c_uint64)
+    cfg.constraint_max_dist = _ptr(dists, C.c_float)
+    cfg.kf_position_weight = kf_position_weight
+    cfg.kf_velocity_weight = kf_velocity_weight
+    cfg.flags = flags
+    cfg._keep = keep
+    return cfg
+
+
+def make_tracks(ids, boxes, epochs, kf_mean=None, kf_cov=None, feats=None, feat_present=None):
+    keep = Keep()
+    t = sa_tracks()
+    ids = keep.arr(ids, np.uint64)
+    t.n = len(ids)
+    boxes = keep.arr(boxes, BOX_DTYPE)
+    t.ids = _ptr(ids, C.c_uint64)
+    t.boxes = C.cast(boxes.ctypes.data, C.POINTER(sa_box)) if t.n else C.cast(None, C.POINTER(sa_box))
+    t.epochs = _ptr(keep.arr(epochs, np.uint64), C.c_uint64)
+    t.kf_mean = _ptr(keep.arr(kf_mean, np.float32), C.c_float)
+    t.kf_cov = _ptr(keep.arr(kf_cov, np.float32), C.c_float)
+    t.feats = _ptr(keep.arr(feats, np.float32), C.c_float)
+    t.feat_present = _ptr(keep.arr(feat_present, np.uint8), C.c_uint8)
+    t._keep = keep
+    return t
+
+
+def make_detections(boxes, feats=None, feat_present=None, feat_quality=None, own_area=None):
+    keep = Keep()
+    d = sa_detections()
+    boxes = keep.arr(boxes, BOX_DTYPE)
+    d.n = len(boxes)
+    d.boxes = C.cast(boxes.ctypes.data, C.POINTER(sa_box)) if d.n else C.cast(None, C.POINTER(sa_box))
+    d.feats = _ptr(keep.arr(feats, np.float32), C.c_float)
+    d.feat_present = _ptr(keep.arr(feat_present, np.uint8), C.c_uint8)
+    d.feat_quality = _ptr(keep.arr(feat_quality, np.float32), C.c_float)
+    d.own_area = _ptr(keep.arr(own_area, np.float32), C.c_float)
+    d._keep = keep
+    return d
+
+
+# ---- prototypes of every symbol include/similari_assoc.h declares -------------------------------
+u32, u64, i32, f64p = C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_double)
+P = C.POINTER
+ENGINE = C.c_void_p
+PROTOTYPES = {
+    "sa_config_default": (None, [P(sa_config)]),
+    "sa_engine_create": (C.c_int, [P(sa_config), P(ENGINE)]),
+    "sa_engine_destroy": (None, [ENGINE]),
+    "sa_last_error": (C.c_char_p, [ENGINE]),
+    "sa_api_version": (u32, []),
+    "sa_tracks_upsert": (C.c_int, [ENGINE, u64, P(sa_tracks)]),
+    "sa_tracks_remove": (C.c_int, [ENGINE, u64, u32, P(u64)]),
+    "sa_tracks_count": (C.c_int, [ENGINE, u64, P(u32)]),
+    "sa_tracks_order": (C.c_int, [ENGINE, u64, P(u64), u32, P(u32)]),
+    "sa_associate": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u64), P(C.c_uint8)]),
+    "sa_batch_begin": (C.c_int, [ENGINE]),
+    "sa_batch_add": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u32)]),
+    "sa_batch_run": (C.c_int, [ENGINE]),
+    "sa_batch_sync": (C.c_int, [ENGINE]),
+    "sa_batch_fetch": (C.c_int, [ENGINE, u32, P(u64), P(C.c_uint8)]),
+    "sa_associate_batch": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(sa_scene_result)]),
+    "sa_tap_dims": (C.c_int, [ENGINE, u32, P(u32), P(u32), P(u32)]),
+    "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
+    "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),
+    "sa_tap_quantised": (C.c_int, [ENGINE, u32, P(C.c_int64)]),
+    "sa_profile_reset": (C.c_int, [ENGINE]),
+    "sa_profile_read": (C.c_int, [ENGINE, P(sa_kernel_stat), u32, P(u32)]),
+    "sa_batch_time": (C.c_int, [ENGINE, u32, f64p]),
+    "sa_feature_distance_matrix": (
+        C.c_int,
+        [ENGINE, i32, u32, u32, u32, P(C.c_float), P(C.c_float), P(C.c_float), u32, f64p],
+    ),
+}
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """Load libsimilari_assoc.so and attach prototypes. Fails loudly when it is not built."""
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(str(p))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    return lib
