@@ -1,0 +1,361 @@
+// sa_device.h — per-cell and per-component device logic of the association engine (gfx950).
+//
+// Everything here is scalar, branch-for-branch faithful to the reference's arithmetic (f32 boxes and
+// Kalman, f64 polygon clipping, i64 quantised weights) and marked SA_HD so that tests/emu can compile
+// the very same source with g++ and check it against the oracle on the CPU (test infrastructure; the
+// product never runs these on the host).  Wave-level / MFMA code lives in the .hip files.
+//
+// Build with -ffp-contract=off: rustc never fuses a*b+c, and the bit-exact gates (IoU quantised
+// matrix, assignment indices) rely on the same rounding sequence.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SA_HD __host__ __device__ __forceinline__
+#else
+#define SA_HD inline
+#endif
+
+#define SA_EPS 0.00001f                 // src/lib.rs:80
+#define SA_F32_U64_MULT 1000000.0f      // src/trackers/sort/voting.rs:9
+#define SA_CHI2INV95_4 11.070f          // src/utils/kalman.rs:18-20
+#define SA_CHI2_UPPER_BOUND 100.0f      // src/utils/kalman.rs:16
+#define SA_MAX_CONSTRAINTS 16
+#define SA_NONE 0xffffffffu
+
+// Per-box derived geometry, 16 B: centre, bounding-circle radius (bbox.rs:157-161), f32 area term
+// h*h*aspect exactly as calculate_metric_object forms it (bbox.rs:523).
+struct sa_geo {
+  float xc, yc, r, hha;
+};
+
+struct sa_constraints {
+  uint32_t n;
+  uint32_t pad;
+  uint64_t delta[SA_MAX_CONSTRAINTS];
+  float max_dist[SA_MAX_CONSTRAINTS];
+};
+
+// ---- box preparation (bbox.rs:157-166, 287-330) -------------------------------------------------------
+SA_HD float sa_radius(float aspect, float height) {
+  float hw = aspect * height / 2.0f;
+  float hh = height / 2.0f;
+  return sqrtf(hw * hw + hh * hh);
+}
+SA_HD float sa_area(float aspect, float height) {  // Universal2DBox::area  bbox.rs:163-166
+  float w = height * aspect;
+  return w * height;
+}
+// Polygon::from(&Universal2DBox) with cos/sin of (angle as f64) supplied by the host's libm
+// (c = 1, s = 0 for boxes without an angle).
+SA_HD void sa_vertices(float xc, float yc, float aspect_f, float height_f, double c, double s, double* o) {
+  double height = (double)height_f;
+  double aspect = (double)aspect_f;
+  double half_width = height * aspect / 2.0;
+  double half_height = height / 2.0;
+  double r1x = -half_width * c - half_height * s;
+  double r1y = -half_width * s + half_height * c;
+  double r2x = half_width * c - half_height * s;
+  double r2y = half_width * s + half_height * c;
+  double x = (double)xc, y = (double)yc;
+  o[0] = x + r1x; o[1] = y + r1y;
+  o[2] = x + r2x; o[3] = y + r2y;
+  o[4] = x - r1x; o[5] = y - r1y;
+  o[6] = x - r2x; o[7] = y - r2y;
+}
+
+// ---- pair pre-filter (sort.rs:250-270, spatio_temporal_constraints.rs:48-59, bbox.rs:452-474) ----------
+SA_HD bool sa_too_far(const sa_geo& l, const sa_geo& r) {
+  float max_distance = l.r + r.r;
+  float x = l.xc - r.xc, y = l.yc - r.yc;
+  return x * x + y * y > max_distance * max_distance;
+}
+SA_HD float sa_dist_in_2r(const sa_geo& l, const sa_geo& r) {
+  float radial = l.r + r.r;
+  float x = l.xc - r.xc, y = l.yc - r.yc;
+  return sqrtf(x * x + y * y) / sqrtf(radial * radial + SA_EPS);
+}
+SA_HD bool sa_compatible(const sa_geo& c, uint64_t ce, const sa_geo& t, uint64_t te, uint64_t max_idle,
+                         const sa_constraints& cons) {
+  uint64_t delta = ce > te ? ce - te : te - ce;
+  float dist = sa_dist_in_2r(c, t);
+  if (!(max_idle >= delta)) return false;
+  for (uint32_t i = 0; i < cons.n; ++i)
+    if (cons.delta[i] >= delta) return dist <= cons.max_dist[i];
+  return true;
+}
+
+// ---- Sutherland–Hodgman + shoelace (clipping.rs:12-91, geo Area) ------------------------------------------
+#define SA_POLY_CAP 12
+// Clips the open ring `subj` (4 vertices) by the open ring `clip` (4 vertices); returns the unsigned area
+// of the result exactly as Polygon::new(...).unsigned_area() evaluates it.
+SA_HD double sa_clip_area(const double* subj, const double* clip) {
+  double ax[SA_POLY_CAP], ay[SA_POLY_CAP], bx[SA_POLY_CAP], by[SA_POLY_CAP];
+  int n = 4;
+  for (int i = 0; i < 4; ++i) { ax[i] = subj[2 * i]; ay[i] = subj[2 * i + 1]; }
+  double* px = ax; double* py = ay; double* qx = bx; double* qy = by;
+  for (int i = 0; i < 4; ++i) {
+    int ii = i == 0 ? 3 : i - 1;
+    double csx = clip[2 * ii], csy = clip[2 * ii + 1];
+    double cex = clip[2 * i], cey = clip[2 * i + 1];
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+      int ji = j == 0 ? n - 1 : j - 1;
+      double ssx = px[ji], ssy = py[ji];
+      double sex = px[j], sey = py[j];
+      bool in_e = ((cex - csx) * (sey - csy) - (cey - csy) * (sex - csx)) <= 0.0;
+      bool in_s = ((cex - csx) * (ssy - csy) - (cey - csy) * (ssx - csx)) <= 0.0;
+      if (in_e != in_s) {
+        // compute_intersection(cp1 = s_edge_start, cp2 = s_edge_end, s = c_edge_start, e = c_edge_end)
+        double dcx = ssx - sex, dcy = ssy - sey;
+        double dpx = csx - cex, dpy = csy - cey;
+        double n1 = ssx * sey - ssy * sex;
+        double n2 = csx * cey - csy * cex;
+        double n3 = 1.0 / (dcx * dpy - dcy * dpx);
+        if (m < SA_POLY_CAP) { qx[m] = (n1 * dpx - n2 * dcx) * n3; qy[m] = (n1 * dpy - n2 * dcy) * n3; ++m; }
+      }
+      if (in_e && m < SA_POLY_CAP) { qx[m] = sex; qy[m] = sey; ++m; }
+    }
+    double* t = px; px = qx; qx = t;
+    t = py; py = qy; qy = t;
+    n = m;
+  }
+  if (n == 0) return 0.0;
+  // Polygon::new closes the ring unless first == last; < 3 coordinates -> 0
+  bool closed = px[0] == px[n - 1] && py[0] == py[n - 1];
+  int m = closed ? n : n + 1;
+  if (m < 3) return 0.0;
+  double shx = px[0], shy = py[0];
+  double tmp = 0.0;
+  for (int i = 0; i + 1 < m; ++i) {
+    int i1 = (i + 1 == n) ? 0 : i + 1;  // the appended closing coordinate is ring[0]
+    double x0 = px[i] - shx, y0 = py[i] - shy;
+    double x1 = px[i1] - shx, y1 = py[i1] - shy;
+    tmp = tmp + (x0 * y1 - y0 * x1);
+  }
+  double area = tmp / (1.0 + 1.0);
+  return fabs(area);
+}
+
+// Universal2DBox::calculate_metric_object (bbox.rs:512-535) for a pair that is not too_far.
+SA_HD bool sa_iou_cell(const double* cand_verts, const double* track_verts, float c_hha, float t_hha, float* out) {
+  double inter = sa_clip_area(cand_verts, track_verts);
+  if (inter == 0.0) return false;
+  double uni = (double)(c_hha + t_hha) - inter;
+  *out = (float)(inter / uni);
+  return true;
+}
+
+// ---- Mahalanobis (kalman_2d_box.rs:104-120, 150-184) -------------------------------------------------------
+// Per track, once: projected mean = mean[0..5]; projected cov = cov[0..5,0..5] + diag(std^2);
+// L = nalgebra Cholesky::new(cov).l().  out20 = mean5 | L as 15 packed lower-triangular values
+// (row-major: L00, L10 L11, L20 L21 L22, ...).  A non-positive pivot poisons L with NaN (the
+// reference unwrap()-panics there).
+SA_HD void sa_maha_prepare(float pw, const float* mean5, const float* cov25, float* out20) {
+  float M[25];
+  float sw = 1.0f * pw * mean5[4];
+  float sd[5] = {sw, sw, sw, 1e-1f, sw};
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) M[i * 5 + j] = cov25[i * 5 + j] + (i == j ? sd[i] * sd[i] : 0.0f);
+  bool ok = true;
+  for (int j = 0; j < 5; ++j) {
+    for (int k = 0; k < j; ++k) {
+      float factor = -M[j * 5 + k];
+      for (int r = j; r < 5; ++r) M[r * 5 + j] = factor * M[r * 5 + k] + M[r * 5 + j];
+    }
+    float diag = M[j * 5 + j];
+    if (diag == 0.0f || !(diag >= 0.0f)) { ok = false; break; }
+    float denom = sqrtf(diag);
+    M[j * 5 + j] = denom;
+    for (int r = j + 1; r < 5; ++r) M[r * 5 + j] = M[r * 5 + j] / denom;
+  }
+  for (int i = 0; i < 5; ++i) out20[i] = mean5[i];
+  int o = 5;
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j <= i; ++j) out20[o++] = ok ? M[i * 5 + j] : NAN;
+}
+// Per cell: d2 = || L^-1 (z - mean) ||^2 with nalgebra's column-oriented forward substitution,
+// then calculate_cost(d2, inverted = true) / conf  (sort/metric.rs:54-63).
+SA_HD float sa_maha_cell(const float* m20, const float* z5, float conf) {
+  float r[5];
+  for (int i = 0; i < 5; ++i) r[i] = z5[i] - m20[i];
+  const float* L = m20 + 5;
+  for (int i = 0; i < 5; ++i) {
+    float diag = L[i * (i + 1) / 2 + i];
+    float coeff = r[i] / diag;
+    r[i] = coeff;
+    float nc = -coeff;
+    for (int k = i + 1; k < 5; ++k) r[k] = nc * L[k * (k + 1) / 2 + i] + r[k];
+  }
+  float s = 0.0f;
+  for (int i = 0; i < 5; ++i) s = s + r[i] * r[i];
+  float cost = s > SA_CHI2INV95_4 ? 0.0f : SA_CHI2_UPPER_BOUND - s;
+  return cost / conf;
+}
+
+// ---- quantisation (sort/voting.rs:20,59): (w * 1e6f) as i64 — trunc, saturating, NaN -> 0 ---------------------
+SA_HD int64_t sa_quantise(float w) {
+  float v = w * SA_F32_U64_MULT;
+  if (v != v) return 0;
+  if (v >= 9223372036854775808.0f) return INT64_MAX;
+  if (v <= -9223372036854775808.0f) return INT64_MIN;
+  return (int64_t)v;
+}
+
+// ---- order-preserving float <-> uint key (for atomicMax over possibly negative floats) ---------------------
+SA_HD uint32_t sa_f32_key(float f) {
+  union { float f; uint32_t u; } c;
+  c.f = f;
+  return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+SA_HD float sa_key_f32(uint32_t k) {
+  union { float f; uint32_t u; } c;
+  c.u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return c.f;
+}
+
+// ---- memory access shims: agent-scope relaxed atomics on the device, plain ops in the host emulation ------
+#if defined(__HIP_DEVICE_COMPILE__)
+SA_HD uint32_t sa_ld_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SA_HD void sa_st_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SA_HD uint32_t sa_cas_u32(uint32_t* p, uint32_t expect, uint32_t desired) {
+  __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expect;
+}
+#else
+SA_HD uint32_t sa_ld_u32(const uint32_t* p) { return *p; }
+SA_HD void sa_st_u32(uint32_t* p, uint32_t v) { *p = v; }
+SA_HD uint32_t sa_cas_u32(uint32_t* p, uint32_t expect, uint32_t desired) {
+  uint32_t old = *p;
+  if (old == expect) *p = desired;
+  return old;
+}
+#endif
+
+// ---- union-find over rows [0,N) and columns [N,N+T): hook the larger root under the smaller, so a
+// component's representative is its minimum vertex — always a candidate row.  Lock-free (ECL-CC style). ---
+SA_HD uint32_t sa_uf_find(uint32_t* parent, uint32_t v) {
+  uint32_t p = sa_ld_u32(parent + v);
+  while (p != v) {
+    uint32_t gp = sa_ld_u32(parent + p);
+    if (gp != p) sa_st_u32(parent + v, gp);  // path halving: any ancestor is a valid parent
+    v = p;
+    p = gp;
+  }
+  return v;
+}
+SA_HD void sa_uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = sa_uf_find(parent, a);
+    b = sa_uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { uint32_t t = a; a = b; b = t; }
+    if (sa_cas_u32(parent + a, a, b) == a) return;
+  }
+}
+
+// ---- exact sparse assignment of one connected component -----------------------------------------------------
+// SortVoting::winners (sort/voting.rs:30-100) maximises sum of quantised weights over an N x (N+T) matrix
+// whose diagonal "self" columns carry the threshold.  With threshold > 0 that is the same optimum as:
+// maximise sum(gain) over a matching that uses only edges with gain = w - threshold > 0, every unmatched
+// row falling back to its private self column.  The thresholded graph splits into
+// connected components that are solved independently; this routine solves one, by successive shortest
+// augmenting paths (Jonker–Volgenant style Dijkstra on reduced costs c = -gain, all i64), walking only real
+// edges.  Every tree row offers its free self column as a terminal, so searches stay local.
+struct sa_assign_ws {
+  // edges, row-major with row stride `estride`
+  const uint32_t* e_cnt;   // [N]
+  const uint32_t* e_col;   // [N][estride]
+  const int64_t* e_gain;   // [N][estride]
+  uint32_t estride;
+  const uint32_t* next_row;  // [N] next row of the same component (ascending), SA_NONE at the end
+  int64_t* u;       // [N] row duals   (initialised to -max gain of the row)
+  int64_t* v;       // [T] column duals (initialised to 0)
+  int32_t* rmatch;  // [N] matched column or -1 (= self)
+  int32_t* cmatch;  // [T] matched row or -1
+  int64_t* dist;    // [T]
+  int32_t* pred;    // [T] tree row that labelled the column
+  uint32_t* cstamp; // [T] search id that labelled the column   (0 = never)
+  uint32_t* cscan;  // [T] search id that scanned the column
+  int32_t* cnext;   // [T] linked list of labelled columns of the current search
+  int64_t* rdist;   // [N] distance at which a row entered the tree
+  int32_t* rnext;   // [N] linked list of tree rows of the current search
+};
+
+SA_HD void sa_assign_relax_row(const sa_assign_ws& w, uint32_t row, int64_t base, uint32_t stamp, int32_t* list_head) {
+  uint32_t cnt = w.e_cnt[row];
+  const uint32_t* cols = w.e_col + (size_t)row * w.estride;
+  const int64_t* gains = w.e_gain + (size_t)row * w.estride;
+  int64_t ur = w.u[row];
+  for (uint32_t e = 0; e < cnt; ++e) {
+    uint32_t j = cols[e];
+    if (w.cscan[j] == stamp) continue;
+    int64_t d = base + (-gains[e] - ur - w.v[j]);
+    if (w.cstamp[j] != stamp) {
+      w.cstamp[j] = stamp;
+      w.dist[j] = d;
+      w.pred[j] = (int32_t)row;
+      w.cnext[j] = *list_head;
+      *list_head = (int32_t)j;
+    } else if (d < w.dist[j]) {
+      w.dist[j] = d;
+      w.pred[j] = (int32_t)row;
+    }
+  }
+}
+
+SA_HD void sa_assign_component(const sa_assign_ws& w, uint32_t first_row) {
+  for (uint32_t root = first_row; root != SA_NONE; root = w.next_row[root]) {
+    const uint32_t stamp = root + 1u;
+    int32_t col_list = -1;   // labelled columns of this search
+    int32_t row_list = (int32_t)root;
+    w.rnext[root] = -1;
+    w.rdist[root] = 0;
+    int64_t best_term = -w.u[root];  // reduced cost of the root's own self column
+    int32_t term_row = (int32_t)root;
+    sa_assign_relax_row(w, root, 0, stamp, &col_list);
+    int32_t end_col = -1;
+    int64_t delta;
+    for (;;) {
+      // smallest labelled, unscanned column (ties: lowest column index)
+      int32_t bj = -1;
+      int64_t bd = 0;
+      for (int32_t j = col_list; j >= 0; j = w.cnext[j]) {
+        if (w.cscan[j] == stamp) continue;
+        int64_t d = w.dist[j];
+        if (bj < 0 || d < bd || (d == bd && j < bj)) { bj = j; bd = d; }
+      }
+      if (bj < 0 || bd >= best_term) { delta = best_term; break; }  // a self column ends the path
+      w.cscan[bj] = stamp;
+      int32_t i = w.cmatch[bj];
+      if (i < 0) { end_col = bj; delta = bd; break; }               // free real column
+      w.rdist[i] = bd;
+      w.rnext[i] = row_list;
+      row_list = i;
+      int64_t t = bd + (-w.u[i]);
+      if (t < best_term) { best_term = t; term_row = i; }
+      sa_assign_relax_row(w, (uint32_t)i, bd, stamp, &col_list);
+    }
+    // dual update: tree rows u += delta - rdist ; scanned columns v += dist - delta
+    for (int32_t i = row_list; i >= 0; i = w.rnext[i]) w.u[i] += delta - w.rdist[i];
+    for (int32_t j = col_list; j >= 0; j = w.cnext[j])
+      if (w.cscan[j] == stamp) w.v[j] += w.dist[j] - delta;
+    // augment
+    int32_t j;
+    if (end_col >= 0) j = end_col;
+    else {
+      if (term_row == (int32_t)root) continue;  // root keeps its self column
+      j = w.rmatch[term_row];                  // term_row falls back to self and frees its column
+      w.rmatch[term_row] = -1;
+    }
+    for (;;) {
+      int32_t i = w.pred[j];
+      int32_t prev = w.rmatch[i];
+      w.rmatch[i] = j;
+      w.cmatch[j] = i;
+      if (i == (int32_t)root) break;
+      j = prev;
+    }
+  }
+}

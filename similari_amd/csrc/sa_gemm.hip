@@ -1,0 +1,390 @@
+// sa_gemm.hip — the N x (T*K) feature-distance contraction of VisualSORT on gfx950.
+//
+// Reference: distance::cosine / distance::euclidean (src/distance.rs:9-47) evaluated for every
+// (candidate, stored observation) pair by VisualMetric::visual_metric (visual_sort/metric.rs:200-225).
+//
+// cosine   : dot products on the f32 matrix cores — v_mfma_f32_32x32x2_f32, exact f32 (an fmaf chain),
+//            157 TF/s peak; A = candidates [N][D8], B = track bank [T*K][D8], both k-contiguous, so the
+//            contraction is C = A * B^T.  128x128 (or 64x64 for small frames) block tile, 4 waves as 2x2,
+//            BK = 32 staged through XOR-swizzled LDS, ds_read_b128 fragments (each lane takes 4 consecutive
+//            k of its row; the k-slot permutation is the same for A and B, so the sum is unchanged).
+//            The epilogue fuses everything the reference does per pair after the dot product:
+//            d = dot / sqrt(n1*n2) with hoisted norms, is_ok threshold, distance_to_weight (1 - d), the
+//            feature_can_be_used / minimal-track-length gates, compatible(), and the running maximum that
+//            BestFitVoting needs (voting/best.rs:59-76).
+// euclidean: sum (a-b)^2 directly on the VALU — the GEMM expansion |a|^2+|b|^2-2ab cancels catastrophically
+//            on near-identical vectors, which are exactly the true matches (SURVEY §7 hard parts).
+#include "sa_engine.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BK 32
+
+// Physical float offset of logical 16-byte chunk `kc` (0..7) of row `row` in a [rows][32] f32 LDS tile.
+// XOR with (row>>1)&7: with a 128-B row stride, the 16 rows one ds_read_b128 lane group touches land on
+// 16 distinct 16-B slots of the 256-B bank row (conflict-free); see MI355X_MICROARCH.md §LDS.
+__device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t kc) { return row * BK + ((kc ^ ((row >> 1) & 7u)) << 2); }
+
+struct GemmCols {   // per-lane column metadata kept in registers through the epilogue
+  float nb;
+  bool ok;
+  sa_geo g;
+  uint64_t epoch;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+                                              uint32_t Ncols, uint32_t D8, uint32_t m0, uint32_t n0, float* lds,
+                                              f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per tile
+  float* As = lds;
+  float* Bs = lds + BM * BK;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wm = wave >> 1, wn = wave & 1u;
+  const uint32_t lr = lane & 31u, lh = lane >> 5;
+  f32x4 ra[A_CH], rb[B_CH];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int r = 0; r < A_CH; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      uint32_t gr = m0 + row, gk = k0 + kc * 4u;
+      ra[r] = (gr < M && gk < D8) ? *(const f32x4*)(A + (size_t)gr * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < B_CH; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      uint32_t gr = n0 + row, gk = k0 + kc * 4u;
+      rb[r] = (gr < Ncols && gk < D8) ? *(const f32x4*)(B + (size_t)gr * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int r = 0; r < A_CH; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      *(f32x4*)(As + lds_off(row, kc)) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B_CH; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      *(f32x4*)(Bs + lds_off(row, kc)) = rb[r];
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  gload(0);
+  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
+    lstore();
+    __syncthreads();
+    if (k0 + BK < D8) gload(k0 + BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
+#pragma unroll
+    for (uint32_t kk = 0; kk < 4; ++kk) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) fa[m] = *(const f32x4*)(As + lds_off(wm * (BM / 2) + m * 32 + lr, kk * 2 + lh));
+#pragma unroll
+      for (int n = 0; n < TN; ++n) fb[n] = *(const f32x4*)(Bs + lds_off(wn * (BN / 2) + n * 32 + lr, kk * 2 + lh));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][e], fb[n][e], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
+// Row of accumulator register r for lane half lh in a 32x32 MFMA tile (C/D layout, cdna_hip_programming.md §3)
+__device__ __forceinline__ uint32_t acc_row(int r, uint32_t lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+  const SceneDev& S = scenes[blockIdx.z];
+  const uint32_t N = S.N, TK = S.TK, K = S.K;
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= N || n0 >= TK) return;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  f32x16 acc[TM][TN];
+  gemm_mainloop<BM, BN>(S.c_feat, S.t_feat, N, TK, S.D8, m0, n0, lds, acc);
+
+  // ---- fused epilogue ----
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wm = wave >> 1, wn = wave & 1u, lr = lane & 31u, lh = lane >> 5;
+  // row metadata through LDS (the main loop's last barrier has passed): na, usable, geometry
+  float* s_na = lds;                    // [BM]
+  float* s_us = lds + BM;               // [BM] 1.0 / 0.0
+  sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
+  for (uint32_t r = tid; r < (uint32_t)BM; r += 256) {
+    uint32_t gi = m0 + r;
+    bool in = gi < N;
+    s_na[r] = in ? S.c_fnorm[gi] : 0.f;
+    s_us[r] = (in && S.c_usable[gi]) ? 1.f : 0.f;
+    s_g[r] = in ? S.c_geo[gi] : sa_geo{0.f, 0.f, 0.f, 0.f};
+  }
+  GemmCols col[TN];
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
+    col[n].ok = false;
+    col[n].nb = 0.f;
+    col[n].g = sa_geo{0.f, 0.f, 0.f, 0.f};
+    col[n].epoch = 0;
+    if (gj < TK) {
+      uint32_t t = gj / K;
+      col[n].nb = S.t_fnorm[gj];
+      col[n].ok = S.t_fpresent[gj] != 0 && S.t_fcount[t] >= p.min_track_len;
+      col[n].g = S.t_geo[t];
+      col[n].epoch = S.t_epoch[t];
+    }
+  }
+  __syncthreads();
+  const float nanv = __builtin_nanf("");
+  const uint64_t epoch = S.epoch;
+  uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      uint32_t li = wm * (BM / 2) + m * 32 + acc_row(r, lh);
+      uint32_t gi = m0 + li;
+      if (gi >= N) continue;
+      float na = s_na[li];
+      bool us = s_us[li] != 0.f;
+      sa_geo cg = s_g[li];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
+        if (gj >= TK) continue;
+        float out = nanv;
+        if (us && col[n].ok && sa_compatible(cg, epoch, col[n].g, col[n].epoch, p.max_idle, p.cons)) {
+          float d = acc[m][n][r] / sqrtf(na * col[n].nb);  // divided / (f1_divisor * f2_divisor).sqrt()
+          if (d >= p.visual_threshold) {                    // VisualSortMetricType::is_ok (NaN fails)
+            out = 1.0f - d;                                 // distance_to_weight
+            uint32_t key = sa_f32_key(out);
+            kmax = key > kmax ? key : kmax;
+          }
+        }
+        S.vis[(size_t)gi * TK + gj] = out;
+      }
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t ok = __shfl_xor(kmax, o);
+    kmax = ok > kmax ? ok : kmax;
+  }
+  if (lane == 0 && kmax) atomicMax(S.vis_max_key, kmax);
+}
+
+// Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
+// swizzled LDS tiles.  Column c of a thread is tx + 16*c so a wave's stores cover 64-B row segments.
+__global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr int BM = 64, BN = 64;
+  const SceneDev& S = scenes[blockIdx.z];
+  const uint32_t N = S.N, TK = S.TK, K = S.K, D8 = S.D8;
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= N || n0 >= TK) return;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + BM * BK;
+  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      uint32_t gk = k0 + kc * 4u;
+      uint32_t ga = m0 + row, gb = n0 + row;
+      f32x4 va = (ga < N && gk < D8) ? *(const f32x4*)(S.c_feat + (size_t)ga * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 vb = (gb < TK && gk < D8) ? *(const f32x4*)(S.t_feat + (size_t)gb * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(As + lds_off(row, kc)) = va;
+      *(f32x4*)(Bs + lds_off(row, kc)) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t kc = 0; kc < 8; ++kc) {
+      f32x4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const f32x4*)(As + lds_off(ty * 4 + i, kc));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const f32x4*)(Bs + lds_off(tx + 16 * j, kc));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float df = fa[i][e] - fb[j][e];
+            acc[i][j] += df * df;
+          }
+    }
+    __syncthreads();
+  }
+  const float nanv = __builtin_nanf("");
+  const uint64_t epoch = S.epoch;
+  uint32_t kmax = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t gi = m0 + ty * 4 + i;
+    if (gi >= N) continue;
+    bool us = S.c_usable[gi] != 0;
+    sa_geo cg = S.c_geo[gi];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t gj = n0 + tx + 16 * j;
+      if (gj >= TK) continue;
+      uint32_t t = gj / K;
+      float out = nanv;
+      if (us && S.t_fpresent[gj] && S.t_fcount[t] >= p.min_track_len &&
+          sa_compatible(cg, epoch, S.t_geo[t], S.t_epoch[t], p.max_idle, p.cons)) {
+        float d = sqrtf(acc[i][j]);
+        if (d <= p.visual_threshold) {
+          out = d;
+          uint32_t key = sa_f32_key(out);
+          kmax = key > kmax ? key : kmax;
+        }
+      }
+      S.vis[(size_t)gi * TK + gj] = out;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t ok = __shfl_xor(kmax, o);
+    kmax = ok > kmax ? ok : kmax;
+  }
+  if ((tid & 63u) == 0 && kmax) atomicMax(S.vis_max_key, kmax);
+}
+
+// ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
+                                                       const float* __restrict__ B, const float* __restrict__ bn,
+                                                       uint32_t M, uint32_t Ncols, uint32_t D8, float* __restrict__ out) {
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  f32x16 acc[TM][TN];
+  gemm_mainloop<BM, BN>(A, B, M, Ncols, D8, m0, n0, lds, acc);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wm = wave >> 1, wn = wave & 1u, lr = lane & 31u, lh = lane >> 5;
+  float nb[TN];
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
+    nb[n] = gj < Ncols ? bn[gj] : 1.f;
+  }
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      uint32_t gi = m0 + wm * (BM / 2) + m * 32 + acc_row(r, lh);
+      if (gi >= M) continue;
+      float na = an[gi];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
+        if (gj < Ncols) out[(size_t)gi * Ncols + gj] = acc[m][n][r] / sqrtf(na * nb[n]);
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+                                                       uint32_t Ncols, uint32_t D8, float* __restrict__ out) {
+  constexpr int BM = 64, BN = 64;
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + BM * BK;
+  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+      uint32_t gk = k0 + kc * 4u;
+      uint32_t ga = m0 + row, gb = n0 + row;
+      f32x4 va = (ga < M && gk < D8) ? *(const f32x4*)(A + (size_t)ga * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 vb = (gb < Ncols && gk < D8) ? *(const f32x4*)(B + (size_t)gb * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(As + lds_off(row, kc)) = va;
+      *(f32x4*)(Bs + lds_off(row, kc)) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t kc = 0; kc < 8; ++kc) {
+      f32x4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const f32x4*)(As + lds_off(ty * 4 + i, kc));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const f32x4*)(Bs + lds_off(tx + 16 * j, kc));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float df = fa[i][e] - fb[j][e];
+            acc[i][j] += df * df;
+          }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t gi = m0 + ty * 4 + i;
+    if (gi >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t gj = n0 + tx + 16 * j;
+      if (gj < Ncols) out[(size_t)gi * Ncols + gj] = sqrtf(acc[i][j]);
+    }
+  }
+}
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Tile choice: 128x128 when that alone fills the 256 CUs, otherwise 64x64 (4x the workgroups).
+static inline bool big_tiles(uint32_t M, uint32_t Ncols, uint32_t ns) {
+  return (size_t)cdiv(M, 128) * cdiv(Ncols, 128) * ns >= 192;
+}
+
+hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
+                            hipStream_t st) {
+  if (!maxN || !maxTK) return hipSuccess;
+  if (p.visual_kind == SA_VIS_COSINE) {
+    if (big_tiles(maxN, maxTK, ns))
+      hipLaunchKernelGGL((k_visual_cosine<128, 128>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p);
+    else
+      hipLaunchKernelGGL((k_visual_cosine<64, 64>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+  } else {
+    hipLaunchKernelGGL(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
+                                     uint32_t n, uint32_t t, uint32_t d8, float* out, hipStream_t st) {
+  if (!n || !t) return hipSuccess;
+  if (kind == SA_VIS_COSINE) {
+    if (big_tiles(n, t, 1))
+      hipLaunchKernelGGL((k_cosine_matrix<128, 128>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, d8, out);
+    else
+      hipLaunchKernelGGL((k_cosine_matrix<64, 64>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, d8, out);
+  } else {
+    hipLaunchKernelGGL(k_euclid_matrix, dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, b, n, t, d8, out);
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,150 @@
+"""Thin Python host binding of the C ABI (include/similari_assoc.h).  No arithmetic happens here: every call
+lands in libsimilari_assoc.so, whose compute path is HIP-only (no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"similari_assoc error {code}: {msg}")
+        self.code = code
+
+
+class Engine:
+    """One association engine = one GPU stream set. Mirrors sa_engine_* 1:1."""
+
+    def __init__(self, cfg: abi.sa_config, lib: C.CDLL | None = None):
+        self.lib = lib or abi.load_library()
+        self.cfg = cfg
+        self.h = abi.ENGINE()
+        rc = self.lib.sa_engine_create(C.byref(cfg), C.byref(self.h))
+        if rc != abi.SA_OK:
+            msg = self.lib.sa_last_error(None)
+            raise EngineError(rc, msg.decode() if msg else "")
+        self.K = cfg.max_observations if cfg.visual_kind != abi.SA_VIS_NONE else 1
+
+    def close(self):
+        if self.h:
+            self.lib.sa_engine_destroy(self.h)
+            self.h = abi.ENGINE()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != abi.SA_OK:
+            msg = self.lib.sa_last_error(self.h)
+            raise EngineError(rc, msg.decode() if msg else "")
+
+    # ---- track state ----
+    def upsert(self, scene: int, tracks: abi.sa_tracks):
+        self._chk(self.lib.sa_tracks_upsert(self.h, scene, C.byref(tracks)))
+
+    def remove(self, scene: int, ids):
+        ids = np.ascontiguousarray(ids, np.uint64)
+        self._chk(self.lib.sa_tracks_remove(self.h, scene, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def count(self, scene: int) -> int:
+        n = C.c_uint32()
+        self._chk(self.lib.sa_tracks_count(self.h, scene, C.byref(n)))
+        return n.value
+
+    def order(self, scene: int) -> np.ndarray:
+        n = self.count(scene)
+        out = np.zeros(n, np.uint64)
+        m = C.c_uint32()
+        self._chk(self.lib.sa_tracks_order(self.h, scene, out.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(m)))
+        return out
+
+    # ---- association ----
+    def associate(self, scene: int, epoch: int, det: abi.sa_detections):
+        ids = np.zeros(det.n, np.uint64)
+        votes = np.zeros(det.n, np.uint8)
+        self._chk(
+            self.lib.sa_associate(self.h, scene, epoch, C.byref(det), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  votes.ctypes.data_as(C.POINTER(C.c_uint8)))
+        )
+        return ids, votes
+
+    def batch_begin(self):
+        self._chk(self.lib.sa_batch_begin(self.h))
+
+    def batch_add(self, scene: int, epoch: int, det: abi.sa_detections) -> int:
+        slot = C.c_uint32()
+        self._chk(self.lib.sa_batch_add(self.h, scene, epoch, C.byref(det), C.byref(slot)))
+        return slot.value
+
+    def batch_run(self):
+        self._chk(self.lib.sa_batch_run(self.h))
+
+    def batch_sync(self):
+        self._chk(self.lib.sa_batch_sync(self.h))
+
+    def batch_fetch(self, slot: int, n: int):
+        ids = np.zeros(n, np.uint64)
+        votes = np.zeros(n, np.uint8)
+        self._chk(self.lib.sa_batch_fetch(self.h, slot, ids.ctypes.data_as(C.POINTER(C.c_uint64)), votes.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return ids, votes
+
+    def batch_time(self, iters: int) -> float:
+        ms = C.c_double()
+        self._chk(self.lib.sa_batch_time(self.h, iters, C.byref(ms)))
+        return ms.value
+
+    # ---- taps ----
+    def tap_dims(self, slot: int = 0):
+        n, t, k = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.sa_tap_dims(self.h, slot, C.byref(n), C.byref(t), C.byref(k)))
+        return n.value, t.value, k.value
+
+    def tap_positional(self, slot: int = 0) -> np.ndarray:
+        n, t, _ = self.tap_dims(slot)
+        out = np.empty((n, t), np.float32)
+        self._chk(self.lib.sa_tap_positional(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def tap_visual(self, slot: int = 0) -> np.ndarray:
+        n, t, k = self.tap_dims(slot)
+        out = np.empty((n, t, k), np.float32)
+        self._chk(self.lib.sa_tap_visual(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def tap_quantised(self, slot: int = 0) -> np.ndarray:
+        n, t, _ = self.tap_dims(slot)
+        out = np.empty((n, t), np.int64)
+        self._chk(self.lib.sa_tap_quantised(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    # ---- measurement ----
+    def profile_reset(self):
+        self._chk(self.lib.sa_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        arr = (abi.sa_kernel_stat * 32)()
+        n = C.c_uint32()
+        self._chk(self.lib.sa_profile_read(self.h, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n.value, 32))}
+
+    def distance_matrix(self, kind: str, a: np.ndarray, b: np.ndarray, iters: int = 1, want_out: bool = True):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        n, d = a.shape
+        t, d2 = b.shape
+        assert d == d2
+        out = np.empty((n, t), np.float32) if want_out else None
+        ms = C.c_double()
+        fp = C.POINTER(C.c_float)
+        self._chk(
+            self.lib.sa_feature_distance_matrix(
+                self.h, abi.SA_VIS_COSINE if kind == "cosine" else abi.SA_VIS_EUCLIDEAN, n, t, d, a.ctypes.data_as(fp),
+                b.ctypes.data_as(fp), out.ctypes.data_as(fp) if want_out else None, iters, C.byref(ms))
+        )
+        return out, ms.value

@@ -1,0 +1,139 @@
+// emu.cpp — TEST INFRASTRUCTURE.  Compiles the product's scalar device logic (similari_amd/csrc/sa_device.h,
+// the exact source the HIP kernels call) with g++ so its arithmetic and the sparse assignment solver can be
+// checked against the oracle on a machine without a GPU.  The product never links this file.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/similari_assoc.h"
+#include "../../similari_amd/csrc/sa_device.h"
+
+namespace {
+void prep(const sa_box& b, sa_geo* g, double* verts) {
+  g->xc = b.xc;
+  g->yc = b.yc;
+  g->r = sa_radius(b.aspect, b.height);
+  g->hha = b.height * b.height * b.aspect;
+  double a = (double)(b.has_angle ? b.angle : 0.0f);
+  double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+  sa_vertices(b.xc, b.yc, b.aspect, b.height, c, s, verts);
+}
+sa_constraints make_cons(const sa_config* cfg) {
+  sa_constraints c;
+  std::memset(&c, 0, sizeof c);
+  c.n = cfg->n_constraints;
+  for (uint32_t i = 0; i < c.n; ++i) {
+    c.delta[i] = cfg->constraint_epoch_delta[i];
+    c.max_dist[i] = cfg->constraint_max_dist[i];
+  }
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+// k_positional for one cell, exactly as the kernel sequences it. Returns 1 and *out when present.
+int emu_positional_cell(const sa_config* cfg, const sa_box* cand, uint64_t cand_epoch, const sa_box* track,
+                        uint64_t track_epoch, const float* mean5, const float* cov25, float* out, int* compatible) {
+  sa_geo cg, tg;
+  double cv[8], tv[8];
+  prep(*cand, &cg, cv);
+  prep(*track, &tg, tv);
+  sa_constraints cons = make_cons(cfg);
+  bool comp = sa_compatible(cg, cand_epoch, tg, track_epoch, cfg->max_idle_epochs, cons);
+  if (compatible) *compatible = comp;
+  if (!comp || sa_too_far(cg, tg)) return 0;
+  float conf = cand->confidence < cfg->positional_min_confidence ? cfg->positional_min_confidence : cand->confidence;
+  if (cfg->positional_kind == SA_POS_MAHALANOBIS) {
+    float m20[20];
+    sa_maha_prepare(cfg->kf_position_weight, mean5, cov25, m20);
+    float z5[5] = {cand->xc, cand->yc, cand->has_angle ? cand->angle : 0.0f, cand->aspect, cand->height};
+    *out = sa_maha_cell(m20, z5, conf);
+    return 1;
+  }
+  float iou;
+  if (!sa_iou_cell(cv, tv, cg.hha, tg.hha, &iou)) return 0;
+  float e = iou * conf;
+  if (!(e >= cfg->positional_threshold)) return 0;
+  *out = e;
+  return 1;
+}
+
+int64_t emu_quantise(float w) { return sa_quantise(w); }
+uint32_t emu_f32_key(float f) { return sa_f32_key(f); }
+float emu_key_f32(uint32_t k) { return sa_key_f32(k); }
+
+// Runs the assignment stages (k_assign_edges -> label -> next -> solve) sequentially on a dense positional
+// matrix pos[N][T] (NaN = absent).  row_skip / col_skip mimic the visual exclusions.  rmatch[N] = column or -1.
+int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip,
+               const uint8_t* col_skip, int32_t* rmatch_out, int64_t* total_gain) {
+  std::vector<uint32_t> parent(N + T), label(N, SA_NONE), next_row(N, SA_NONE), e_cnt(N, 0);
+  const uint32_t estride = T ? T : 1;
+  std::vector<uint32_t> e_col((size_t)N * estride);
+  std::vector<int64_t> e_gain((size_t)N * estride);
+  std::vector<int64_t> u(N, 0), v(T, 0), dist(T, 0), rdist(N, 0);
+  std::vector<int32_t> rmatch(N, -1), cmatch(T, -1), pred(T, 0), cnext(T, 0), rnext(N, 0);
+  std::vector<uint32_t> cstamp(T, 0), cscan(T, 0);
+  for (uint32_t i = 0; i < N + T; ++i) parent[i] = i;
+  for (uint32_t q = 0; q < N; ++q) {
+    if (row_skip && row_skip[q]) continue;
+    uint32_t cnt = 0;
+    int64_t maxg = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      if (col_skip && col_skip[t]) continue;
+      float w = pos[(size_t)q * T + t];
+      if (!(w == w)) continue;
+      int64_t gain = sa_quantise(w) - threshold_q;
+      if (gain > 0) {
+        e_col[(size_t)q * estride + cnt] = t;
+        e_gain[(size_t)q * estride + cnt] = gain;
+        ++cnt;
+        if (gain > maxg) maxg = gain;
+        sa_uf_union(parent.data(), q, N + t);
+      }
+    }
+    e_cnt[q] = cnt;
+    u[q] = -maxg;
+  }
+  for (uint32_t q = 0; q < N; ++q) label[q] = e_cnt[q] ? sa_uf_find(parent.data(), q) : SA_NONE;
+  for (uint32_t q = 0; q < N; ++q) {
+    if (label[q] == SA_NONE) continue;
+    for (uint32_t r = q + 1; r < N; ++r)
+      if (label[r] == label[q]) { next_row[q] = r; break; }
+  }
+  sa_assign_ws w;
+  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.estride = estride;
+  w.next_row = next_row.data();
+  w.u = u.data(); w.v = v.data(); w.rmatch = rmatch.data(); w.cmatch = cmatch.data();
+  w.dist = dist.data(); w.pred = pred.data(); w.cstamp = cstamp.data(); w.cscan = cscan.data(); w.cnext = cnext.data();
+  w.rdist = rdist.data(); w.rnext = rnext.data();
+  for (uint32_t q = 0; q < N; ++q)
+    if (label[q] == q) sa_assign_component(w, q);
+  int64_t tot = 0;
+  for (uint32_t q = 0; q < N; ++q) {
+    rmatch_out[q] = rmatch[q];
+    if (rmatch[q] >= 0) {
+      for (uint32_t e = 0; e < e_cnt[q]; ++e)
+        if ((int32_t)e_col[(size_t)q * estride + e] == rmatch[q]) tot += e_gain[(size_t)q * estride + e];
+      if (cmatch[rmatch[q]] != (int32_t)q) return -1;  // inconsistent matching
+    }
+  }
+  // dual feasibility + complementary slackness = proof of optimality
+  for (uint32_t q = 0; q < N; ++q) {
+    if (u[q] > 0) return -2;
+    for (uint32_t e = 0; e < e_cnt[q]; ++e) {
+      uint32_t t = e_col[(size_t)q * estride + e];
+      int64_t rc = -e_gain[(size_t)q * estride + e] - u[q] - v[t];
+      if (rc < 0) return -3;
+      if (rmatch[q] == (int32_t)t && rc != 0) return -4;
+    }
+    if (rmatch[q] < 0 && e_cnt[q] && u[q] != 0) return -5;  // self column must be tight when used
+  }
+  for (uint32_t t = 0; t < T; ++t)
+    if (cmatch[t] < 0 && v[t] != 0) return -6;  // free columns keep their initial dual
+  if (total_gain) *total_gain = tot;
+  return 0;
+}
+
+}  // extern "C"

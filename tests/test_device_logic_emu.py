@@ -1,0 +1,235 @@
+"""CPU checks of the product's scalar device logic (similari_amd/csrc/sa_device.h compiled with g++ by
+tests/emu) against the oracle: per-cell IoU / Mahalanobis / pre-filter arithmetic must be bit-identical, the
+sparse per-component assignment must reach the dense kuhn_munkres optimum.  No GPU needed."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from similari_amd import abi
+
+ROOT = Path(__file__).resolve().parent.parent
+EMU_DIR = ROOT / "tests" / "emu"
+
+
+def emu():
+    so = EMU_DIR / "libemu.so"
+    srcs = [EMU_DIR / "emu.cpp", ROOT / "similari_amd" / "csrc" / "sa_device.h"]
+    if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.run(
+            ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", str(so), str(EMU_DIR / "emu.cpp")],
+            check=True,
+        )
+    L = C.CDLL(str(so))
+    B = C.POINTER(abi.sa_box)
+    fp = C.POINTER(C.c_float)
+    L.emu_positional_cell.restype = C.c_int
+    L.emu_positional_cell.argtypes = [C.POINTER(abi.sa_config), B, C.c_uint64, B, C.c_uint64, fp, fp, fp, C.POINTER(C.c_int)]
+    L.emu_quantise.restype = C.c_int64
+    L.emu_quantise.argtypes = [C.c_float]
+    L.emu_f32_key.restype = C.c_uint32
+    L.emu_f32_key.argtypes = [C.c_float]
+    L.emu_key_f32.restype = C.c_float
+    L.emu_key_f32.argtypes = [C.c_uint32]
+    L.emu_assign.restype = C.c_int
+    L.emu_assign.argtypes = [C.c_uint32, C.c_uint32, fp, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    return L
+
+
+E = emu()
+OL = O.lib()
+
+
+def random_boxes(rng, n, canvas=400.0, oriented=False):
+    b = abi.make_boxes(
+        rng.uniform(0, canvas, n), rng.uniform(0, canvas, n), rng.uniform(0.3, 1.5, n), rng.uniform(20, 120, n),
+        confidence=rng.uniform(0.0, 1.0, n), angle=rng.uniform(0, 3.2, n) if oriented else None,
+    )
+    return b
+
+
+@pytest.mark.parametrize("oriented", [False, True])
+def test_iou_cells_bit_identical(oriented):
+    rng = np.random.default_rng(3 + oriented)
+    n = 400
+    a = random_boxes(rng, n, oriented=oriented)
+    b = random_boxes(rng, n, oriented=oriented)
+    # half of the pairs: near-duplicates (true matches), which stress the clipper's degenerate branches
+    b[: n // 2] = a[: n // 2]
+    b["xc"][: n // 2] += rng.normal(0, 2, n // 2).astype(np.float32)
+    b["yc"][: n // 2] += rng.normal(0, 2, n // 2).astype(np.float32)
+    b[:5] = a[:5]  # exact duplicates
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, positional_min_confidence=0.05, max_idle_epochs=3,
+                          constraints=[(1, 1.0), (3, 2.5)])
+    present = 0
+    for i in range(n):
+        for te in (5, 3, 1):
+            ov, ev = C.c_float(), C.c_float()
+            comp = C.c_int()
+            oc = OL.or_compatible(C.byref(cfg), O.box_ptr(a, i), 5, O.box_ptr(b, i), te)
+            r_o = OL.or_positional_metric(C.byref(cfg), O.box_ptr(a, i), O.box_ptr(b, i), None, None, C.byref(ov)) if oc else 0
+            r_e = E.emu_positional_cell(C.byref(cfg), O.box_ptr(a, i), 5, O.box_ptr(b, i), te, None, None, C.byref(ev), C.byref(comp))
+            assert bool(comp.value) == bool(oc)
+            assert r_o == r_e, (i, te)
+            if r_o:
+                present += 1
+                assert np.float32(ov.value).tobytes() == np.float32(ev.value).tobytes()
+                assert OL.or_quantise(ov.value) == E.emu_quantise(ev.value)
+    assert present > 100
+
+
+def test_maha_cells_bit_identical():
+    rng = np.random.default_rng(5)
+    n = 300
+    pw, vw = np.float32(1 / 20), np.float32(1 / 160)
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.1)
+    tracks = random_boxes(rng, n)
+    hits = 0
+    for i in range(n):
+        m = np.zeros(10, np.float32)
+        c = np.zeros(100, np.float32)
+        OL.or_kf_initiate(pw, vw, O.box_ptr(tracks, i), O.fptr(m), O.fptr(c))
+        for _ in range(int(rng.integers(1, 4))):  # a few predict/update steps -> realistic state
+            m2, c2 = np.zeros(10, np.float32), np.zeros(100, np.float32)
+            OL.or_kf_predict(pw, vw, O.fptr(m), O.fptr(c), O.fptr(m2), O.fptr(c2))
+            z = tracks[i : i + 1].copy()
+            z["xc"] += np.float32(rng.normal(0, 2))
+            z["yc"] += np.float32(rng.normal(0, 2))
+            OL.or_kf_update(pw, vw, O.fptr(m2), O.fptr(c2), O.box_ptr(z), O.fptr(m), O.fptr(c))
+        tb = np.zeros(1, abi.BOX_DTYPE)
+        OL.or_kf_state_box(O.fptr(m), O.box_ptr(tb))
+        tb["confidence"] = 1.0
+        cand = tb.copy()
+        cand["xc"] += np.float32(rng.normal(0, 3))
+        cand["yc"] += np.float32(rng.normal(0, 3))
+        cand["confidence"] = np.float32(rng.uniform(0, 1))
+        m5 = m[:5].copy()
+        c25 = c.reshape(10, 10)[:5, :5].copy().ravel()
+        ov, ev = C.c_float(), C.c_float()
+        r_o = OL.or_positional_metric(C.byref(cfg), O.box_ptr(cand), O.box_ptr(tb), O.fptr(m5), O.fptr(c25), C.byref(ov))
+        r_e = E.emu_positional_cell(C.byref(cfg), O.box_ptr(cand), 0, O.box_ptr(tb), 0, O.fptr(m5), O.fptr(c25), C.byref(ev), None)
+        assert r_o == r_e
+        if r_o:
+            hits += 1
+            assert np.float32(ov.value).tobytes() == np.float32(ev.value).tobytes(), (ov.value, ev.value)
+    assert hits > 200
+
+
+def test_float_key_roundtrip_and_order():
+    vals = np.array([-3.5, -1.0, -0.0, 0.0, 1e-30, 0.5, 1.0, 2.0, 3.4e38], np.float32)
+    keys = [E.emu_f32_key(float(v)) for v in vals]
+    assert keys == sorted(keys)
+    for v, k in zip(vals, keys):
+        assert np.float32(E.emu_key_f32(k)).tobytes() == np.float32(v).tobytes()
+    assert all(k > 0 for k in keys)
+
+
+def dense_reference(pos, thr_q):
+    """SortVoting's dense N x (N+T) matrix through the oracle's kuhn_munkres."""
+    N, T = pos.shape
+    w = np.zeros((N, N + T), np.int64)
+    for i in range(N):
+        for j in range(T):
+            if pos[i, j] == pos[i, j]:
+                w[i, N + j] = OL.or_quantise(float(pos[i, j]))
+        w[i, i] = thr_q
+    total = C.c_int64()
+    assign = np.zeros(N, np.uint32)
+    OL.or_kuhn_munkres(N, N + T, w.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total), assign.ctypes.data_as(C.POINTER(C.c_uint32)))
+    ref = np.where(assign >= N, assign.astype(np.int64) - N, -1)
+    return total.value, ref, w
+
+
+def run_emu_assign(pos, thr_q, row_skip=None, col_skip=None):
+    N, T = pos.shape
+    pos = np.ascontiguousarray(pos, np.float32)
+    rm = np.zeros(N, np.int32)
+    tot = C.c_int64()
+    rs = None if row_skip is None else row_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    cs = None if col_skip is None else col_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    rc = E.emu_assign(N, T, O.fptr(pos), thr_q, rs, cs, rm.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tot))
+    assert rc == 0, f"optimality certificate failed: {rc}"
+    return rm, tot.value
+
+
+@pytest.mark.parametrize("density", [0.02, 0.1, 0.5, 1.0])
+def test_sparse_assignment_reaches_dense_optimum(density):
+    rng = np.random.default_rng(int(density * 100))
+    thr_q = 300000
+    for trial in range(30):
+        N = int(rng.integers(1, 40))
+        T = int(rng.integers(1, 40))
+        pos = rng.uniform(0.05, 1.0, (N, T)).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > density] = np.nan
+        rm, gain = run_emu_assign(pos, thr_q)
+        total, ref, w = dense_reference(pos, thr_q)
+        assert gain + N * thr_q == total
+        # a matched edge always beats the threshold; unmatched rows are the "self" rows
+        for i in range(N):
+            if rm[i] >= 0:
+                assert w[i, N + rm[i]] > thr_q
+        # unique optimum (random f32 weights: ties have probability ~0) -> identical indices
+        np.testing.assert_array_equal(rm, ref)
+
+
+def test_sparse_assignment_kat_from_reference():
+    # sort/voting.rs:110-174 : {10->20, 11->25, 12->self}
+    pos = np.array([[0.6, 0.4, 0.4], [0.5, 0.69, 0.4], [0.2, 0.27, 0.28]], np.float32)
+    rm, gain = run_emu_assign(pos, 300000)
+    assert list(rm) == [0, 1, -1]
+    assert gain + 3 * 300000 == 1_590_000
+
+
+def test_sparse_assignment_long_chains_and_exclusions():
+    # a chain r0-c0-r1-c1-...: augmenting paths must run through the whole component
+    n = 60
+    pos = np.full((n, n), np.nan, np.float32)
+    rng = np.random.default_rng(9)
+    for i in range(n):
+        pos[i, i] = 0.5 + 0.001 * i
+        if i + 1 < n:
+            pos[i + 1, i] = 0.9 - 0.002 * i
+    rm, gain = run_emu_assign(pos, 300000)
+    total, ref, _ = dense_reference(pos, 300000)
+    assert gain + n * 300000 == total
+    np.testing.assert_array_equal(rm, ref)
+    # exclusions behave like absent rows / columns
+    row_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    col_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    rm2, gain2 = run_emu_assign(pos, 300000, row_skip, col_skip)
+    p2 = pos.copy()
+    p2[row_skip.astype(bool), :] = np.nan
+    p2[:, col_skip.astype(bool)] = np.nan
+    total2, ref2, _ = dense_reference(p2, 300000)
+    assert gain2 + n * 300000 == total2
+    np.testing.assert_array_equal(rm2, ref2)
+
+
+def test_sparse_assignment_ties_keep_total():
+    # integer-valued weights -> many ties: totals must still agree (indices are unpinned on ties)
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        N, T = int(rng.integers(2, 25)), int(rng.integers(2, 25))
+        pos = (rng.integers(1, 6, (N, T)) / 5.0).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > 0.4] = np.nan
+        rm, gain = run_emu_assign(pos, 300000)
+        total, _, _ = dense_reference(pos, 300000)
+        assert gain + N * 300000 == total
+        used = [c for c in rm if c >= 0]
+        assert len(used) == len(set(used))
+
+
+def test_mahalanobis_scale_weights():
+    # Mahalanobis weights reach 100/min_conf * 1e6 ~ 1e9..1e10: i64 arithmetic end to end
+    rng = np.random.default_rng(13)
+    for _ in range(20):
+        N, T = int(rng.integers(2, 20)), int(rng.integers(2, 20))
+        pos = (rng.uniform(88.0, 100.0, (N, T)) / rng.uniform(0.05, 1.0, (N, 1))).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > 0.3] = np.nan
+        rm, gain = run_emu_assign(pos, 1000000)
+        total, ref, _ = dense_reference(pos, 1000000)
+        assert gain + N * 1000000 == total
+        np.testing.assert_array_equal(rm, ref)

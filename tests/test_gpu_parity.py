@@ -1,0 +1,425 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Gates: positional f32 cells bit-identical with identical present/absent masks; IoU-quantised i64
+matrix bit-exact; cosine |d| <= 1e-5 abs, euclid 1e-5 rel; BestFit winners identical; assignment indices identical
+(unique optima: random f32 weights) and always equal total weight."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from similari_amd import abi, synth
+from similari_amd.engine import Engine, EngineError
+
+pytestmark = pytest.mark.gpu
+
+PW, VW = np.float32(1 / 20), np.float32(1 / 160)
+
+
+def kf_states(rng, boxes, steps=3):
+    """Realistic track Kalman states: initiate + `steps` oracle predict/update cycles.
+    Returns (state boxes, mean5, cov25)."""
+    L = O.lib()
+    n = len(boxes)
+    out_boxes = boxes.copy()
+    m5 = np.zeros((n, 5), np.float32)
+    c25 = np.zeros((n, 25), np.float32)
+    for i in range(n):
+        m = np.zeros(10, np.float32)
+        c = np.zeros(100, np.float32)
+        b = boxes[i : i + 1].copy()
+        sb = np.zeros(1, abi.BOX_DTYPE)
+        L.or_make_prediction(PW, VW, 0, O.fptr(m), O.fptr(c), O.box_ptr(b), O.box_ptr(sb))
+        for _ in range(steps - 1):
+            b["xc"] += np.float32(rng.normal(0, 1.5))
+            b["yc"] += np.float32(rng.normal(0, 1.5))
+            L.or_make_prediction(PW, VW, 1, O.fptr(m), O.fptr(c), O.box_ptr(b), O.box_ptr(sb))
+        out_boxes[i] = sb[0]
+        m5[i] = m[:5]
+        c25[i] = c.reshape(10, 10)[:5, :5].ravel()
+    return out_boxes, m5, c25
+
+
+def total_gain(res_ids, quant, track_ids, thr_q):
+    col = {int(t): j for j, t in enumerate(track_ids)}
+    g = 0
+    for i, t in enumerate(res_ids):
+        if t:
+            g += int(quant[i, col[int(t)]]) - thr_q
+    return g
+
+
+def check_sort(cfg, sc, epoch=1, kf=None, require_ids=True):
+    tb = sc["track_boxes"]
+    kw = {}
+    if kf is not None:
+        tb, m5, c25 = kf
+        kw = dict(kf_mean=m5, kf_cov=c25)
+    tracks = abi.make_tracks(sc["track_ids"], tb, sc["track_epochs"], **kw)
+    det = abi.make_detections(sc["det_boxes"])
+    ref = O.associate(cfg, tracks, epoch, det)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        ids, votes = eng.associate(0, epoch, det)
+        pos = eng.tap_positional()
+        q = eng.tap_quantised()
+    finally:
+        eng.close()
+    # identical present/absent mask and bit-identical f32 cells
+    np.testing.assert_array_equal(np.isnan(pos), np.isnan(ref["positional"]))
+    np.testing.assert_array_equal(pos.view(np.uint32)[~np.isnan(pos)], ref["positional"].view(np.uint32)[~np.isnan(pos)])
+    np.testing.assert_array_equal(q, ref["quantised"])
+    thr_q = 1000000 if cfg.positional_kind == abi.SA_POS_MAHALANOBIS else int(O.lib().or_quantise(cfg.positional_threshold))
+    g_gpu = total_gain(ids, q, sc["track_ids"], thr_q)
+    g_ref = total_gain(ref["track_id"], ref["quantised"], sc["track_ids"], thr_q)
+    assert g_gpu == g_ref, "assignment totals differ"
+    if require_ids:
+        np.testing.assert_array_equal(ids, ref["track_id"])
+        np.testing.assert_array_equal(votes, ref["voting_type"])
+    return ids, ref
+
+
+@pytest.mark.parametrize("oriented", [False, True])
+@pytest.mark.parametrize("n,t", [(257, 300), (64, 64), (1, 1), (130, 65)])
+def test_sort_iou_parity(oriented, n, t):
+    rng = np.random.default_rng(100 + n + 7 * t + oriented)
+    sc = synth.sort_scene(rng, t, n, canvas=(1500.0, 900.0), oriented=oriented)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    if n > 60:
+        assert (ids != 0).sum() > 0.5 * min(n, t)
+        assert (ids == sc["truth"]).mean() > 0.9
+
+
+def test_sort_iou_constraints_and_idle_epochs():
+    rng = np.random.default_rng(7)
+    sc = synth.sort_scene(rng, 200, 220, canvas=(1200.0, 800.0))
+    sc["track_epochs"] = rng.integers(0, 9, 200).astype(np.uint64)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.2, max_idle_epochs=4, constraints=[(1, 0.05), (2, 0.5), (5, 1.5)])
+    check_sort(cfg, sc, epoch=8)
+
+
+def test_sort_maha_parity():
+    rng = np.random.default_rng(21)
+    sc = synth.sort_scene(rng, 180, 200, canvas=(1500.0, 900.0))
+    kf = kf_states(rng, sc["track_boxes"])
+    sc["det_boxes"] = synth.jitter_boxes(rng, kf[0], 2.0)[rng.permutation(180)]
+    sc["det_boxes"] = np.concatenate([sc["det_boxes"], synth.dense_boxes(rng, 20, (1500.0, 900.0))])
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.05, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc, kf=kf)
+    assert (ids != 0).sum() > 100
+
+
+def test_sort_maha_oriented_parity():
+    rng = np.random.default_rng(22)
+    sc = synth.sort_scene(rng, 90, 90, canvas=(900.0, 900.0), oriented=True)
+    kf = kf_states(rng, sc["track_boxes"])
+    sc["det_boxes"] = synth.jitter_boxes(rng, kf[0], 2.0, angle_sigma=0.01)
+    cfg = abi.make_config(positional="maha", max_idle_epochs=5)
+    check_sort(cfg, sc, kf=kf)
+
+
+def visual_run(cfg, sc, epoch=1, kf=None, own_area=None, det_present=None):
+    tb = sc["track_boxes"]
+    kw = {}
+    if kf is not None:
+        tb, m5, c25 = kf
+        kw = dict(kf_mean=m5, kf_cov=c25)
+    tracks = abi.make_tracks(sc["track_ids"], tb, sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"], **kw)
+    det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"], own_area=own_area, feat_present=det_present)
+    ref = O.associate(cfg, tracks, epoch, det)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        ids, votes = eng.associate(0, epoch, det)
+        pos = eng.tap_positional()
+        vis = eng.tap_visual()
+    finally:
+        eng.close()
+    return ids, votes, pos, vis, ref
+
+
+def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
+    ids, votes, pos, vis, ref = visual_run(cfg, sc, **kw)
+    np.testing.assert_array_equal(np.isnan(pos), np.isnan(ref["positional"]))
+    np.testing.assert_array_equal(pos.view(np.uint32)[~np.isnan(pos)], ref["positional"].view(np.uint32)[~np.isnan(pos)])
+    rv = ref["visual"]
+    both = ~np.isnan(vis) & ~np.isnan(rv)
+    err = np.abs(vis[both] - rv[both])
+    assert (err <= tol_abs + tol_rel * np.abs(rv[both])).all(), err.max()
+    # cells present on one side only must sit within tolerance of the is_ok threshold
+    mism = np.isnan(vis) != np.isnan(rv)
+    borderline = 0
+    if mism.any():
+        thr_w = 1.0 - cfg.visual_threshold if cfg.visual_kind == abi.SA_VIS_COSINE else cfg.visual_threshold
+        v = np.where(np.isnan(vis), rv, vis)[mism]
+        assert (np.abs(v - thr_w) <= 2 * tol_abs + tol_rel * abs(thr_w)).all(), "present/absent mask differs away from the threshold"
+        borderline = int(mism.sum())
+    if borderline == 0:
+        np.testing.assert_array_equal(ids, ref["track_id"])
+        np.testing.assert_array_equal(votes, ref["voting_type"])
+    return ids, votes, ref
+
+
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36)])
+def test_visual_cosine_parity(k, n, t, d):
+    rng = np.random.default_rng(1000 + n + t + d + k)
+    sc = synth.visual_scene(rng, t, n, d, k, canvas=(1500.0, 900.0), new_fraction=0.1)
+    # ragged banks: some observations missing, some tracks too short, some candidates unusable
+    pres = sc["track_present"]
+    pres[rng.uniform(size=pres.shape) < 0.15] = 0
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1 if k == 1 else 2,
+                          visual_minimal_quality_use=0.55, visual_minimal_area=3000.0, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc)
+    assert (votes == abi.SA_VOTE_VISUAL).sum() > 0
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 0
+
+
+def test_visual_euclid_parity():
+    rng = np.random.default_rng(77)
+    sc = synth.visual_scene(rng, 120, 140, 256, 3, canvas=(1500.0, 900.0), new_fraction=0.1)
+    cfg = abi.make_config(positional="iou", visual="euclidean", visual_threshold=0.6, feature_len=256, max_observations=3,
+                          visual_min_votes=2, visual_minimal_track_length=1, positional_min_confidence=0.1, max_idle_epochs=5)
+    check_visual(cfg, sc, tol_abs=1e-6, tol_rel=1e-5)
+
+
+def test_visual_euclid_reference_bench_distribution():
+    # features = 10*idx +- 0.01 (benches/simple_visual_sort_tracker.rs:135-141): the case a GEMM expansion cannot hold
+    rng = np.random.default_rng(78)
+    t = n = 100
+    d = 128
+    sc = synth.visual_scene(rng, t, n, d, 3, canvas=(3000.0, 3000.0))
+    base = (10.0 * np.arange(t, dtype=np.float32))[:, None, None]
+    sc["track_feats"] = (base + rng.uniform(-0.01, 0.01, (t, 3, d))).astype(np.float32)
+    perm = (sc["truth"].astype(np.int64) - 1)
+    sc["det_feats"] = (10.0 * perm[:, None] + rng.uniform(-0.01, 0.01, (n, d))).astype(np.float32)
+    cfg = abi.make_config(positional="iou", visual="euclidean", visual_threshold=3.4e38, feature_len=d, max_observations=3,
+                          visual_min_votes=1, positional_min_confidence=0.1, max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc, tol_abs=0.0, tol_rel=1e-5)
+    np.testing.assert_array_equal(ids, sc["truth"])
+
+
+def test_visual_maha_with_constraints_and_own_area():
+    rng = np.random.default_rng(79)
+    sc = synth.visual_scene(rng, 100, 110, 64, 2, canvas=(1200.0, 800.0), new_fraction=0.1)
+    kf = kf_states(rng, sc["track_boxes"])
+    own = rng.uniform(0.2, 1.0, 110).astype(np.float32)
+    own[::7] = np.nan  # None
+    dpres = (rng.uniform(size=110) > 0.1).astype(np.uint8)
+    cfg = abi.make_config(positional="maha", visual="cosine", visual_threshold=0.3, feature_len=64, max_observations=2,
+                          visual_min_votes=1, visual_minimal_own_area_percentage_use=0.5, constraints=[(1, 1.0)],
+                          max_idle_epochs=3, positional_min_confidence=0.1)
+    check_visual(cfg, sc, kf=kf, own_area=own, det_present=dpres)
+
+
+def test_zero_feature_vectors_are_absent():
+    rng = np.random.default_rng(80)
+    sc = synth.visual_scene(rng, 20, 20, 32, 1, canvas=(800.0, 600.0))
+    sc["det_feats"][3] = 0.0  # cosine -> 0/0 = NaN -> fails is_ok -> absent
+    sc["track_feats"][5] = 0.0
+    cfg = abi.make_config(positional="iou", visual="cosine", visual_threshold=-1.0, feature_len=32, max_observations=1,
+                          max_idle_epochs=5)
+    ids, votes, pos, vis, ref = visual_run(cfg, sc)
+    assert np.isnan(vis[3]).all() and np.isnan(vis[:, 5]).all()
+    np.testing.assert_array_equal(np.isnan(vis), np.isnan(ref["visual"]))
+    np.testing.assert_array_equal(ids, ref["track_id"])
+
+
+def test_empty_and_degenerate_frames():
+    cfg = abi.make_config(positional="iou", max_idle_epochs=5)
+    rng = np.random.default_rng(81)
+    eng = Engine(cfg)
+    try:
+        boxes = synth.dense_boxes(rng, 10)
+        # no tracks at all: everything is a new track
+        ids, votes = eng.associate(0, 1, abi.make_detections(boxes))
+        assert (ids == 0).all() and (votes == 0).all()
+        eng.upsert(0, abi.make_tracks(np.arange(1, 11), boxes, np.zeros(10)))
+        # no detections
+        ids, votes = eng.associate(0, 1, abi.make_detections(boxes[:0]))
+        assert len(ids) == 0
+        ids, _ = eng.associate(0, 1, abi.make_detections(boxes))
+        np.testing.assert_array_equal(ids, np.arange(1, 11))
+        # other scene is isolated (compatible(): scene_id equality, sort.rs:251)
+        ids, _ = eng.associate(5, 1, abi.make_detections(boxes))
+        assert (ids == 0).all()
+        assert eng.count(0) == 10 and eng.count(5) == 0
+    finally:
+        eng.close()
+
+
+def test_bad_arguments_are_errors_not_aborts():
+    cfg = abi.make_config(positional="iou")
+    eng = Engine(cfg)
+    try:
+        b = synth.dense_boxes(np.random.default_rng(0), 3)
+        bad = b.copy(); bad["height"][1] = 0.0
+        with pytest.raises(EngineError) as ei:
+            eng.associate(0, 1, abi.make_detections(bad))
+        assert ei.value.code == abi.SA_ERR_BAD_ARG
+        bad = b.copy(); bad["confidence"][0] = 1.5
+        with pytest.raises(EngineError):
+            eng.associate(0, 1, abi.make_detections(bad))
+        with pytest.raises(EngineError):
+            eng.upsert(0, abi.make_tracks([0, 1, 2], b, [0, 0, 0]))  # id 0
+        with pytest.raises(EngineError) as ei:
+            eng.remove(0, [42])
+        assert ei.value.code == abi.SA_ERR_NOT_FOUND
+    finally:
+        eng.close()
+    cfg2 = abi.make_config(positional="iou", visual="cosine", visual_threshold=2.0, feature_len=8)
+    with pytest.raises(EngineError):
+        Engine(cfg2)
+
+
+def test_upsert_replace_remove_keep_order():
+    rng = np.random.default_rng(82)
+    cfg = abi.make_config(positional="iou", visual="cosine", visual_threshold=0.2, feature_len=40, max_observations=2, max_idle_epochs=50)
+    sc = synth.visual_scene(rng, 50, 50, 40, 2, canvas=(900.0, 700.0))
+    eng = Engine(cfg)
+    try:
+        first = slice(0, 30)
+        eng.upsert(0, abi.make_tracks(sc["track_ids"][first], sc["track_boxes"][first], sc["track_epochs"][first],
+                                      feats=sc["track_feats"][first], feat_present=sc["track_present"][first]))
+        rest = slice(30, 50)
+        eng.upsert(0, abi.make_tracks(sc["track_ids"][rest], sc["track_boxes"][rest], sc["track_epochs"][rest],
+                                      feats=sc["track_feats"][rest], feat_present=sc["track_present"][rest]))
+        np.testing.assert_array_equal(eng.order(0), sc["track_ids"])
+        # replace a few rows in place (merge of a candidate into a stored track)
+        upd = np.array([4, 17, 44])
+        nb = synth.jitter_boxes(rng, sc["track_boxes"][upd], 1.0)
+        nf = synth.observe(rng, sc["track_feats"][upd].reshape(-1, 40)).reshape(3, 2, 40)
+        sc["track_boxes"][upd] = nb
+        sc["track_feats"][upd] = nf
+        sc["track_epochs"][upd] = 1
+        eng.upsert(0, abi.make_tracks(sc["track_ids"][upd], nb, sc["track_epochs"][upd], feats=nf, feat_present=sc["track_present"][upd]))
+        np.testing.assert_array_equal(eng.order(0), sc["track_ids"])
+        # remove some: stable compaction keeps ascending-id order
+        gone = np.array([3, 4, 20, 50], np.uint64)
+        eng.remove(0, gone)
+        keep = ~np.isin(sc["track_ids"], gone)
+        np.testing.assert_array_equal(eng.order(0), sc["track_ids"][keep])
+        tracks = abi.make_tracks(sc["track_ids"][keep], sc["track_boxes"][keep], sc["track_epochs"][keep],
+                                 feats=sc["track_feats"][keep], feat_present=sc["track_present"][keep])
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ref = O.associate(cfg, tracks, 2, det)
+        ids, votes = eng.associate(0, 2, det)
+        np.testing.assert_array_equal(ids, ref["track_id"])
+        np.testing.assert_array_equal(votes, ref["voting_type"])
+        assert not np.isin(ids, gone).any()
+    finally:
+        eng.close()
+
+
+def test_batched_scenes_match_single_scene_runs():
+    rng = np.random.default_rng(83)
+    cfg = abi.make_config(positional="iou", max_idle_epochs=5)
+    sizes = [(60, 50), (1, 7), (130, 200), (33, 0), (0, 12), (257, 255)]
+    scenes = [synth.sort_scene(rng, t, n, canvas=(1000.0, 800.0)) for n, t in sizes]
+    eng = Engine(cfg)
+    try:
+        for s, sc in enumerate(scenes):
+            eng.upsert(10 + s, abi.make_tracks(sc["track_ids"] + 1000 * s, sc["track_boxes"], sc["track_epochs"]))
+        eng.batch_begin()
+        dets = [abi.make_detections(sc["det_boxes"]) for sc in scenes]
+        slots = [eng.batch_add(10 + s, 1, d) for s, d in enumerate(dets)]
+        eng.batch_run()
+        eng.batch_sync()
+        for s, sc in enumerate(scenes):
+            ids, votes = eng.batch_fetch(slots[s], dets[s].n)
+            tracks = abi.make_tracks(sc["track_ids"] + 1000 * s, sc["track_boxes"], sc["track_epochs"])
+            ref = O.associate(cfg, tracks, 1, dets[s], want_matrices=False)
+            np.testing.assert_array_equal(ids, ref["track_id"])
+            np.testing.assert_array_equal(votes, ref["voting_type"])
+        # the same scene twice in one batch is a state error (one entry per scene, trackers/batch.rs)
+        eng.batch_begin()
+        eng.batch_add(10, 2, dets[0])
+        with pytest.raises(EngineError):
+            eng.batch_add(10, 2, dets[0])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("kind", ["cosine", "euclidean"])
+@pytest.mark.parametrize("n,t,d", [(100, 130, 512), (257, 129, 72), (64, 64, 33), (1, 1, 5)])
+def test_distance_matrix_vs_numpy_f64(kind, n, t, d):
+    rng = np.random.default_rng(n + t + d)
+    a = rng.standard_normal((n, d)).astype(np.float32)
+    b = rng.standard_normal((t, d)).astype(np.float32)
+    b[: min(n, t)] = a[: min(n, t)] + rng.uniform(-0.01, 0.01, (min(n, t), d)).astype(np.float32)
+    cfg = abi.make_config()
+    eng = Engine(cfg)
+    try:
+        out, ms = eng.distance_matrix(kind, a, b)
+    finally:
+        eng.close()
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    if kind == "cosine":
+        ref = (a64 @ b64.T) / np.sqrt((a64 * a64).sum(1)[:, None] * (b64 * b64).sum(1)[None, :])
+        assert np.abs(out - ref).max() <= 1e-5
+    else:
+        ref = np.sqrt(((a64[:, None, :] - b64[None, :, :]) ** 2).sum(-1))
+        assert (np.abs(out - ref) <= 1e-5 * ref + 1e-7).all()
+    # asymmetric operands + non-square shape: a transposed C write cannot pass
+    assert out.shape == (n, t)
+
+
+def test_full_size_properties_c2():
+    """BASELINE config C2 (1000 x 1000 x 512 cosine): size-independent properties instead of the slow oracle."""
+    rng = np.random.default_rng(2)
+    n = t = 1000
+    d = 512
+    sc = synth.visual_scene(rng, t, n, d, 1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ids, votes = eng.associate(0, 1, det)
+        # every identity is re-found, each track used once
+        np.testing.assert_array_equal(ids, sc["truth"])
+        assert (votes == abi.SA_VOTE_VISUAL).all()
+        # idempotence
+        ids2, votes2 = eng.associate(0, 1, det)
+        np.testing.assert_array_equal(ids, ids2)
+        # permutation equivariance over candidates
+        p = rng.permutation(n)
+        det_p = abi.make_detections(sc["det_boxes"][p], feats=sc["det_feats"][p], feat_quality=sc["det_quality"][p])
+        ids3, _ = eng.associate(0, 1, det_p)
+        np.testing.assert_array_equal(ids3, ids[p])
+        # the visual matrix agrees with an f64 numpy contraction
+        vis = eng.tap_visual()[:, :, 0]
+        a64, b64 = sc["det_feats"][p].astype(np.float64), sc["track_feats"][:, 0].astype(np.float64)
+        ref = 1.0 - (a64 @ b64.T) / np.sqrt((a64 * a64).sum(1)[:, None] * (b64 * b64).sum(1)[None, :])
+        m = ~np.isnan(vis)
+        assert m.mean() > 0.5
+        assert np.abs(vis[m] - ref[m]).max() <= 1e-5
+    finally:
+        eng.close()
+
+
+def test_full_size_sort_oriented_c4_properties():
+    """C4-sized oriented SORT (2000 x 2000): every shuffled, jittered detection returns to its track."""
+    rng = np.random.default_rng(4)
+    sc = synth.sort_scene(rng, 2000, 2000, canvas=(8192.0, 8192.0), oriented=True, pos_sigma=1.0)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"]))
+        ids, votes = eng.associate(0, 1, abi.make_detections(sc["det_boxes"]))
+        assert (ids == sc["truth"]).mean() > 0.97
+        used = ids[ids != 0]
+        assert len(used) == len(set(used.tolist()))
+        q = eng.tap_quantised()
+        assert (q >= 0).all() and (q <= 1_000_000).all()
+        assert ((q == 0) | (q >= 300_000)).all()
+    finally:
+        eng.close()
