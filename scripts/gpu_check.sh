@@ -25,7 +25,7 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "bench" ]; then
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof_run.log" 2>&1; echo "rocprof exit $?")
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof_run.log" 2>&1; echo "rocprof exit $?")
   find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep the merge-back small: drop the big per-dispatch traces
   find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete
