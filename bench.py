@@ -81,7 +81,7 @@ def stage(eng, cfg, scenes):
 def kernel_models(cfg, scenes):
     visual = cfg.visual_kind != abi.SA_VIS_NONE
     K = cfg.max_observations if visual else 1
-    D8 = (cfg.feature_len + 7) // 8 * 8
+    D8 = (cfg.feature_len + 31) // 32 * 32
     cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
     nt = sum(len(s["det_boxes"]) + len(s["track_boxes"]) for s in scenes)
     n_ = sum(len(s["det_boxes"]) for s in scenes)
@@ -91,13 +91,13 @@ def kernel_models(cfg, scenes):
         "k_positional": ("hbm", 4.0 * cells + 80.0 * nt),
         # one read of the positional matrix (4 B/cell; the i64 matrix is never materialised) + 4 B/row out
         "k_assign_edges": ("hbm", 4.0 * cells + 4.0 * n_),
-        "k_bestfit_rows": ("hbm", 4.0 * K * cells + 12.0 * n_),
-        "k_bestfit_ties": ("hbm", 4.0 * K * cells),
+        # one read of the visual weights (4 B per cell and bank slot) + the per-tile partials
+        "k_bestfit_tile": ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0),
     }
     if visual:
         flops = sum(2.0 * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
         m["k_visual_cost"] = ("mfma", flops)
-        m["k_pad_features"] = ("hbm", 4.0 * n_ * (cfg.feature_len + D8))
+        m["k_frame_prep"] = ("hbm", 4.0 * n_ * (cfg.feature_len + D8) + 160.0 * n_)
     return m, cells
 
 

@@ -7,13 +7,21 @@
 #include "sa_device.h"
 
 // Device-visible description of one scene of the current batch (blockIdx.z selects it).
-// HBM layout (all row-major, structure-of-arrays; T tracks, K bank slots, D8 = feature length padded to 8):
+// HBM layout (all row-major, structure-of-arrays; T tracks, K bank slots, Dp = feature length padded to 32):
 //   t_geo[T] 16 B | t_verts[T][8] f64 | t_epoch[T] | t_maha[T][20] (mean5 + packed Cholesky L15)
-//   t_feat[T][K][D8] f32 | t_fnorm[T][K] | t_fpresent[T][K] | t_fcount[T] | t_ids[T]
+//   t_feat[T][K][Dp] f32 | t_fnorm[T][K] | t_fpresent[T][K] | t_fcount[T] | t_ids[T]
 //   c_* the same for the N candidates of the frame; pos[N][T], vis[N][T][K] f32 with NaN = absent.
+// Raw per-box staging record uploaded by the host: the caller's sa_box plus libm cos/sin of the angle.
+struct BoxRaw {
+  sa_box box;
+  double c, s;
+};
+
 struct SceneDev {
-  uint32_t N, T, K, D8;
-  uint32_t TK, estride;
+  uint32_t N, T, K, Dp;      // candidates, tracks, bank depth, feature row stride (D rounded up to 32)
+  uint32_t TK, estride;      // T*K ; row stride of the edge lists
+  uint32_t D, flags;         // un-padded feature length ; SCN_* bits
+  uint32_t CT, RT;           // BestFit tiles: ceil(T/64), ceil(N/64)
   uint64_t epoch;
   // stored tracks (persist across frames)
   const sa_geo* t_geo;
@@ -25,23 +33,29 @@ struct SceneDev {
   const uint8_t* t_fpresent;
   const uint32_t* t_fcount;
   const uint64_t* t_ids;
-  // candidates of this frame
-  const sa_geo* c_geo;
-  const double* c_verts;
-  const float* c_z;
-  const float* c_conf;
-  const float* c_feat;
-  const float* c_fnorm;
-  const uint8_t* c_usable;
+  // raw candidate inputs of this frame (as uploaded)
+  const BoxRaw* c_raw;
+  const float* c_quality;
+  const float* c_own;
+  const uint8_t* c_fpresent_in;
+  const float* c_feat_raw;
+  // derived candidate arrays (written by k_frame_prep)
+  sa_geo* c_geo;
+  double* c_verts;
+  float* c_z;
+  float* c_conf;
+  float* c_feat;
+  float* c_fnorm;
+  uint8_t* c_usable;
   // cost matrices
   float* pos;
   float* vis;
   // BestFit vote
   uint32_t* vis_max_key;
-  unsigned long long* col_max_w;
-  uint32_t* col_min_q;
-  double* row_best_w;
-  int32_t* row_best_t;
+  double* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
+  int32_t* row_part_t;  // [N][CT]
+  double* col_part_w;   // [RT][T] best weight of the column inside row tile rt
+  uint32_t* col_part_q; // [RT][T] lowest row attaining it
   uint8_t* row_has;
   int32_t* vis_winner;
   uint8_t* col_excluded;
@@ -63,11 +77,15 @@ struct SceneDev {
   int32_t* cnext;
   int64_t* rdist;
   int32_t* rnext;
-  // results
+  // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t* out_track_id;
   uint8_t* out_vote;
   int64_t* quant;  // optional N x T tap
 };
+#define SCN_HAS_FEATS 1u
+#define SCN_HAS_QUALITY 2u
+#define SCN_HAS_OWN 4u
+#define SCN_HAS_FPRESENT 8u
 
 // Engine-wide constants, passed to kernels by value.
 struct SaParams {
@@ -83,32 +101,12 @@ struct SaParams {
   float visual_minimal_quality_use;
   float visual_minimal_own_area_use;
   float kf_position_weight;
-  uint32_t pad;
+  uint32_t Dp;                  // feature row stride of this engine (D rounded up to 32)
   uint64_t max_idle;
   sa_constraints cons;
 };
 
-// Raw per-box staging record uploaded by the host: the caller's sa_box plus libm cos/sin of the angle.
-struct BoxRaw {
-  sa_box box;
-  double c, s;
-};
-
 // ---- launchers (sa_kernels.hip / sa_gemm.hip).  All enqueue on `st` and return the launch status. ----
-struct PrepCandArgs {
-  const BoxRaw* raw;
-  const float* quality;      // or nullptr
-  const float* own_area;     // or nullptr
-  const uint8_t* feat_present;  // or nullptr
-  int has_feats;
-  uint32_t n;
-  sa_geo* geo;
-  double* verts;
-  float* z;
-  float* conf;
-  uint8_t* usable;
-};
-hipError_t sa_launch_prep_cands(const PrepCandArgs& a, const SaParams& p, hipStream_t st);
 
 struct PrepTrackArgs {
   const BoxRaw* raw;        // [n] compact
@@ -126,9 +124,9 @@ struct PrepTrackArgs {
 };
 hipError_t sa_launch_prep_tracks(const PrepTrackArgs& a, const SaParams& p, hipStream_t st);
 
-// Pads `rows` feature rows of length D to D8, scatters row r to dst[(slots ? slots[r / K] * K + r % K : r)],
+// Pads `rows` feature rows of length D to Dp, scatters row r to dst[(slots ? slots[r / K] * K + r % K : r)],
 // and stores the squared norm; `present` (or nullptr) zeroes absent rows.
-hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t D8, uint32_t K,
+hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                   const uint32_t* slots, const uint8_t* present, float* dst, float* norms,
                                   uint8_t* dst_present, uint32_t* fcount, hipStream_t st);
 hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* index, uint32_t rows, uint32_t row_bytes,
@@ -138,16 +136,20 @@ hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t n_scenes, uint3
                                 const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
                             const SaParams& p, hipStream_t st);
-hipError_t sa_launch_frame_init(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
+// init of the per-frame state + candidate preparation + candidate feature padding/norms, one launch
+hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual,
                                 const SaParams& p, hipStream_t st);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
+// stage 0 edges+union, 1 label, 2 next, 3 solve, 4 finalize; stage 5 = stages 1-4 fused in ONE workgroup per
+// scene (requires maxN <= SA_SMALL_N)
+#define SA_SMALL_N 1024
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                             const SaParams& p, hipStream_t st, int stage);
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                hipStream_t st);
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
-                                     uint32_t n, uint32_t t, uint32_t d8, float* out, hipStream_t st);
+                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st);
 
 const char* sa_kernel_name(int id);

@@ -16,13 +16,12 @@ namespace {
 thread_local std::string g_create_error;
 
 enum KernelId {
-  KID_PREP_CANDS = 0, KID_PAD_CANDS, KID_FRAME_INIT, KID_POSITIONAL, KID_VISUAL, KID_BESTFIT_ROWS, KID_BESTFIT_TIES,
-  KID_BESTFIT_RESOLVE, KID_ASSIGN_EDGES, KID_ASSIGN_LABEL, KID_ASSIGN_NEXT, KID_ASSIGN_SOLVE, KID_FINALIZE, KID_D2H,
-  KID_COUNT
+  KID_FRAME_PREP = 0, KID_POSITIONAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_EDGES, KID_ASSIGN_SMALL,
+  KID_ASSIGN_LABEL, KID_ASSIGN_NEXT, KID_ASSIGN_SOLVE, KID_FINALIZE, KID_D2H, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
-    "k_prep_cands", "k_pad_features", "k_frame_init", "k_positional", "k_visual_cost", "k_bestfit_rows", "k_bestfit_ties",
-    "k_bestfit_resolve", "k_assign_edges", "k_assign_label", "k_assign_next", "k_assign_solve", "k_finalize", "d2h_results"};
+    "k_frame_prep", "k_positional", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_edges", "k_assign_small",
+    "k_assign_label", "k_assign_next", "k_assign_solve", "k_finalize", "d2h_results"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -53,9 +52,9 @@ struct Slot {  // one scene of the current batch
   DevBuf geo, verts, z, conf, usable, feat, fnorm;
   // matrices + vote + assignment state
   DevBuf pos, vis, quant;
-  DevBuf vis_max_key, col_max_w, col_min_q, row_best_w, row_best_t, row_has, vis_winner, col_excluded;
+  DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
   DevBuf parent, label, next_row, e_cnt, e_col, e_gain, u, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
-  DevBuf out_id, out_vote;
+  DevBuf out;  // ids[N] then votes[N]
   HostBuf h_in, h_out;
   bool ran = false;
 };
@@ -70,7 +69,7 @@ struct sa_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  uint32_t K = 1, D = 0, D8 = 0;
+  uint32_t K = 1, D = 0, Dp = 0;
   bool visual = false;
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
@@ -225,14 +224,14 @@ int scene_reserve(sa_engine* e, SceneTable* s, uint32_t need) {
   if (need <= s->cap) return SA_OK;
   uint32_t ncap = s->cap ? s->cap : 64;
   while (ncap < need) ncap *= 2;
-  const size_t KD8 = (size_t)e->K * e->D8;
+  const size_t KDp = (size_t)e->K * e->Dp;
   TRY(dev_ensure(e, s->geo, (size_t)ncap * sizeof(sa_geo), true));
   TRY(dev_ensure(e, s->verts, (size_t)ncap * 8 * sizeof(double), true));
   TRY(dev_ensure(e, s->epoch, (size_t)ncap * 8, true));
   TRY(dev_ensure(e, s->maha, (size_t)ncap * 20 * sizeof(float), true));
   TRY(dev_ensure(e, s->tids, (size_t)ncap * 8, true));
   if (e->visual) {
-    TRY(dev_ensure(e, s->feat, (size_t)ncap * KD8 * sizeof(float), true));
+    TRY(dev_ensure(e, s->feat, (size_t)ncap * KDp * sizeof(float), true));
     TRY(dev_ensure(e, s->fnorm, (size_t)ncap * e->K * sizeof(float), true));
     TRY(dev_ensure(e, s->fpresent, (size_t)ncap * e->K, true));
     TRY(dev_ensure(e, s->fcount, (size_t)ncap * 4, true));
@@ -247,7 +246,8 @@ Slot* get_slot(sa_engine* e, uint32_t i) {
 }
 
 int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
-  const size_t n = N ? N : 1, t = T ? T : 1, K = e->K, D8 = e->D8 ? e->D8 : 8;
+  const size_t n = N ? N : 1, t = T ? T : 1, K = e->K, Dp = e->Dp ? e->Dp : 32;
+  const size_t CT = (t + 63) / 64, RT = (n + 63) / 64;
   TRY(dev_ensure(e, s->raw, n * sizeof(BoxRaw)));
   TRY(dev_ensure(e, s->quality, n * 4));
   TRY(dev_ensure(e, s->own, n * 4));
@@ -259,16 +259,18 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->usable, n));
   if (e->visual) {
     TRY(dev_ensure(e, s->feat_raw, n * (e->D ? e->D : 1) * 4));
-    TRY(dev_ensure(e, s->feat, n * D8 * 4));
+    TRY(dev_ensure(e, s->feat, n * Dp * 4));
     TRY(dev_ensure(e, s->fnorm, n * 4));
     TRY(dev_ensure(e, s->vis, n * t * K * 4));
   }
   TRY(dev_ensure(e, s->pos, n * t * 4));
   TRY(dev_ensure(e, s->vis_max_key, 256));
-  TRY(dev_ensure(e, s->col_max_w, t * 8));
-  TRY(dev_ensure(e, s->col_min_q, t * 4));
-  TRY(dev_ensure(e, s->row_best_w, n * 8));
-  TRY(dev_ensure(e, s->row_best_t, n * 4));
+  if (e->visual) {
+    TRY(dev_ensure(e, s->row_part_w, n * CT * 8));
+    TRY(dev_ensure(e, s->row_part_t, n * CT * 4));
+    TRY(dev_ensure(e, s->col_part_w, RT * t * 8));
+    TRY(dev_ensure(e, s->col_part_q, RT * t * 4));
+  }
   TRY(dev_ensure(e, s->row_has, n));
   TRY(dev_ensure(e, s->vis_winner, n * 4));
   TRY(dev_ensure(e, s->col_excluded, t));
@@ -289,8 +291,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->cnext, t * 4));
   TRY(dev_ensure(e, s->rdist, n * 8));
   TRY(dev_ensure(e, s->rnext, n * 4));
-  TRY(dev_ensure(e, s->out_id, n * 8));
-  TRY(dev_ensure(e, s->out_vote, n));
+  TRY(dev_ensure(e, s->out, n * 9));
   TRY(host_ensure(e, s->h_out, n * 9));
   return SA_OK;
 }
@@ -298,25 +299,32 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
 void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   SceneTable* sc = s->scene;
   std::memset(d, 0, sizeof *d);
-  d->N = s->N; d->T = s->T; d->K = e->K; d->D8 = e->D8;
+  d->N = s->N; d->T = s->T; d->K = e->K; d->Dp = e->Dp;
   d->TK = s->T * e->K; d->estride = s->T ? s->T : 1;
+  d->D = e->D;
+  d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
+             (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
+  d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
   d->epoch = s->epoch;
   d->t_geo = (const sa_geo*)sc->geo.p; d->t_verts = (const double*)sc->verts.p; d->t_epoch = (const uint64_t*)sc->epoch.p;
   d->t_maha = (const float*)sc->maha.p; d->t_feat = (const float*)sc->feat.p; d->t_fnorm = (const float*)sc->fnorm.p;
   d->t_fpresent = (const uint8_t*)sc->fpresent.p; d->t_fcount = (const uint32_t*)sc->fcount.p; d->t_ids = (const uint64_t*)sc->tids.p;
-  d->c_geo = (const sa_geo*)s->geo.p; d->c_verts = (const double*)s->verts.p; d->c_z = (const float*)s->z.p;
-  d->c_conf = (const float*)s->conf.p; d->c_feat = (const float*)s->feat.p; d->c_fnorm = (const float*)s->fnorm.p;
-  d->c_usable = (const uint8_t*)s->usable.p;
+  d->c_raw = (const BoxRaw*)s->raw.p; d->c_quality = (const float*)s->quality.p; d->c_own = (const float*)s->own.p;
+  d->c_fpresent_in = (const uint8_t*)s->fpresent_in.p; d->c_feat_raw = (const float*)s->feat_raw.p;
+  d->c_geo = (sa_geo*)s->geo.p; d->c_verts = (double*)s->verts.p; d->c_z = (float*)s->z.p;
+  d->c_conf = (float*)s->conf.p; d->c_feat = (float*)s->feat.p; d->c_fnorm = (float*)s->fnorm.p;
+  d->c_usable = (uint8_t*)s->usable.p;
   d->pos = (float*)s->pos.p; d->vis = (float*)s->vis.p;
-  d->vis_max_key = (uint32_t*)s->vis_max_key.p; d->col_max_w = (unsigned long long*)s->col_max_w.p;
-  d->col_min_q = (uint32_t*)s->col_min_q.p; d->row_best_w = (double*)s->row_best_w.p; d->row_best_t = (int32_t*)s->row_best_t.p;
+  d->vis_max_key = (uint32_t*)s->vis_max_key.p;
+  d->row_part_w = (double*)s->row_part_w.p; d->row_part_t = (int32_t*)s->row_part_t.p;
+  d->col_part_w = (double*)s->col_part_w.p; d->col_part_q = (uint32_t*)s->col_part_q.p;
   d->row_has = (uint8_t*)s->row_has.p; d->vis_winner = (int32_t*)s->vis_winner.p; d->col_excluded = (uint8_t*)s->col_excluded.p;
   d->parent = (uint32_t*)s->parent.p; d->label = (uint32_t*)s->label.p; d->next_row = (uint32_t*)s->next_row.p;
   d->e_cnt = (uint32_t*)s->e_cnt.p; d->e_col = (uint32_t*)s->e_col.p; d->e_gain = (int64_t*)s->e_gain.p;
   d->u = (int64_t*)s->u.p; d->v = (int64_t*)s->v.p; d->rmatch = (int32_t*)s->rmatch.p; d->cmatch = (int32_t*)s->cmatch.p;
   d->dist = (int64_t*)s->dist.p; d->pred = (int32_t*)s->pred.p; d->cstamp = (uint32_t*)s->cstamp.p; d->cscan = (uint32_t*)s->cscan.p;
   d->cnext = (int32_t*)s->cnext.p; d->rdist = (int64_t*)s->rdist.p; d->rnext = (int32_t*)s->rnext.p;
-  d->out_track_id = (uint64_t*)s->out_id.p; d->out_vote = (uint8_t*)s->out_vote.p;
+  d->out_track_id = (uint64_t*)s->out.p; d->out_vote = (uint8_t*)s->out.p + (size_t)(s->N ? s->N : 1) * 8;
   d->quant = (int64_t*)s->quant.p;
 }
 
@@ -346,51 +354,29 @@ int run_pipeline(sa_engine* e) {
   e->synced = false;
   const SceneDev* ds = (const SceneDev*)e->d_scenes.p;
   hipStream_t st = e->stream;
-  // candidate preparation (per scene: pointers differ and the work is O(N))
-  for (uint32_t i = 0; i < ns; ++i) {
-    Slot* s = e->slots[i];
-    if (!s->N) continue;
-    {
-      ProfScope ps(e, KID_PREP_CANDS);
-      PrepCandArgs a{};
-      a.raw = (const BoxRaw*)s->raw.p;
-      a.quality = s->has_quality ? (const float*)s->quality.p : nullptr;
-      a.own_area = s->has_own ? (const float*)s->own.p : nullptr;
-      a.feat_present = s->has_fpresent ? (const uint8_t*)s->fpresent_in.p : nullptr;
-      a.has_feats = s->has_feats;
-      a.n = s->N;
-      a.geo = (sa_geo*)s->geo.p; a.verts = (double*)s->verts.p; a.z = (float*)s->z.p; a.conf = (float*)s->conf.p;
-      a.usable = (uint8_t*)s->usable.p;
-      HIPCHK(e, sa_launch_prep_cands(a, e->P, st));
-    }
-    if (e->visual && s->has_feats) {
-      ProfScope ps(e, KID_PAD_CANDS);
-      HIPCHK(e, sa_launch_pad_features((const float*)s->feat_raw.p, s->N, e->D, e->D8, 1, nullptr,
-                                       s->has_fpresent ? (const uint8_t*)s->fpresent_in.p : nullptr, (float*)s->feat.p,
-                                       (float*)s->fnorm.p, nullptr, nullptr, st));
-    }
-  }
-  { ProfScope ps(e, KID_FRAME_INIT); HIPCHK(e, sa_launch_frame_init(ds, ns, maxN, maxT, e->P, st)); }
+  { ProfScope ps(e, KID_FRAME_PREP); HIPCHK(e, sa_launch_frame_prep(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   { ProfScope ps(e, KID_POSITIONAL); HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, st)); }
   if (e->visual) {
     { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
-    { ProfScope ps(e, KID_BESTFIT_ROWS); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
-    { ProfScope ps(e, KID_BESTFIT_TIES); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
-    { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 2)); }
+    { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
+    { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
   }
   { ProfScope ps(e, KID_ASSIGN_EDGES); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 0)); }
-  { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 1)); }
-  { ProfScope ps(e, KID_ASSIGN_NEXT); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 2)); }
-  { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 3)); }
-  { ProfScope ps(e, KID_FINALIZE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 4)); }
+  if (maxN <= SA_SMALL_N) {
+    ProfScope ps(e, KID_ASSIGN_SMALL);
+    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 5));
+  } else {
+    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 1)); }
+    { ProfScope ps(e, KID_ASSIGN_NEXT); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 2)); }
+    { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 3)); }
+    { ProfScope ps(e, KID_FINALIZE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 4)); }
+  }
   {
     ProfScope ps(e, KID_D2H);
     for (uint32_t i = 0; i < ns; ++i) {
       Slot* s = e->slots[i];
       if (!s->N) continue;
-      uint8_t* h = (uint8_t*)s->h_out.p;
-      HIPCHK(e, hipMemcpyAsync(h, s->out_id.p, (size_t)s->N * 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(e, hipMemcpyAsync(h + (size_t)s->N * 8, s->out_vote.p, s->N, hipMemcpyDeviceToHost, st));
+      HIPCHK(e, hipMemcpyAsync(s->h_out.p, s->out.p, (size_t)s->N * 9, hipMemcpyDeviceToHost, st));
     }
   }
   for (uint32_t i = 0; i < ns; ++i) e->slots[i]->ran = true;
@@ -474,7 +460,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   e->visual = cfg->visual_kind != SA_VIS_NONE;
   e->K = e->visual ? cfg->max_observations : 1;
   e->D = e->visual ? cfg->feature_len : 0;
-  e->D8 = e->visual ? (e->D + 7u) / 8u * 8u : 0;
+  e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
   e->profile = (cfg->flags & SA_FLAG_PROFILE) != 0;
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else {
@@ -501,6 +487,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.visual_minimal_own_area_use = cfg->visual_minimal_own_area_percentage_use;
   P.kf_position_weight = cfg->kf_position_weight;
   P.max_idle = cfg->max_idle_epochs;
+  P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
   for (uint32_t i = 0; i < cfg->n_constraints; ++i) {
     P.cons.delta[i] = cfg->constraint_epoch_delta[i];
@@ -535,11 +522,10 @@ void sa_engine_destroy(sa_engine* e) {
   }
   for (Slot* s : e->slots) {
     for (DevBuf* b : {&s->raw, &s->quality, &s->own, &s->fpresent_in, &s->feat_raw, &s->geo, &s->verts, &s->z, &s->conf,
-                      &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->col_max_w,
-                      &s->col_min_q, &s->row_best_w, &s->row_best_t, &s->row_has, &s->vis_winner, &s->col_excluded,
+                      &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
+                      &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
                       &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_col, &s->e_gain, &s->u, &s->v, &s->rmatch,
-                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->out_id,
-                      &s->out_vote})
+                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->out})
       free_dev(*b);
     free_host(s->h_in);
     free_host(s->h_out);
@@ -644,7 +630,7 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
       TRY(dev_ensure(e, e->up_feats, (size_t)n * K * D * 4));
       HIPCHK(e, hipMemcpyAsync(e->up_feats.p, h + o_feat, (size_t)n * K * D * 4, hipMemcpyHostToDevice, st));
     }
-    HIPCHK(e, sa_launch_pad_features(have_feats ? (const float*)e->up_feats.p : nullptr, n * K, D, e->D8, K,
+    HIPCHK(e, sa_launch_pad_features(have_feats ? (const float*)e->up_feats.p : nullptr, n * K, D, e->Dp, K,
                                      (const uint32_t*)e->up_slots.p, (const uint8_t*)e->up_present.p, (float*)sc->feat.p,
                                      (float*)sc->fnorm.p, (uint8_t*)sc->fpresent.p, (uint32_t*)sc->fcount.p, st));
   }
@@ -677,7 +663,7 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
     const uint32_t K = e->K;
     std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u}};
     if (e->visual) {
-      arrs.push_back({&sc->feat, K * e->D8 * 4u});
+      arrs.push_back({&sc->feat, K * e->Dp * 4u});
       arrs.push_back({&sc->fnorm, K * 4u});
       arrs.push_back({&sc->fpresent, K});
       arrs.push_back({&sc->fcount, 4u});
@@ -922,7 +908,7 @@ int sa_feature_distance_matrix(sa_engine* e, int32_t kind, uint32_t n, uint32_t 
   if (kind != SA_VIS_COSINE && kind != SA_VIS_EUCLIDEAN) return fail(e, SA_ERR_BAD_ARG, "kind must be cosine or euclidean");
   HIPCHK(e, hipSetDevice(e->device));
   TRY(engine_sync(e));
-  const uint32_t d8 = (d + 7u) / 8u * 8u;
+  const uint32_t d8 = (d + 31u) / 32u * 32u;
   DevBuf ra, rb, pa, pb, na, nb, o;
   TRY(dev_ensure(e, ra, (size_t)n * d * 4));
   TRY(dev_ensure(e, rb, (size_t)t * d * 4));

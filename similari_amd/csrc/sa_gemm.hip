@@ -4,10 +4,13 @@
 // (candidate, stored observation) pair by VisualMetric::visual_metric (visual_sort/metric.rs:200-225).
 //
 // cosine   : dot products on the f32 matrix cores — v_mfma_f32_32x32x2_f32, exact f32 (an fmaf chain),
-//            157 TF/s peak; A = candidates [N][D8], B = track bank [T*K][D8], both k-contiguous, so the
-//            contraction is C = A * B^T.  128x128 (or 64x64 for small frames) block tile, 4 waves as 2x2,
-//            BK = 32 staged through XOR-swizzled LDS, ds_read_b128 fragments (each lane takes 4 consecutive
-//            k of its row; the k-slot permutation is the same for A and B, so the sum is unchanged).
+//            157 TF/s peak; A = candidates [N][Dp], B = track bank [T*K][Dp], both k-contiguous, so the
+//            contraction is C = A * B^T.  Block tile 128x128 (big frames) or 64x64 (small frames), 4 waves
+//            as 2x2 per k-group, k staged 32 floats at a time through XOR-swizzled LDS, ds_read_b128
+//            fragments (each lane takes 4 consecutive k of its row; the k-slot permutation is the same for A
+//            and B, so the sum is unchanged).  Small frames cannot fill 256 CUs x 4 SIMDs with 32x32 wave
+//            tiles, so the 64x64 kernel splits k across KG wave groups inside the block (each group owns its
+//            LDS stage and accumulators; one LDS reduction at the end) — 2-4 waves per SIMD instead of 1.
 //            The epilogue fuses everything the reference does per pair after the dot product:
 //            d = dot / sqrt(n1*n2) with hoisted norms, is_ok threshold, distance_to_weight (1 - d), the
 //            feature_can_be_used / minimal-track-length gates, compatible(), and the running maximum that
@@ -33,43 +36,49 @@ struct GemmCols {   // per-lane column metadata kept in registers through the ep
   uint64_t epoch;
 };
 
-template <int BM, int BN>
+// Dp is a multiple of 32, so a 32-float chunk is either entirely inside a row or absent; rows past the
+// matrix edge are clamped to the last row (their results are never stored) — no branches around the loads.
+template <int BM, int BN, int KG>
 __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
-                                              uint32_t Ncols, uint32_t D8, uint32_t m0, uint32_t n0, float* lds,
+                                              uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
                                               f32x16 (&acc)[BM / 64][BN / 64]) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per tile
-  float* As = lds;
-  float* Bs = lds + BM * BK;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t wm = wave >> 1, wn = wave & 1u;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per stage
+  const uint32_t tid = threadIdx.x;
+  const uint32_t kg = tid >> 8;          // k-group of this wave (0 when KG == 1)
+  const uint32_t ltid = tid & 255u, lane = tid & 63u, w4 = (tid >> 6) & 3u;
+  float* As = lds + kg * (BM + BN) * BK;
+  float* Bs = As + BM * BK;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u;
   const uint32_t lr = lane & 31u, lh = lane >> 5;
+  const uint32_t nchunks = Dp / BK;
+  const uint32_t niter = (nchunks + KG - 1) / KG;
+  const float* pa[A_CH];
+  const float* pb[B_CH];
+  uint32_t sa_[A_CH], sb_[B_CH];
+#pragma unroll
+  for (int r = 0; r < A_CH; ++r) {
+    uint32_t c = ltid + 256u * r, row = c >> 3, kc = c & 7u;
+    uint32_t gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    pa[r] = A + (size_t)gr * Dp + kc * 4u;
+    sa_[r] = lds_off(row, kc);
+  }
+#pragma unroll
+  for (int r = 0; r < B_CH; ++r) {
+    uint32_t c = ltid + 256u * r, row = c >> 3, kc = c & 7u;
+    uint32_t gr = n0 + row;
+    gr = gr < Ncols ? gr : Ncols - 1;
+    pb[r] = B + (size_t)gr * Dp + kc * 4u;
+    sb_[r] = lds_off(row, kc);
+  }
   f32x4 ra[A_CH], rb[B_CH];
-  auto gload = [&](uint32_t k0) {
+  auto gload = [&](uint32_t chunk) {
+    const uint32_t k0 = chunk * BK;
 #pragma unroll
-    for (int r = 0; r < A_CH; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      uint32_t gr = m0 + row, gk = k0 + kc * 4u;
-      ra[r] = (gr < M && gk < D8) ? *(const f32x4*)(A + (size_t)gr * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int r = 0; r < A_CH; ++r) ra[r] = *(const f32x4*)(pa[r] + k0);
 #pragma unroll
-    for (int r = 0; r < B_CH; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      uint32_t gr = n0 + row, gk = k0 + kc * 4u;
-      rb[r] = (gr < Ncols && gk < D8) ? *(const f32x4*)(B + (size_t)gr * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int r = 0; r < A_CH; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      *(f32x4*)(As + lds_off(row, kc)) = ra[r];
-    }
-#pragma unroll
-    for (int r = 0; r < B_CH; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      *(f32x4*)(Bs + lds_off(row, kc)) = rb[r];
-    }
+    for (int r = 0; r < B_CH; ++r) rb[r] = *(const f32x4*)(pb[r] + k0);
   };
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -78,25 +87,78 @@ __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-  gload(0);
-  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
-    lstore();
+  uint32_t aoff[TM], boff[TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) aoff[m] = wm * (BM / 2) + m * 32 + lr;
+#pragma unroll
+  for (int n = 0; n < TN; ++n) boff[n] = wn * (BN / 2) + n * 32 + lr;
+
+  if (kg < nchunks) gload(kg);
+  for (uint32_t it = 0; it < niter; ++it) {
+    const uint32_t chunk = it * KG + kg;          // uniform inside a k-group
+    const bool live = chunk < nchunks;
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < A_CH; ++r) *(f32x4*)(As + sa_[r]) = ra[r];
+#pragma unroll
+      for (int r = 0; r < B_CH; ++r) *(f32x4*)(Bs + sb_[r]) = rb[r];
+    }
     __syncthreads();
-    if (k0 + BK < D8) gload(k0 + BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
+    if (chunk + KG < nchunks) gload(chunk + KG);  // next stage's L2/HBM loads fly under this stage's MFMAs
+    if (live) {
+      f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (uint32_t kk = 0; kk < 4; ++kk) {
-      f32x4 fa[TM], fb[TN];
+      for (int m = 0; m < TM; ++m) fa[0][m] = *(const f32x4*)(As + lds_off(aoff[m], lh));
 #pragma unroll
-      for (int m = 0; m < TM; ++m) fa[m] = *(const f32x4*)(As + lds_off(wm * (BM / 2) + m * 32 + lr, kk * 2 + lh));
+      for (int n = 0; n < TN; ++n) fb[0][n] = *(const f32x4*)(Bs + lds_off(boff[n], lh));
 #pragma unroll
-      for (int n = 0; n < TN; ++n) fb[n] = *(const f32x4*)(Bs + lds_off(wn * (BN / 2) + n * 32 + lr, kk * 2 + lh));
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {  // fragments of the next k-slice are in flight while this slice's MFMAs issue
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+          for (int m = 0; m < TM; ++m) fa[(kk + 1) & 1][m] = *(const f32x4*)(As + lds_off(aoff[m], (kk + 1) * 2 + lh));
+#pragma unroll
+          for (int n = 0; n < TN; ++n) fb[(kk + 1) & 1][n] = *(const f32x4*)(Bs + lds_off(boff[n], (kk + 1) * 2 + lh));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][m][e], fb[kk & 1][n][e], acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (KG > 1) {
+    // fold the k-groups: group g > 0 parks its accumulators in LDS, group 0 adds them in group order
+    constexpr int ACC = TM * TN * 16;
+    float* red = lds;  // (KG-1) * 256 threads * ACC floats <= KG * (BM+BN) * BK for the 64x64 tile
+    if (kg > 0) {
+      float* dst = red + ((size_t)(kg - 1) * 256 + ltid) * ACC;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; e += 4)
+            *(f32x4*)(dst + (m * TN + n) * 16 + e) = f32x4{acc[m][n][e], acc[m][n][e + 1], acc[m][n][e + 2], acc[m][n][e + 3]};
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* src = red + ((size_t)(g - 1) * 256 + ltid) * ACC;
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][e], fb[n][e], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+              f32x4 v = *(const f32x4*)(src + (m * TN + n) * 16 + e);
+              acc[m][n][e] += v[0]; acc[m][n][e + 1] += v[1]; acc[m][n][e + 2] += v[2]; acc[m][n][e + 3] += v[3];
+            }
+      }
     }
     __syncthreads();
   }
@@ -105,25 +167,25 @@ __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const
 // Row of accumulator register r for lane half lh in a 32x32 MFMA tile (C/D layout, cdna_hip_programming.md §3)
 __device__ __forceinline__ uint32_t acc_row(int r, uint32_t lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+template <int BM, int BN, int KG>
+__global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev& S = scenes[blockIdx.z];
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[KG * (BM + BN) * BK];
   f32x16 acc[TM][TN];
-  gemm_mainloop<BM, BN>(S.c_feat, S.t_feat, N, TK, S.D8, m0, n0, lds, acc);
+  gemm_mainloop<BM, BN, KG>(S.c_feat, S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
 
-  // ---- fused epilogue ----
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t wm = wave >> 1, wn = wave & 1u, lr = lane & 31u, lh = lane >> 5;
-  // row metadata through LDS (the main loop's last barrier has passed): na, usable, geometry
-  float* s_na = lds;                    // [BM]
-  float* s_us = lds + BM;               // [BM] 1.0 / 0.0
+  // ---- fused epilogue (k-group 0 holds the sums; the other groups only keep the barriers company) ----
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u;
+  const bool worker = tid < 256;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  float* s_na = lds;                      // [BM]
+  float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
-  for (uint32_t r = tid; r < (uint32_t)BM; r += 256) {
+  for (uint32_t r = tid; r < (uint32_t)BM; r += 256 * KG) {
     uint32_t gi = m0 + r;
     bool in = gi < N;
     s_na[r] = in ? S.c_fnorm[gi] : 0.f;
@@ -138,7 +200,7 @@ __global__ __launch_bounds__(256) void k_visual_cosine(const SceneDev* __restric
     col[n].nb = 0.f;
     col[n].g = sa_geo{0.f, 0.f, 0.f, 0.f};
     col[n].epoch = 0;
-    if (gj < TK) {
+    if (worker && gj < TK) {
       uint32_t t = gj / K;
       col[n].nb = S.t_fnorm[gj];
       col[n].ok = S.t_fpresent[gj] != 0 && S.t_fcount[t] >= p.min_track_len;
@@ -147,6 +209,7 @@ __global__ __launch_bounds__(256) void k_visual_cosine(const SceneDev* __restric
     }
   }
   __syncthreads();
+  if (!worker) return;
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
   uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
@@ -185,33 +248,41 @@ __global__ __launch_bounds__(256) void k_visual_cosine(const SceneDev* __restric
 
 // Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
 // swizzled LDS tiles.  Column c of a thread is tx + 16*c so a wave's stores cover 64-B row segments.
-__global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
+__device__ __forceinline__ void euclid_mainloop(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+                                                uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
+                                                float (&acc)[4][4]) {
   constexpr int BM = 64, BN = 64;
-  const SceneDev& S = scenes[blockIdx.z];
-  const uint32_t N = S.N, TK = S.TK, K = S.K, D8 = S.D8;
-  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  if (m0 >= N || n0 >= TK) return;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
   float* As = lds;
   float* Bs = lds + BM * BK;
   const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
-  float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
+  const float* pa[2];
+  const float* pb[2];
+  uint32_t so[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      uint32_t gk = k0 + kc * 4u;
-      uint32_t ga = m0 + row, gb = n0 + row;
-      f32x4 va = (ga < N && gk < D8) ? *(const f32x4*)(S.c_feat + (size_t)ga * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 vb = (gb < TK && gk < D8) ? *(const f32x4*)(S.t_feat + (size_t)gb * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      *(f32x4*)(As + lds_off(row, kc)) = va;
-      *(f32x4*)(Bs + lds_off(row, kc)) = vb;
-    }
+  for (int r = 0; r < 2; ++r) {
+    uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
+    uint32_t ga = m0 + row, gb = n0 + row;
+    ga = ga < M ? ga : M - 1;
+    gb = gb < Ncols ? gb : Ncols - 1;
+    pa[r] = A + (size_t)ga * Dp + kc * 4u;
+    pb[r] = B + (size_t)gb * Dp + kc * 4u;
+    so[r] = lds_off(row, kc);
+  }
+  f32x4 ra[2], rb[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) { ra[r] = *(const f32x4*)pa[r]; rb[r] = *(const f32x4*)pb[r]; }
+  for (uint32_t k0 = 0; k0 < Dp; k0 += BK) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { *(f32x4*)(As + so[r]) = ra[r]; *(f32x4*)(Bs + so[r]) = rb[r]; }
     __syncthreads();
+    if (k0 + BK < Dp) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { ra[r] = *(const f32x4*)(pa[r] + k0 + BK); rb[r] = *(const f32x4*)(pb[r] + k0 + BK); }
+    }
 #pragma unroll
     for (uint32_t kc = 0; kc < 8; ++kc) {
       f32x4 fa[4], fb[4];
@@ -231,6 +302,18 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr int BM = 64, BN = 64;
+  const SceneDev& S = scenes[blockIdx.z];
+  const uint32_t N = S.N, TK = S.TK, K = S.K;
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= N || n0 >= TK) return;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  float acc[4][4];
+  euclid_mainloop(S.c_feat, S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
+  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
   uint32_t kmax = 0;
@@ -266,17 +349,18 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
 }
 
 // ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
-                                                       const float* __restrict__ B, const float* __restrict__ bn,
-                                                       uint32_t M, uint32_t Ncols, uint32_t D8, float* __restrict__ out) {
+template <int BM, int BN, int KG>
+__global__ __launch_bounds__(256 * KG) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
+                                                            const float* __restrict__ B, const float* __restrict__ bn,
+                                                            uint32_t M, uint32_t Ncols, uint32_t Dp, float* __restrict__ out) {
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[KG * (BM + BN) * BK];
   f32x16 acc[TM][TN];
-  gemm_mainloop<BM, BN>(A, B, M, Ncols, D8, m0, n0, lds, acc);
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t wm = wave >> 1, wn = wave & 1u, lr = lane & 31u, lh = lane >> 5;
+  gemm_mainloop<BM, BN, KG>(A, B, M, Ncols, Dp, m0, n0, lds, acc);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u;
+  if (tid >= 256) return;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   float nb[TN];
 #pragma unroll
   for (int n = 0; n < TN; ++n) {
@@ -299,49 +383,13 @@ __global__ __launch_bounds__(256) void k_cosine_matrix(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
-                                                       uint32_t Ncols, uint32_t D8, float* __restrict__ out) {
+                                                       uint32_t Ncols, uint32_t Dp, float* __restrict__ out) {
   constexpr int BM = 64, BN = 64;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
-  float* As = lds;
-  float* Bs = lds + BM * BK;
-  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
   float acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (uint32_t k0 = 0; k0 < D8; k0 += BK) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-      uint32_t gk = k0 + kc * 4u;
-      uint32_t ga = m0 + row, gb = n0 + row;
-      f32x4 va = (ga < M && gk < D8) ? *(const f32x4*)(A + (size_t)ga * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 vb = (gb < Ncols && gk < D8) ? *(const f32x4*)(B + (size_t)gb * D8 + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      *(f32x4*)(As + lds_off(row, kc)) = va;
-      *(f32x4*)(Bs + lds_off(row, kc)) = vb;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t kc = 0; kc < 8; ++kc) {
-      f32x4 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const f32x4*)(As + lds_off(ty * 4 + i, kc));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const f32x4*)(Bs + lds_off(tx + 16 * j, kc));
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float df = fa[i][e] - fb[j][e];
-            acc[i][j] += df * df;
-          }
-    }
-    __syncthreads();
-  }
+  euclid_mainloop(A, B, M, Ncols, Dp, m0, n0, lds, acc);
+  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     uint32_t gi = m0 + ty * 4 + i;
@@ -356,19 +404,29 @@ __global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Tile choice: 128x128 when that alone fills the 256 CUs, otherwise 64x64 (4x the workgroups).
-static inline bool big_tiles(uint32_t M, uint32_t Ncols, uint32_t ns) {
-  return (size_t)cdiv(M, 128) * cdiv(Ncols, 128) * ns >= 192;
+// Tile choice by the number of workgroups the frame yields on 256 CUs:
+//   128x128 when that alone gives >= 192 workgroups; else 64x64, with the k dimension split over 2 or 4 wave
+//   groups inside each workgroup when there are too few workgroups to put more than one wave on every SIMD.
+static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp) {
+  if ((size_t)cdiv(M, 128) * cdiv(Ncols, 128) * ns >= 192) return 0;
+  size_t b64 = (size_t)cdiv(M, 64) * cdiv(Ncols, 64) * ns;
+  uint32_t nchunks = Dp / BK;
+  if (b64 <= 320 && nchunks >= 8) return 4;
+  if (b64 <= 768 && nchunks >= 4) return 2;
+  return 1;
 }
 
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
                             hipStream_t st) {
   if (!maxN || !maxTK) return hipSuccess;
   if (p.visual_kind == SA_VIS_COSINE) {
-    if (big_tiles(maxN, maxTK, ns))
-      hipLaunchKernelGGL((k_visual_cosine<128, 128>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p);
-    else
-      hipLaunchKernelGGL((k_visual_cosine<64, 64>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+    const uint32_t Dp = p.Dp;  // one feature length per engine
+    switch (tile_plan(maxN, maxTK, ns, Dp)) {
+      case 0: hipLaunchKernelGGL((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 4: hipLaunchKernelGGL((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
+      case 2: hipLaunchKernelGGL((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
+      default: hipLaunchKernelGGL((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+    }
   } else {
     hipLaunchKernelGGL(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
   }
@@ -376,15 +434,17 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
 }
 
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
-                                     uint32_t n, uint32_t t, uint32_t d8, float* out, hipStream_t st) {
+                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st) {
   if (!n || !t) return hipSuccess;
   if (kind == SA_VIS_COSINE) {
-    if (big_tiles(n, t, 1))
-      hipLaunchKernelGGL((k_cosine_matrix<128, 128>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, d8, out);
-    else
-      hipLaunchKernelGGL((k_cosine_matrix<64, 64>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, d8, out);
+    switch (tile_plan(n, t, 1, dp)) {
+      case 0: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 1>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 4: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 4>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(1024), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 2: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 2>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(512), 0, st, a, an, b, bn, n, t, dp, out); break;
+      default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+    }
   } else {
-    hipLaunchKernelGGL(k_euclid_matrix, dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, b, n, t, d8, out);
+    hipLaunchKernelGGL(k_euclid_matrix, dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, b, n, t, dp, out);
   }
   return hipGetLastError();
 }

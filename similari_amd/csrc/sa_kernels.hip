@@ -1,13 +1,16 @@
 // sa_kernels.hip — gfx950 kernels of the association path other than the feature contraction:
-// box / track preparation, pair pre-filter + IoU / Mahalanobis cost cells, BestFit vote, and the
-// positional assignment (edge compaction, connected components, exact per-component solve).
+// frame preparation, pair pre-filter + IoU / Mahalanobis cost cells, BestFit vote, and the positional
+// assignment (edge compaction, connected components, exact per-component solve).
 //
 // These are HBM/latency-bound integer / f64 / f32 elementwise kernels: the design rules are coalesced
-// 256-B row segments per wave, LDS staging of the per-tile operands, wave ballots for compaction, and
+// 256-B row segments per wave, LDS staging of the per-tile operands, wave ballots for compaction, no
+// global atomics on the hot cells, few launches (each dependent launch costs ~2-4 us on this chip), and
 // grid.z = scene so a whole batch of scenes goes through one launch.  No MFMA here on purpose.
 #include "sa_engine.h"
 
 #define WAVE 64
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // =====================================================================================================
 // Preparation
@@ -23,31 +26,53 @@ __device__ __forceinline__ void prep_box_common(const BoxRaw& r, sa_geo* geo, do
   sa_vertices(b.xc, b.yc, b.aspect, b.height, r.c, r.s, verts);
 }
 
-// Candidates of one frame (visual_sort/simple_api.rs:130-170): geometry, vertices, Mahalanobis measurement
-// (angle.unwrap_or(0), kalman_2d_box.rs:159), clamped confidence (sort/metric.rs:43-47) and the
-// feature_can_be_used gate (visual_sort/metric.rs:227-249).
-__global__ void k_prep_cands(PrepCandArgs a, SaParams p) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  BoxRaw r = a.raw[i];
-  prep_box_common(r, &a.geo[i], &a.verts[(size_t)i * 8]);
-  const sa_box& b = r.box;
-  float* z = &a.z[(size_t)i * 5];
-  z[0] = b.xc; z[1] = b.yc; z[2] = b.has_angle ? b.angle : 0.0f; z[3] = b.aspect; z[4] = b.height;
-  a.conf[i] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
-  bool usable = false;
-  if (a.has_feats && (!a.feat_present || a.feat_present[i])) {
-    float q = a.quality ? a.quality[i] : 1.0f;
-    bool quality_ok = q >= p.visual_minimal_quality_use;
-    bool perc_ok = true;
-    if (a.own_area) {
-      float oa = a.own_area[i];
-      if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+// One wave per feature row: zero-pad D -> Dp (Feature::from_vec, track/utils.rs:45-71; the extra zero lanes
+// add +0.0 to every sum), scatter, squared norm (the per-pair norms of distance.rs:36-44 hoisted to once
+// per vector).
+__device__ __forceinline__ void pad_feature_row(const float* __restrict__ s, float* __restrict__ d, uint32_t D, uint32_t Dp,
+                                                bool pres, uint32_t lane, float* norm_out) {
+  float acc = 0.0f;
+  if (pres && (D & 3u) == 0 && ((uintptr_t)s & 15u) == 0) {
+    for (uint32_t k = lane * 4; k < Dp; k += WAVE * 4) {
+      float4 x = k < D ? *(const float4*)(s + k) : float4{0.f, 0.f, 0.f, 0.f};
+      *(float4*)(d + k) = x;
+      acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     }
-    bool bbox_ok = sa_area(b.aspect, b.height) >= p.visual_minimal_area;
-    usable = bbox_ok && quality_ok && perc_ok;
+  } else {
+    for (uint32_t k = lane; k < Dp; k += WAVE) {
+      float x = (pres && k < D) ? s[k] : 0.0f;
+      d[k] = x;
+      acc += x * x;
+    }
   }
-  a.usable[i] = usable ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  *norm_out = acc;
+}
+
+__global__ void k_pad_features(const float* __restrict__ src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
+                               const uint32_t* __restrict__ slots, const uint8_t* __restrict__ present,
+                               float* __restrict__ dst, float* __restrict__ norms, uint8_t* __restrict__ dst_present) {
+  uint32_t row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  uint32_t lane = threadIdx.x % WAVE;
+  if (row >= rows) return;
+  uint32_t drow = slots ? slots[row / K] * K + row % K : row;
+  bool pres = present ? present[row] != 0 : true;
+  float nrm;
+  pad_feature_row(src + (size_t)row * D, dst + (size_t)drow * Dp, D, Dp, pres && src, lane, &nrm);
+  if (lane == 0) {
+    norms[drow] = nrm;
+    if (dst_present) dst_present[drow] = pres ? 1 : 0;
+  }
+}
+// visual_features_collected_count = observations that carry a feature (visual_sort/metric.rs:368-371)
+__global__ void k_feat_count(const uint32_t* __restrict__ slots, uint32_t n, uint32_t K,
+                             const uint8_t* __restrict__ fpresent, uint32_t* __restrict__ fcount) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = slots[i];
+  uint32_t c = 0;
+  for (uint32_t k = 0; k < K; ++k) c += fpresent[(size_t)s * K + k] ? 1u : 0u;
+  fcount[s] = c;
 }
 
 // Stored tracks touched by an upsert: scatter to their table rows; Kalman projection + Cholesky once per
@@ -61,41 +86,6 @@ __global__ void k_prep_tracks(PrepTrackArgs a, SaParams p) {
   a.t_epoch[s] = a.epochs[i];
   a.t_ids[s] = a.ids[i];
   if (a.kf_mean && a.kf_cov) sa_maha_prepare(p.kf_position_weight, a.kf_mean + (size_t)i * 5, a.kf_cov + (size_t)i * 25, a.maha + (size_t)s * 20);
-}
-
-// One wave per feature row: zero-pad D -> D8 (Feature::from_vec, track/utils.rs:45-71), scatter, squared norm
-// (the per-pair norms of distance.rs:36-44 hoisted to once per vector).
-__global__ void k_pad_features(const float* __restrict__ src, uint32_t rows, uint32_t D, uint32_t D8, uint32_t K,
-                               const uint32_t* __restrict__ slots, const uint8_t* __restrict__ present,
-                               float* __restrict__ dst, float* __restrict__ norms, uint8_t* __restrict__ dst_present) {
-  uint32_t row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  uint32_t lane = threadIdx.x % WAVE;
-  if (row >= rows) return;
-  uint32_t drow = slots ? slots[row / K] * K + row % K : row;
-  bool pres = present ? present[row] != 0 : true;
-  const float* s = src + (size_t)row * D;
-  float* d = dst + (size_t)drow * D8;
-  float acc = 0.0f;
-  for (uint32_t k = lane; k < D8; k += WAVE) {
-    float x = (pres && k < D) ? s[k] : 0.0f;
-    d[k] = x;
-    acc += x * x;
-  }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) {
-    norms[drow] = acc;
-    if (dst_present) dst_present[drow] = pres ? 1 : 0;
-  }
-}
-// visual_features_collected_count = observations that carry a feature (visual_sort/metric.rs:368-371)
-__global__ void k_feat_count(const uint32_t* __restrict__ slots, uint32_t n, uint32_t K,
-                             const uint8_t* __restrict__ fpresent, uint32_t* __restrict__ fcount) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s = slots[i];
-  uint32_t c = 0;
-  for (uint32_t k = 0; k < K; ++k) c += fpresent[(size_t)s * K + k] ? 1u : 0u;
-  fcount[s] = c;
 }
 
 __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
@@ -112,14 +102,26 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restri
 }
 
 // =====================================================================================================
-// Per-frame state reset (one thread per vertex of the bipartite graph)
+// k_frame_prep: everything that is O(N + T) at the start of a frame, in ONE launch:
+//   * reset of the vote / assignment state (one thread per vertex of the bipartite graph),
+//   * candidate preparation (visual_sort/simple_api.rs:130-170): geometry, f64 vertices, Mahalanobis
+//     measurement (angle.unwrap_or(0), kalman_2d_box.rs:159), clamped confidence (sort/metric.rs:43-47),
+//     the feature_can_be_used gate (visual_sort/metric.rs:227-249),
+//   * candidate feature padding + squared norms (one wave per row).
 // =====================================================================================================
-__global__ void k_frame_init(const SceneDev* __restrict__ scenes) {
+__global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev& S = scenes[blockIdx.z];
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t N = S.N, T = S.T;
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) *S.vis_max_key = sa_f32_key(-1.0f);  // BestFit max_dist starts at -1.0 (voting/best.rs:59)
   if (i < N + T) S.parent[i] = i;
+  if (i < T) {
+    S.col_excluded[i] = 0;
+    S.v[i] = 0;
+    S.cmatch[i] = -1;
+    S.cstamp[i] = 0;
+    S.cscan[i] = 0;
+  }
   if (i < N) {
     S.vis_winner[i] = -1;
     S.row_has[i] = 0;
@@ -127,24 +129,44 @@ __global__ void k_frame_init(const SceneDev* __restrict__ scenes) {
     S.e_cnt[i] = 0;
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
+    BoxRaw r = S.c_raw[i];
+    prep_box_common(r, &S.c_geo[i], &S.c_verts[(size_t)i * 8]);
+    const sa_box& b = r.box;
+    float* z = &S.c_z[(size_t)i * 5];
+    z[0] = b.xc; z[1] = b.yc; z[2] = b.has_angle ? b.angle : 0.0f; z[3] = b.aspect; z[4] = b.height;
+    S.c_conf[i] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
+    bool usable = false;
+    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[i])) {
+      float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[i] : 1.0f;
+      bool quality_ok = q >= p.visual_minimal_quality_use;
+      bool perc_ok = true;
+      if (S.flags & SCN_HAS_OWN) {
+        float oa = S.c_own[i];
+        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+      }
+      bool bbox_ok = sa_area(b.aspect, b.height) >= p.visual_minimal_area;
+      usable = bbox_ok && quality_ok && perc_ok;
+    }
+    S.c_usable[i] = usable ? 1 : 0;
   }
-  if (i < T) {
-    S.col_max_w[i] = 0ull;
-    S.col_min_q[i] = SA_NONE;
-    S.col_excluded[i] = 0;
-    S.v[i] = 0;
-    S.cmatch[i] = -1;
-    S.cstamp[i] = 0;
-    S.cscan[i] = 0;
+  if (S.flags & SCN_HAS_FEATS) {
+    const uint32_t row = blockIdx.x * 4 + threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    if (row < N) {
+      bool pres = !(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[row] != 0;
+      float nrm;
+      pad_feature_row(S.c_feat_raw + (size_t)row * S.D, S.c_feat + (size_t)row * S.Dp, S.D, S.Dp, pres, lane, &nrm);
+      if (lane == 0) S.c_fnorm[row] = nrm;
+    }
   }
 }
 
 // =====================================================================================================
 // Positional cost cells: pair pre-filter -> (survivors only) IoU by f64 Sutherland–Hodgman / Mahalanobis.
 // Tile = 16 candidates x 64 tracks per 256-thread block; each wave owns whole 256-B row segments of `pos`.
-// Phase 1 tests every cell against compatible() and too_far() from LDS-staged geometry and writes NaN
-// for the dead ones; the few survivors are compacted into an LDS list so that phase 2 runs the expensive
-// clip with full lanes instead of 1-2 live lanes per wave.
+// Phase 1 tests every cell: too_far() first (no sqrt), then compatible() — whose dist_in_2r costs a sqrt and
+// a division — only for the cells that pass, and writes NaN for the dead ones; the few survivors are
+// compacted into an LDS list so that phase 2 runs the expensive clip with full lanes instead of 1-2 live
+// lanes per wave.
 // =====================================================================================================
 #define POS_TI 16
 #define POS_TJ 64
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
     bool live = false;
     if (i < N && j < T) {
       const sa_geo cg = s_cg[li], tg = s_tg[lj];
-      live = sa_compatible(cg, epoch, tg, s_te[lj], p.max_idle, p.cons) && !sa_too_far(cg, tg);
+      live = !sa_too_far(cg, tg) && sa_compatible(cg, epoch, tg, s_te[lj], p.max_idle, p.cons);
       if (!live) S.pos[(size_t)i * T + j] = nanv;
     }
     if (live) {
@@ -232,71 +254,68 @@ __global__ void k_quant_tap(const SceneDev* __restrict__ scenes) {
 }
 
 // =====================================================================================================
-// BestFit vote (track/voting/best.rs:52-128) without the sort: candidate q wins track t*(q) iff its group
-// (q, t*) is the first group of column t* in (weight desc, q asc) order — SURVEY Appendix A3.
-//   stage 0: one wave per candidate row: W[q,t] = sum_k f64(max_dist - w_k) over present k (count >= votes),
-//            row argmax (W desc, t asc), column max via 64-bit atomicMax on the f64 bit pattern (W >= 0).
-//   stage 1: second sweep: lowest q among the cells that reach the column max.
-//   stage 2: per candidate decision + excluded_tracks (visual_sort/voting.rs:62-71).
+// BestFit vote (track/voting/best.rs:52-128) without the sort and without atomics.  Candidate q wins track
+// t*(q) — its heaviest group — iff (q, t*) is the first group of column t* in (weight desc, q asc, t asc)
+// order; that is the order the reference's stable sort gives a canonically ordered list.
+//   k_bestfit_tile   : 64 x 64 cells per block, lane = column, wave = 16 rows.  W[q,t] = sum_k f64(max_dist -
+//                      w_k) over present k (needs count >= min_votes).  Emits, per (row, column tile), the row's
+//                      best (W, t) and, per (row tile, column), the column's best (W, lowest q).
+//   k_bestfit_resolve: one thread per candidate folds its CT row partials, then the RT column partials of
+//                      the winning column, and decides; winners mark excluded_tracks (visual_sort/voting.rs:62-71).
 // =====================================================================================================
-__device__ __forceinline__ bool bestfit_cell(const SceneDev& S, const SaParams& p, uint32_t q, uint32_t t, float max_dist,
-                                             double* W) {
-  const float* v = S.vis + ((size_t)q * S.T + t) * S.K;
-  uint32_t cnt = 0;
-  double w = 0.0;
-  for (uint32_t k = 0; k < S.K; ++k) {
-    float x = v[k];
-    if (x == x) { ++cnt; w += (double)(max_dist - x); }
-  }
-  *W = w;
-  return cnt >= 1 && cnt >= p.min_votes;
-}
-
-__global__ __launch_bounds__(256) void k_bestfit_rows(const SceneDev* __restrict__ scenes, SaParams p) {
+__global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev& S = scenes[blockIdx.z];
-  const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (q >= S.N) return;
+  const uint32_t N = S.N, T = S.T, K = S.K;
+  const uint32_t ct = blockIdx.x, rt = blockIdx.y;
+  if (ct >= S.CT || rt >= S.RT) return;
+  __shared__ double s_w[4][WAVE];
+  __shared__ uint32_t s_q[4][WAVE];
+  const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const uint32_t t = ct * 64 + lane;
   const float max_dist = sa_key_f32(*S.vis_max_key);
-  double bw = -1.0;
-  int32_t bt = -1;
-  for (uint32_t base = 0; base < S.T; base += WAVE) {
-    uint32_t t = base + lane;
-    if (t < S.T) {
-      double W;
-      if (bestfit_cell(S, p, q, t, max_dist, &W)) {
-        atomicMax(&S.col_max_w[t], (unsigned long long)__double_as_longlong(W));
-        if (W > bw) { bw = W; bt = (int32_t)t; }  // per lane t ascends, so strict > keeps the lowest t
+  double cw = -1.0;      // column best inside this wave's 16 rows
+  uint32_t cq = SA_NONE;
+  for (uint32_t r = 0; r < 16; ++r) {
+    const uint32_t q = rt * 64 + wave * 16 + r;  // wave-uniform
+    if (q >= N) break;
+    double W = -1.0;
+    if (t < T) {
+      const float* v = S.vis + ((size_t)q * T + t) * K;
+      uint32_t cnt = 0;
+      double w = 0.0;
+      for (uint32_t k = 0; k < K; ++k) {
+        float x = v[k];
+        if (x == x) { ++cnt; w += (double)(max_dist - x); }
       }
+      if (cnt >= 1 && cnt >= p.min_votes) W = w;
+    }
+    if (W > cw) { cw = W; cq = q; }  // q ascends: strict > keeps the lowest q
+    // row argmax over the 64 columns of the tile: (W desc, t asc)
+    double bw = W;
+    uint32_t bt = W >= 0.0 ? t : SA_NONE;
+    for (int o = 32; o > 0; o >>= 1) {
+      double ow = __shfl_xor(bw, o);
+      uint32_t ot = __shfl_xor(bt, o);
+      if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
+    }
+    if (lane == 0) {
+      S.row_part_w[(size_t)q * S.CT + ct] = bw;
+      S.row_part_t[(size_t)q * S.CT + ct] = bw >= 0.0 ? (int32_t)bt : -1;
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    double ow = __shfl_xor(bw, o);
-    int32_t ot = __shfl_xor(bt, o);
-    if (ot >= 0 && (bt < 0 || ow > bw || (ow == bw && ot < bt))) { bw = ow; bt = ot; }
-  }
-  if (lane == 0) {
-    S.row_has[q] = bt >= 0 ? 1 : 0;
-    S.row_best_t[q] = bt;
-    S.row_best_w[q] = bw;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_bestfit_ties(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
-  const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (q >= S.N) return;
-  if (!S.row_has[q]) return;
-  const float max_dist = sa_key_f32(*S.vis_max_key);
-  for (uint32_t base = 0; base < S.T; base += WAVE) {
-    uint32_t t = base + lane;
-    if (t < S.T) {
-      double W;
-      if (bestfit_cell(S, p, q, t, max_dist, &W) &&
-          (unsigned long long)__double_as_longlong(W) == S.col_max_w[t])
-        atomicMin(&S.col_min_q[t], q);
+  s_w[wave][lane] = cw;
+  s_q[wave][lane] = cq;
+  __syncthreads();
+  if (wave == 0 && t < T) {
+    double bw = s_w[0][lane];
+    uint32_t bq = s_q[0][lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      double ow = s_w[w2][lane];
+      if (ow > bw) { bw = ow; bq = s_q[w2][lane]; }  // wave index ascends with q
     }
+    S.col_part_w[(size_t)rt * T + t] = bw;
+    S.col_part_q[(size_t)rt * T + t] = bq;
   }
 }
 
@@ -304,27 +323,37 @@ __global__ void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
   const SceneDev& S = scenes[blockIdx.z];
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  if (!S.row_has[q]) return;
-  int32_t t = S.row_best_t[q];
-  bool win = (unsigned long long)__double_as_longlong(S.row_best_w[q]) == S.col_max_w[t] && S.col_min_q[t] == q;
-  if (win) {
-    S.vis_winner[q] = t;
-    S.col_excluded[t] = 1;
+  double bw = -1.0;
+  int32_t bt = -1;
+  for (uint32_t ct = 0; ct < S.CT; ++ct) {
+    double w = S.row_part_w[(size_t)q * S.CT + ct];
+    if (w > bw) { bw = w; bt = S.row_part_t[(size_t)q * S.CT + ct]; }  // tiles ascend with t
+  }
+  if (bt < 0) return;  // no group at all: the candidate goes to the positional vote
+  S.row_has[q] = 1;    // feature_winners.contains_key(q)
+  double cw = -1.0;
+  uint32_t cq = SA_NONE;
+  for (uint32_t rt = 0; rt < S.RT; ++rt) {
+    double w = S.col_part_w[(size_t)rt * S.T + bt];
+    if (w > cw) { cw = w; cq = S.col_part_q[(size_t)rt * S.T + bt]; }  // tiles ascend with q
+  }
+  if (cq == q) {
+    S.vis_winner[q] = bt;
+    S.col_excluded[bt] = 1;
   }
 }
 
 // =====================================================================================================
 // Positional assignment = SortVoting::winners (sort/voting.rs:30-100) as an exact sparse solve.
-//   stage 0  k_assign_edges : one wave per candidate row scans pos[q][*] (the HBM-bound read of the cost
-//            matrix), quantises, keeps cells whose gain = w_q - threshold_q > 0 in column order (wave
-//            ballot + prefix popcount), records the row dual, and unions row and column in the
-//            lock-free forest.  Rows that already hold a visual decision and excluded columns are
-//            skipped (visual_sort/voting.rs:73-79).
-//   stage 1  k_assign_label : label[q] = component representative (minimum row of the component).
-//   stage 2  k_assign_next  : next_row[q] = next row of the same component, one wave per row, 64 labels
-//            per probe — gives each component its rows in ascending order without a sort.
-//   stage 3  k_assign_solve : one thread per component runs sa_assign_component.
-//   stage 4  k_finalize     : winners -> (track id, VotingType).
+//   k_assign_edges : one wave per candidate row scans pos[q][*] (the HBM-bound read of the cost matrix,
+//            16 B per lane per step), quantises, keeps cells whose gain = w_q - threshold_q > 0 in column
+//            order (wave prefix sum), records the row dual, and unions row and column in the lock-free
+//            forest.  Rows that already hold a visual decision and excluded columns are skipped
+//            (visual_sort/voting.rs:73-79).
+//   then either (N <= SA_SMALL_N) k_assign_small: ONE workgroup per scene does labels -> per-component row
+//            order (bitonic sort of (label, row) keys in LDS) -> solve -> results,
+//   or the general path: k_assign_label, k_assign_next (one wave per row, 64 labels per probe),
+//            k_assign_solve (one thread per component), k_finalize.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev& S = scenes[blockIdx.z];
@@ -332,28 +361,50 @@ __global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
   if (S.row_has[q]) return;  // feature_winners.contains_key(from)
-  const float* prow = S.pos + (size_t)q * S.T;
+  const uint32_t T = S.T;
+  const float* prow = S.pos + (size_t)q * T;
   uint32_t* ecol = S.e_col + (size_t)q * S.estride;
   int64_t* egain = S.e_gain + (size_t)q * S.estride;
+  const bool vec = (T & 3u) == 0;  // rows stay 16-B aligned
   uint32_t cnt = 0;
   int64_t maxg = 0;
-  for (uint32_t base = 0; base < S.T; base += WAVE) {
-    uint32_t t = base + lane;
-    int64_t gain = 0;
-    if (t < S.T && !S.col_excluded[t]) {
-      float w = prow[t];
-      if (w == w) gain = sa_quantise(w) - p.threshold_q;
+  for (uint32_t base = 0; base < T; base += WAVE * 4) {
+    const uint32_t t0 = base + lane * 4;
+    float w4[4];
+    if (vec && t0 + 3 < T) {
+      float4 x = *(const float4*)(prow + t0);
+      w4[0] = x.x; w4[1] = x.y; w4[2] = x.z; w4[3] = x.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w4[e] = (t0 + e < T) ? prow[t0 + e] : __builtin_nanf("");
     }
-    bool has = gain > 0;
-    unsigned long long m = __ballot(has);
-    if (has) {
-      uint32_t off = cnt + __popcll(m & ((1ull << lane) - 1ull));
-      ecol[off] = t;
-      egain[off] = gain;
-      if (gain > maxg) maxg = gain;
-      sa_uf_union(S.parent, q, S.N + t);
+    int64_t g4[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int64_t gain = 0;
+      float w = w4[e];
+      if (w == w && !S.col_excluded[t0 + e]) gain = sa_quantise(w) - p.threshold_q;  // w present => t0+e < T
+      g4[e] = gain;
+      mine += gain > 0 ? 1u : 0u;
     }
-    cnt += __popcll(m);
+    // exclusive prefix of `mine` over the wave
+    uint32_t incl = mine;
+    for (int o = 1; o < WAVE; o <<= 1) {
+      uint32_t up = __shfl_up(incl, o);
+      if (lane >= (uint32_t)o) incl += up;
+    }
+    uint32_t off = cnt + incl - mine;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (g4[e] > 0) {
+        ecol[off] = t0 + e;
+        egain[off] = g4[e];
+        ++off;
+        if (g4[e] > maxg) maxg = g4[e];
+        sa_uf_union(S.parent, q, S.N + t0 + e);
+      }
+    cnt += __shfl(incl, WAVE - 1);
   }
   for (int o = 32; o > 0; o >>= 1) {
     int64_t og = __shfl_xor(maxg, o);
@@ -363,6 +414,73 @@ __global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict
     S.e_cnt[q] = cnt;
     S.u[q] = -maxg;
   }
+}
+
+__device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
+  sa_assign_ws w;
+  w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride;
+  w.next_row = S.next_row;
+  w.u = S.u; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
+  w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
+  w.rdist = S.rdist; w.rnext = S.rnext;
+  return w;
+}
+
+__device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
+  uint64_t id = 0;
+  uint8_t vt = SA_VOTE_NONE;
+  int32_t vw = S.vis_winner[q];
+  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+  else if (!S.row_has[q]) {
+    int32_t c = S.rmatch[q];
+    if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; }
+  }
+  S.out_track_id[q] = id;
+  S.out_vote[q] = vt;
+}
+
+// One 1024-thread workgroup per scene: labels, row order inside components, solve, results.
+__global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
+  const SceneDev& S = scenes[blockIdx.z];
+  const uint32_t N = S.N;
+  const uint32_t q = threadIdx.x;
+  __shared__ uint32_t s_key[SA_SMALL_N];  // (label << 10 | row), rows without edges sort to the end
+  uint32_t lab = SA_NONE;
+  if (q < N && S.e_cnt[q]) lab = sa_uf_find(S.parent, q);
+  s_key[q] = lab == SA_NONE ? 0xffffffffu : ((lab << 10) | q);
+  __syncthreads();
+  // bitonic sort of 1024 keys (ascending): components become runs, rows ascending inside a run
+  for (uint32_t k = 2; k <= SA_SMALL_N; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      uint32_t ixj = q ^ j;
+      if (ixj > q) {
+        uint32_t a = s_key[q], b = s_key[ixj];
+        bool up = (q & k) == 0;
+        if ((a > b) == up) { s_key[q] = b; s_key[ixj] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  // position q of the sorted array: link to the next row of the same component
+  {
+    uint32_t key = s_key[q];
+    if (key != 0xffffffffu) {
+      uint32_t row = key & 1023u, l = key >> 10;
+      uint32_t nxt = SA_NONE;
+      if (q + 1 < SA_SMALL_N) {
+        uint32_t k2 = s_key[q + 1];
+        if (k2 != 0xffffffffu && (k2 >> 10) == l) nxt = k2 & 1023u;
+      }
+      S.next_row[row] = nxt;
+    }
+  }
+  __syncthreads();
+  if (q < N && lab == q) {  // representative = minimum row of its component
+    sa_assign_ws w = make_ws(S);
+    sa_assign_component(w, q);
+  }
+  __syncthreads();
+  if (q < N) finalize_row(S, q);
 }
 
 __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
@@ -394,12 +512,7 @@ __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
   if (S.label[q] != q) return;  // only the representative (minimum row) of a component works
-  sa_assign_ws w;
-  w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride;
-  w.next_row = S.next_row;
-  w.u = S.u; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
-  w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
-  w.rdist = S.rdist; w.rnext = S.rnext;
+  sa_assign_ws w = make_ws(S);
   sa_assign_component(w, q);
 }
 
@@ -407,38 +520,22 @@ __global__ void k_finalize(const SceneDev* __restrict__ scenes) {
   const SceneDev& S = scenes[blockIdx.z];
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  uint64_t id = 0;
-  uint8_t vt = SA_VOTE_NONE;
-  int32_t vw = S.vis_winner[q];
-  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
-  else if (!S.row_has[q]) {
-    int32_t c = S.rmatch[q];
-    if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; }
-  }
-  S.out_track_id[q] = id;
-  S.out_vote[q] = vt;
+  finalize_row(S, q);
 }
 
 // =====================================================================================================
 // Launchers
 // =====================================================================================================
-static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
-
-hipError_t sa_launch_prep_cands(const PrepCandArgs& a, const SaParams& p, hipStream_t st) {
-  if (!a.n) return hipSuccess;
-  hipLaunchKernelGGL(k_prep_cands, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a, p);
-  return hipGetLastError();
-}
 hipError_t sa_launch_prep_tracks(const PrepTrackArgs& a, const SaParams& p, hipStream_t st) {
   if (!a.n) return hipSuccess;
   hipLaunchKernelGGL(k_prep_tracks, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a, p);
   return hipGetLastError();
 }
-hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t D8, uint32_t K,
+hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                   const uint32_t* slots, const uint8_t* present, float* dst, float* norms,
                                   uint8_t* dst_present, uint32_t* fcount, hipStream_t st) {
   if (!rows) return hipSuccess;
-  hipLaunchKernelGGL(k_pad_features, dim3(cdiv(rows, 4)), dim3(256), 0, st, src, rows, D, D8, K, slots, present, dst,
+  hipLaunchKernelGGL(k_pad_features, dim3(cdiv(rows, 4)), dim3(256), 0, st, src, rows, D, Dp, K, slots, present, dst,
                      norms, dst_present);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -456,9 +553,11 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
                      (uint8_t*)dst, index, rows, row_bytes);
   return hipGetLastError();
 }
-hipError_t sa_launch_frame_init(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams&,
-                                hipStream_t st) {
-  hipLaunchKernelGGL(k_frame_init, dim3(cdiv(maxN + maxT + 1, 256), 1, ns), dim3(256), 0, st, scenes);
+hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual,
+                                const SaParams& p, hipStream_t st) {
+  uint32_t blocks = cdiv(maxN + maxT + 1, 256);
+  if (visual && cdiv(maxN, 4) > blocks) blocks = cdiv(maxN, 4);
+  hipLaunchKernelGGL(k_frame_prep, dim3(blocks, 1, ns), dim3(256), 0, st, scenes, p);
   return hipGetLastError();
 }
 hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
@@ -469,19 +568,16 @@ hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t ma
 }
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, hipStream_t st) {
   if (!maxN || !maxT) return hipSuccess;
-  uint32_t blocks = cdiv((uint32_t)(((size_t)maxN * maxT + 255) / 256), 1);
-  if (blocks > 2048) blocks = 2048;
+  size_t b = ((size_t)maxN * maxT + 255) / 256;
+  uint32_t blocks = b > 2048 ? 2048u : (uint32_t)b;
   hipLaunchKernelGGL(k_quant_tap, dim3(blocks, 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                              hipStream_t st, int stage) {
   if (!maxN || !maxT) return hipSuccess;
-  switch (stage) {
-    case 0: hipLaunchKernelGGL(k_bestfit_rows, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes, p); break;
-    case 1: hipLaunchKernelGGL(k_bestfit_ties, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes, p); break;
-    default: hipLaunchKernelGGL(k_bestfit_resolve, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-  }
+  if (stage == 0) hipLaunchKernelGGL(k_bestfit_tile, dim3(cdiv(maxT, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+  else hipLaunchKernelGGL(k_bestfit_resolve, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
@@ -492,7 +588,8 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     case 1: hipLaunchKernelGGL(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     case 2: hipLaunchKernelGGL(k_assign_next, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes); break;
     case 3: hipLaunchKernelGGL(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
-    default: hipLaunchKernelGGL(k_finalize, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
+    case 4: hipLaunchKernelGGL(k_finalize, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
+    default: hipLaunchKernelGGL(k_assign_small, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); break;
   }
   return hipGetLastError();
 }
