@@ -79,10 +79,12 @@ SA_HD float sa_dist_in_2r(const sa_geo& l, const sa_geo& r) {
 SA_HD bool sa_compatible(const sa_geo& c, uint64_t ce, const sa_geo& t, uint64_t te, uint64_t max_idle,
                          const sa_constraints& cons) {
   uint64_t delta = ce > te ? ce - te : te - ce;
-  float dist = sa_dist_in_2r(c, t);
   if (!(max_idle >= delta)) return false;
+  // validate(): the first constraint with delta_i >= epoch_delta decides; none -> true.  dist_in_2r (a sqrt and a
+  // division) is only evaluated when a constraint actually applies — the reference computes it unconditionally
+  // but reads it nowhere else.
   for (uint32_t i = 0; i < cons.n; ++i)
-    if (cons.delta[i] >= delta) return dist <= cons.max_dist[i];
+    if (cons.delta[i] >= delta) return sa_dist_in_2r(c, t) <= cons.max_dist[i];
   return true;
 }
 

@@ -51,7 +51,7 @@ struct SceneDev {
   float* pos;
   float* vis;
   // BestFit vote
-  uint32_t* vis_max_key;
+  uint32_t* vis_max_key;   // [SA_MAXKEY_SHARDS] order-preserving keys; max over the shards = BestFit max_dist
   double* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
   int32_t* row_part_t;  // [N][CT]
   double* col_part_w;   // [RT][T] best weight of the column inside row tile rt
@@ -82,6 +82,7 @@ struct SceneDev {
   uint8_t* out_vote;
   int64_t* quant;  // optional N x T tap
 };
+#define SA_MAXKEY_SHARDS 64
 #define SCN_HAS_FEATS 1u
 #define SCN_HAS_QUALITY 2u
 #define SCN_HAS_OWN 4u

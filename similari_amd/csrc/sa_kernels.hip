@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
   const SceneDev& S = scenes[blockIdx.z];
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) *S.vis_max_key = sa_f32_key(-1.0f);  // BestFit max_dist starts at -1.0 (voting/best.rs:59)
+  if (i < SA_MAXKEY_SHARDS) S.vis_max_key[i] = sa_f32_key(-1.0f);  // BestFit max_dist starts at -1.0 (voting/best.rs:59)
   if (i < N + T) S.parent[i] = i;
   if (i < T) {
     S.col_excluded[i] = 0;
@@ -272,25 +272,53 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
   __shared__ uint32_t s_q[4][WAVE];
   const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const uint32_t t = ct * 64 + lane;
-  const float max_dist = sa_key_f32(*S.vis_max_key);
-  double cw = -1.0;      // column best inside this wave's 16 rows
-  uint32_t cq = SA_NONE;
-  for (uint32_t r = 0; r < 16; ++r) {
-    const uint32_t q = rt * 64 + wave * 16 + r;  // wave-uniform
-    if (q >= N) break;
-    double W = -1.0;
-    if (t < T) {
-      const float* v = S.vis + ((size_t)q * T + t) * K;
-      uint32_t cnt = 0;
-      double w = 0.0;
-      for (uint32_t k = 0; k < K; ++k) {
-        float x = v[k];
-        if (x == x) { ++cnt; w += (double)(max_dist - x); }
-      }
-      if (cnt >= 1 && cnt >= p.min_votes) W = w;
+  const uint32_t q0 = rt * 64 + wave * 16;
+  uint32_t mk = S.vis_max_key[lane & (SA_MAXKEY_SHARDS - 1)];
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t ok = __shfl_xor(mk, o);
+    mk = ok > mk ? ok : mk;
+  }
+  const float max_dist = sa_key_f32(mk);
+  // phase 1: the 16 group weights of this lane's column — all loads issued before any reduction
+  double Wr[16];
+  if (K == 1) {
+    float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t q = q0 + r;
+      x[r] = (q < N && t < T) ? S.vis[(size_t)q * T + t] : __builtin_nanf("");
     }
-    if (W > cw) { cw = W; cq = q; }  // q ascends: strict > keeps the lowest q
-    // row argmax over the 64 columns of the tile: (W desc, t asc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double w = 0.0 + (double)(max_dist - x[r]);  // the reference's sum starts from 0.0
+      Wr[r] = (x[r] == x[r] && 1u >= p.min_votes) ? w : -1.0;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t q = q0 + r;
+      double W = -1.0;
+      if (q < N && t < T) {
+        const float* v = S.vis + ((size_t)q * T + t) * K;
+        uint32_t cnt = 0;
+        double w = 0.0;
+        for (uint32_t k = 0; k < K; ++k) {
+          float xv = v[k];
+          if (xv == xv) { ++cnt; w += (double)(max_dist - xv); }
+        }
+        if (cnt >= 1 && cnt >= p.min_votes) W = w;
+      }
+      Wr[r] = W;
+    }
+  }
+  // phase 2: column best over the wave's 16 rows (q ascends: strict > keeps the lowest q) and row argmax
+  double cw = -1.0;
+  uint32_t cq = SA_NONE;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t q = q0 + r;  // wave-uniform
+    const double W = Wr[r];
+    if (W > cw) { cw = W; cq = q; }
     double bw = W;
     uint32_t bt = W >= 0.0 ? t : SA_NONE;
     for (int o = 32; o > 0; o >>= 1) {
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
       uint32_t ot = __shfl_xor(bt, o);
       if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
     }
-    if (lane == 0) {
+    if (lane == 0 && q < N) {
       S.row_part_w[(size_t)q * S.CT + ct] = bw;
       S.row_part_t[(size_t)q * S.CT + ct] = bw >= 0.0 ? (int32_t)bt : -1;
     }
@@ -319,27 +347,43 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
   }
 }
 
-__global__ void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
+// One wave per candidate: lanes fold the CT row partials, then the RT column partials of the winning column.
+__global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
   const SceneDev& S = scenes[blockIdx.z];
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
   double bw = -1.0;
-  int32_t bt = -1;
-  for (uint32_t ct = 0; ct < S.CT; ++ct) {
+  uint32_t bt = SA_NONE;
+  for (uint32_t ct = lane; ct < S.CT; ct += WAVE) {
     double w = S.row_part_w[(size_t)q * S.CT + ct];
-    if (w > bw) { bw = w; bt = S.row_part_t[(size_t)q * S.CT + ct]; }  // tiles ascend with t
+    int32_t tt = S.row_part_t[(size_t)q * S.CT + ct];
+    if (w > bw && tt >= 0) { bw = w; bt = (uint32_t)tt; }  // a lane's tiles ascend with t
   }
-  if (bt < 0) return;  // no group at all: the candidate goes to the positional vote
-  S.row_has[q] = 1;    // feature_winners.contains_key(q)
+  for (int o = 32; o > 0; o >>= 1) {
+    double ow = __shfl_xor(bw, o);
+    uint32_t ot = __shfl_xor(bt, o);
+    if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
+  }
+  if (bt == SA_NONE) return;  // no group at all: the candidate goes to the positional vote (wave-uniform)
   double cw = -1.0;
   uint32_t cq = SA_NONE;
-  for (uint32_t rt = 0; rt < S.RT; ++rt) {
+  for (uint32_t rt = lane; rt < S.RT; rt += WAVE) {
     double w = S.col_part_w[(size_t)rt * S.T + bt];
-    if (w > cw) { cw = w; cq = S.col_part_q[(size_t)rt * S.T + bt]; }  // tiles ascend with q
+    uint32_t qq = S.col_part_q[(size_t)rt * S.T + bt];
+    if (w > cw) { cw = w; cq = qq; }  // a lane's tiles ascend with q
   }
-  if (cq == q) {
-    S.vis_winner[q] = bt;
-    S.col_excluded[bt] = 1;
+  for (int o = 32; o > 0; o >>= 1) {
+    double ow = __shfl_xor(cw, o);
+    uint32_t oq = __shfl_xor(cq, o);
+    if (ow > cw || (ow == cw && oq < cq)) { cw = ow; cq = oq; }
+  }
+  if (lane == 0) {
+    S.row_has[q] = 1;  // feature_winners.contains_key(q)
+    if (cq == q) {
+      S.vis_winner[q] = (int32_t)bt;
+      S.col_excluded[bt] = 1;
+    }
   }
 }
 
@@ -439,15 +483,37 @@ __device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
   S.out_vote[q] = vt;
 }
 
-// One 1024-thread workgroup per scene: labels, row order inside components, solve, results.
+// One 1024-thread workgroup per scene: labels, row order inside components, solve, results.  The solver's
+// duals / matches / search scratch live in LDS (68 KB) whenever the scene has at most 1024 tracks: every step of
+// the shortest-path search is a chain of dependent accesses, ~10x cheaper in LDS than in L2.
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
   const SceneDev& S = scenes[blockIdx.z];
-  const uint32_t N = S.N;
+  const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
   __shared__ uint32_t s_key[SA_SMALL_N];  // (label << 10 | row), rows without edges sort to the end
+  __shared__ uint32_t s_next[SA_SMALL_N];
+  __shared__ int64_t s_u[SA_SMALL_N], s_rdist[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
+  __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
+  __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
   uint32_t lab = SA_NONE;
   if (q < N && S.e_cnt[q]) lab = sa_uf_find(S.parent, q);
+  s_rmatch[q] = -1;
+  if (!__syncthreads_or(lab != SA_NONE)) {  // nothing left for the positional vote (every row decided visually)
+    if (q < N) {
+      uint64_t id = 0;
+      uint8_t vt = SA_VOTE_NONE;
+      int32_t vw = S.vis_winner[q];
+      if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+      S.out_track_id[q] = id;
+      S.out_vote[q] = vt;
+    }
+    return;
+  }
+  const bool cols_in_lds = T <= SA_SMALL_N;
   s_key[q] = lab == SA_NONE ? 0xffffffffu : ((lab << 10) | q);
+  s_next[q] = SA_NONE;
+  s_u[q] = q < N ? S.u[q] : 0;
+  if (cols_in_lds) { s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0; }
   __syncthreads();
   // bitonic sort of 1024 keys (ascending): components become runs, rows ascending inside a run
   for (uint32_t k = 2; k <= SA_SMALL_N; k <<= 1) {
@@ -461,26 +527,39 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       __syncthreads();
     }
   }
-  // position q of the sorted array: link to the next row of the same component
-  {
+  {  // position q of the sorted array: link to the next row of the same component
     uint32_t key = s_key[q];
-    if (key != 0xffffffffu) {
-      uint32_t row = key & 1023u, l = key >> 10;
-      uint32_t nxt = SA_NONE;
-      if (q + 1 < SA_SMALL_N) {
-        uint32_t k2 = s_key[q + 1];
-        if (k2 != 0xffffffffu && (k2 >> 10) == l) nxt = k2 & 1023u;
-      }
-      S.next_row[row] = nxt;
+    if (key != 0xffffffffu && q + 1 < SA_SMALL_N) {
+      uint32_t k2 = s_key[q + 1];
+      if (k2 != 0xffffffffu && (k2 >> 10) == (key >> 10)) s_next[key & 1023u] = k2 & 1023u;
     }
   }
   __syncthreads();
   if (q < N && lab == q) {  // representative = minimum row of its component
-    sa_assign_ws w = make_ws(S);
+    sa_assign_ws w;
+    w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride;
+    w.next_row = s_next;
+    w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
+    if (cols_in_lds) {
+      w.v = s_v; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan; w.cnext = s_cnext;
+    } else {
+      w.v = S.v; w.cmatch = S.cmatch; w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
+    }
     sa_assign_component(w, q);
   }
   __syncthreads();
-  if (q < N) finalize_row(S, q);
+  if (q < N) {
+    uint64_t id = 0;
+    uint8_t vt = SA_VOTE_NONE;
+    int32_t vw = S.vis_winner[q];
+    if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+    else if (!S.row_has[q]) {
+      int32_t c = s_rmatch[q];
+      if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; }
+    }
+    S.out_track_id[q] = id;
+    S.out_vote[q] = vt;
+  }
 }
 
 __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
@@ -577,7 +656,7 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
                              hipStream_t st, int stage) {
   if (!maxN || !maxT) return hipSuccess;
   if (stage == 0) hipLaunchKernelGGL(k_bestfit_tile, dim3(cdiv(maxT, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
-  else hipLaunchKernelGGL(k_bestfit_resolve, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes);
+  else hipLaunchKernelGGL(k_bestfit_resolve, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
