@@ -91,21 +91,21 @@ SA_HD bool sa_compatible(const sa_geo& c, uint64_t ce, const sa_geo& t, uint64_t
 // ---- Sutherland–Hodgman + shoelace (clipping.rs:12-91, geo Area) ------------------------------------------
 #define SA_POLY_CAP 12
 // Clips the open ring `subj` (4 vertices) by the open ring `clip` (4 vertices); returns the unsigned area
-// of the result exactly as Polygon::new(...).unsigned_area() evaluates it.
-SA_HD double sa_clip_area(const double* subj, const double* clip) {
-  double ax[SA_POLY_CAP], ay[SA_POLY_CAP], bx[SA_POLY_CAP], by[SA_POLY_CAP];
+// of the result exactly as Polygon::new(...).unsigned_area() evaluates it.  The two ping-pong vertex lists live
+// in caller-provided storage (element v of a list at [v * stride]): on the GPU that is an LDS slice per worker
+// lane — dynamically indexed per-lane arrays would otherwise be spilled to scratch memory.
+SA_HD double sa_clip_area_ws(const double* subj, const double* clip, double* ax, double* ay, double* bx, double* by, int stride) {
   int n = 4;
-  for (int i = 0; i < 4; ++i) { ax[i] = subj[2 * i]; ay[i] = subj[2 * i + 1]; }
+  for (int i = 0; i < 4; ++i) { ax[i * stride] = subj[2 * i]; ay[i * stride] = subj[2 * i + 1]; }
   double* px = ax; double* py = ay; double* qx = bx; double* qy = by;
   for (int i = 0; i < 4; ++i) {
     int ii = i == 0 ? 3 : i - 1;
     double csx = clip[2 * ii], csy = clip[2 * ii + 1];
     double cex = clip[2 * i], cey = clip[2 * i + 1];
     int m = 0;
+    double ssx = n ? px[(n - 1) * stride] : 0.0, ssy = n ? py[(n - 1) * stride] : 0.0;  // s_edge_start of j = 0
     for (int j = 0; j < n; ++j) {
-      int ji = j == 0 ? n - 1 : j - 1;
-      double ssx = px[ji], ssy = py[ji];
-      double sex = px[j], sey = py[j];
+      double sex = px[j * stride], sey = py[j * stride];
       bool in_e = ((cex - csx) * (sey - csy) - (cey - csy) * (sex - csx)) <= 0.0;
       bool in_s = ((cex - csx) * (ssy - csy) - (cey - csy) * (ssx - csx)) <= 0.0;
       if (in_e != in_s) {
@@ -115,9 +115,10 @@ SA_HD double sa_clip_area(const double* subj, const double* clip) {
         double n1 = ssx * sey - ssy * sex;
         double n2 = csx * cey - csy * cex;
         double n3 = 1.0 / (dcx * dpy - dcy * dpx);
-        if (m < SA_POLY_CAP) { qx[m] = (n1 * dpx - n2 * dcx) * n3; qy[m] = (n1 * dpy - n2 * dcy) * n3; ++m; }
+        if (m < SA_POLY_CAP) { qx[m * stride] = (n1 * dpx - n2 * dcx) * n3; qy[m * stride] = (n1 * dpy - n2 * dcy) * n3; ++m; }
       }
-      if (in_e && m < SA_POLY_CAP) { qx[m] = sex; qy[m] = sey; ++m; }
+      if (in_e && m < SA_POLY_CAP) { qx[m * stride] = sex; qy[m * stride] = sey; ++m; }
+      ssx = sex; ssy = sey;
     }
     double* t = px; px = qx; qx = t;
     t = py; py = qy; qy = t;
@@ -125,22 +126,33 @@ SA_HD double sa_clip_area(const double* subj, const double* clip) {
   }
   if (n == 0) return 0.0;
   // Polygon::new closes the ring unless first == last; < 3 coordinates -> 0
-  bool closed = px[0] == px[n - 1] && py[0] == py[n - 1];
+  double shx = px[0], shy = py[0];
+  bool closed = shx == px[(n - 1) * stride] && shy == py[(n - 1) * stride];
   int m = closed ? n : n + 1;
   if (m < 3) return 0.0;
-  double shx = px[0], shy = py[0];
   double tmp = 0.0;
+  double x0 = 0.0, y0 = 0.0;  // ring[0] - shift
   for (int i = 0; i + 1 < m; ++i) {
     int i1 = (i + 1 == n) ? 0 : i + 1;  // the appended closing coordinate is ring[0]
-    double x0 = px[i] - shx, y0 = py[i] - shy;
-    double x1 = px[i1] - shx, y1 = py[i1] - shy;
+    double x1 = px[i1 * stride] - shx, y1 = py[i1 * stride] - shy;
     tmp = tmp + (x0 * y1 - y0 * x1);
+    x0 = x1; y0 = y1;
   }
   double area = tmp / (1.0 + 1.0);
   return fabs(area);
 }
+SA_HD double sa_clip_area(const double* subj, const double* clip) {
+  double ax[SA_POLY_CAP], ay[SA_POLY_CAP], bx[SA_POLY_CAP], by[SA_POLY_CAP];
+  return sa_clip_area_ws(subj, clip, ax, ay, bx, by, 1);
+}
 
 // Universal2DBox::calculate_metric_object (bbox.rs:512-535) for a pair that is not too_far.
+SA_HD bool sa_iou_from_area(double inter, float c_hha, float t_hha, float* out) {
+  if (inter == 0.0) return false;
+  double uni = (double)(c_hha + t_hha) - inter;
+  *out = (float)(inter / uni);
+  return true;
+}
 SA_HD bool sa_iou_cell(const double* cand_verts, const double* track_verts, float c_hha, float t_hha, float* out) {
   double inter = sa_clip_area(cand_verts, track_verts);
   if (inter == 0.0) return false;

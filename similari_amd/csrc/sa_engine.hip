@@ -54,8 +54,9 @@ struct Slot {  // one scene of the current batch
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
   DevBuf parent, label, next_row, e_cnt, e_col, e_gain, u, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
-  DevBuf out;  // ids[N] then votes[N]
-  HostBuf h_in, h_out;
+  HostBuf h_in;
+  HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
+  void* d_out = nullptr;  // device view of h_out
   bool ran = false;
 };
 
@@ -69,6 +70,8 @@ struct sa_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;  // side stream: the positional cost kernel runs beside the feature contraction
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t K = 1, D = 0, Dp = 0;
   bool visual = false;
   std::string err;
@@ -133,7 +136,7 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
   b.p = nullptr;
   b.cap = 0;
   size_t ncap = bytes < 4096 ? 4096 : bytes + bytes / 2;
-  hipError_t s = hipHostMalloc(&b.p, ncap, hipHostMallocDefault);
+  hipError_t s = hipHostMalloc(&b.p, ncap, hipHostMallocMapped | hipHostMallocCoherent);
   if (s != hipSuccess) return fail(e, SA_ERR_OOM, "hipHostMalloc(%zu) failed: %s", ncap, hipGetErrorString(s));
   b.cap = ncap;
   return SA_OK;
@@ -292,8 +295,11 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->cnext, t * 4));
   TRY(dev_ensure(e, s->rdist, n * 8));
   TRY(dev_ensure(e, s->rnext, n * 4));
-  TRY(dev_ensure(e, s->out, n * 9));
-  TRY(host_ensure(e, s->h_out, n * 9));
+  {
+    void* before = s->h_out.p;
+    TRY(host_ensure(e, s->h_out, n * 9));
+    if (s->h_out.p != before || !s->d_out) HIPCHK(e, hipHostGetDevicePointer(&s->d_out, s->h_out.p, 0));
+  }
   return SA_OK;
 }
 
@@ -325,7 +331,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->u = (int64_t*)s->u.p; d->v = (int64_t*)s->v.p; d->rmatch = (int32_t*)s->rmatch.p; d->cmatch = (int32_t*)s->cmatch.p;
   d->dist = (int64_t*)s->dist.p; d->pred = (int32_t*)s->pred.p; d->cstamp = (uint32_t*)s->cstamp.p; d->cscan = (uint32_t*)s->cscan.p;
   d->cnext = (int32_t*)s->cnext.p; d->rdist = (int64_t*)s->rdist.p; d->rnext = (int32_t*)s->rnext.p;
-  d->out_track_id = (uint64_t*)s->out.p; d->out_vote = (uint8_t*)s->out.p + (size_t)(s->N ? s->N : 1) * 8;
+  d->out_track_id = (uint64_t*)s->d_out; d->out_vote = (uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8;
   d->quant = (int64_t*)s->quant.p;
 }
 
@@ -365,12 +371,26 @@ int run_pipeline(sa_engine* e) {
   const SceneDev* ds = (const SceneDev*)e->d_scenes.p;
   hipStream_t st = e->stream;
   { ProfScope ps(e, KID_FRAME_PREP); HIPCHK(e, sa_launch_frame_prep(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
-  { ProfScope ps(e, KID_POSITIONAL); HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, st)); }
+  // The positional cost cells (f64 VALU) and the feature contraction (matrix cores) are independent until the
+  // positional vote: fork them onto two streams, join before k_assign_edges.
+  // Measured on MI355X / ROCm 7.2: the two cross-stream event waits cost more (~14 us) than the ~9 us of overlap
+  // they buy at C2, so the fork is opt-in (SA_FLAG_FORK).
+  const bool fork = (e->cfg.flags & SA_FLAG_FORK) && e->visual && !e->profile && e->stream2 && maxN && maxT;
+  if (fork) {
+    HIPCHK(e, hipEventRecord(e->ev_fork, st));
+    HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, e->stream2));
+    HIPCHK(e, hipEventRecord(e->ev_join, e->stream2));
+  } else {
+    ProfScope ps(e, KID_POSITIONAL);
+    HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, st));
+  }
   if (e->visual) {
     { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
     { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
     { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
   }
+  if (fork) HIPCHK(e, hipStreamWaitEvent(st, e->ev_join, 0));
   { ProfScope ps(e, KID_ASSIGN_EDGES); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 0)); }
   if (maxN <= SA_SMALL_N) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
@@ -380,14 +400,6 @@ int run_pipeline(sa_engine* e) {
     { ProfScope ps(e, KID_ASSIGN_NEXT); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 2)); }
     { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 3)); }
     { ProfScope ps(e, KID_FINALIZE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 4)); }
-  }
-  {
-    ProfScope ps(e, KID_D2H);
-    for (uint32_t i = 0; i < ns; ++i) {
-      Slot* s = e->slots[i];
-      if (!s->N) continue;
-      HIPCHK(e, hipMemcpyAsync(s->h_out.p, s->out.p, (size_t)s->N * 9, hipMemcpyDeviceToHost, st));
-    }
   }
   for (uint32_t i = 0; i < ns; ++i) e->slots[i]->ran = true;
   return SA_OK;
@@ -505,6 +517,11 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   }
   hipEventCreate(&e->ev_t0);
   hipEventCreate(&e->ev_t1);
+  if (e->visual) {
+    if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) e->stream2 = nullptr;
+    hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+  }
   *out = e;
   return SA_OK;
 }
@@ -535,7 +552,7 @@ void sa_engine_destroy(sa_engine* e) {
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                       &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
                       &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_col, &s->e_gain, &s->u, &s->v, &s->rmatch,
-                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->out})
+                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext})
       free_dev(*b);
     free_host(s->h_in);
     free_host(s->h_out);
@@ -550,6 +567,9 @@ void sa_engine_destroy(sa_engine* e) {
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
   if (e->ev_t0) hipEventDestroy(e->ev_t0);
   if (e->ev_t1) hipEventDestroy(e->ev_t1);
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
 }

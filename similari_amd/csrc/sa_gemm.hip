@@ -208,7 +208,7 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 
 template <int BM, int BN, int KG>
 __global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void euclid_mainloop(const float* __restrict__ A, con
 
 __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
   constexpr int BM = 64, BN = 64;
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;

@@ -110,7 +110,7 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restri
 //   * candidate feature padding + squared norms (one wave per row).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < SA_MAXKEY_SHARDS) S.vis_max_key[i] = sa_f32_key(-1.0f);  // BestFit max_dist starts at -1.0 (voting/best.rs:59)
@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
 // =====================================================================================================
 #define POS_TI 16
 #define POS_TJ 64
+#define POS_WORKERS 64
 __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = blockIdx.y * POS_TI, j0 = blockIdx.x * POS_TJ;
   if (i0 >= N || j0 >= T) return;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
   __shared__ uint64_t s_te[POS_TJ];
   __shared__ uint16_t s_list[POS_TI * POS_TJ];
   __shared__ uint32_t s_cnt;
+  __shared__ double s_poly[4 * SA_POLY_CAP * POS_WORKERS];  // 24 KB
   const uint32_t tid = threadIdx.x;
   if (tid < POS_TI) {
     uint32_t i = i0 + tid;
@@ -211,13 +213,11 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
   }
   __syncthreads();
   const uint32_t cnt = s_cnt;
-  for (uint32_t sidx = tid; sidx < cnt; sidx += 256) {
-    uint32_t c = s_list[sidx];
-    uint32_t li = c / POS_TJ, lj = c % POS_TJ;
-    uint32_t i = i0 + li, j = j0 + lj;
-    float conf = S.c_conf[i];
-    float out;
-    if (p.positional_kind == SA_POS_MAHALANOBIS) {
+  if (p.positional_kind == SA_POS_MAHALANOBIS) {
+    for (uint32_t sidx = tid; sidx < cnt; sidx += 256) {
+      uint32_t c = s_list[sidx];
+      uint32_t li = c / POS_TJ, lj = c % POS_TJ;
+      uint32_t i = i0 + li, j = j0 + lj;
       float m20[20], z5[5];
       const float* mp = S.t_maha + (size_t)j * 20;
 #pragma unroll
@@ -225,27 +225,35 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       const float* zp = S.c_z + (size_t)i * 5;
 #pragma unroll
       for (int k = 0; k < 5; ++k) z5[k] = zp[k];
-      out = sa_maha_cell(m20, z5, conf);
-    } else {
+      S.pos[(size_t)i * T + j] = sa_maha_cell(m20, z5, S.c_conf[i]);
+    }
+  } else if (tid < POS_WORKERS) {
+    // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS
+    double* ws = s_poly + tid;
+    for (uint32_t sidx = tid; sidx < cnt; sidx += POS_WORKERS) {
+      uint32_t c = s_list[sidx];
+      uint32_t li = c / POS_TJ, lj = c % POS_TJ;
+      uint32_t i = i0 + li, j = j0 + lj;
       double cv[8], tv[8];
       const double* cp = S.c_verts + (size_t)i * 8;
       const double* tp = S.t_verts + (size_t)j * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cv[k] = cp[k]; tv[k] = tp[k]; }
-      float iou;
-      out = nanv;
-      if (sa_iou_cell(cv, tv, s_cg[li].hha, s_tg[lj].hha, &iou)) {
-        float e = iou * conf;
+      double inter = sa_clip_area_ws(cv, tv, ws, ws + SA_POLY_CAP * POS_WORKERS, ws + 2 * SA_POLY_CAP * POS_WORKERS,
+                                     ws + 3 * SA_POLY_CAP * POS_WORKERS, POS_WORKERS);
+      float iou, out = nanv;
+      if (sa_iou_from_area(inter, s_cg[li].hha, s_tg[lj].hha, &iou)) {
+        float e = iou * S.c_conf[i];
         if (e >= p.positional_threshold) out = e;
       }
+      S.pos[(size_t)i * T + j] = out;
     }
-    S.pos[(size_t)i * T + j] = out;
   }
 }
 
 // Debug tap: (w * 1e6f) as i64 of every positional cell, 0 where absent (sort/voting.rs:59).
 __global__ void k_quant_tap(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   size_t n = (size_t)S.N * S.T;
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
     float w = S.pos[c];
@@ -264,7 +272,7 @@ __global__ void k_quant_tap(const SceneDev* __restrict__ scenes) {
 //                      the winning column, and decides; winners mark excluded_tracks (visual_sort/voting.rs:62-71).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T, K = S.K;
   const uint32_t ct = blockIdx.x, rt = blockIdx.y;
   if (ct >= S.CT || rt >= S.RT) return;
@@ -311,29 +319,43 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
       Wr[r] = W;
     }
   }
-  // phase 2: column best over the wave's 16 rows (q ascends: strict > keeps the lowest q) and row argmax
+  // phase 2a: column best over the wave's 16 rows (q ascends: strict > keeps the lowest q) — registers only;
+  // the weights also go to LDS, transposed use below
+  __shared__ double s_tile[64][65];  // [row][col], +1 padding
   double cw = -1.0;
   uint32_t cq = SA_NONE;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const uint32_t q = q0 + r;  // wave-uniform
     const double W = Wr[r];
-    if (W > cw) { cw = W; cq = q; }
-    double bw = W;
-    uint32_t bt = W >= 0.0 ? t : SA_NONE;
-    for (int o = 32; o > 0; o >>= 1) {
-      double ow = __shfl_xor(bw, o);
-      uint32_t ot = __shfl_xor(bt, o);
-      if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
-    }
-    if (lane == 0 && q < N) {
-      S.row_part_w[(size_t)q * S.CT + ct] = bw;
-      S.row_part_t[(size_t)q * S.CT + ct] = bw >= 0.0 ? (int32_t)bt : -1;
-    }
+    if (W > cw) { cw = W; cq = q0 + r; }
+    s_tile[wave * 16 + r][lane] = W;
   }
   s_w[wave][lane] = cw;
   s_q[wave][lane] = cq;
   __syncthreads();
+  // phase 2b: row argmax (W desc, t asc): 4 threads per row scan 16 columns each, then two shuffle steps
+  {
+    const uint32_t row = threadIdx.x >> 2, quarter = threadIdx.x & 3u;
+    double bw = -1.0;
+    uint32_t bt = SA_NONE;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t c = quarter * 16 + j;
+      const double W = s_tile[row][c];
+      if (W > bw) { bw = W; bt = ct * 64 + c; }  // columns ascend: strict > keeps the lowest t
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      double ow = __shfl_xor(bw, o);
+      uint32_t ot = __shfl_xor(bt, o);
+      if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
+    }
+    const uint32_t q = rt * 64 + row;
+    if (quarter == 0 && q < N) {
+      S.row_part_w[(size_t)q * S.CT + ct] = bw;
+      S.row_part_t[(size_t)q * S.CT + ct] = bw >= 0.0 ? (int32_t)bt : -1;
+    }
+  }
   if (wave == 0 && t < T) {
     double bw = s_w[0][lane];
     uint32_t bq = s_q[0][lane];
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
 
 // One wave per candidate: lanes fold the CT row partials, then the RT column partials of the winning column.
 __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 //            k_assign_solve (one thread per component), k_finalize.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
@@ -487,7 +509,7 @@ __device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
 // duals / matches / search scratch live in LDS (68 KB) whenever the scene has at most 1024 tracks: every step of
 // the shortest-path search is a chain of dependent accesses, ~10x cheaper in LDS than in L2.
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
   __shared__ uint32_t s_key[SA_SMALL_N];  // (label << 10 | row), rows without edges sort to the end
@@ -563,14 +585,14 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 }
 
 __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
   S.label[q] = S.e_cnt[q] ? sa_uf_find(S.parent, q) : SA_NONE;
 }
 
 __global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
@@ -587,7 +609,7 @@ __global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict_
 }
 
 __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
   if (S.label[q] != q) return;  // only the representative (minimum row) of a component works
@@ -596,7 +618,7 @@ __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
 }
 
 __global__ void k_finalize(const SceneDev* __restrict__ scenes) {
-  const SceneDev& S = scenes[blockIdx.z];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
   finalize_row(S, q);

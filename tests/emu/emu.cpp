@@ -53,7 +53,10 @@ int emu_positional_cell(const sa_config* cfg, const sa_box* cand, uint64_t cand_
     return 1;
   }
   float iou;
-  if (!sa_iou_cell(cv, tv, cg.hha, tg.hha, &iou)) return 0;
+  double ws[4 * SA_POLY_CAP * 3];  // element v of list k at ws[k * 36 + v * 3]: the strided layout the kernel uses in LDS
+  double inter = sa_clip_area_ws(cv, tv, ws, ws + 36, ws + 72, ws + 108, 3);
+  if (inter != sa_clip_area(cv, tv)) return -1;
+  if (!sa_iou_from_area(inter, cg.hha, tg.hha, &iou)) return 0;
   float e = iou * conf;
   if (!(e >= cfg->positional_threshold)) return 0;
   *out = e;
