@@ -1,0 +1,120 @@
+/*
+ * similari_tracker.h — C ABI of the tracker facade that sits on top of the association engine.
+ *
+ * It preserves the reference's public tracker surface for the accelerated path, so that examples, benches and
+ * tests written against it translate 1:1:
+ *
+ *   Sort::new / predict / predict_with_scene / idle_tracks_with_scene        src/trackers/sort/simple_api.rs:41-215
+ *   BatchSort::new / predict(PredictionBatchRequest)                         src/trackers/sort/batch_api.rs:157-290
+ *   VisualSort::new / predict / predict_with_scene                           src/trackers/visual_sort/simple_api.rs:45-230
+ *   BatchVisualSort::new / predict                                           src/trackers/visual_sort/batch_api.rs:161-317
+ *   TrackerAPI::{skip_epochs_for_scene, current_epoch_with_scene, wasted, clear_wasted, active_shard_stats}
+ *                                                                            src/trackers/tracker_api.rs:9-118
+ *
+ * What runs where: the per-frame N x T cost matrices and the assignment run on the GPU through
+ * similari_assoc.h (sa_associate_batch).  The O(N) upkeep either side of it — epoch counters, Kalman
+ * predict/update of the merged tracks (kalman_prediction.rs:13-32), history deques, the feature-bank policy
+ * (visual_sort/metric.rs:129-154, 297-374), track ids, wasted-track lifecycle — stays on the host exactly as the
+ * reference keeps it on the host; SURVEY §8(f) lists moving it to the device as the next step.
+ *
+ * Not provided (out of scope): exclusively_owned_areas.  A caller that uses the own-area
+ * thresholds supplies the per-detection share in sa_observation.own_area (NaN = None).
+ */
+#ifndef SIMILARI_TRACKER_H
+#define SIMILARI_TRACKER_H
+
+#include "similari_assoc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SortTrack  src/trackers/sort.rs:286-311 */
+typedef struct sa_sort_track {
+  uint64_t id;
+  uint64_t epoch;
+  sa_box predicted_bbox;
+  sa_box observed_bbox;
+  uint64_t scene_id;
+  uint64_t length;
+  int32_t voting_type;           /* sa_voting_type: SA_VOTE_VISUAL / SA_VOTE_POSITIONAL */
+  int32_t has_custom_object_id;  /* Option<i64>::is_some */
+  int64_t custom_object_id;
+} sa_sort_track;
+
+/* VisualSortObservation  src/trackers/visual_sort.rs:34-56  (plain SORT uses bbox + custom id only) */
+typedef struct sa_observation {
+  sa_box bbox;
+  const float* feature;          /* feature_len floats or NULL (Option<&[f32]>) */
+  float feature_quality;         /* NaN = None -> 1.0 (visual_sort/simple_api.rs:146) */
+  float own_area;                /* NaN = None */
+  int32_t has_custom_object_id;
+  int32_t reserved;
+  int64_t custom_object_id;
+} sa_observation;
+
+/* Sort::new arguments / VisualSortOptions (+ VisualMetricBuilder) in one POD. */
+typedef struct sa_tracker_options {
+  uint32_t struct_size;
+  int32_t device;                       /* HIP device ordinal, -1 = current */
+  int32_t visual;                       /* 0 = Sort / BatchSort, 1 = VisualSort / BatchVisualSort */
+  int32_t batch_ids;                    /* 1 = Batch* id policy: a track id is drawn per candidate even when it merges
+                                           (sort/batch_api.rs:102-106) */
+  uint32_t history_length;              /* bbox_history / kept_history_length, must be > 0 */
+  uint32_t auto_waste_periodicity;      /* DEFAULT_AUTO_WASTE_PERIODICITY = 100 (sort.rs:378) */
+  uint64_t max_idle_epochs;
+  int32_t positional_kind;              /* sa_positional_kind */
+  float positional_threshold;           /* IoU(t) */
+  float positional_min_confidence;      /* Sort: min_confidence ; VisualSort: positional_min_confidence (0.1) */
+  uint32_t n_constraints;
+  const uint64_t* constraint_epoch_delta;
+  const float* constraint_max_dist;
+  float kalman_position_weight;
+  float kalman_velocity_weight;
+  /* VisualSort only */
+  int32_t visual_kind;                  /* sa_visual_kind */
+  float visual_threshold;
+  uint32_t feature_len;
+  uint32_t visual_max_observations;
+  uint32_t visual_min_votes;
+  uint32_t visual_minimal_track_length;
+  float visual_minimal_area;
+  float visual_minimal_quality_use;
+  float visual_minimal_quality_collect;
+  float visual_minimal_own_area_percentage_use;
+  float visual_minimal_own_area_percentage_collect;
+} sa_tracker_options;
+
+typedef struct sa_tracker sa_tracker;
+
+/* Defaults of Sort (visual = 0: IoU(0.3), min_confidence 0.05) or of VisualSortOptions/VisualMetricBuilder
+ * (visual = 1: Euclidean(f32::MAX), IoU(0.3), minimal track length 3, 5 observations, 1 vote, max_idle_epochs 2,
+ * history 10, positional_min_confidence 0.1). */
+void sa_tracker_options_default(sa_tracker_options* o, int visual);
+int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out);
+void sa_tracker_destroy(sa_tracker* t);
+const char* sa_tracker_last_error(const sa_tracker* t);
+
+/* predict_with_scene: out[n] in candidate order. */
+int sa_tracker_predict(sa_tracker* t, uint64_t scene_id, uint32_t n, const sa_observation* obs, sa_sort_track* out);
+/* Batch*::predict: scenes are processed in request order; every scene goes through ONE set of kernel launches. */
+int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                             const sa_observation* const* obs, sa_sort_track* const* out);
+
+int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
+int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n);
+int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out);
+/* wasted(): runs auto_waste, then drains the wasted store into out (cap entries at most; *out_n = total). */
+int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
+int sa_tracker_clear_wasted(sa_tracker* t);
+int sa_tracker_active_tracks(sa_tracker* t, uint64_t* out_n); /* sum of active_shard_stats() */
+/* Kalman state of a stored track (debug / parity): mean[10], cov[100] row-major. */
+int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, float* cov100);
+/* {visual_features_collected_count, stored observations, observed_boxes.len(), track_length} of a stored track. */
+int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]);
+sa_engine* sa_tracker_engine(sa_tracker* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMILARI_TRACKER_H */

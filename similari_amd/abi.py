@@ -128,6 +128,63 @@ class sa_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
+class sa_sort_track(C.Structure):
+    _fields_ = [
+        ("id", C.c_uint64),
+        ("epoch", C.c_uint64),
+        ("predicted_bbox", sa_box),
+        ("observed_bbox", sa_box),
+        ("scene_id", C.c_uint64),
+        ("length", C.c_uint64),
+        ("voting_type", C.c_int32),
+        ("has_custom_object_id", C.c_int32),
+        ("custom_object_id", C.c_int64),
+    ]
+
+
+class sa_observation(C.Structure):
+    _fields_ = [
+        ("bbox", sa_box),
+        ("feature", C.POINTER(C.c_float)),
+        ("feature_quality", C.c_float),
+        ("own_area", C.c_float),
+        ("has_custom_object_id", C.c_int32),
+        ("reserved", C.c_int32),
+        ("custom_object_id", C.c_int64),
+    ]
+
+
+class sa_tracker_options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("visual", C.c_int32),
+        ("batch_ids", C.c_int32),
+        ("history_length", C.c_uint32),
+        ("auto_waste_periodicity", C.c_uint32),
+        ("max_idle_epochs", C.c_uint64),
+        ("positional_kind", C.c_int32),
+        ("positional_threshold", C.c_float),
+        ("positional_min_confidence", C.c_float),
+        ("n_constraints", C.c_uint32),
+        ("constraint_epoch_delta", C.POINTER(C.c_uint64)),
+        ("constraint_max_dist", C.POINTER(C.c_float)),
+        ("kalman_position_weight", C.c_float),
+        ("kalman_velocity_weight", C.c_float),
+        ("visual_kind", C.c_int32),
+        ("visual_threshold", C.c_float),
+        ("feature_len", C.c_uint32),
+        ("visual_max_observations", C.c_uint32),
+        ("visual_min_votes", C.c_uint32),
+        ("visual_minimal_track_length", C.c_uint32),
+        ("visual_minimal_area", C.c_float),
+        ("visual_minimal_quality_use", C.c_float),
+        ("visual_minimal_quality_collect", C.c_float),
+        ("visual_minimal_own_area_percentage_use", C.c_float),
+        ("visual_minimal_own_area_percentage_collect", C.c_float),
+    ]
+
+
 def _ptr(arr, ctype):
     if arr is None:
         return C.cast(None, C.POINTER(ctype))
@@ -293,6 +350,22 @@ PROTOTYPES = {
         C.c_int,
         [ENGINE, i32, u32, u32, u32, P(C.c_float), P(C.c_float), P(C.c_float), u32, f64p],
     ),
+    # include/similari_tracker.h
+    "sa_tracker_options_default": (None, [P(sa_tracker_options), C.c_int]),
+    "sa_tracker_create": (C.c_int, [P(sa_tracker_options), P(C.c_void_p)]),
+    "sa_tracker_destroy": (None, [C.c_void_p]),
+    "sa_tracker_last_error": (C.c_char_p, [C.c_void_p]),
+    "sa_tracker_predict": (C.c_int, [C.c_void_p, u64, u32, P(sa_observation), P(sa_sort_track)]),
+    "sa_tracker_predict_batch": (C.c_int, [C.c_void_p, u32, P(u64), P(u32), P(P(sa_observation)), P(P(sa_sort_track))]),
+    "sa_tracker_idle_tracks": (C.c_int, [C.c_void_p, u64, P(sa_sort_track), u32, P(u32)]),
+    "sa_tracker_skip_epochs": (C.c_int, [C.c_void_p, u64, u64]),
+    "sa_tracker_current_epoch": (C.c_int, [C.c_void_p, u64, P(u64)]),
+    "sa_tracker_wasted": (C.c_int, [C.c_void_p, P(sa_sort_track), u32, P(u32)]),
+    "sa_tracker_clear_wasted": (C.c_int, [C.c_void_p]),
+    "sa_tracker_active_tracks": (C.c_int, [C.c_void_p, P(u64)]),
+    "sa_tracker_track_state": (C.c_int, [C.c_void_p, u64, P(C.c_float), P(C.c_float)]),
+    "sa_tracker_track_info": (C.c_int, [C.c_void_p, u64, P(u64)]),
+    "sa_tracker_engine": (C.c_void_p, [C.c_void_p]),
 }
 
 

@@ -1,0 +1,592 @@
+// sa_tracker.cpp — host facade with the reference's tracker surface (include/similari_tracker.h) on top of the
+// association engine.  Association (cost matrices + votes) = sa_associate_batch on the GPU; everything in this
+// file is the O(N) bookkeeping the reference also does on the host around that call:
+//   Sort::predict_with_scene          src/trackers/sort/simple_api.rs:110-196
+//   VisualSort::predict_with_scene    src/trackers/visual_sort/simple_api.rs:99-230
+//   Batch*::predict / voting_thread   src/trackers/sort/batch_api.rs:68-153,222-290
+//   SortMetric / VisualMetric::optimize (Kalman step, history, feature bank)   sort/metric.rs:79-105,
+//                                     visual_sort/metric.rs:129-154,297-374
+//   TrackerAPI (epochs, waste)        src/trackers/tracker_api.rs, epoch_db.rs
+// The Kalman step is written against the filter's structure (motion = I + shift, update matrix = [I 0]); skipping
+// the multiplications by the constant 0/1 entries leaves every f32 result unchanged (kalman_2d_box.rs:58-148).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/similari_tracker.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct KF {
+  float mean[10];
+  float cov[100];
+};
+
+inline float opt_angle(const sa_box& b) { return b.has_angle ? b.angle : 0.0f; }
+
+void std_diag(float w, float k, float cnst, float p, float* out5) {  // std_position / std_velocity, squared later
+  float v = k * w * p;
+  out5[0] = v; out5[1] = v; out5[2] = v; out5[3] = cnst; out5[4] = v;
+}
+
+void kf_initiate(float pw, float vw, const sa_box& b, KF& s) {  // kalman_2d_box.rs:58-83
+  s.mean[0] = b.xc; s.mean[1] = b.yc; s.mean[2] = opt_angle(b); s.mean[3] = b.aspect; s.mean[4] = b.height;
+  for (int i = 5; i < 10; ++i) s.mean[i] = 0.0f;
+  float sd[10];
+  std_diag(pw, 2.0f, 1e-2f, b.height, sd);
+  std_diag(vw, 10.0f, 1e-5f, b.height, sd + 5);
+  std::memset(s.cov, 0, sizeof s.cov);
+  for (int i = 0; i < 10; ++i) s.cov[i * 10 + i] = sd[i] * sd[i];
+}
+
+void kf_predict(float pw, float vw, KF& s) {  // kalman_2d_box.rs:87-102
+  float sd[10];
+  std_diag(pw, 1.0f, 1e-2f, s.mean[4], sd);
+  std_diag(vw, 1.0f, 1e-5f, s.mean[4], sd + 5);
+  for (int i = 0; i < 5; ++i) s.mean[i] = s.mean[i] + s.mean[i + 5];
+  float mc[100];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j) mc[i * 10 + j] = i < 5 ? s.cov[i * 10 + j] + s.cov[(i + 5) * 10 + j] : s.cov[i * 10 + j];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j) {
+      float v = j < 5 ? mc[i * 10 + j] + mc[i * 10 + j + 5] : mc[i * 10 + j];
+      s.cov[i * 10 + j] = v + (i == j ? sd[i] * sd[i] : 0.0f);
+    }
+}
+
+void kf_update(float pw, KF& s, const sa_box& z) {  // kalman_2d_box.rs:122-148
+  float sd[5];
+  std_diag(pw, 1.0f, 1e-1f, s.mean[4], sd);
+  float P[25];
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) P[i * 5 + j] = s.cov[i * 10 + j] + (i == j ? sd[i] * sd[i] : 0.0f);
+  // kalman_gain = projected_cov.solve_lower_triangular(B), B[r][c] = cov[c][r]: the UN-factorised covariance is
+  // used as the triangular matrix — the reference's formula, kept as is
+  float G[50];
+  for (int r = 0; r < 5; ++r)
+    for (int c = 0; c < 10; ++c) G[r * 10 + c] = s.cov[c * 10 + r];
+  for (int c = 0; c < 10; ++c)
+    for (int i = 0; i < 5; ++i) {
+      float coeff = G[i * 10 + c] / P[i * 5 + i];
+      G[i * 10 + c] = coeff;
+      float nc = -coeff;
+      for (int r = i + 1; r < 5; ++r) G[r * 10 + c] = nc * P[r * 5 + i] + G[r * 10 + c];
+    }
+  float innov[5] = {z.xc - s.mean[0], z.yc - s.mean[1], opt_angle(z) - s.mean[2], z.aspect - s.mean[3], z.height - s.mean[4]};
+  float nm[10];
+  for (int c = 0; c < 10; ++c) {
+    float acc = innov[0] * G[c];
+    for (int r = 1; r < 5; ++r) acc = innov[r] * G[r * 10 + c] + acc;
+    nm[c] = s.mean[c] + acc;
+  }
+  float gtp[50];  // 10 x 5
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 5; ++j) {
+      float acc = G[i] * P[j];
+      for (int k = 1; k < 5; ++k) acc = G[k * 10 + i] * P[k * 5 + j] + acc;
+      gtp[i * 5 + j] = acc;
+    }
+  float nc[100];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j) {
+      float acc = gtp[i * 5] * G[j];
+      for (int k = 1; k < 5; ++k) acc = gtp[i * 5 + k] * G[k * 10 + j] + acc;
+      nc[i * 10 + j] = s.cov[i * 10 + j] - acc;
+    }
+  std::memcpy(s.mean, nm, sizeof nm);
+  std::memcpy(s.cov, nc, sizeof nc);
+}
+
+sa_box state_box(const KF& s) {  // TryFrom<KalmanState> for Universal2DBox  kalman.rs:72-92
+  sa_box b;
+  std::memset(&b, 0, sizeof b);
+  b.xc = s.mean[0]; b.yc = s.mean[1];
+  b.has_angle = s.mean[2] == 0.0f ? 0 : 1;
+  b.angle = s.mean[2];
+  b.aspect = s.mean[3]; b.height = s.mean[4];
+  b.confidence = 1.0f;
+  return b;
+}
+
+// make_prediction  kalman_prediction.rs:13-32
+sa_box make_prediction(float pw, float vw, bool& has_state, KF& s, const sa_box& obs) {
+  if (!has_state) { kf_initiate(pw, vw, obs, s); has_state = true; }
+  kf_predict(pw, vw, s);
+  kf_update(pw, s, obs);
+  sa_box r = state_box(s);
+  r.confidence = obs.confidence;
+  return r;
+}
+
+struct Obs {  // one stored observation of a VisualSORT track; index 0 carries the bbox
+  float quality = 1.0f;
+  bool has_own = false;
+  float own = 0.0f;
+  bool has_feat = false;
+  std::vector<float> feat;
+};
+
+struct Track {
+  uint64_t id = 0, scene = 0, epoch = 0, length = 0;
+  bool has_custom = false;
+  int64_t custom = 0;
+  int32_t voting = -1;  // VisualAttributes::voting_type: None
+  bool has_state = false;
+  KF kf;
+  std::deque<sa_box> predicted, observed;
+  std::vector<Obs> obs;
+  uint32_t feat_count = 0;
+};
+
+}  // namespace
+
+struct sa_tracker {
+  sa_tracker_options o{};
+  std::vector<uint64_t> cons_delta;
+  std::vector<float> cons_dist;
+  sa_engine* eng = nullptr;
+  std::string err;
+  uint64_t track_id = 0;
+  std::map<uint64_t, uint64_t> epochs;            // scene -> current epoch
+  std::unordered_map<uint64_t, Track> store;      // main store
+  std::map<uint64_t, std::vector<uint64_t>> by_scene;  // scene -> ids (ascending)
+  std::vector<Track> wasted_store;
+  uint32_t waste_counter = 0;
+};
+
+namespace {
+
+int tfail(sa_tracker* t, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (t) t->err = buf;
+  else g_err = buf;
+  return code;
+}
+
+bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, float min_q, bool has_own, float own, float min_own) {
+  bool quality_ok = q >= min_q;                       // visual_sort/metric.rs:227-249
+  bool perc_ok = has_own ? own >= min_own : true;
+  float w = b.height * b.aspect;
+  bool bbox_ok = w * b.height >= o.visual_minimal_area;
+  return bbox_ok && quality_ok && perc_ok;
+}
+
+void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
+  tr.length += 1;                                     // sort.rs:160-176, track_attributes.rs:60-78
+  tr.observed.push_back(observed);
+  tr.predicted.push_back(predicted);
+  if (o.history_length > 0 && tr.observed.size() > o.history_length) {
+    tr.observed.pop_front();
+    tr.predicted.pop_front();
+  }
+}
+
+sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
+  sa_sort_track s;
+  std::memset(&s, 0, sizeof s);
+  s.id = tr.id;
+  s.epoch = tr.epoch;
+  s.predicted_bbox = tr.predicted.back();
+  s.observed_bbox = tr.observed.back();
+  s.scene_id = tr.scene;
+  s.length = tr.length;
+  // Sort: always Positional (sort/simple_api.rs:260) ; VisualSort: attrs.voting_type.unwrap_or(Positional)
+  s.voting_type = (o.visual && tr.voting >= 0) ? tr.voting : SA_VOTE_POSITIONAL;
+  s.has_custom_object_id = tr.has_custom ? 1 : 0;
+  s.custom_object_id = tr.custom;
+  return s;
+}
+
+uint64_t current_epoch(sa_tracker* t, uint64_t scene) {
+  auto it = t->epochs.find(scene);
+  return it == t->epochs.end() ? 0 : it->second;
+}
+
+// get_main_store_wasted + auto_waste  tracker_api.rs:68-88 ; baked(): epoch_db.rs:52-66
+int auto_waste(sa_tracker* t) {
+  std::map<uint64_t, std::vector<uint64_t>> gone;
+  for (auto& kv : t->store) {
+    const Track& tr = kv.second;
+    if (tr.epoch + t->o.max_idle_epochs < current_epoch(t, tr.scene)) gone[tr.scene].push_back(tr.id);
+  }
+  for (auto& kv : gone) {
+    std::sort(kv.second.begin(), kv.second.end());
+    int rc = sa_tracks_remove(t->eng, kv.first, (uint32_t)kv.second.size(), kv.second.data());
+    if (rc != SA_OK) return tfail(t, rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
+    auto& ids = t->by_scene[kv.first];
+    for (uint64_t id : kv.second) {
+      t->wasted_store.push_back(std::move(t->store[id]));
+      t->store.erase(id);
+      ids.erase(std::find(ids.begin(), ids.end(), id));
+    }
+  }
+  return SA_OK;
+}
+
+// Pushes the rows of `ids` (tracks of one scene that were created or merged this frame) to the engine.
+int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids) {
+  if (ids.empty()) return SA_OK;
+  const uint32_t n = (uint32_t)ids.size(), K = t->o.visual ? t->o.visual_max_observations : 1, D = t->o.feature_len;
+  std::vector<sa_box> boxes(n);
+  std::vector<uint64_t> epochs(n);
+  std::vector<float> mean(n * 5), cov(n * 25), feats;
+  std::vector<uint8_t> present;
+  if (t->o.visual) { feats.assign((size_t)n * K * D, 0.0f); present.assign((size_t)n * K, 0); }
+  for (uint32_t i = 0; i < n; ++i) {
+    const Track& tr = t->store[ids[i]];
+    boxes[i] = tr.predicted.back();
+    epochs[i] = tr.epoch;
+    for (int a = 0; a < 5; ++a) {
+      mean[i * 5 + a] = tr.kf.mean[a];
+      for (int b = 0; b < 5; ++b) cov[i * 25 + a * 5 + b] = tr.kf.cov[a * 10 + b];
+    }
+    if (t->o.visual)
+      for (uint32_t k = 0; k < tr.obs.size() && k < K; ++k)
+        if (tr.obs[k].has_feat) {
+          present[(size_t)i * K + k] = 1;
+          std::memcpy(&feats[((size_t)i * K + k) * D], tr.obs[k].feat.data(), (size_t)D * 4);
+        }
+  }
+  sa_tracks st;
+  std::memset(&st, 0, sizeof st);
+  st.n = n; st.ids = ids.data(); st.boxes = boxes.data(); st.epochs = epochs.data();
+  st.kf_mean = mean.data(); st.kf_cov = cov.data();
+  if (t->o.visual) { st.feats = feats.data(); st.feat_present = present.data(); }
+  int rc = sa_tracks_upsert(t->eng, scene, &st);
+  if (rc != SA_OK) return tfail(t, rc, "sa_tracks_upsert: %s", sa_last_error(t->eng));
+  return SA_OK;
+}
+
+struct Cand {  // the throw-away candidate track of one detection (simple_api.rs:125-145)
+  sa_box raw;      // detection as passed
+  sa_box box;      // after its own Kalman no-op step: angle 0.0 -> None, confidence kept
+  KF kf;
+  Obs obs;
+  bool has_custom;
+  int64_t custom;
+};
+
+int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                   const sa_observation* const* obs, sa_sort_track* const* out) {
+  const sa_tracker_options& o = t->o;
+  const float pw = o.kalman_position_weight, vw = o.kalman_velocity_weight;
+  const uint32_t D = o.feature_len;
+  for (uint32_t s = 0; s < n_scenes; ++s)
+    for (uint32_t s2 = 0; s2 < s; ++s2)
+      if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
+  // auto waste (simple_api.rs:115-120)
+  if (t->waste_counter == 0) {
+    int rc = auto_waste(t);
+    if (rc != SA_OK) return rc;
+    t->waste_counter = o.auto_waste_periodicity;
+  } else t->waste_counter -= 1;
+
+  std::vector<std::vector<Cand>> cands(n_scenes);
+  std::vector<uint64_t> epoch(n_scenes);
+  std::vector<sa_scene_request> req(n_scenes);
+  std::vector<sa_scene_result> res(n_scenes);
+  std::vector<std::vector<sa_box>> cboxes(n_scenes);
+  std::vector<std::vector<float>> cfeat(n_scenes), cq(n_scenes), cown(n_scenes);
+  std::vector<std::vector<uint8_t>> cpres(n_scenes), votes(n_scenes);
+  std::vector<std::vector<uint64_t>> winners(n_scenes);
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    const uint32_t n = counts[s];
+    epoch[s] = ++t->epochs[scene_ids[s]];  // next_epoch  epoch_db.rs:35-49
+    auto& cs = cands[s];
+    cs.resize(n);
+    cboxes[s].resize(n);
+    if (o.visual) { cfeat[s].assign((size_t)n * D, 0.0f); cq[s].resize(n); cown[s].resize(n); cpres[s].resize(n); }
+    for (uint32_t i = 0; i < n; ++i) {
+      const sa_observation& ob = obs[s][i];
+      if (!(ob.bbox.aspect > 0.0f) || !(ob.bbox.height > 0.0f) || !(ob.bbox.confidence >= 0.0f && ob.bbox.confidence <= 1.0f))
+        return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
+      Cand& c = cs[i];
+      c.raw = ob.bbox;
+      bool hs = false;
+      c.box = make_prediction(pw, vw, hs, c.kf, ob.bbox);
+      c.has_custom = ob.has_custom_object_id != 0;
+      c.custom = ob.custom_object_id;
+      c.obs.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
+      c.obs.has_own = ob.own_area == ob.own_area;
+      c.obs.own = c.obs.has_own ? ob.own_area : 0.0f;
+      c.obs.has_feat = o.visual && ob.feature != nullptr;
+      if (c.obs.has_feat) c.obs.feat.assign(ob.feature, ob.feature + D);
+      cboxes[s][i] = c.box;
+      if (o.visual) {
+        cq[s][i] = c.obs.quality;
+        cown[s][i] = c.obs.has_own ? c.obs.own : NAN;
+        cpres[s][i] = c.obs.has_feat ? 1 : 0;
+        if (c.obs.has_feat) std::memcpy(&cfeat[s][(size_t)i * D], ob.feature, (size_t)D * 4);
+      }
+    }
+    winners[s].assign(n, 0);
+    votes[s].assign(n, 0);
+    sa_scene_request& r = req[s];
+    std::memset(&r, 0, sizeof r);
+    r.scene_id = scene_ids[s];
+    r.epoch = epoch[s];
+    r.detections.n = n;
+    r.detections.boxes = cboxes[s].data();
+    if (o.visual) {
+      r.detections.feats = cfeat[s].data();
+      r.detections.feat_present = cpres[s].data();
+      r.detections.feat_quality = cq[s].data();
+      r.detections.own_area = cown[s].data();
+    }
+    res[s].out_track_id = winners[s].data();
+    res[s].out_voting_type = votes[s].data();
+  }
+  // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
+  int rc = sa_associate_batch(t->eng, n_scenes, req.data(), res.data());
+  if (rc != SA_OK) return tfail(t, rc, "sa_associate_batch: %s", sa_last_error(t->eng));
+
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    const uint64_t scene = scene_ids[s];
+    std::vector<uint64_t> touched;
+    for (uint32_t i = 0; i < counts[s]; ++i) {
+      Cand& c = cands[s][i];
+      uint64_t dest = winners[s][i];
+      uint64_t drawn = 0;
+      if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
+      uint64_t tid;
+      if (dest == 0) {
+        // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
+        tid = o.batch_ids ? drawn : ++t->track_id;
+        Track tr;
+        tr.id = tid; tr.scene = scene; tr.epoch = epoch[s];
+        tr.has_custom = c.has_custom; tr.custom = c.custom;
+        tr.has_state = true; tr.kf = c.kf;
+        tr.length = 0;
+        update_history(o, tr, c.raw, c.box);
+        if (o.visual) {
+          tr.obs.push_back(c.obs);                     // is_merge = false: the feature is kept as is
+          tr.feat_count = c.obs.has_feat ? 1 : 0;
+        }
+        t->store[tid] = std::move(tr);
+        t->by_scene[scene].push_back(tid);
+      } else {
+        tid = dest;
+        auto it = t->store.find(dest);
+        if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
+        Track& tr = it->second;
+        // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215
+        tr.epoch = epoch[s];
+        tr.has_custom = c.has_custom; tr.custom = c.custom;
+        if (o.visual) tr.voting = votes[s][i];
+        // optimize(is_merge = true): Kalman predict + update with the candidate's box, history
+        sa_box predicted = make_prediction(pw, vw, tr.has_state, tr.kf, c.box);
+        update_history(o, tr, c.box, predicted);
+        if (o.visual) {
+          Obs nw = c.obs;
+          if (!feature_can_be_used(o, c.box, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
+                                   o.visual_minimal_own_area_percentage_collect)) {
+            nw.has_feat = false;
+            nw.feat.clear();
+          }
+          // optimize_observations  visual_sort/metric.rs:129-154
+          std::vector<Obs> kept;
+          for (auto& ob : tr.obs) if (ob.has_feat) kept.push_back(std::move(ob));
+          std::stable_sort(kept.begin(), kept.end(), [](const Obs& a, const Obs& b) { return a.quality > b.quality; });
+          if (kept.size() >= o.visual_max_observations && !kept.empty()) kept.pop_back();
+          kept.push_back(std::move(nw));
+          std::swap(kept.front(), kept.back());
+          tr.obs = std::move(kept);
+          tr.feat_count = 0;
+          for (auto& ob : tr.obs) tr.feat_count += ob.has_feat ? 1u : 0u;
+        }
+      }
+      touched.push_back(tid);
+      out[s][i] = to_sort_track(o, t->store[tid]);
+    }
+    rc = sync_engine(t, scene, touched);
+    if (rc != SA_OK) return rc;
+  }
+  return SA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sa_tracker_options_default(sa_tracker_options* o, int visual) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->struct_size = sizeof *o;
+  o->device = -1;
+  o->visual = visual ? 1 : 0;
+  o->auto_waste_periodicity = 100;
+  o->positional_kind = SA_POS_IOU;
+  o->positional_threshold = 0.3f;
+  o->kalman_position_weight = 1.0f / 20.0f;
+  o->kalman_velocity_weight = 1.0f / 160.0f;
+  if (!visual) {
+    o->history_length = 1;
+    o->max_idle_epochs = 5;
+    o->positional_min_confidence = 0.05f;
+  } else {
+    o->history_length = 10;                 // VisualSortOptions::default  options.rs:194-205
+    o->max_idle_epochs = 2;
+    o->positional_min_confidence = 0.1f;    // VisualMetricBuilder::default  metric/builder.rs:26-42
+    o->visual_kind = SA_VIS_EUCLIDEAN;
+    o->visual_threshold = 3.4028234663852886e38f;
+    o->visual_max_observations = 5;
+    o->visual_min_votes = 1;
+    o->visual_minimal_track_length = 3;
+  }
+}
+
+const char* sa_tracker_last_error(const sa_tracker* t) { return t ? t->err.c_str() : g_err.c_str(); }
+sa_engine* sa_tracker_engine(sa_tracker* t) { return t ? t->eng : nullptr; }
+
+int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
+  if (!o || !out) return tfail(nullptr, SA_ERR_BAD_ARG, "sa_tracker_create: null argument");
+  *out = nullptr;
+  if (o->struct_size != sizeof(sa_tracker_options)) return tfail(nullptr, SA_ERR_BAD_ARG, "sa_tracker_options.struct_size mismatch");
+  if (o->history_length == 0) return tfail(nullptr, SA_ERR_BAD_ARG, "bbox_history must be > 0 (sort/simple_api.rs:51)");
+  if (o->visual && (o->feature_len == 0 || o->visual_max_observations == 0))
+    return tfail(nullptr, SA_ERR_BAD_ARG, "VisualSort needs feature_len and visual_max_observations");
+  sa_tracker* t = new sa_tracker();
+  t->o = *o;
+  t->cons_delta.assign(o->constraint_epoch_delta, o->constraint_epoch_delta + o->n_constraints);
+  t->cons_dist.assign(o->constraint_max_dist, o->constraint_max_dist + o->n_constraints);
+  t->o.constraint_epoch_delta = t->cons_delta.data();
+  t->o.constraint_max_dist = t->cons_dist.data();
+  t->waste_counter = o->auto_waste_periodicity;
+  sa_config c;
+  sa_config_default(&c);
+  c.device = o->device;
+  c.positional_kind = o->positional_kind;
+  c.positional_threshold = o->positional_threshold;
+  c.positional_min_confidence = o->positional_min_confidence;
+  c.visual_kind = o->visual ? o->visual_kind : SA_VIS_NONE;
+  c.visual_threshold = o->visual_threshold;
+  c.feature_len = o->feature_len;
+  c.max_observations = o->visual ? o->visual_max_observations : 1;
+  c.visual_min_votes = o->visual_min_votes;
+  c.visual_minimal_track_length = o->visual_minimal_track_length;
+  c.visual_minimal_area = o->visual_minimal_area;
+  c.visual_minimal_quality_use = o->visual_minimal_quality_use;
+  c.visual_minimal_own_area_percentage_use = o->visual_minimal_own_area_percentage_use;
+  c.max_idle_epochs = o->max_idle_epochs;
+  c.n_constraints = o->n_constraints;
+  c.constraint_epoch_delta = t->cons_delta.data();
+  c.constraint_max_dist = t->cons_dist.data();
+  c.kf_position_weight = o->kalman_position_weight;
+  c.kf_velocity_weight = o->kalman_velocity_weight;
+  int rc = sa_engine_create(&c, &t->eng);
+  if (rc != SA_OK) {
+    tfail(nullptr, rc, "sa_engine_create: %s", sa_last_error(nullptr));
+    delete t;
+    return rc;
+  }
+  *out = t;
+  return SA_OK;
+}
+
+void sa_tracker_destroy(sa_tracker* t) {
+  if (!t) return;
+  if (t->eng) sa_engine_destroy(t->eng);
+  delete t;
+}
+
+int sa_tracker_predict(sa_tracker* t, uint64_t scene_id, uint32_t n, const sa_observation* obs, sa_sort_track* out) {
+  if (!t || (n && (!obs || !out))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict: null argument");
+  const sa_observation* op = obs;
+  sa_sort_track* outp = out;
+  return predict_scenes(t, 1, &scene_id, &n, &op, &outp);
+}
+
+int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                             const sa_observation* const* obs, sa_sort_track* const* out) {
+  if (!t || (n_scenes && (!scene_ids || !counts || !obs || !out))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict_batch: null argument");
+  return predict_scenes(t, n_scenes, scene_ids, counts, obs, out);
+}
+
+int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
+  if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_idle_tracks: null argument");
+  // IdleLookup  sort.rs:213-228: same scene and last_updated_epoch != current epoch
+  uint32_t n = 0;
+  auto it = t->by_scene.find(scene_id);
+  if (it != t->by_scene.end())
+    for (uint64_t id : it->second) {
+      const Track& tr = t->store[id];
+      if (tr.epoch != current_epoch(t, scene_id)) {
+        if (out && n < cap) out[n] = to_sort_track(t->o, tr);
+        ++n;
+      }
+    }
+  *out_n = n;
+  return SA_OK;
+}
+
+int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n) {
+  if (!t) return SA_ERR_BAD_ARG;
+  t->epochs[scene_id] += n;  // skip_epochs_for_scene  epoch_db.rs:11-20
+  return auto_waste(t);      // tracker_api.rs:48-51
+}
+
+int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out) {
+  if (!t || !out) return SA_ERR_BAD_ARG;
+  *out = current_epoch(t, scene_id);
+  return SA_OK;
+}
+
+int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
+  if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_wasted: null argument");
+  int rc = auto_waste(t);
+  if (rc != SA_OK) return rc;
+  std::sort(t->wasted_store.begin(), t->wasted_store.end(), [](const Track& a, const Track& b) { return a.id < b.id; });
+  uint32_t n = (uint32_t)t->wasted_store.size();
+  for (uint32_t i = 0; i < n && i < cap && out; ++i) out[i] = to_sort_track(t->o, t->wasted_store[i]);
+  *out_n = n;
+  if (out && cap >= n) t->wasted_store.clear();  // fetch_tracks removes them from the wasted store
+  return SA_OK;
+}
+
+int sa_tracker_clear_wasted(sa_tracker* t) {
+  if (!t) return SA_ERR_BAD_ARG;
+  t->wasted_store.clear();
+  return SA_OK;
+}
+
+int sa_tracker_active_tracks(sa_tracker* t, uint64_t* out_n) {
+  if (!t || !out_n) return SA_ERR_BAD_ARG;
+  *out_n = t->store.size();
+  return SA_OK;
+}
+
+int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, float* cov100) {
+  if (!t) return SA_ERR_BAD_ARG;
+  auto it = t->store.find(track_id);
+  if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  if (mean10) std::memcpy(mean10, it->second.kf.mean, sizeof it->second.kf.mean);
+  if (cov100) std::memcpy(cov100, it->second.kf.cov, sizeof it->second.kf.cov);
+  return SA_OK;
+}
+
+int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]) {
+  if (!t || !out4) return SA_ERR_BAD_ARG;
+  auto it = t->store.find(track_id);
+  if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  const Track& tr = it->second;
+  out4[0] = tr.feat_count;
+  out4[1] = t->o.visual ? tr.obs.size() : 1;
+  out4[2] = tr.observed.size();
+  out4[3] = tr.length;
+  return SA_OK;
+}
+
+}  // extern "C"

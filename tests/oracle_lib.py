@@ -82,6 +82,20 @@ def lib() -> C.CDLL:
         ),
         "or_associate": (C.c_int, [P(abi.sa_config), u32, P(abi.sa_tracks), u64, P(abi.sa_detections), P(or_frame_out)]),
     }
+    T = C.c_void_p
+    OBS, TRK = P(abi.sa_observation), P(abi.sa_sort_track)
+    sig.update({
+        "or_tracker_create": (T, [P(abi.sa_tracker_options)]),
+        "or_tracker_destroy": (None, [T]),
+        "or_tracker_predict_batch": (C.c_int, [T, u32, P(u64), P(u32), P(OBS), P(TRK)]),
+        "or_tracker_skip_epochs": (C.c_int, [T, u64, u64]),
+        "or_tracker_current_epoch": (u64, [T, u64]),
+        "or_tracker_active_tracks": (u64, [T]),
+        "or_tracker_wasted": (u32, [T, TRK, u32]),
+        "or_tracker_idle_tracks": (u32, [T, u64, TRK, u32]),
+        "or_tracker_track_state": (C.c_int, [T, u64, fp, fp]),
+        "or_tracker_track_info": (C.c_int, [T, u64, P(u64)]),
+    })
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
@@ -128,3 +142,89 @@ def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True):
     res["total_weight"] = int(out.total_weight)
     res["n_distances"] = int(out.n_distances)
     return res
+
+
+class OracleTracker:
+    """The oracle's Sort / VisualSort / Batch* loops behind the same Python surface as similari_amd.trackers._Tracker."""
+
+    def __init__(self, opts, keep=None):
+        from similari_amd import trackers as TR
+
+        self.TR = TR
+        self.L = lib()
+        self.opts = opts
+        self._keep = keep
+        self.h = self.L.or_tracker_create(C.byref(opts))
+
+    def close(self):
+        if self.h:
+            self.L.or_tracker_destroy(self.h)
+            self.h = None
+
+    _obs_array = None
+
+    def predict_batch_raw(self, scenes: dict):
+        TR = self.TR
+        keys = list(scenes.keys())
+        keep = []
+        arrs = [TR._Tracker._obs_array(self, scenes[s], keep) for s in keys]
+        outs = [(abi.sa_sort_track * max(1, len(scenes[s])))() for s in keys]
+        ids = (C.c_uint64 * max(1, len(keys)))(*keys)
+        counts = (C.c_uint32 * max(1, len(keys)))(*[len(scenes[s]) for s in keys])
+        pa = (P(abi.sa_observation) * max(1, len(keys)))(*[C.cast(a, P(abi.sa_observation)) for a in arrs])
+        po = (P(abi.sa_sort_track) * max(1, len(keys)))(*[C.cast(o, P(abi.sa_sort_track)) for o in outs])
+        rc = self.L.or_tracker_predict_batch(self.h, len(keys), ids, counts, pa, po)
+        assert rc == 0
+        return {s: [TR.SortTrack.from_c(outs[k][i]) for i in range(len(scenes[s]))] for k, s in enumerate(keys)}
+
+    def predict_with_scene(self, scene_id, items):
+        return self.predict_batch_raw({scene_id: list(items)})[scene_id]
+
+    def predict(self, items):
+        return self.predict_with_scene(0, items)
+
+    def predict_batch(self, batch):
+        return self.predict_batch_raw(batch.scenes)
+
+    def skip_epochs_for_scene(self, scene_id, n):
+        self.L.or_tracker_skip_epochs(self.h, scene_id, n)
+
+    def current_epoch_with_scene(self, scene_id):
+        return self.L.or_tracker_current_epoch(self.h, scene_id)
+
+    def current_epoch(self):
+        return self.current_epoch_with_scene(0)
+
+    def active_tracks(self):
+        return self.L.or_tracker_active_tracks(self.h)
+
+    def wasted(self):
+        n = self.L.or_tracker_wasted(self.h, None, 0)
+        out = (abi.sa_sort_track * max(1, n))()
+        n = self.L.or_tracker_wasted(self.h, out, n)
+        return [self.TR.SortTrack.from_c(out[i]) for i in range(n)]
+
+    def wasted_count(self):
+        return self.L.or_tracker_wasted(self.h, None, 0)
+
+    def clear_wasted(self):
+        n = self.L.or_tracker_wasted(self.h, None, 0)
+        out = (abi.sa_sort_track * max(1, n))()
+        self.L.or_tracker_wasted(self.h, out, n)
+
+    def idle_tracks_with_scene(self, scene_id):
+        n = self.L.or_tracker_idle_tracks(self.h, scene_id, None, 0)
+        out = (abi.sa_sort_track * max(1, n))()
+        n = self.L.or_tracker_idle_tracks(self.h, scene_id, out, n)
+        return [self.TR.SortTrack.from_c(out[i]) for i in range(n)]
+
+    def track_state(self, track_id):
+        m = np.zeros(10, np.float32)
+        c = np.zeros(100, np.float32)
+        assert self.L.or_tracker_track_state(self.h, track_id, fptr(m), fptr(c)) == 0
+        return m, c
+
+    def track_info(self, track_id):
+        out = (C.c_uint64 * 4)()
+        assert self.L.or_tracker_track_info(self.h, track_id, out) == 0
+        return dict(visual_features_collected_count=out[0], observations=out[1], history=out[2], track_length=out[3])

@@ -1,0 +1,296 @@
+"""Tracker-level tests.  The reference's own end-to-end tests (sort/simple_api.rs:280-432,
+visual_sort/simple_api.rs:328-666) are ported literally and run against
+  * the oracle's tracker loops (CPU, always) — this pins the oracle's orchestration on the reference's expectations,
+  * the product facade on the GPU (marked gpu) — same assertions, so the parity tests read like the reference's.
+Then the product is compared frame by frame with the oracle on seeded multi-frame sequences."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from similari_amd import abi, synth
+from similari_amd import trackers as TR
+
+IoU = TR.PositionalMetricType.iou
+BB = TR.BoundingBox
+
+
+def make(backend, kind, **kw):
+    """kind: 'sort' | 'visual'; backend: 'oracle' | 'gpu'."""
+    if kind == "sort":
+        o, keep = TR.sort_options(kw.get("bbox_history", 10), kw.get("max_idle_epochs", 2), kw.get("method", IoU(0.3)),
+                                  kw.get("min_confidence", 0.05), kw.get("constraints"), 1.0 / 20.0, 1.0 / 160.0,
+                                  batch=kw.get("batch", False))
+    else:
+        o, keep = TR.visual_options(kw["opts"], kw["feature_len"], batch=kw.get("batch", False))
+    if backend == "oracle":
+        return O.OracleTracker(o, keep)
+    return TR._Tracker(o, keep)
+
+
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+
+
+def box_eq(a: TR.Universal2DBox, b: TR.Universal2DBox, eps=1e-5):
+    # Universal2DBox PartialEq  bbox.rs:537-545
+    return (abs(a.xc - b.xc) < eps and abs(a.yc - b.yc) < eps and ((a.angle or 0.0) - (b.angle or 0.0)) < eps
+            and (a.aspect - b.aspect) < eps and (a.height - b.height) < eps)
+
+
+# ---- sort/simple_api.rs:280-342 -------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sort(backend):
+    t = make(backend, "sort", bbox_history=10, max_idle_epochs=2)
+    assert t.current_epoch() == 0
+    bb = BB(0.0, 0.0, 10.0, 20.0)
+    v = t.predict([(bb.as_xyaah(), None)])
+    assert t.wasted() == []
+    assert len(v) == 1
+    v = v[0]
+    track_id = v.id
+    assert v.custom_object_id is None and v.length == 1 and v.epoch == 1
+    assert box_eq(v.observed_bbox, bb.as_xyaah())
+    assert t.current_epoch() == 1
+
+    bb = BB(0.1, 0.1, 10.1, 20.0)
+    v = t.predict([(bb.as_xyaah(), 2)])
+    assert t.wasted() == []
+    v = v[0]
+    assert v.custom_object_id == 2 and v.id == track_id and v.length == 2 and v.epoch == 2
+    assert box_eq(v.observed_bbox, bb.as_xyaah())
+    assert t.current_epoch() == 2
+
+    bb = BB(10.1, 10.1, 10.1, 20.0)
+    v = t.predict([(bb.as_xyaah(), 3)])
+    assert len(v) == 1 and v[0].custom_object_id == 3 and v[0].id != track_id
+    assert t.wasted() == []
+    assert t.current_epoch() == 3
+
+    assert t.predict([]) == []
+    assert t.wasted() == []
+    assert t.current_epoch() == 4
+
+    assert t.predict([]) == []
+    w = t.wasted()
+    assert len(w) == 1 and w[0].id == track_id
+    assert t.current_epoch() == 5
+    t.close()
+
+
+# ---- sort/simple_api.rs:344-372 -------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sort_with_scenes(backend):
+    t = make(backend, "sort")
+    bb = BB(0.0, 0.0, 10.0, 20.0).as_xyaah()
+    assert t.current_epoch_with_scene(1) == 0 and t.current_epoch_with_scene(2) == 0
+    t.predict_with_scene(1, [(bb, 4)])
+    t.predict_with_scene(1, [(bb, 5)])
+    assert t.current_epoch_with_scene(1) == 2 and t.current_epoch_with_scene(2) == 0
+    t.predict_with_scene(2, [(bb, 6)])
+    assert t.current_epoch_with_scene(1) == 2 and t.current_epoch_with_scene(2) == 1
+    t.close()
+
+
+# ---- sort/simple_api.rs:374-398 -------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_idle_tracks(backend):
+    t = make(backend, "sort")
+    bb = BB(0.0, 0.0, 10.0, 20.0).as_xyaah()
+    t.predict_with_scene(1, [(bb, 4)])
+    assert t.idle_tracks_with_scene(1) == []
+    t.predict_with_scene(1, [])
+    idle = t.idle_tracks_with_scene(1)
+    assert len(idle) == 1 and idle[0].id == 1
+    t.close()
+
+
+# ---- sort/simple_api.rs:400-432 -------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_clear_wasted_tracks(backend):
+    t = make(backend, "sort")
+    bb = BB(0.0, 0.0, 10.0, 20.0).as_xyaah()
+    t.predict_with_scene(1, [(bb, 4)])
+    t.skip_epochs_for_scene(1, 3)
+    assert t.wasted_count() == 1
+    t.clear_wasted()
+    assert t.wasted_count() == 0
+    t.close()
+
+
+# ---- visual_sort/simple_api.rs:328-666 (first track's life) ---------------------------------------------
+def vobs(feat, q, bb, cid):
+    return TR.VisualSortObservation(feat, q, bb.as_xyaah(), cid)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_visual_sort(backend):
+    opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3)
+            .visual_metric(TR.VisualSortMetricType.euclidean(1.0)).positional_metric(TR.PositionalMetricType.maha())
+            .visual_minimal_track_length(2).visual_minimal_area(5.0).visual_minimal_quality_use(0.45)
+            .visual_minimal_quality_collect(0.7).visual_max_observations(3).visual_min_votes(2))
+    t = make(backend, "visual", opts=opts, feature_len=2)
+    P, V = TR.VotingType.Positional, TR.VotingType.Visual
+
+    tr = t.predict_with_scene(10, [vobs([1.0, 1.0], 0.9, BB(1.0, 1.0, 3.0, 5.0), 13)])[0]
+    assert (tr.custom_object_id, tr.scene_id, tr.voting_type, tr.epoch) == (13, 10, P, 1)
+    first = tr.id
+    info = t.track_info(first)
+    assert info == dict(visual_features_collected_count=1, observations=1, history=1, track_length=1)
+
+    tr = t.predict_with_scene(1, [vobs([1.0, 1.0], 0.9, BB(1.0, 1.0, 3.0, 5.0), 133)])[0]  # another scene: new track
+    assert (tr.custom_object_id, tr.scene_id, tr.voting_type, tr.epoch) == (133, 1, P, 1)
+    assert tr.id != first
+
+    tr = t.predict_with_scene(10, [vobs([0.95, 0.95], 0.93, BB(1.1, 1.1, 3.05, 5.01), 15)])[0]  # merge by position
+    assert (tr.id, tr.custom_object_id, tr.voting_type, tr.epoch) == (first, 15, P, 2)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"], info["history"]) == (2, 2, 2)
+
+    tr = t.predict_with_scene(10, [vobs(None, 0.93, BB(1.11, 1.15, 3.15, 5.05), 25)])[0]  # no feature
+    assert (tr.id, tr.custom_object_id, tr.voting_type, tr.epoch) == (first, 25, P, 3)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"], info["history"]) == (2, 3, 3)
+
+    tr = t.predict_with_scene(10, [vobs(None, 0.93, BB(1.15, 1.25, 3.10, 5.05), 2)])[0]
+    assert (tr.id, tr.voting_type, tr.epoch) == (first, P, 4)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"], info["history"]) == (2, 4, 3)
+
+    # feature of low quality: no use, no collect
+    tr = t.predict_with_scene(10, [vobs([0.97, 0.97], 0.44, BB(1.15, 1.25, 3.10, 5.05), 2)])[0]
+    assert (tr.id, tr.voting_type) == (first, P)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"]) == (2, 5)
+
+    # use, but no collect
+    tr = t.predict_with_scene(10, [vobs([0.97, 0.97], 0.6, BB(1.15, 1.25, 3.10, 5.05), 2)])[0]
+    assert (tr.id, tr.voting_type) == (first, V)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"]) == (2, 6)
+
+    # use and collect
+    tr = t.predict_with_scene(10, [vobs([0.97, 0.97], 0.8, BB(1.15, 1.25, 3.10, 5.05), 2)])[0]
+    assert (tr.id, tr.voting_type) == (first, V)
+    info = t.track_info(first)
+    assert (info["visual_features_collected_count"], info["track_length"], info["observations"]) == (3, 7, 3)
+
+    # far away: new track
+    tr = t.predict_with_scene(10, [vobs([0.1, 0.1], 0.9, BB(10.0, 10.0, 3.0, 5.0), 33)])[0]
+    assert (tr.custom_object_id, tr.scene_id, tr.voting_type, tr.epoch) == (33, 10, P, 8)
+    assert tr.id != first
+    info = t.track_info(tr.id)
+    assert info == dict(visual_features_collected_count=1, observations=1, history=1, track_length=1)
+    t.close()
+
+
+# ---- product vs oracle, frame by frame -------------------------------------------------------------------
+def assert_tracks_equal(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert (x.id, x.epoch, x.scene_id, x.length, x.voting_type, x.custom_object_id) == \
+               (y.id, y.epoch, y.scene_id, y.length, y.voting_type, y.custom_object_id)
+        for bx, by in ((x.predicted_bbox, y.predicted_bbox), (x.observed_bbox, y.observed_bbox)):
+            assert (bx.xc, bx.yc, bx.aspect, bx.height, bx.confidence) == (by.xc, by.yc, by.aspect, by.height, by.confidence)
+            assert (bx.angle is None) == (by.angle is None)
+            assert bx.angle is None or bx.angle == by.angle
+
+
+def boxes_to_u2d(b):
+    return [TR.Universal2DBox(float(r["xc"]), float(r["yc"]), float(r["angle"]) if r["has_angle"] else None,
+                              float(r["aspect"]), float(r["height"]), float(r["confidence"])) for r in b]
+
+
+def run_sort_sequence(method, oriented, seed, frames=8, n=60, scenes=(0,), batch=False, constraints=None):
+    rng = np.random.default_rng(seed)
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=method, min_confidence=0.05, constraints=constraints, batch=batch)
+    g, o = make("gpu", "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        world = {s: synth.dense_boxes(rng, n, (900.0, 700.0), oriented) for s in scenes}
+        for f in range(frames):
+            req = TR.PredictionBatchRequest()
+            for s in scenes:
+                world[s] = synth.jitter_boxes(rng, world[s], 2.0, angle_sigma=0.01 if oriented else 0.0)
+                keep = rng.uniform(size=len(world[s])) > 0.15           # missed detections
+                det = world[s][keep]
+                extra = synth.dense_boxes(rng, int(rng.integers(0, 6)), (900.0, 700.0), oriented)  # false positives
+                det = np.concatenate([det, extra])[rng.permutation(len(det) + len(extra))]
+                for i, bx in enumerate(boxes_to_u2d(det)):
+                    req.add(s, (bx, int(rng.integers(0, 1000)) if i % 3 == 0 else None))
+                if f == 4 and len(world[s]) > 10:             # a few objects leave for good
+                    world[s] = world[s][:-5]
+            rg, ro = g.predict_batch(req), o.predict_batch(req)
+            for s in scenes:
+                assert_tracks_equal(rg[s], ro[s])
+                ids = [x.id for x in rg[s]]
+                assert len(ids) == len(set(ids)), "a track id repeats within one frame"
+            if f % 3 == 2:
+                assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+                for s in scenes:
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id),
+                                        sorted(o.idle_tracks_with_scene(s), key=lambda x: x.id))
+        assert g.active_tracks() == o.active_tracks()
+        # Kalman states agree value for value
+        for x in rg[scenes[0]][:10]:
+            mg, cg = g.track_state(x.id)
+            mo, co = o.track_state(x.id)
+            np.testing.assert_array_equal(mg, mo)
+            np.testing.assert_array_equal(cg, co)
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oriented", [False, True])
+def test_sort_iou_sequence_matches_oracle(oriented):
+    run_sort_sequence(IoU(0.3), oriented, seed=11 + oriented)
+
+
+@pytest.mark.gpu
+def test_sort_maha_sequence_matches_oracle():
+    run_sort_sequence(TR.PositionalMetricType.maha(), False, seed=13)
+
+
+@pytest.mark.gpu
+def test_batch_sort_scenes_and_constraints_match_oracle():
+    c = TR.SpatioTemporalConstraints().add_constraints([(1, 1.0), (2, 1.5)])
+    run_sort_sequence(IoU(0.3), False, seed=17, scenes=(3, 7, 11), batch=True, constraints=c, n=40)
+
+
+def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False):
+    rng = np.random.default_rng(seed)
+    opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(metric)
+            .positional_metric(positional).visual_minimal_track_length(2).visual_minimal_area(500.0)
+            .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(3).visual_min_votes(1))
+    g = make("gpu", "visual", opts=opts, feature_len=d, batch=batch)
+    o = make("oracle", "visual", opts=opts, feature_len=d, batch=batch)
+    try:
+        ident = synth.reid_identities(rng, n, d)
+        world = synth.dense_boxes(rng, n, (900.0, 700.0))
+        for f in range(frames):
+            world = synth.jitter_boxes(rng, world, 2.0)
+            order = rng.permutation(n)
+            keep = order[rng.uniform(size=n) > 0.1]
+            feats = synth.observe(rng, ident[keep], 0.01)
+            req = TR.PredictionBatchRequest()
+            for k, (bx, ft) in enumerate(zip(boxes_to_u2d(world[keep]), feats)):
+                q = float(rng.uniform(0.2, 1.0))
+                req.add(5, TR.VisualSortObservation(None if k % 7 == 3 else ft, None if k % 5 == 0 else q, bx, k if k % 2 else None))
+            rg, ro = g.predict_batch(req), o.predict_batch(req)
+            assert_tracks_equal(rg[5], ro[5])
+            for x in rg[5][:8]:
+                assert g.track_info(x.id) == o.track_info(x.id)
+        votes = [x.voting_type for x in rg[5]]
+        assert TR.VotingType.Visual in votes
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+def test_visual_cosine_sequence_matches_oracle():
+    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=21)
+
+
+@pytest.mark.gpu
+def test_visual_euclid_maha_sequence_matches_oracle():
+    run_visual_sequence(TR.VisualSortMetricType.euclidean(0.5), TR.PositionalMetricType.maha(), seed=23, batch=True)
