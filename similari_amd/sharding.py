@@ -1,0 +1,254 @@
+"""Scene sharding of the batched trackers (BatchSort / BatchVisualSort) over the GPUs of one node.
+
+Scenes are independent units on this path: `compatible()` is false across scene ids (src/trackers/sort.rs:251,
+visual_sort/track_attributes.rs:189), and the reference already fans the scenes of one PredictionBatchRequest out to voting
+threads (sort/batch_api.rs:278-288).  Here a scene is owned by rank `scene_id % world` — sticky, so the scene's track table
+(boxes, Kalman projection, feature bank) stays resident in that GPU's HBM, the way `track_id % shards` pins a track to a
+store shard in the reference (track/store.rs:490-493).
+
+There is NO data-path collective: no cost cell or assignment depends on another scene.  The only exchange is the request
+scatter and the result gather of one `predict(batch)` call — KB-scale, latency-bound — done with `torch.distributed`
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
+
+    root                         every rank
+    ----                         ----------
+    partition scenes by owner
+    broadcast  header[world][2]  (request bytes, observation count per rank)
+    scatter    request bytes  ->  decode, local tracker.predict_batch (one set of launches for all local scenes)
+    gather     result records <-  encode SortTrack records
+    reassemble {scene: [SortTrack]}
+
+Track ids: each rank's tracker counts 1, 2, 3, ... on its own; the global id is `(local - 1) * world + rank + 1`, unique
+across ranks and equal to the local id when world == 1 (the reference draws ids from one shared counter whose interleaving
+across scenes is timing-dependent, sort/batch_api.rs:102-106, so only uniqueness is contractual).
+
+The local tracker is anything with `predict_batch(PredictionBatchRequest) -> {scene: [SortTrack]}`: `BatchSort` /
+`BatchVisualSort` of similari_amd.trackers in production.  This module computes nothing on the hot path."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import trackers as TR
+
+OBS_WIRE = np.dtype([("xc", "<f4"), ("yc", "<f4"), ("angle", "<f4"), ("aspect", "<f4"), ("height", "<f4"), ("confidence", "<f4"),
+                     ("has_angle", "<i4"), ("has_feature", "<i4"), ("quality", "<f4"), ("own_area", "<f4"),
+                     ("has_cid", "<i4"), ("pad", "<i4"), ("cid", "<i8")])          # 56 B
+TRACK_WIRE = np.dtype([("id", "<u8"), ("epoch", "<u8"), ("scene_id", "<u8"), ("length", "<u8"), ("cid", "<i8"),
+                       ("voting_type", "<i4"), ("has_cid", "<i4"),
+                       ("pred", "<f4", (6,)), ("obs", "<f4", (6,)), ("pred_has_angle", "<i4"), ("obs_has_angle", "<i4")])  # 104 B
+SHUTDOWN = -1
+
+
+def owner(scene_id: int, world: int) -> int:
+    return int(scene_id) % world
+
+
+def global_id(local_id: int, rank: int, world: int) -> int:
+    return (int(local_id) - 1) * world + rank + 1 if local_id else 0
+
+
+def partition(batch: "TR.PredictionBatchRequest", world: int) -> List[Dict[int, list]]:
+    """Scenes of one request -> per-rank sub-requests, scene order preserved."""
+    parts: List[Dict[int, list]] = [dict() for _ in range(world)]
+    for scene, items in batch.scenes.items():
+        parts[owner(scene, world)][scene] = items
+    return parts
+
+
+# ---- wire format ---------------------------------------------------------------------------------------------------------
+def _box_fields(rec, box):
+    if isinstance(box, TR.BoundingBox):
+        box = box.as_xyaah()
+    rec["xc"], rec["yc"], rec["aspect"], rec["height"], rec["confidence"] = box.xc, box.yc, box.aspect, box.height, box.confidence
+    rec["has_angle"] = 0 if box.angle is None else 1
+    rec["angle"] = 0.0 if box.angle is None else box.angle
+
+
+def encode_request(scenes: Dict[int, list], feature_len: int) -> np.ndarray:
+    """{scene: [VisualSortObservation | (box, custom_id)]} -> one uint8 buffer:
+    int64 header [n_scenes, n_obs, n_feat_rows, D] | int64 [n_scenes][2] (scene, count) | OBS_WIRE[n_obs] | f32 [n_feat_rows][D]"""
+    ids = list(scenes.keys())
+    n_obs = sum(len(scenes[s]) for s in ids)
+    obs = np.zeros(n_obs, OBS_WIRE)
+    feats = []
+    i = 0
+    for s in ids:
+        for it in scenes[s]:
+            r = obs[i]
+            if isinstance(it, TR.VisualSortObservation):
+                _box_fields(r, it.bounding_box)
+                r["quality"] = math.nan if it.feature_quality is None else it.feature_quality
+                r["own_area"] = math.nan if it.own_area is None else it.own_area
+                cid = it.custom_object_id
+                if it.feature is not None:
+                    assert len(it.feature) == feature_len, f"feature length {len(it.feature)} != {feature_len}"
+                    r["has_feature"] = 1
+                    feats.append(np.asarray(it.feature, np.float32))
+            else:
+                box, cid = it
+                _box_fields(r, box)
+                r["quality"] = math.nan
+                r["own_area"] = math.nan
+            r["has_cid"] = 0 if cid is None else 1
+            r["cid"] = 0 if cid is None else cid
+            i += 1
+    head = np.array([len(ids), n_obs, len(feats), feature_len], np.int64)
+    table = np.array([[s, len(scenes[s])] for s in ids], np.int64).reshape(len(ids), 2)
+    fm = np.stack(feats).astype(np.float32) if feats else np.zeros((0, max(feature_len, 1)), np.float32)
+    return np.concatenate([head.view(np.uint8), table.reshape(-1).view(np.uint8), obs.view(np.uint8), fm.reshape(-1).view(np.uint8)])
+
+
+def decode_request(buf: np.ndarray) -> "TR.PredictionBatchRequest":
+    buf = np.ascontiguousarray(buf, np.uint8)
+    n_scenes, n_obs, n_feat, D = (int(x) for x in buf[:32].view(np.int64))
+    o = 32
+    table = buf[o:o + 16 * n_scenes].view(np.int64).reshape(n_scenes, 2)
+    o += 16 * n_scenes
+    obs = buf[o:o + OBS_WIRE.itemsize * n_obs].view(OBS_WIRE)
+    o += OBS_WIRE.itemsize * n_obs
+    feats = buf[o:o + 4 * n_feat * D].view(np.float32).reshape(n_feat, D) if n_feat else None
+    req = TR.PredictionBatchRequest()
+    i = f = 0
+    for scene, count in table:
+        req.scenes[int(scene)] = []
+        for _ in range(int(count)):
+            r = obs[i]
+            box = TR.Universal2DBox(float(r["xc"]), float(r["yc"]), float(r["angle"]) if r["has_angle"] else None, float(r["aspect"]),
+                                    float(r["height"]), float(r["confidence"]))
+            cid = int(r["cid"]) if r["has_cid"] else None
+            if D:
+                ft = None
+                if r["has_feature"]:
+                    ft = feats[f].copy()
+                    f += 1
+                q = None if math.isnan(float(r["quality"])) else float(r["quality"])
+                oa = None if math.isnan(float(r["own_area"])) else float(r["own_area"])
+                req.scenes[int(scene)].append(TR.VisualSortObservation(ft, q, box, cid, oa))
+            else:
+                req.scenes[int(scene)].append((box, cid))
+            i += 1
+    return req
+
+
+def _b6(b: "TR.Universal2DBox"):
+    return [b.xc, b.yc, 0.0 if b.angle is None else b.angle, b.aspect, b.height, b.confidence], (0 if b.angle is None else 1)
+
+
+def encode_results(results: Dict[int, list], order: List[int], rank: int, world: int) -> np.ndarray:
+    n = sum(len(results[s]) for s in order)
+    out = np.zeros(n, TRACK_WIRE)
+    i = 0
+    for s in order:
+        for t in results[s]:
+            r = out[i]
+            r["id"] = global_id(t.id, rank, world)
+            r["epoch"], r["scene_id"], r["length"], r["voting_type"] = t.epoch, t.scene_id, t.length, t.voting_type
+            r["has_cid"] = 0 if t.custom_object_id is None else 1
+            r["cid"] = 0 if t.custom_object_id is None else t.custom_object_id
+            r["pred"], r["pred_has_angle"] = _b6(t.predicted_bbox)
+            r["obs"], r["obs_has_angle"] = _b6(t.observed_bbox)
+            i += 1
+    return out.view(np.uint8)
+
+
+def decode_results(buf: np.ndarray) -> List["TR.SortTrack"]:
+    recs = np.ascontiguousarray(buf, np.uint8).view(TRACK_WIRE)
+    out = []
+    for r in recs:
+        def bx(v, has):
+            return TR.Universal2DBox(float(v[0]), float(v[1]), float(v[2]) if has else None, float(v[3]), float(v[4]), float(v[5]))
+        out.append(TR.SortTrack(int(r["id"]), int(r["epoch"]), bx(r["pred"], r["pred_has_angle"]), bx(r["obs"], r["obs_has_angle"]),
+                                int(r["scene_id"]), int(r["length"]), int(r["voting_type"]), int(r["cid"]) if r["has_cid"] else None))
+    return out
+
+
+# ---- the collective call ---------------------------------------------------------------------------------------------------
+class ShardedBatchTracker:
+    """SPMD wrapper: every rank constructs it around its local tracker and calls `predict` in lockstep; the root passes
+    the PredictionBatchRequest and gets {scene: [SortTrack]} back, the other ranks pass None and get None.
+    Workers that have nothing else to do call `serve_forever()`; the root ends them with `shutdown()`."""
+
+    def __init__(self, local_tracker, feature_len: int = 0, group=None, root: int = 0, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.local = local_tracker
+        self.feature_len = int(feature_len)
+        self.group = group
+        self.root = root
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.device = device
+
+    def owner(self, scene_id: int) -> int:
+        return owner(scene_id, self.world)
+
+    def _t(self, arr: np.ndarray, size: int):
+        t = self.torch.zeros(size, dtype=self.torch.uint8)
+        if len(arr):
+            t[: len(arr)] = self.torch.from_numpy(np.ascontiguousarray(arr))
+        return t.to(self.device)
+
+    def predict(self, batch: Optional["TR.PredictionBatchRequest"] = None):
+        """Collective.  Root: pass the request, get {scene: [SortTrack]}.  Other ranks: pass None, get None."""
+        return self._step(batch, False)[1]
+
+    def _step(self, batch, shutdown: bool):
+        torch, dist = self.torch, self.dist
+        is_root = self.rank == self.root
+        header = torch.zeros((self.world, 2), dtype=torch.int64)
+        bufs, orders = None, None
+        if is_root:
+            if shutdown:
+                header[:, 0] = SHUTDOWN
+            else:
+                parts = partition(batch, self.world)
+                orders = [list(p.keys()) for p in parts]
+                bufs = [encode_request(p, self.feature_len) for p in parts]
+                for r in range(self.world):
+                    header[r, 0] = len(bufs[r])
+                    header[r, 1] = sum(len(v) for v in parts[r].values())
+        header = header.to(self.device)
+        dist.broadcast(header, src=self.root, group=self.group)
+        header = header.cpu()
+        if int(header[0, 0]) == SHUTDOWN:
+            return "shutdown", None
+        req_max = int(header[:, 0].max())
+        res_max = int(header[:, 1].max()) * TRACK_WIRE.itemsize
+        # scatter the encoded sub-requests (padded to the longest: collectives want equal shapes)
+        mine = torch.zeros(req_max, dtype=torch.uint8, device=self.device)
+        dist.scatter(mine, [self._t(b, req_max) for b in bufs] if is_root else None, src=self.root, group=self.group)
+        sub = decode_request(mine.cpu().numpy()[: int(header[self.rank, 0])])
+        local = self.local.predict_batch(sub) if sub.scenes else {}
+        enc = encode_results(local, list(sub.scenes.keys()), self.rank, self.world)
+        out = self._t(enc, max(res_max, 1))
+        gathered = [torch.zeros(max(res_max, 1), dtype=torch.uint8, device=self.device) for _ in range(self.world)] if is_root else None
+        dist.gather(out, gathered, dst=self.root, group=self.group)
+        if not is_root:
+            return "served", None
+        result: Dict[int, list] = {}
+        for r in range(self.world):
+            n = int(header[r, 1])
+            tracks = decode_results(gathered[r].cpu().numpy()[: n * TRACK_WIRE.itemsize])
+            i = 0
+            for s in orders[r]:
+                c = len(batch.scenes[s])
+                result[s] = tracks[i:i + c]
+                i += c
+        return "served", {s: result[s] for s in batch.scenes}  # request order
+
+    def serve_forever(self):
+        """Worker loop: take part in the root's predict() calls until it calls shutdown()."""
+        assert self.rank != self.root
+        while self._step(None, False)[0] != "shutdown":
+            pass
+
+    def shutdown(self):
+        assert self.rank == self.root
+        self._step(None, True)
