@@ -1,6 +1,7 @@
 // sa_engine.h — internal types shared by the host engine and the HIP kernels (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/similari_assoc.h"
@@ -17,6 +18,28 @@ struct BoxRaw {
   double c, s;
 };
 
+// Every array a kernel reaches through this descriptor lives in HBM.  Pointers loaded from a struct are "generic" to the
+// compiler, and generic loads/stores become flat_* instructions, which tick BOTH vmcnt and lgkmcnt (an LDS wait then also
+// waits for memory) and must resolve the aperture per access: measured on the fused contraction, the flat metadata
+// loads alone cost 30 us of serialisation at C2.  On the device side the members are therefore global-address-space
+// pointers (same size and layout as on the host, where the qualifier is empty).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SA_G __attribute__((address_space(1)))
+#else
+#define SA_G
+#endif
+// whole-struct load / store through a global pointer (the implicit copy operations only bind generic references)
+template <class T>
+__device__ __forceinline__ T sa_ldg(const T SA_G* p) {
+  T v;
+  __builtin_memcpy(&v, (const T*)p, sizeof(T));
+  return v;
+}
+template <class T>
+__device__ __forceinline__ void sa_stg(T SA_G* p, const T& v) {
+  __builtin_memcpy((T*)p, &v, sizeof(T));
+}
+
 struct SceneDev {
   uint32_t N, T, K, Dp;      // candidates, tracks, bank depth, feature row stride (D rounded up to 32)
   uint32_t TK, estride;      // T*K ; row stride of the edge lists
@@ -24,63 +47,63 @@ struct SceneDev {
   uint32_t CT, RT;           // BestFit tiles: ceil(T/64), ceil(N/64)
   uint64_t epoch;
   // stored tracks (persist across frames)
-  const sa_geo* t_geo;
-  const double* t_verts;
-  const uint64_t* t_epoch;
-  const float* t_maha;
-  const float* t_feat;
-  const float* t_fnorm;
-  const uint8_t* t_fpresent;
-  const uint32_t* t_fcount;
-  const uint64_t* t_ids;
+  const sa_geo SA_G* t_geo;
+  const double SA_G* t_verts;
+  const uint64_t SA_G* t_epoch;
+  const float SA_G* t_maha;
+  const float SA_G* t_feat;
+  const float SA_G* t_fnorm;
+  const uint8_t SA_G* t_fpresent;
+  const uint32_t SA_G* t_fcount;
+  const uint64_t SA_G* t_ids;
   // raw candidate inputs of this frame (as uploaded)
-  const BoxRaw* c_raw;
-  const float* c_quality;
-  const float* c_own;
-  const uint8_t* c_fpresent_in;
-  const float* c_feat_raw;
+  const BoxRaw SA_G* c_raw;
+  const float SA_G* c_quality;
+  const float SA_G* c_own;
+  const uint8_t SA_G* c_fpresent_in;
+  const float SA_G* c_feat_raw;
   // derived candidate arrays (written by k_frame_prep)
-  sa_geo* c_geo;
-  double* c_verts;
-  float* c_z;
-  float* c_conf;
-  float* c_feat;
-  float* c_fnorm;
-  uint8_t* c_usable;
+  sa_geo SA_G* c_geo;
+  double SA_G* c_verts;
+  float SA_G* c_z;
+  float SA_G* c_conf;
+  float SA_G* c_feat;
+  float SA_G* c_fnorm;
+  uint8_t SA_G* c_usable;
   // cost matrices
-  float* pos;
-  float* vis;
+  float SA_G* pos;
+  float SA_G* vis;
   // BestFit vote
-  uint32_t* vis_max_key;   // [SA_MAXKEY_SHARDS] order-preserving keys; max over the shards = BestFit max_dist
-  double* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
-  int32_t* row_part_t;  // [N][CT]
-  double* col_part_w;   // [RT][T] best weight of the column inside row tile rt
-  uint32_t* col_part_q; // [RT][T] lowest row attaining it
-  uint8_t* row_has;
-  int32_t* vis_winner;
-  uint8_t* col_excluded;
+  uint32_t SA_G* vis_max_key;   // [SA_MAXKEY_SHARDS] order-preserving keys; max over the shards = BestFit max_dist
+  double SA_G* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
+  int32_t SA_G* row_part_t;  // [N][CT]
+  double SA_G* col_part_w;   // [RT][T] best weight of the column inside row tile rt
+  uint32_t SA_G* col_part_q; // [RT][T] lowest row attaining it
+  uint8_t SA_G* row_has;
+  int32_t SA_G* vis_winner;
+  uint8_t SA_G* col_excluded;
   // positional assignment
-  uint32_t* parent;
-  uint32_t* label;
-  uint32_t* next_row;
-  uint32_t* e_cnt;
-  uint32_t* e_col;
-  int64_t* e_gain;
-  int64_t* u;
-  int64_t* v;
-  int32_t* rmatch;
-  int32_t* cmatch;
-  int64_t* dist;
-  int32_t* pred;
-  uint32_t* cstamp;
-  uint32_t* cscan;
-  int32_t* cnext;
-  int64_t* rdist;
-  int32_t* rnext;
+  uint32_t SA_G* parent;
+  uint32_t SA_G* label;
+  uint32_t SA_G* next_row;
+  uint32_t SA_G* e_cnt;
+  uint32_t SA_G* e_col;
+  int64_t SA_G* e_gain;
+  int64_t SA_G* u;
+  int64_t SA_G* v;
+  int32_t SA_G* rmatch;
+  int32_t SA_G* cmatch;
+  int64_t SA_G* dist;
+  int32_t SA_G* pred;
+  uint32_t SA_G* cstamp;
+  uint32_t SA_G* cscan;
+  int32_t SA_G* cnext;
+  int64_t SA_G* rdist;
+  int32_t SA_G* rnext;
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
-  uint64_t* out_track_id;
-  uint8_t* out_vote;
-  int64_t* quant;  // optional N x T tap
+  uint64_t SA_G* out_track_id;
+  uint8_t SA_G* out_vote;
+  int64_t SA_G* quant;  // optional N x T tap
 };
 #define SA_MAXKEY_SHARDS 64
 #define SCN_HAS_FEATS 1u
@@ -106,6 +129,16 @@ struct SaParams {
   uint64_t max_idle;
   sa_constraints cons;
 };
+
+// Profile mode (SA_FLAG_PROFILE): while sa_prof_start is set, the per-frame launches go through hipExtLaunchKernelGGL,
+// which stamps the two events with the dispatch's OWN begin / end timestamps — the same clock rocprofv3's kernel trace
+// reads — instead of bracketing the launch with hipEventRecord (that adds ~2 us of command-processor time per kernel).
+extern thread_local hipEvent_t sa_prof_start, sa_prof_stop;
+#define SA_LAUNCH(kern, grid, block, shmem, st, ...)                                                           \
+  do {                                                                                                         \
+    if (sa_prof_start) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                        \
+  } while (0)
 
 // ---- launchers (sa_kernels.hip / sa_gemm.hip).  All enqueue on `st` and return the launch status. ----
 

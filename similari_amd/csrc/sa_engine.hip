@@ -184,12 +184,13 @@ struct ProfScope {
     if (e->profile) {
       a = prof_event(e);
       b = prof_event(e);
-      hipEventRecord(a, e->stream);
+      sa_prof_start = a;  // the next SA_LAUNCH stamps a / b with the dispatch's begin / end
+      sa_prof_stop = b;
     }
   }
   ~ProfScope() {
     if (e->profile) {
-      hipEventRecord(b, e->stream);
+      sa_prof_start = sa_prof_stop = nullptr;
       e->prof_open.push_back({kid, a, b});
     }
   }
@@ -303,6 +304,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   return SA_OK;
 }
 
+// (host code is also parsed in the device pass, where the members are global-address-space pointers: cast to the member type)
 void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   SceneTable* sc = s->scene;
   std::memset(d, 0, sizeof *d);
@@ -313,26 +315,26 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
              (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
   d->epoch = s->epoch;
-  d->t_geo = (const sa_geo*)sc->geo.p; d->t_verts = (const double*)sc->verts.p; d->t_epoch = (const uint64_t*)sc->epoch.p;
-  d->t_maha = (const float*)sc->maha.p; d->t_feat = (const float*)sc->feat.p; d->t_fnorm = (const float*)sc->fnorm.p;
-  d->t_fpresent = (const uint8_t*)sc->fpresent.p; d->t_fcount = (const uint32_t*)sc->fcount.p; d->t_ids = (const uint64_t*)sc->tids.p;
-  d->c_raw = (const BoxRaw*)s->raw.p; d->c_quality = (const float*)s->quality.p; d->c_own = (const float*)s->own.p;
-  d->c_fpresent_in = (const uint8_t*)s->fpresent_in.p; d->c_feat_raw = (const float*)s->feat_raw.p;
-  d->c_geo = (sa_geo*)s->geo.p; d->c_verts = (double*)s->verts.p; d->c_z = (float*)s->z.p;
-  d->c_conf = (float*)s->conf.p; d->c_feat = (float*)s->feat.p; d->c_fnorm = (float*)s->fnorm.p;
-  d->c_usable = (uint8_t*)s->usable.p;
-  d->pos = (float*)s->pos.p; d->vis = (float*)s->vis.p;
-  d->vis_max_key = (uint32_t*)s->vis_max_key.p;
-  d->row_part_w = (double*)s->row_part_w.p; d->row_part_t = (int32_t*)s->row_part_t.p;
-  d->col_part_w = (double*)s->col_part_w.p; d->col_part_q = (uint32_t*)s->col_part_q.p;
-  d->row_has = (uint8_t*)s->row_has.p; d->vis_winner = (int32_t*)s->vis_winner.p; d->col_excluded = (uint8_t*)s->col_excluded.p;
-  d->parent = (uint32_t*)s->parent.p; d->label = (uint32_t*)s->label.p; d->next_row = (uint32_t*)s->next_row.p;
-  d->e_cnt = (uint32_t*)s->e_cnt.p; d->e_col = (uint32_t*)s->e_col.p; d->e_gain = (int64_t*)s->e_gain.p;
-  d->u = (int64_t*)s->u.p; d->v = (int64_t*)s->v.p; d->rmatch = (int32_t*)s->rmatch.p; d->cmatch = (int32_t*)s->cmatch.p;
-  d->dist = (int64_t*)s->dist.p; d->pred = (int32_t*)s->pred.p; d->cstamp = (uint32_t*)s->cstamp.p; d->cscan = (uint32_t*)s->cscan.p;
-  d->cnext = (int32_t*)s->cnext.p; d->rdist = (int64_t*)s->rdist.p; d->rnext = (int32_t*)s->rnext.p;
-  d->out_track_id = (uint64_t*)s->d_out; d->out_vote = (uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8;
-  d->quant = (int64_t*)s->quant.p;
+  d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
+  d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
+  d->t_fpresent = (decltype(d->t_fpresent))(sc->fpresent.p); d->t_fcount = (decltype(d->t_fcount))(sc->fcount.p); d->t_ids = (decltype(d->t_ids))(sc->tids.p);
+  d->c_raw = (decltype(d->c_raw))(s->raw.p); d->c_quality = (decltype(d->c_quality))(s->quality.p); d->c_own = (decltype(d->c_own))(s->own.p);
+  d->c_fpresent_in = (decltype(d->c_fpresent_in))(s->fpresent_in.p); d->c_feat_raw = (decltype(d->c_feat_raw))(s->feat_raw.p);
+  d->c_geo = (decltype(d->c_geo))(s->geo.p); d->c_verts = (decltype(d->c_verts))(s->verts.p); d->c_z = (decltype(d->c_z))(s->z.p);
+  d->c_conf = (decltype(d->c_conf))(s->conf.p); d->c_feat = (decltype(d->c_feat))(s->feat.p); d->c_fnorm = (decltype(d->c_fnorm))(s->fnorm.p);
+  d->c_usable = (decltype(d->c_usable))(s->usable.p);
+  d->pos = (decltype(d->pos))(s->pos.p); d->vis = (decltype(d->vis))(s->vis.p);
+  d->vis_max_key = (decltype(d->vis_max_key))(s->vis_max_key.p);
+  d->row_part_w = (decltype(d->row_part_w))(s->row_part_w.p); d->row_part_t = (decltype(d->row_part_t))(s->row_part_t.p);
+  d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
+  d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
+  d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
+  d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_col = (decltype(d->e_col))(s->e_col.p); d->e_gain = (decltype(d->e_gain))(s->e_gain.p);
+  d->u = (decltype(d->u))(s->u.p); d->v = (decltype(d->v))(s->v.p); d->rmatch = (decltype(d->rmatch))(s->rmatch.p); d->cmatch = (decltype(d->cmatch))(s->cmatch.p);
+  d->dist = (decltype(d->dist))(s->dist.p); d->pred = (decltype(d->pred))(s->pred.p); d->cstamp = (decltype(d->cstamp))(s->cstamp.p); d->cscan = (decltype(d->cscan))(s->cscan.p);
+  d->cnext = (decltype(d->cnext))(s->cnext.p); d->rdist = (decltype(d->rdist))(s->rdist.p); d->rnext = (decltype(d->rnext))(s->rnext.p);
+  d->out_track_id = (decltype(d->out_track_id))(s->d_out); d->out_vote = (decltype(d->out_vote))((uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8);
+  d->quant = (decltype(d->quant))(s->quant.p);
 }
 
 // Descriptors go through one pinned buffer.  A run that finds them unchanged (a benchmark loop, or a frame

@@ -19,12 +19,33 @@
 //            on near-identical vectors, which are exactly the true matches (SURVEY §7 hard parts).
 #include "sa_engine.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Pointers that reach a kernel through the SceneDev descriptor are generic ("flat") to the compiler: their loads become
+// flat_load, which counts on BOTH vmcnt and lgkmcnt — every s_waitcnt lgkmcnt for an LDS fragment then also drains the
+// feature loads in flight and the software pipeline collapses (C2: 20 -> 41 us).  The feature operands are therefore
+// re-typed as global-address-space pointers before the main loop.
+#define SA_AS1 __attribute__((address_space(1)))
+typedef const SA_AS1 float* gfloat_p;
+typedef const SA_AS1 f32x4* gf32x4_p;
 
 #define BK 32
+
+// In-kernel timeline (build with -DSA_GEMM_TRACE, run with SA_GEMM_TRACE=<launch #> to dump gpurun_out/gemm_trace.txt):
+// s_memtime stamps per workgroup at  0 entry | 1 prologue done | 2 main loop done | 3 k-group reduction done |
+// 4 epilogue stores issued | 5 exit.  Compiled out of the product.
+#ifdef SA_GEMM_TRACE
+#define SA_STAMP(tr, i) do { if ((tr) && threadIdx.x == 0) (tr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ uint64_t* g_trace_dev;
+#define SA_TRACE_PTR() (g_trace_dev ? g_trace_dev + 8 * (blockIdx.x + blockIdx.y * gridDim.x) : nullptr)
+#else
+#define SA_STAMP(tr, i) do { } while (0)
+#define SA_TRACE_PTR() nullptr
+#endif
 
 // Physical float offset of logical 16-byte chunk `kc` (0..7) of row `row` in a [rows][32] f32 LDS tile.
 // XOR with (row>>1)&7: with a 128-B row stride, the 16 rows one ds_read_b128 lane group touches land on
@@ -32,65 +53,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t kc) { return row * BK + ((kc ^ ((row >> 1) & 7u)) << 2); }
 
 struct GemmCols {   // per-lane column metadata kept in registers through the epilogue
-  float nb;
-  bool ok;
+  float nb;         // squared norm of the stored feature
+  bool ok;          // feature present, track long enough, epoch distance within max_idle_epochs
+  float cmax;       // max_dist of the spatio-temporal constraint that applies to this column's epoch distance; < 0 = none
   sa_geo g;
-  uint64_t epoch;
 };
 
 // Dp is a multiple of 32, so a 32-float chunk is either entirely inside a row or absent; rows past the
 // matrix edge are clamped to the last row (their results are never stored) — no branches around the loads.
 //
-// Pipeline per k-group (256 threads, 2 LDS stages of (BM+BN) x 32 floats), ONE barrier per 32-deep chunk:
-//   iteration c:  ds_read the fragments of stage c&1 | ds_write chunk c+1 (already in registers) to the other
-//                 stage | issue the global loads of chunk c+2 | MFMAs of chunk c | barrier.
-// The LDS write and the L2/HBM loads of the next chunks sit between the MFMAs of the current one, so the matrix
-// pipe only sees one LDS read latency and one barrier per chunk.
+// Pipeline per k-group (256 threads, 2 LDS stages of (BM+BN) x 32 floats), ONE barrier per 32-deep chunk.
+// f32 MFMA is slow (64 cycles per 32x32x2 on a SIMD), so LDS and L2 bandwidth are never the limit; what costs is every
+// cycle a wave spends issuing something else while its matrix pipe is free.  Iteration c is therefore laid out as four
+// k-steps (8 floats of k each), each one a straight run of 4*TM*TN MFMAs with the other work of the iteration placed
+// in their shadow (an MFMA takes 4 cycles to issue and 64 to execute; the wave keeps issuing meanwhile):
+//     k-step kk:  MFMAs on fragment buffer kk&1
+//                 | ds_read the fragments of k-step kk+1 into the other fragment buffer
+//                 | a quarter of: ds_write chunk c+1 (already in registers) to the other LDS stage, then re-issue those
+//                   registers' global loads for chunk c+2
+// Only the fragment read of k-step 0 (right after the barrier) is exposed; the co-resident workgroup covers it.
+// The body is branch-free (three specialisations: steady state / last-but-one chunk / last chunk) so that the whole
+// iteration is ONE scheduling region, pinned with sched_group_barrier; measured against the same loop with the loads and
+// stores hoisted to the top of the iteration (what the compiler does on its own): 110 -> see profiles/.
 template <int BM, int BN, int KG>
-__device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+__device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M,
                                               uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
-                                              f32x16 (&acc)[BM / 64][BN / 64]) {
+                                              f32x16 (&acc)[BM / 64][BN / 64], uint64_t* tr = nullptr) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per stage
+  constexpr int L_CH = A_CH + B_CH;                          // 4 (64x64) .. 8 (128x128): a multiple of 4 or exactly 6
   constexpr int STAGE = (BM + BN) * BK;                     // floats per LDS stage
   const uint32_t tid = threadIdx.x;
-  const uint32_t kg = tid >> 8;          // k-group of this wave (0 when KG == 1)
+  // k-group of this wave (0 when KG == 1).  readfirstlane: the value is wave-uniform, and telling the compiler so keeps
+  // every branch of the main loop scalar — with a divergent-looking branch it parks the 16-64 accumulator registers
+  // in VGPRs and copies them to and from the matrix-core register file on EVERY chunk (128 v_accvgpr moves + a
+  // pipeline drain per 64 MFMAs in the 128x128 kernel).
+  const uint32_t kg = KG == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 8));
   const uint32_t ltid = tid & 255u, lane = tid & 63u, w4 = (tid >> 6) & 3u;
   float* base = lds + kg * 2 * STAGE;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u;
   const uint32_t lr = lane & 31u, lh = lane >> 5;
   const uint32_t nchunks = Dp / BK;
   const uint32_t niter = (nchunks + KG - 1) / KG;
-  uint32_t ga[A_CH], gb[B_CH], sa_[A_CH], sb_[B_CH];
+  // entries 0..A_CH-1 belong to A, the rest to B
+  uint32_t goff[L_CH], soff[L_CH];
 #pragma unroll
-  for (int r = 0; r < A_CH; ++r) {
-    uint32_t c = ltid + 256u * r, row = c >> 3, kc = c & 7u;
-    uint32_t gr = m0 + row;
-    gr = gr < M ? gr : M - 1;
-    ga[r] = gr * Dp + kc * 4u;
-    sa_[r] = lds_off(row, kc);
+  for (int r = 0; r < L_CH; ++r) {
+    const bool isA = r < A_CH;
+    uint32_t c = ltid + 256u * (isA ? r : r - A_CH), row = c >> 3, kc = c & 7u;
+    uint32_t gr = (isA ? m0 : n0) + row;
+    const uint32_t lim = isA ? M : Ncols;
+    gr = gr < lim ? gr : lim - 1;
+    goff[r] = gr * Dp + kc * 4u;
+    soff[r] = (isA ? 0 : BM * BK) + lds_off(row, kc);
   }
+  // Two register sets: the rows of chunk i+1 are written to LDS from set (i+1)&1, which is then reloaded with chunk i+3 —
+  // whatever place inside the iteration the scheduler gives a load, it has at least one whole iteration to land (with
+  // one set, loads that sink to the end of an iteration are consumed 5 MFMAs later: a full L2 round trip exposed per
+  // chunk, 28 us instead of 15 at C2).
+  f32x4 rg[2][L_CH];
+  auto gload_set = [&](int set, uint32_t k0) {
 #pragma unroll
-  for (int r = 0; r < B_CH; ++r) {
-    uint32_t c = ltid + 256u * r, row = c >> 3, kc = c & 7u;
-    uint32_t gr = n0 + row;
-    gr = gr < Ncols ? gr : Ncols - 1;
-    gb[r] = gr * Dp + kc * 4u;
-    sb_[r] = BM * BK + lds_off(row, kc);
-  }
-  f32x4 ra[A_CH], rb[B_CH];
-  auto gload = [&](uint32_t chunk) {
-    const uint32_t k0 = chunk * BK;
-#pragma unroll
-    for (int r = 0; r < A_CH; ++r) ra[r] = *(const f32x4*)(A + (size_t)(ga[r] + k0));
-#pragma unroll
-    for (int r = 0; r < B_CH; ++r) rb[r] = *(const f32x4*)(B + (size_t)(gb[r] + k0));
-  };
-  auto lstore = [&](float* st) {
-#pragma unroll
-    for (int r = 0; r < A_CH; ++r) *(f32x4*)(st + sa_[r]) = ra[r];
-#pragma unroll
-    for (int r = 0; r < B_CH; ++r) *(f32x4*)(st + sb_[r]) = rb[r];
+    for (int r = 0; r < L_CH; ++r) rg[set][r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + k0));
   };
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -105,37 +129,247 @@ __device__ __forceinline__ void gemm_mainloop(const float* __restrict__ A, const
 #pragma unroll
   for (int n = 0; n < TN; ++n) boff[n] = wn * (BN / 2) + n * 32 + lr;
 
-  if (kg < nchunks) { gload(kg); lstore(base); }
-  if (kg + KG < nchunks) gload(kg + KG);
+  // chunks of this group: local index i <-> chunk i*KG + kg, i < mine
+  const uint32_t mine = kg < nchunks ? (nchunks - kg + KG - 1) / KG : 0u;
+  if (mine > 0) {
+    gload_set(0, kg * BK);
+#pragma unroll
+    for (int r = 0; r < L_CH; ++r) *(f32x4*)(base + soff[r]) = rg[0][r];
+  }
+  if (mine > 1) gload_set(1, (kg + KG) * BK);
+  if (mine > 2) gload_set(0, (kg + 2 * KG) * BK);
   __syncthreads();
-  for (uint32_t it = 0; it < niter; ++it) {
-    const uint32_t chunk = it * KG + kg;          // uniform inside a k-group
+  SA_STAMP(tr, 1);
+
+  // One iteration.  SET = (i+1)&1; STORE: chunk i+1 exists (set -> other LDS stage); LOAD: chunk i+3 exists (global -> set).
+  auto body = [&](uint32_t it, auto set_tag, auto store_tag, auto load_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    constexpr bool STORE = decltype(store_tag)::value, LOAD = decltype(load_tag)::value;
     const float* As = base + (it & 1u) * STAGE;
     const float* Bs = As + BM * BK;
     float* nxt = base + ((it + 1u) & 1u) * STAGE;
-    if (chunk < nchunks) {
-      f32x4 fa[4][TM], fb[4][TN];
+    const uint32_t k3 = ((it + 3u) * KG + kg) * BK;
+    f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+    for (int m = 0; m < TM; ++m) fa[0][m] = *(const f32x4*)(As + lds_off(aoff[m], lh));
 #pragma unroll
-        for (int m = 0; m < TM; ++m) fa[kk][m] = *(const f32x4*)(As + lds_off(aoff[m], kk * 2 + lh));
+    for (int n = 0; n < TN; ++n) fb[0][n] = *(const f32x4*)(Bs + lds_off(boff[n], lh));
+    auto kstep = [&](auto kk_tag) {
+      constexpr int kk = decltype(kk_tag)::value;
+      constexpr int cur = kk & 1, nx = cur ^ 1;
+      if constexpr (kk < 3) {
 #pragma unroll
-        for (int n = 0; n < TN; ++n) fb[kk][n] = *(const f32x4*)(Bs + lds_off(boff[n], kk * 2 + lh));
+        for (int m = 0; m < TM; ++m) fa[nx][m] = *(const f32x4*)(As + lds_off(aoff[m], (kk + 1) * 2 + lh));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[nx][n] = *(const f32x4*)(Bs + lds_off(boff[n], (kk + 1) * 2 + lh));
       }
-      if (chunk + KG < nchunks) lstore(nxt);          // chunk c+1 -> the other stage
-      if (chunk + 2 * KG < nchunks) gload(chunk + 2 * KG);  // chunk c+2 -> registers
+      // this k-step's share of the register -> LDS -> register hand-over of the staged rows
+      constexpr int lo_of[5] = {0, (L_CH + 3) / 4, (L_CH + 1) / 2, (3 * L_CH + 3) / 4, L_CH};
+      constexpr int lo = lo_of[kk], hi = lo_of[kk + 1];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int r = lo; r < hi; ++r) {
+        if constexpr (STORE) *(f32x4*)(nxt + soff[r]) = rg[SET][r];
+        if constexpr (LOAD) rg[SET][r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + k3));
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int m = 0; m < TM; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int n = 0; n < TN; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][m][e], fb[kk][n][e], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < TN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m][e], fb[cur][n][e], acc[m][n], 0, 0, 0);
+      // pin the interleave: one side instruction in the shadow of each of the first MFMAs of the k-step
+      constexpr int NM = 4 * TM * TN;
+      constexpr int nrd = kk < 3 ? TM + TN : 0, nst = STORE ? hi - lo : 0, nld = LOAD ? hi - lo : 0;
+      constexpr int used = nrd + nst + nld;
+#pragma unroll
+      for (int i = 0; i < nrd; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+      for (int i = 0; i < (nst > nld ? nst : nld); ++i) {
+        if (i < nst) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+        if (i < nld) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+      }
+      if constexpr (used < NM) __builtin_amdgcn_sched_group_barrier(0x008, NM - used, 0);
+    };
+    kstep(std::integral_constant<int, 0>{});
+    kstep(std::integral_constant<int, 1>{});
+    kstep(std::integral_constant<int, 2>{});
+    kstep(std::integral_constant<int, 3>{});
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  uint32_t it = 0;
+  // steady state two iterations per trip, so that the register set is a compile-time constant (set of iteration i = (i+1)&1)
+  for (; it + 4 < mine; it += 2) {
+    body(it, S1{}, T_{}, T_{});
+    __syncthreads();
+    body(it + 1, S0{}, T_{}, T_{});
+    __syncthreads();
+  }
+  for (; it < mine; ++it) {  // at most 4 iterations left; `it` is even on entry
+    const bool st = it + 1 < mine, ld = it + 3 < mine;
+    if (it & 1u) {
+      if (ld) body(it, S0{}, T_{}, T_{});
+      else if (st) body(it, S0{}, T_{}, F_{});
+      else body(it, S0{}, F_{}, F_{});
+    } else {
+      if (ld) body(it, S1{}, T_{}, T_{});
+      else if (st) body(it, S1{}, T_{}, F_{});
+      else body(it, S1{}, F_{}, F_{});
     }
     __syncthreads();
   }
+  for (; it < niter; ++it) __syncthreads();  // a group that ran out of chunks still meets the others at the barrier
+  SA_STAMP(tr, 2);
+}
+
+// Ring variant (KG == 0 in the kernel templates): ONE wave per SIMD, a 3-stage LDS ring, nothing left for a partner wave
+// to cover.  Used where a frame yields about one workgroup per CU (C2: 16 x 16 tiles of 64x64 on 256 CUs), so that the
+// k-group trick above would put the two waves of a SIMD behind the SAME barrier — they then stall together (measured:
+// 2583 cycles per iteration against 2048 of MFMA work).  Here a wave's own instruction stream keeps its matrix pipe fed:
+//     iteration c:  MFMAs of chunk c from stage c%3, fragments double-buffered in registers
+//                   | ds_write chunk c+2 (registers, loaded two iterations ago) -> stage (c+2)%3
+//                   | re-issue those registers' global loads for chunk c+4
+//                   | during the LAST k-step: ds_read the first fragments of chunk c+1 (stage (c+1)%3, complete since the
+//                     previous barrier) — so nothing but the barrier itself sits between two chunks' MFMAs.
+// Hazards: stage (c+2)%3 was last read in iteration c-1, and every wave has passed that iteration's barrier.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_mainloop_ring(gfloat_p A, gfloat_p B, uint32_t M,
+                                                   uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
+                                                   f32x16 (&acc)[BM / 64][BN / 64], uint64_t* tr = nullptr) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256, L_CH = A_CH + B_CH;
+  constexpr int STAGE = (BM + BN) * BK;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = tid >> 6;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  const uint32_t nchunks = Dp / BK;
+  uint32_t goff[L_CH], soff[L_CH];
+#pragma unroll
+  for (int r = 0; r < L_CH; ++r) {
+    const bool isA = r < A_CH;
+    uint32_t c = tid + 256u * (isA ? r : r - A_CH), row = c >> 3, kc = c & 7u;
+    uint32_t gr = (isA ? m0 : n0) + row;
+    const uint32_t lim = isA ? M : Ncols;
+    gr = gr < lim ? gr : lim - 1;
+    goff[r] = gr * Dp + kc * 4u;
+    soff[r] = (isA ? 0 : BM * BK) + lds_off(row, kc);
+  }
+  f32x4 rg[2][L_CH];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  uint32_t aoff[TM], boff[TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) aoff[m] = wm * (BM / 2) + m * 32 + lr;
+#pragma unroll
+  for (int n = 0; n < TN; ++n) boff[n] = wn * (BN / 2) + n * 32 + lr;
+
+  // prologue: chunks 0 and 1 -> stages 0 and 1; chunks 2 and 3 -> register sets 0 and 1
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if ((uint32_t)c < nchunks) {
+#pragma unroll
+      for (int r = 0; r < L_CH; ++r) rg[c & 1][r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + c * BK));
+      if (c < 2) {
+#pragma unroll
+        for (int r = 0; r < L_CH; ++r) *(f32x4*)(lds + c * STAGE + soff[r]) = rg[c & 1][r];
+      }
+    }
+  __syncthreads();
+  SA_STAMP(tr, 1);
+  f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) fa[0][m] = *(const f32x4*)(lds + lds_off(aoff[m], lh));
+#pragma unroll
+  for (int n = 0; n < TN; ++n) fb[0][n] = *(const f32x4*)(lds + BM * BK + lds_off(boff[n], lh));
+
+  // PAR: parity of the iteration (selects the register set); STORE: chunk c+2 exists; LOAD: chunk c+4 exists;
+  // NEXT: chunk c+1 exists (prefetch its first fragments)
+  auto body = [&](uint32_t c, uint32_t st, auto par_tag, auto store_tag, auto load_tag, auto next_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr bool STORE = decltype(store_tag)::value, LOAD = decltype(load_tag)::value, NEXT = decltype(next_tag)::value;
+    const uint32_t st1 = st == 2 ? 0u : st + 1u, st2 = st == 0 ? 2u : st - 1u;  // (c+1)%3, (c+2)%3
+    const float* As = lds + st * STAGE;
+    const float* Bs = As + BM * BK;
+    const float* An = lds + st1 * STAGE;
+    const float* Bn = An + BM * BK;
+    float* wr = lds + st2 * STAGE;
+    const uint32_t k4 = (c + 4u) * BK;
+    auto kstep = [&](auto kk_tag) {
+      constexpr int kk = decltype(kk_tag)::value;
+      constexpr int cur = kk & 1, nx = cur ^ 1;
+      if constexpr (kk < 3) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) fa[nx][m] = *(const f32x4*)(As + lds_off(aoff[m], (kk + 1) * 2 + lh));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[nx][n] = *(const f32x4*)(Bs + lds_off(boff[n], (kk + 1) * 2 + lh));
+      } else if constexpr (NEXT) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) fa[nx][m] = *(const f32x4*)(An + lds_off(aoff[m], lh));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[nx][n] = *(const f32x4*)(Bn + lds_off(boff[n], lh));
+      }
+      constexpr int lo_of[5] = {0, (L_CH + 3) / 4, (L_CH + 1) / 2, (3 * L_CH + 3) / 4, L_CH};
+      constexpr int lo = lo_of[kk], hi = lo_of[kk + 1];
+#pragma unroll
+      for (int r = lo; r < hi; ++r) {
+        if constexpr (STORE) *(f32x4*)(wr + soff[r]) = rg[PAR][r];
+        if constexpr (LOAD) rg[PAR][r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + k4));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m][e], fb[cur][n][e], acc[m][n], 0, 0, 0);
+      constexpr int NM = 4 * TM * TN;
+      constexpr int nrd = (kk < 3 || NEXT) ? TM + TN : 0, nst = STORE ? hi - lo : 0, nld = LOAD ? hi - lo : 0;
+      constexpr int used = nrd + nst + nld;
+#pragma unroll
+      for (int i = 0; i < nrd; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+      for (int i = 0; i < (nst > nld ? nst : nld); ++i) {
+        if (i < nst) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+        if (i < nld) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+      }
+      if constexpr (used < NM) __builtin_amdgcn_sched_group_barrier(0x008, NM - used, 0);
+    };
+    kstep(std::integral_constant<int, 0>{});
+    kstep(std::integral_constant<int, 1>{});
+    kstep(std::integral_constant<int, 2>{});
+    kstep(std::integral_constant<int, 3>{});
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  uint32_t c = 0, st = 0;
+  auto adv = [&]() { ++c; st = st == 2 ? 0u : st + 1u; __syncthreads(); };
+  // steady state, two iterations per trip so that the register-set parity is static
+  for (; c + 5 < nchunks; ) { body(c, st, P0{}, T_{}, T_{}, T_{}); adv(); body(c, st, P1{}, T_{}, T_{}, T_{}); adv(); }
+  // c is even here.  Remaining chunks: at most 5.
+  if (c + 4 < nchunks) { body(c, st, P0{}, T_{}, T_{}, T_{}); adv(); }          // c+4 exists
+  // from here no more loads; parity alternates from (c & 1)
+  while (c < nchunks) {
+    const bool store = c + 2 < nchunks, next = c + 1 < nchunks;
+    if (c & 1u) {
+      if (store) body(c, st, P1{}, T_{}, F_{}, T_{});
+      else if (next) body(c, st, P1{}, F_{}, F_{}, T_{});
+      else body(c, st, P1{}, F_{}, F_{}, F_{});
+    } else {
+      if (store) body(c, st, P0{}, T_{}, F_{}, T_{});
+      else if (next) body(c, st, P0{}, F_{}, F_{}, T_{});
+      else body(c, st, P0{}, F_{}, F_{}, F_{});
+    }
+    adv();
+  }
+  SA_STAMP(tr, 2);
 }
 
 // k-group reductions (64x64 tile only: one 32x32 accumulator per wave).  Every group parks its 16 partial
@@ -189,11 +423,14 @@ __device__ __forceinline__ void block_max_key(uint32_t* shards, uint32_t kmax, f
   }
 }
 
-// Everything the reference does per (candidate, observation) pair after the dot product.
-__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, bool us, const sa_geo& cg, uint64_t epoch,
-                                             const GemmCols& col, uint32_t* kmax) {
+// Everything the reference does per (candidate, observation) pair after the dot product.  compatible() (sort.rs:250-270)
+// compares the candidate's epoch — the same for every row of a scene-frame — with the track's, so its epoch part and the
+// choice of the constraint (spatio_temporal_constraints.rs:48-59) are per-COLUMN facts, folded into GemmCols before the
+// main loop; what is left per cell is dist_in_2r <= max_dist when a constraint applies.
+__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, bool us, const sa_geo& cg, const GemmCols& col,
+                                             uint32_t* kmax) {
   float out = __builtin_nanf("");
-  if (us && col.ok && sa_compatible(cg, epoch, col.g, col.epoch, p.max_idle, p.cons)) {
+  if (us && col.ok && (col.cmax < 0.0f || sa_dist_in_2r(cg, col.g) <= col.cmax)) {
     // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
     // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
     float d = dot * __frsqrt_rn(na * col.nb);
@@ -206,34 +443,31 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
   return out;
 }
 
-template <int BM, int BN, int KG>
-__global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+template <int BM, int BN, int KGT>
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
+  uint64_t* tr = SA_TRACE_PTR();
+  SA_STAMP(tr, 0);
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
-  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (BM + BN) * BK];
-  f32x16 acc[TM][TN];
-  gemm_mainloop<BM, BN, KG>(S.c_feat, S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
-
+  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
-  constexpr int R = 16 / KG;
-  float part[TM == 1 && TN == 1 ? R : 1];
-  if constexpr (TM == 1 && TN == 1) kgroup_reduce_spread<KG>(acc[0][0], lds, part);
-
-  // ---- fused epilogue: row metadata through LDS, column metadata in registers ----
-  float* s_na = lds;                      // [BM]
-  float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
-  sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
-  for (uint32_t r = tid; r < (uint32_t)BM; r += 256 * KG) {
-    uint32_t gi = m0 + r;
-    bool in = gi < N;
-    s_na[r] = in ? S.c_fnorm[gi] : 0.f;
-    s_us[r] = (in && S.c_usable[gi]) ? 1.f : 0.f;
-    s_g[r] = in ? S.c_geo[gi] : sa_geo{0.f, 0.f, 0.f, 0.f};
+  // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
+  // dependent loads that used to sit, fully exposed, between the last MFMA and the first store: ~2 us of a 18 us kernel at
+  // C2) disappears behind the main loop.  Row operands: thread r < BM holds row r (goes through LDS afterwards).
+  float pre_na = 0.f, pre_us = 0.f;
+  sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  static_assert(BM <= 256, "one thread per tile row");
+  if (tid < (uint32_t)BM && m0 + tid < N) {
+    const uint32_t gi = m0 + tid;
+    pre_na = S.c_fnorm[gi];
+    pre_us = S.c_usable[gi] ? 1.f : 0.f;
+    pre_g = sa_ldg(S.c_geo + gi);
   }
   GemmCols col[TN];
 #pragma unroll
@@ -241,18 +475,43 @@ __global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __re
     uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
     col[n].ok = false;
     col[n].nb = 0.f;
+    col[n].cmax = -1.0f;
     col[n].g = sa_geo{0.f, 0.f, 0.f, 0.f};
-    col[n].epoch = 0;
     if (gj < TK) {
-      uint32_t t = gj / K;
-      col[n].nb = S.t_fnorm[gj];
-      col[n].ok = S.t_fpresent[gj] != 0 && S.t_fcount[t] >= p.min_track_len;
-      col[n].g = S.t_geo[t];
-      col[n].epoch = S.t_epoch[t];
+      // independent loads, no short-circuit: one round trip instead of a chain of three
+      const uint32_t t = gj / K;
+      const float nb = S.t_fnorm[gj];
+      const uint8_t pres = S.t_fpresent[gj];
+      const uint32_t cnt = S.t_fcount[t];
+      const uint64_t te = S.t_epoch[t];
+      col[n].g = sa_ldg(S.t_geo + t);
+      col[n].nb = nb;
+      const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
+      col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
+      for (uint32_t i = 0; i < p.cons.n; ++i)
+        if (p.cons.delta[i] >= delta) { col[n].cmax = p.cons.max_dist[i]; break; }
     }
   }
+
+  f32x16 acc[TM][TN];
+  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+  else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+
+  constexpr int R = 16 / KG;
+  float part[TM == 1 && TN == 1 ? R : 1];
+  if constexpr (TM == 1 && TN == 1) kgroup_reduce_spread<KG>(acc[0][0], lds, part);
+  SA_STAMP(tr, 3);
+
+  // ---- fused epilogue: row metadata through LDS, column metadata in registers ----
+  float* s_na = lds;                      // [BM]
+  float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
+  sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
+  if (tid < (uint32_t)BM) {
+    s_na[tid] = pre_na;
+    s_us[tid] = pre_us;
+    s_g[tid] = pre_g;
+  }
   __syncthreads();
-  const uint64_t epoch = S.epoch;
   uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
   if constexpr (TM == 1 && TN == 1) {
     const uint32_t gj = n0 + wn * 32 + lr;
@@ -261,7 +520,7 @@ __global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __re
       const uint32_t li = wm * 32 + acc_row(kg * R + i, lh);
       const uint32_t gi = m0 + li;
       if (gi < N && gj < TK)
-        S.vis[(size_t)gi * TK + gj] = visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], epoch, col[0], &kmax);
+        S.vis[(size_t)gi * TK + gj] = visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax);
     }
   } else {
 #pragma unroll
@@ -277,16 +536,18 @@ __global__ __launch_bounds__(256 * KG) void k_visual_cosine(const SceneDev* __re
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           const uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
-          if (gj < TK) S.vis[(size_t)gi * TK + gj] = visual_cell(p, acc[m][n][r], na, us, cg, epoch, col[n], &kmax);
+          if (gj < TK) S.vis[(size_t)gi * TK + gj] = visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax);
         }
       }
   }
+  SA_STAMP(tr, 4);
   block_max_key(S.vis_max_key, kmax, lds);
+  SA_STAMP(tr, 5);
 }
 
 // Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
 // swizzled LDS tiles.  Column c of a thread is tx + 16*c so a wave's stores cover 64-B row segments.
-__device__ __forceinline__ void euclid_mainloop(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+__device__ __forceinline__ void euclid_mainloop(gfloat_p A, gfloat_p B, uint32_t M,
                                                 uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
                                                 float (&acc)[4][4]) {
   constexpr int BM = 64, BN = 64;
@@ -297,8 +558,8 @@ __device__ __forceinline__ void euclid_mainloop(const float* __restrict__ A, con
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  const float* pa[2];
-  const float* pb[2];
+  gfloat_p pa[2];
+  gfloat_p pb[2];
   uint32_t so[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -312,14 +573,14 @@ __device__ __forceinline__ void euclid_mainloop(const float* __restrict__ A, con
   }
   f32x4 ra[2], rb[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) { ra[r] = *(const f32x4*)pa[r]; rb[r] = *(const f32x4*)pb[r]; }
+  for (int r = 0; r < 2; ++r) { ra[r] = *(gf32x4_p)pa[r]; rb[r] = *(gf32x4_p)pb[r]; }
   for (uint32_t k0 = 0; k0 < Dp; k0 += BK) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) { *(f32x4*)(As + so[r]) = ra[r]; *(f32x4*)(Bs + so[r]) = rb[r]; }
     __syncthreads();
     if (k0 + BK < Dp) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) { ra[r] = *(const f32x4*)(pa[r] + k0 + BK); rb[r] = *(const f32x4*)(pb[r] + k0 + BK); }
+      for (int r = 0; r < 2; ++r) { ra[r] = *(gf32x4_p)(pa[r] + k0 + BK); rb[r] = *(gf32x4_p)(pb[r] + k0 + BK); }
     }
 #pragma unroll
     for (uint32_t kc = 0; kc < 8; ++kc) {
@@ -350,7 +611,7 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
   if (m0 >= N || n0 >= TK) return;
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
   float acc[4][4];
-  euclid_mainloop(S.c_feat, S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
+  euclid_mainloop((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
   const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
@@ -360,7 +621,7 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
     uint32_t gi = m0 + ty * 4 + i;
     if (gi >= N) continue;
     bool us = S.c_usable[gi] != 0;
-    sa_geo cg = S.c_geo[gi];
+    sa_geo cg = sa_ldg(S.c_geo + gi);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint32_t gj = n0 + tx + 16 * j;
@@ -368,7 +629,7 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
       uint32_t t = gj / K;
       float out = nanv;
       if (us && S.t_fpresent[gj] && S.t_fcount[t] >= p.min_track_len &&
-          sa_compatible(cg, epoch, S.t_geo[t], S.t_epoch[t], p.max_idle, p.cons)) {
+          sa_compatible(cg, epoch, sa_ldg(S.t_geo + t), S.t_epoch[t], p.max_idle, p.cons)) {
         float d = sqrtf(acc[i][j]);
         if (d <= p.visual_threshold) {
           out = d;
@@ -383,22 +644,27 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
 }
 
 // ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----
-template <int BM, int BN, int KG>
-__global__ __launch_bounds__(256 * KG) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
+template <int BM, int BN, int KGT>
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
                                                             const float* __restrict__ B, const float* __restrict__ bn,
                                                             uint32_t M, uint32_t Ncols, uint32_t Dp, float* __restrict__ out) {
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  uint64_t* tr = SA_TRACE_PTR();
+  SA_STAMP(tr, 0);
   constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int KG = KGT ? KGT : 1;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
-  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   f32x16 acc[TM][TN];
-  gemm_mainloop<BM, BN, KG>(A, B, M, Ncols, Dp, m0, n0, lds, acc);
+  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
+  else gemm_mainloop<BM, BN, KG>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   if constexpr (TM == 1 && TN == 1) {
     constexpr int R = 16 / KG;
     float part[R];
     kgroup_reduce_spread<KG>(acc[0][0], lds, part);
+    SA_STAMP(tr, 3);
     const uint32_t gj = n0 + wn * 32 + lr;
     const float nb = bn[gj < Ncols ? gj : Ncols - 1];
     float na[R];
@@ -440,6 +706,7 @@ __global__ __launch_bounds__(256 * KG) void k_cosine_matrix(const float* __restr
         }
       }
   }
+  SA_STAMP(tr, 4);
 }
 
 __global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
@@ -448,7 +715,7 @@ __global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
   float acc[4][4];
-  euclid_mainloop(A, B, M, Ncols, Dp, m0, n0, lds, acc);
+  euclid_mainloop((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc);
   const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -462,17 +729,61 @@ __global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__
   }
 }
 
+#ifdef SA_GEMM_TRACE
+// dumps the stamps of the PREVIOUS launches when the call counter reaches $SA_GEMM_TRACE
+static void sa_trace_hook(hipStream_t st, uint32_t nb) {
+  static uint64_t* buf = nullptr;
+  static int calls = 0;
+  const char* env = getenv("SA_GEMM_TRACE");
+  if (!env) return;
+  if (!buf) {
+    hipMalloc(&buf, 8 * 8 * 65536);
+    hipMemset(buf, 0, 8 * 8 * 65536);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace_dev), &buf, sizeof(void*));
+  }
+  if (++calls != atoi(env)) return;
+  hipStreamSynchronize(st);
+  if (nb > 65536) nb = 65536;
+  uint64_t* h = (uint64_t*)malloc((size_t)nb * 64);
+  hipMemcpy(h, buf, (size_t)nb * 64, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen("gpurun_out/gemm_trace.txt", "w")) {
+    for (uint32_t i = 0; i < nb; ++i)
+      if (h[i * 8])
+        fprintf(f, "%u %llu %llu %llu %llu %llu %llu\n", i, (unsigned long long)h[i * 8], (unsigned long long)h[i * 8 + 1],
+                (unsigned long long)h[i * 8 + 2], (unsigned long long)h[i * 8 + 3], (unsigned long long)h[i * 8 + 4],
+                (unsigned long long)h[i * 8 + 5]);
+    fclose(f);
+  }
+  free(h);
+}
+#else
+static inline void sa_trace_hook(hipStream_t, uint32_t) {}
+#endif
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Tile choice by the number of workgroups the frame yields on 256 CUs:
-//   128x128 when that alone gives >= 192 workgroups; else 64x64, with the k dimension split over 2 or 4 wave
-//   groups inside each workgroup when there are too few workgroups to put more than one wave on every SIMD.
+// Tile plans: 0 = 128x128, 5 = 64x128, 6 = 128x64 (4 waves, one k-group), 1/2/4 = 64x64 with 1/2/4 k-groups.
+// The contraction is matrix-core bound once every SIMD holds >= 2 waves, so a CU's time is (tiles it receives) x (tile
+// area); the plan minimises ceil(tiles / 256 CUs) x area x (1 + 16/BM + 16/BN) — the last factor is the measured cost of
+// the shorter MFMA runs between barriers on narrower tiles.  C5 (2000 x 5000): 128x128 gives 640 tiles = 2.5 per CU
+// (3 rounds of 16384 cells), 64x128 gives 1280 = 5 per CU (5 rounds of 8192 cells) — 17 % less work on the critical CU.
+// Frames that fit in one round of 64x64 tiles split k over 2 or 4 wave groups inside each workgroup so that every SIMD
+// still holds 2-4 waves.
 static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp) {
-  if (const char* f = getenv("SA_GEMM_PLAN")) return atoi(f);  // tuning override: 0 = 128x128, 1/2/4 = 64x64 with KG groups
-  if ((size_t)cdiv(M, 128) * cdiv(Ncols, 128) * ns >= 192) return 0;
-  size_t b64 = (size_t)cdiv(M, 64) * cdiv(Ncols, 64) * ns;
-  uint32_t nchunks = Dp / BK;
-  if (b64 <= 320 && nchunks >= 8) return 4;
+  if (const char* f = getenv("SA_GEMM_PLAN")) return atoi(f);  // tuning override
+  struct Cand { int plan, bm, bn; };
+  const Cand cands[4] = {{0, 128, 128}, {5, 64, 128}, {6, 128, 64}, {1, 64, 64}};
+  int best = 1;
+  double best_cost = 1e300;
+  for (const Cand& c : cands) {
+    const size_t tiles = (size_t)cdiv(M, c.bm) * cdiv(Ncols, c.bn) * ns;
+    const double rounds = (double)((tiles + 255) / 256);
+    const double cost = rounds * c.bm * c.bn * (1.0 + 16.0 / c.bm + 16.0 / c.bn);
+    if (cost < best_cost) { best_cost = cost; best = c.plan; }
+  }
+  if (best != 1) return best;
+  const size_t b64 = (size_t)cdiv(M, 64) * cdiv(Ncols, 64) * ns;
+  const uint32_t nchunks = Dp / BK;
+  if (b64 <= 320 && nchunks >= 8) return 2;
   if (b64 <= 768 && nchunks >= 4) return 2;
   return 1;
 }
@@ -480,16 +791,21 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
                             hipStream_t st) {
   if (!maxN || !maxTK) return hipSuccess;
+  sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     switch (tile_plan(maxN, maxTK, ns, Dp)) {
-      case 0: hipLaunchKernelGGL((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 4: hipLaunchKernelGGL((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
-      case 2: hipLaunchKernelGGL((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
-      default: hipLaunchKernelGGL((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
+      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
+      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
     }
   } else {
-    hipLaunchKernelGGL(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+    SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
   }
   return hipGetLastError();
 }
@@ -497,9 +813,14 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
                                      uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st) {
   if (!n || !t) return hipSuccess;
+  sa_trace_hook(st, cdiv(t, 64) * cdiv(n, 64));
   if (kind == SA_VIS_COSINE) {
     switch (tile_plan(n, t, 1, dp)) {
       case 0: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 1>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 5: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 1>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 7: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 0>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 8: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 0>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 6: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 4: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 4>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(1024), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 2: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 2>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(512), 0, st, a, an, b, bn, n, t, dp, out); break;
       default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;

@@ -10,6 +10,8 @@
 
 #define WAVE 64
 
+thread_local hipEvent_t sa_prof_start = nullptr, sa_prof_stop = nullptr;
+
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // =====================================================================================================
@@ -129,10 +131,10 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
     S.e_cnt[i] = 0;
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
-    BoxRaw r = S.c_raw[i];
-    prep_box_common(r, &S.c_geo[i], &S.c_verts[(size_t)i * 8]);
+    BoxRaw r = sa_ldg(S.c_raw + i);
+    prep_box_common(r, (sa_geo*)(S.c_geo + i), (double*)(S.c_verts + (size_t)i * 8));
     const sa_box& b = r.box;
-    float* z = &S.c_z[(size_t)i * 5];
+    float SA_G* z = S.c_z + (size_t)i * 5;
     z[0] = b.xc; z[1] = b.yc; z[2] = b.has_angle ? b.angle : 0.0f; z[3] = b.aspect; z[4] = b.height;
     S.c_conf[i] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
     bool usable = false;
@@ -185,10 +187,10 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
   const uint32_t tid = threadIdx.x;
   if (tid < POS_TI) {
     uint32_t i = i0 + tid;
-    s_cg[tid] = i < N ? S.c_geo[i] : sa_geo{0.f, 0.f, 0.f, 0.f};
+    s_cg[tid] = i < N ? sa_ldg(S.c_geo + i) : sa_geo{0.f, 0.f, 0.f, 0.f};
   } else if (tid >= 64 && tid < 64 + POS_TJ) {
     uint32_t lj = tid - 64, j = j0 + lj;
-    s_tg[lj] = j < T ? S.t_geo[j] : sa_geo{0.f, 0.f, 0.f, 0.f};
+    s_tg[lj] = j < T ? sa_ldg(S.t_geo + j) : sa_geo{0.f, 0.f, 0.f, 0.f};
     s_te[lj] = j < T ? S.t_epoch[j] : 0ull;
   }
   if (tid == 0) s_cnt = 0;
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       uint32_t li = c / POS_TJ, lj = c % POS_TJ;
       uint32_t i = i0 + li, j = j0 + lj;
       float m20[20], z5[5];
-      const float* mp = S.t_maha + (size_t)j * 20;
+      const float SA_G* mp = S.t_maha + (size_t)j * 20;
 #pragma unroll
       for (int k = 0; k < 20; ++k) m20[k] = mp[k];
-      const float* zp = S.c_z + (size_t)i * 5;
+      const float SA_G* zp = S.c_z + (size_t)i * 5;
 #pragma unroll
       for (int k = 0; k < 5; ++k) z5[k] = zp[k];
       S.pos[(size_t)i * T + j] = sa_maha_cell(m20, z5, S.c_conf[i]);
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       uint32_t li = c / POS_TJ, lj = c % POS_TJ;
       uint32_t i = i0 + li, j = j0 + lj;
       double cv[8], tv[8];
-      const double* cp = S.c_verts + (size_t)i * 8;
-      const double* tp = S.t_verts + (size_t)j * 8;
+      const double SA_G* cp = S.c_verts + (size_t)i * 8;
+      const double SA_G* tp = S.t_verts + (size_t)j * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cv[k] = cp[k]; tv[k] = tp[k]; }
       double inter = sa_clip_area_ws(cv, tv, ws, ws + SA_POLY_CAP * POS_WORKERS, ws + 2 * SA_POLY_CAP * POS_WORKERS,
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict
         egain[off] = g4[e];
         ++off;
         if (g4[e] > maxg) maxg = g4[e];
-        sa_uf_union(S.parent, q, S.N + t0 + e);
+        sa_uf_union((uint32_t*)S.parent, q, S.N + t0 + e);
       }
     cnt += __shfl(incl, WAVE - 1);
   }
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
   __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
   uint32_t lab = SA_NONE;
-  if (q < N && S.e_cnt[q]) lab = sa_uf_find(S.parent, q);
+  if (q < N && S.e_cnt[q]) lab = sa_uf_find((uint32_t*)S.parent, q);
   s_rmatch[q] = -1;
   if (!__syncthreads_or(lab != SA_NONE)) {  // nothing left for the positional vote (every row decided visually)
     if (q < N) {
@@ -558,16 +560,24 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
   __syncthreads();
   if (q < N && lab == q) {  // representative = minimum row of its component
-    sa_assign_ws w;
-    w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride;
-    w.next_row = s_next;
-    w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
+    // two call sites so that every pointer of the work set has ONE known address space (LDS or global) after inlining;
+    // a work set that is "LDS or global, decided at run time" compiles to flat_* accesses
     if (cols_in_lds) {
+      sa_assign_ws w;
+      w.e_cnt = (const uint32_t*)S.e_cnt; w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.estride = S.estride;
+      w.next_row = s_next;
+      w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
       w.v = s_v; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan; w.cnext = s_cnext;
+      sa_assign_component(w, q);
     } else {
-      w.v = S.v; w.cmatch = S.cmatch; w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
+      sa_assign_ws w;
+      w.e_cnt = (const uint32_t*)S.e_cnt; w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.estride = S.estride;
+      w.next_row = s_next;
+      w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
+      w.v = (int64_t*)S.v; w.cmatch = (int32_t*)S.cmatch; w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred;
+      w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan; w.cnext = (int32_t*)S.cnext;
+      sa_assign_component(w, q);
     }
-    sa_assign_component(w, q);
   }
   __syncthreads();
   if (q < N) {
@@ -588,7 +598,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  S.label[q] = S.e_cnt[q] ? sa_uf_find(S.parent, q) : SA_NONE;
+  S.label[q] = S.e_cnt[q] ? sa_uf_find((uint32_t*)S.parent, q) : SA_NONE;
 }
 
 __global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict__ scenes) {
@@ -658,13 +668,13 @@ hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t ns, uint32_t ma
                                 const SaParams& p, hipStream_t st) {
   uint32_t blocks = cdiv(maxN + maxT + 1, 256);
   if (visual && cdiv(maxN, 4) > blocks) blocks = cdiv(maxN, 4);
-  hipLaunchKernelGGL(k_frame_prep, dim3(blocks, 1, ns), dim3(256), 0, st, scenes, p);
+  SA_LAUNCH(k_frame_prep, dim3(blocks, 1, ns), dim3(256), 0, st, scenes, p);
   return hipGetLastError();
 }
 hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                                 hipStream_t st) {
   if (!maxN || !maxT) return hipSuccess;
-  hipLaunchKernelGGL(k_positional, dim3(cdiv(maxT, POS_TJ), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
+  SA_LAUNCH(k_positional, dim3(cdiv(maxT, POS_TJ), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
   return hipGetLastError();
 }
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, hipStream_t st) {
@@ -677,20 +687,20 @@ hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t ns, uint32_t max
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                              hipStream_t st, int stage) {
   if (!maxN || !maxT) return hipSuccess;
-  if (stage == 0) hipLaunchKernelGGL(k_bestfit_tile, dim3(cdiv(maxT, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
-  else hipLaunchKernelGGL(k_bestfit_resolve, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
+  if (stage == 0) SA_LAUNCH(k_bestfit_tile, dim3(cdiv(maxT, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+  else SA_LAUNCH(k_bestfit_resolve, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                             hipStream_t st, int stage) {
   if (!maxN) return hipSuccess;
   switch (stage) {
-    case 0: if (maxT) hipLaunchKernelGGL(k_assign_edges, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes, p); break;
-    case 1: hipLaunchKernelGGL(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    case 2: hipLaunchKernelGGL(k_assign_next, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes); break;
-    case 3: hipLaunchKernelGGL(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
-    case 4: hipLaunchKernelGGL(k_finalize, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    default: hipLaunchKernelGGL(k_assign_small, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); break;
+    case 0: if (maxT) SA_LAUNCH(k_assign_edges, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes, p); break;
+    case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
+    case 2: SA_LAUNCH(k_assign_next, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes); break;
+    case 3: SA_LAUNCH(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
+    case 4: SA_LAUNCH(k_finalize, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
+    default: SA_LAUNCH(k_assign_small, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); break;
   }
   return hipGetLastError();
 }

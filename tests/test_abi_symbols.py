@@ -1,0 +1,66 @@
+"""The drop-in boundary as a library: libsimilari_assoc.so loads without a GPU and exports every function that
+include/similari_assoc.h and include/similari_tracker.h declare; without a gfx950 device the product path fails loudly
+(SA_ERR_NO_DEVICE) instead of falling back to any CPU code."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from similari_amd import abi, build
+
+ROOT = Path(__file__).resolve().parent.parent
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|sa_engine\s*\*|const char\s*\*)\s*\*?\s*(sa_[a-z0-9_]+)\s*\(", re.M)
+
+
+def declared(header: str):
+    text = (ROOT / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(DECL.findall(text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return abi.load_library(build.build_lib())
+
+
+@pytest.mark.parametrize("header", ["similari_assoc.h", "similari_tracker.h"])
+def test_every_declared_function_is_exported(lib, header):
+    names = declared(header)
+    assert len(names) == (24 if header == "similari_assoc.h" else 15), names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"{header} declares functions the library does not export: {missing}"
+
+
+def test_no_oracle_or_cpu_fallback_linked():
+    so = build.build_lib()
+    out = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
+    assert " or_" not in out, "the product library must not contain oracle symbols"
+    deps = subprocess.run(["ldd", str(so)], capture_output=True, text=True).stdout
+    assert "liboracle" not in deps
+
+
+def test_struct_sizes_match_the_headers(lib):
+    assert lib.sa_api_version() == 1
+    assert C.sizeof(abi.sa_box) == 32 and abi.BOX_DTYPE.itemsize == 32
+    cfg = abi.sa_config()
+    lib.sa_config_default(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(abi.sa_config)  # the C side wrote its own sizeof
+    assert abs(cfg.positional_threshold - 0.3) < 1e-7 and abs(cfg.positional_min_confidence - 0.05) < 1e-7
+    o = abi.sa_tracker_options()
+    lib.sa_tracker_options_default(C.byref(o), 1)
+    assert o.struct_size == C.sizeof(abi.sa_tracker_options)
+    assert o.visual_max_observations == 5 and o.visual_minimal_track_length == 3 and o.max_idle_epochs == 2
+
+
+def test_engine_refuses_to_run_without_a_gpu(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    cfg = abi.make_config()
+    h = abi.ENGINE()
+    rc = lib.sa_engine_create(C.byref(cfg), C.byref(h))
+    assert rc == abi.SA_ERR_NO_DEVICE, rc
+    assert b"no CPU fallback" in lib.sa_last_error(None)

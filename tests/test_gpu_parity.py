@@ -369,6 +369,30 @@ def test_distance_matrix_vs_numpy_f64(kind, n, t, d):
     assert out.shape == (n, t)
 
 
+@pytest.mark.parametrize("plan", [0, 1, 2, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("n,t,d", [(300, 333, 512), (129, 70, 96)])
+def test_every_tile_plan_of_the_contraction(plan, n, t, d, monkeypatch):
+    """All six tile plans (128x128, 64x128, 128x64, 64x64 with 1/2/4 k-groups) produce the same cosine matrix, both in the
+    standalone entry point and in the fused VisualSORT kernel (tap), including ragged edge tiles."""
+    monkeypatch.setenv("SA_GEMM_PLAN", str(plan))
+    rng = np.random.default_rng(plan + n)
+    a = rng.standard_normal((n, d)).astype(np.float32)
+    b = rng.standard_normal((t, d)).astype(np.float32)
+    eng = Engine(abi.make_config())
+    try:
+        out, _ = eng.distance_matrix("cosine", a, b)
+    finally:
+        eng.close()
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    ref = (a64 @ b64.T) / np.sqrt((a64 * a64).sum(1)[:, None] * (b64 * b64).sum(1)[None, :])
+    assert np.abs(out - ref).max() <= 1e-5
+    sc = synth.visual_scene(np.random.default_rng(3 + plan), t, n, d, 2, canvas=(1500.0, 900.0), new_fraction=0.1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=2, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    check_visual(cfg, sc)
+
+
 def test_full_size_properties_c2():
     """BASELINE config C2 (1000 x 1000 x 512 cosine): size-independent properties instead of the slow oracle."""
     rng = np.random.default_rng(2)
