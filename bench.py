@@ -87,10 +87,9 @@ def kernel_models(cfg, scenes):
     n_ = sum(len(s["det_boxes"]) for s in scenes)
     t_ = sum(len(s["track_boxes"]) for s in scenes)
     m = {
-        # f32 cost out (4 B/cell) + 64 B vertices + 16 B geometry per box
+        # SURVEY §8d figure for the positional cells: f32 cost out (4 B/cell) + 64 B vertices + 16 B geometry per box.  The kernel
+        # itself no longer writes the dense matrix (it emits the edges of the vote directly), so this is effective bandwidth.
         "k_positional": ("hbm", 4.0 * cells + 80.0 * nt),
-        # one read of the positional matrix (4 B/cell; the i64 matrix is never materialised) + 4 B/row out
-        "k_assign_edges": ("hbm", 4.0 * cells + 4.0 * n_),
         # one read of the visual weights (4 B per cell and bank slot) + the per-tile partials
         "k_bestfit_tile": ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0),
     }

@@ -277,12 +277,18 @@ SA_HD void sa_uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
 // connected components that are solved independently; this routine solves one, by successive shortest
 // augmenting paths (Jonker–Volgenant style Dijkstra on reduced costs c = -gain, all i64), walking only real
 // edges.  Every tree row offers its free self column as a terminal, so searches stay local.
+// Edge order inside a row is irrelevant (the kernels append edges with atomics): every choice below is made on
+// (distance, column index), never on list position.  Row duals may start from ANY value <= -max gain of the row's usable
+// edges (here: -max over all its edges, excluded columns included) — reduced costs stay non-negative.
 struct sa_assign_ws {
   // edges, row-major with row stride `estride`
   const uint32_t* e_cnt;   // [N]
-  const uint32_t* e_col;   // [N][estride]
-  const int64_t* e_gain;   // [N][estride]
+  const uint32_t* e_col;   // [N][estride], or a packed pool indexed through e_off
+  const int64_t* e_gain;   // same layout as e_col
   uint32_t estride;
+  const uint32_t* e_off;   // nullptr: row r starts at r * estride; else at e_off[r] (edge lists packed into an LDS pool)
+  const uint8_t* excluded;   // [T] or nullptr: columns already taken by the visual vote (visual_sort/voting.rs:62-79);
+                             // their edges stay in the lists (the edge pass runs beside the visual vote) and are skipped here
   const uint32_t* next_row;  // [N] next row of the same component (ascending), SA_NONE at the end
   int64_t* u;       // [N] row duals   (initialised to -max gain of the row)
   int64_t* v;       // [T] column duals (initialised to 0)
@@ -299,11 +305,13 @@ struct sa_assign_ws {
 
 SA_HD void sa_assign_relax_row(const sa_assign_ws& w, uint32_t row, int64_t base, uint32_t stamp, int32_t* list_head) {
   uint32_t cnt = w.e_cnt[row];
-  const uint32_t* cols = w.e_col + (size_t)row * w.estride;
-  const int64_t* gains = w.e_gain + (size_t)row * w.estride;
+  const size_t first = w.e_off ? (size_t)w.e_off[row] : (size_t)row * w.estride;
+  const uint32_t* cols = w.e_col + first;
+  const int64_t* gains = w.e_gain + first;
   int64_t ur = w.u[row];
   for (uint32_t e = 0; e < cnt; ++e) {
     uint32_t j = cols[e];
+    if (w.excluded && w.excluded[j]) continue;
     if (w.cscan[j] == stamp) continue;
     int64_t d = base + (-gains[e] - ur - w.v[j]);
     if (w.cstamp[j] != stamp) {

@@ -86,6 +86,7 @@ struct SceneDev {
   uint32_t SA_G* parent;
   uint32_t SA_G* label;
   uint32_t SA_G* next_row;
+  uint8_t SA_G* not_first;   // [N] row has a predecessor inside its component
   uint32_t SA_G* e_cnt;
   uint32_t SA_G* e_col;
   int64_t SA_G* e_gain;
@@ -168,6 +169,8 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
 
 hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                 const SaParams& p, hipStream_t st);
+hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
+                                      const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
                             const SaParams& p, hipStream_t st);
 // init of the per-frame state + candidate preparation + candidate feature padding/norms, one launch
@@ -175,7 +178,7 @@ hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t n_scenes, uint3
                                 const SaParams& p, hipStream_t st);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
-// stage 0 edges+union, 1 label, 2 next, 3 solve, 4 finalize; stage 5 = stages 1-4 fused in ONE workgroup per
+// stage 1 label, 2 next, 3 solve, 4 finalize; stage 5 = stages 1-4 fused in ONE workgroup per
 // scene (requires maxN <= SA_SMALL_N)
 #define SA_SMALL_N 1024
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,

@@ -16,11 +16,11 @@ namespace {
 thread_local std::string g_create_error;
 
 enum KernelId {
-  KID_FRAME_PREP = 0, KID_POSITIONAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_EDGES, KID_ASSIGN_SMALL,
+  KID_FRAME_PREP = 0, KID_POSITIONAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
   KID_ASSIGN_LABEL, KID_ASSIGN_NEXT, KID_ASSIGN_SOLVE, KID_FINALIZE, KID_D2H, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
-    "k_frame_prep", "k_positional", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_edges", "k_assign_small",
+    "k_frame_prep", "k_positional", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
     "k_assign_label", "k_assign_next", "k_assign_solve", "k_finalize", "d2h_results"};
 
 struct DevBuf {
@@ -53,7 +53,7 @@ struct Slot {  // one scene of the current batch
   // matrices + vote + assignment state
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
-  DevBuf parent, label, next_row, e_cnt, e_col, e_gain, u, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
+  DevBuf parent, label, next_row, not_first, e_cnt, e_col, e_gain, u, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   HostBuf h_in;
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
@@ -268,7 +268,6 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->fnorm, n * 4));
     TRY(dev_ensure(e, s->vis, n * t * K * 4));
   }
-  TRY(dev_ensure(e, s->pos, n * t * 4));
   TRY(dev_ensure(e, s->vis_max_key, SA_MAXKEY_SHARDS * 4));
   if (e->visual) {
     TRY(dev_ensure(e, s->row_part_w, n * CT * 8));
@@ -282,6 +281,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->parent, (n + t) * 4));
   TRY(dev_ensure(e, s->label, n * 4));
   TRY(dev_ensure(e, s->next_row, n * 4));
+  TRY(dev_ensure(e, s->not_first, n));
   TRY(dev_ensure(e, s->e_cnt, n * 4));
   TRY(dev_ensure(e, s->e_col, n * t * 4));
   TRY(dev_ensure(e, s->e_gain, n * t * 8));
@@ -328,7 +328,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->row_part_w = (decltype(d->row_part_w))(s->row_part_w.p); d->row_part_t = (decltype(d->row_part_t))(s->row_part_t.p);
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
-  d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
+  d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p); d->not_first = (decltype(d->not_first))(s->not_first.p);
   d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_col = (decltype(d->e_col))(s->e_col.p); d->e_gain = (decltype(d->e_gain))(s->e_gain.p);
   d->u = (decltype(d->u))(s->u.p); d->v = (decltype(d->v))(s->v.p); d->rmatch = (decltype(d->rmatch))(s->rmatch.p); d->cmatch = (decltype(d->cmatch))(s->cmatch.p);
   d->dist = (decltype(d->dist))(s->dist.p); d->pred = (decltype(d->pred))(s->pred.p); d->cstamp = (decltype(d->cstamp))(s->cstamp.p); d->cscan = (decltype(d->cscan))(s->cscan.p);
@@ -374,7 +374,7 @@ int run_pipeline(sa_engine* e) {
   hipStream_t st = e->stream;
   { ProfScope ps(e, KID_FRAME_PREP); HIPCHK(e, sa_launch_frame_prep(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   // The positional cost cells (f64 VALU) and the feature contraction (matrix cores) are independent until the
-  // positional vote: fork them onto two streams, join before k_assign_edges.
+  // positional vote: fork them onto two streams, join before the assignment tail.
   // Measured on MI355X / ROCm 7.2: the two cross-stream event waits cost more (~14 us) than the ~9 us of overlap
   // they buy at C2, so the fork is opt-in (SA_FLAG_FORK).
   const bool fork = (e->cfg.flags & SA_FLAG_FORK) && e->visual && !e->profile && e->stream2 && maxN && maxT;
@@ -393,7 +393,6 @@ int run_pipeline(sa_engine* e) {
     { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
   }
   if (fork) HIPCHK(e, hipStreamWaitEvent(st, e->ev_join, 0));
-  { ProfScope ps(e, KID_ASSIGN_EDGES); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 0)); }
   if (maxN <= SA_SMALL_N) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
     HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 5));
@@ -553,7 +552,7 @@ void sa_engine_destroy(sa_engine* e) {
     for (DevBuf* b : {&s->raw, &s->quality, &s->own, &s->fpresent_in, &s->feat_raw, &s->geo, &s->verts, &s->z, &s->conf,
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                       &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
-                      &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_col, &s->e_gain, &s->u, &s->v, &s->rmatch,
+                      &s->parent, &s->label, &s->next_row, &s->not_first, &s->e_cnt, &s->e_col, &s->e_gain, &s->u, &s->v, &s->rmatch,
                       &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext})
       free_dev(*b);
     free_host(s->h_in);
@@ -859,10 +858,28 @@ int sa_tap_dims(sa_engine* e, uint32_t slot, uint32_t* n, uint32_t* t, uint32_t*
   if (k) *k = e->K;
   return SA_OK;
 }
+// The product path never writes the dense positional matrix (k_positional emits the edges of the vote directly); the taps
+// recompute it on demand from the slot's resident inputs with the DENSE specialisation of the same kernel, which touches no
+// assignment state.  Valid until the slot's scene is upserted or re-staged.
+static int dense_positional(sa_engine* e, Slot* s) {
+  const size_t cells = (size_t)s->N * s->T;
+  if (!cells) return SA_OK;
+  TRY(dev_ensure(e, s->pos, cells * 4));
+  SceneDev h;
+  fill_scene_dev(e, s, &h);
+  DevBuf tmp;
+  TRY(dev_ensure(e, tmp, sizeof h));
+  HIPCHK(e, hipMemcpy(tmp.p, &h, sizeof h, hipMemcpyHostToDevice));
+  HIPCHK(e, sa_launch_positional_dense((const SceneDev*)tmp.p, 1, s->N, s->T, e->P, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  hipFree(tmp.p);
+  return SA_OK;
+}
 int sa_tap_positional(sa_engine* e, uint32_t slot, float* out) {
   Slot* s;
   TRY(tap_slot(e, slot, &s));
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
+  TRY(dense_positional(e, s));
   size_t bytes = (size_t)s->N * s->T * 4;
   if (bytes) HIPCHK(e, hipMemcpy(out, s->pos.p, bytes, hipMemcpyDeviceToHost));
   return SA_OK;
@@ -882,6 +899,7 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
   size_t cells = (size_t)s->N * s->T;
   if (!cells) return SA_OK;
+  TRY(dense_positional(e, s));
   TRY(dev_ensure(e, s->quant, cells * 8));
   // one-scene descriptor array with the tap buffer attached
   SceneDev h;

@@ -8,6 +8,8 @@
 // grid.z = scene so a whole batch of scenes goes through one launch.  No MFMA here on purpose.
 #include "sa_engine.h"
 
+#include <type_traits>
+
 #define WAVE 64
 
 thread_local hipEvent_t sa_prof_start = nullptr, sa_prof_stop = nullptr;
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
     S.row_has[i] = 0;
     S.rmatch[i] = -1;
     S.e_cnt[i] = 0;
+    S.u[i] = 0;          // row dual: k_positional folds -gain into it with atomic min
+    S.not_first[i] = 0;
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
     BoxRaw r = sa_ldg(S.c_raw + i);
@@ -163,63 +167,98 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
 }
 
 // =====================================================================================================
-// Positional cost cells: pair pre-filter -> (survivors only) IoU by f64 Sutherland–Hodgman / Mahalanobis.
-// Tile = 16 candidates x 64 tracks per 256-thread block; each wave owns whole 256-B row segments of `pos`.
-// Phase 1 tests every cell: too_far() first (no sqrt), then compatible() — whose dist_in_2r costs a sqrt and
-// a division — only for the cells that pass, and writes NaN for the dead ones; the few survivors are
-// compacted into an LDS list so that phase 2 runs the expensive clip with full lanes instead of 1-2 live
-// lanes per wave.
+// Positional cost cells: pair pre-filter -> (survivors only) IoU by f64 Sutherland–Hodgman / Mahalanobis -> the sparse
+// input of the positional vote.
+// Tile = 16 candidates x 256 tracks per 256-thread block: lane = track, each wave owns 4 candidate rows, a thread tests
+// 16 cells.  Phase 1 tests every cell: too_far() first (no sqrt), then compatible() — whose dist_in_2r costs a sqrt and a
+// division — only for the cells that pass; the few survivors are compacted into an LDS list so that phase 2 runs the
+// expensive clip with full lanes instead of 1-2 live lanes per wave.
+// EDGES (the product path): a surviving cell whose quantised weight beats the new-track threshold becomes an edge of the
+//   assignment graph right here — appended to its row's list (order inside a row is irrelevant to the solver), folded
+//   into the row dual and the union-find forest.  The dense N x T matrix of SortVoting (sort/voting.rs:44-84) and even the
+//   dense f32 cost matrix are never written: what this kernel moves is 80 B per box in and ~20 B per edge out.
+// DENSE (parity taps only): the f32 cost matrix, NaN = absent.
 // =====================================================================================================
+// NSUB = 64-track sub-tiles per block: 4 (16 x 256 cells, 128 clip lanes) when the frame still yields several blocks per
+// CU that way — fewer, longer-lived blocks amortise the fixed cost of a block (C4: 62 500 blocks of 16 x 64 took 25 us, 1000
+// blocks of 16 x 256 take 15) — else 1 (16 x 64 cells, 64 clip lanes), which keeps every CU busy on small or dense frames
+// where the clip rounds, not the pre-filter, set the time (C2: ~60 surviving pairs per candidate).
 #define POS_TI 16
-#define POS_TJ 64
-#define POS_WORKERS 64
+// UNION: also fold each edge into the row dual and the global union-find forest (needed by the many-workgroup assignment
+// tail).  When the whole scene is solved by ONE workgroup (k_assign_small) that workgroup builds both from the edge lists in
+// LDS instead — the chain of dependent global atomics per edge would otherwise sit at the tail of every block here.
+template <bool DENSE, bool EDGES, int NSUB, bool UNION>
 __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = 64u;
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = blockIdx.y * POS_TI, j0 = blockIdx.x * POS_TJ;
   if (i0 >= N || j0 >= T) return;
   __shared__ sa_geo s_cg[POS_TI];
-  __shared__ sa_geo s_tg[POS_TJ];
-  __shared__ uint64_t s_te[POS_TJ];
-  __shared__ uint16_t s_list[POS_TI * POS_TJ];
+  __shared__ uint16_t s_list[POS_TI * POS_TJ];  // (li << 8) | lj
   __shared__ uint32_t s_cnt;
   __shared__ double s_poly[4 * SA_POLY_CAP * POS_WORKERS];  // 24 KB
-  const uint32_t tid = threadIdx.x;
+  __shared__ float s_thha[POS_TJ];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   if (tid < POS_TI) {
     uint32_t i = i0 + tid;
     s_cg[tid] = i < N ? sa_ldg(S.c_geo + i) : sa_geo{0.f, 0.f, 0.f, 0.f};
-  } else if (tid >= 64 && tid < 64 + POS_TJ) {
-    uint32_t lj = tid - 64, j = j0 + lj;
-    s_tg[lj] = j < T ? sa_ldg(S.t_geo + j) : sa_geo{0.f, 0.f, 0.f, 0.f};
-    s_te[lj] = j < T ? S.t_epoch[j] : 0ull;
   }
   if (tid == 0) s_cnt = 0;
+  // this thread's 4 tracks (one per 64-wide sub-tile): loads in flight while the candidate tile lands in LDS
+  sa_geo tg[NSUB];
+  uint64_t te[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    const uint32_t j = j0 + s * 64 + lane;
+    tg[s] = j < T ? sa_ldg(S.t_geo + j) : sa_geo{0.f, 0.f, 0.f, 0.f};
+    te[s] = j < T ? S.t_epoch[j] : 0ull;
+    if (wave == 0) s_thha[s * 64 + lane] = tg[s].hha;
+  }
   __syncthreads();
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
 #pragma unroll
-  for (int it = 0; it < (POS_TI * POS_TJ) / 256; ++it) {
-    uint32_t c = it * 256 + tid;
-    uint32_t li = c / POS_TJ, lj = c % POS_TJ;
-    uint32_t i = i0 + li, j = j0 + lj;
-    bool live = false;
-    if (i < N && j < T) {
-      const sa_geo cg = s_cg[li], tg = s_tg[lj];
-      live = !sa_too_far(cg, tg) && sa_compatible(cg, epoch, tg, s_te[lj], p.max_idle, p.cons);
-      if (!live) S.pos[(size_t)i * T + j] = nanv;
-    }
-    if (live) {
-      uint32_t slot = atomicAdd(&s_cnt, 1u);
-      s_list[slot] = (uint16_t)c;
+  for (int s = 0; s < NSUB; ++s) {
+    const uint32_t lj = s * 64 + lane, j = j0 + lj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t li = wave * 4 + r, i = i0 + li;
+      bool live = false;
+      if (i < N && j < T) {
+        const sa_geo cg = s_cg[li];
+        live = !sa_too_far(cg, tg[s]) && sa_compatible(cg, epoch, tg[s], te[s], p.max_idle, p.cons);
+        if (DENSE && !live) S.pos[(size_t)i * T + j] = nanv;
+      }
+      if (live) {
+        uint32_t slot = atomicAdd(&s_cnt, 1u);
+        s_list[slot] = (uint16_t)((li << 8) | lj);
+      }
     }
   }
   __syncthreads();
   const uint32_t cnt = s_cnt;
+  // one surviving cell -> (optionally) the dense matrix, and its edge
+  auto emit = [&](uint32_t i, uint32_t j, float w, bool present) {
+    if (DENSE) S.pos[(size_t)i * T + j] = present ? w : nanv;
+    if (EDGES && present) {
+      const int64_t gain = sa_quantise(w) - p.threshold_q;  // (w * 1e6f) as i64 vs the diagonal of SortVoting's matrix
+      if (gain > 0) {
+        const uint32_t slot = atomicAdd((uint32_t*)(S.e_cnt + i), 1u);
+        S.e_col[(size_t)i * S.estride + slot] = j;
+        S.e_gain[(size_t)i * S.estride + slot] = gain;
+        if (UNION) {
+          __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
+          sa_uf_union((uint32_t*)S.parent, i, N + j);
+        }
+      }
+    }
+  };
   if (p.positional_kind == SA_POS_MAHALANOBIS) {
     for (uint32_t sidx = tid; sidx < cnt; sidx += 256) {
-      uint32_t c = s_list[sidx];
-      uint32_t li = c / POS_TJ, lj = c % POS_TJ;
-      uint32_t i = i0 + li, j = j0 + lj;
+      const uint32_t c = s_list[sidx];
+      const uint32_t li = c >> 8, lj = c & 255u;
+      const uint32_t i = i0 + li, j = j0 + lj;
       float m20[20], z5[5];
       const float SA_G* mp = S.t_maha + (size_t)j * 20;
 #pragma unroll
@@ -227,28 +266,30 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       const float SA_G* zp = S.c_z + (size_t)i * 5;
 #pragma unroll
       for (int k = 0; k < 5; ++k) z5[k] = zp[k];
-      S.pos[(size_t)i * T + j] = sa_maha_cell(m20, z5, S.c_conf[i]);
+      emit(i, j, sa_maha_cell(m20, z5, S.c_conf[i]), true);
     }
   } else if (tid < POS_WORKERS) {
     // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS
     double* ws = s_poly + tid;
     for (uint32_t sidx = tid; sidx < cnt; sidx += POS_WORKERS) {
-      uint32_t c = s_list[sidx];
-      uint32_t li = c / POS_TJ, lj = c % POS_TJ;
-      uint32_t i = i0 + li, j = j0 + lj;
+      const uint32_t c = s_list[sidx];
+      const uint32_t li = c >> 8, lj = c & 255u;
+      const uint32_t i = i0 + li, j = j0 + lj;
       double cv[8], tv[8];
       const double SA_G* cp = S.c_verts + (size_t)i * 8;
       const double SA_G* tp = S.t_verts + (size_t)j * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cv[k] = cp[k]; tv[k] = tp[k]; }
+      const float t_hha = s_thha[lj];
       double inter = sa_clip_area_ws(cv, tv, ws, ws + SA_POLY_CAP * POS_WORKERS, ws + 2 * SA_POLY_CAP * POS_WORKERS,
                                      ws + 3 * SA_POLY_CAP * POS_WORKERS, POS_WORKERS);
       float iou, out = nanv;
-      if (sa_iou_from_area(inter, s_cg[li].hha, s_tg[lj].hha, &iou)) {
+      bool present = false;
+      if (sa_iou_from_area(inter, s_cg[li].hha, t_hha, &iou)) {
         float e = iou * S.c_conf[i];
-        if (e >= p.positional_threshold) out = e;
+        if (e >= p.positional_threshold) { out = e; present = true; }
       }
-      S.pos[(size_t)i * T + j] = out;
+      emit(i, j, out, present);
     }
   }
 }
@@ -413,80 +454,20 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 
 // =====================================================================================================
 // Positional assignment = SortVoting::winners (sort/voting.rs:30-100) as an exact sparse solve.
-//   k_assign_edges : one wave per candidate row scans pos[q][*] (the HBM-bound read of the cost matrix,
-//            16 B per lane per step), quantises, keeps cells whose gain = w_q - threshold_q > 0 in column
-//            order (wave prefix sum), records the row dual, and unions row and column in the lock-free
-//            forest.  Rows that already hold a visual decision and excluded columns are skipped
-//            (visual_sort/voting.rs:73-79).
-//   then either (N <= SA_SMALL_N) k_assign_small: ONE workgroup per scene does labels -> per-component row
-//            order (bitonic sort of (label, row) keys in LDS) -> solve -> results,
-//   or the general path: k_assign_label, k_assign_next (one wave per row, 64 labels per probe),
-//            k_assign_solve (one thread per component), k_finalize.
+// The edges (cells whose quantised weight beats the new-track threshold), the row duals and the union-find forest come
+// straight out of k_positional, which runs beside the visual vote; the visual vote's verdicts are applied here, lazily:
+// rows that already hold a visual decision take no part (feature_winners.contains_key(from), visual_sort/voting.rs:77) and
+// columns won visually are skipped while relaxing (excluded_tracks, :62-71).  A component may therefore be larger than
+// strictly needed — harmless, it is still solved exactly.
+//   N <= SA_SMALL_N: k_assign_small — ONE workgroup per scene does labels -> per-component row order (bitonic sort of
+//            (label, row) keys in LDS) -> solve (one thread per component, duals in LDS) -> results,
+//   else: k_assign_label, k_assign_next (one wave per row, 64 labels per probe; marks every row that has a predecessor),
+//            k_assign_solve (one thread per component, started from its first row), k_finalize.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_assign_edges(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (q >= S.N) return;
-  if (S.row_has[q]) return;  // feature_winners.contains_key(from)
-  const uint32_t T = S.T;
-  const float* prow = S.pos + (size_t)q * T;
-  uint32_t* ecol = S.e_col + (size_t)q * S.estride;
-  int64_t* egain = S.e_gain + (size_t)q * S.estride;
-  const bool vec = (T & 3u) == 0;  // rows stay 16-B aligned
-  uint32_t cnt = 0;
-  int64_t maxg = 0;
-  for (uint32_t base = 0; base < T; base += WAVE * 4) {
-    const uint32_t t0 = base + lane * 4;
-    float w4[4];
-    if (vec && t0 + 3 < T) {
-      float4 x = *(const float4*)(prow + t0);
-      w4[0] = x.x; w4[1] = x.y; w4[2] = x.z; w4[3] = x.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w4[e] = (t0 + e < T) ? prow[t0 + e] : __builtin_nanf("");
-    }
-    int64_t g4[4];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int64_t gain = 0;
-      float w = w4[e];
-      if (w == w && !S.col_excluded[t0 + e]) gain = sa_quantise(w) - p.threshold_q;  // w present => t0+e < T
-      g4[e] = gain;
-      mine += gain > 0 ? 1u : 0u;
-    }
-    // exclusive prefix of `mine` over the wave
-    uint32_t incl = mine;
-    for (int o = 1; o < WAVE; o <<= 1) {
-      uint32_t up = __shfl_up(incl, o);
-      if (lane >= (uint32_t)o) incl += up;
-    }
-    uint32_t off = cnt + incl - mine;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (g4[e] > 0) {
-        ecol[off] = t0 + e;
-        egain[off] = g4[e];
-        ++off;
-        if (g4[e] > maxg) maxg = g4[e];
-        sa_uf_union((uint32_t*)S.parent, q, S.N + t0 + e);
-      }
-    cnt += __shfl(incl, WAVE - 1);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    int64_t og = __shfl_xor(maxg, o);
-    if (og > maxg) maxg = og;
-  }
-  if (lane == 0) {
-    S.e_cnt[q] = cnt;
-    S.u[q] = -maxg;
-  }
-}
-
 __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   sa_assign_ws w;
-  w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride;
+  w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride; w.e_off = nullptr;
+  w.excluded = S.col_excluded;
   w.next_row = S.next_row;
   w.u = S.u; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
   w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
@@ -519,10 +500,39 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ int64_t s_u[SA_SMALL_N], s_rdist[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
   __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
   __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
-  uint32_t lab = SA_NONE;
-  if (q < N && S.e_cnt[q]) lab = sa_uf_find((uint32_t*)S.parent, q);
+  // The edge lists k_positional left behind live in HBM, one strided row per candidate: every access from here on would be
+  // a dependent, uncoalesced round trip (the solve is a chain of them).  They are packed ONCE into an LDS pool — an
+  // exclusive scan of the row counts gives the offsets — and the row duals, the connected components of the usable graph
+  // (rows without a visual verdict) and the solve itself then run out of LDS.  A scene whose lists do not fit (dense
+  // Mahalanobis frames) works on the HBM lists.
+  constexpr uint32_t POOL = 3072;
+  __shared__ uint32_t s_parent[2 * SA_SMALL_N];
+  __shared__ uint32_t s_ecnt[SA_SMALL_N], s_eoff[SA_SMALL_N], s_wsum[SA_SMALL_N / WAVE];
+  __shared__ uint32_t s_ecol[POOL];
+  __shared__ int64_t s_egain[POOL];
+  const bool uf_in_lds = T <= SA_SMALL_N;
+  const uint32_t mycnt = (q < N && !S.row_has[q]) ? S.e_cnt[q] : 0u;
   s_rmatch[q] = -1;
-  if (!__syncthreads_or(lab != SA_NONE)) {  // nothing left for the positional vote (every row decided visually)
+  s_ecnt[q] = mycnt;
+  if (uf_in_lds) { s_parent[q] = q; s_parent[q + SA_SMALL_N] = q + SA_SMALL_N; }
+  // exclusive scan of mycnt over the 1024 threads: wave scan, then the 16 wave totals
+  uint32_t incl = mycnt;
+  {
+    const uint32_t lane = q % WAVE;
+    for (int o = 1; o < WAVE; o <<= 1) {
+      uint32_t up = __shfl_up(incl, o);
+      if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane == WAVE - 1) s_wsum[q / WAVE] = incl;
+  }
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+  for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) {
+    const uint32_t v = s_wsum[w2];
+    if (w2 < q / WAVE) woff += v;
+    total += v;
+  }
+  if (total == 0) {  // nothing left for the positional vote (every row decided visually, or no edge at all)
     if (q < N) {
       uint64_t id = 0;
       uint8_t vt = SA_VOTE_NONE;
@@ -533,23 +543,71 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     }
     return;
   }
+  const bool pool = total <= POOL;
+  const uint32_t myoff = woff + incl - mycnt;
+  s_eoff[q] = myoff;
+  int64_t maxg = 0;
+  uint32_t usable = 0;
+  if (mycnt) {
+    const uint32_t SA_G* cols = S.e_col + (size_t)q * S.estride;
+    const int64_t SA_G* gains = S.e_gain + (size_t)q * S.estride;
+    for (uint32_t e = 0; e < mycnt; ++e) {
+      const uint32_t j = cols[e];
+      const int64_t g = gains[e];
+      if (S.col_excluded[j]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71): dropped while packing
+      if (pool) { s_ecol[myoff + usable] = j; s_egain[myoff + usable] = g; }
+      ++usable;
+      maxg = g > maxg ? g : maxg;
+      if (uf_in_lds) sa_uf_union(s_parent, q, N + j);
+      else sa_uf_union((uint32_t*)S.parent, q, N + j);
+    }
+    if (pool) s_ecnt[q] = usable;  // the packed list holds usable edges only (the HBM list keeps them all: solve skips there)
+  }
+  __syncthreads();
+  uint32_t lab = SA_NONE;
+  if (usable) lab = uf_in_lds ? sa_uf_find(s_parent, q) : sa_uf_find((uint32_t*)S.parent, q);
   const bool cols_in_lds = T <= SA_SMALL_N;
   s_key[q] = lab == SA_NONE ? 0xffffffffu : ((lab << 10) | q);
   s_next[q] = SA_NONE;
-  s_u[q] = q < N ? S.u[q] : 0;
+  s_u[q] = -maxg;
   if (cols_in_lds) { s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0; }
   __syncthreads();
-  // bitonic sort of 1024 keys (ascending): components become runs, rows ascending inside a run
-  for (uint32_t k = 2; k <= SA_SMALL_N; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      uint32_t ixj = q ^ j;
-      if (ixj > q) {
-        uint32_t a = s_key[q], b = s_key[ixj];
-        bool up = (q & k) == 0;
-        if ((a > b) == up) { s_key[q] = b; s_key[ixj] = a; }
+  // bitonic sort of 1024 keys (ascending): components become runs, rows ascending inside a run.  One key per thread, in a
+  // register; the network is fully unrolled so that every exchange distance is a constant:
+  //   distance 1, 2, 8  -> DPP (quad_perm / row_ror:8), a plain VALU move
+  //   distance 4, 16    -> ds_swizzle bit-mask mode (no address register)
+  //   distance 32       -> ds_bpermute
+  //   distance >= 64    -> through LDS, ping-pong halves of s_sort so that each of these 10 steps costs ONE barrier
+  // (55 LDS round trips with two barriers each were 7 us of this kernel at 500 x 500).
+  {
+    __shared__ uint32_t s_sort[2][SA_SMALL_N];
+    uint32_t key = s_key[q];
+    int pp = 0;
+#pragma unroll
+    for (uint32_t k = 2; k <= SA_SMALL_N; k <<= 1) {
+      const bool up = (q & k) == 0;
+#pragma unroll
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint32_t other;
+        if (j >= WAVE) {
+          s_sort[pp][q] = key;
+          __syncthreads();
+          other = s_sort[pp][q ^ j];
+          pp ^= 1;  // the next LDS step writes the other half: no thread can still be reading it (one barrier in between)
+        } else if (j == 1) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        else if (j == 2) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+        else if (j == 8) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0x128, 0xF, 0xF, true);      // row_ror:8
+        else if (j == 4) other = (uint32_t)__builtin_amdgcn_ds_swizzle((int)key, (4 << 10) | 0x1F);        // xor 4
+        else if (j == 16) other = (uint32_t)__builtin_amdgcn_ds_swizzle((int)key, (16 << 10) | 0x1F);      // xor 16
+        else other = __shfl_xor(key, (int)j);
+        const bool keep_min = ((q & j) == 0) == up;
+        const uint32_t lo = key < other ? key : other, hi = key < other ? other : key;
+        key = keep_min ? lo : hi;
       }
-      __syncthreads();
     }
+    __syncthreads();
+    s_key[q] = key;
+    __syncthreads();
   }
   {  // position q of the sorted array: link to the next row of the same component
     uint32_t key = s_key[q];
@@ -559,25 +617,33 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     }
   }
   __syncthreads();
-  if (q < N && lab == q) {  // representative = minimum row of its component
-    // two call sites so that every pointer of the work set has ONE known address space (LDS or global) after inlining;
-    // a work set that is "LDS or global, decided at run time" compiles to flat_* accesses
-    if (cols_in_lds) {
+  // the thread at the head of a run of the sorted keys solves that component, starting from its first (lowest) row
+  const uint32_t mykey = s_key[q];
+  if (mykey != 0xffffffffu && (q == 0 || (s_key[q - 1] >> 10) != (mykey >> 10))) {
+    const uint32_t first = mykey & 1023u;
+    // one call site per combination of address spaces (edge lists: LDS pool or HBM; column state: LDS or HBM), so that every
+    // pointer of the work set has ONE known address space after inlining — "LDS or global, decided at run time" compiles
+    // to flat_* accesses
+    auto solve = [&](auto pool_tag, auto cols_tag) {
       sa_assign_ws w;
-      w.e_cnt = (const uint32_t*)S.e_cnt; w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.estride = S.estride;
+      w.estride = S.estride;
+      w.e_cnt = s_ecnt;
+      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.e_off = s_eoff; w.excluded = nullptr; }
+      else { w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.e_off = nullptr; w.excluded = (const uint8_t*)S.col_excluded; }
       w.next_row = s_next;
       w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
-      w.v = s_v; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan; w.cnext = s_cnext;
-      sa_assign_component(w, q);
-    } else {
-      sa_assign_ws w;
-      w.e_cnt = (const uint32_t*)S.e_cnt; w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.estride = S.estride;
-      w.next_row = s_next;
-      w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
-      w.v = (int64_t*)S.v; w.cmatch = (int32_t*)S.cmatch; w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred;
-      w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan; w.cnext = (int32_t*)S.cnext;
-      sa_assign_component(w, q);
-    }
+      if constexpr (decltype(cols_tag)::value) {
+        w.v = s_v; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan; w.cnext = s_cnext;
+      } else {
+        w.v = (int64_t*)S.v; w.cmatch = (int32_t*)S.cmatch; w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred;
+        w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan; w.cnext = (int32_t*)S.cnext;
+      }
+      sa_assign_component(w, first);
+    };
+    if (pool && cols_in_lds) solve(std::true_type{}, std::true_type{});
+    else if (pool) solve(std::true_type{}, std::false_type{});
+    else if (cols_in_lds) solve(std::false_type{}, std::true_type{});
+    else solve(std::false_type{}, std::false_type{});
   }
   __syncthreads();
   if (q < N) {
@@ -598,7 +664,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  S.label[q] = S.e_cnt[q] ? sa_uf_find((uint32_t*)S.parent, q) : SA_NONE;
+  S.label[q] = (S.e_cnt[q] && !S.row_has[q]) ? sa_uf_find((uint32_t*)S.parent, q) : SA_NONE;
 }
 
 __global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict__ scenes) {
@@ -615,14 +681,17 @@ __global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict_
     unsigned long long m = __ballot(hit);
     if (m) { found = base + (uint32_t)__ffsll((long long)m) - 1u; break; }
   }
-  if (lane == 0) S.next_row[q] = found;
+  if (lane == 0) {
+    S.next_row[q] = found;
+    if (found != SA_NONE) S.not_first[found] = 1;  // `found` has a predecessor: it does not start a component
+  }
 }
 
 __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  if (S.label[q] != q) return;  // only the representative (minimum row) of a component works
+  if (S.label[q] == SA_NONE || S.not_first[q]) return;  // only the first row of a component works
   sa_assign_ws w = make_ws(S);
   sa_assign_component(w, q);
 }
@@ -674,7 +743,20 @@ hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t ns, uint32_t ma
 hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                                 hipStream_t st) {
   if (!maxN || !maxT) return hipSuccess;
-  SA_LAUNCH(k_positional, dim3(cdiv(maxT, POS_TJ), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
+  const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
+  const bool uni = maxN > SA_SMALL_N;  // the one-workgroup tail builds duals and components itself
+  const dim3 grid(cdiv(maxT, wide ? 256 : 64), cdiv(maxN, POS_TI), ns);
+  if (wide && uni) SA_LAUNCH((k_positional<false, true, 4, true>), grid, dim3(256), 0, st, scenes, p);
+  else if (wide) SA_LAUNCH((k_positional<false, true, 4, false>), grid, dim3(256), 0, st, scenes, p);
+  else if (uni) SA_LAUNCH((k_positional<false, true, 1, true>), grid, dim3(256), 0, st, scenes, p);
+  else SA_LAUNCH((k_positional<false, true, 1, false>), grid, dim3(256), 0, st, scenes, p);
+  return hipGetLastError();
+}
+// parity taps: the dense f32 cost matrix of the staged scenes, no side effects on the assignment state
+hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
+                                      hipStream_t st) {
+  if (!maxN || !maxT) return hipSuccess;
+  hipLaunchKernelGGL((k_positional<true, false, 1, false>), dim3(cdiv(maxT, 64), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
   return hipGetLastError();
 }
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, hipStream_t st) {
@@ -695,7 +777,6 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
                             hipStream_t st, int stage) {
   if (!maxN) return hipSuccess;
   switch (stage) {
-    case 0: if (maxT) SA_LAUNCH(k_assign_edges, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes, p); break;
     case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     case 2: SA_LAUNCH(k_assign_next, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes); break;
     case 3: SA_LAUNCH(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;

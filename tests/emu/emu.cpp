@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/similari_assoc.h"
@@ -67,11 +68,15 @@ int64_t emu_quantise(float w) { return sa_quantise(w); }
 uint32_t emu_f32_key(float f) { return sa_f32_key(f); }
 float emu_key_f32(uint32_t k) { return sa_key_f32(k); }
 
-// Runs the assignment stages (k_assign_edges -> label -> next -> solve) sequentially on a dense positional
-// matrix pos[N][T] (NaN = absent).  row_skip / col_skip mimic the visual exclusions.  rmatch[N] = column or -1.
+// Runs the assignment stages sequentially on a dense positional matrix pos[N][T] (NaN = absent), the way the kernels
+// sequence them: k_positional turns EVERY cell that beats the threshold into an edge (rows and columns the visual vote has
+// taken included — it runs beside that vote), appending in no particular order (atomics; mimicked here by a deterministic
+// shuffle); label / next / solve then ignore rows in row_skip and skip columns in col_skip while relaxing.
+// rmatch[N] = column or -1.
 int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip,
                const uint8_t* col_skip, int32_t* rmatch_out, int64_t* total_gain) {
   std::vector<uint32_t> parent(N + T), label(N, SA_NONE), next_row(N, SA_NONE), e_cnt(N, 0);
+  std::vector<uint8_t> not_first(N, 0);
   const uint32_t estride = T ? T : 1;
   std::vector<uint32_t> e_col((size_t)N * estride);
   std::vector<int64_t> e_gain((size_t)N * estride);
@@ -79,12 +84,11 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
   std::vector<int32_t> rmatch(N, -1), cmatch(T, -1), pred(T, 0), cnext(T, 0), rnext(N, 0);
   std::vector<uint32_t> cstamp(T, 0), cscan(T, 0);
   for (uint32_t i = 0; i < N + T; ++i) parent[i] = i;
+  uint64_t lcg = 0x9e3779b97f4a7c15ull;
   for (uint32_t q = 0; q < N; ++q) {
-    if (row_skip && row_skip[q]) continue;
     uint32_t cnt = 0;
     int64_t maxg = 0;
     for (uint32_t t = 0; t < T; ++t) {
-      if (col_skip && col_skip[t]) continue;
       float w = pos[(size_t)q * T + t];
       if (!(w == w)) continue;
       int64_t gain = sa_quantise(w) - threshold_q;
@@ -96,42 +100,55 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
         sa_uf_union(parent.data(), q, N + t);
       }
     }
+    for (uint32_t a = cnt; a > 1; --a) {  // Fisher–Yates: arbitrary append order
+      lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      uint32_t b = (uint32_t)((lcg >> 33) % a);
+      std::swap(e_col[(size_t)q * estride + a - 1], e_col[(size_t)q * estride + b]);
+      std::swap(e_gain[(size_t)q * estride + a - 1], e_gain[(size_t)q * estride + b]);
+    }
     e_cnt[q] = cnt;
     u[q] = -maxg;
   }
-  for (uint32_t q = 0; q < N; ++q) label[q] = e_cnt[q] ? sa_uf_find(parent.data(), q) : SA_NONE;
+  for (uint32_t q = 0; q < N; ++q) label[q] = (e_cnt[q] && !(row_skip && row_skip[q])) ? sa_uf_find(parent.data(), q) : SA_NONE;
   for (uint32_t q = 0; q < N; ++q) {
     if (label[q] == SA_NONE) continue;
     for (uint32_t r = q + 1; r < N; ++r)
-      if (label[r] == label[q]) { next_row[q] = r; break; }
+      if (label[r] == label[q]) { next_row[q] = r; not_first[r] = 1; break; }
   }
   sa_assign_ws w;
-  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.estride = estride;
+  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.estride = estride; w.e_off = nullptr;
+  w.excluded = col_skip;
   w.next_row = next_row.data();
   w.u = u.data(); w.v = v.data(); w.rmatch = rmatch.data(); w.cmatch = cmatch.data();
   w.dist = dist.data(); w.pred = pred.data(); w.cstamp = cstamp.data(); w.cscan = cscan.data(); w.cnext = cnext.data();
   w.rdist = rdist.data(); w.rnext = rnext.data();
   for (uint32_t q = 0; q < N; ++q)
-    if (label[q] == q) sa_assign_component(w, q);
+    if (label[q] != SA_NONE && !not_first[q]) sa_assign_component(w, q);
   int64_t tot = 0;
   for (uint32_t q = 0; q < N; ++q) {
     rmatch_out[q] = rmatch[q];
     if (rmatch[q] >= 0) {
+      if (row_skip && row_skip[q]) return -7;                 // a visually decided row took part
+      if (col_skip && col_skip[rmatch[q]]) return -8;         // an excluded column was used
       for (uint32_t e = 0; e < e_cnt[q]; ++e)
         if ((int32_t)e_col[(size_t)q * estride + e] == rmatch[q]) tot += e_gain[(size_t)q * estride + e];
       if (cmatch[rmatch[q]] != (int32_t)q) return -1;  // inconsistent matching
     }
   }
-  // dual feasibility + complementary slackness = proof of optimality
+  // dual feasibility + complementary slackness over the usable graph = proof of optimality
   for (uint32_t q = 0; q < N; ++q) {
+    if (row_skip && row_skip[q]) continue;
     if (u[q] > 0) return -2;
+    bool usable = false;
     for (uint32_t e = 0; e < e_cnt[q]; ++e) {
       uint32_t t = e_col[(size_t)q * estride + e];
+      if (col_skip && col_skip[t]) continue;
+      usable = true;
       int64_t rc = -e_gain[(size_t)q * estride + e] - u[q] - v[t];
       if (rc < 0) return -3;
       if (rmatch[q] == (int32_t)t && rc != 0) return -4;
     }
-    if (rmatch[q] < 0 && e_cnt[q] && u[q] != 0) return -5;  // self column must be tight when used
+    if (rmatch[q] < 0 && usable && u[q] != 0) return -5;  // self column must be tight when used
   }
   for (uint32_t t = 0; t < T; ++t)
     if (cmatch[t] < 0 && v[t] != 0) return -6;  // free columns keep their initial dual
