@@ -84,9 +84,8 @@ struct SceneDev {
   uint8_t SA_G* col_excluded;
   // positional assignment
   uint32_t SA_G* parent;
-  uint32_t SA_G* label;
+  uint32_t SA_G* label;      // [N] general tail: head of the row list of the component rooted at this row
   uint32_t SA_G* next_row;
-  uint8_t SA_G* not_first;   // [N] row has a predecessor inside its component
   uint32_t SA_G* e_cnt;
   uint32_t SA_G* e_col;
   int64_t SA_G* e_gain;
@@ -178,7 +177,7 @@ hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t n_scenes, uint3
                                 const SaParams& p, hipStream_t st);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
-// stage 1 label, 2 next, 3 solve, 4 finalize; stage 5 = stages 1-4 fused in ONE workgroup per
+// stage 1 label + push, 3 solve + results; stage 5 = the whole tail in ONE workgroup per
 // scene (requires maxN <= SA_SMALL_N)
 #define SA_SMALL_N 1024
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,

@@ -8,6 +8,8 @@
 // grid.z = scene so a whole batch of scenes goes through one launch.  No MFMA here on purpose.
 #include "sa_engine.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #define WAVE 64
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
     S.rmatch[i] = -1;
     S.e_cnt[i] = 0;
     S.u[i] = 0;          // row dual: k_positional folds -gain into it with atomic min
-    S.not_first[i] = 0;
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
     BoxRaw r = sa_ldg(S.c_raw + i);
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // strictly needed — harmless, it is still solved exactly.
 //   N <= SA_SMALL_N: k_assign_small — ONE workgroup per scene does labels -> per-component row order (bitonic sort of
 //            (label, row) keys in LDS) -> solve (one thread per component, duals in LDS) -> results,
-//   else: k_assign_label, k_assign_next (one wave per row, 64 labels per probe; marks every row that has a predecessor),
-//            k_assign_solve (one thread per component, started from its first row), k_finalize.
+//   else: k_assign_label (component root per row, rows pushed onto their root's list), k_assign_solve (one thread per
+//            component: orders its rows, solves, writes their results).
 // =====================================================================================================
 __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   sa_assign_ws w;
@@ -660,47 +661,45 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
 }
 
+// General tail, kernel 1 of 2: every participating row finds its component (root = minimum vertex, always a row) and
+// pushes itself onto that root's list — S.label[root] is the list head, S.next_row the links.  No O(N^2) scan for "the
+// next row of my component"; the push order is arbitrary and is put right by the solver thread.
 __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  S.label[q] = (S.e_cnt[q] && !S.row_has[q]) ? sa_uf_find((uint32_t*)S.parent, q) : SA_NONE;
+  if (!S.e_cnt[q] || S.row_has[q]) return;
+  const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
+  S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
 }
 
-__global__ __launch_bounds__(256) void k_assign_next(const SceneDev* __restrict__ scenes) {
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (q >= S.N) return;
-  const uint32_t lab = S.label[q];
-  if (lab == SA_NONE) return;
-  uint32_t found = SA_NONE;
-  for (uint32_t base = q + 1; base < S.N; base += WAVE) {
-    uint32_t r = base + lane;
-    bool hit = r < S.N && S.label[r] == lab;
-    unsigned long long m = __ballot(hit);
-    if (m) { found = base + (uint32_t)__ffsll((long long)m) - 1u; break; }
-  }
-  if (lane == 0) {
-    S.next_row[q] = found;
-    if (found != SA_NONE) S.not_first[found] = 1;  // `found` has a predecessor: it does not start a component
-  }
-}
-
+// Kernel 2 of 2: thread `root` owns the component rooted at row `root`: sorts its row list ascending (insertion sort on the
+// links — components are a handful of rows in tracking workloads; the order only has to be deterministic), solves it, and
+// writes the results of all its rows.  Rows that take no part write their own result.
 __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  if (S.label[q] == SA_NONE || S.not_first[q]) return;  // only the first row of a component works
+  if (!S.e_cnt[q] || S.row_has[q]) finalize_row(S, q);
+  uint32_t cur = S.label[q];
+  if (cur == SA_NONE) return;
+  uint32_t first = SA_NONE;
+  while (cur != SA_NONE) {
+    const uint32_t nxt = S.next_row[cur];
+    if (first == SA_NONE || cur < first) {
+      S.next_row[cur] = first;
+      first = cur;
+    } else {
+      uint32_t p = first, pn = S.next_row[p];
+      while (pn != SA_NONE && pn < cur) { p = pn; pn = S.next_row[p]; }
+      S.next_row[cur] = pn;
+      S.next_row[p] = cur;
+    }
+    cur = nxt;
+  }
   sa_assign_ws w = make_ws(S);
-  sa_assign_component(w, q);
-}
-
-__global__ void k_finalize(const SceneDev* __restrict__ scenes) {
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= S.N) return;
-  finalize_row(S, q);
+  sa_assign_component(w, first);
+  for (uint32_t r = first; r != SA_NONE; r = S.next_row[r]) finalize_row(S, r);
 }
 
 // =====================================================================================================
@@ -744,7 +743,8 @@ hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t ma
                                 hipStream_t st) {
   if (!maxN || !maxT) return hipSuccess;
   const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
-  const bool uni = maxN > SA_SMALL_N;  // the one-workgroup tail builds duals and components itself
+  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const bool uni = maxN > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
   const dim3 grid(cdiv(maxT, wide ? 256 : 64), cdiv(maxN, POS_TI), ns);
   if (wide && uni) SA_LAUNCH((k_positional<false, true, 4, true>), grid, dim3(256), 0, st, scenes, p);
   else if (wide) SA_LAUNCH((k_positional<false, true, 4, false>), grid, dim3(256), 0, st, scenes, p);
@@ -778,9 +778,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (!maxN) return hipSuccess;
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    case 2: SA_LAUNCH(k_assign_next, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes); break;
     case 3: SA_LAUNCH(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
-    case 4: SA_LAUNCH(k_finalize, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     default: SA_LAUNCH(k_assign_small, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); break;
   }
   return hipGetLastError();

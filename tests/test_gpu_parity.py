@@ -93,6 +93,26 @@ def test_sort_iou_parity(oriented, n, t):
         assert (ids == sc["truth"]).mean() > 0.9
 
 
+def test_general_assignment_tail_matches_oracle_too():
+    """Frames with more than 1024 candidates leave the one-workgroup tail for the two-kernel one (component lists + one solver
+    thread per component).  It is exercised here twice: at a size that needs it, and — in a child process, because the switch
+    is read once per process — forced onto the small frames of the other parity tests."""
+    rng = np.random.default_rng(5)
+    sc = synth.sort_scene(rng, 1500, 1300, canvas=(6000.0, 4000.0), oriented=True)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    assert (ids != 0).sum() > 900
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SA_TAIL="general")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "test_sort_iou_parity or test_sort_maha_parity or test_visual_cosine_parity or test_batched_scenes"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_sort_iou_constraints_and_idle_epochs():
     rng = np.random.default_rng(7)
     sc = synth.sort_scene(rng, 200, 220, canvas=(1200.0, 800.0))
