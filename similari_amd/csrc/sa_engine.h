@@ -45,6 +45,7 @@ struct SceneDev {
   uint32_t TK, estride;      // T*K ; row stride of the edge lists
   uint32_t D, flags;         // un-padded feature length ; SCN_* bits
   uint32_t CT, RT;           // BestFit tiles: ceil(T/64), ceil(N/64)
+  uint32_t nkeys, pad0;      // max-key slots = tiles of the visual cost kernel inside this scene
   uint64_t epoch;
   // stored tracks (persist across frames)
   const sa_geo SA_G* t_geo;
@@ -74,7 +75,7 @@ struct SceneDev {
   float SA_G* pos;
   float SA_G* vis;
   // BestFit vote
-  uint32_t SA_G* vis_max_key;   // [SA_MAXKEY_SHARDS] order-preserving keys; max over the shards = BestFit max_dist
+  uint32_t SA_G* vis_max_key;   // [nkeys] order-preserving key of the largest present weight per cost-kernel workgroup (0 = none)
   double SA_G* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
   int32_t SA_G* row_part_t;  // [N][CT]
   double SA_G* col_part_w;   // [RT][T] best weight of the column inside row tile rt
@@ -105,7 +106,6 @@ struct SceneDev {
   uint8_t SA_G* out_vote;
   int64_t SA_G* quant;  // optional N x T tap
 };
-#define SA_MAXKEY_SHARDS 64
 #define SCN_HAS_FEATS 1u
 #define SCN_HAS_QUALITY 2u
 #define SCN_HAS_OWN 4u
@@ -172,6 +172,7 @@ hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes,
                                       const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
                             const SaParams& p, hipStream_t st);
+void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
 // init of the per-frame state + candidate preparation + candidate feature padding/norms, one launch
 hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual,
                                 const SaParams& p, hipStream_t st);

@@ -73,6 +73,7 @@ struct sa_engine {
   hipStream_t stream2 = nullptr;  // side stream: the positional cost kernel runs beside the feature contraction
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t K = 1, D = 0, Dp = 0;
+  uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
   bool visual = false;
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
@@ -268,7 +269,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->fnorm, n * 4));
     TRY(dev_ensure(e, s->vis, n * t * K * 4));
   }
-  TRY(dev_ensure(e, s->vis_max_key, SA_MAXKEY_SHARDS * 4));
+  TRY(dev_ensure(e, s->vis_max_key, ((n + 63) / 64) * ((t * K + 63) / 64) * 4));  // 64x64 tiles: the most slots any plan needs
   if (e->visual) {
     TRY(dev_ensure(e, s->row_part_w, n * CT * 8));
     TRY(dev_ensure(e, s->row_part_t, n * CT * 4));
@@ -313,6 +314,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
              (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
+  d->nkeys = e->visual ? ((s->N + e->tile_bm - 1) / e->tile_bm) * ((s->T * e->K + e->tile_bn - 1) / e->tile_bn) : 0;
   d->epoch = s->epoch;
   d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
   d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
@@ -367,6 +369,7 @@ int run_pipeline(sa_engine* e) {
     maxT = s->T > maxT ? s->T : maxT;
   }
   for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, e->slots[i], e->slots[i]->N, e->slots[i]->T));
+  if (e->visual) sa_visual_tile(e->cfg.visual_kind, maxN, maxT * e->K, ns, e->Dp, &e->tile_bm, &e->tile_bn);
   TRY(upload_scene_descs(e));
   e->synced = false;
   const SceneDev* ds = (const SceneDev*)e->d_scenes.p;

@@ -403,23 +403,31 @@ __device__ __forceinline__ void kgroup_reduce_spread(const f32x16& acc, float* l
 // Row of accumulator register r for lane half lh in a 32x32 MFMA tile (C/D layout, cdna_hip_programming.md §3)
 __device__ __forceinline__ uint32_t acc_row(uint32_t r, uint32_t lh) { return (r & 3u) + 8u * (r >> 2) + 4u * lh; }
 
-// Running maximum of the present weights (BestFitVoting's max_dist): wave shuffle -> LDS -> ONE atomic per
-// workgroup, spread over SA_MAXKEY_SHARDS words.  Atomics on a single word serialise at ~12 ns each on this chip
-// (MI355X_MICROARCH.md "fanin"): one per wave on one word cost 45 us at 4096 waves.
-__device__ __forceinline__ void block_max_key(uint32_t* shards, uint32_t kmax, float* lds) {
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t ok = __shfl_xor(kmax, o);
-    kmax = ok > kmax ? ok : kmax;
-  }
-  uint32_t* s_k = (uint32_t*)lds;
-  __syncthreads();  // every wave is past its last read of the LDS stash
+// Running maximum of the present weights (BestFitVoting's max_dist, voting/best.rs:59-76) WITHOUT atomics: a register-level
+// wave reduction (DPP / ds_swizzle), the wave maxima through one LDS word each and one barrier, then every workgroup stores
+// its maximum into its own slot of S.vis_max_key (slot = tile index inside the scene; the host puts the tile grid into the
+// descriptor).  k_bestfit_tile folds the slots.  Device-scope atomics on shared words serialise on this chip
+// (MI355X_MICROARCH.md "fanin"): one per wave on one word cost 45 us at 4096 waves; sharded 64 ways, one per wave (2048)
+// still +8.7 us and one per workgroup (256) +1.1 us on the C2 kernel.  Key 0 = "no weight" (reads back as -1.0).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));    // xor 1
+  v = mx(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));    // xor 2
+  v = mx(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1F));     // xor 4
+  v = mx(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true));   // row_ror:8 = xor 8
+  v = mx(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F));    // xor 16
+  return mx((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
+}
+__device__ __forceinline__ void block_max_key(uint32_t SA_G* slots, uint32_t slot, uint32_t kmax) {
+  __shared__ uint32_t s_wmax[16];
+  const uint32_t m = wave_max_u32(kmax);
   const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63u) == 0) s_k[wave] = kmax;
+  if ((threadIdx.x & 63u) == 0) s_wmax[wave] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t m = 0;
-    for (uint32_t w = 0; w < nw; ++w) m = s_k[w] > m ? s_k[w] : m;
-    if (m) atomicMax(&shards[(blockIdx.x + blockIdx.y * gridDim.x) & (SA_MAXKEY_SHARDS - 1)], m);
+    uint32_t b = 0;
+    for (uint32_t w = 0; w < nw; ++w) b = s_wmax[w] > b ? s_wmax[w] : b;
+    slots[slot] = b;
   }
 }
 
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;
+  const uint32_t key_slot = blockIdx.y * ((TK + BN - 1) / BN) + blockIdx.x;  // < S.nkeys = tiles of THIS scene
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
       }
   }
   SA_STAMP(tr, 4);
-  block_max_key(S.vis_max_key, kmax, lds);
+  block_max_key(S.vis_max_key, key_slot, kmax);
   SA_STAMP(tr, 5);
 }
 
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restric
       S.vis[(size_t)gi * TK + gj] = out;
     }
   }
-  block_max_key(S.vis_max_key, kmax, lds);
+  block_max_key(S.vis_max_key, blockIdx.y * ((TK + BN - 1) / BN) + blockIdx.x, kmax);
 }
 
 // ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----
@@ -786,6 +795,19 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
   if (b64 <= 320 && nchunks >= 8) return 2;
   if (b64 <= 768 && nchunks >= 4) return 2;
   return 1;
+}
+
+// Tile extents the visual cost kernel will use for a batch with these maxima (the host needs them for the per-scene number of
+// max-key slots, SceneDev::nkeys).
+void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn) {
+  *bm = 64; *bn = 64;
+  if (visual_kind != SA_VIS_COSINE || !maxN || !maxTK) return;
+  switch (tile_plan(maxN, maxTK, ns, Dp)) {
+    case 0: case 8: *bm = 128; *bn = 128; break;
+    case 5: *bm = 64; *bn = 128; break;
+    case 6: *bm = 128; *bn = 64; break;
+    default: break;
+  }
 }
 
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,

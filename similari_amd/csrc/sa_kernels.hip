@@ -119,7 +119,6 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < SA_MAXKEY_SHARDS) S.vis_max_key[i] = sa_f32_key(-1.0f);  // BestFit max_dist starts at -1.0 (voting/best.rs:59)
   if (i < N + T) S.parent[i] = i;
   if (i < T) {
     S.col_excluded[i] = 0;
@@ -325,12 +324,25 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
   const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const uint32_t t = ct * 64 + lane;
   const uint32_t q0 = rt * 64 + wave * 16;
-  uint32_t mk = S.vis_max_key[lane & (SA_MAXKEY_SHARDS - 1)];
+  // BestFit max_dist = the largest present weight of the scene-frame, -1.0 when there is none (voting/best.rs:59): fold the
+  // per-workgroup slots the cost kernel left (every one of them is rewritten each frame; key 0 = none) — all 256 threads
+  // share the loads, the four wave maxima meet in LDS
+  __shared__ uint32_t s_mk[4];
+  uint32_t mk = 0;
+  for (uint32_t i = threadIdx.x; i < S.nkeys; i += 256) {
+    const uint32_t v = S.vis_max_key[i];
+    mk = v > mk ? v : mk;
+  }
   for (int o = 32; o > 0; o >>= 1) {
     uint32_t ok = __shfl_xor(mk, o);
     mk = ok > mk ? ok : mk;
   }
-  const float max_dist = sa_key_f32(mk);
+  if (lane == 0) s_mk[wave] = mk;
+  __syncthreads();
+  mk = s_mk[0] > s_mk[1] ? s_mk[0] : s_mk[1];
+  mk = s_mk[2] > mk ? s_mk[2] : mk;
+  mk = s_mk[3] > mk ? s_mk[3] : mk;
+  const float max_dist = mk ? sa_key_f32(mk) : -1.0f;
   // phase 1: the 16 group weights of this lane's column — all loads issued before any reduction
   double Wr[16];
   if (K == 1) {
