@@ -26,6 +26,7 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 from similari_amd import abi, synth  # noqa: E402
 
+DEFAULT_FLAGS = 0            # engine flags of the timed pass
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
@@ -177,6 +178,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=50)
+    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default: the tuned setting; 0 eager, 4 fork, 8 graph, 12 graph + fork)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate of sa_associate from host buffers")
     args = ap.parse_args()
 
@@ -201,6 +203,7 @@ def main():
 
     cfg, scenes, desc = workload(args.workload, seed=1234 + rank)
     cfg.device = local_rank
+    cfg.flags = DEFAULT_FLAGS if args.flags < 0 else args.flags
     eng = Engine(cfg)
     keep = stage(eng, cfg, scenes)
     models, cells = kernel_models(cfg, scenes)

@@ -110,6 +110,7 @@ typedef struct sa_config {
 #define SA_FLAG_NO_GRAPH 0x1u       /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define SA_FLAG_PROFILE 0x2u        /* bracket every kernel with hipEvents (implies eager launches)    */
 #define SA_FLAG_FORK 0x4u           /* run the positional kernel on a side stream beside the contraction */
+#define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
 /* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,
  * max_idle_epochs 5? -> no: caller must set it; KF weights 1/20, 1/160). */

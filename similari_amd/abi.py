@@ -35,6 +35,7 @@ SA_VOTE_POSITIONAL = 2
 SA_FLAG_NO_GRAPH = 0x1
 SA_FLAG_PROFILE = 0x2
 SA_FLAG_FORK = 0x4
+SA_FLAG_GRAPH = 0x8
 
 
 class sa_box(C.Structure):

@@ -72,6 +72,11 @@ struct sa_engine {
   bool own_stream = false;
   hipStream_t stream2 = nullptr;  // side stream: the positional cost kernel runs beside the feature contraction
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the staged set changes)
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_key[4] = {0, 0, 0, 0};  // ns, maxN, maxT, valid
+  bool descs_changed = true;
   uint32_t K = 1, D = 0, Dp = 0;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
   bool visual = false;
@@ -348,6 +353,7 @@ int upload_scene_descs(sa_engine* e) {
   for (uint32_t i = 0; i < ns; ++i) fill_scene_dev(e, e->slots[i], &b[i]);
   if (e->desc_last.size() == bytes && bytes && std::memcmp(e->desc_last.data(), e->desc_build.data(), bytes) == 0 && e->d_scenes.p)
     return SA_OK;
+  e->descs_changed = true;
   if (!e->synced) TRY(engine_sync(e));
   TRY(host_ensure(e, e->h_scenes, bytes));
   TRY(dev_ensure(e, e->d_scenes, bytes));
@@ -357,29 +363,15 @@ int upload_scene_descs(sa_engine* e) {
   return SA_OK;
 }
 
-// The whole per-frame device pipeline for the staged scenes.  One stream, ~13 launches, no host decisions.
-int run_pipeline(sa_engine* e) {
-  const uint32_t ns = e->n_slots;
-  if (!ns) return SA_OK;
-  uint32_t maxN = 0, maxT = 0;
-  for (uint32_t i = 0; i < ns; ++i) {
-    Slot* s = e->slots[i];
-    s->T = s->scene->T;  // tracks may have been upserted since sa_batch_add
-    maxN = s->N > maxN ? s->N : maxN;
-    maxT = s->T > maxT ? s->T : maxT;
-  }
-  for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, e->slots[i], e->slots[i]->N, e->slots[i]->T));
-  if (e->visual) sa_visual_tile(e->cfg.visual_kind, maxN, maxT * e->K, ns, e->Dp, &e->tile_bm, &e->tile_bn);
-  TRY(upload_scene_descs(e));
-  e->synced = false;
-  const SceneDev* ds = (const SceneDev*)e->d_scenes.p;
+// The per-frame launches for the staged scenes, in order, on the engine's stream (and, when `fork`, the positional kernel on
+// the side stream between two events).  Also the body of the captured graph.
+int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT, bool fork) {
   hipStream_t st = e->stream;
   { ProfScope ps(e, KID_FRAME_PREP); HIPCHK(e, sa_launch_frame_prep(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   // The positional cost cells (f64 VALU) and the feature contraction (matrix cores) are independent until the
   // positional vote: fork them onto two streams, join before the assignment tail.
   // Measured on MI355X / ROCm 7.2: the two cross-stream event waits cost more (~14 us) than the ~9 us of overlap
   // they buy at C2, so the fork is opt-in (SA_FLAG_FORK).
-  const bool fork = (e->cfg.flags & SA_FLAG_FORK) && e->visual && !e->profile && e->stream2 && maxN && maxT;
   if (fork) {
     HIPCHK(e, hipEventRecord(e->ev_fork, st));
     HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
@@ -403,6 +395,46 @@ int run_pipeline(sa_engine* e) {
   } else {
     { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 1)); }
     { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 3)); }
+  }
+  return SA_OK;
+}
+
+// The whole per-frame device pipeline for the staged scenes.  One stream, ~13 launches, no host decisions.
+int run_pipeline(sa_engine* e) {
+  const uint32_t ns = e->n_slots;
+  if (!ns) return SA_OK;
+  uint32_t maxN = 0, maxT = 0;
+  for (uint32_t i = 0; i < ns; ++i) {
+    Slot* s = e->slots[i];
+    s->T = s->scene->T;  // tracks may have been upserted since sa_batch_add
+    maxN = s->N > maxN ? s->N : maxN;
+    maxT = s->T > maxT ? s->T : maxT;
+  }
+  for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, e->slots[i], e->slots[i]->N, e->slots[i]->T));
+  if (e->visual) sa_visual_tile(e->cfg.visual_kind, maxN, maxT * e->K, ns, e->Dp, &e->tile_bm, &e->tile_bn);
+  TRY(upload_scene_descs(e));
+  e->synced = false;
+  const SceneDev* ds = (const SceneDev*)e->d_scenes.p;
+  hipStream_t st = e->stream;
+  const bool want_fork = (e->cfg.flags & SA_FLAG_FORK) && e->visual && !e->profile && e->stream2 && maxN && maxT;
+  if ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile) {
+    const uint32_t key[4] = {ns, maxN, maxT, 1u};
+    if (!e->graph_exec || e->descs_changed || std::memcmp(key, e->graph_key, sizeof key) != 0) {
+      if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+      if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+      HIPCHK(e, hipStreamSynchronize(st));  // the descriptor upload must not be part of the capture
+      HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = enqueue_frame(e, ds, ns, maxN, maxT, want_fork);
+      hipError_t ce = hipStreamEndCapture(st, &e->graph);
+      if (rc != SA_OK) return rc;
+      if (ce != hipSuccess) return fail(e, SA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+      std::memcpy(e->graph_key, key, sizeof key);
+      e->descs_changed = false;
+    }
+    HIPCHK(e, hipGraphLaunch(e->graph_exec, st));
+  } else {
+    TRY(enqueue_frame(e, ds, ns, maxN, maxT, want_fork));
   }
   for (uint32_t i = 0; i < ns; ++i) e->slots[i]->ran = true;
   return SA_OK;
@@ -570,6 +602,8 @@ void sa_engine_destroy(sa_engine* e) {
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
   if (e->ev_t0) hipEventDestroy(e->ev_t0);
   if (e->ev_t1) hipEventDestroy(e->ev_t1);
+  if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+  if (e->graph) hipGraphDestroy(e->graph);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
