@@ -87,17 +87,19 @@ def kernel_models(cfg, scenes):
     nt = sum(len(s["det_boxes"]) + len(s["track_boxes"]) for s in scenes)
     n_ = sum(len(s["det_boxes"]) for s in scenes)
     t_ = sum(len(s["track_boxes"]) for s in scenes)
+    # k_frame = positional tiles + frame-preparation blocks in one launch.  SURVEY §8d figure for the positional cells: f32 cost
+    # out (4 B/cell) + 64 B vertices + 16 B geometry per box — effective bandwidth, the kernel no longer writes the dense matrix
+    # (it emits the edges of the vote directly); plus what the preparation blocks really move (features in and out, 160 B/box).
+    frame_bytes = 4.0 * cells + 80.0 * nt + 160.0 * n_
     m = {
-        # SURVEY §8d figure for the positional cells: f32 cost out (4 B/cell) + 64 B vertices + 16 B geometry per box.  The kernel
-        # itself no longer writes the dense matrix (it emits the edges of the vote directly), so this is effective bandwidth.
-        "k_positional": ("hbm", 4.0 * cells + 80.0 * nt),
         # one read of the visual weights (4 B per cell and bank slot) + the per-tile partials
         "k_bestfit_tile": ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0),
     }
     if visual:
         flops = sum(2.0 * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
         m["k_visual_cost"] = ("mfma", flops)
-        m["k_frame_prep"] = ("hbm", 4.0 * n_ * (cfg.feature_len + D8) + 160.0 * n_)
+        frame_bytes += 4.0 * n_ * (cfg.feature_len + D8)
+    m["k_frame"] = ("hbm", frame_bytes)
     return m, cells
 
 

@@ -87,10 +87,12 @@ struct SceneDev {
   uint32_t SA_G* parent;
   uint32_t SA_G* label;      // [N] general tail: head of the row list of the component rooted at this row
   uint32_t SA_G* next_row;
-  uint32_t SA_G* e_cnt;
+  uint32_t SA_G* e_cnt;      // [N] edges appended by the positional tiles; zero between frames (the tail leaves it clean)
+  uint32_t SA_G* e_use;      // [N] many-workgroup tail: the counts the solver works on
   uint32_t SA_G* e_col;
   int64_t SA_G* e_gain;
-  int64_t SA_G* u;
+  int64_t SA_G* u;           // [N] -max gain per row, folded by the positional tiles (UNION); zero between frames
+  int64_t SA_G* u_use;       // [N] many-workgroup tail: the solver's row duals
   int64_t SA_G* v;
   int32_t SA_G* rmatch;
   int32_t SA_G* cmatch;
@@ -166,16 +168,15 @@ hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, u
 hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* index, uint32_t rows, uint32_t row_bytes,
                                  hipStream_t st);
 
-hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
-                                const SaParams& p, hipStream_t st);
+// first launch of a frame: positional tiles + frame-preparation blocks
+hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
+                           hipStream_t st);
+hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices, hipStream_t st);
 hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                       const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
                             const SaParams& p, hipStream_t st);
 void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
-// init of the per-frame state + candidate preparation + candidate feature padding/norms, one launch
-hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual,
-                                const SaParams& p, hipStream_t st);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
 // stage 1 label + push, 3 solve + results; stage 5 = the whole tail in ONE workgroup per

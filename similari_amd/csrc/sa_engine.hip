@@ -16,11 +16,11 @@ namespace {
 thread_local std::string g_create_error;
 
 enum KernelId {
-  KID_FRAME_PREP = 0, KID_POSITIONAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
+  KID_FRAME = 0, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
   KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
-    "k_frame_prep", "k_positional", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
+    "k_frame", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
     "k_assign_label", "k_assign_solve", "d2h_results"};
 
 struct DevBuf {
@@ -53,11 +53,12 @@ struct Slot {  // one scene of the current batch
   // matrices + vote + assignment state
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
-  DevBuf parent, label, next_row, e_cnt, e_col, e_gain, u, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
+  DevBuf parent, label, next_row, e_cnt, e_use, e_col, e_gain, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   HostBuf h_in;
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   bool ran = false;
+  bool needs_init = true;  // e_cnt / u / parent were (re)allocated, or a run may have died half-way: k_slot_init before the next frame
 };
 
 }  // namespace
@@ -284,13 +285,17 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->row_has, n));
   TRY(dev_ensure(e, s->vis_winner, n * 4));
   TRY(dev_ensure(e, s->col_excluded, t));
+  void *p_par = s->parent.p, *p_ec = s->e_cnt.p, *p_u = s->u.p;
   TRY(dev_ensure(e, s->parent, (n + t) * 4));
   TRY(dev_ensure(e, s->label, n * 4));
   TRY(dev_ensure(e, s->next_row, n * 4));
   TRY(dev_ensure(e, s->e_cnt, n * 4));
+  TRY(dev_ensure(e, s->e_use, n * 4));
   TRY(dev_ensure(e, s->e_col, n * t * 4));
   TRY(dev_ensure(e, s->e_gain, n * t * 8));
   TRY(dev_ensure(e, s->u, n * 8));
+  TRY(dev_ensure(e, s->u_use, n * 8));
+  if (s->parent.p != p_par || s->e_cnt.p != p_ec || s->u.p != p_u) s->needs_init = true;
   TRY(dev_ensure(e, s->v, t * 8));
   TRY(dev_ensure(e, s->rmatch, n * 4));
   TRY(dev_ensure(e, s->cmatch, t * 4));
@@ -335,8 +340,8 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
   d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
-  d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_col = (decltype(d->e_col))(s->e_col.p); d->e_gain = (decltype(d->e_gain))(s->e_gain.p);
-  d->u = (decltype(d->u))(s->u.p); d->v = (decltype(d->v))(s->v.p); d->rmatch = (decltype(d->rmatch))(s->rmatch.p); d->cmatch = (decltype(d->cmatch))(s->cmatch.p);
+  d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_col = (decltype(d->e_col))(s->e_col.p); d->e_gain = (decltype(d->e_gain))(s->e_gain.p);
+  d->u = (decltype(d->u))(s->u.p); d->u_use = (decltype(d->u_use))(s->u_use.p); d->v = (decltype(d->v))(s->v.p); d->rmatch = (decltype(d->rmatch))(s->rmatch.p); d->cmatch = (decltype(d->cmatch))(s->cmatch.p);
   d->dist = (decltype(d->dist))(s->dist.p); d->pred = (decltype(d->pred))(s->pred.p); d->cstamp = (decltype(d->cstamp))(s->cstamp.p); d->cscan = (decltype(d->cscan))(s->cscan.p);
   d->cnext = (decltype(d->cnext))(s->cnext.p); d->rdist = (decltype(d->rdist))(s->rdist.p); d->rnext = (decltype(d->rnext))(s->rnext.p);
   d->out_track_id = (decltype(d->out_track_id))(s->d_out); d->out_vote = (decltype(d->out_vote))((uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8);
@@ -365,28 +370,15 @@ int upload_scene_descs(sa_engine* e) {
 
 // The per-frame launches for the staged scenes, in order, on the engine's stream (and, when `fork`, the positional kernel on
 // the side stream between two events).  Also the body of the captured graph.
-int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT, bool fork) {
+int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
   hipStream_t st = e->stream;
-  { ProfScope ps(e, KID_FRAME_PREP); HIPCHK(e, sa_launch_frame_prep(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
-  // The positional cost cells (f64 VALU) and the feature contraction (matrix cores) are independent until the
-  // positional vote: fork them onto two streams, join before the assignment tail.
-  // Measured on MI355X / ROCm 7.2: the two cross-stream event waits cost more (~14 us) than the ~9 us of overlap
-  // they buy at C2, so the fork is opt-in (SA_FLAG_FORK).
-  if (fork) {
-    HIPCHK(e, hipEventRecord(e->ev_fork, st));
-    HIPCHK(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, e->stream2));
-    HIPCHK(e, hipEventRecord(e->ev_join, e->stream2));
-  } else {
-    ProfScope ps(e, KID_POSITIONAL);
-    HIPCHK(e, sa_launch_positional(ds, ns, maxN, maxT, e->P, st));
-  }
+  // launch 1: positional tiles (edges of the positional vote) + frame-preparation blocks, side by side
+  { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   if (e->visual) {
     { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
     { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
     { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
   }
-  if (fork) HIPCHK(e, hipStreamWaitEvent(st, e->ev_join, 0));
   // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle)
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   if (maxN <= SA_SMALL_N && !force_general) {
@@ -416,7 +408,15 @@ int run_pipeline(sa_engine* e) {
   e->synced = false;
   const SceneDev* ds = (const SceneDev*)e->d_scenes.p;
   hipStream_t st = e->stream;
-  const bool want_fork = (e->cfg.flags & SA_FLAG_FORK) && e->visual && !e->profile && e->stream2 && maxN && maxT;
+  // assignment state that the tail kernels keep clean from frame to frame: establish it after (re)allocation
+  for (uint32_t i = 0; i < ns; ++i) {
+    Slot* s = e->slots[i];
+    if (!s->needs_init) continue;
+    HIPCHK(e, sa_launch_slot_init((uint32_t*)s->e_cnt.p, (int64_t*)s->u.p, (uint32_t)(s->e_cnt.cap / 4 < s->u.cap / 8 ? s->e_cnt.cap / 4 : s->u.cap / 8),
+                                  (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
+    s->needs_init = false;
+    e->descs_changed = true;  // a captured graph must not skip this
+  }
   if ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile) {
     const uint32_t key[4] = {ns, maxN, maxT, 1u};
     if (!e->graph_exec || e->descs_changed || std::memcmp(key, e->graph_key, sizeof key) != 0) {
@@ -424,7 +424,7 @@ int run_pipeline(sa_engine* e) {
       if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
       HIPCHK(e, hipStreamSynchronize(st));  // the descriptor upload must not be part of the capture
       HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = enqueue_frame(e, ds, ns, maxN, maxT, want_fork);
+      int rc = enqueue_frame(e, ds, ns, maxN, maxT);
       hipError_t ce = hipStreamEndCapture(st, &e->graph);
       if (rc != SA_OK) return rc;
       if (ce != hipSuccess) return fail(e, SA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
@@ -434,7 +434,11 @@ int run_pipeline(sa_engine* e) {
     }
     HIPCHK(e, hipGraphLaunch(e->graph_exec, st));
   } else {
-    TRY(enqueue_frame(e, ds, ns, maxN, maxT, want_fork));
+    int rc = enqueue_frame(e, ds, ns, maxN, maxT);
+    if (rc != SA_OK) {  // a frame that died half-way may leave the self-cleaning state dirty
+      for (uint32_t i = 0; i < ns; ++i) e->slots[i]->needs_init = true;
+      return rc;
+    }
   }
   for (uint32_t i = 0; i < ns; ++i) e->slots[i]->ran = true;
   return SA_OK;
@@ -586,7 +590,7 @@ void sa_engine_destroy(sa_engine* e) {
     for (DevBuf* b : {&s->raw, &s->quality, &s->own, &s->fpresent_in, &s->feat_raw, &s->geo, &s->verts, &s->z, &s->conf,
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                       &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
-                      &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_col, &s->e_gain, &s->u, &s->v, &s->rmatch,
+                      &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_col, &s->e_gain, &s->u, &s->u_use, &s->v, &s->rmatch,
                       &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext})
       free_dev(*b);
     free_host(s->h_in);

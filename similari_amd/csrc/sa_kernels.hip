@@ -108,18 +108,21 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restri
 }
 
 // =====================================================================================================
-// k_frame_prep: everything that is O(N + T) at the start of a frame, in ONE launch:
+// Frame preparation blocks: everything that is O(N + T) at the start of a frame and that the kernels AFTER the first launch
+// consume —
 //   * reset of the vote / assignment state (one thread per vertex of the bipartite graph),
-//   * candidate preparation (visual_sort/simple_api.rs:130-170): geometry, f64 vertices, Mahalanobis
-//     measurement (angle.unwrap_or(0), kalman_2d_box.rs:159), clamped confidence (sort/metric.rs:43-47),
-//     the feature_can_be_used gate (visual_sort/metric.rs:227-249),
+//   * candidate preparation (visual_sort/simple_api.rs:130-170): geometry, f64 vertices, Mahalanobis measurement
+//     (angle.unwrap_or(0), kalman_2d_box.rs:159), clamped confidence (sort/metric.rs:43-47), the feature_can_be_used gate
+//     (visual_sort/metric.rs:227-249) — for the contraction's epilogue and the parity taps,
 //   * candidate feature padding + squared norms (one wave per row).
+// They ride in the SAME launch as the positional tiles (k_frame below), which re-derive the few candidates they need from
+// the raw boxes instead of waiting for these arrays: one dependent launch (~4.7 us) less per frame.  State the positional
+// tiles themselves write (edge counters, and for the many-workgroup tail the row duals and the union-find forest) cannot be
+// reset beside them; the assignment tail leaves it clean for the next frame instead (k_slot_init establishes it once).
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__ scenes, SaParams p) {
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk) {
   const uint32_t N = S.N, T = S.T;
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < N + T) S.parent[i] = i;
+  const uint32_t i = blk * 256 + threadIdx.x;
   if (i < T) {
     S.col_excluded[i] = 0;
     S.v[i] = 0;
@@ -131,8 +134,6 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
     S.vis_winner[i] = -1;
     S.row_has[i] = 0;
     S.rmatch[i] = -1;
-    S.e_cnt[i] = 0;
-    S.u[i] = 0;          // row dual: k_positional folds -gain into it with atomic min
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
     BoxRaw r = sa_ldg(S.c_raw + i);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
     S.c_usable[i] = usable ? 1 : 0;
   }
   if (S.flags & SCN_HAS_FEATS) {
-    const uint32_t row = blockIdx.x * 4 + threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const uint32_t row = blk * 4 + threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (row < N) {
       bool pres = !(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[row] != 0;
       float nrm;
@@ -164,6 +165,13 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
       if (lane == 0) S.c_fnorm[row] = nrm;
     }
   }
+}
+
+// Once per (re)allocation of a slot's assignment state: what the tail kernels afterwards leave behind every frame.
+__global__ void k_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows) { e_cnt[i] = 0; u[i] = 0; }
+  if (i < n_vertices) parent[i] = i;
 }
 
 // =====================================================================================================
@@ -188,21 +196,30 @@ __global__ __launch_bounds__(256) void k_frame_prep(const SceneDev* __restrict__
 // tail).  When the whole scene is solved by ONE workgroup (k_assign_small) that workgroup builds both from the edge lists in
 // LDS instead — the chain of dependent global atomics per edge would otherwise sit at the tail of every block here.
 template <bool DENSE, bool EDGES, int NSUB, bool UNION>
-__global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__ scenes, SaParams p) {
+__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by) {
   constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = 64u;
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
-  const uint32_t i0 = blockIdx.y * POS_TI, j0 = blockIdx.x * POS_TJ;
+  const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
   __shared__ sa_geo s_cg[POS_TI];
+  __shared__ double s_cv[POS_TI][8];   // candidate polygons, derived here from the raw boxes (see frame_prep_block)
+  __shared__ float s_cconf[POS_TI], s_cz[POS_TI][5];
   __shared__ uint16_t s_list[POS_TI * POS_TJ];  // (li << 8) | lj
   __shared__ uint32_t s_cnt;
   __shared__ double s_poly[4 * SA_POLY_CAP * POS_WORKERS];  // 24 KB
   __shared__ float s_thha[POS_TJ];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   if (tid < POS_TI) {
-    uint32_t i = i0 + tid;
-    s_cg[tid] = i < N ? sa_ldg(S.c_geo + i) : sa_geo{0.f, 0.f, 0.f, 0.f};
+    const uint32_t i = i0 + tid;
+    if (i < N) {
+      const BoxRaw r = sa_ldg(S.c_raw + i);
+      prep_box_common(r, &s_cg[tid], s_cv[tid]);
+      const sa_box& b = r.box;
+      s_cconf[tid] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
+      s_cz[tid][0] = b.xc; s_cz[tid][1] = b.yc; s_cz[tid][2] = b.has_angle ? b.angle : 0.0f; s_cz[tid][3] = b.aspect; s_cz[tid][4] = b.height;
+    } else {
+      s_cg[tid] = sa_geo{0.f, 0.f, 0.f, 0.f};
+    }
   }
   if (tid == 0) s_cnt = 0;
   // this thread's 4 tracks (one per 64-wide sub-tile): loads in flight while the candidate tile lands in LDS
@@ -263,10 +280,9 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       const float SA_G* mp = S.t_maha + (size_t)j * 20;
 #pragma unroll
       for (int k = 0; k < 20; ++k) m20[k] = mp[k];
-      const float SA_G* zp = S.c_z + (size_t)i * 5;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) z5[k] = zp[k];
-      emit(i, j, sa_maha_cell(m20, z5, S.c_conf[i]), true);
+      for (int k = 0; k < 5; ++k) z5[k] = s_cz[li][k];
+      emit(i, j, sa_maha_cell(m20, z5, s_cconf[li]), true);
     }
   } else if (tid < POS_WORKERS) {
     // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS
@@ -276,22 +292,34 @@ __global__ __launch_bounds__(256) void k_positional(const SceneDev* __restrict__
       const uint32_t li = c >> 8, lj = c & 255u;
       const uint32_t i = i0 + li, j = j0 + lj;
       double cv[8], tv[8];
-      const double SA_G* cp = S.c_verts + (size_t)i * 8;
       const double SA_G* tp = S.t_verts + (size_t)j * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { cv[k] = cp[k]; tv[k] = tp[k]; }
+      for (int k = 0; k < 8; ++k) { cv[k] = s_cv[li][k]; tv[k] = tp[k]; }
       const float t_hha = s_thha[lj];
       double inter = sa_clip_area_ws(cv, tv, ws, ws + SA_POLY_CAP * POS_WORKERS, ws + 2 * SA_POLY_CAP * POS_WORKERS,
                                      ws + 3 * SA_POLY_CAP * POS_WORKERS, POS_WORKERS);
       float iou, out = nanv;
       bool present = false;
       if (sa_iou_from_area(inter, s_cg[li].hha, t_hha, &iou)) {
-        float e = iou * S.c_conf[i];
+        float e = iou * s_cconf[li];
         if (e >= p.positional_threshold) { out = e; present = true; }
       }
       emit(i, j, out, present);
     }
   }
+}
+
+// The first launch of a frame: blockIdx.y < pos_rows -> a positional tile; the rows above carry the frame-preparation blocks.
+template <int NSUB, bool UNION>
+__global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows) {
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION>(S, p, blockIdx.x, blockIdx.y);
+  else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x);
+}
+// Parity taps: the dense f32 cost matrix, no side effects.
+__global__ __launch_bounds__(256) void k_positional_dense(const SceneDev* __restrict__ scenes, SaParams p) {
+  const SceneDev S = scenes[blockIdx.z];
+  positional_tile<true, false, 1, false>(S, p, blockIdx.x, blockIdx.y);
 }
 
 // Debug tap: (w * 1e6f) as i64 of every positional cell, 0 where absent (sort/voting.rs:59).
@@ -479,10 +507,10 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // =====================================================================================================
 __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   sa_assign_ws w;
-  w.e_cnt = S.e_cnt; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride; w.e_off = nullptr;
+  w.e_cnt = S.e_use; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride; w.e_off = nullptr;
   w.excluded = S.col_excluded;
   w.next_row = S.next_row;
-  w.u = S.u; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
+  w.u = S.u_use; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
   w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
   w.rdist = S.rdist; w.rnext = S.rnext;
   return w;
@@ -524,7 +552,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ uint32_t s_ecol[POOL];
   __shared__ int64_t s_egain[POOL];
   const bool uf_in_lds = T <= SA_SMALL_N;
-  const uint32_t mycnt = (q < N && !S.row_has[q]) ? S.e_cnt[q] : 0u;
+  const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
+  if (q < N) S.e_cnt[q] = 0;  // left clean for the next frame's positional tiles (nothing below reads the global counter)
+  const uint32_t mycnt = (q < N && !S.row_has[q]) ? rawcnt : 0u;
   s_rmatch[q] = -1;
   s_ecnt[q] = mycnt;
   if (uf_in_lds) { s_parent[q] = q; s_parent[q + SA_SMALL_N] = q + SA_SMALL_N; }
@@ -680,7 +710,13 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S.N) return;
-  if (!S.e_cnt[q] || S.row_has[q]) return;
+  // move this row's edge count and dual to the solver's copies and leave the accumulators clean for the next frame
+  const uint32_t cnt = S.e_cnt[q];
+  S.e_use[q] = cnt;
+  S.e_cnt[q] = 0;
+  S.u_use[q] = S.u[q];
+  S.u[q] = 0;
+  if (!cnt || S.row_has[q]) return;
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
 }
@@ -691,8 +727,10 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
 __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
+  for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * blockDim.x) S.parent[i] = i;
   if (q >= S.N) return;
-  if (!S.e_cnt[q] || S.row_has[q]) finalize_row(S, q);
+  if (!S.e_use[q] || S.row_has[q]) finalize_row(S, q);
   uint32_t cur = S.label[q];
   if (cur == SA_NONE) return;
   uint32_t first = SA_NONE;
@@ -744,31 +782,34 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
                      (uint8_t*)dst, index, rows, row_bytes);
   return hipGetLastError();
 }
-hipError_t sa_launch_frame_prep(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual,
-                                const SaParams& p, hipStream_t st) {
-  uint32_t blocks = cdiv(maxN + maxT + 1, 256);
-  if (visual && cdiv(maxN, 4) > blocks) blocks = cdiv(maxN, 4);
-  SA_LAUNCH(k_frame_prep, dim3(blocks, 1, ns), dim3(256), 0, st, scenes, p);
+hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices, hipStream_t st) {
+  const uint32_t n = n_rows > n_vertices ? n_rows : n_vertices;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_slot_init, dim3(cdiv(n, 256)), dim3(256), 0, st, e_cnt, u, n_rows, parent, n_vertices);
   return hipGetLastError();
 }
-hipError_t sa_launch_positional(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
-                                hipStream_t st) {
-  if (!maxN || !maxT) return hipSuccess;
-  const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
+// First launch of a frame: positional tiles + frame-preparation blocks (see k_frame).
+hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
+                           hipStream_t st) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
   const bool uni = maxN > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
-  const dim3 grid(cdiv(maxT, wide ? 256 : 64), cdiv(maxN, POS_TI), ns);
-  if (wide && uni) SA_LAUNCH((k_positional<false, true, 4, true>), grid, dim3(256), 0, st, scenes, p);
-  else if (wide) SA_LAUNCH((k_positional<false, true, 4, false>), grid, dim3(256), 0, st, scenes, p);
-  else if (uni) SA_LAUNCH((k_positional<false, true, 1, true>), grid, dim3(256), 0, st, scenes, p);
-  else SA_LAUNCH((k_positional<false, true, 1, false>), grid, dim3(256), 0, st, scenes, p);
+  const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
+  const uint32_t pos_rows = (maxN && maxT) ? cdiv(maxN, POS_TI) : 0u;
+  uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
+  if (visual && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
+  if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
+  else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
+  else if (uni) SA_LAUNCH((k_frame<1, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
+  else SA_LAUNCH((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
   return hipGetLastError();
 }
 // parity taps: the dense f32 cost matrix of the staged scenes, no side effects on the assignment state
 hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                                       hipStream_t st) {
   if (!maxN || !maxT) return hipSuccess;
-  hipLaunchKernelGGL((k_positional<true, false, 1, false>), dim3(cdiv(maxT, 64), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
+  hipLaunchKernelGGL(k_positional_dense, dim3(cdiv(maxT, 64), cdiv(maxN, POS_TI), ns), dim3(256), 0, st, scenes, p);
   return hipGetLastError();
 }
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, hipStream_t st) {
