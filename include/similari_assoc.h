@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SA_API_VERSION 1u
+#define SA_API_VERSION 2u
 
 typedef enum sa_status {
   SA_OK = 0,
@@ -105,11 +105,13 @@ typedef struct sa_config {
   float kf_velocity_weight;         /* 1/160 by default                        */
 
   uint32_t flags;                   /* SA_FLAG_* */
+
+  /* device-side track upkeep (sa_tracks_apply): the COLLECT gates of VisualMetric::optimize, visual_sort/metric.rs:337-349 */
+  float visual_minimal_quality_collect;
+  float visual_minimal_own_area_percentage_collect;
 } sa_config;
 
-#define SA_FLAG_NO_GRAPH 0x1u       /* launch kernels eagerly instead of replaying a captured hipGraph */
-#define SA_FLAG_PROFILE 0x2u        /* bracket every kernel with hipEvents (implies eager launches)    */
-#define SA_FLAG_FORK 0x4u           /* run the positional kernel on a side stream beside the contraction */
+#define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
 /* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,
@@ -181,6 +183,26 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
 int sa_batch_run(sa_engine* e);
 int sa_batch_sync(sa_engine* e);
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type);
+
+/* ---- device-side track upkeep: the step either side of the association ------------
+ * Applies the result of the last run of batch slot `slot` to that scene's device-resident track table, the way
+ * Sort / VisualSort::predict do after voting (sort/simple_api.rs:164-190, visual_sort/simple_api.rs:189-226 ->
+ * Track::merge -> SortMetric / VisualMetric::optimize), without a host round trip of boxes, Kalman state or features:
+ *   candidate i won track w    -> w takes one Kalman predict + update with the candidate's box (make_prediction,
+ *                                 kalman_prediction.rs:13-32), its epoch becomes the frame's, its feature bank follows
+ *                                 optimize_observations (visual_sort/metric.rs:129-154; COLLECT gates from sa_config)
+ *   candidate i has no winner  -> a new track with id new_ids[i] is appended: initiate -> predict -> update, bank = [its
+ *                                 observation]
+ * out_predicted[i] = the box of the destination track after the step (SortTrack::predicted_bbox).  new_ids[i] must be > 0
+ * and unused in the scene where candidate i has no winner (ignored elsewhere).  Tracks must have been created by this call
+ * (or given a full state with sa_tracks_set_state): a track upserted with the 5 x 5 projection only cannot be stepped. */
+int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted);
+/* Full per-track state for the device-side upkeep (debug / parity / seeding): Kalman mean[10] + cov[100] row-major, and per
+ * bank slot the feature quality[K].  Any of the output pointers may be NULL. */
+int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality,
+                        uint8_t* present, float* feats /* K x D */);
+int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const float* mean10, const float* cov100,
+                        const float* quality /* K or NULL */);
 
 typedef struct sa_scene_request {
   uint64_t scene_id;

@@ -83,6 +83,9 @@ typedef struct sa_tracker_options {
   float visual_minimal_quality_collect;
   float visual_minimal_own_area_percentage_use;
   float visual_minimal_own_area_percentage_collect;
+  int32_t device_upkeep;                /* 1 = Kalman step, table refresh and feature-bank policy run on the GPU (sa_tracks_apply):
+                                           no per-frame upload of boxes / Kalman state / features; 0 = host upkeep + sa_tracks_upsert */
+  int32_t reserved;
 } sa_tracker_options;
 
 typedef struct sa_tracker sa_tracker;

@@ -32,7 +32,6 @@ SA_VOTE_NONE = 0
 SA_VOTE_VISUAL = 1
 SA_VOTE_POSITIONAL = 2
 
-SA_FLAG_NO_GRAPH = 0x1
 SA_FLAG_PROFILE = 0x2
 SA_FLAG_FORK = 0x4
 SA_FLAG_GRAPH = 0x8
@@ -90,6 +89,8 @@ class sa_config(C.Structure):
         ("kf_position_weight", C.c_float),
         ("kf_velocity_weight", C.c_float),
         ("flags", C.c_uint32),
+        ("visual_minimal_quality_collect", C.c_float),
+        ("visual_minimal_own_area_percentage_collect", C.c_float),
     ]
 
 
@@ -183,6 +184,8 @@ class sa_tracker_options(C.Structure):
         ("visual_minimal_quality_collect", C.c_float),
         ("visual_minimal_own_area_percentage_use", C.c_float),
         ("visual_minimal_own_area_percentage_collect", C.c_float),
+        ("device_upkeep", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -250,6 +253,8 @@ def make_config(
     device=-1,
     stream=None,
     flags=0,
+    visual_minimal_quality_collect=0.0,
+    visual_minimal_own_area_percentage_collect=0.0,
 ):
     """sa_config with the reference's defaults; returns (cfg, keepalive)."""
     keep = Keep()
@@ -284,6 +289,8 @@ def make_config(
     cfg.kf_position_weight = kf_position_weight
     cfg.kf_velocity_weight = kf_velocity_weight
     cfg.flags = flags
+    cfg.visual_minimal_quality_collect = visual_minimal_quality_collect
+    cfg.visual_minimal_own_area_percentage_collect = visual_minimal_own_area_percentage_collect
     cfg._keep = keep
     return cfg
 
@@ -340,6 +347,9 @@ PROTOTYPES = {
     "sa_batch_sync": (C.c_int, [ENGINE]),
     "sa_batch_fetch": (C.c_int, [ENGINE, u32, P(u64), P(C.c_uint8)]),
     "sa_associate_batch": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(sa_scene_result)]),
+    "sa_tracks_apply": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
+    "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
+    "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_tap_dims": (C.c_int, [ENGINE, u32, P(u32), P(u32), P(u32)]),
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),

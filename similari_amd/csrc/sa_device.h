@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define SA_HD __host__ __device__ __forceinline__
 #else
 #define SA_HD inline

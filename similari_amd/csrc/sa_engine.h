@@ -106,6 +106,7 @@ struct SceneDev {
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t SA_G* out_track_id;
   uint8_t SA_G* out_vote;
+  int32_t SA_G* win_col;     // [N] winning track as a column of the table, -1 = none: what the device-side upkeep consumes
   int64_t SA_G* quant;  // optional N x T tap
 };
 #define SCN_HAS_FEATS 1u
@@ -127,6 +128,7 @@ struct SaParams {
   float visual_minimal_quality_use;
   float visual_minimal_own_area_use;
   float kf_position_weight;
+  float kf_velocity_weight;
   uint32_t Dp;                  // feature row stride of this engine (D rounded up to 32)
   uint64_t max_idle;
   sa_constraints cons;
@@ -189,5 +191,41 @@ hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
                                      uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st);
+
+// ---- device-side track upkeep (sa_upkeep.hip) ----
+struct ApplyArgs {
+  const BoxRaw* c_raw;       // [n] candidates of the slot
+  const int32_t* win_col;    // [n] winning column or -1
+  const uint32_t* new_row;   // [n] table row for a candidate that starts a track
+  const uint64_t* new_ids;   // [n] its id
+  uint32_t n;
+  uint64_t epoch;
+  float* kf;                 // [T][110] Kalman mean(10) + covariance(100)
+  sa_geo* geo;
+  double* verts;
+  uint64_t* t_epoch;
+  uint64_t* t_ids;
+  float* maha;
+  sa_box* out_pred;          // [n] device view of pinned host memory
+};
+struct BankArgs {
+  const BoxRaw* c_raw;
+  const int32_t* win_col;
+  const uint32_t* new_row;
+  uint32_t n, K, Dp;
+  const float* c_feat;       // [n][Dp] padded candidate features (nullptr: the frame carried none)
+  const float* c_fnorm;
+  const uint8_t* c_fpresent_in;
+  const float* c_quality;
+  const float* c_own;
+  float* t_feat;
+  float* t_fnorm;
+  uint8_t* t_fpresent;
+  float* t_fquality;
+  uint32_t* t_fcount;
+  float* tmp;                // [n][K][Dp]
+  float minimal_area, q_collect, own_collect;
+};
+hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st);
 
 const char* sa_kernel_name(int id);

@@ -2,6 +2,7 @@
 // scene, per-batch staging, the kernel pipeline, parity taps and hipEvent timing.  No CPU compute path:
 // without a gfx950 device sa_engine_create fails with SA_ERR_NO_DEVICE.
 #include "sa_engine.h"
+#include "sa_kalman.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -39,6 +40,8 @@ struct SceneTable {
   std::vector<uint64_t> ids;                       // slot -> id
   std::unordered_map<uint64_t, uint32_t> slot_of;  // id -> slot
   DevBuf geo, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
+  DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
+  std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
 };
 
 struct Slot {  // one scene of the current batch
@@ -54,6 +57,9 @@ struct Slot {  // one scene of the current batch
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
   DevBuf parent, label, next_row, e_cnt, e_use, e_col, e_gain, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
+  DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
+  HostBuf h_apply, h_pred;
+  void* d_pred = nullptr;
   HostBuf h_in;
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
@@ -242,11 +248,13 @@ int scene_reserve(sa_engine* e, SceneTable* s, uint32_t need) {
   TRY(dev_ensure(e, s->epoch, (size_t)ncap * 8, true));
   TRY(dev_ensure(e, s->maha, (size_t)ncap * 20 * sizeof(float), true));
   TRY(dev_ensure(e, s->tids, (size_t)ncap * 8, true));
+  TRY(dev_ensure(e, s->kf, (size_t)ncap * 110 * sizeof(float), true));
   if (e->visual) {
     TRY(dev_ensure(e, s->feat, (size_t)ncap * KDp * sizeof(float), true));
     TRY(dev_ensure(e, s->fnorm, (size_t)ncap * e->K * sizeof(float), true));
     TRY(dev_ensure(e, s->fpresent, (size_t)ncap * e->K, true));
     TRY(dev_ensure(e, s->fcount, (size_t)ncap * 4, true));
+    TRY(dev_ensure(e, s->fquality, (size_t)ncap * e->K * sizeof(float), true));
   }
   s->cap = ncap;
   return SA_OK;
@@ -306,6 +314,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->cnext, t * 4));
   TRY(dev_ensure(e, s->rdist, n * 8));
   TRY(dev_ensure(e, s->rnext, n * 4));
+  TRY(dev_ensure(e, s->win_col, n * 4));
   {
     void* before = s->h_out.p;
     TRY(host_ensure(e, s->h_out, n * 9));
@@ -346,6 +355,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->cnext = (decltype(d->cnext))(s->cnext.p); d->rdist = (decltype(d->rdist))(s->rdist.p); d->rnext = (decltype(d->rnext))(s->rnext.p);
   d->out_track_id = (decltype(d->out_track_id))(s->d_out); d->out_vote = (decltype(d->out_vote))((uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8);
   d->quant = (decltype(d->quant))(s->quant.p);
+  d->win_col = (decltype(d->win_col))(s->win_col.p);
 }
 
 // Descriptors go through one pinned buffer.  A run that finds them unchanged (a benchmark loop, or a frame
@@ -475,6 +485,8 @@ const char* sa_last_error(const sa_engine* e) { return e ? e->err.c_str() : g_cr
 int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   if (!cfg || !out) return fail(nullptr, SA_ERR_BAD_ARG, "sa_engine_create: null argument");
   *out = nullptr;
+  if (cfg->max_observations > SA_MAX_BANK && cfg->visual_kind != SA_VIS_NONE)
+    return fail(nullptr, SA_ERR_UNSUPPORTED, "at most %d observations per track", SA_MAX_BANK);
   if (cfg->struct_size != sizeof(sa_config))
     return fail(nullptr, SA_ERR_BAD_ARG, "sa_config.struct_size %u != %zu", cfg->struct_size, sizeof(sa_config));
   if (cfg->n_constraints > SA_MAX_CONSTRAINTS)
@@ -547,6 +559,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.visual_minimal_quality_use = cfg->visual_minimal_quality_use;
   P.visual_minimal_own_area_use = cfg->visual_minimal_own_area_percentage_use;
   P.kf_position_weight = cfg->kf_position_weight;
+  P.kf_velocity_weight = cfg->kf_velocity_weight;
   P.max_idle = cfg->max_idle_epochs;
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
@@ -583,7 +596,7 @@ void sa_engine_destroy(sa_engine* e) {
   for (void* p : e->garbage) hipFree(p);
   for (auto& kv : e->scenes) {
     SceneTable* s = kv.second;
-    for (DevBuf* b : {&s->geo, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids}) free_dev(*b);
+    for (DevBuf* b : {&s->geo, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
     delete s;
   }
   for (Slot* s : e->slots) {
@@ -591,8 +604,11 @@ void sa_engine_destroy(sa_engine* e) {
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                       &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
                       &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_col, &s->e_gain, &s->u, &s->u_use, &s->v, &s->rmatch,
-                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext})
+                      &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
+                      &s->bank_tmp})
       free_dev(*b);
+    free_host(s->h_apply);
+    free_host(s->h_pred);
     free_host(s->h_in);
     free_host(s->h_out);
     delete s;
@@ -643,6 +659,8 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
   }
   TRY(scene_reserve(e, sc, T));
   sc->T = T;
+  sc->full.resize(T, 0);
+  for (uint32_t i = 0; i < n; ++i) sc->full[slots[i]] = 0;  // an upsert carries the 5 x 5 projection only
   const uint32_t K = e->K, D = e->D;
   const bool feats = e->visual;
   // pinned staging: raw | slots | epochs | ids | mean | cov | present | feats
@@ -732,12 +750,14 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
     HIPCHK(e, hipMemcpy(e->up_index.p, keep.data(), (size_t)nT * 4, hipMemcpyHostToDevice));
     struct Arr { DevBuf* b; uint32_t row; };
     const uint32_t K = e->K;
-    std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u}};
+    std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u},
+                             {&sc->kf, 440u}};
     if (e->visual) {
       arrs.push_back({&sc->feat, K * e->Dp * 4u});
       arrs.push_back({&sc->fnorm, K * 4u});
       arrs.push_back({&sc->fpresent, K});
       arrs.push_back({&sc->fcount, 4u});
+      arrs.push_back({&sc->fquality, K * 4u});
     }
     for (auto& a : arrs) {
       DevBuf nb;
@@ -746,6 +766,12 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
       e->garbage.push_back(a.b->p);
       *a.b = nb;
     }
+  }
+  {
+    std::vector<uint8_t> nfull;
+    sc->full.resize(sc->T, 0);
+    for (uint32_t s2 : keep) nfull.push_back(sc->full[s2]);
+    sc->full = nfull;
   }
   sc->T = nT;
   sc->ids = nids;
@@ -878,6 +904,135 @@ int sa_associate(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
   rs.out_track_id = out_track_id;
   rs.out_voting_type = out_voting_type;
   return sa_associate_batch(e, 1, &rq, &rs);
+}
+
+// ---- device-side track upkeep ---------------------------------------------------------------------------
+int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted) {
+  if (!e) return SA_ERR_BAD_ARG;
+  if (slot >= e->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->n_slots);
+  Slot* s = e->slots[slot];
+  if (!s->ran) return fail(e, SA_ERR_STATE, "sa_tracks_apply before sa_batch_run");
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->synced) TRY(engine_sync(e));
+  SceneTable* sc = s->scene;
+  const uint32_t n = s->N, K = e->K;
+  if (!n) return SA_OK;
+  if (s->T != sc->T) return fail(e, SA_ERR_STATE, "the scene's track table changed since the slot ran");
+  const uint64_t* winners = (const uint64_t*)s->h_out.p;
+  sc->full.resize(sc->T, 0);
+  uint32_t n_new = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (winners[i] == 0) {
+      if (!new_ids || new_ids[i] == 0) return fail(e, SA_ERR_BAD_ARG, "candidate %u starts a track and needs new_ids[%u] > 0", i, i);
+      if (sc->slot_of.count(new_ids[i])) return fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)new_ids[i]);
+      for (uint32_t j = 0; j < i; ++j)
+        if (winners[j] == 0 && new_ids[j] == new_ids[i]) return fail(e, SA_ERR_BAD_ARG, "new id %llu given twice", (unsigned long long)new_ids[i]);
+      ++n_new;
+    } else {
+      auto it = sc->slot_of.find(winners[i]);
+      if (it == sc->slot_of.end()) return fail(e, SA_ERR_STATE, "winner %llu is not in the table", (unsigned long long)winners[i]);
+      if (!sc->full[it->second])
+        return fail(e, SA_ERR_STATE, "track %llu was upserted without a Kalman state: device-side upkeep needs tracks created by "
+                    "sa_tracks_apply or seeded with sa_tracks_set_state", (unsigned long long)winners[i]);
+    }
+  }
+  const uint32_t T0 = sc->T;
+  TRY(scene_reserve(e, sc, T0 + n_new));
+  // staging: table row + id of every candidate that starts a track
+  TRY(host_ensure(e, s->h_apply, (size_t)n * 12));
+  uint32_t* h_row = (uint32_t*)s->h_apply.p;
+  uint64_t* h_ids = (uint64_t*)((uint8_t*)s->h_apply.p + (((size_t)n * 4 + 7) & ~(size_t)7));
+  TRY(host_ensure(e, s->h_apply, (((size_t)n * 4 + 7) & ~(size_t)7) + (size_t)n * 8));
+  h_row = (uint32_t*)s->h_apply.p;
+  h_ids = (uint64_t*)((uint8_t*)s->h_apply.p + (((size_t)n * 4 + 7) & ~(size_t)7));
+  uint32_t next = T0;
+  for (uint32_t i = 0; i < n; ++i) {
+    h_row[i] = winners[i] == 0 ? next++ : SA_NONE;
+    h_ids[i] = winners[i] == 0 ? new_ids[i] : 0;
+  }
+  TRY(dev_ensure(e, s->new_row, (size_t)n * 4));
+  TRY(dev_ensure(e, s->new_ids, (size_t)n * 8));
+  {
+    void* before = s->h_pred.p;
+    TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
+    if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
+  }
+  hipStream_t st = e->stream;
+  HIPCHK(e, hipMemcpyAsync(s->new_row.p, h_row, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(e, hipMemcpyAsync(s->new_ids.p, h_ids, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  ApplyArgs a{};
+  a.c_raw = (const BoxRaw*)s->raw.p; a.win_col = (const int32_t*)s->win_col.p; a.new_row = (const uint32_t*)s->new_row.p;
+  a.new_ids = (const uint64_t*)s->new_ids.p; a.n = n; a.epoch = s->epoch;
+  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
+  a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
+  BankArgs b{};
+  if (e->visual) {
+    TRY(dev_ensure(e, s->bank_tmp, (size_t)n * K * e->Dp * 4));
+    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.n = n; b.K = K; b.Dp = e->Dp;
+    b.c_feat = s->has_feats ? (const float*)s->feat.p : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
+    b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->fpresent_in.p : nullptr;
+    b.c_quality = s->has_quality ? (const float*)s->quality.p : nullptr;
+    b.c_own = s->has_own ? (const float*)s->own.p : nullptr;
+    b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
+    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p; b.tmp = (float*)s->bank_tmp.p;
+    b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
+    b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
+  }
+  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
+  e->synced = false;
+  TRY(engine_sync(e));
+  if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
+  // host side of the table: the new rows
+  for (uint32_t i = 0; i < n; ++i)
+    if (winners[i] == 0) {
+      sc->slot_of[new_ids[i]] = (uint32_t)sc->ids.size();
+      sc->ids.push_back(new_ids[i]);
+    }
+  sc->T = T0 + n_new;
+  sc->full.resize(sc->T, 1);
+  for (uint32_t i = 0; i < n; ++i)
+    if (winners[i] != 0) sc->full[sc->slot_of[winners[i]]] = 1;
+  s->ran = false;  // the table the slot ran against is gone
+  return SA_OK;
+}
+
+int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality, uint8_t* present,
+                        float* feats) {
+  if (!e) return SA_ERR_BAD_ARG;
+  SceneTable* sc = get_scene(e, scene_id, false);
+  if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
+  auto it = sc->slot_of.find(id);
+  if (it == sc->slot_of.end()) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(engine_sync(e));
+  const uint32_t r = it->second, K = e->K;
+  if (mean10) HIPCHK(e, hipMemcpy(mean10, (float*)sc->kf.p + (size_t)r * 110, 40, hipMemcpyDeviceToHost));
+  if (cov100) HIPCHK(e, hipMemcpy(cov100, (float*)sc->kf.p + (size_t)r * 110 + 10, 400, hipMemcpyDeviceToHost));
+  if (e->visual) {
+    if (quality) HIPCHK(e, hipMemcpy(quality, (float*)sc->fquality.p + (size_t)r * K, (size_t)K * 4, hipMemcpyDeviceToHost));
+    if (present) HIPCHK(e, hipMemcpy(present, (uint8_t*)sc->fpresent.p + (size_t)r * K, K, hipMemcpyDeviceToHost));
+    if (feats)
+      for (uint32_t k = 0; k < K; ++k)
+        HIPCHK(e, hipMemcpy(feats + (size_t)k * e->D, (float*)sc->feat.p + ((size_t)r * K + k) * e->Dp, (size_t)e->D * 4, hipMemcpyDeviceToHost));
+  }
+  return SA_OK;
+}
+
+int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const float* mean10, const float* cov100, const float* quality) {
+  if (!e || !mean10 || !cov100) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_set_state: null argument");
+  SceneTable* sc = get_scene(e, scene_id, false);
+  if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
+  auto it = sc->slot_of.find(id);
+  if (it == sc->slot_of.end()) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(engine_sync(e));
+  const uint32_t r = it->second, K = e->K;
+  HIPCHK(e, hipMemcpy((float*)sc->kf.p + (size_t)r * 110, mean10, 40, hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy((float*)sc->kf.p + (size_t)r * 110 + 10, cov100, 400, hipMemcpyHostToDevice));
+  if (e->visual && quality) HIPCHK(e, hipMemcpy((float*)sc->fquality.p + (size_t)r * K, quality, (size_t)K * 4, hipMemcpyHostToDevice));
+  sc->full.resize(sc->T, 0);
+  sc->full[r] = 1;
+  return SA_OK;
 }
 
 // ---- parity taps ----------------------------------------------------------------------------------------

@@ -519,14 +519,16 @@ __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
 __device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
   uint64_t id = 0;
   uint8_t vt = SA_VOTE_NONE;
+  int32_t win = -1;
   int32_t vw = S.vis_winner[q];
-  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
   else if (!S.row_has[q]) {
     int32_t c = S.rmatch[q];
-    if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; }
+    if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; win = c; }
   }
   S.out_track_id[q] = id;
   S.out_vote[q] = vt;
+  S.win_col[q] = win;
 }
 
 // One 1024-thread workgroup per scene: labels, row order inside components, solve, results.  The solver's
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
       S.out_track_id[q] = id;
       S.out_vote[q] = vt;
+      S.win_col[q] = vw >= 0 ? vw : -1;
     }
     return;
   }
@@ -692,14 +695,16 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   if (q < N) {
     uint64_t id = 0;
     uint8_t vt = SA_VOTE_NONE;
+    int32_t win = -1;
     int32_t vw = S.vis_winner[q];
-    if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+    if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
     else if (!S.row_has[q]) {
       int32_t c = s_rmatch[q];
-      if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; }
+      if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; win = c; }
     }
     S.out_track_id[q] = id;
     S.out_vote[q] = vt;
+    S.win_col[q] = win;
   }
 }
 

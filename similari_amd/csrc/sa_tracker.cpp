@@ -21,109 +21,18 @@
 #include <vector>
 
 #include "../../include/similari_tracker.h"
+#include "sa_kalman.h"
 
 namespace {
 
 thread_local std::string g_err;
 
-struct KF {
-  float mean[10];
-  float cov[100];
-};
-
-inline float opt_angle(const sa_box& b) { return b.has_angle ? b.angle : 0.0f; }
-
-void std_diag(float w, float k, float cnst, float p, float* out5) {  // std_position / std_velocity, squared later
-  float v = k * w * p;
-  out5[0] = v; out5[1] = v; out5[2] = v; out5[3] = cnst; out5[4] = v;
-}
-
-void kf_initiate(float pw, float vw, const sa_box& b, KF& s) {  // kalman_2d_box.rs:58-83
-  s.mean[0] = b.xc; s.mean[1] = b.yc; s.mean[2] = opt_angle(b); s.mean[3] = b.aspect; s.mean[4] = b.height;
-  for (int i = 5; i < 10; ++i) s.mean[i] = 0.0f;
-  float sd[10];
-  std_diag(pw, 2.0f, 1e-2f, b.height, sd);
-  std_diag(vw, 10.0f, 1e-5f, b.height, sd + 5);
-  std::memset(s.cov, 0, sizeof s.cov);
-  for (int i = 0; i < 10; ++i) s.cov[i * 10 + i] = sd[i] * sd[i];
-}
-
-void kf_predict(float pw, float vw, KF& s) {  // kalman_2d_box.rs:87-102
-  float sd[10];
-  std_diag(pw, 1.0f, 1e-2f, s.mean[4], sd);
-  std_diag(vw, 1.0f, 1e-5f, s.mean[4], sd + 5);
-  for (int i = 0; i < 5; ++i) s.mean[i] = s.mean[i] + s.mean[i + 5];
-  float mc[100];
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 10; ++j) mc[i * 10 + j] = i < 5 ? s.cov[i * 10 + j] + s.cov[(i + 5) * 10 + j] : s.cov[i * 10 + j];
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 10; ++j) {
-      float v = j < 5 ? mc[i * 10 + j] + mc[i * 10 + j + 5] : mc[i * 10 + j];
-      s.cov[i * 10 + j] = v + (i == j ? sd[i] * sd[i] : 0.0f);
-    }
-}
-
-void kf_update(float pw, KF& s, const sa_box& z) {  // kalman_2d_box.rs:122-148
-  float sd[5];
-  std_diag(pw, 1.0f, 1e-1f, s.mean[4], sd);
-  float P[25];
-  for (int i = 0; i < 5; ++i)
-    for (int j = 0; j < 5; ++j) P[i * 5 + j] = s.cov[i * 10 + j] + (i == j ? sd[i] * sd[i] : 0.0f);
-  // kalman_gain = projected_cov.solve_lower_triangular(B), B[r][c] = cov[c][r]: the UN-factorised covariance is
-  // used as the triangular matrix — the reference's formula, kept as is
-  float G[50];
-  for (int r = 0; r < 5; ++r)
-    for (int c = 0; c < 10; ++c) G[r * 10 + c] = s.cov[c * 10 + r];
-  for (int c = 0; c < 10; ++c)
-    for (int i = 0; i < 5; ++i) {
-      float coeff = G[i * 10 + c] / P[i * 5 + i];
-      G[i * 10 + c] = coeff;
-      float nc = -coeff;
-      for (int r = i + 1; r < 5; ++r) G[r * 10 + c] = nc * P[r * 5 + i] + G[r * 10 + c];
-    }
-  float innov[5] = {z.xc - s.mean[0], z.yc - s.mean[1], opt_angle(z) - s.mean[2], z.aspect - s.mean[3], z.height - s.mean[4]};
-  float nm[10];
-  for (int c = 0; c < 10; ++c) {
-    float acc = innov[0] * G[c];
-    for (int r = 1; r < 5; ++r) acc = innov[r] * G[r * 10 + c] + acc;
-    nm[c] = s.mean[c] + acc;
-  }
-  float gtp[50];  // 10 x 5
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 5; ++j) {
-      float acc = G[i] * P[j];
-      for (int k = 1; k < 5; ++k) acc = G[k * 10 + i] * P[k * 5 + j] + acc;
-      gtp[i * 5 + j] = acc;
-    }
-  float nc[100];
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 10; ++j) {
-      float acc = gtp[i * 5] * G[j];
-      for (int k = 1; k < 5; ++k) acc = gtp[i * 5 + k] * G[k * 10 + j] + acc;
-      nc[i * 10 + j] = s.cov[i * 10 + j] - acc;
-    }
-  std::memcpy(s.mean, nm, sizeof nm);
-  std::memcpy(s.cov, nc, sizeof nc);
-}
-
-sa_box state_box(const KF& s) {  // TryFrom<KalmanState> for Universal2DBox  kalman.rs:72-92
-  sa_box b;
-  std::memset(&b, 0, sizeof b);
-  b.xc = s.mean[0]; b.yc = s.mean[1];
-  b.has_angle = s.mean[2] == 0.0f ? 0 : 1;
-  b.angle = s.mean[2];
-  b.aspect = s.mean[3]; b.height = s.mean[4];
-  b.confidence = 1.0f;
-  return b;
-}
+using KF = sa_kf;  // sa_kalman.h: the reference's box filter, shared with the device-side upkeep
 
 // make_prediction  kalman_prediction.rs:13-32
 sa_box make_prediction(float pw, float vw, bool& has_state, KF& s, const sa_box& obs) {
-  if (!has_state) { kf_initiate(pw, vw, obs, s); has_state = true; }
-  kf_predict(pw, vw, s);
-  kf_update(pw, s, obs);
-  sa_box r = state_box(s);
-  r.confidence = obs.confidence;
+  sa_box r = sa_kf_make_prediction(pw, vw, has_state, s, obs);
+  has_state = true;
   return r;
 }
 
@@ -177,11 +86,7 @@ int tfail(sa_tracker* t, int code, const char* fmt, ...) {
 }
 
 bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, float min_q, bool has_own, float own, float min_own) {
-  bool quality_ok = q >= min_q;                       // visual_sort/metric.rs:227-249
-  bool perc_ok = has_own ? own >= min_own : true;
-  float w = b.height * b.aspect;
-  bool bbox_ok = w * b.height >= o.visual_minimal_area;
-  return bbox_ok && quality_ok && perc_ok;
+  return sa_feature_can_be_used(o.visual_minimal_area, b, q, min_q, has_own, own, min_own);
 }
 
 void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
@@ -356,15 +261,28 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint64_t scene = scene_ids[s];
     std::vector<uint64_t> touched;
+    // ids first (same order the reference draws them in), so that the device-side upkeep can create the new tracks
+    std::vector<uint64_t> tids(counts[s]), new_ids(counts[s], 0);
+    for (uint32_t i = 0; i < counts[s]; ++i) {
+      const uint64_t dest = winners[s][i];
+      uint64_t drawn = 0;
+      if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
+      if (dest == 0) { tids[i] = o.batch_ids ? drawn : ++t->track_id; new_ids[i] = tids[i]; }
+      else tids[i] = dest;
+    }
+    std::vector<sa_box> dev_pred;
+    if (o.device_upkeep) {
+      // Kalman step, table refresh and feature-bank policy on the GPU: nothing but the predicted boxes comes back
+      dev_pred.resize(counts[s]);
+      rc = sa_tracks_apply(t->eng, s, new_ids.data(), dev_pred.data());
+      if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
+    }
     for (uint32_t i = 0; i < counts[s]; ++i) {
       Cand& c = cands[s][i];
       uint64_t dest = winners[s][i];
-      uint64_t drawn = 0;
-      if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
-      uint64_t tid;
+      const uint64_t tid = tids[i];
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        tid = o.batch_ids ? drawn : ++t->track_id;
         Track tr;
         tr.id = tid; tr.scene = scene; tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
@@ -373,12 +291,12 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         update_history(o, tr, c.raw, c.box);
         if (o.visual) {
           tr.obs.push_back(c.obs);                     // is_merge = false: the feature is kept as is
+          if (o.device_upkeep) tr.obs.back().feat.clear();  // the vectors live in the device bank only
           tr.feat_count = c.obs.has_feat ? 1 : 0;
         }
         t->store[tid] = std::move(tr);
         t->by_scene[scene].push_back(tid);
       } else {
-        tid = dest;
         auto it = t->store.find(dest);
         if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
         Track& tr = it->second;
@@ -387,16 +305,18 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         tr.has_custom = c.has_custom; tr.custom = c.custom;
         if (o.visual) tr.voting = votes[s][i];
         // optimize(is_merge = true): Kalman predict + update with the candidate's box, history
-        sa_box predicted = make_prediction(pw, vw, tr.has_state, tr.kf, c.box);
+        sa_box predicted = o.device_upkeep ? dev_pred[i] : make_prediction(pw, vw, tr.has_state, tr.kf, c.box);
         update_history(o, tr, c.box, predicted);
         if (o.visual) {
           Obs nw = c.obs;
+          if (o.device_upkeep) nw.feat.clear();
           if (!feature_can_be_used(o, c.box, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
                                    o.visual_minimal_own_area_percentage_collect)) {
             nw.has_feat = false;
             nw.feat.clear();
           }
-          // optimize_observations  visual_sort/metric.rs:129-154
+          // optimize_observations  visual_sort/metric.rs:129-154 (with device upkeep: the bookkeeping only — the same
+          // policy moves the feature rows inside the device bank, sa_upkeep.hip)
           std::vector<Obs> kept;
           for (auto& ob : tr.obs) if (ob.has_feat) kept.push_back(std::move(ob));
           std::stable_sort(kept.begin(), kept.end(), [](const Obs& a, const Obs& b) { return a.quality > b.quality; });
@@ -411,6 +331,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       touched.push_back(tid);
       out[s][i] = to_sort_track(o, t->store[tid]);
     }
+    if (o.device_upkeep) continue;
     rc = sync_engine(t, scene, touched);
     if (rc != SA_OK) return rc;
   }
@@ -486,6 +407,8 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
   c.constraint_max_dist = t->cons_dist.data();
   c.kf_position_weight = o->kalman_position_weight;
   c.kf_velocity_weight = o->kalman_velocity_weight;
+  c.visual_minimal_quality_collect = o->visual_minimal_quality_collect;
+  c.visual_minimal_own_area_percentage_collect = o->visual_minimal_own_area_percentage_collect;
   int rc = sa_engine_create(&c, &t->eng);
   if (rc != SA_OK) {
     tfail(nullptr, rc, "sa_engine_create: %s", sa_last_error(nullptr));
@@ -572,6 +495,10 @@ int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, floa
   if (!t) return SA_ERR_BAD_ARG;
   auto it = t->store.find(track_id);
   if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  if (t->o.device_upkeep) {  // the state lives on the device
+    int rc = sa_tracks_get_state(t->eng, it->second.scene, track_id, mean10, cov100, nullptr, nullptr, nullptr);
+    return rc == SA_OK ? SA_OK : tfail(t, rc, "sa_tracks_get_state: %s", sa_last_error(t->eng));
+  }
   if (mean10) std::memcpy(mean10, it->second.kf.mean, sizeof it->second.kf.mean);
   if (cov100) std::memcpy(cov100, it->second.kf.cov, sizeof it->second.kf.cov);
   return SA_OK;

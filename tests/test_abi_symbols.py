@@ -28,7 +28,7 @@ def lib():
 @pytest.mark.parametrize("header", ["similari_assoc.h", "similari_tracker.h"])
 def test_every_declared_function_is_exported(lib, header):
     names = declared(header)
-    assert len(names) == (24 if header == "similari_assoc.h" else 15), names
+    assert len(names) == (27 if header == "similari_assoc.h" else 15), names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"{header} declares functions the library does not export: {missing}"
 
@@ -42,7 +42,7 @@ def test_no_oracle_or_cpu_fallback_linked():
 
 
 def test_struct_sizes_match_the_headers(lib):
-    assert lib.sa_api_version() == 1
+    assert lib.sa_api_version() == 2
     assert C.sizeof(abi.sa_box) == 32 and abi.BOX_DTYPE.itemsize == 32
     cfg = abi.sa_config()
     lib.sa_config_default(C.byref(cfg))

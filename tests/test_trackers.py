@@ -15,19 +15,22 @@ BB = TR.BoundingBox
 
 
 def make(backend, kind, **kw):
-    """kind: 'sort' | 'visual'; backend: 'oracle' | 'gpu'."""
+    """kind: 'sort' | 'visual'; backend: 'oracle' | 'gpu' (host upkeep around the GPU association) | 'gpu_dev' (Kalman step,
+    table refresh and feature bank on the GPU too: sa_tracks_apply)."""
+    dev = backend == "gpu_dev"
     if kind == "sort":
         o, keep = TR.sort_options(kw.get("bbox_history", 10), kw.get("max_idle_epochs", 2), kw.get("method", IoU(0.3)),
                                   kw.get("min_confidence", 0.05), kw.get("constraints"), 1.0 / 20.0, 1.0 / 160.0,
-                                  batch=kw.get("batch", False))
+                                  batch=kw.get("batch", False), device_upkeep=dev)
     else:
-        o, keep = TR.visual_options(kw["opts"], kw["feature_len"], batch=kw.get("batch", False))
+        o, keep = TR.visual_options(kw["opts"], kw["feature_len"], batch=kw.get("batch", False), device_upkeep=dev)
     if backend == "oracle":
         return O.OracleTracker(o, keep)
     return TR._Tracker(o, keep)
 
 
-BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu),
+            pytest.param("gpu_dev", id="gpu_device_upkeep", marks=pytest.mark.gpu)]
 
 
 def box_eq(a: TR.Universal2DBox, b: TR.Universal2DBox, eps=1e-5):
@@ -199,10 +202,10 @@ def boxes_to_u2d(b):
                               float(r["aspect"]), float(r["height"]), float(r["confidence"])) for r in b]
 
 
-def run_sort_sequence(method, oriented, seed, frames=8, n=60, scenes=(0,), batch=False, constraints=None):
+def run_sort_sequence(method, oriented, seed, frames=8, n=60, scenes=(0,), batch=False, constraints=None, backend="gpu"):
     rng = np.random.default_rng(seed)
     kw = dict(bbox_history=3, max_idle_epochs=2, method=method, min_confidence=0.05, constraints=constraints, batch=batch)
-    g, o = make("gpu", "sort", **kw), make("oracle", "sort", **kw)
+    g, o = make(backend, "sort", **kw), make("oracle", "sort", **kw)
     try:
         world = {s: synth.dense_boxes(rng, n, (900.0, 700.0), oriented) for s in scenes}
         for f in range(frames):
@@ -239,29 +242,37 @@ def run_sort_sequence(method, oriented, seed, frames=8, n=60, scenes=(0,), batch
         o.close()
 
 
+UPKEEP = pytest.mark.parametrize("backend", ["gpu", "gpu_dev"], ids=["host_upkeep", "device_upkeep"])
+
+
 @pytest.mark.gpu
+@UPKEEP
 @pytest.mark.parametrize("oriented", [False, True])
-def test_sort_iou_sequence_matches_oracle(oriented):
-    run_sort_sequence(IoU(0.3), oriented, seed=11 + oriented)
+def test_sort_iou_sequence_matches_oracle(oriented, backend):
+    # device upkeep + oriented boxes: the polygon's cos/sin come from the device's libm (<= 1 ulp from the host's); the f32
+    # IoU cells and every box still have to match the oracle exactly on this seeded sequence
+    run_sort_sequence(IoU(0.3), oriented, seed=11 + oriented, backend=backend)
 
 
 @pytest.mark.gpu
-def test_sort_maha_sequence_matches_oracle():
-    run_sort_sequence(TR.PositionalMetricType.maha(), False, seed=13)
+@UPKEEP
+def test_sort_maha_sequence_matches_oracle(backend):
+    run_sort_sequence(TR.PositionalMetricType.maha(), False, seed=13, backend=backend)
 
 
 @pytest.mark.gpu
-def test_batch_sort_scenes_and_constraints_match_oracle():
+@UPKEEP
+def test_batch_sort_scenes_and_constraints_match_oracle(backend):
     c = TR.SpatioTemporalConstraints().add_constraints([(1, 1.0), (2, 1.5)])
-    run_sort_sequence(IoU(0.3), False, seed=17, scenes=(3, 7, 11), batch=True, constraints=c, n=40)
+    run_sort_sequence(IoU(0.3), False, seed=17, scenes=(3, 7, 11), batch=True, constraints=c, n=40, backend=backend)
 
 
-def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False):
+def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False, backend="gpu"):
     rng = np.random.default_rng(seed)
     opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(metric)
             .positional_metric(positional).visual_minimal_track_length(2).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(3).visual_min_votes(1))
-    g = make("gpu", "visual", opts=opts, feature_len=d, batch=batch)
+    g = make(backend, "visual", opts=opts, feature_len=d, batch=batch)
     o = make("oracle", "visual", opts=opts, feature_len=d, batch=batch)
     try:
         ident = synth.reid_identities(rng, n, d)
@@ -287,10 +298,56 @@ def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=Fa
 
 
 @pytest.mark.gpu
-def test_visual_cosine_sequence_matches_oracle():
-    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=21)
+@UPKEEP
+def test_visual_cosine_sequence_matches_oracle(backend):
+    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=21, backend=backend)
 
 
 @pytest.mark.gpu
-def test_visual_euclid_maha_sequence_matches_oracle():
-    run_visual_sequence(TR.VisualSortMetricType.euclidean(0.5), TR.PositionalMetricType.maha(), seed=23, batch=True)
+@UPKEEP
+def test_visual_euclid_maha_sequence_matches_oracle(backend):
+    run_visual_sequence(TR.VisualSortMetricType.euclidean(0.5), TR.PositionalMetricType.maha(), seed=23, batch=True, backend=backend)
+
+
+@pytest.mark.gpu
+def test_device_bank_equals_host_policy_bank():
+    """The feature bank the device keeps (rows, presence flags, qualities, order) is what the host policy
+    (optimize_observations, visual_sort/metric.rs:129-154) builds from the same observations: two facades, one with host
+    upkeep (its bank is uploaded every frame), one with device upkeep, are fed the same frames and their engines' banks are
+    read back and compared slot for slot."""
+    import ctypes as C
+
+    rng = np.random.default_rng(31)
+    d, n = 48, 30
+    opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
+            .positional_metric(IoU(0.3)).visual_minimal_track_length(1).visual_minimal_area(500.0)
+            .visual_minimal_quality_use(0.3).visual_minimal_quality_collect(0.5).visual_max_observations(3).visual_min_votes(1))
+    h, g = make("gpu", "visual", opts=opts, feature_len=d), make("gpu_dev", "visual", opts=opts, feature_len=d)
+    try:
+        ident = synth.reid_identities(rng, n, d)
+        world = synth.dense_boxes(rng, n, (900.0, 700.0))
+        for f in range(7):
+            world = synth.jitter_boxes(rng, world, 2.0)
+            feats = synth.observe(rng, ident, 0.01)
+            items = [TR.VisualSortObservation(None if (k + f) % 6 == 5 else ft, float(rng.uniform(0.2, 1.0)), bx, None)
+                     for k, (bx, ft) in enumerate(zip(boxes_to_u2d(world), feats))]
+            rh, rg = h.predict(items), g.predict(items)
+            assert_tracks_equal(rg, rh)
+        fp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        checked = 0
+        for x in rg:
+            banks = []
+            for trk in (h, g):
+                eng = trk.lib.sa_tracker_engine(trk.h)
+                q, pres, ft = np.zeros(3, np.float32), np.zeros(3, np.uint8), np.zeros((3, d), np.float32)
+                rc = trk.lib.sa_tracks_get_state(eng, 0, x.id, None, None, q.ctypes.data_as(fp), pres.ctypes.data_as(u8p), ft.ctypes.data_as(fp))
+                assert rc == 0
+                banks.append((q, pres, ft))
+            (qh, ph, fh), (qg, pg, fg) = banks
+            np.testing.assert_array_equal(ph, pg)
+            np.testing.assert_array_equal(fh[ph != 0], fg[pg != 0])
+            checked += int(pg.sum())
+        assert checked > n
+    finally:
+        h.close()
+        g.close()
