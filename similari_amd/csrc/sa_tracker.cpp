@@ -178,8 +178,8 @@ int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids)
 struct Cand {  // the throw-away candidate track of one detection (simple_api.rs:125-145)
   sa_box raw;      // detection as passed
   sa_box box;      // after its own Kalman no-op step: angle 0.0 -> None, confidence kept
-  KF kf;
-  Obs obs;
+  Obs obs;                  // bookkeeping only: the feature itself is borrowed from the caller (fptr) until a track stores it
+  const float* fptr = nullptr;
   bool has_custom;
   int64_t custom;
 };
@@ -220,15 +220,23 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
       Cand& c = cs[i];
       c.raw = ob.bbox;
-      bool hs = false;
-      c.box = make_prediction(pw, vw, hs, c.kf, ob.bbox);
+      // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from,
+      // kalman_prediction.rs:13-32) is the identity on the box: zero velocity, zero innovation, so the new mean is the
+      // observation plus (+-0) * gain.  All that changes is TryFrom<KalmanState>: an angle of exactly 0.0 reads back as None
+      // (kalman.rs:82-86).  The 10 x 10 filter arithmetic (about 1 us per detection on the host) is therefore only run for
+      // the candidates that become tracks and need the state (below); the tests compare every box with the oracle, which
+      // does run the filter.
+      c.box = ob.bbox;
+      c.box.angle = ob.bbox.has_angle ? ob.bbox.angle : 0.0f;
+      c.box.has_angle = (ob.bbox.has_angle && ob.bbox.angle != 0.0f) ? 1 : 0;
+      c.box.reserved = 0;
       c.has_custom = ob.has_custom_object_id != 0;
       c.custom = ob.custom_object_id;
       c.obs.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
       c.obs.has_own = ob.own_area == ob.own_area;
       c.obs.own = c.obs.has_own ? ob.own_area : 0.0f;
       c.obs.has_feat = o.visual && ob.feature != nullptr;
-      if (c.obs.has_feat) c.obs.feat.assign(ob.feature, ob.feature + D);
+      c.fptr = c.obs.has_feat ? ob.feature : nullptr;
       cboxes[s][i] = c.box;
       if (o.visual) {
         cq[s][i] = c.obs.quality;
@@ -286,12 +294,13 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         Track tr;
         tr.id = tid; tr.scene = scene; tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
-        tr.has_state = true; tr.kf = c.kf;
+        tr.has_state = true;
+        if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, c.raw); }  // with device upkeep the state is born on the GPU
         tr.length = 0;
         update_history(o, tr, c.raw, c.box);
         if (o.visual) {
           tr.obs.push_back(c.obs);                     // is_merge = false: the feature is kept as is
-          if (o.device_upkeep) tr.obs.back().feat.clear();  // the vectors live in the device bank only
+          if (!o.device_upkeep && c.fptr) tr.obs.back().feat.assign(c.fptr, c.fptr + D);  // device upkeep: the vectors live in the device bank only
           tr.feat_count = c.obs.has_feat ? 1 : 0;
         }
         t->store[tid] = std::move(tr);
@@ -309,12 +318,10 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         update_history(o, tr, c.box, predicted);
         if (o.visual) {
           Obs nw = c.obs;
-          if (o.device_upkeep) nw.feat.clear();
           if (!feature_can_be_used(o, c.box, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
-                                   o.visual_minimal_own_area_percentage_collect)) {
+                                   o.visual_minimal_own_area_percentage_collect))
             nw.has_feat = false;
-            nw.feat.clear();
-          }
+          if (!o.device_upkeep && nw.has_feat) nw.feat.assign(c.fptr, c.fptr + D);
           // optimize_observations  visual_sort/metric.rs:129-154 (with device upkeep: the bookkeeping only — the same
           // policy moves the feature rows inside the device bank, sa_upkeep.hip)
           std::vector<Obs> kept;
