@@ -12,10 +12,11 @@
  *                                                                            src/trackers/tracker_api.rs:9-118
  *
  * What runs where: the per-frame N x T cost matrices and the assignment run on the GPU through
- * similari_assoc.h (sa_associate_batch).  The O(N) upkeep either side of it — epoch counters, Kalman
- * predict/update of the merged tracks (kalman_prediction.rs:13-32), history deques, the feature-bank policy
- * (visual_sort/metric.rs:129-154, 297-374), track ids, wasted-track lifecycle — stays on the host exactly as the
- * reference keeps it on the host; SURVEY §8(f) lists moving it to the device as the next step.
+ * similari_assoc.h (sa_associate_batch).  The O(N) upkeep either side of it — Kalman predict/update of the merged
+ * tracks (kalman_prediction.rs:13-32) and the feature-bank policy (visual_sort/metric.rs:129-154, 297-374) — runs
+ * either on the host exactly as the reference keeps it (device_upkeep = 0: the refreshed rows are uploaded with
+ * sa_tracks_upsert every frame) or on the GPU (device_upkeep = 1: sa_tracks_apply, nothing but the predicted boxes
+ * comes back).  Epoch counters, history deques, track ids and the wasted-track lifecycle stay on the host.
  *
  * Not provided (out of scope): exclusively_owned_areas.  A caller that uses the own-area
  * thresholds supplies the per-detection share in sa_observation.own_area (NaN = None).
