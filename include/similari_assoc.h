@@ -204,6 +204,15 @@ int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mea
 int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const float* mean10, const float* cov100,
                         const float* quality /* K or NULL */);
 
+/* ---- non-maximum suppression (src/utils/nms.rs:32-72) --------------------------------
+ * nms(detections, nms_threshold, score_threshold): boxes with score <= score_threshold (or height / aspect <= 0) are dropped,
+ * the rest are visited in descending rank (score, or the box height where the score is None; stable) and a visited box
+ * suppresses every later one with  intersection(visited, later) as f32 / area(later) > nms_threshold.
+ * scores: NULL or NaN entries = None.  score_threshold: NaN = None (f32::MIN).  out_keep[*out_n] = indices into `boxes` of the
+ * survivors in the reference's output order; capacity n.  The pair tests run on the GPU (same f64 clip as the IoU cells). */
+int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, float nms_threshold, float score_threshold,
+           uint32_t* out_keep, uint32_t* out_n);
+
 typedef struct sa_scene_request {
   uint64_t scene_id;
   uint64_t epoch;

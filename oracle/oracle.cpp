@@ -762,3 +762,36 @@ int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_
 }
 
 }  // extern "C"
+
+// ---- src/utils/nms.rs:32-72 -------------------------------------------------------------------------------------------
+// scores: NULL or NaN entries = Option::None (rank = height, passes every score threshold); score_threshold NaN = None (f32::MIN).
+// out_keep: indices into `boxes` of the surviving boxes, in the reference's output order (rank descending, stable).
+extern "C" int or_nms(uint32_t n, const sa_box* boxes, const float* scores, float nms_threshold, float score_threshold,
+                      uint32_t* out_keep, uint32_t* out_n) {
+  const float thr = score_threshold == score_threshold ? score_threshold : -3.4028234663852886e38f;
+  struct Cand { uint32_t src; float rank; };
+  std::vector<Cand> c;
+  for (uint32_t i = 0; i < n; ++i) {
+    const bool has = scores && scores[i] == scores[i];
+    const float sc = has ? scores[i] : 3.4028234663852886e38f;   // score.unwrap_or(f32::MAX) > score_threshold
+    if (!(sc > thr && boxes[i].height > 0.0f && boxes[i].aspect > 0.0f)) continue;
+    c.push_back({i, has ? scores[i] : boxes[i].height});           // rank.unwrap_or(bbox.height)
+  }
+  std::stable_sort(c.begin(), c.end(), [](const Cand& a, const Cand& b) { return a.rank > b.rank; });  // sorted_by(b.rank cmp a.rank)
+  std::vector<uint8_t> excluded(c.size(), 0);
+  for (size_t i = 0; i < c.size(); ++i) {
+    if (excluded[i]) continue;
+    for (size_t j = i + 1; j < c.size(); ++j) {
+      if (excluded[j]) continue;
+      const sa_box* cb = &boxes[c[i].src];
+      const sa_box* ob = &boxes[c[j].src];
+      float metric = (float)or_intersection(cb, ob) / or_area(ob);
+      if (metric > nms_threshold) excluded[j] = 1;
+    }
+  }
+  uint32_t k = 0;
+  for (size_t i = 0; i < c.size(); ++i)
+    if (!excluded[i]) out_keep[k++] = c[i].src;
+  *out_n = k;
+  return 0;
+}

@@ -81,6 +81,10 @@ int or_visual_voting(float positional_threshold, float max_feature_distance, uin
                      const uint64_t* from, const uint64_t* to, const float* positional, const float* visual,
                      uint32_t n_ids, const uint64_t* cand_ids, uint64_t* out_to, uint8_t* out_type);
 
+/* ---- src/utils/nms.rs:32-72 ---------------------------------------------- */
+int or_nms(uint32_t n, const sa_box* boxes, const float* scores /* NULL / NaN = None */, float nms_threshold,
+           float score_threshold /* NaN = None */, uint32_t* out_keep, uint32_t* out_n);
+
 /* ---- one scene-frame, end to end (the thing sa_associate replaces) --------------------------
  * total_tracks_in_store: SortVoting's track_num for plain SORT (= store size over all scenes,
  * sort/simple_api.rs:160); pass tracks->n for a single-scene store.

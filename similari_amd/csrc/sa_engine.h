@@ -227,5 +227,8 @@ struct BankArgs {
   float minimal_area, q_collect, own_collect;
 };
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st);
+// NMS: mask[n][ceil(n/64)] words + keep[n] flags for rank-sorted boxes (at most SA_NMS_MAX)
+#define SA_NMS_MAX 16384u
+hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st);
 
 const char* sa_kernel_name(int id);

@@ -4,6 +4,7 @@
 #include "sa_engine.h"
 #include "sa_kalman.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -97,6 +98,7 @@ struct sa_engine {
   bool synced = true;
   std::vector<void*> garbage;  // device buffers to free at the next sync
   // upload scratch for upserts
+  DevBuf nms_mask, nms_keep;
   DevBuf up_raw, up_slots, up_epochs, up_ids, up_mean, up_cov, up_feats, up_present, up_index;
   HostBuf up_host;
   // profiling
@@ -613,7 +615,7 @@ void sa_engine_destroy(sa_engine* e) {
     free_host(s->h_out);
     delete s;
   }
-  for (DevBuf* b : {&e->d_scenes, &e->up_raw, &e->up_slots, &e->up_epochs, &e->up_ids, &e->up_mean, &e->up_cov, &e->up_feats,
+  for (DevBuf* b : {&e->d_scenes, &e->nms_mask, &e->nms_keep, &e->up_raw, &e->up_slots, &e->up_epochs, &e->up_ids, &e->up_mean, &e->up_cov, &e->up_feats,
                     &e->up_present, &e->up_index})
     free_dev(*b);
   free_host(e->h_scenes);
@@ -1032,6 +1034,51 @@ int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const floa
   if (e->visual && quality) HIPCHK(e, hipMemcpy((float*)sc->fquality.p + (size_t)r * K, quality, (size_t)K * 4, hipMemcpyHostToDevice));
   sc->full.resize(sc->T, 0);
   sc->full[r] = 1;
+  return SA_OK;
+}
+
+// ---- non-maximum suppression ------------------------------------------------------------------------------
+int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, float nms_threshold, float score_threshold,
+           uint32_t* out_keep, uint32_t* out_n) {
+  if (!e || !out_n || (n && (!boxes || !out_keep))) return fail(e, SA_ERR_BAD_ARG, "sa_nms: null argument");
+  *out_n = 0;
+  if (!n) return SA_OK;
+  const float thr = score_threshold == score_threshold ? score_threshold : -3.4028234663852886e38f;
+  struct Cand { uint32_t src; float rank; };
+  std::vector<Cand> c;
+  c.reserve(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const bool has = scores && scores[i] == scores[i];
+    const float sc = has ? scores[i] : 3.4028234663852886e38f;  // score.unwrap_or(f32::MAX) > score_threshold
+    if (!(sc > thr && boxes[i].height > 0.0f && boxes[i].aspect > 0.0f)) continue;
+    c.push_back({i, has ? scores[i] : boxes[i].height});
+  }
+  std::stable_sort(c.begin(), c.end(), [](const Cand& a, const Cand& b) { return a.rank > b.rank; });
+  const uint32_t m = (uint32_t)c.size();
+  if (!m) return SA_OK;
+  if (m > SA_NMS_MAX) return fail(e, SA_ERR_UNSUPPORTED, "sa_nms: at most %u boxes pass to the pair stage (got %u)", SA_NMS_MAX, m);
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(engine_sync(e));
+  const uint32_t W = (m + 63) / 64;
+  TRY(host_ensure(e, e->up_host, (size_t)m * sizeof(BoxRaw) + m));
+  BoxRaw* hraw = (BoxRaw*)e->up_host.p;
+  std::vector<sa_box> sorted(m);
+  for (uint32_t i = 0; i < m; ++i) sorted[i] = boxes[c[i].src];
+  fill_raw(hraw, sorted.data(), m);  // libm cos / sin of the angle, as for every other box
+  TRY(dev_ensure(e, e->up_raw, (size_t)m * sizeof(BoxRaw)));
+  TRY(dev_ensure(e, e->nms_mask, (size_t)m * W * 8));
+  TRY(dev_ensure(e, e->nms_keep, m));
+  hipStream_t st = e->stream;
+  HIPCHK(e, hipMemcpyAsync(e->up_raw.p, hraw, (size_t)m * sizeof(BoxRaw), hipMemcpyHostToDevice, st));
+  HIPCHK(e, sa_launch_nms((const BoxRaw*)e->up_raw.p, m, nms_threshold, (uint64_t*)e->nms_mask.p, (uint8_t*)e->nms_keep.p, st));
+  uint8_t* hkeep = (uint8_t*)e->up_host.p + (size_t)m * sizeof(BoxRaw);
+  HIPCHK(e, hipMemcpyAsync(hkeep, e->nms_keep.p, m, hipMemcpyDeviceToHost, st));
+  e->synced = false;
+  TRY(engine_sync(e));
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < m; ++i)
+    if (hkeep[i]) out_keep[k++] = c[i].src;
+  *out_n = k;
   return SA_OK;
 }
 

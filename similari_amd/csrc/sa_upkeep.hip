@@ -141,3 +141,131 @@ hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams
   hipLaunchKernelGGL(k_apply_bank, dim3(a.n), dim3(256), 0, st, *b);
   return hipGetLastError();
 }
+
+// =====================================================================================================
+// Non-maximum suppression (src/utils/nms.rs:32-72) on the clip machinery of the positional tiles.
+// The host filters and rank-sorts the boxes (O(N log N), and it owns libm's cos/sin); the O(N^2) part runs here:
+//   k_nms_mask  : bit (i, j), i < j in rank order, = intersection(box_i, box_j) as f32 / area(box_j) > threshold.  One block =
+//                 16 rows x 64 columns = exactly one 64-bit word of 16 mask rows, so no global atomics: pairs are pruned with
+//                 too_far() (bbox.rs:452-462, what Universal2DBox::intersection does first), the survivors are compacted in
+//                 LDS and clipped by 64 worker lanes (f64 Sutherland–Hodgman + shoelace, clipping.rs:12-91).
+//   k_nms_sweep : the greedy pass of the reference — a box that is still alive suppresses the boxes its row marks — by one
+//                 wave that keeps the "removed" bitmap in registers and streams the mask rows 16 at a time.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_nms_mask(const BoxRaw* __restrict__ raw, uint32_t n, uint32_t W, float thr,
+                                                  uint64_t* __restrict__ mask) {
+  const uint32_t i0 = blockIdx.y * 16, j0 = blockIdx.x * 64;
+  if (i0 >= n || j0 >= n) return;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  __shared__ unsigned long long s_bits[16];
+  if (j0 + 63 <= i0) {  // the whole word lies on or below the diagonal: no pair with i < j
+    if (tid < 16 && i0 + tid < n) mask[(size_t)(i0 + tid) * W + blockIdx.x] = 0ull;
+    return;
+  }
+  __shared__ sa_geo s_rg[16], s_cg[64];
+  __shared__ double s_rv[16][8], s_cv[64][8];
+  __shared__ float s_carea[64];
+  __shared__ uint16_t s_list[16 * 64];
+  __shared__ uint32_t s_cnt;
+  __shared__ double s_poly[4 * SA_POLY_CAP * 64];
+  if (tid < 16) {
+    s_bits[tid] = 0ull;
+    const uint32_t i = i0 + tid;
+    if (i < n) {
+      const BoxRaw r = raw[i];
+      sa_geo g;
+      g.xc = r.box.xc; g.yc = r.box.yc; g.r = sa_radius(r.box.aspect, r.box.height); g.hha = 0.f;
+      s_rg[tid] = g;
+      sa_vertices(r.box.xc, r.box.yc, r.box.aspect, r.box.height, r.c, r.s, s_rv[tid]);
+    }
+  } else if (tid >= 64 && tid < 128) {
+    const uint32_t lj = tid - 64, j = j0 + lj;
+    if (j < n) {
+      const BoxRaw r = raw[j];
+      sa_geo g;
+      g.xc = r.box.xc; g.yc = r.box.yc; g.r = sa_radius(r.box.aspect, r.box.height); g.hha = 0.f;
+      s_cg[lj] = g;
+      sa_vertices(r.box.xc, r.box.yc, r.box.aspect, r.box.height, r.c, r.s, s_cv[lj]);
+      s_carea[lj] = sa_area(r.box.aspect, r.box.height);
+    }
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t li = wave * 4 + r, i = i0 + li, j = j0 + lane;
+    if (i < n && j < n && i < j) {
+      if (!sa_too_far(s_rg[li], s_cg[lane])) {
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+        s_list[slot] = (uint16_t)((li << 8) | lane);
+      } else if (0.0f > thr) {  // intersection() is 0.0 for far boxes: 0 / area still beats a negative threshold
+        atomicOr(&s_bits[li], 1ull << lane);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  if (tid < 64) {
+    double* ws = s_poly + tid;
+    for (uint32_t sidx = tid; sidx < cnt; sidx += 64) {
+      const uint32_t c = s_list[sidx], li = c >> 8, lj = c & 255u;
+      double sv[8], cv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sv[k] = s_rv[li][k]; cv[k] = s_cv[lj][k]; }
+      const double inter = sa_clip_area_ws(sv, cv, ws, ws + SA_POLY_CAP * 64, ws + 2 * SA_POLY_CAP * 64, ws + 3 * SA_POLY_CAP * 64, 64);
+      const float metric = (float)inter / s_carea[lj];
+      if (metric > thr) atomicOr(&s_bits[li], 1ull << lj);
+    }
+  }
+  __syncthreads();
+  if (tid < 16 && i0 + tid < n) mask[(size_t)(i0 + tid) * W + blockIdx.x] = s_bits[tid];
+}
+
+template <int S>  // S = words of the removed-bitmap per lane: up to 64 * 64 * S boxes
+__global__ __launch_bounds__(64) void k_nms_sweep(const uint64_t* __restrict__ mask, uint32_t n, uint32_t W, uint8_t* __restrict__ keep) {
+  const uint32_t lane = threadIdx.x;
+  uint64_t rw[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) rw[s] = 0ull;
+  constexpr int B = 16;
+  for (uint32_t i0 = 0; i0 < n; i0 += B) {
+    uint64_t rows[B][S];
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const uint32_t w = s * 64 + lane;
+        rows[r][s] = (i0 + r < n && w < W) ? mask[(size_t)(i0 + r) * W + w] : 0ull;
+      }
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+      const uint32_t i = i0 + r;
+      if (i >= n) break;
+      const uint32_t word = i >> 6, owner = word & 63u, slot = word >> 6, bit = i & 63u;
+      uint64_t mine = rw[0];
+#pragma unroll
+      for (int s = 1; s < S; ++s) mine = slot == (uint32_t)s ? rw[s] : mine;
+      const uint64_t cur = __shfl(mine, (int)owner);
+      const bool removed = (cur >> bit) & 1ull;
+      if (!removed) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) rw[s] |= rows[r][s];
+      }
+      if (lane == 0) keep[i] = removed ? 0 : 1;
+    }
+  }
+}
+
+hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st) {
+  if (!n) return hipSuccess;
+  const uint32_t W = cdiv(n, 64);
+  hipLaunchKernelGGL(k_nms_mask, dim3(W, cdiv(n, 16)), dim3(256), 0, st, raw, n, W, thr, mask);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const uint32_t S = cdiv(W, 64);
+  if (S <= 1) hipLaunchKernelGGL(k_nms_sweep<1>, dim3(1), dim3(64), 0, st, mask, n, W, keep);
+  else if (S <= 2) hipLaunchKernelGGL(k_nms_sweep<2>, dim3(1), dim3(64), 0, st, mask, n, W, keep);
+  else if (S <= 4) hipLaunchKernelGGL(k_nms_sweep<4>, dim3(1), dim3(64), 0, st, mask, n, W, keep);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}

@@ -99,6 +99,20 @@ class Engine:
         self._chk(self.lib.sa_batch_time(self.h, iters, C.byref(ms)))
         return ms.value
 
+    # ---- NMS (src/utils/nms.rs) ----
+    def nms(self, boxes: np.ndarray, scores=None, nms_threshold: float = 0.5, score_threshold=None) -> np.ndarray:
+        """Indices of the surviving boxes in the reference's output order (rank descending)."""
+        boxes = np.ascontiguousarray(boxes, abi.BOX_DTYPE)
+        n = len(boxes)
+        keep = np.zeros(max(n, 1), np.uint32)
+        m = C.c_uint32()
+        sc = None if scores is None else np.ascontiguousarray(scores, np.float32)
+        self._chk(self.lib.sa_nms(self.h, n, C.cast(boxes.ctypes.data, C.POINTER(abi.sa_box)),
+                                  None if sc is None else sc.ctypes.data_as(C.POINTER(C.c_float)), nms_threshold,
+                                  float("nan") if score_threshold is None else score_threshold,
+                                  keep.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(m)))
+        return keep[: m.value].copy()
+
     # ---- taps ----
     def tap_dims(self, slot: int = 0):
         n, t, k = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
             C.c_int,
             [f32, f32, u32, u32, P(u64), P(u64), fp, fp, u32, P(u64), P(u64), P(C.c_uint8)],
         ),
+        "or_nms": (C.c_int, [u32, B, fp, f32, f32, P(u32), P(u32)]),
         "or_associate": (C.c_int, [P(abi.sa_config), u32, P(abi.sa_tracks), u64, P(abi.sa_detections), P(or_frame_out)]),
     }
     T = C.c_void_p
@@ -114,6 +115,18 @@ def fptr(a):
 
 def dptr(a):
     return a.ctypes.data_as(P(C.c_double))
+
+
+def nms(boxes, scores=None, nms_threshold=0.5, score_threshold=None):
+    """Oracle NMS (oracle.cpp: or_nms, following src/utils/nms.rs:32-72)."""
+    L = lib()
+    boxes = np.ascontiguousarray(boxes, abi.BOX_DTYPE)
+    keep = np.zeros(max(len(boxes), 1), np.uint32)
+    m = u32()
+    sc = None if scores is None else np.ascontiguousarray(scores, np.float32)
+    L.or_nms(len(boxes), box_ptr(boxes), None if sc is None else fptr(sc), nms_threshold,
+             float("nan") if score_threshold is None else score_threshold, keep.ctypes.data_as(P(u32)), C.byref(m))
+    return keep[: m.value].copy()
 
 
 def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True):
