@@ -108,9 +108,42 @@ def test_general_assignment_tail_matches_oracle_too():
 
     env = dict(os.environ, SA_TAIL="general")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_sort_iou_parity or test_sort_maha_parity or test_visual_cosine_parity or test_batched_scenes"],
+                        "test_sort_iou_parity or test_sort_maha_parity or test_visual_cosine_parity or test_batched_scenes or "
+                        "test_state_kept_clean"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_state_kept_clean_across_frames_of_changing_size():
+    """Edge counters, row duals and the union-find forest are not reset at the start of a frame: the assignment tail leaves
+    them clean (k_slot_init only after a reallocation).  One engine, one slot, frames whose N and T grow, shrink and cross
+    the 1024-row boundary between the two tails: every frame must match the oracle."""
+    rng = np.random.default_rng(77)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        prev_t = 0
+        for f, (n, t) in enumerate([(300, 320), (1300, 1200), (90, 1200), (1100, 1250), (1024, 1250), (5, 1250), (700, 1300)]):
+            sc = synth.sort_scene(rng, t, n, canvas=(5000.0, 3000.0), oriented=(f % 2 == 1))
+            # tracks accumulate in the engine's table: upsert only the new ids, replace the boxes of the old ones
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+            eng.upsert(0, tracks)
+            assert eng.count(0) == max(prev_t, t)
+            if t < prev_t:
+                eng.remove(0, np.arange(t + 1, prev_t + 1, dtype=np.uint64))
+            prev_t = t
+            det = abi.make_detections(sc["det_boxes"])
+            ids, votes = eng.associate(0, 1, det)
+            ref = O.associate(cfg, tracks, 1, det)
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"frame {f} ({n} x {t})")
+            np.testing.assert_array_equal(votes, ref["voting_type"])
+            # and again on the same staged frame: a second run must find the state as clean as the first
+            eng.batch_run()
+            eng.batch_sync()
+            ids2, _ = eng.batch_fetch(0, n)
+            np.testing.assert_array_equal(ids2, ref["track_id"], err_msg=f"frame {f} rerun")
+    finally:
+        eng.close()
 
 
 def test_sort_iou_constraints_and_idle_epochs():
