@@ -28,10 +28,18 @@ class Engine:
             raise EngineError(rc, msg.decode() if msg else "")
         self.K = cfg.max_observations if cfg.visual_kind != abi.SA_VIS_NONE else 1
 
+    @classmethod
+    def borrowed(cls, lib, handle, cfg=None):
+        """Non-owning view of an engine that belongs to someone else (a tracker facade: sa_tracker_engine)."""
+        self = cls.__new__(cls)
+        self.lib, self.cfg, self.h, self._borrowed = lib, cfg, abi.ENGINE(handle), True
+        self.K = 1
+        return self
+
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "_borrowed", False):
             self.lib.sa_engine_destroy(self.h)
-            self.h = abi.ENGINE()
+        self.h = abi.ENGINE()
 
     def __del__(self):
         try:
