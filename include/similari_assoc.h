@@ -112,6 +112,8 @@ typedef struct sa_config {
 } sa_config;
 
 #define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */
+#define SA_FLAG_FUSED_FRAME 0x10u   /* VisualSORT, small frames: contraction tiles, positional tiles and preparation blocks in ONE
+                                       heterogeneous launch (faster frame, lower matrix-core fraction of that launch) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
 /* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,

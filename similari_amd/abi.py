@@ -35,6 +35,7 @@ SA_VOTE_POSITIONAL = 2
 SA_FLAG_PROFILE = 0x2
 SA_FLAG_FORK = 0x4
 SA_FLAG_GRAPH = 0x8
+SA_FLAG_FUSED_FRAME = 0x10
 
 
 class sa_box(C.Structure):

@@ -18,11 +18,11 @@ namespace {
 thread_local std::string g_create_error;
 
 enum KernelId {
-  KID_FRAME = 0, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
+  KID_FRAME = 0, KID_FRAME_VISUAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
   KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
-    "k_frame", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
+    "k_frame", "k_frame_visual", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
     "k_assign_label", "k_assign_solve", "d2h_results"};
 
 struct DevBuf {
@@ -203,10 +203,13 @@ struct ProfScope {
       sa_prof_stop = b;
     }
   }
+  void cancel() {  // nothing was launched under this scope: give the events back
+    if (e->profile && a) { e->ev_pool.push_back(a); e->ev_pool.push_back(b); a = b = nullptr; }
+  }
   ~ProfScope() {
     if (e->profile) {
       sa_prof_start = sa_prof_stop = nullptr;
-      e->prof_open.push_back({kid, a, b});
+      if (a) e->prof_open.push_back({kid, a, b});
     }
   }
 };
@@ -384,10 +387,21 @@ int upload_scene_descs(sa_engine* e) {
 // the side stream between two events).  Also the body of the captured graph.
 int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
   hipStream_t st = e->stream;
-  // launch 1: positional tiles (edges of the positional vote) + frame-preparation blocks, side by side
-  { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
+  // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
+  // launch; otherwise positional tiles + preparation blocks, then the contraction
+  bool fused = false;
+  if (e->visual && (e->cfg.flags & SA_FLAG_FUSED_FRAME)) {
+    ProfScope ps(e, KID_FRAME_VISUAL);
+    bool all_feats = true;
+    for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && e->slots[i]->has_feats;
+    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, e->P, st) : hipErrorNotSupported;
+    if (fe == hipSuccess) fused = true;
+    else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
+    else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
+  }
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   if (e->visual) {
-    { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
     { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
     { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
   }

@@ -1,0 +1,248 @@
+// sa_frame.h — device code of the first launch of a frame, shared by sa_kernels.hip (k_frame: positional tiles + frame
+// preparation blocks) and sa_gemm.hip (k_frame_visual: the same two block kinds riding beside the contraction's tiles).
+#pragma once
+#include "sa_engine.h"
+
+#ifndef WAVE
+#define WAVE 64
+#endif
+
+__device__ __forceinline__ void prep_box_common(const BoxRaw& r, sa_geo* geo, double* verts) {
+  const sa_box& b = r.box;
+  sa_geo g;
+  g.xc = b.xc;
+  g.yc = b.yc;
+  g.r = sa_radius(b.aspect, b.height);
+  g.hha = b.height * b.height * b.aspect;
+  *geo = g;
+  sa_vertices(b.xc, b.yc, b.aspect, b.height, r.c, r.s, verts);
+}
+
+// One wave per feature row: zero-pad D -> Dp (Feature::from_vec, track/utils.rs:45-71; the extra zero lanes
+// add +0.0 to every sum), scatter, squared norm (the per-pair norms of distance.rs:36-44 hoisted to once
+// per vector).
+__device__ __forceinline__ void pad_feature_row(const float* __restrict__ s, float* __restrict__ d, uint32_t D, uint32_t Dp,
+                                                bool pres, uint32_t lane, float* norm_out) {
+  float acc = 0.0f;
+  if (pres && (D & 3u) == 0 && ((uintptr_t)s & 15u) == 0) {
+    for (uint32_t k = lane * 4; k < Dp; k += WAVE * 4) {
+      float4 x = k < D ? *(const float4*)(s + k) : float4{0.f, 0.f, 0.f, 0.f};
+      *(float4*)(d + k) = x;
+      acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+  } else {
+    for (uint32_t k = lane; k < Dp; k += WAVE) {
+      float x = (pres && k < D) ? s[k] : 0.0f;
+      d[k] = x;
+      acc += x * x;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  *norm_out = acc;
+}
+
+
+// =====================================================================================================
+// Frame preparation blocks: everything that is O(N + T) at the start of a frame and that the kernels AFTER the first launch
+// consume —
+//   * reset of the vote / assignment state (one thread per vertex of the bipartite graph),
+//   * candidate preparation (visual_sort/simple_api.rs:130-170): geometry, f64 vertices, Mahalanobis measurement
+//     (angle.unwrap_or(0), kalman_2d_box.rs:159), clamped confidence (sort/metric.rs:43-47), the feature_can_be_used gate
+//     (visual_sort/metric.rs:227-249) — for the contraction's epilogue and the parity taps,
+//   * candidate feature padding + squared norms (one wave per row).
+// They ride in the SAME launch as the positional tiles (k_frame below), which re-derive the few candidates they need from
+// the raw boxes instead of waiting for these arrays: one dependent launch (~4.7 us) less per frame.  State the positional
+// tiles themselves write (edge counters, and for the many-workgroup tail the row duals and the union-find forest) cannot be
+// reset beside them; the assignment tail leaves it clean for the next frame instead (k_slot_init establishes it once).
+// =====================================================================================================
+__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk) {
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t i = blk * 256 + threadIdx.x;
+  if (i < T) {
+    S.col_excluded[i] = 0;
+    S.v[i] = 0;
+    S.cmatch[i] = -1;
+    S.cstamp[i] = 0;
+    S.cscan[i] = 0;
+  }
+  if (i < N) {
+    S.vis_winner[i] = -1;
+    S.row_has[i] = 0;
+    S.rmatch[i] = -1;
+    S.label[i] = SA_NONE;
+    S.next_row[i] = SA_NONE;
+    BoxRaw r = sa_ldg(S.c_raw + i);
+    prep_box_common(r, (sa_geo*)(S.c_geo + i), (double*)(S.c_verts + (size_t)i * 8));
+    const sa_box& b = r.box;
+    float SA_G* z = S.c_z + (size_t)i * 5;
+    z[0] = b.xc; z[1] = b.yc; z[2] = b.has_angle ? b.angle : 0.0f; z[3] = b.aspect; z[4] = b.height;
+    S.c_conf[i] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
+    bool usable = false;
+    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[i])) {
+      float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[i] : 1.0f;
+      bool quality_ok = q >= p.visual_minimal_quality_use;
+      bool perc_ok = true;
+      if (S.flags & SCN_HAS_OWN) {
+        float oa = S.c_own[i];
+        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+      }
+      bool bbox_ok = sa_area(b.aspect, b.height) >= p.visual_minimal_area;
+      usable = bbox_ok && quality_ok && perc_ok;
+    }
+    S.c_usable[i] = usable ? 1 : 0;
+  }
+  if (S.flags & SCN_HAS_FEATS) {
+    const uint32_t row = blk * 4 + threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    if (row < N) {
+      bool pres = !(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[row] != 0;
+      float nrm;
+      pad_feature_row(S.c_feat_raw + (size_t)row * S.D, S.c_feat + (size_t)row * S.Dp, S.D, S.Dp, pres, lane, &nrm);
+      if (lane == 0) S.c_fnorm[row] = nrm;
+    }
+  }
+}
+
+
+// =====================================================================================================
+// Positional cost cells: pair pre-filter -> (survivors only) IoU by f64 Sutherland–Hodgman / Mahalanobis -> the sparse
+// input of the positional vote.
+// Tile = 16 candidates x 256 tracks per 256-thread block: lane = track, each wave owns 4 candidate rows, a thread tests
+// 16 cells.  Phase 1 tests every cell: too_far() first (no sqrt), then compatible() — whose dist_in_2r costs a sqrt and a
+// division — only for the cells that pass; the few survivors are compacted into an LDS list so that phase 2 runs the
+// expensive clip with full lanes instead of 1-2 live lanes per wave.
+// EDGES (the product path): a surviving cell whose quantised weight beats the new-track threshold becomes an edge of the
+//   assignment graph right here — appended to its row's list (order inside a row is irrelevant to the solver), folded
+//   into the row dual and the union-find forest.  The dense N x T matrix of SortVoting (sort/voting.rs:44-84) and even the
+//   dense f32 cost matrix are never written: what this kernel moves is 80 B per box in and ~20 B per edge out.
+// DENSE (parity taps only): the f32 cost matrix, NaN = absent.
+// =====================================================================================================
+// NSUB = 64-track sub-tiles per block: 4 (16 x 256 cells, 128 clip lanes) when the frame still yields several blocks per
+// CU that way — fewer, longer-lived blocks amortise the fixed cost of a block (C4: 62 500 blocks of 16 x 64 took 25 us, 1000
+// blocks of 16 x 256 take 15) — else 1 (16 x 64 cells, 64 clip lanes), which keeps every CU busy on small or dense frames
+// where the clip rounds, not the pre-filter, set the time (C2: ~60 surviving pairs per candidate).
+#define POS_TI 16
+// UNION: also fold each edge into the row dual and the global union-find forest (needed by the many-workgroup assignment
+// tail).  When the whole scene is solved by ONE workgroup (k_assign_small) that workgroup builds both from the edge lists in
+// LDS instead — the chain of dependent global atomics per edge would otherwise sit at the tail of every block here.
+template <int NSUB>
+struct PosSmem {
+  double poly[4 * SA_POLY_CAP * 64];   // 24 KB: Sutherland–Hodgman ping-pong lists, [list][vertex][worker lane]
+  double cv[POS_TI][8];                // candidate polygons, derived here from the raw boxes (see frame_prep_block)
+  sa_geo cg[POS_TI];
+  float cconf[POS_TI], cz[POS_TI][5];
+  float thha[64 * NSUB];
+  uint32_t cnt;
+  uint16_t list[POS_TI * 64 * NSUB];   // (li << 8) | lj
+};
+template <bool DENSE, bool EDGES, int NSUB, bool UNION>
+__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem) {
+  constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = 64u;
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
+  if (i0 >= N || j0 >= T) return;
+  // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
+  // static LDS with the contraction's stages instead of adding to it
+  PosSmem<NSUB>& sm = *reinterpret_cast<PosSmem<NSUB>*>(smem);
+  auto& s_cg = sm.cg; auto& s_cv = sm.cv; auto& s_cconf = sm.cconf; auto& s_cz = sm.cz; auto& s_list = sm.list;
+  uint32_t& s_cnt = sm.cnt; auto& s_poly = sm.poly; auto& s_thha = sm.thha;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  if (tid < POS_TI) {
+    const uint32_t i = i0 + tid;
+    if (i < N) {
+      const BoxRaw r = sa_ldg(S.c_raw + i);
+      prep_box_common(r, &s_cg[tid], s_cv[tid]);
+      const sa_box& b = r.box;
+      s_cconf[tid] = b.confidence < p.min_confidence ? p.min_confidence : b.confidence;
+      s_cz[tid][0] = b.xc; s_cz[tid][1] = b.yc; s_cz[tid][2] = b.has_angle ? b.angle : 0.0f; s_cz[tid][3] = b.aspect; s_cz[tid][4] = b.height;
+    } else {
+      s_cg[tid] = sa_geo{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (tid == 0) s_cnt = 0;
+  // this thread's 4 tracks (one per 64-wide sub-tile): loads in flight while the candidate tile lands in LDS
+  sa_geo tg[NSUB];
+  uint64_t te[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    const uint32_t j = j0 + s * 64 + lane;
+    tg[s] = j < T ? sa_ldg(S.t_geo + j) : sa_geo{0.f, 0.f, 0.f, 0.f};
+    te[s] = j < T ? S.t_epoch[j] : 0ull;
+    if (wave == 0) s_thha[s * 64 + lane] = tg[s].hha;
+  }
+  __syncthreads();
+  const float nanv = __builtin_nanf("");
+  const uint64_t epoch = S.epoch;
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    const uint32_t lj = s * 64 + lane, j = j0 + lj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t li = wave * 4 + r, i = i0 + li;
+      bool live = false;
+      if (i < N && j < T) {
+        const sa_geo cg = s_cg[li];
+        live = !sa_too_far(cg, tg[s]) && sa_compatible(cg, epoch, tg[s], te[s], p.max_idle, p.cons);
+        if (DENSE && !live) S.pos[(size_t)i * T + j] = nanv;
+      }
+      if (live) {
+        uint32_t slot = atomicAdd(&s_cnt, 1u);
+        s_list[slot] = (uint16_t)((li << 8) | lj);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  // one surviving cell -> (optionally) the dense matrix, and its edge
+  auto emit = [&](uint32_t i, uint32_t j, float w, bool present) {
+    if (DENSE) S.pos[(size_t)i * T + j] = present ? w : nanv;
+    if (EDGES && present) {
+      const int64_t gain = sa_quantise(w) - p.threshold_q;  // (w * 1e6f) as i64 vs the diagonal of SortVoting's matrix
+      if (gain > 0) {
+        const uint32_t slot = atomicAdd((uint32_t*)(S.e_cnt + i), 1u);
+        S.e_col[(size_t)i * S.estride + slot] = j;
+        S.e_gain[(size_t)i * S.estride + slot] = gain;
+        if (UNION) {
+          __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
+          sa_uf_union((uint32_t*)S.parent, i, N + j);
+        }
+      }
+    }
+  };
+  if (p.positional_kind == SA_POS_MAHALANOBIS) {
+    for (uint32_t sidx = tid; sidx < cnt; sidx += 256) {
+      const uint32_t c = s_list[sidx];
+      const uint32_t li = c >> 8, lj = c & 255u;
+      const uint32_t i = i0 + li, j = j0 + lj;
+      float m20[20], z5[5];
+      const float SA_G* mp = S.t_maha + (size_t)j * 20;
+#pragma unroll
+      for (int k = 0; k < 20; ++k) m20[k] = mp[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) z5[k] = s_cz[li][k];
+      emit(i, j, sa_maha_cell(m20, z5, s_cconf[li]), true);
+    }
+  } else if (tid < POS_WORKERS) {
+    // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS
+    double* ws = s_poly + tid;
+    for (uint32_t sidx = tid; sidx < cnt; sidx += POS_WORKERS) {
+      const uint32_t c = s_list[sidx];
+      const uint32_t li = c >> 8, lj = c & 255u;
+      const uint32_t i = i0 + li, j = j0 + lj;
+      double cv[8], tv[8];
+      const double SA_G* tp = S.t_verts + (size_t)j * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cv[k] = s_cv[li][k]; tv[k] = tp[k]; }
+      const float t_hha = s_thha[lj];
+      double inter = sa_clip_area_ws(cv, tv, ws, ws + SA_POLY_CAP * POS_WORKERS, ws + 2 * SA_POLY_CAP * POS_WORKERS,
+                                     ws + 3 * SA_POLY_CAP * POS_WORKERS, POS_WORKERS);
+      float iou, out = nanv;
+      bool present = false;
+      if (sa_iou_from_area(inter, s_cg[li].hha, t_hha, &iou)) {
+        float e = iou * s_cconf[li];
+        if (e >= p.positional_threshold) { out = e; present = true; }
+      }
+      emit(i, j, out, present);
+    }
+  }
+}
+

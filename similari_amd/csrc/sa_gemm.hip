@@ -18,9 +18,11 @@
 // euclidean: sum (a-b)^2 directly on the VALU — the GEMM expansion |a|^2+|b|^2-2ab cancels catastrophically
 //            on near-identical vectors, which are exactly the true matches (SURVEY §7 hard parts).
 #include "sa_engine.h"
+#include "sa_frame.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -75,10 +77,12 @@ struct GemmCols {   // per-lane column metadata kept in registers through the ep
 // The body is branch-free (three specialisations: steady state / last-but-one chunk / last chunk) so that the whole
 // iteration is ONE scheduling region, pinned with sched_group_barrier; measured against the same loop with the loads and
 // stores hoisted to the top of the iteration (what the compiler does on its own): 110 -> see profiles/.
-template <int BM, int BN, int KG>
+// NORM: also accumulate, per lane, the sum of squares of the A fragments it multiplies (its half of the k values of row
+// wm*32 + lr, this k-group's chunks) into nsq[0] — the raw-feature mode of the fused frame launch has no pre-computed norms.
+template <int BM, int BN, int KG, bool NORM = false>
 __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M,
                                               uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
-                                              f32x16 (&acc)[BM / 64][BN / 64], uint64_t* tr = nullptr) {
+                                              f32x16 (&acc)[BM / 64][BN / 64], uint64_t* tr = nullptr, float* nsq = nullptr) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-B chunks per thread per stage
   constexpr int L_CH = A_CH + B_CH;                          // 4 (64x64) .. 8 (128x128): a multiple of 4 or exactly 6
@@ -178,6 +182,10 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
 #pragma unroll
           for (int n = 0; n < TN; ++n)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m][e], fb[cur][n][e], acc[m][n], 0, 0, 0);
+      if constexpr (NORM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nsq[0] += fa[cur][0][e] * fa[cur][0][e];
+      }
       // pin the interleave: one side instruction in the shadow of each of the first MFMAs of the k-step
       constexpr int NM = 4 * TM * TN;
       constexpr int nrd = kk < 3 ? TM + TN : 0, nst = STORE ? hi - lo : 0, nld = LOAD ? hi - lo : 0;
@@ -451,19 +459,22 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
   return out;
 }
 
-template <int BM, int BN, int KGT>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+// One tile of the fused visual cost kernel.  RAW (the heterogeneous frame launch, k_frame_visual): the frame-preparation
+// blocks run BESIDE this tile, not before it, so nothing they produce may be read — the candidate features come straight
+// from the uploaded rows (their length is a multiple of 32: no padding needed), their squared norms are accumulated from
+// the A fragments inside the main loop, and the row's geometry / feature_can_be_used gate are derived from the raw box.
+template <int BM, int BN, int KGT, bool RAW>
+__device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
   constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, TK = S.TK, K = S.K;
-  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const uint32_t m0 = by * BM, n0 = bx * BN;
   if (m0 >= N || n0 >= TK) return;
-  const uint32_t key_slot = blockIdx.y * ((TK + BN - 1) / BN) + blockIdx.x;  // < S.nkeys = tiles of THIS scene
+  const uint32_t key_slot = by * ((TK + BN - 1) / BN) + bx;  // < S.nkeys = tiles of THIS scene
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
-  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
+  static_assert(!RAW || (TM == 1 && TN == 1 && KGT != 0), "raw mode: 64x64 tiles with k-groups");
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
@@ -474,9 +485,27 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   static_assert(BM <= 256, "one thread per tile row");
   if (tid < (uint32_t)BM && m0 + tid < N) {
     const uint32_t gi = m0 + tid;
-    pre_na = S.c_fnorm[gi];
-    pre_us = S.c_usable[gi] ? 1.f : 0.f;
-    pre_g = sa_ldg(S.c_geo + gi);
+    if constexpr (RAW) {
+      // what frame_prep_block derives for this candidate (visual_sort/simple_api.rs:130-170, metric.rs:227-249)
+      const BoxRaw r = sa_ldg(S.c_raw + gi);
+      const sa_box& b = r.box;
+      pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
+      bool usable = false;
+      if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
+        const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
+        bool perc_ok = true;
+        if (S.flags & SCN_HAS_OWN) {
+          const float oa = S.c_own[gi];
+          if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+        }
+        usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
+      }
+      pre_us = usable ? 1.f : 0.f;
+    } else {
+      pre_na = S.c_fnorm[gi];
+      pre_us = S.c_usable[gi] ? 1.f : 0.f;
+      pre_g = sa_ldg(S.c_geo + gi);
+    }
   }
   GemmCols col[TN];
 #pragma unroll
@@ -503,7 +532,9 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   }
 
   f32x16 acc[TM][TN];
+  float nsq = 0.f;
   if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+  else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
 
   constexpr int R = 16 / KG;
@@ -515,12 +546,28 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   float* s_na = lds;                      // [BM]
   float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
+  float* s_np = lds + 6 * BM;             // [KG][BM] raw mode: squared-norm partials of the k-groups
   if (tid < (uint32_t)BM) {
     s_na[tid] = pre_na;
     s_us[tid] = pre_us;
     s_g[tid] = pre_g;
   }
+  if constexpr (RAW) {
+    // the two halves of a row's k values sit in lanes lr and lr + 32; the waves wn = 0 / 1 of a group hold the same rows
+    nsq += __shfl_xor(nsq, 32);
+    if (wn == 0 && lh == 0) s_np[kg * BM + wm * 32 + lr] = nsq;
+  }
   __syncthreads();
+  if constexpr (RAW) {
+    __syncthreads();
+    if (tid < (uint32_t)BM) {
+      float s = s_np[tid];
+#pragma unroll
+      for (int g2 = 1; g2 < KG; ++g2) s += s_np[g2 * BM + tid];
+      s_na[tid] = s;
+    }
+    __syncthreads();
+  }
   uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
   if constexpr (TM == 1 && TN == 1) {
     const uint32_t gj = n0 + wn * 32 + lr;
@@ -552,6 +599,42 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   SA_STAMP(tr, 4);
   block_max_key(S.vis_max_key, key_slot, kmax);
   SA_STAMP(tr, 5);
+}
+
+template <int BM, int BN, int KGT>
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr int KG = KGT ? KGT : 1;
+  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  visual_cosine_tile<BM, BN, KGT, false>(S, p, blockIdx.x, blockIdx.y, lds);
+}
+
+// The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
+//   n_gemm            : a 64x64 tile of the feature contraction (matrix cores; raw-feature mode, see visual_cosine_tile)
+//   n_gemm + n_pos    : a 16x64 positional tile (f64 VALU + LDS: pair pre-filter, polygon clipping, edges of the vote)
+//   ...               : a frame-preparation block (padded features + norms for the upkeep and the taps, vote-state reset)
+// The three kinds are independent of each other, so the positional tiles and the preparation blocks fill the issue slots and
+// the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
+// dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
+// static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
+                                                           uint32_t px, uint32_t py) {
+  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
+  static_assert(sizeof(PosSmem<1>) <= sizeof(float) * KG * 2 * 128 * BK, "the positional tile must fit the contraction's LDS");
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  // Contraction tiles first in blockIdx order: the dispatcher hands blocks out in that order, breadth-first over the CUs, so
+  // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
+  // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6.
+  uint32_t b = blockIdx.x;
+  if (b < gx * gy) {
+    visual_cosine_tile<64, 64, KG, true>(S, p, b % gx, b / gx, lds);
+    return;
+  }
+  b -= gx * gy;
+  if (threadIdx.x >= 256) return;  // the other two kinds are 256-thread blocks (ended waves do not take part in s_barrier)
+  if (b < px * py) positional_tile<false, true, 1, false>(S, p, b % px, b / px, lds);
+  else frame_prep_block(S, p, b - px * py);
 }
 
 // Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
@@ -808,6 +891,29 @@ void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns,
     case 6: *bm = 128; *bn = 64; break;
     default: break;
   }
+}
+
+// The fused first phase (k_frame_visual) applies when the contraction would run as 64x64 tiles with 2 or 4 k-groups — small
+// frames, where the other two kinds of work are a sizeable part of the frame — the feature length needs no padding, and the
+// one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
+// it does not apply: the caller falls back to k_frame + k_visual_cost.
+hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
+                                  const SaParams& p, hipStream_t st) {
+  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const uint32_t maxTK = maxT * K;
+  if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
+  const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
+  if (plan != 2 && plan != 4) return hipErrorNotSupported;
+  const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 64), py = cdiv(maxN, POS_TI);
+  uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
+  if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
+  sa_trace_hook(st, gx * gy);
+  // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
+  // contraction alone is faster (14.5 vs 16 us) but every block of the launch then owns 512 threads and 73 KB: two blocks per
+  // CU, and the 1250 positional / preparation blocks queue behind each other (29 us for the launch against 22.6).
+  SA_LAUNCH((k_frame_visual<1>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+  return hipGetLastError();
 }
 
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,

@@ -216,9 +216,10 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
+@pytest.mark.parametrize("fused", [0, abi.SA_FLAG_FUSED_FRAME], ids=["separate_launches", "fused_frame_launch"])
 @pytest.mark.parametrize("k", [1, 3])
-@pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36)])
-def test_visual_cosine_parity(k, n, t, d):
+@pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
+def test_visual_cosine_parity(k, n, t, d, fused):
     rng = np.random.default_rng(1000 + n + t + d + k)
     sc = synth.visual_scene(rng, t, n, d, k, canvas=(1500.0, 900.0), new_fraction=0.1)
     # ragged banks: some observations missing, some tracks too short, some candidates unusable
@@ -227,7 +228,7 @@ def test_visual_cosine_parity(k, n, t, d):
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
                           max_observations=k, visual_min_votes=1, visual_minimal_track_length=1 if k == 1 else 2,
                           visual_minimal_quality_use=0.55, visual_minimal_area=3000.0, positional_min_confidence=0.1,
-                          max_idle_epochs=5)
+                          max_idle_epochs=5, flags=fused)
     ids, votes, ref = check_visual(cfg, sc)
     assert (votes == abi.SA_VOTE_VISUAL).sum() > 0
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 0
