@@ -362,7 +362,7 @@ def main():
         }
         if h2d is not None:
             out["h2d_inclusive"] = h2d
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, scenes)
         print(json.dumps(out))
     if dist is not None:
