@@ -146,6 +146,68 @@ def test_state_kept_clean_across_frames_of_changing_size():
         eng.close()
 
 
+def test_graph_replay_gives_the_same_answers():
+    """SA_FLAG_GRAPH: the per-frame launches are captured once and replayed while the staged set is unchanged, re-captured when
+    it changes (new frame size, re-allocated buffers).  Same answers as the eager pipeline, frame after frame."""
+    rng = np.random.default_rng(9)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,
+                          max_observations=2, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5, flags=abi.SA_FLAG_GRAPH)
+    eng = Engine(cfg)
+    try:
+        for n, t in [(120, 150), (120, 150), (300, 310), (80, 310)]:
+            sc = synth.visual_scene(rng, t, n, 64, 2, canvas=(1200.0, 800.0), new_fraction=0.1)
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+            det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+            eng.upsert(0, tracks)
+            ids, votes = eng.associate(0, 1, det)
+            ref = O.associate(cfg, tracks, 1, det)
+            np.testing.assert_array_equal(ids, ref["track_id"])
+            np.testing.assert_array_equal(votes, ref["voting_type"])
+            for _ in range(3):  # replays of the captured graph
+                eng.batch_run()
+            eng.batch_sync()
+            ids2, votes2 = eng.batch_fetch(0, n)
+            np.testing.assert_array_equal(ids2, ref["track_id"])
+    finally:
+        eng.close()
+
+
+def test_device_upkeep_refuses_tracks_without_state():
+    """sa_tracks_apply steps the Kalman filter of the winner: a track that was upserted with the 5 x 5 projection only has no
+    full state on the device — the call must say so instead of stepping garbage; after sa_tracks_set_state it works."""
+    import ctypes as C
+
+    rng = np.random.default_rng(3)
+    sc = synth.sort_scene(rng, 20, 20, canvas=(600.0, 400.0))
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"]))
+        ids, _ = eng.associate(0, 1, abi.make_detections(sc["det_boxes"]))
+        assert (ids != 0).sum() > 10
+        new_ids = np.where(ids == 0, 1000 + np.arange(20), 0).astype(np.uint64)
+        pred = np.zeros(20, abi.BOX_DTYPE)
+        u64p, bp, fp = C.POINTER(C.c_uint64), C.POINTER(abi.sa_box), C.POINTER(C.c_float)
+        rc = eng.lib.sa_tracks_apply(eng.h, 0, new_ids.ctypes.data_as(u64p), C.cast(pred.ctypes.data, bp))
+        assert rc == abi.SA_ERR_STATE and b"without a Kalman state" in eng.lib.sa_last_error(eng.h)
+        # seed every track with a state (initiate from its box: mean = box, diagonal covariance), then the same call goes through
+        for tid, b in zip(sc["track_ids"], sc["track_boxes"]):
+            mean = np.array([b["xc"], b["yc"], 0.0, b["aspect"], b["height"], 0, 0, 0, 0, 0], np.float32)
+            cov = np.diag(np.full(10, 4.0, np.float32)).astype(np.float32)
+            assert eng.lib.sa_tracks_set_state(eng.h, 0, int(tid), mean.ctypes.data_as(fp), cov.ctypes.data_as(fp), None) == 0
+        rc = eng.lib.sa_tracks_apply(eng.h, 0, new_ids.ctypes.data_as(u64p), C.cast(pred.ctypes.data, bp))
+        assert rc == 0, eng.lib.sa_last_error(eng.h)
+        assert eng.count(0) == 20 + int((ids == 0).sum())
+        # a merged track's predicted box sits between its old box and the detection that continued it
+        k = int(np.nonzero(ids != 0)[0][0])
+        tb = sc["track_boxes"][int(ids[k]) - 1]
+        lo, hi = min(tb["xc"], sc["det_boxes"][k]["xc"]) - 1e-3, max(tb["xc"], sc["det_boxes"][k]["xc"]) + 1e-3
+        assert lo <= pred[k]["xc"] <= hi
+    finally:
+        eng.close()
+
+
 def test_sort_iou_constraints_and_idle_epochs():
     rng = np.random.default_rng(7)
     sc = synth.sort_scene(rng, 200, 220, canvas=(1200.0, 800.0))
