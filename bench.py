@@ -257,7 +257,7 @@ def main():
     for _ in range(args.steps):
         eng.batch_run()
     eng.batch_sync()
-    torch.cuda.synchronize()
+    barrier()  # barrier + synchronize on both sides of the timed region: every rank's dt covers the slowest rank
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
