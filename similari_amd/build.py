@@ -11,8 +11,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libsimilari_assoc.so"
 SOURCES = ["sa_kernels.hip", "sa_gemm.hip", "sa_upkeep.hip", "sa_engine.hip", "sa_tracker.cpp"]
-HEADERS = [CSRC / "sa_device.h", CSRC / "sa_engine.h", CSRC / "sa_kalman.h", PKG.parent / "include" / "similari_assoc.h",
-           PKG.parent / "include" / "similari_tracker.h"]
+HEADERS = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "similari_assoc.h", PKG.parent / "include" / "similari_tracker.h"]
 # -ffp-contract=off: the reference (rustc) never fuses a*b+c; the bit-exact IoU / assignment gates rely on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-value", "-Wno-unused-result"]
