@@ -215,6 +215,14 @@ int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const floa
 int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, float nms_threshold, float score_threshold,
            uint32_t* out_keep, uint32_t* out_n);
 
+/* ---- exclusively owned areas (src/utils/clipping/bbox_own_areas.rs:8-46) --------------
+ * exclusively_owned_areas_normalized_shares(boxes, exclusively_owned_areas(boxes)): out_share[i] = area of box i not covered by
+ * any other box of the frame / (area_i + EPS), clamped to 1.0 — the value VisualSORT's own-area gates read
+ * (visual_sort/simple_api.rs:111-127); feed it to sa_detections.own_area.  The reference builds the difference polygons with
+ * geo's BooleanOps; the device integrates the boundary of the same region in f64 (agreement to the reference test's EPS = 1e-5).
+ * SA_ERR_UNSUPPORTED when one box overlaps more than 127 others. */
+int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share);
+
 typedef struct sa_scene_request {
   uint64_t scene_id;
   uint64_t epoch;

@@ -18,8 +18,9 @@
  * sa_tracks_upsert every frame) or on the GPU (device_upkeep = 1: sa_tracks_apply, nothing but the predicted boxes
  * comes back).  Epoch counters, history deques, track ids and the wasted-track lifecycle stay on the host.
  *
- * Not provided (out of scope): exclusively_owned_areas.  A caller that uses the own-area
- * thresholds supplies the per-detection share in sa_observation.own_area (NaN = None).
+ * exclusively_owned_areas (clipping/bbox_own_areas.rs:8-46): when either own-area threshold is > 0 the facade computes the
+ * shares of the frame's boxes on the GPU (sa_own_areas) exactly where the reference computes them
+ * (visual_sort/simple_api.rs:111-127); a caller may override a detection's share through sa_observation.own_area.
  */
 #ifndef SIMILARI_TRACKER_H
 #define SIMILARI_TRACKER_H
@@ -48,7 +49,7 @@ typedef struct sa_observation {
   sa_box bbox;
   const float* feature;          /* feature_len floats or NULL (Option<&[f32]>) */
   float feature_quality;         /* NaN = None -> 1.0 (visual_sort/simple_api.rs:146) */
-  float own_area;                /* NaN = None */
+  float own_area;                /* NaN = computed by the tracker when the own-area gates are armed, else None */
   int32_t has_custom_object_id;
   int32_t reserved;
   int64_t custom_object_id;

@@ -795,3 +795,71 @@ extern "C" int or_nms(uint32_t n, const sa_box* boxes, const float* scores, floa
   *out_n = k;
   return 0;
 }
+
+// ---- src/utils/clipping/bbox_own_areas.rs:8-46 -----------------------------------------------------------
+// exclusively_owned_areas(): own_poly = Polygon(box i) minus, one after another, the polygon of every other box that is not
+// too_far() (geo 0.27 BooleanOps::difference — NOT under /root/reference); ..._normalized_shares(): (unsigned_area(own_poly) /
+// (area_i + EPS) as f64) as f32, clamped to 1.0.  Only the share reaches the tracker (visual_sort/simple_api.rs:111-127), so the
+// restatement computes the AREA of the difference, not its outline: the set difference of a convex piece and a convex quad is
+// the disjoint union of "piece ∩ inside(f_0..f_{k-1}) ∩ outside(f_k)" over the quad's edges f_k, each of which is convex again
+// (half-plane clipping), so the owned region is carried as a list of convex pieces and its area is the sum of shoelace areas.
+// PARITY UNPINNED below f64 rounding: geo's sweep-line produces the same region with differently rounded intersection points;
+// the reference's own test (bbox_own_areas.rs:58-82) checks to EPS = 1e-5 and so do ours.
+namespace {
+typedef std::vector<std::pair<double, double>> ConvexPiece;
+// keep the part of a convex polygon on one side of the directed line a->b: side(p) = cross(b-a, p-a); keep_le: side <= 0
+// (the interior side of the reference's clockwise box polygons, clipping.rs:12-15), else side > 0.
+ConvexPiece halfplane_clip(const ConvexPiece& in, double ax, double ay, double bx, double by, bool keep_le) {
+  ConvexPiece out;
+  const size_t n = in.size();
+  for (size_t i = 0; i < n; ++i) {
+    const auto& p = in[i];
+    const auto& q = in[(i + 1) % n];
+    const double sp = (bx - ax) * (p.second - ay) - (by - ay) * (p.first - ax);
+    const double sq = (bx - ax) * (q.second - ay) - (by - ay) * (q.first - ax);
+    const bool ip = keep_le ? sp <= 0.0 : sp > 0.0;
+    const bool iq = keep_le ? sq <= 0.0 : sq > 0.0;
+    if (ip) out.push_back(p);
+    if (ip != iq) {
+      const double t = sp / (sp - sq);
+      out.emplace_back(p.first + t * (q.first - p.first), p.second + t * (q.second - p.second));
+    }
+  }
+  return out;
+}
+double piece_area(const ConvexPiece& p) {
+  if (p.size() < 3) return 0.0;
+  double s = 0.0;
+  for (size_t i = 1; i + 1 < p.size(); ++i)
+    s += (p[i].first - p[0].first) * (p[i + 1].second - p[0].second) - (p[i + 1].first - p[0].first) * (p[i].second - p[0].second);
+  return std::fabs(s) * 0.5;
+}
+}  // namespace
+
+extern "C" int or_own_area_shares(uint32_t n, const sa_box* boxes, float* out_share) {
+  std::vector<double> verts((size_t)n * 8);
+  for (uint32_t i = 0; i < n; ++i) or_vertices(&boxes[i], &verts[(size_t)i * 8]);
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<ConvexPiece> pieces(1);
+    for (int v = 0; v < 4; ++v) pieces[0].emplace_back(verts[(size_t)i * 8 + 2 * v], verts[(size_t)i * 8 + 2 * v + 1]);
+    for (uint32_t j = 0; j < n && !pieces.empty(); ++j) {
+      if (j == i || or_too_far(&boxes[i], &boxes[j])) continue;
+      const double* q = &verts[(size_t)j * 8];
+      std::vector<ConvexPiece> next;
+      for (ConvexPiece rem : pieces) {
+        for (int k = 0; k < 4 && rem.size() >= 3; ++k) {
+          const double ax = q[2 * k], ay = q[2 * k + 1], bx = q[2 * ((k + 1) & 3)], by = q[2 * ((k + 1) & 3) + 1];
+          ConvexPiece outside = halfplane_clip(rem, ax, ay, bx, by, false);
+          if (piece_area(outside) > 0.0) next.push_back(std::move(outside));
+          rem = halfplane_clip(rem, ax, ay, bx, by, true);
+        }
+      }
+      pieces.swap(next);
+    }
+    double own = 0.0;
+    for (const auto& p : pieces) own += piece_area(p);
+    float e = (float)(own / (double)(or_area(&boxes[i]) + 1e-5f));
+    out_share[i] = e >= 1.0f ? 1.0f : e;
+  }
+  return 0;
+}

@@ -13,6 +13,7 @@
  *   geo 0.27         Area::unsigned_area (shoelace with first-vertex shift)    (or_polygon_area)
  *   nalgebra 0.32    SMatrix mul / cholesky / solve_lower_triangular           (kf_* helpers)
  *   wide (via ultraviolet 0.9) f32x8::reduce_add lane order                    (reduce_add8)
+ *   geo 0.27         BooleanOps::difference (own areas only)  restated as convex-piece decomposition (or_own_area_shares)
  * Tie-breaking of kuhn_munkres on non-unique optima and the f32x8 lane order below 1e-6
  * relative are PARITY-UNPINNED: no reference test exercises them.
  *
@@ -84,6 +85,10 @@ int or_visual_voting(float positional_threshold, float max_feature_distance, uin
 /* ---- src/utils/nms.rs:32-72 ---------------------------------------------- */
 int or_nms(uint32_t n, const sa_box* boxes, const float* scores /* NULL / NaN = None */, float nms_threshold,
            float score_threshold /* NaN = None */, uint32_t* out_keep, uint32_t* out_n);
+
+/* ---- src/utils/clipping/bbox_own_areas.rs:8-46 ----------------------------
+ * share[i] = area(box i minus every other box that is not too_far) / (area_i + EPS), clamped to 1. */
+int or_own_area_shares(uint32_t n, const sa_box* boxes, float* out_share);
 
 /* ---- one scene-frame, end to end (the thing sa_associate replaces) --------------------------
  * total_tracks_in_store: SortVoting's track_num for plain SORT (= store size over all scenes,

@@ -193,6 +193,15 @@ int or_tracker_predict_batch(or_tracker* t, uint32_t n_scenes, const uint64_t* s
     const uint64_t scene = scene_ids[s];
     const uint32_t n = counts[s];
     const uint64_t epoch = ++t->epoch_db[scene];
+    // own-area shares of the frame's boxes when either gate is armed (visual_sort/simple_api.rs:111-127)
+    std::vector<float> shares;
+    if (t->o.visual && n &&
+        t->o.visual_minimal_own_area_percentage_collect + t->o.visual_minimal_own_area_percentage_use > 0.0f) {
+      std::vector<sa_box> frame(n);
+      for (uint32_t i = 0; i < n; ++i) frame[i] = obs[s][i].bbox;
+      shares.resize(n);
+      or_own_area_shares(n, frame.data(), shares.data());
+    }
     // candidate tracks: one observation each, optimised (Kalman no-op step)
     std::vector<TrackO> cand(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -206,8 +215,8 @@ int or_tracker_predict_batch(or_tracker* t, uint32_t n_scenes, const uint64_t* s
       o1.has_bbox = true;
       o1.bbox = ob.bbox;
       o1.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
-      o1.has_own = ob.own_area == ob.own_area;
-      o1.own = o1.has_own ? ob.own_area : 0.0f;
+      o1.has_own = ob.own_area == ob.own_area || !shares.empty();   // a caller-supplied share takes precedence (facade extension)
+      o1.own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
       o1.has_feature = t->o.visual && ob.feature != nullptr;
       if (o1.has_feature) o1.feature.assign(ob.feature, ob.feature + D);
       c.observations.push_back(o1);

@@ -352,6 +352,7 @@ PROTOTYPES = {
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_nms": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float), C.c_float, C.c_float, P(u32), P(u32)]),
+    "sa_own_areas": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float)]),
     "sa_tap_dims": (C.c_int, [ENGINE, u32, P(u32), P(u32), P(u32)]),
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),

@@ -147,6 +147,127 @@ SA_HD double sa_clip_area(const double* subj, const double* clip) {
   return sa_clip_area_ws(subj, clip, ax, ay, bx, by, 1);
 }
 
+// ---- exclusively owned area (clipping/bbox_own_areas.rs:8-46) -----------------------------------------------
+// The reference subtracts, one after another, every near box from box i with geo's BooleanOps and takes the area of what is
+// left; only that area reaches the tracker.  The device never builds the outline: by Green's theorem the area of
+// R = Q_0 \ (Q_1 ∪ … ∪ Q_m) is half the sum of cross(A, B) · (length fraction) over the pieces of polygon edges A→B that
+// separate R from its complement —
+//   * an edge of Q_0 (the box itself), where it is not inside any Q_k;
+//   * an edge of Q_j (j ≥ 1), traversed backwards, where it is inside Q_0 and not inside any other Q_k.
+// A segment meets a convex quad in ONE parameter interval (four half-plane cuts), so per edge the work is m intervals and the
+// measure of what they leave uncovered.  Edges that lie exactly on the same line (duplicate detections, boxes on a grid) are
+// decided by which side the interiors are on, so that every geometric piece of the boundary is emitted exactly once:
+//   same_in / opp_in = does an edge of Y that is collinear with the segment, in the same / the opposite direction, count as
+//   containing it.  Q_0's edges: (true, false) against every Q_k — just inside Q_0 is inside Q_k only when the interiors are
+//   on the same side.  Q_j's edges: (false, false) against Q_0 (Q_0 emits the shared piece itself), (k < j, true) against Q_k —
+//   of two coincident edges the lower index emits.
+// All polygons are the reference's clockwise quads (bbox.rs:287-330): interior = cross(f1 - f0, p - f0) <= 0 (clipping.rs:12-15).
+SA_HD bool sa_seg_in_quad(double ax, double ay, double bx, double by, const double* q, bool same_in, bool opp_in, double* t0,
+                          double* t1) {
+  double lo = *t0, hi = *t1;
+  for (int k = 0; k < 4; ++k) {
+    const int k1 = (k + 1) & 3;
+    const double f0x = q[2 * k], f0y = q[2 * k + 1];
+    const double dx = q[2 * k1] - f0x, dy = q[2 * k1 + 1] - f0y;
+    const double ga = dx * (ay - f0y) - dy * (ax - f0x);
+    const double gb = dx * (by - f0y) - dy * (bx - f0x);
+    if (ga == 0.0 && gb == 0.0) {
+      const bool same = dx * (bx - ax) + dy * (by - ay) > 0.0;
+      if (!(same ? same_in : opp_in)) return false;
+      continue;
+    }
+    if (ga <= 0.0 && gb <= 0.0) continue;
+    if (ga > 0.0 && gb > 0.0) return false;
+    const double t = ga / (ga - gb);
+    if (ga > 0.0) lo = t > lo ? t : lo;
+    else hi = t < hi ? t : hi;
+  }
+  *t0 = lo;
+  *t1 = hi;
+  return lo < hi;
+}
+// Measure of [lo, hi] minus the union of cnt intervals [a_k, b_k] ⊂ [lo, hi] (non-empty, element k at [k * stride]): every gap
+// starts at lo or at some b_k; O(cnt^2), cnt is the handful of boxes that actually cross this edge.
+SA_HD double sa_uncovered(double lo, double hi, uint32_t cnt, const double* a, const double* b, uint32_t stride) {
+  double total = 0.0;
+  for (uint32_t si = 0; si <= cnt; ++si) {
+    const double s = si == 0 ? lo : b[(si - 1) * stride];
+    if (!(s < hi)) continue;
+    bool skip = false;
+    double next = hi;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const double aj = a[j * stride], bj = b[j * stride];
+      if (aj <= s && s < bj) { skip = true; break; }                 // s is covered
+      if (si > 0 && j < si - 1 && bj == s) { skip = true; break; }   // the same gap start, counted at the lower index
+      if (aj > s && aj < next) next = aj;
+    }
+    if (!skip) total += next - s;
+  }
+  return total;
+}
+// Signed contribution (twice the area) of edge ek of polygon xi of the list polys[m1][8] (index 0 = the box itself), using
+// iva / ivb (cap elements, stride apart) as interval storage.  Returns NaN when more than cap disjoint stretches of this edge
+// are covered (a full list is first fused into disjoint intervals).
+SA_HD double sa_own_edge(const double* polys, uint32_t m1, uint32_t xi, uint32_t ek, double* iva, double* ivb, uint32_t stride,
+                         uint32_t cap) {
+  const double* X = polys + (size_t)xi * 8;
+  const uint32_t e1 = (ek + 1) & 3u;
+  const double ax = X[2 * ek], ay = X[2 * ek + 1], bx = X[2 * e1], by = X[2 * e1 + 1];
+  double lo = 0.0, hi = 1.0;
+  if (xi != 0 && !sa_seg_in_quad(ax, ay, bx, by, polys, false, false, &lo, &hi)) return 0.0;
+  uint32_t cnt = 0;
+  for (uint32_t yi = 1; yi < m1; ++yi) {
+    if (yi == xi) continue;
+    double t0 = lo, t1 = hi;
+    const bool same_in = xi == 0 ? true : yi < xi;
+    const bool opp_in = xi != 0;
+    if (!sa_seg_in_quad(ax, ay, bx, by, polys + (size_t)yi * 8, same_in, opp_in, &t0, &t1)) continue;
+    if (t0 <= lo && t1 >= hi) return 0.0;  // wholly covered
+    if (cnt >= cap) {  // storage full: fuse overlapping intervals into disjoint ones (only very crowded edges get here)
+      for (uint32_t i = 0; i < cnt; ++i) {
+        bool changed = true;
+        while (changed) {
+          changed = false;
+          for (uint32_t j = i + 1; j < cnt; ++j) {
+            const double ai = iva[i * stride], bi = ivb[i * stride], aj = iva[j * stride], bj = ivb[j * stride];
+            if (aj <= bi && bj >= ai) {
+              iva[i * stride] = aj < ai ? aj : ai;
+              ivb[i * stride] = bj > bi ? bj : bi;
+              --cnt;
+              iva[j * stride] = iva[cnt * stride];
+              ivb[j * stride] = ivb[cnt * stride];
+              changed = true;
+              --j;
+            }
+          }
+        }
+      }
+      if (cnt >= cap) return NAN;  // more than cap DISJOINT covered stretches on one edge
+    }
+    iva[cnt * stride] = t0;
+    ivb[cnt * stride] = t1;
+    ++cnt;
+  }
+  const double mu = sa_uncovered(lo, hi, cnt, iva, ivb, stride);
+  const double cr = ax * by - ay * bx;
+  return xi == 0 ? cr * mu : -cr * mu;
+}
+// Conservative "do these two quads overlap" (never false for quads that share area): a separating axis among the 8 edges.
+SA_HD bool sa_quads_separated(const double* p, const double* q) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* f = pass ? q : p;
+    const double* g = pass ? p : q;
+    for (int k = 0; k < 4; ++k) {
+      const int k1 = (k + 1) & 3;
+      const double f0x = f[2 * k], f0y = f[2 * k + 1], dx = f[2 * k1] - f0x, dy = f[2 * k1 + 1] - f0y;
+      bool all_out = true;
+      for (int v = 0; v < 4; ++v) all_out = all_out && (dx * (g[2 * v + 1] - f0y) - dy * (g[2 * v] - f0x) > 0.0);
+      if (all_out) return true;
+    }
+  }
+  return false;
+}
+
 // Universal2DBox::calculate_metric_object (bbox.rs:512-535) for a pair that is not too_far.
 SA_HD bool sa_iou_from_area(double inter, float c_hha, float t_hha, float* out) {
   if (inter == 0.0) return false;

@@ -1096,6 +1096,36 @@ int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, f
   return SA_OK;
 }
 
+// exclusively_owned_areas + ..._normalized_shares (clipping/bbox_own_areas.rs:8-46) for one frame's boxes.
+int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share) {
+  if (!e || (n && (!boxes || !out_share))) return fail(e, SA_ERR_BAD_ARG, "sa_own_areas: null argument");
+  if (!n) return SA_OK;
+  for (uint32_t i = 0; i < n; ++i) TRY(check_box(e, boxes[i], "boxes", i));
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(engine_sync(e));
+  const size_t raw_bytes = (size_t)n * sizeof(BoxRaw), out_bytes = (size_t)n * 4 + 4;
+  TRY(host_ensure(e, e->up_host, raw_bytes + out_bytes));
+  BoxRaw* hraw = (BoxRaw*)e->up_host.p;
+  fill_raw(hraw, boxes, n);
+  TRY(dev_ensure(e, e->up_raw, raw_bytes));
+  TRY(dev_ensure(e, e->nms_keep, out_bytes));   // share[n] + status word
+  hipStream_t st = e->stream;
+  float* dshare = (float*)e->nms_keep.p;
+  uint32_t* dstatus = (uint32_t*)(dshare + n);
+  HIPCHK(e, hipMemcpyAsync(e->up_raw.p, hraw, raw_bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(e, sa_launch_own_areas((const BoxRaw*)e->up_raw.p, n, dshare, dstatus, st));
+  uint8_t* hout = (uint8_t*)e->up_host.p + raw_bytes;
+  HIPCHK(e, hipMemcpyAsync(hout, dshare, out_bytes, hipMemcpyDeviceToHost, st));
+  e->synced = false;
+  TRY(engine_sync(e));
+  uint32_t status;
+  memcpy(&status, hout + (size_t)n * 4, 4);
+  if (status & 1u) return fail(e, SA_ERR_UNSUPPORTED, "sa_own_areas: a box overlaps more than 127 other boxes");
+  if (status & 2u) return fail(e, SA_ERR_UNSUPPORTED, "sa_own_areas: more than 24 disjoint stretches of one box edge are covered by other boxes");
+  memcpy(out_share, hout, (size_t)n * 4);
+  return SA_OK;
+}
+
 // ---- parity taps ----------------------------------------------------------------------------------------
 static int tap_slot(sa_engine* e, uint32_t slot, Slot** out) {
   if (!e) return SA_ERR_BAD_ARG;

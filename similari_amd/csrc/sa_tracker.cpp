@@ -215,9 +215,26 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     cboxes[s].resize(n);
     if (o.visual) { cfeat[s].assign((size_t)n * D, 0.0f); cq[s].resize(n); cown[s].resize(n); cpres[s].resize(n); }
     for (uint32_t i = 0; i < n; ++i) {
-      const sa_observation& ob = obs[s][i];
-      if (!(ob.bbox.aspect > 0.0f) || !(ob.bbox.height > 0.0f) || !(ob.bbox.confidence >= 0.0f && ob.bbox.confidence <= 1.0f))
+      const sa_box& bb = obs[s][i].bbox;
+      if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f))
         return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
+    }
+    // exclusively_owned_areas_normalized_shares over the frame's observed boxes, when either own-area gate is armed
+    // (visual_sort/simple_api.rs:111-127) — on the GPU (sa_own_areas).  A share the caller supplies takes precedence.
+    std::vector<float> shares;
+    if (o.visual && n && o.visual_minimal_own_area_percentage_collect + o.visual_minimal_own_area_percentage_use > 0.0f) {
+      bool any_missing = false;
+      for (uint32_t i = 0; i < n; ++i) any_missing = any_missing || obs[s][i].own_area != obs[s][i].own_area;
+      if (any_missing) {
+        std::vector<sa_box> frame(n);
+        for (uint32_t i = 0; i < n; ++i) frame[i] = obs[s][i].bbox;
+        shares.resize(n);
+        int rc = sa_own_areas(t->eng, n, frame.data(), shares.data());
+        if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
+      }
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+      const sa_observation& ob = obs[s][i];
       Cand& c = cs[i];
       c.raw = ob.bbox;
       // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from,
@@ -233,8 +250,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       c.has_custom = ob.has_custom_object_id != 0;
       c.custom = ob.custom_object_id;
       c.obs.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
-      c.obs.has_own = ob.own_area == ob.own_area;
-      c.obs.own = c.obs.has_own ? ob.own_area : 0.0f;
+      c.obs.has_own = ob.own_area == ob.own_area || !shares.empty();
+      c.obs.own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
       c.obs.has_feat = o.visual && ob.feature != nullptr;
       c.fptr = c.obs.has_feat ? ob.feature : nullptr;
       cboxes[s][i] = c.box;

@@ -256,6 +256,81 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const uint64_t* __restrict__ m
   }
 }
 
+// =====================================================================================================
+// Exclusively owned areas  (src/utils/clipping/bbox_own_areas.rs:8-46 — SURVEY §8f rank 4)
+//   share_i = area(box_i minus every other box that is not too_far()) / (area_i + EPS), clamped to 1 — what VisualSORT's
+//   own-area gates read (visual_sort/simple_api.rs:111-127).  One wave per box:
+//     1. the lanes scan all boxes: too_far() (the reference's neighbour rule), then a separating-axis test that drops the
+//        circle-neighbours that do not actually overlap; the survivors' polygons go to LDS, relative to the box's centre;
+//     2. one lane per polygon edge (4 per neighbour + 4 own) integrates its share of the owned region's boundary
+//        (sa_own_edge, sa_device.h); a wave reduction and the reference's f32 epilogue finish the box.
+//   status: bit 0 = a box overlaps more than SA_OWN_MAXNB others, bit 1 = more than SA_OWN_CAP disjoint stretches of one edge are covered.
+// =====================================================================================================
+#define SA_OWN_MAXNB 127
+#define SA_OWN_CAP 24
+__global__ __launch_bounds__(64) void k_own_area(const BoxRaw* __restrict__ raw, uint32_t n, float* __restrict__ share,
+                                                 uint32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x, lane = threadIdx.x;
+  __shared__ double s_poly[(SA_OWN_MAXNB + 1) * 8];
+  __shared__ double s_iva[SA_OWN_CAP * 64], s_ivb[SA_OWN_CAP * 64];
+  __shared__ uint32_t s_cnt;
+  const BoxRaw me = raw[i];
+  sa_geo mg;
+  mg.xc = me.box.xc; mg.yc = me.box.yc; mg.r = sa_radius(me.box.aspect, me.box.height); mg.hha = 0.f;
+  double mv[8];
+  sa_vertices(me.box.xc, me.box.yc, me.box.aspect, me.box.height, me.c, me.s, mv);
+  const double ox = (double)me.box.xc, oy = (double)me.box.yc;
+  if (lane < 8) s_poly[lane] = mv[lane] - ((lane & 1u) ? oy : ox);
+  if (lane == 0) s_cnt = 1;
+  __syncthreads();
+  bool overflow = false;
+  for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    if (j < n && j != i) {
+      const BoxRaw r = raw[j];
+      sa_geo g;
+      g.xc = r.box.xc; g.yc = r.box.yc; g.r = sa_radius(r.box.aspect, r.box.height); g.hha = 0.f;
+      if (!sa_too_far(mg, g)) {
+        double v[8];
+        sa_vertices(r.box.xc, r.box.yc, r.box.aspect, r.box.height, r.c, r.s, v);
+        if (!sa_quads_separated(mv, v)) {
+          const uint32_t slot = atomicAdd(&s_cnt, 1u);
+          if (slot <= SA_OWN_MAXNB) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_poly[slot * 8 + k] = v[k] - ((k & 1) ? oy : ox);
+          } else {
+            overflow = true;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (__any(overflow)) {
+    if (lane == 0) { share[i] = NAN; atomicOr(status, 1u); }
+    return;
+  }
+  const uint32_t m1 = s_cnt;
+  double acc = 0.0;
+  for (uint32_t e = lane; e < m1 * 4; e += 64)
+    acc += sa_own_edge(s_poly, m1, e >> 2, e & 3u, s_iva + lane, s_ivb + lane, 64, SA_OWN_CAP);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    if (acc != acc) atomicOr(status, 2u);
+    const double own = fabs(acc) * 0.5;
+    const float e = (float)(own / (double)(sa_area(me.box.aspect, me.box.height) + SA_EPS));
+    share[i] = e >= 1.0f ? 1.0f : e;
+  }
+}
+
+hipError_t sa_launch_own_areas(const BoxRaw* raw, uint32_t n, float* share, uint32_t* status, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipError_t e = hipMemsetAsync(status, 0, 4, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_own_area, dim3(n), dim3(64), 0, st, raw, n, share, status);
+  return hipGetLastError();
+}
+
 hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st) {
   if (!n) return hipSuccess;
   const uint32_t W = cdiv(n, 64);

@@ -121,6 +121,15 @@ class Engine:
                                   keep.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(m)))
         return keep[: m.value].copy()
 
+    # ---- own-area shares (src/utils/clipping/bbox_own_areas.rs) ----
+    def own_areas(self, boxes: np.ndarray) -> np.ndarray:
+        """exclusively_owned_areas_normalized_shares of one frame's boxes (f32 per box, <= 1)."""
+        boxes = np.ascontiguousarray(boxes, abi.BOX_DTYPE)
+        out = np.zeros(max(len(boxes), 1), np.float32)
+        self._chk(self.lib.sa_own_areas(self.h, len(boxes), C.cast(boxes.ctypes.data, C.POINTER(abi.sa_box)),
+                                        out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out[: len(boxes)].copy()
+
     # ---- taps ----
     def tap_dims(self, slot: int = 0):
         n, t, k = C.c_uint32(), C.c_uint32(), C.c_uint32()

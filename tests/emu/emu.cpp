@@ -156,4 +156,38 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
   return 0;
 }
 
+// k_own_area for every box of a frame, as the kernel sequences it (neighbour scan, relative coordinates, one call of
+// sa_own_edge per polygon edge, the reference's f32 epilogue).  Returns the status bits the kernel would raise.
+int emu_own_areas(uint32_t n, const sa_box* boxes, float* out_share, uint32_t max_nb, uint32_t cap) {
+  std::vector<double> verts((size_t)n * 8);
+  std::vector<sa_geo> geo(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const sa_box& b = boxes[i];
+    double a = (double)(b.has_angle ? b.angle : 0.0f);
+    double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+    sa_vertices(b.xc, b.yc, b.aspect, b.height, c, s, &verts[(size_t)i * 8]);
+    geo[i].xc = b.xc; geo[i].yc = b.yc; geo[i].r = sa_radius(b.aspect, b.height); geo[i].hha = 0.f;
+  }
+  int status = 0;
+  std::vector<double> polys, iva(cap), ivb(cap);
+  for (uint32_t i = 0; i < n; ++i) {
+    const double ox = (double)boxes[i].xc, oy = (double)boxes[i].yc;
+    polys.clear();
+    for (int k = 0; k < 8; ++k) polys.push_back(verts[(size_t)i * 8 + k] - ((k & 1) ? oy : ox));
+    for (uint32_t j = 0; j < n; ++j) {
+      if (j == i || sa_too_far(geo[i], geo[j]) || sa_quads_separated(&verts[(size_t)i * 8], &verts[(size_t)j * 8])) continue;
+      for (int k = 0; k < 8; ++k) polys.push_back(verts[(size_t)j * 8 + k] - ((k & 1) ? oy : ox));
+    }
+    const uint32_t m1 = (uint32_t)(polys.size() / 8);
+    if (m1 - 1 > max_nb) { status |= 1; out_share[i] = NAN; continue; }
+    double acc = 0.0;
+    for (uint32_t e = 0; e < m1 * 4; ++e) acc += sa_own_edge(polys.data(), m1, e >> 2, e & 3u, iva.data(), ivb.data(), 1, cap);
+    if (acc != acc) status |= 2;
+    const double own = fabs(acc) * 0.5;
+    const float e = (float)(own / (double)(sa_area(boxes[i].aspect, boxes[i].height) + SA_EPS));
+    out_share[i] = e >= 1.0f ? 1.0f : e;
+  }
+  return status;
+}
+
 }  // extern "C"

@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
             [f32, f32, u32, u32, P(u64), P(u64), fp, fp, u32, P(u64), P(u64), P(C.c_uint8)],
         ),
         "or_nms": (C.c_int, [u32, B, fp, f32, f32, P(u32), P(u32)]),
+        "or_own_area_shares": (C.c_int, [u32, B, fp]),
         "or_associate": (C.c_int, [P(abi.sa_config), u32, P(abi.sa_tracks), u64, P(abi.sa_detections), P(or_frame_out)]),
     }
     T = C.c_void_p
@@ -127,6 +128,14 @@ def nms(boxes, scores=None, nms_threshold=0.5, score_threshold=None):
     L.or_nms(len(boxes), box_ptr(boxes), None if sc is None else fptr(sc), nms_threshold,
              float("nan") if score_threshold is None else score_threshold, keep.ctypes.data_as(P(u32)), C.byref(m))
     return keep[: m.value].copy()
+
+
+def own_area_shares(boxes):
+    """Oracle own-area shares (oracle.cpp: or_own_area_shares, following src/utils/clipping/bbox_own_areas.rs:8-46)."""
+    boxes = np.ascontiguousarray(boxes, abi.BOX_DTYPE)
+    out = np.zeros(max(len(boxes), 1), np.float32)
+    lib().or_own_area_shares(len(boxes), box_ptr(boxes), fptr(out))
+    return out[: len(boxes)].copy()
 
 
 def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True):

@@ -267,11 +267,13 @@ def test_batch_sort_scenes_and_constraints_match_oracle(backend):
     run_sort_sequence(IoU(0.3), False, seed=17, scenes=(3, 7, 11), batch=True, constraints=c, n=40, backend=backend)
 
 
-def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False, backend="gpu"):
+def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False, backend="gpu", own=None):
     rng = np.random.default_rng(seed)
     opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(metric)
             .positional_metric(positional).visual_minimal_track_length(2).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(3).visual_min_votes(1))
+    if own is not None:   # arm the own-area gates: the trackers compute exclusively_owned_areas shares themselves
+        opts = opts.visual_minimal_own_area_percentage_use(own[0]).visual_minimal_own_area_percentage_collect(own[1])
     g = make(backend, "visual", opts=opts, feature_len=d, batch=batch)
     o = make("oracle", "visual", opts=opts, feature_len=d, batch=batch)
     try:
@@ -307,6 +309,40 @@ def test_visual_cosine_sequence_matches_oracle(backend):
 @UPKEEP
 def test_visual_euclid_maha_sequence_matches_oracle(backend):
     run_visual_sequence(TR.VisualSortMetricType.euclidean(0.5), TR.PositionalMetricType.maha(), seed=23, batch=True, backend=backend)
+
+
+@pytest.mark.gpu
+@UPKEEP
+def test_visual_sequence_with_own_area_gates_matches_oracle(backend):
+    """visual_sort/simple_api.rs:111-127: with either own-area threshold > 0 the tracker computes the shares of the frame's boxes
+    (sa_own_areas on the device, or_own_area_shares in the oracle) and gates feature use / collection on them."""
+    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=27, n=60, backend=backend, own=(0.55, 0.7))
+
+
+def test_oracle_own_area_gates_change_the_outcome():
+    """The gates must actually bite on the sequence above, otherwise the parity test proves nothing."""
+    def collected(own):
+        rng = np.random.default_rng(27)
+        opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
+                .positional_metric(IoU(0.3)).visual_minimal_track_length(2).visual_minimal_area(500.0)
+                .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(3).visual_min_votes(1))
+        if own:
+            opts = opts.visual_minimal_own_area_percentage_use(own[0]).visual_minimal_own_area_percentage_collect(own[1])
+        o = make("oracle", "visual", opts=opts, feature_len=16)
+        try:
+            ident = synth.reid_identities(rng, 60, 16)
+            world = synth.dense_boxes(rng, 60, (900.0, 700.0))
+            tot = 0
+            for f in range(4):
+                world = synth.jitter_boxes(rng, world, 2.0)
+                items = [TR.VisualSortObservation(ft, 0.9, bx, None) for bx, ft in zip(boxes_to_u2d(world), synth.observe(rng, ident, 0.01))]
+                r = o.predict(items)
+            for x in r:
+                tot += o.track_info(x.id)["visual_features_collected_count"]
+            return tot
+        finally:
+            o.close()
+    assert collected((0.55, 0.7)) < collected(None)
 
 
 @pytest.mark.gpu
