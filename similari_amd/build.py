@@ -35,7 +35,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+    extra = os.environ.get("SA_EXTRA_FLAGS", "").split()   # e.g. -DSA_GEMM_TRACE / -DSA_POS_TRACE (in-kernel timelines)
+    cmd = [hipcc(), *FLAGS, *extra, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=str(CSRC))
