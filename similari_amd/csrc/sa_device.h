@@ -405,9 +405,10 @@ SA_HD void sa_uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
 struct sa_assign_ws {
   // edges, row-major with row stride `estride`
   const uint32_t* e_cnt;   // [N]
-  const uint32_t* e_col;   // [N][estride], or a packed pool indexed through e_off
-  const int64_t* e_gain;   // same layout as e_col
-  uint32_t estride;
+  const uint32_t* e_col;   // edge e of a row at e_col[e * ecs] / e_gain[e * egs]: two packed arrays (ecs = egs = 1: the LDS pool) or
+  const int64_t* e_gain;   // both pointing into one array of 16-byte {gain, col} records (ecs = 4, egs = 2: the lists in HBM)
+  uint32_t ecs, egs;
+  uint32_t estride;        // records per row
   const uint32_t* e_off;   // nullptr: row r starts at r * estride; else at e_off[r] (edge lists packed into an LDS pool)
   const uint8_t* excluded;   // [T] or nullptr: columns already taken by the visual vote (visual_sort/voting.rs:62-79);
                              // their edges stay in the lists (the edge pass runs beside the visual vote) and are skipped here
@@ -428,14 +429,14 @@ struct sa_assign_ws {
 SA_HD void sa_assign_relax_row(const sa_assign_ws& w, uint32_t row, int64_t base, uint32_t stamp, int32_t* list_head) {
   uint32_t cnt = w.e_cnt[row];
   const size_t first = w.e_off ? (size_t)w.e_off[row] : (size_t)row * w.estride;
-  const uint32_t* cols = w.e_col + first;
-  const int64_t* gains = w.e_gain + first;
+  const uint32_t* cols = w.e_col + first * w.ecs;
+  const int64_t* gains = w.e_gain + first * w.egs;
   int64_t ur = w.u[row];
   for (uint32_t e = 0; e < cnt; ++e) {
-    uint32_t j = cols[e];
+    uint32_t j = cols[(size_t)e * w.ecs];
     if (w.excluded && w.excluded[j]) continue;
     if (w.cscan[j] == stamp) continue;
-    int64_t d = base + (-gains[e] - ur - w.v[j]);
+    int64_t d = base + (-gains[(size_t)e * w.egs] - ur - w.v[j]);
     if (w.cstamp[j] != stamp) {
       w.cstamp[j] = stamp;
       w.dist[j] = d;

@@ -13,6 +13,13 @@
 //   t_feat[T][K][Dp] f32 | t_fnorm[T][K] | t_fpresent[T][K] | t_fcount[T] | t_ids[T]
 //   c_* the same for the N candidates of the frame; pos[N][T], vis[N][T][K] f32 with NaN = absent.
 // Raw per-box staging record uploaded by the host: the caller's sa_box plus libm cos/sin of the angle.
+// One edge of the positional vote's graph: (candidate row ->) track column, gain = quantised weight - new-track threshold.
+struct alignas(16) SaEdge {
+  int64_t gain;
+  uint32_t col;
+  uint32_t pad;
+};
+
 struct BoxRaw {
   sa_box box;
   double c, s;
@@ -89,8 +96,7 @@ struct SceneDev {
   uint32_t SA_G* next_row;
   uint32_t SA_G* e_cnt;      // [N] edges appended by the positional tiles; zero between frames (the tail leaves it clean)
   uint32_t SA_G* e_use;      // [N] many-workgroup tail: the counts the solver works on
-  uint32_t SA_G* e_col;
-  int64_t SA_G* e_gain;
+  SaEdge SA_G* e_edge;       // [N][estride] edge records (one 16-byte store per edge, one cache line per short row)
   int64_t SA_G* u;           // [N] -max gain per row, folded by the positional tiles (UNION); zero between frames
   int64_t SA_G* u_use;       // [N] many-workgroup tail: the solver's row duals
   int64_t SA_G* v;

@@ -57,7 +57,7 @@ struct Slot {  // one scene of the current batch
   // matrices + vote + assignment state
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
-  DevBuf parent, label, next_row, e_cnt, e_use, e_col, e_gain, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
+  DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
   HostBuf h_apply, h_pred;
   void* d_pred = nullptr;
@@ -304,8 +304,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->next_row, n * 4));
   TRY(dev_ensure(e, s->e_cnt, n * 4));
   TRY(dev_ensure(e, s->e_use, n * 4));
-  TRY(dev_ensure(e, s->e_col, n * t * 4));
-  TRY(dev_ensure(e, s->e_gain, n * t * 8));
+  TRY(dev_ensure(e, s->e_edge, n * t * sizeof(SaEdge)));
   TRY(dev_ensure(e, s->u, n * 8));
   TRY(dev_ensure(e, s->u_use, n * 8));
   if (s->parent.p != p_par || s->e_cnt.p != p_ec || s->u.p != p_u) s->needs_init = true;
@@ -354,7 +353,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
   d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
-  d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_col = (decltype(d->e_col))(s->e_col.p); d->e_gain = (decltype(d->e_gain))(s->e_gain.p);
+  d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_edge = (decltype(d->e_edge))(s->e_edge.p);
   d->u = (decltype(d->u))(s->u.p); d->u_use = (decltype(d->u_use))(s->u_use.p); d->v = (decltype(d->v))(s->v.p); d->rmatch = (decltype(d->rmatch))(s->rmatch.p); d->cmatch = (decltype(d->cmatch))(s->cmatch.p);
   d->dist = (decltype(d->dist))(s->dist.p); d->pred = (decltype(d->pred))(s->pred.p); d->cstamp = (decltype(d->cstamp))(s->cstamp.p); d->cscan = (decltype(d->cscan))(s->cscan.p);
   d->cnext = (decltype(d->cnext))(s->cnext.p); d->rdist = (decltype(d->rdist))(s->rdist.p); d->rnext = (decltype(d->rnext))(s->rnext.p);
@@ -619,7 +618,7 @@ void sa_engine_destroy(sa_engine* e) {
     for (DevBuf* b : {&s->raw, &s->quality, &s->own, &s->fpresent_in, &s->feat_raw, &s->geo, &s->verts, &s->z, &s->conf,
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                       &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
-                      &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_col, &s->e_gain, &s->u, &s->u_use, &s->v, &s->rmatch,
+                      &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                       &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
                       &s->bank_tmp})
       free_dev(*b);

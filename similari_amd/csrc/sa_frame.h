@@ -199,8 +199,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
       const int64_t gain = sa_quantise(w) - p.threshold_q;  // (w * 1e6f) as i64 vs the diagonal of SortVoting's matrix
       if (gain > 0) {
         const uint32_t slot = atomicAdd((uint32_t*)(S.e_cnt + i), 1u);
-        S.e_col[(size_t)i * S.estride + slot] = j;
-        S.e_gain[(size_t)i * S.estride + slot] = gain;
+        sa_stg(S.e_edge + (size_t)i * S.estride + slot, SaEdge{gain, j, 0u});
         if (UNION) {
           __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
           sa_uf_union((uint32_t*)S.parent, i, N + j);

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // =====================================================================================================
 __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   sa_assign_ws w;
-  w.e_cnt = S.e_use; w.e_col = S.e_col; w.e_gain = S.e_gain; w.estride = S.estride; w.e_off = nullptr;
+  w.e_cnt = S.e_use; w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2;
+  w.estride = S.estride; w.e_off = nullptr;
   w.excluded = S.col_excluded;
   w.next_row = S.next_row;
   w.u = S.u_use; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
@@ -305,14 +306,65 @@ __device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
   S.win_col[q] = win;
 }
 
-// One 1024-thread workgroup per scene: labels, row order inside components, solve, results.  The solver's
-// duals / matches / search scratch live in LDS (68 KB) whenever the scene has at most 1024 tracks: every step of
-// the shortest-path search is a chain of dependent accesses, ~10x cheaper in LDS than in L2.
+// In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
+// thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
+#ifdef SA_TAIL_TRACE
+__device__ unsigned long long* g_tail_buf;
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && g_tail_buf) g_tail_buf[blockIdx.z * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+static void sa_tail_trace_hook(hipStream_t st, uint32_t ns) {
+  static int calls = 0;
+  static unsigned long long* buf = nullptr;
+  const char* env = getenv("SA_TAIL_TRACE");
+  if (!env) return;
+  ++calls;
+  const int at = atoi(env);
+  if (calls == at - 1) {
+    hipStreamSynchronize(st);
+    hipMalloc(&buf, 64 * 1024);
+    hipMemset(buf, 0, 64 * 1024);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tail_buf), &buf, sizeof buf);
+    hipDeviceSynchronize();
+  }
+  if (calls != at) return;
+  hipStreamSynchronize(st);
+  unsigned long long* nul = nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tail_buf), &nul, sizeof nul);
+  unsigned long long h[8 * 64];
+  hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen("gpurun_out/tail_trace.txt", "a")) {
+    for (uint32_t z = 0; z < ns && z < 64; ++z) {
+      const unsigned long long* t = h + z * 8;
+      fprintf(f, "scene %u: scan %llu pack+union %llu label %llu sort %llu link %llu solve %llu out %llu  total %llu\n", z, t[1] - t[0],
+              t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[7] - t[0]);
+    }
+    fclose(f);
+  }
+}
+#else
+#define TAIL_STAMP(k) do { } while (0)
+static inline void sa_tail_trace_hook(hipStream_t, uint32_t) {}
+#endif
+
+// One 1024-thread workgroup per scene: edge lists -> LDS, components, solve, results.  The solver's duals / matches / search
+// scratch live in LDS whenever the scene has at most 1024 tracks: every step of the shortest-path search is a chain of
+// dependent accesses, ~10x cheaper in LDS than in L2.  VISUAL = the engine has a visual vote whose verdicts (row_has,
+// vis_winner, col_excluded) must be honoured; plain SORT skips those loads altogether.
+// Timeline at C3 (500 x 500 IoU, -DSA_TAIL_TRACE) before / after this version: scan 2.9 k cycles | pack + unite 8.1 k -> edge
+// loads batched four at a time instead of one dependent round trip per edge | order rows inside components: 1024-key bitonic
+// sort 6.8 k + link 0.7 k -> each row pushes itself on its root's LDS list, the solver thread orders the (short) list |
+// solve 9.8 k | results 3.2 k.
+// Workgroup barrier for phases that hand over LDS data only: __syncthreads() carries a workgroup-scope release, which on gfx9
+// drains vmcnt as well (loads and stores share the counter) — every global load in flight would have to land before the
+// barrier.  Here the long-latency loads (edge lists and track ids written by other XCDs: a trip to memory) are meant to stay in
+// flight across the LDS phases, so only the LDS counter is drained.
+__device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool VISUAL>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
-  __shared__ uint32_t s_key[SA_SMALL_N];  // (label << 10 | row), rows without edges sort to the end
+  __shared__ uint32_t s_head[SA_SMALL_N];  // per component root: the rows of the component (pushed in any order)
   __shared__ uint32_t s_next[SA_SMALL_N];
   __shared__ int64_t s_u[SA_SMALL_N], s_rdist[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
   __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
@@ -328,11 +380,33 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ uint32_t s_ecol[POOL];
   __shared__ int64_t s_egain[POOL];
   const bool uf_in_lds = T <= SA_SMALL_N;
+  TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
+  const bool has_verdict = VISUAL && q < N && S.row_has[q];
+  // Plain SORT (with a visual vote most rows arrive decided and their lists are never read): the first four edges of the row
+  // are fetched before their count is known (what lies beyond the count is stale but
+  // addressable), so that this round trip — the lists were written by other XCDs a moment ago, it goes to memory — overlaps the
+  // count's.  What depends on them — the excluded-column flags and the track ids the results will need — is requested right after
+  // the scan; the ids are not awaited before the results are written (sa_lds_barrier).  Tracking frames rarely have more than
+  // four edges in a row.
+  uint32_t sj[4];
+  int64_t sg[4];
+  {
+    const SaEdge SA_G* row = S.e_edge + (size_t)(q < N ? q : 0) * S.estride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = !VISUAL && q < N && (uint32_t)k < S.estride;
+      const SaEdge ed = in ? sa_ldg(row + k) : SaEdge{0, 0u, 0u};
+      sj[k] = ed.col;
+      sg[k] = ed.gain;
+    }
+  }
   if (q < N) S.e_cnt[q] = 0;  // left clean for the next frame's positional tiles (nothing below reads the global counter)
-  const uint32_t mycnt = (q < N && !S.row_has[q]) ? rawcnt : 0u;
+  const uint32_t mycnt = (q < N && !has_verdict) ? rawcnt : 0u;
   s_rmatch[q] = -1;
   s_ecnt[q] = mycnt;
+  s_head[q] = SA_NONE;
+  s_next[q] = SA_NONE;
   if (uf_in_lds) { s_parent[q] = q; s_parent[q + SA_SMALL_N] = q + SA_SMALL_N; }
   // exclusive scan of mycnt over the 1024 threads: wave scan, then the 16 wave totals
   uint32_t incl = mycnt;
@@ -344,7 +418,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     }
     if (lane == WAVE - 1) s_wsum[q / WAVE] = incl;
   }
-  __syncthreads();
+  sa_lds_barrier();
   uint32_t woff = 0, total = 0;
   for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) {
     const uint32_t v = s_wsum[w2];
@@ -355,7 +429,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     if (q < N) {
       uint64_t id = 0;
       uint8_t vt = SA_VOTE_NONE;
-      int32_t vw = S.vis_winner[q];
+      int32_t vw = VISUAL ? S.vis_winner[q] : -1;
       if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
       S.out_track_id[q] = id;
       S.out_vote[q] = vt;
@@ -363,84 +437,104 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     }
     return;
   }
+  TAIL_STAMP(1);
+  if (VISUAL) {
+    const SaEdge SA_G* row = S.e_edge + (size_t)(q < N ? q : 0) * S.estride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const SaEdge ed = (uint32_t)k < mycnt ? sa_ldg(row + k) : SaEdge{0, 0u, 0u};
+      sj[k] = ed.col;
+      sg[k] = ed.gain;
+    }
+  }
+  bool sx[4];
+  uint64_t sid[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (uint32_t)k < mycnt;
+    sx[k] = VISUAL && in && S.col_excluded[sj[k]] != 0;
+    sid[k] = in ? S.t_ids[sj[k]] : 0ull;
+  }
   const bool pool = total <= POOL;
   const uint32_t myoff = woff + incl - mycnt;
   s_eoff[q] = myoff;
   int64_t maxg = 0;
   uint32_t usable = 0;
   if (mycnt) {
-    const uint32_t SA_G* cols = S.e_col + (size_t)q * S.estride;
-    const int64_t SA_G* gains = S.e_gain + (size_t)q * S.estride;
-    for (uint32_t e = 0; e < mycnt; ++e) {
-      const uint32_t j = cols[e];
-      const int64_t g = gains[e];
-      if (S.col_excluded[j]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71): dropped while packing
-      if (pool) { s_ecol[myoff + usable] = j; s_egain[myoff + usable] = g; }
-      ++usable;
-      maxg = g > maxg ? g : maxg;
-      if (uf_in_lds) sa_uf_union(s_parent, q, N + j);
-      else sa_uf_union((uint32_t*)S.parent, q, N + j);
+    const SaEdge SA_G* row = S.e_edge + (size_t)q * S.estride;
+    // four edges per step: all their loads (and, with a visual vote, the dependent excluded-column flags) are in flight together
+    for (uint32_t e0 = 0; e0 < mycnt; e0 += 4) {
+      uint32_t jj[4];
+      int64_t gg[4];
+      bool skip[4];
+      if (e0 == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { jj[k] = sj[k]; gg[k] = sg[k]; skip[k] = !((uint32_t)k < mycnt) || sx[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool in = e0 + k < mycnt;
+          const SaEdge ed = in ? sa_ldg(row + e0 + k) : SaEdge{0, 0u, 0u};
+          jj[k] = ed.col;
+          gg[k] = ed.gain;
+          skip[k] = !in;
+        }
+        if (VISUAL) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (!skip[k]) skip[k] = S.col_excluded[jj[k]] != 0;  // excluded_tracks (visual_sort/voting.rs:62-71): dropped while packing
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (skip[k]) continue;
+        const uint32_t j = jj[k];
+        if (pool) { s_ecol[myoff + usable] = j; s_egain[myoff + usable] = gg[k]; }
+        ++usable;
+        maxg = gg[k] > maxg ? gg[k] : maxg;
+        if (uf_in_lds) sa_uf_union(s_parent, q, N + j);
+        else sa_uf_union((uint32_t*)S.parent, q, N + j);
+      }
     }
     if (pool) s_ecnt[q] = usable;  // the packed list holds usable edges only (the HBM list keeps them all: solve skips there)
   }
-  __syncthreads();
+  if (uf_in_lds) sa_lds_barrier();
+  else __syncthreads();  // the forest is in HBM: its updates must be visible too
+  TAIL_STAMP(2);
+  // component label = root of the union-find tree = the lowest vertex = the component's first row; every row pushes itself
+  // onto that row's list (LDS atomics, any order)
   uint32_t lab = SA_NONE;
   if (usable) lab = uf_in_lds ? sa_uf_find(s_parent, q) : sa_uf_find((uint32_t*)S.parent, q);
   const bool cols_in_lds = T <= SA_SMALL_N;
-  s_key[q] = lab == SA_NONE ? 0xffffffffu : ((lab << 10) | q);
-  s_next[q] = SA_NONE;
   s_u[q] = -maxg;
   if (cols_in_lds) { s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0; }
-  __syncthreads();
-  // bitonic sort of 1024 keys (ascending): components become runs, rows ascending inside a run.  One key per thread, in a
-  // register; the network is fully unrolled so that every exchange distance is a constant:
-  //   distance 1, 2, 8  -> DPP (quad_perm / row_ror:8), a plain VALU move
-  //   distance 4, 16    -> ds_swizzle bit-mask mode (no address register)
-  //   distance 32       -> ds_bpermute
-  //   distance >= 64    -> through LDS, ping-pong halves of s_sort so that each of these 10 steps costs ONE barrier
-  // (55 LDS round trips with two barriers each were 7 us of this kernel at 500 x 500).
-  {
-    __shared__ uint32_t s_sort[2][SA_SMALL_N];
-    uint32_t key = s_key[q];
-    int pp = 0;
-#pragma unroll
-    for (uint32_t k = 2; k <= SA_SMALL_N; k <<= 1) {
-      const bool up = (q & k) == 0;
-#pragma unroll
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint32_t other;
-        if (j >= WAVE) {
-          s_sort[pp][q] = key;
-          __syncthreads();
-          other = s_sort[pp][q ^ j];
-          pp ^= 1;  // the next LDS step writes the other half: no thread can still be reading it (one barrier in between)
-        } else if (j == 1) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-        else if (j == 2) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
-        else if (j == 8) other = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0x128, 0xF, 0xF, true);      // row_ror:8
-        else if (j == 4) other = (uint32_t)__builtin_amdgcn_ds_swizzle((int)key, (4 << 10) | 0x1F);        // xor 4
-        else if (j == 16) other = (uint32_t)__builtin_amdgcn_ds_swizzle((int)key, (16 << 10) | 0x1F);      // xor 16
-        else other = __shfl_xor(key, (int)j);
-        const bool keep_min = ((q & j) == 0) == up;
-        const uint32_t lo = key < other ? key : other, hi = key < other ? other : key;
-        key = keep_min ? lo : hi;
+  if (lab != SA_NONE) s_next[q] = atomicExch(&s_head[lab], q);
+  if (uf_in_lds) sa_lds_barrier();
+  else {
+    // the forest in HBM is shared with the next frame: give it back clean (a stale tree would hand out labels that are not
+    // rows of this frame)
+    __syncthreads();
+    for (uint32_t i = q; i < N + T; i += SA_SMALL_N) S.parent[i] = i;
+  }
+  TAIL_STAMP(3);
+  TAIL_STAMP(4);
+  TAIL_STAMP(5);
+  // the first row of a component orders the component's rows (ascending: the canonical augmentation order — lists are a
+  // handful of rows in tracking frames) and solves it
+  if (lab == q) {
+    uint32_t sorted = SA_NONE;
+    for (uint32_t cur = s_head[q]; cur != SA_NONE;) {
+      const uint32_t nxt = s_next[cur];
+      if (sorted == SA_NONE || cur < sorted) { s_next[cur] = sorted; sorted = cur; }
+      else {
+        uint32_t pr = sorted;
+        for (uint32_t pn = s_next[pr]; pn != SA_NONE && pn < cur; pn = s_next[pr]) pr = pn;
+        s_next[cur] = s_next[pr];
+        s_next[pr] = cur;
       }
+      cur = nxt;
     }
-    __syncthreads();
-    s_key[q] = key;
-    __syncthreads();
-  }
-  {  // position q of the sorted array: link to the next row of the same component
-    uint32_t key = s_key[q];
-    if (key != 0xffffffffu && q + 1 < SA_SMALL_N) {
-      uint32_t k2 = s_key[q + 1];
-      if (k2 != 0xffffffffu && (k2 >> 10) == (key >> 10)) s_next[key & 1023u] = k2 & 1023u;
-    }
-  }
-  __syncthreads();
-  // the thread at the head of a run of the sorted keys solves that component, starting from its first (lowest) row
-  const uint32_t mykey = s_key[q];
-  if (mykey != 0xffffffffu && (q == 0 || (s_key[q - 1] >> 10) != (mykey >> 10))) {
-    const uint32_t first = mykey & 1023u;
+    const uint32_t first = sorted;
     // one call site per combination of address spaces (edge lists: LDS pool or HBM; column state: LDS or HBM), so that every
     // pointer of the work set has ONE known address space after inlining — "LDS or global, decided at run time" compiles
     // to flat_* accesses
@@ -448,8 +542,11 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       sa_assign_ws w;
       w.estride = S.estride;
       w.e_cnt = s_ecnt;
-      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.e_off = s_eoff; w.excluded = nullptr; }
-      else { w.e_col = (const uint32_t*)S.e_col; w.e_gain = (const int64_t*)S.e_gain; w.e_off = nullptr; w.excluded = (const uint8_t*)S.col_excluded; }
+      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.e_off = s_eoff; w.excluded = nullptr; }
+      else {
+        w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.e_off = nullptr;
+        w.excluded = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
+      }
       w.next_row = s_next;
       w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
       if constexpr (decltype(cols_tag)::value) {
@@ -465,21 +562,31 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     else if (cols_in_lds) solve(std::false_type{}, std::true_type{});
     else solve(std::false_type{}, std::false_type{});
   }
-  __syncthreads();
+  sa_lds_barrier();  // rmatch is in LDS in every variant
+  TAIL_STAMP(6);
   if (q < N) {
     uint64_t id = 0;
     uint8_t vt = SA_VOTE_NONE;
     int32_t win = -1;
-    int32_t vw = S.vis_winner[q];
+    const int32_t vw = VISUAL ? S.vis_winner[q] : -1;
     if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
-    else if (!S.row_has[q]) {
+    else if (!has_verdict) {
       int32_t c = s_rmatch[q];
-      if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; win = c; }
+      if (c >= 0) {
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((uint32_t)k < mycnt && sj[k] == (uint32_t)c) { id = sid[k]; found = true; }
+        if (!found) id = S.t_ids[c];
+        vt = SA_VOTE_POSITIONAL;
+        win = c;
+      }
     }
     S.out_track_id[q] = id;
     S.out_vote[q] = vt;
     S.win_col[q] = win;
   }
+  TAIL_STAMP(7);
 }
 
 // General tail, kernel 1 of 2: every participating row finds its component (root = minimum vertex, always a row) and
@@ -611,7 +718,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     case 3: SA_LAUNCH(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
-    default: SA_LAUNCH(k_assign_small, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); break;
+    default:
+      sa_tail_trace_hook(st, ns);
+      if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_small<true>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      else SA_LAUNCH(k_assign_small<false>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      break;
   }
   return hipGetLastError();
 }
