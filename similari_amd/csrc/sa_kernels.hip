@@ -291,20 +291,6 @@ __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   return w;
 }
 
-__device__ __forceinline__ void finalize_row(const SceneDev& S, uint32_t q) {
-  uint64_t id = 0;
-  uint8_t vt = SA_VOTE_NONE;
-  int32_t win = -1;
-  int32_t vw = S.vis_winner[q];
-  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
-  else if (!S.row_has[q]) {
-    int32_t c = S.rmatch[q];
-    if (c >= 0) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; win = c; }
-  }
-  S.out_track_id[q] = id;
-  S.out_vote[q] = vt;
-  S.win_col[q] = win;
-}
 
 // In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
 // thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
@@ -607,20 +593,111 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
 }
 
-// Kernel 2 of 2: thread `root` owns the component rooted at row `root`: sorts its row list ascending (insertion sort on the
-// links — components are a handful of rows in tracking workloads; the order only has to be deterministic), solves it, and
-// writes the results of all its rows.  Rows that take no part write their own result.
-__global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
+// Kernel 2 of 2: thread `root` owns the component rooted at row `root`: orders its rows ascending (components are a handful of
+// rows in tracking workloads; the order only has to be deterministic), solves it, and writes the results of all its rows.  Rows
+// that take no part write their own result.
+// The shortest-path search is a chain of dependent reads and writes of per-row / per-column state; in HBM every link of that
+// chain is an L2 (or, for what other XCDs just wrote, a memory) round trip — ~10 of them even for a one-row component, 14 us
+// at C4.  A component that fits a small private block of LDS (SL_R rows, SL_C distinct columns, SL_E usable edges) is therefore
+// gathered once — rows sorted, columns renumbered in ascending order so that every index comparison the solver makes keeps
+// its outcome — solved there by the same sa_assign_component, and scattered back; larger components use the HBM work set.
+#define SL_R 8
+#define SL_C 12
+#define SL_E 24
+struct SolveLocal {
+  int64_t u[SL_R], rdist[SL_R], v[SL_C], dist[SL_C], e_gain[SL_E];
+  uint32_t e_cnt[SL_R], e_off[SL_R], next_row[SL_R], rows[SL_R];
+  int32_t rmatch[SL_R], rnext[SL_R], cmatch[SL_C], pred[SL_C], cnext[SL_C];
+  uint32_t cstamp[SL_C], cscan[SL_C], colmap[SL_C], e_col[SL_E];
+};
+template <bool VISUAL>
+__device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q, int32_t c) {
+  uint64_t id = 0;
+  uint8_t vt = SA_VOTE_NONE;
+  int32_t win = -1;
+  const int32_t vw = VISUAL ? S.vis_winner[q] : -1;
+  if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
+  else if (c >= 0 && !(VISUAL && S.row_has[q])) { id = S.t_ids[c]; vt = SA_VOTE_POSITIONAL; win = c; }
+  S.out_track_id[q] = id;
+  S.out_vote[q] = vt;
+  S.win_col[q] = win;
+}
+template <bool VISUAL>
+__global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ SolveLocal s_local[64];
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
   for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * blockDim.x) S.parent[i] = i;
   if (q >= S.N) return;
-  if (!S.e_use[q] || S.row_has[q]) finalize_row(S, q);
-  uint32_t cur = S.label[q];
-  if (cur == SA_NONE) return;
+  const uint32_t head = S.label[q];
+  if (!S.e_use[q] || (VISUAL && S.row_has[q])) finalize_row_with<VISUAL>(S, q, -1);
+  if (head == SA_NONE) return;
+  SolveLocal& L = s_local[threadIdx.x];
+  // rows of the component, ascending
+  uint32_t R = 0;
+  for (uint32_t cur = head; cur != SA_NONE; cur = S.next_row[cur]) {
+    if (R < SL_R) {
+      uint32_t k = R;
+      while (k > 0 && L.rows[k - 1] > cur) { L.rows[k] = L.rows[k - 1]; --k; }
+      L.rows[k] = cur;
+    }
+    ++R;
+  }
+  bool fits = R <= SL_R;
+  uint32_t E = 0, C = 0;
+  if (fits) {
+    for (uint32_t r = 0; r < R && fits; ++r) {
+      const uint32_t row = L.rows[r];
+      const uint32_t cnt = S.e_use[row];
+      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+      L.e_off[r] = E;
+      uint32_t n = 0;
+      int64_t maxg = 0;
+      for (uint32_t e = 0; e < cnt; ++e) {
+        const SaEdge ed = sa_ldg(ep + e);
+        if (VISUAL && S.col_excluded[ed.col]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71)
+        uint32_t c = 0;
+        while (c < C && L.colmap[c] != ed.col) ++c;
+        if (E >= SL_E || (c == C && C >= SL_C)) { fits = false; break; }
+        if (c == C) L.colmap[C++] = ed.col;
+        L.e_col[E] = c;
+        L.e_gain[E] = ed.gain;
+        ++E; ++n;
+        maxg = ed.gain > maxg ? ed.gain : maxg;
+      }
+      L.e_cnt[r] = n;
+      L.u[r] = -maxg;
+      L.rmatch[r] = -1;
+      L.next_row[r] = r + 1 < R ? r + 1 : SA_NONE;
+    }
+  }
+  if (fits) {
+    // columns in ascending order of their track index: rank, permute, renumber the edges
+    for (uint32_t c = 0; c < C; ++c) {
+      uint32_t rank = 0;
+      for (uint32_t d = 0; d < C; ++d) rank += L.colmap[d] < L.colmap[c];
+      L.cnext[c] = (int32_t)rank;
+    }
+    for (uint32_t c = 0; c < C; ++c) L.pred[L.cnext[c]] = (int32_t)L.colmap[c];
+    for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
+    for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
+    sa_assign_ws w;
+    w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.estride = 0; w.e_off = L.e_off;
+    w.excluded = nullptr;
+    w.next_row = L.next_row;
+    w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;
+    w.cstamp = L.cstamp; w.cscan = L.cscan; w.cnext = L.cnext; w.rdist = L.rdist; w.rnext = L.rnext;
+    sa_assign_component(w, 0);
+    for (uint32_t r = 0; r < R; ++r) {
+      const int32_t c = L.rmatch[r];
+      finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
+    }
+    return;
+  }
+  // a large component: order the list on its links and solve on the work set in HBM
   uint32_t first = SA_NONE;
-  while (cur != SA_NONE) {
+  for (uint32_t cur = head; cur != SA_NONE;) {
     const uint32_t nxt = S.next_row[cur];
     if (first == SA_NONE || cur < first) {
       S.next_row[cur] = first;
@@ -634,8 +711,9 @@ __global__ void k_assign_solve(const SceneDev* __restrict__ scenes) {
     cur = nxt;
   }
   sa_assign_ws w = make_ws(S);
+  if (!VISUAL) w.excluded = nullptr;
   sa_assign_component(w, first);
-  for (uint32_t r = first; r != SA_NONE; r = S.next_row[r]) finalize_row(S, r);
+  for (uint32_t r = first; r != SA_NONE; r = S.next_row[r]) finalize_row_with<VISUAL>(S, r, S.rmatch[r]);
 }
 
 // =====================================================================================================
@@ -717,7 +795,10 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (!maxN) return hipSuccess;
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    case 3: SA_LAUNCH(k_assign_solve, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes); break;
+    case 3:
+      if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_solve<true>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
+      else SA_LAUNCH(k_assign_solve<false>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
+      break;
     default:
       sa_tail_trace_hook(st, ns);
       if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_small<true>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
