@@ -104,22 +104,36 @@ SA_HD double sa_clip_area_ws(const double* subj, const double* clip, double* ax,
     double csx = clip[2 * ii], csy = clip[2 * ii + 1];
     double cex = clip[2 * i], cey = clip[2 * i + 1];
     int m = 0;
+    // Two subject vertices per step.  Everything a vertex needs — its own coordinates and its predecessor's — comes from the
+    // input list of the pass, so the two chains of dependent f64 operations (side test, crossing point with its division) are
+    // independent and overlap; only the output position is carried.  is_inside(s_edge_start) is the previous vertex's
+    // is_inside(s_edge_end) — the same expression on the same values — and is carried instead of recomputed.
     double ssx = n ? px[(n - 1) * stride] : 0.0, ssy = n ? py[(n - 1) * stride] : 0.0;  // s_edge_start of j = 0
-    for (int j = 0; j < n; ++j) {
-      double sex = px[j * stride], sey = py[j * stride];
-      bool in_e = ((cex - csx) * (sey - csy) - (cey - csy) * (sex - csx)) <= 0.0;
-      bool in_s = ((cex - csx) * (ssy - csy) - (cey - csy) * (ssx - csx)) <= 0.0;
-      if (in_e != in_s) {
-        // compute_intersection(cp1 = s_edge_start, cp2 = s_edge_end, s = c_edge_start, e = c_edge_end)
-        double dcx = ssx - sex, dcy = ssy - sey;
-        double dpx = csx - cex, dpy = csy - cey;
-        double n1 = ssx * sey - ssy * sex;
-        double n2 = csx * cey - csy * cex;
-        double n3 = 1.0 / (dcx * dpy - dcy * dpx);
-        if (m < SA_POLY_CAP) { qx[m * stride] = (n1 * dpx - n2 * dcx) * n3; qy[m * stride] = (n1 * dpy - n2 * dcy) * n3; ++m; }
+    bool in_s = ((cex - csx) * (ssy - csy) - (cey - csy) * (ssx - csx)) <= 0.0;
+    const double dpx = csx - cex, dpy = csy - cey;
+    const double n2 = csx * cey - csy * cex;
+    for (int j = 0; j < n; j += 2) {
+      const bool has_b = j + 1 < n;
+      const double ax_ = px[j * stride], ay_ = py[j * stride];
+      const double bx_ = has_b ? px[(j + 1) * stride] : ax_, by_ = has_b ? py[(j + 1) * stride] : ay_;
+      const bool in_a = ((cex - csx) * (ay_ - csy) - (cey - csy) * (ax_ - csx)) <= 0.0;
+      const bool in_b = ((cex - csx) * (by_ - csy) - (cey - csy) * (bx_ - csx)) <= 0.0;
+      // compute_intersection(cp1 = s_edge_start, cp2 = s_edge_end, s = c_edge_start, e = c_edge_end)  clipping.rs:17-38
+      const double dcxa = ssx - ax_, dcya = ssy - ay_;
+      const double n1a = ssx * ay_ - ssy * ax_;
+      const double n3a = 1.0 / (dcxa * dpy - dcya * dpx);
+      const double dcxb = ax_ - bx_, dcyb = ay_ - by_;
+      const double n1b = ax_ * by_ - ay_ * bx_;
+      const double n3b = 1.0 / (dcxb * dpy - dcyb * dpx);
+      if (in_a != in_s && m < SA_POLY_CAP) { qx[m * stride] = (n1a * dpx - n2 * dcxa) * n3a; qy[m * stride] = (n1a * dpy - n2 * dcya) * n3a; ++m; }
+      if (in_a && m < SA_POLY_CAP) { qx[m * stride] = ax_; qy[m * stride] = ay_; ++m; }
+      if (has_b) {
+        if (in_b != in_a && m < SA_POLY_CAP) { qx[m * stride] = (n1b * dpx - n2 * dcxb) * n3b; qy[m * stride] = (n1b * dpy - n2 * dcyb) * n3b; ++m; }
+        if (in_b && m < SA_POLY_CAP) { qx[m * stride] = bx_; qy[m * stride] = by_; ++m; }
+        ssx = bx_; ssy = by_; in_s = in_b;
+      } else {
+        ssx = ax_; ssy = ay_; in_s = in_a;
       }
-      if (in_e && m < SA_POLY_CAP) { qx[m * stride] = sex; qy[m * stride] = sey; ++m; }
-      ssx = sex; ssy = sey;
     }
     double* t = px; px = qx; qx = t;
     t = py; py = qy; qy = t;
