@@ -57,6 +57,16 @@ def workload(name: str, seed: int):
         scs = [synth.sort_scene(rng, 500, 500, canvas=(4096.0, 4096.0)) for _ in range(8)]
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
         return cfg, scs, "BatchSORT IoU, 8 scenes x 500 x 500 per GPU (BASELINE C3: 64 scenes over 8 GPUs)"
+    if name == "c1":
+        sc = synth.sort_scene(rng, 100, 100, canvas=(1920.0, 1080.0))
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU 100 x 100, dense variant (BASELINE C1)"
+    if name == "sd":
+        # not a BASELINE config: a crowd for plain SORT (the C2 frame without features) — the positional vote alone has to untangle
+        # the overlaps, so its graph has large connected components
+        sc = synth.sort_scene(rng, 1000, 1000, canvas=(1920.0, 1080.0))
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU 1000 x 1000 on the C2 canvas (crowd: large components in the positional vote)"
     if name == "c3m":
         # BASELINE C3's Mahalanobis half: the Kalman states come from the product's own device-side upkeep (three frames through
         # the BatchSort facade), see maha_engine() below — no synthetic scene dict

@@ -134,6 +134,9 @@ int dev_ensure(sa_engine* e, DevBuf& b, size_t bytes, bool keep = false) {
   if (bytes <= b.cap && b.p) return SA_OK;
   size_t ncap = bytes < 256 ? 256 : bytes;
   if (keep && b.cap) ncap = ncap < b.cap * 2 ? b.cap * 2 : ncap;
+  // a buffer that grows once usually grows again (a track table gains a few rows every frame): a quarter of slack on regrowth,
+  // or every frame would pay a dozen hipMalloc / hipFree pairs (~0.3 ms at 1000 tracks)
+  else if (b.cap) ncap += ncap / 4;
   void* np = nullptr;
   hipError_t s = hipMalloc(&np, ncap);
   if (s != hipSuccess) return fail(e, SA_ERR_OOM, "hipMalloc(%zu) failed: %s", ncap, hipGetErrorString(s));
@@ -823,6 +826,14 @@ int sa_batch_begin(sa_engine* e) {
 }
 
 int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, uint32_t* out_slot) {
+  return sa_batch_add_rows(e, scene_id, epoch, d, nullptr, out_slot);
+}
+
+// sa_batch_add with the feature rows given one pointer per detection (nullptr = no feature) instead of one N x D block: the
+// tracker facade receives its observations that way (VisualSortObservation.feature) and would otherwise assemble the block only
+// for it to be copied again into the pinned staging buffer — 2 MB twice per frame at C2.  Not part of the C ABI.
+int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
+                      uint32_t* out_slot) {
   if (!e || !d) return fail(e, SA_ERR_BAD_ARG, "sa_batch_add: null argument");
   const uint32_t N = d->n;
   if (N && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
@@ -837,7 +848,7 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
   s->N = N;
   s->T = sc->T;
   s->ran = false;
-  s->has_feats = e->visual && d->feats != nullptr;
+  s->has_feats = e->visual && (d->feats != nullptr || feat_rows != nullptr);
   s->has_quality = d->feat_quality != nullptr;
   s->has_own = d->own_area != nullptr;
   s->has_fpresent = d->feat_present != nullptr;
@@ -865,7 +876,13 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
       HIPCHK(e, hipMemcpyAsync(s->fpresent_in.p, h + o_fp, N, hipMemcpyHostToDevice, st));
     }
     if (s->has_feats) {
-      std::memcpy(h + o_feat, d->feats, (size_t)N * D * 4);
+      if (feat_rows) {
+        for (uint32_t i = 0; i < N; ++i) {
+          float* dst = (float*)(h + o_feat) + (size_t)i * D;
+          if (feat_rows[i]) std::memcpy(dst, feat_rows[i], (size_t)D * 4);
+          else std::memset(dst, 0, (size_t)D * 4);
+        }
+      } else std::memcpy(h + o_feat, d->feats, (size_t)N * D * 4);
       HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, h + o_feat, (size_t)N * D * 4, hipMemcpyHostToDevice, st));
     }
     e->synced = false;

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -22,6 +23,10 @@
 
 #include "../../include/similari_tracker.h"
 #include "sa_kalman.h"
+
+// engine-internal entry point (sa_engine.hip): detections with one feature pointer per row
+extern "C" int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
+                                 uint32_t* out_slot);
 
 namespace {
 
@@ -193,6 +198,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     for (uint32_t s2 = 0; s2 < s; ++s2)
       if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
   // auto waste (simple_api.rs:115-120)
+  const auto t_entry = std::chrono::steady_clock::now();
   if (t->waste_counter == 0) {
     int rc = auto_waste(t);
     if (rc != SA_OK) return rc;
@@ -204,7 +210,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   std::vector<sa_scene_request> req(n_scenes);
   std::vector<sa_scene_result> res(n_scenes);
   std::vector<std::vector<sa_box>> cboxes(n_scenes);
-  std::vector<std::vector<float>> cfeat(n_scenes), cq(n_scenes), cown(n_scenes);
+  std::vector<std::vector<float>> cq(n_scenes), cown(n_scenes);
+  std::vector<std::vector<const float*>> cfeat(n_scenes);   // one pointer per detection: the engine gathers the rows itself
   std::vector<std::vector<uint8_t>> cpres(n_scenes), votes(n_scenes);
   std::vector<std::vector<uint64_t>> winners(n_scenes);
   for (uint32_t s = 0; s < n_scenes; ++s) {
@@ -213,7 +220,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     auto& cs = cands[s];
     cs.resize(n);
     cboxes[s].resize(n);
-    if (o.visual) { cfeat[s].assign((size_t)n * D, 0.0f); cq[s].resize(n); cown[s].resize(n); cpres[s].resize(n); }
+    if (o.visual) { cfeat[s].assign(n, nullptr); cq[s].resize(n); cown[s].resize(n); cpres[s].resize(n); }
     for (uint32_t i = 0; i < n; ++i) {
       const sa_box& bb = obs[s][i].bbox;
       if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f))
@@ -259,7 +266,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         cq[s][i] = c.obs.quality;
         cown[s][i] = c.obs.has_own ? c.obs.own : NAN;
         cpres[s][i] = c.obs.has_feat ? 1 : 0;
-        if (c.obs.has_feat) std::memcpy(&cfeat[s][(size_t)i * D], ob.feature, (size_t)D * 4);
+        if (c.obs.has_feat) cfeat[s][i] = ob.feature;
       }
     }
     winners[s].assign(n, 0);
@@ -271,7 +278,6 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     r.detections.n = n;
     r.detections.boxes = cboxes[s].data();
     if (o.visual) {
-      r.detections.feats = cfeat[s].data();
       r.detections.feat_present = cpres[s].data();
       r.detections.feat_quality = cq[s].data();
       r.detections.own_area = cown[s].data();
@@ -279,9 +285,21 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     res[s].out_track_id = winners[s].data();
     res[s].out_voting_type = votes[s].data();
   }
+  // SA_TRACKER_TRACE=1: where a predict() spends its time (request assembly | association on the GPU | device upkeep |
+  // host bookkeeping), in microseconds on stderr
+  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
+  using clk = std::chrono::steady_clock;
+  const auto t_built = clk::now();
+  double us_apply = 0.0;
   // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
-  int rc = sa_associate_batch(t->eng, n_scenes, req.data(), res.data());
-  if (rc != SA_OK) return tfail(t, rc, "sa_associate_batch: %s", sa_last_error(t->eng));
+  int rc = sa_batch_begin(t->eng);
+  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
+    rc = sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? cfeat[s].data() : nullptr, nullptr);
+  if (rc == SA_OK) rc = sa_batch_run(t->eng);
+  if (rc == SA_OK) rc = sa_batch_sync(t->eng);
+  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) rc = sa_batch_fetch(t->eng, s, res[s].out_track_id, res[s].out_voting_type);
+  if (rc != SA_OK) return tfail(t, rc, "association: %s", sa_last_error(t->eng));
+  const auto t_assoc = clk::now();
 
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint64_t scene = scene_ids[s];
@@ -299,8 +317,10 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     if (o.device_upkeep) {
       // Kalman step, table refresh and feature-bank policy on the GPU: nothing but the predicted boxes comes back
       dev_pred.resize(counts[s]);
+      const auto ta = clk::now();
       rc = sa_tracks_apply(t->eng, s, new_ids.data(), dev_pred.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
+      us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
     }
     for (uint32_t i = 0; i < counts[s]; ++i) {
       Cand& c = cands[s][i];
@@ -358,6 +378,12 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     if (o.device_upkeep) continue;
     rc = sync_engine(t, scene, touched);
     if (rc != SA_OK) return rc;
+  }
+  if (trace) {
+    const auto t_end = clk::now();
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[sa_tracker] assemble %.1f  associate %.1f  apply %.1f  bookkeeping %.1f us\n", us(t_entry, t_built),
+            us(t_built, t_assoc), us_apply, us(t_assoc, t_end) - us_apply);
   }
   return SA_OK;
 }
