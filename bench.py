@@ -231,8 +231,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SA_BENCH_ONE_DEVICE"):
+            # rehearsal of the multi-rank control flow on a one-GPU box: every rank drives device 0, collectives over gloo
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -270,10 +276,11 @@ def main():
     barrier()  # barrier + synchronize on both sides of the timed region: every rank's dt covers the slowest rank
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ct = torch.tensor([float(cells)], dtype=torch.float64, device="cuda")
+        ct = torch.tensor([float(cells)], dtype=torch.float64, device=cdev)
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         total_cells = float(ct.item())
     else:
