@@ -563,3 +563,73 @@ def test_full_size_sort_oriented_c4_properties():
         assert ((q == 0) | (q >= 300_000)).all()
     finally:
         eng.close()
+
+
+# ---- randomized sweep over the configuration space --------------------------------------------------------------------
+def _fuzz_case(seed):
+    """One random (config, scene): sizes around the tile edges (16, 64, 128, 256), every metric pair, ragged banks, missing
+    features, qualities, own areas, idle epochs and spatio-temporal constraints."""
+    rng = np.random.default_rng(90000 + seed)
+    n = int(rng.choice([0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 200, 257]))
+    t = int(rng.choice([0, 1, 3, 16, 63, 64, 65, 128, 130, 255, 256, 260, 300]))
+    oriented = bool(rng.integers(2))
+    canvas = (float(rng.uniform(300, 2500)), float(rng.uniform(300, 1500)))
+    visual = [None, "cosine", "euclidean"][int(rng.integers(3))]
+    positional = ["iou", "maha"][int(rng.integers(2))]
+    cons = ()
+    if rng.uniform() < 0.5:
+        cons = tuple(sorted((int(e), float(rng.uniform(0.3, 3.0))) for e in rng.choice(np.arange(1, 6), size=int(rng.integers(1, 3)), replace=False)))
+    common = dict(positional=positional, positional_threshold=float(rng.choice([0.1, 0.3, 0.5])), max_idle_epochs=int(rng.integers(1, 6)),
+                  positional_min_confidence=float(rng.choice([0.05, 0.1, 0.4])), constraints=cons, flags=int(rng.choice([0, abi.SA_FLAG_FUSED_FRAME])))
+    if visual is None:
+        sc = synth.sort_scene(rng, t, n, canvas=canvas, oriented=oriented)
+        cfg = abi.make_config(**common)
+    else:
+        # (d = 1 is left out: every cosine is exactly +-1 there, the BestFit vote is one big tie and the 1e-5 freedom of the
+        # feature distances decides the winners)
+        d = int(rng.choice([5, 7, 8, 31, 32, 33, 64, 100, 128, 200]))
+        k = int(rng.integers(1, 5))
+        sc = synth.visual_scene(rng, max(t, 1), max(n, 1), d, k, canvas=canvas, oriented=oriented, new_fraction=float(rng.uniform(0, 0.3)))
+        for key in ("track_ids", "track_boxes", "track_epochs", "track_feats", "track_present"):
+            sc[key] = sc[key][:t]
+        for key in ("det_boxes", "det_feats", "det_quality", "truth"):
+            sc[key] = sc[key][:n]
+        pres = sc["track_present"]
+        pres[rng.uniform(size=pres.shape) < 0.2] = 0
+        cfg = abi.make_config(visual=visual, visual_threshold=float(rng.choice([0.2, 0.5])) if visual == "cosine" else float(rng.choice([0.3, 0.8, 3.0e38])),
+                              feature_len=d, max_observations=k, visual_min_votes=int(rng.integers(1, k + 1)),
+                              visual_minimal_track_length=int(rng.integers(1, k + 1)), visual_minimal_area=float(rng.choice([0.0, 3000.0])),
+                              visual_minimal_quality_use=float(rng.choice([0.0, 0.5])),
+                              visual_minimal_own_area_percentage_use=float(rng.choice([0.0, 0.4])), **common)
+    # epochs spread around the current one so that max_idle_epochs and the constraints' epoch deltas bite
+    epoch = 7
+    if t:
+        sc["track_epochs"] = rng.integers(1, 8, size=t).astype(np.uint64)
+    return rng, cfg, sc, epoch, positional, visual
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SA_FUZZ_N", "40"))))
+def test_random_configurations(seed):
+    rng, cfg, sc, epoch, positional, visual = _fuzz_case(seed)
+    n, t = len(sc["det_boxes"]), len(sc["track_boxes"])
+    kf = kf_states(rng, sc["track_boxes"]) if (positional == "maha" and t) else None
+    if positional == "maha" and not t:
+        kf = (sc["track_boxes"], np.zeros((0, 5), np.float32), np.zeros((0, 25), np.float32))
+    if visual is None:
+        # Mahalanobis cells are often exactly tied at cost 0 (d2 above the chi-square bound): ids only on IoU
+        check_sort(cfg, sc, epoch=epoch, kf=kf, require_ids=positional == "iou")
+    else:
+        own = rng.uniform(0, 1, n).astype(np.float32) if rng.uniform() < 0.5 else None
+        if own is not None:
+            own[rng.uniform(size=n) < 0.2] = np.nan
+        dp = (rng.uniform(size=n) > 0.15).astype(np.uint8) if rng.uniform() < 0.5 else None
+        tol_rel = 1e-5 if visual == "euclidean" else 0.0
+        if positional == "maha":
+            ids, votes, pos, vis, ref = visual_run(cfg, sc, epoch=epoch, kf=kf, own_area=own, det_present=dp)
+            np.testing.assert_array_equal(np.isnan(pos), np.isnan(ref["positional"]))
+            np.testing.assert_array_equal(pos.view(np.uint32)[~np.isnan(pos)], ref["positional"].view(np.uint32)[~np.isnan(pos)])
+            both = ~np.isnan(vis) & ~np.isnan(ref["visual"])
+            assert (np.abs(vis[both] - ref["visual"][both]) <= 1e-5 + tol_rel * np.abs(ref["visual"][both])).all()
+            np.testing.assert_array_equal(votes == abi.SA_VOTE_VISUAL, ref["voting_type"] == abi.SA_VOTE_VISUAL)
+        else:
+            check_visual(cfg, sc, tol_abs=1e-5 if visual == "cosine" else 0.0, tol_rel=tol_rel, epoch=epoch, kf=kf, own_area=own, det_present=dp)
