@@ -87,6 +87,8 @@ struct sa_engine {
   bool descs_changed = true;
   uint32_t K = 1, D = 0, Dp = 0;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
+  bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
+                                        // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
@@ -340,6 +342,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
              (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
+  if (e->bf_partials) { d->CT = (s->T + e->tile_bn - 1) / e->tile_bn; d->RT = (s->N + e->tile_bm - 1) / e->tile_bm; }  // the contraction's own tile grid
   d->nkeys = e->visual ? ((s->N + e->tile_bm - 1) / e->tile_bm) * ((s->T * e->K + e->tile_bn - 1) / e->tile_bn) : 0;
   d->epoch = s->epoch;
   d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
@@ -396,16 +399,16 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
     ProfScope ps(e, KID_FRAME_VISUAL);
     bool all_feats = true;
     for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && e->slots[i]->has_feats;
-    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, e->P, st) : hipErrorNotSupported;
+    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, e->P, st, e->bf_partials) : hipErrorNotSupported;
     if (fe == hipSuccess) fused = true;
     else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
     else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   if (e->visual) {
-    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st)); }
-    { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
-    { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 1)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st, e->bf_partials)); }
+    if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
+    { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, e->bf_partials ? 2 : 1)); }
   }
   // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle)
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
@@ -550,6 +553,11 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   e->cfg.constraint_max_dist = e->cons_dist.data();
   e->visual = cfg->visual_kind != SA_VIS_NONE;
   e->K = e->visual ? cfg->max_observations : 1;
+  {
+    // SA_BESTFIT=tile keeps the two-kernel BestFit (weight matrix + k_bestfit_tile) for A/B runs and for the tests of that path
+    const char* bf = getenv("SA_BESTFIT");
+    e->bf_partials = cfg->visual_kind == SA_VIS_COSINE && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
+  }
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
   e->profile = (cfg->flags & SA_FLAG_PROFILE) != 0;
@@ -1192,7 +1200,19 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
   if (!e->visual) return fail(e, SA_ERR_UNSUPPORTED, "engine has no visual part");
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
   size_t bytes = (size_t)s->N * s->T * e->K * 4;
-  if (bytes) HIPCHK(e, hipMemcpy(out, s->vis.p, bytes, hipMemcpyDeviceToHost));
+  if (!bytes) return SA_OK;
+  if (e->bf_partials) {
+    // the product path never wrote the weight matrix: run the contraction once more, in matrix mode, on the slot's resident inputs
+    SceneDev h;
+    fill_scene_dev(e, s, &h);
+    DevBuf tmp;
+    TRY(dev_ensure(e, tmp, sizeof h));
+    HIPCHK(e, hipMemcpy(tmp.p, &h, sizeof h, hipMemcpyHostToDevice));
+    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, e->P, e->stream, false));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    hipFree(tmp.p);
+  }
+  HIPCHK(e, hipMemcpy(out, s->vis.p, bytes, hipMemcpyDeviceToHost));
   return SA_OK;
 }
 int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {

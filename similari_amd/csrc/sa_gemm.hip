@@ -426,6 +426,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   v = mx(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F));    // xor 16
   return mx((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
 }
+// minimum over each 16-lane row of the wave, left in every lane of the row: quad exchanges, then two rotations — DPP only, no
+// trip through the LDS crossbar
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
+  auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: the quad's minimum
+  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true));   // row_ror:4: two quads
+  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true));   // row_ror:8: the row
+  return v;
+}
 __device__ __forceinline__ void block_max_key(uint32_t SA_G* slots, uint32_t slot, uint32_t kmax) {
   __shared__ uint32_t s_wmax[16];
   const uint32_t m = wave_max_u32(kmax);
@@ -463,7 +473,16 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // blocks run BESIDE this tile, not before it, so nothing they produce may be read — the candidate features come straight
 // from the uploaded rows (their length is a multiple of 32: no padding needed), their squared norms are accumulated from
 // the A fragments inside the main loop, and the row's geometry / feature_can_be_used gate are derived from the raw box.
-template <int BM, int BN, int KGT, bool RAW>
+//
+// PART (bank depth 1 only): instead of the N x T weight matrix the tile emits what k_bestfit_tile would derive from it — per row
+// the lightest weight over the tile's columns (lowest column on ties), per column the lightest over its rows (lowest row) — as
+// the BestFit partials k_bestfit_resolve folds.  BestFit ranks groups by W = sum_k f64(max_dist - w_k); with one observation per
+// track that is decreasing in w, so the heaviest group of a row or column inside a tile is its lightest weight and max_dist
+// (known only when every tile is done) is not needed here: the resolve kernel applies it to the handful of partials.  Where two
+// DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
+// differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
+// (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
+template <int BM, int BN, int KGT, bool RAW, bool PART>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
   constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
@@ -547,10 +566,15 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
   float* s_np = lds + 6 * BM;             // [KG][BM] raw mode: squared-norm partials of the k-groups
+  unsigned long long* s_rk = (unsigned long long*)(lds + 6 * BM + KG * BM + (((6 + KG) * BM) & 1));  // [BM] (weight key << 32) | column
+  unsigned long long* s_ck = s_rk + BM;                                                               // [BN] (weight key << 32) | row
   if (tid < (uint32_t)BM) {
     s_na[tid] = pre_na;
     s_us[tid] = pre_us;
     s_g[tid] = pre_g;
+  }
+  if constexpr (PART) {
+    for (uint32_t i = tid; i < (uint32_t)(BM + BN); i += blockDim.x) s_rk[i] = ~0ull;
   }
   if constexpr (RAW) {
     // the two halves of a row's k values sit in lanes lr and lr + 32; the waves wn = 0 / 1 of a group hold the same rows
@@ -569,44 +593,124 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     __syncthreads();
   }
   uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
+  // PART: a row's lightest weight over 16 of this wave's columns = the minimum of the order-preserving keys over a 16-lane row
+  // (DPP), the lowest lane that holds it = the lowest column; the rows and waves side by side meet in LDS (64-bit minimum of
+  // key << 32 | index).
+  auto row_candidate = [&](uint32_t key, uint32_t li, uint32_t col0) {
+    const uint32_t m = row_min_u32(key);
+    const unsigned long long ball = __ballot(key == m && m != 0xffffffffu);
+    const uint32_t rm = (uint32_t)(ball >> (lane & 48u)) & 0xffffu;   // this 16-lane row's lanes that hold the minimum
+    if ((lane & 15u) == 0 && rm) atomicMin(&s_rk[li], ((unsigned long long)m << 32) | (col0 + (lr & 16u) + (uint32_t)__builtin_ctz(rm)));
+  };
+  // (PART: all weights of a lane first, the cross-lane reductions afterwards — ballots and DPP moves are convergent operations the
+  // scheduler will not move loads across, and the per-row operands come from LDS: interleaved, every cell paid its LDS latency.)
   if constexpr (TM == 1 && TN == 1) {
-    const uint32_t gj = n0 + wn * 32 + lr;
+    const uint32_t lc = wn * 32 + lr, gj = n0 + lc;
+    float wv[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const uint32_t li = wm * 32 + acc_row(kg * R + i, lh);
       const uint32_t gi = m0 + li;
-      if (gi < N && gj < TK)
-        S.vis[(size_t)gi * TK + gj] = visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax);
+      const bool in = gi < N && gj < TK;
+      if constexpr (PART) wv[i] = in ? visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax) : __builtin_nanf("");
+      else if (in) S.vis[(size_t)gi * TK + gj] = visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax);
+    }
+    if constexpr (PART) {
+      unsigned long long cb = ~0ull;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const uint32_t li = wm * 32 + acc_row(kg * R + i, lh);
+        const float w = wv[i];
+        const uint32_t key = w == w ? sa_f32_key(w) : 0xffffffffu;
+        row_candidate(key, li, n0 + wn * 32);
+        const unsigned long long cand = ((unsigned long long)key << 32) | (m0 + li);
+        if (w == w && cand < cb) cb = cand;
+      }
+      const unsigned long long ob = __shfl_xor(cb, 32);
+      cb = ob < cb ? ob : cb;
+      if (lh == 0 && cb != ~0ull) atomicMin(&s_ck[lc], cb);
     }
   } else {
+    unsigned long long cb[TN];
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
+    for (int n = 0; n < TN; ++n) cb[n] = ~0ull;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float wv[16][TN];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t li = wm * (BM / 2) + m * 32 + acc_row(r, lh);
         const uint32_t gi = m0 + li;
-        if (gi >= N) continue;
+        if constexpr (!PART) {
+          if (gi >= N) continue;
+        }
         const float na = s_na[li];
         const bool us = s_us[li] != 0.f;
         const sa_geo cg = s_g[li];
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           const uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
-          if (gj < TK) S.vis[(size_t)gi * TK + gj] = visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax);
+          if constexpr (PART) wv[r][n] = (gi < N && gj < TK) ? visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax) : __builtin_nanf("");
+          else if (gj < TK) S.vis[(size_t)gi * TK + gj] = visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax);
         }
       }
+      if constexpr (PART) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t li = wm * (BM / 2) + m * 32 + acc_row(r, lh);
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            const float w = wv[r][n];
+            const uint32_t key = w == w ? sa_f32_key(w) : 0xffffffffu;
+            row_candidate(key, li, n0 + wn * (BN / 2) + n * 32);
+            const unsigned long long cand = ((unsigned long long)key << 32) | (m0 + li);
+            if (w == w && cand < cb[n]) cb[n] = cand;
+          }
+        }
+      }
+    }
+    if constexpr (PART) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const unsigned long long ob = __shfl_xor(cb[n], 32);
+        const unsigned long long b2 = ob < cb[n] ? ob : cb[n];
+        if (lh == 0 && b2 != ~0ull) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
+      }
+    }
+  }
+  if constexpr (PART) {
+    // the partials of this tile, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles)
+    SA_STAMP(tr, 6);
+    __syncthreads();
+    SA_STAMP(tr, 7);
+    for (uint32_t i = tid; i < (uint32_t)BM; i += blockDim.x) {
+      const uint32_t gi = m0 + i;
+      if (gi >= N) continue;
+      const unsigned long long k2 = s_rk[i];
+      const bool has = k2 != ~0ull;
+      S.row_part_w[(size_t)gi * S.CT + bx] = has ? (double)sa_key_f32((uint32_t)(k2 >> 32)) : -1.0;
+      S.row_part_t[(size_t)gi * S.CT + bx] = has ? (int32_t)(uint32_t)k2 : -1;
+    }
+    for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) {
+      const uint32_t gj = n0 + i;
+      if (gj >= TK) continue;
+      const unsigned long long k2 = s_ck[i];
+      const bool has = k2 != ~0ull;
+      S.col_part_w[(size_t)by * TK + gj] = has ? (double)sa_key_f32((uint32_t)(k2 >> 32)) : -1.0;
+      S.col_part_q[(size_t)by * TK + gj] = has ? (uint32_t)k2 : SA_NONE;
+    }
   }
   SA_STAMP(tr, 4);
   block_max_key(S.vis_max_key, key_slot, kmax);
   SA_STAMP(tr, 5);
 }
 
-template <int BM, int BN, int KGT>
+template <int BM, int BN, int KGT, bool PART = false>
 __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  visual_cosine_tile<BM, BN, KGT, false>(S, p, blockIdx.x, blockIdx.y, lds);
+  visual_cosine_tile<BM, BN, KGT, false, PART>(S, p, blockIdx.x, blockIdx.y, lds);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -617,7 +721,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
-template <int KG>
+template <int KG, bool PART>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py) {
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
@@ -628,7 +732,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6.
   uint32_t b = blockIdx.x;
   if (b < gx * gy) {
-    visual_cosine_tile<64, 64, KG, true>(S, p, b % gx, b / gx, lds);
+    visual_cosine_tile<64, 64, KG, true, PART>(S, p, b % gx, b / gx, lds);
     return;
   }
   b -= gx * gy;
@@ -841,9 +945,9 @@ static void sa_trace_hook(hipStream_t st, uint32_t nb) {
   if (FILE* f = fopen("gpurun_out/gemm_trace.txt", "w")) {
     for (uint32_t i = 0; i < nb; ++i)
       if (h[i * 8])
-        fprintf(f, "%u %llu %llu %llu %llu %llu %llu\n", i, (unsigned long long)h[i * 8], (unsigned long long)h[i * 8 + 1],
+        fprintf(f, "%u %llu %llu %llu %llu %llu %llu %llu %llu\n", i, (unsigned long long)h[i * 8], (unsigned long long)h[i * 8 + 1],
                 (unsigned long long)h[i * 8 + 2], (unsigned long long)h[i * 8 + 3], (unsigned long long)h[i * 8 + 4],
-                (unsigned long long)h[i * 8 + 5]);
+                (unsigned long long)h[i * 8 + 5], (unsigned long long)h[i * 8 + 6], (unsigned long long)h[i * 8 + 7]);
     fclose(f);
   }
   free(h);
@@ -898,7 +1002,7 @@ void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns,
 // one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
 // it does not apply: the caller falls back to k_frame + k_visual_cost.
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st) {
+                                  const SaParams& p, hipStream_t st, bool partials) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
   if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
@@ -912,17 +1016,33 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (14.5 vs 16 us) but every block of the launch then owns 512 threads and 73 KB: two blocks per
   // CU, and the 1250 positional / preparation blocks queue behind each other (29 us for the launch against 22.6).
-  SA_LAUNCH((k_frame_visual<1>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+  if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
   return hipGetLastError();
 }
 
+// partials = the contraction emits the BestFit partials itself (bank depth 1, cosine: visual_cosine_tile PART) instead of the
+// weight matrix.  The experimental plans (4: four k-groups, 7 / 8: ring main loop) exist in matrix mode only; with partials they
+// run as the product plan of the same tile size.
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
-                            hipStream_t st) {
+                            hipStream_t st, bool partials) {
   if (!maxN || !maxTK) return hipSuccess;
   sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
-    switch (tile_plan(maxN, maxTK, ns, Dp)) {
+    int plan = tile_plan(maxN, maxTK, ns, Dp);
+    if (partials) {
+      plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
+      switch (plan) {
+        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
+        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      }
+      return hipGetLastError();
+    }
+    switch (plan) {
       case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
       case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
       case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;

@@ -228,17 +228,36 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
 }
 
 // One wave per candidate: lanes fold the CT row partials, then the RT column partials of the winning column.
+// RAW_W: the partials come from the contraction's own epilogue (visual_cosine_tile PART, bank depth 1) and hold the lightest
+// WEIGHT of a row / column inside a tile; the group weight the vote compares is W = 0.0 + f64(max_dist - w), formed here once
+// max_dist — the largest present weight of the frame, the per-tile slots folded — is known.
+template <bool RAW_W>
 __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
+  float max_dist = 0.0f;
+  if (RAW_W) {
+    uint32_t mk = 0;
+    for (uint32_t i = lane; i < S.nkeys; i += WAVE) {
+      const uint32_t v = S.vis_max_key[i];
+      mk = v > mk ? v : mk;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t ok = __shfl_xor(mk, o);
+      mk = ok > mk ? ok : mk;
+    }
+    max_dist = mk ? sa_key_f32(mk) : -1.0f;  // voting/best.rs:59: -1.0 when there is no weight at all
+  }
+  auto group_weight = [&](double part) { return RAW_W ? 0.0 + (double)(max_dist - (float)part) : part; };
   double bw = -1.0;
   uint32_t bt = SA_NONE;
   for (uint32_t ct = lane; ct < S.CT; ct += WAVE) {
-    double w = S.row_part_w[(size_t)q * S.CT + ct];
-    int32_t tt = S.row_part_t[(size_t)q * S.CT + ct];
-    if (w > bw && tt >= 0) { bw = w; bt = (uint32_t)tt; }  // a lane's tiles ascend with t
+    const double part = S.row_part_w[(size_t)q * S.CT + ct];
+    const int32_t tt = S.row_part_t[(size_t)q * S.CT + ct];
+    const double w = group_weight(part);
+    if (tt >= 0 && w > bw) { bw = w; bt = (uint32_t)tt; }  // a lane's tiles ascend with t
   }
   for (int o = 32; o > 0; o >>= 1) {
     double ow = __shfl_xor(bw, o);
@@ -249,9 +268,10 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
   double cw = -1.0;
   uint32_t cq = SA_NONE;
   for (uint32_t rt = lane; rt < S.RT; rt += WAVE) {
-    double w = S.col_part_w[(size_t)rt * S.T + bt];
-    uint32_t qq = S.col_part_q[(size_t)rt * S.T + bt];
-    if (w > cw) { cw = w; cq = qq; }  // a lane's tiles ascend with q
+    const double part = S.col_part_w[(size_t)rt * S.T + bt];
+    const uint32_t qq = S.col_part_q[(size_t)rt * S.T + bt];
+    const double w = group_weight(part);
+    if (qq != SA_NONE && w > cw) { cw = w; cq = qq; }  // a lane's tiles ascend with q
   }
   for (int o = 32; o > 0; o >>= 1) {
     double ow = __shfl_xor(cw, o);
@@ -787,7 +807,8 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
                              hipStream_t st, int stage) {
   if (!maxN || !maxT) return hipSuccess;
   if (stage == 0) SA_LAUNCH(k_bestfit_tile, dim3(cdiv(maxT, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
-  else SA_LAUNCH(k_bestfit_resolve, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
+  else if (stage == 2) SA_LAUNCH(k_bestfit_resolve<true>, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);  // partials from the contraction
+  else SA_LAUNCH(k_bestfit_resolve<false>, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,

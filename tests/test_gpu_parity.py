@@ -114,6 +114,20 @@ def test_general_assignment_tail_matches_oracle_too():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_two_kernel_bestfit_matches_oracle_too():
+    """With one observation per track the contraction emits the BestFit partials itself (no weight matrix, no k_bestfit_tile).
+    SA_BESTFIT=tile keeps the matrix + k_bestfit_tile path for those frames as well: same tests, same oracle."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SA_BESTFIT="tile")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_zero_feature"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_state_kept_clean_across_frames_of_changing_size():
     """Edge counters, row duals and the union-find forest are not reset at the start of a frame: the assignment tail leaves
     them clean (k_slot_init only after a reallocation).  One engine, one slot, frames whose N and T grow, shrink and cross
