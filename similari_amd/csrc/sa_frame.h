@@ -55,9 +55,10 @@ __device__ __forceinline__ void pad_feature_row(const float* __restrict__ s, flo
 // tiles themselves write (edge counters, and for the many-workgroup tail the row duals and the union-find forest) cannot be
 // reset beside them; the assignment tail leaves it clean for the next frame instead (k_slot_init establishes it once).
 // =====================================================================================================
-__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk) {
+// (tid = thread index inside the 256-thread unit: a 512-thread block of the fused launch runs two units side by side)
+__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk, uint32_t tid) {
   const uint32_t N = S.N, T = S.T;
-  const uint32_t i = blk * 256 + threadIdx.x;
+  const uint32_t i = blk * 256 + tid;
   if (i < T) {
     S.col_excluded[i] = 0;
     S.v[i] = 0;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
     S.c_usable[i] = usable ? 1 : 0;
   }
   if (S.flags & SCN_HAS_FEATS) {
-    const uint32_t row = blk * 4 + threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const uint32_t row = blk * 4 + tid / WAVE, lane = tid % WAVE;
     if (row < N) {
       bool pres = !(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[row] != 0;
       float nrm;
@@ -135,7 +136,7 @@ struct PosSmem {
   uint16_t list[POS_TI * 64 * NSUB];   // (li << 8) | lj
 };
 template <bool DENSE, bool EDGES, int NSUB, bool UNION>
-__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem) {
+__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem, uint32_t tid) {
   constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = 64u;
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
@@ -145,7 +146,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   PosSmem<NSUB>& sm = *reinterpret_cast<PosSmem<NSUB>*>(smem);
   auto& s_cg = sm.cg; auto& s_cv = sm.cv; auto& s_cconf = sm.cconf; auto& s_cz = sm.cz; auto& s_list = sm.list;
   uint32_t& s_cnt = sm.cnt; auto& s_poly = sm.poly; auto& s_thha = sm.thha;
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
   if (tid < POS_TI) {
     const uint32_t i = i0 + tid;
     if (i < N) {

@@ -736,9 +736,14 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
     return;
   }
   b -= gx * gy;
-  if (threadIdx.x >= 256) return;  // the other two kinds are 256-thread blocks (ended waves do not take part in s_barrier)
-  if (b < px * py) positional_tile<false, true, 1, false>(S, p, b % px, b / px, lds);
-  else frame_prep_block(S, p, b - px * py);
+  // the other two kinds are 256-thread units: a block of KG * 256 threads runs KG of them side by side, each in its own part of the
+  // LDS buffer.  Their barriers are the block's; units pair up barrier for barrier (same kind: same count), and a unit that has
+  // nothing to do, or none, simply ends — ended waves do not take part in s_barrier.
+  const uint32_t unit = b * KG + (threadIdx.x >> 8), tid = threadIdx.x & 255u;
+  constexpr uint32_t POS_LDS = (sizeof(PosSmem<1>) + 15u) & ~15u;
+  static_assert(KG * POS_LDS <= sizeof(float) * KG * 2 * 128 * BK, "the positional tiles must fit the contraction's LDS");
+  if (unit < px * py) positional_tile<false, true, 1, false>(S, p, unit % px, unit / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+  else frame_prep_block(S, p, unit - px * py, tid);
 }
 
 // Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
@@ -1011,19 +1016,25 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 64), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
-  const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
   sa_trace_hook(st, gx * gy);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
-  // contraction alone is faster (14.5 vs 16 us) but every block of the launch then owns 512 threads and 73 KB: two blocks per
-  // CU, and the 1250 positional / preparation blocks queue behind each other (29 us for the launch against 22.6).
-  if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
-  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+  // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
+  // per launch, not per block — so only two blocks fit a CU, and even with two positional / preparation units side by side in
+  // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
+  // against 22.7 (raising the contraction's wave priority changes nothing).  SA_FRAME_KG=2 selects that form for comparison.
+  static const bool one_group = !(getenv("SA_FRAME_KG") && atoi(getenv("SA_FRAME_KG")) == 2);
+  if (one_group) {
+    const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
+    if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+    else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+  } else {
+    const dim3 grid(gx * gy + cdiv(px * py + prep_blocks, 2), 1, ns);
+    if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py);
+    else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py);
+  }
   return hipGetLastError();
 }
 
-// partials = the contraction emits the BestFit partials itself (bank depth 1, cosine: visual_cosine_tile PART) instead of the
-// weight matrix.  The experimental plans (4: four k-groups, 7 / 8: ring main loop) exist in matrix mode only; with partials they
-// run as the product plan of the same tile size.
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
                             hipStream_t st, bool partials) {
   if (!maxN || !maxTK) return hipSuccess;

@@ -86,14 +86,14 @@ template <int NSUB, bool UNION>
 __global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
-  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION>(S, p, blockIdx.x, blockIdx.y, smem);
-  else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x);
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
+  else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.
 __global__ __launch_bounds__(256) void k_positional_dense(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev S = scenes[blockIdx.z];
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<1>)];
-  positional_tile<true, false, 1, false>(S, p, blockIdx.x, blockIdx.y, smem);
+  positional_tile<true, false, 1, false>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
 }
 
 // Debug tap: (w * 1e6f) as i64 of every positional cell, 0 where absent (sort/voting.rs:59).
