@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=50)
-    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager separate launches; 8 hipGraph replay; 16 fused frame launch)")
+    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate of sa_associate from host buffers")
     args = ap.parse_args()
 
@@ -302,7 +302,7 @@ def main():
         prof = {}
     else:
         cfg_p = cfg
-        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & abi.SA_FLAG_FUSED_FRAME)  # same launches as the timed pass
+        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME))  # same launches as the timed pass
         engp = Engine(cfg_p)
         keep2 = stage(engp, cfg_p, scenes)
         for _ in range(5):

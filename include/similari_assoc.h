@@ -112,8 +112,11 @@ typedef struct sa_config {
 } sa_config;
 
 #define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */
-#define SA_FLAG_FUSED_FRAME 0x10u   /* VisualSORT, small frames: contraction tiles, positional tiles and preparation blocks in ONE
-                                       heterogeneous launch (faster frame, lower matrix-core fraction of that launch) */
+/* First phase of a VisualSORT frame.  By default the engine puts the contraction's tiles, the positional tiles and the preparation
+ * blocks into ONE heterogeneous launch whenever that applies (cosine, frames of at most 1024 detections that run as 64x64 tiles,
+ * feature length a multiple of 32) — one dependent launch less per frame — and otherwise runs them as two launches. */
+#define SA_FLAG_FUSED_FRAME 0x10u     /* ask for the heterogeneous launch explicitly (same as the default) */
+#define SA_FLAG_SEPARATE_FRAME 0x20u  /* always two launches: the contraction runs as a kernel of its own (per-kernel measurements) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
 /* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,

@@ -395,7 +395,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
   // launch; otherwise positional tiles + preparation blocks, then the contraction
   bool fused = false;
-  if (e->visual && (e->cfg.flags & SA_FLAG_FUSED_FRAME)) {
+  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME)) {
     ProfScope ps(e, KID_FRAME_VISUAL);
     bool all_feats = true;
     for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && e->slots[i]->has_feats;

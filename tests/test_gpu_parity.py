@@ -292,7 +292,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
-@pytest.mark.parametrize("fused", [0, abi.SA_FLAG_FUSED_FRAME], ids=["separate_launches", "fused_frame_launch"])
+@pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME], ids=["separate_launches", "fused_frame_launch"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
 def test_visual_cosine_parity(k, n, t, d, fused):
@@ -594,7 +594,7 @@ def _fuzz_case(seed):
     if rng.uniform() < 0.5:
         cons = tuple(sorted((int(e), float(rng.uniform(0.3, 3.0))) for e in rng.choice(np.arange(1, 6), size=int(rng.integers(1, 3)), replace=False)))
     common = dict(positional=positional, positional_threshold=float(rng.choice([0.1, 0.3, 0.5])), max_idle_epochs=int(rng.integers(1, 6)),
-                  positional_min_confidence=float(rng.choice([0.05, 0.1, 0.4])), constraints=cons, flags=int(rng.choice([0, abi.SA_FLAG_FUSED_FRAME])))
+                  positional_min_confidence=float(rng.choice([0.05, 0.1, 0.4])), constraints=cons, flags=int(rng.choice([0, abi.SA_FLAG_SEPARATE_FRAME])))
     if visual is None:
         sc = synth.sort_scene(rng, t, n, canvas=canvas, oriented=oriented)
         cfg = abi.make_config(**common)
