@@ -1,15 +1,17 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for mode in tile part; do
+#!/bin/bash
+# In-kernel timeline of the contraction's tiles (library built with SA_EXTRA_FLAGS=-DSA_GEMM_TRACE): per-phase cycles, averaged
+# over the tiles of one launch, for the engine flag sets given as arguments (default: 0 = heterogeneous first phase, 32 = separate)
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; mkdir -p gpurun_out
+for fl in ${@:-0 32}; do
   rm -f gpurun_out/gemm_trace.txt
-  if [ $mode = tile ]; then export SA_BESTFIT=tile; else unset SA_BESTFIT; fi
-  SA_GEMM_TRACE=30 timeout 300 python bench.py --workload c2 --no-cpu-baseline --steps 40 --warmup 5 > /dev/null 2>&1
+  SA_GEMM_TRACE=30 timeout 300 python bench.py --workload ${WORKLOAD:-c2} --no-cpu-baseline --steps 40 --warmup 5 --flags $fl > /dev/null 2>&1
   python - <<PY
 import numpy as np
 a=np.loadtxt("gpurun_out/gemm_trace.txt")
 t=a[:,1:7]
 d=np.diff(t,axis=1)
-print("$mode", "blocks",len(a),"phases prologue/main/reduce/epilogue/maxkey:",d.mean(0).round(0), "total",(t[:,5]-t[:,0]).mean().round(0))
+print("flags $fl", "tiles",len(a),"prologue/main/reduce/epilogue/maxkey:",d.mean(0).round(0), "total",(t[:,5]-t[:,0]).mean().round(0), "first entry -> last exit", t[:,5].max()-t[:,0].min(), "entry spread", t[:,0].max()-t[:,0].min())
 if a.shape[1] > 8 and a[:,7].min() > 0:
-    print("   epilogue split: cells+reductions", (a[:,7]-a[:,4]).mean().round(0), "barrier", (a[:,8]-a[:,7]).mean().round(0), "partial stores", (a[:,5]-a[:,8]).mean().round(0))
+    print("   epilogue split: operands + cells", (a[:,7]-a[:,4]).mean().round(0), "rows -> partials", (a[:,8]-a[:,7]).mean().round(0), "column partials", (a[:,5]-a[:,8]).mean().round(0))
 PY
 done

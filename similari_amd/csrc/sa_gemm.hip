@@ -426,16 +426,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   v = mx(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F));    // xor 16
   return mx((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
 }
-// minimum over each 16-lane row of the wave, left in every lane of the row: quad exchanges, then two rotations — DPP only, no
-// trip through the LDS crossbar
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
-  auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
-  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: the quad's minimum
-  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true));   // row_ror:4: two quads
-  v = mn(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true));   // row_ror:8: the row
-  return v;
-}
 __device__ __forceinline__ void block_max_key(uint32_t SA_G* slots, uint32_t slot, uint32_t kmax) {
   __shared__ uint32_t s_wmax[16];
   const uint32_t m = wave_max_u32(kmax);
@@ -453,20 +443,22 @@ __device__ __forceinline__ void block_max_key(uint32_t SA_G* slots, uint32_t slo
 // compares the candidate's epoch — the same for every row of a scene-frame — with the track's, so its epoch part and the
 // choice of the constraint (spatio_temporal_constraints.rs:48-59) are per-COLUMN facts, folded into GemmCols before the
 // main loop; what is left per cell is dist_in_2r <= max_dist when a constraint applies.
-__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, bool us, const sa_geo& cg, const GemmCols& col,
+__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, const sa_geo* row_geo, const GemmCols& col,
                                              uint32_t* kmax) {
-  float out = __builtin_nanf("");
-  if (us && col.ok && (col.cmax < 0.0f || sa_dist_in_2r(cg, col.g) <= col.cmax)) {
-    // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
-    // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
-    float d = dot * __frsqrt_rn(na * col.nb);
-    if (d >= p.visual_threshold) {  // VisualSortMetricType::is_ok (NaN fails)
-      out = 1.0f - d;               // distance_to_weight
-      uint32_t key = sa_f32_key(out);
-      *kmax = key > *kmax ? key : *kmax;
-    }
-  }
-  return out;
+  // Straight-line on purpose: with a short-circuit chain (usable? column ok? ...) the compiler sinks every operand load into the
+  // branch that first needs it, and the row operands come from LDS — each cell then pays two or three LDS round trips one after
+  // the other.  na = squared norm of the candidate's feature, NaN when feature_can_be_used() says no (the distance is then NaN
+  // and fails is_ok like any NaN).  Only the spatio-temporal constraint, rare and expensive, branches and reads the row geometry.
+  bool ok = col.ok;
+  if (col.cmax >= 0.0f) ok = ok && sa_dist_in_2r(*row_geo, col.g) <= col.cmax;
+  // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
+  // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
+  const float d = dot * __frsqrt_rn(na * col.nb);
+  ok = ok & (d >= p.visual_threshold);  // VisualSortMetricType::is_ok (NaN fails)
+  const float w = 1.0f - d;             // distance_to_weight
+  const uint32_t key = ok ? sa_f32_key(w) : 0u;
+  *kmax = key > *kmax ? key : *kmax;
+  return ok ? w : __builtin_nanf("");
 }
 
 // One tile of the fused visual cost kernel.  RAW (the heterogeneous frame launch, k_frame_visual): the frame-preparation
@@ -563,18 +555,18 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 
   // ---- fused epilogue: row metadata through LDS, column metadata in registers ----
   float* s_na = lds;                      // [BM]
-  float* s_us = lds + BM;                 // [BM] 1.0 / 0.0
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
   float* s_np = lds + 6 * BM;             // [KG][BM] raw mode: squared-norm partials of the k-groups
-  unsigned long long* s_rk = (unsigned long long*)(lds + 6 * BM + KG * BM + (((6 + KG) * BM) & 1));  // [BM] (weight key << 32) | column
-  unsigned long long* s_ck = s_rk + BM;                                                               // [BN] (weight key << 32) | row
+  unsigned long long* s_ck = (unsigned long long*)(lds + (6 + KG) * BM);  // [BN] PART: (weight key << 32) | row, minimum per column
+  constexpr uint32_t KS = BN + 4;                                          // row stride of the key tile (words)
+  uint32_t* s_key = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN);             // [64][KS] PART: order-preserving keys of 64 tile rows
+  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile must fit the stages");
   if (tid < (uint32_t)BM) {
-    s_na[tid] = pre_na;
-    s_us[tid] = pre_us;
+    s_na[tid] = pre_us != 0.f ? pre_na : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
     s_g[tid] = pre_g;
   }
   if constexpr (PART) {
-    for (uint32_t i = tid; i < (uint32_t)(BM + BN); i += blockDim.x) s_rk[i] = ~0ull;
+    for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) s_ck[i] = ~0ull;
   }
   if constexpr (RAW) {
     // the two halves of a row's k values sit in lanes lr and lr + 32; the waves wn = 0 / 1 of a group hold the same rows
@@ -583,114 +575,127 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   }
   __syncthreads();
   if constexpr (RAW) {
-    __syncthreads();
     if (tid < (uint32_t)BM) {
       float s = s_np[tid];
 #pragma unroll
       for (int g2 = 1; g2 < KG; ++g2) s += s_np[g2 * BM + tid];
-      s_na[tid] = s;
+      s_na[tid] = pre_us != 0.f ? s : __builtin_nanf("");
     }
     __syncthreads();
   }
   uint32_t kmax = 0;  // order-preserving key of the largest present weight seen by this lane
-  // PART: a row's lightest weight over 16 of this wave's columns = the minimum of the order-preserving keys over a 16-lane row
-  // (DPP), the lowest lane that holds it = the lowest column; the rows and waves side by side meet in LDS (64-bit minimum of
-  // key << 32 | index).
-  auto row_candidate = [&](uint32_t key, uint32_t li, uint32_t col0) {
-    const uint32_t m = row_min_u32(key);
-    const unsigned long long ball = __ballot(key == m && m != 0xffffffffu);
-    const uint32_t rm = (uint32_t)(ball >> (lane & 48u)) & 0xffffu;   // this 16-lane row's lanes that hold the minimum
-    if ((lane & 15u) == 0 && rm) atomicMin(&s_rk[li], ((unsigned long long)m << 32) | (col0 + (lr & 16u) + (uint32_t)__builtin_ctz(rm)));
+  // PART: the order-preserving keys of 64 tile rows at a time go to an LDS tile; after a barrier every row is scanned by
+  // blockDim / 64 threads (contiguous column segments, running minimum with the lowest column on ties, then a few DPP exchanges
+  // between the threads of a row) and its partial goes straight to memory.  Column minima: in-lane over the rows a lane holds,
+  // the two lane halves by one exchange, the waves stacked on each other by a 64-bit LDS minimum.  (A first version reduced every
+  // accumulator register across the wave with DPP + ballot: 30 instructions per cell, 10.7 k cycles of epilogue for the
+  // one-k-group tile where each lane holds 16 cells.)
+  auto rows_to_partials = [&](uint32_t m) {
+    __syncthreads();  // the key tile is complete
+    const uint32_t nthr = blockDim.x, TPR = nthr >> 6, CPT = BN / TPR;  // threads per row, columns per thread
+    const uint32_t rr = tid / TPR, seg = tid % TPR;
+    const uint32_t* kp = s_key + rr * KS + seg * CPT;
+    uint32_t bk = 0xffffffffu, bc = 0;
+    for (uint32_t c4 = 0; c4 < CPT; c4 += 4) {
+      const uint4 v = *(const uint4*)(kp + c4);
+      if (v.x < bk) { bk = v.x; bc = c4; }
+      if (v.y < bk) { bk = v.y; bc = c4 + 1; }
+      if (v.z < bk) { bk = v.z; bc = c4 + 2; }
+      if (v.w < bk) { bk = v.w; bc = c4 + 3; }
+    }
+    bc += seg * CPT;
+    auto take = [&](uint32_t ok, uint32_t oc) { if (ok < bk || (ok == bk && oc < bc)) { bk = ok; bc = oc; } };
+    take((uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0xB1, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)bc, 0xB1, 0xF, 0xF, true));
+    take((uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0x4E, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)bc, 0x4E, 0xF, 0xF, true));
+    if (TPR == 8) take(__shfl_xor(bk, 4), __shfl_xor(bc, 4));  // the other quad of the 8-thread group
+    const uint32_t gi = m0 + (rr >> 5) * (BM / 2) + m * 32 + (rr & 31u);
+    if (seg == 0 && gi < N) {
+      const bool has = bk != 0xffffffffu;
+      S.row_part_w[(size_t)gi * S.CT + bx] = has ? (double)sa_key_f32(bk) : -1.0;
+      S.row_part_t[(size_t)gi * S.CT + bx] = has ? (int32_t)(n0 + bc) : -1;
+    }
   };
-  // (PART: all weights of a lane first, the cross-lane reductions afterwards — ballots and DPP moves are convergent operations the
-  // scheduler will not move loads across, and the per-row operands come from LDS: interleaved, every cell paid its LDS latency.)
+  // The row operands of a lane's cells: accumulator registers 4g .. 4g+3 hold four consecutive tile rows (acc_row), so one
+  // 16-byte LDS read per group of four cells, all issued before the first cell is evaluated.
   if constexpr (TM == 1 && TN == 1) {
     const uint32_t lc = wn * 32 + lr, gj = n0 + lc;
-    float wv[R];
+    constexpr int G = R / 4;
+    static_assert(R % 4 == 0, "a k-group owns whole groups of four accumulator registers");
+    f32x4 nav[G];
+    uint32_t rbase[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      rbase[g] = wm * 32 + 8u * (kg * (R / 4) + g) + 4u * lh;
+      nav[g] = *(const f32x4*)(s_na + rbase[g]);
+    }
+    uint32_t ckey = 0xffffffffu, crow = 0;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const uint32_t li = wm * 32 + acc_row(kg * R + i, lh);
+      const uint32_t li = rbase[i >> 2] + (i & 3);
       const uint32_t gi = m0 + li;
-      const bool in = gi < N && gj < TK;
-      if constexpr (PART) wv[i] = in ? visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax) : __builtin_nanf("");
-      else if (in) S.vis[(size_t)gi * TK + gj] = visual_cell(p, part[i], s_na[li], s_us[li] != 0.f, s_g[li], col[0], &kmax);
+      const float w = visual_cell(p, part[i], nav[i >> 2][i & 3], s_g + li, col[0], &kmax);  // rows / columns past the edge: ok = false
+      if constexpr (PART) {
+        const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
+        s_key[li * KS + lc] = key;
+        if (key < ckey) { ckey = key; crow = gi; }  // rows ascend with i: the lowest row wins ties
+      } else if (gi < N && gj < TK) {
+        S.vis[(size_t)gi * TK + gj] = w;
+      }
     }
     if constexpr (PART) {
-      unsigned long long cb = ~0ull;
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const uint32_t li = wm * 32 + acc_row(kg * R + i, lh);
-        const float w = wv[i];
-        const uint32_t key = w == w ? sa_f32_key(w) : 0xffffffffu;
-        row_candidate(key, li, n0 + wn * 32);
-        const unsigned long long cand = ((unsigned long long)key << 32) | (m0 + li);
-        if (w == w && cand < cb) cb = cand;
-      }
+      unsigned long long cb = ((unsigned long long)ckey << 32) | crow;
       const unsigned long long ob = __shfl_xor(cb, 32);
       cb = ob < cb ? ob : cb;
-      if (lh == 0 && cb != ~0ull) atomicMin(&s_ck[lc], cb);
+      if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);
+      SA_STAMP(tr, 6);
+      rows_to_partials(0);
+      SA_STAMP(tr, 7);
     }
   } else {
-    unsigned long long cb[TN];
+    uint32_t ckey[TN], crow[TN];
 #pragma unroll
-    for (int n = 0; n < TN; ++n) cb[n] = ~0ull;
+    for (int n = 0; n < TN; ++n) { ckey[n] = 0xffffffffu; crow[n] = 0; }
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      float wv[16][TN];
+      f32x4 nav[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nav[g] = *(const f32x4*)(s_na + wm * (BM / 2) + m * 32 + 8 * g + 4 * lh);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        const uint32_t lrow = wm * 32 + acc_row(r, lh);          // row of the 64-row key tile of this pass
         const uint32_t li = wm * (BM / 2) + m * 32 + acc_row(r, lh);
         const uint32_t gi = m0 + li;
-        if constexpr (!PART) {
-          if (gi >= N) continue;
-        }
-        const float na = s_na[li];
-        const bool us = s_us[li] != 0.f;
-        const sa_geo cg = s_g[li];
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
-          const uint32_t gj = n0 + wn * (BN / 2) + n * 32 + lr;
-          if constexpr (PART) wv[r][n] = (gi < N && gj < TK) ? visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax) : __builtin_nanf("");
-          else if (gj < TK) S.vis[(size_t)gi * TK + gj] = visual_cell(p, acc[m][n][r], na, us, cg, col[n], &kmax);
+          const uint32_t lc = wn * (BN / 2) + n * 32 + lr, gj = n0 + lc;
+          const float w = visual_cell(p, acc[m][n][r], nav[r >> 2][r & 3], s_g + li, col[n], &kmax);
+          if constexpr (PART) {
+            const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
+            s_key[lrow * KS + lc] = key;
+            if (key < ckey[n]) { ckey[n] = key; crow[n] = gi; }
+          } else {
+            if (gi < N && gj < TK) S.vis[(size_t)gi * TK + gj] = w;
+          }
         }
       }
       if constexpr (PART) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t li = wm * (BM / 2) + m * 32 + acc_row(r, lh);
-#pragma unroll
-          for (int n = 0; n < TN; ++n) {
-            const float w = wv[r][n];
-            const uint32_t key = w == w ? sa_f32_key(w) : 0xffffffffu;
-            row_candidate(key, li, n0 + wn * (BN / 2) + n * 32);
-            const unsigned long long cand = ((unsigned long long)key << 32) | (m0 + li);
-            if (w == w && cand < cb[n]) cb[n] = cand;
-          }
-        }
+        rows_to_partials(m);
+        if (m + 1 < TM) __syncthreads();  // the next pass overwrites the key tile
       }
     }
     if constexpr (PART) {
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const unsigned long long ob = __shfl_xor(cb[n], 32);
-        const unsigned long long b2 = ob < cb[n] ? ob : cb[n];
-        if (lh == 0 && b2 != ~0ull) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
+        unsigned long long b2 = ((unsigned long long)ckey[n] << 32) | crow[n];
+        const unsigned long long ob = __shfl_xor(b2, 32);
+        b2 = ob < b2 ? ob : b2;
+        if (lh == 0 && (uint32_t)(b2 >> 32) != 0xffffffffu) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
       }
     }
   }
   if constexpr (PART) {
-    // the partials of this tile, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles)
-    SA_STAMP(tr, 6);
+    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles)
     __syncthreads();
-    SA_STAMP(tr, 7);
-    for (uint32_t i = tid; i < (uint32_t)BM; i += blockDim.x) {
-      const uint32_t gi = m0 + i;
-      if (gi >= N) continue;
-      const unsigned long long k2 = s_rk[i];
-      const bool has = k2 != ~0ull;
-      S.row_part_w[(size_t)gi * S.CT + bx] = has ? (double)sa_key_f32((uint32_t)(k2 >> 32)) : -1.0;
-      S.row_part_t[(size_t)gi * S.CT + bx] = has ? (int32_t)(uint32_t)k2 : -1;
-    }
     for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) {
       const uint32_t gj = n0 + i;
       if (gj >= TK) continue;
