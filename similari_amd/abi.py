@@ -33,7 +33,6 @@ SA_VOTE_VISUAL = 1
 SA_VOTE_POSITIONAL = 2
 
 SA_FLAG_PROFILE = 0x2
-SA_FLAG_FORK = 0x4
 SA_FLAG_GRAPH = 0x8
 SA_FLAG_FUSED_FRAME = 0x10
 SA_FLAG_SEPARATE_FRAME = 0x20
