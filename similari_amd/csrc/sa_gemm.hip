@@ -694,8 +694,19 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     }
   }
   if constexpr (PART) {
-    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles)
+    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles); the waves'
+    // maxima for the max_dist slot share this barrier instead of paying for one of their own
+    __shared__ uint32_t s_wmax[16];
+    {
+      const uint32_t wmx = wave_max_u32(kmax);
+      if (lane == 0) s_wmax[tid >> 6] = wmx;
+    }
     __syncthreads();
+    if (tid == 0) {
+      uint32_t bmx = 0;
+      for (uint32_t w2 = 0; w2 < (blockDim.x >> 6); ++w2) bmx = s_wmax[w2] > bmx ? s_wmax[w2] : bmx;
+      S.vis_max_key[key_slot] = bmx;
+    }
     for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) {
       const uint32_t gj = n0 + i;
       if (gj >= TK) continue;
@@ -706,7 +717,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     }
   }
   SA_STAMP(tr, 4);
-  block_max_key(S.vis_max_key, key_slot, kmax);
+  if constexpr (!PART) block_max_key(S.vis_max_key, key_slot, kmax);
   SA_STAMP(tr, 5);
 }
 
