@@ -146,6 +146,19 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
   SA_STAMP(tr, 1);
 
   // One iteration.  SET = (i+1)&1; STORE: chunk i+1 exists (set -> other LDS stage); LOAD: chunk i+3 exists (global -> set).
+  // The iteration's ONE barrier sits between its third and fourth k-step: the rows of chunk i+1 go to the other LDS stage during
+  // k-steps 0-2 (which also fetch the fragments of k-steps 1-3 from this stage), every wave then meets at the barrier with the
+  // MFMAs of k-step 2 still queued on its matrix pipe, and k-step 3 — running on fragments already in registers — fetches the
+  // FIRST fragments of chunk i+1 from the stage that has just become visible.  With the barrier at the end of the iteration
+  // that first fetch came after it, its LDS latency exposed on an idle pipe once per chunk (one wave per SIMD: 1560 cycles per
+  // chunk for 1024 of MFMA work).
+  f32x4 fa[2][TM], fb[2][TN];
+  if (mine > 0) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m) fa[0][m] = *(const f32x4*)(base + lds_off(aoff[m], lh));
+#pragma unroll
+    for (int n = 0; n < TN; ++n) fb[0][n] = *(const f32x4*)(base + BM * BK + lds_off(boff[n], lh));
+  }
   auto body = [&](uint32_t it, auto set_tag, auto store_tag, auto load_tag) {
     constexpr int SET = decltype(set_tag)::value;
     constexpr bool STORE = decltype(store_tag)::value, LOAD = decltype(load_tag)::value;
@@ -153,11 +166,6 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
     const float* Bs = As + BM * BK;
     float* nxt = base + ((it + 1u) & 1u) * STAGE;
     const uint32_t k3 = ((it + 3u) * KG + kg) * BK;
-    f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) fa[0][m] = *(const f32x4*)(As + lds_off(aoff[m], lh));
-#pragma unroll
-    for (int n = 0; n < TN; ++n) fb[0][n] = *(const f32x4*)(Bs + lds_off(boff[n], lh));
     auto kstep = [&](auto kk_tag) {
       constexpr int kk = decltype(kk_tag)::value;
       constexpr int cur = kk & 1, nx = cur ^ 1;
@@ -166,9 +174,15 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
         for (int m = 0; m < TM; ++m) fa[nx][m] = *(const f32x4*)(As + lds_off(aoff[m], (kk + 1) * 2 + lh));
 #pragma unroll
         for (int n = 0; n < TN; ++n) fb[nx][n] = *(const f32x4*)(Bs + lds_off(boff[n], (kk + 1) * 2 + lh));
+      } else if constexpr (STORE) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) fa[nx][m] = *(const f32x4*)(nxt + lds_off(aoff[m], lh));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[nx][n] = *(const f32x4*)(nxt + BM * BK + lds_off(boff[n], lh));
       }
-      // this k-step's share of the register -> LDS -> register hand-over of the staged rows
-      constexpr int lo_of[5] = {0, (L_CH + 3) / 4, (L_CH + 1) / 2, (3 * L_CH + 3) / 4, L_CH};
+      // this k-step's share of the register -> LDS -> register hand-over of the staged rows: the LDS stores in k-steps 0-2
+      // (they must be visible at the barrier), each register's reload from global memory right after its store
+      constexpr int lo_of[5] = {0, (L_CH + 2) / 3, (2 * L_CH + 2) / 3, L_CH, L_CH};
       constexpr int lo = lo_of[kk], hi = lo_of[kk + 1];
 #pragma unroll
       for (int r = lo; r < hi; ++r) {
@@ -188,7 +202,7 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
       }
       // pin the interleave: one side instruction in the shadow of each of the first MFMAs of the k-step
       constexpr int NM = 4 * TM * TN;
-      constexpr int nrd = kk < 3 ? TM + TN : 0, nst = STORE ? hi - lo : 0, nld = LOAD ? hi - lo : 0;
+      constexpr int nrd = (kk < 3 || STORE) ? TM + TN : 0, nst = STORE ? hi - lo : 0, nld = LOAD ? hi - lo : 0;
       constexpr int used = nrd + nst + nld;
 #pragma unroll
       for (int i = 0; i < nrd; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -202,6 +216,7 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
     kstep(std::integral_constant<int, 0>{});
     kstep(std::integral_constant<int, 1>{});
     kstep(std::integral_constant<int, 2>{});
+    __syncthreads();
     kstep(std::integral_constant<int, 3>{});
   };
   using T_ = std::true_type;
@@ -212,9 +227,7 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
   // steady state two iterations per trip, so that the register set is a compile-time constant (set of iteration i = (i+1)&1)
   for (; it + 4 < mine; it += 2) {
     body(it, S1{}, T_{}, T_{});
-    __syncthreads();
     body(it + 1, S0{}, T_{}, T_{});
-    __syncthreads();
   }
   for (; it < mine; ++it) {  // at most 4 iterations left; `it` is even on entry
     const bool st = it + 1 < mine, ld = it + 3 < mine;
@@ -227,7 +240,6 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
       else if (st) body(it, S1{}, T_{}, F_{});
       else body(it, S1{}, F_{}, F_{});
     }
-    __syncthreads();
   }
   for (; it < niter; ++it) __syncthreads();  // a group that ran out of chunks still meets the others at the barrier
   SA_STAMP(tr, 2);
@@ -731,15 +743,15 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
 //   n_gemm            : a 64x64 tile of the feature contraction (matrix cores; raw-feature mode, see visual_cosine_tile)
-//   n_gemm + n_pos    : a 16x64 positional tile (f64 VALU + LDS: pair pre-filter, polygon clipping, edges of the vote)
-//   ...               : a frame-preparation block (padded features + norms for the upkeep and the taps, vote-state reset)
+//   n_gemm + n_prep   : a frame-preparation block (padded features + norms for the upkeep and the taps, vote-state reset)
+//   ...               : a 16x64 positional tile (f64 VALU + LDS: pair pre-filter, polygon clipping, edges of the vote)
 // The three kinds are independent of each other, so the positional tiles and the preparation blocks fill the issue slots and
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
 template <int KG, bool PART>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
-                                                           uint32_t px, uint32_t py) {
+                                                           uint32_t px, uint32_t py, uint32_t nprep) {
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
   static_assert(sizeof(PosSmem<1>) <= sizeof(float) * KG * 2 * 128 * BK, "the positional tile must fit the contraction's LDS");
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -758,8 +770,17 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   const uint32_t unit = b * KG + (threadIdx.x >> 8), tid = threadIdx.x & 255u;
   constexpr uint32_t POS_LDS = (sizeof(PosSmem<1>) + 15u) & ~15u;
   static_assert(KG * POS_LDS <= sizeof(float) * KG * 2 * 128 * BK, "the positional tiles must fit the contraction's LDS");
-  if (unit < px * py) positional_tile<false, true, 1, false>(S, p, unit % px, unit / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
-  else frame_prep_block(S, p, unit - px * py, tid);
+#ifdef SA_GEMM_TRACE
+  uint64_t* tr2 = g_trace_dev && blockIdx.x < 65536 ? g_trace_dev + 8 * blockIdx.x : nullptr;  // entry / exit of the other kinds
+  if (tr2 && threadIdx.x == 0) { tr2[0] = __builtin_amdgcn_s_memtime(); tr2[1] = unit < nprep ? 2 : 1; }
+#endif
+  // preparation blocks (short) before the positional tiles (long): the tiles alone fill every slot the contraction leaves, and
+  // preparation blocks queued behind them started only when the first tiles retired — the last thing to finish in the launch
+  if (unit < nprep) frame_prep_block(S, p, unit, tid);
+  else if (unit - nprep < px * py) positional_tile<false, true, 1, false>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+#ifdef SA_GEMM_TRACE
+  if (tr2 && threadIdx.x == 0) tr2[5] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
@@ -1032,7 +1053,7 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 64), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
-  sa_trace_hook(st, gx * gy);
+  sa_trace_hook(st, gx * gy + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
   // per launch, not per block — so only two blocks fit a CU, and even with two positional / preparation units side by side in
@@ -1041,12 +1062,12 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   static const bool one_group = !(getenv("SA_FRAME_KG") && atoi(getenv("SA_FRAME_KG")) == 2);
   if (one_group) {
     const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
-    if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
-    else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py);
+    if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
   } else {
     const dim3 grid(gx * gy + cdiv(px * py + prep_blocks, 2), 1, ns);
-    if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py);
-    else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py);
+    if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
   }
   return hipGetLastError();
 }
