@@ -8,18 +8,23 @@ for fl in ${@:-0 32}; do
   python - <<PY
 import numpy as np
 a=np.loadtxt("gpurun_out/gemm_trace.txt")
-a=a[a[:,1] > a[:,1].max() - 1e6]   # stamps of the traced launch only (the buffer also holds blocks of earlier, larger launches)
-other=a[(a[:,2]==1)|(a[:,2]==2)]
-a=a[(a[:,2]!=1)&(a[:,2]!=2)]
-if len(other):
-    t0=min(a[:,1].min(), other[:,1].min())
-    for kind,name in ((1,"positional tiles"),(2,"preparation blocks")):
-        o=other[other[:,2]==kind]
-        if len(o): print("   %s: %d blocks, entry %.0f..%.0f, exit %.0f..%.0f (mean life %.0f) cycles after the first entry" % (name,len(o),(o[:,1]-t0).min(),(o[:,1]-t0).max(),(o[:,6]-t0).min(),(o[:,6]-t0).max(),(o[:,6]-o[:,1]).mean()))
-    print("   contraction tiles: entry %.0f..%.0f, exit %.0f..%.0f" % ((a[:,1]-t0).min(),(a[:,1]-t0).max(),(a[:,6]-t0).min(),(a[:,6]-t0).max()))
+# s_memtime has its own base on every XCD and workgroups go round-robin over the 8 XCDs: times are compared inside an XCD only
+xcd=a[:,0].astype(int)%8
+rel=a.copy()
+for x in range(8):
+    m=xcd==x
+    if m.any(): rel[m,1:]=np.where(a[m,1:]>0, a[m,1:]-a[m,1][a[m,1]>0].min(), 0)
+isother=(a[:,2]==1)|(a[:,2]==2)
+if isother.any():
+    for kind,name in ((2,"preparation blocks"),(1,"positional tiles")):
+        o=rel[a[:,2]==kind]
+        if len(o): print("   %s: %d blocks, entry %.0f .. %.0f (median %.0f), exit %.0f .. %.0f, mean life %.0f cycles" % (name,len(o),o[:,1].min(),o[:,1].max(),np.median(o[:,1]),o[:,6].min(),o[:,6].max(),(o[:,6]-o[:,1]).mean()))
+    g=rel[~isother]
+    print("   contraction tiles: entry %.0f .. %.0f, exit %.0f .. %.0f" % (g[:,1].min(),g[:,1].max(),g[:,6].min(),g[:,6].max()))
+a=a[~isother]
 t=a[:,1:7]
 d=np.diff(t,axis=1)
-print("flags $fl", "tiles",len(a),"prologue/main/reduce/epilogue/maxkey:",d.mean(0).round(0), "total",(t[:,5]-t[:,0]).mean().round(0), "first entry -> last exit", t[:,5].max()-t[:,0].min(), "entry spread", t[:,0].max()-t[:,0].min())
+print("flags $fl", "tiles",len(a),"prologue/main/reduce/epilogue/maxkey:",d.mean(0).round(0), "total",(t[:,5]-t[:,0]).mean().round(0))
 if a.shape[1] > 8 and a[:,7].min() > 0:
     print("   epilogue split: operands + cells", (a[:,7]-a[:,4]).mean().round(0), "rows -> partials", (a[:,8]-a[:,7]).mean().round(0), "column partials", (a[:,5]-a[:,8]).mean().round(0))
 PY

@@ -602,7 +602,13 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   // the two lane halves by one exchange, the waves stacked on each other by a 64-bit LDS minimum.  (A first version reduced every
   // accumulator register across the wave with DPP + ballot: 30 instructions per cell, 10.7 k cycles of epilogue for the
   // one-k-group tile where each lane holds 16 cells.)
-  auto rows_to_partials = [&](uint32_t m) {
+  uint32_t* s_wmax = s_key + 64 * KS;  // [16] wave maxima for the max_dist slot
+  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 16) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "");
+  auto rows_to_partials = [&](uint32_t m, bool last) {
+    if (last) {  // the waves' maxima for the max_dist slot and the column minima ride on this barrier too
+      const uint32_t wmx = wave_max_u32(kmax);
+      if (lane == 0) s_wmax[tid >> 6] = wmx;
+    }
     __syncthreads();  // the key tile is complete
     const uint32_t nthr = blockDim.x, TPR = nthr >> 6, CPT = BN / TPR;  // threads per row, columns per thread
     const uint32_t rr = tid / TPR, seg = tid % TPR;
@@ -660,7 +666,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       cb = ob < cb ? ob : cb;
       if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);
       SA_STAMP(tr, 6);
-      rows_to_partials(0);
+      rows_to_partials(0, true);
       SA_STAMP(tr, 7);
     }
   } else {
@@ -691,29 +697,23 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
         }
       }
       if constexpr (PART) {
-        rows_to_partials(m);
-        if (m + 1 < TM) __syncthreads();  // the next pass overwrites the key tile
-      }
-    }
-    if constexpr (PART) {
+        if (m + 1 == TM) {
 #pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        unsigned long long b2 = ((unsigned long long)ckey[n] << 32) | crow[n];
-        const unsigned long long ob = __shfl_xor(b2, 32);
-        b2 = ob < b2 ? ob : b2;
-        if (lh == 0 && (uint32_t)(b2 >> 32) != 0xffffffffu) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
+          for (int n = 0; n < TN; ++n) {
+            unsigned long long b2 = ((unsigned long long)ckey[n] << 32) | crow[n];
+            const unsigned long long ob = __shfl_xor(b2, 32);
+            b2 = ob < b2 ? ob : b2;
+            if (lh == 0 && (uint32_t)(b2 >> 32) != 0xffffffffu) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
+          }
+        }
+        rows_to_partials(m, m + 1 == TM);
+        if (m + 1 < TM) __syncthreads();  // the next pass overwrites the key tile
       }
     }
   }
   if constexpr (PART) {
-    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles); the waves'
-    // maxima for the max_dist slot share this barrier instead of paying for one of their own
-    __shared__ uint32_t s_wmax[16];
-    {
-      const uint32_t wmx = wave_max_u32(kmax);
-      if (lane == 0) s_wmax[tid >> 6] = wmx;
-    }
-    __syncthreads();
+    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles), and the
+    // max_dist slot: complete since the barrier of the last row pass
     if (tid == 0) {
       uint32_t bmx = 0;
       for (uint32_t w2 = 0; w2 < (blockDim.x >> 6); ++w2) bmx = s_wmax[w2] > bmx ? s_wmax[w2] : bmx;
