@@ -1168,7 +1168,7 @@ int sa_tap_dims(sa_engine* e, uint32_t slot, uint32_t* n, uint32_t* t, uint32_t*
   if (k) *k = e->K;
   return SA_OK;
 }
-// The product path never writes the dense positional matrix (k_positional emits the edges of the vote directly); the taps
+// The product path never writes the dense positional matrix (the positional tiles emit the edges of the vote directly); the taps
 // recompute it on demand from the slot's resident inputs with the DENSE specialisation of the same kernel, which touches no
 // assignment state.  Valid until the slot's scene is upserted or re-staged.
 static int dense_positional(sa_engine* e, Slot* s) {

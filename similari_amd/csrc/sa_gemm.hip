@@ -572,7 +572,6 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   unsigned long long* s_ck = (unsigned long long*)(lds + (6 + KG) * BM);  // [BN] PART: (weight key << 32) | row, minimum per column
   constexpr uint32_t KS = BN + 4;                                          // row stride of the key tile (words)
   uint32_t* s_key = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN);             // [64][KS] PART: order-preserving keys of 64 tile rows
-  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile must fit the stages");
   if (tid < (uint32_t)BM) {
     s_na[tid] = pre_us != 0.f ? pre_na : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
     s_g[tid] = pre_g;
@@ -603,7 +602,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   // accumulator register across the wave with DPP + ballot: 30 instructions per cell, 10.7 k cycles of epilogue for the
   // one-k-group tile where each lane holds 16 cells.)
   uint32_t* s_wmax = s_key + 64 * KS;  // [16] wave maxima for the max_dist slot
-  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 16) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "");
+  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 16) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile + wave maxima must fit the stages");
   auto rows_to_partials = [&](uint32_t m, bool last) {
     if (last) {  // the waves' maxima for the max_dist slot and the column minima ride on this barrier too
       const uint32_t wmx = wave_max_u32(kmax);

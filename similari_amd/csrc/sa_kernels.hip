@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // =====================================================================================================
 // Positional assignment = SortVoting::winners (sort/voting.rs:30-100) as an exact sparse solve.
 // The edges (cells whose quantised weight beats the new-track threshold), the row duals and the union-find forest come
-// straight out of k_positional, which runs beside the visual vote; the visual vote's verdicts are applied here, lazily:
+// straight out of the positional tiles, which run beside the visual vote; the visual vote's verdicts are applied here, lazily:
 // rows that already hold a visual decision take no part (feature_winners.contains_key(from), visual_sort/voting.rs:77) and
 // columns won visually are skipped while relaxing (excluded_tracks, :62-71).  A component may therefore be larger than
 // strictly needed — harmless, it is still solved exactly.
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ int64_t s_u[SA_SMALL_N], s_rdist[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
   __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
   __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
-  // The edge lists k_positional left behind live in HBM, one strided row per candidate: every access from here on would be
+  // The edge lists the positional tiles left behind live in HBM, one strided row per candidate: every access from here on would be
   // a dependent, uncoalesced round trip (the solve is a chain of them).  They are packed ONCE into an LDS pool — an
   // exclusive scan of the row counts gives the offsets — and the row duals, the connected components of the usable graph
   // (rows without a visual verdict) and the solve itself then run out of LDS.  A scene whose lists do not fit (dense
