@@ -267,11 +267,11 @@ def test_batch_sort_scenes_and_constraints_match_oracle(backend):
     run_sort_sequence(IoU(0.3), False, seed=17, scenes=(3, 7, 11), batch=True, constraints=c, n=40, backend=backend)
 
 
-def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False, backend="gpu", own=None):
+def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=False, backend="gpu", own=None, bank=3):
     rng = np.random.default_rng(seed)
     opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(metric)
-            .positional_metric(positional).visual_minimal_track_length(2).visual_minimal_area(500.0)
-            .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(3).visual_min_votes(1))
+            .positional_metric(positional).visual_minimal_track_length(min(2, bank)).visual_minimal_area(500.0)
+            .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(bank).visual_min_votes(1))
     if own is not None:   # arm the own-area gates: the trackers compute exclusively_owned_areas shares themselves
         opts = opts.visual_minimal_own_area_percentage_use(own[0]).visual_minimal_own_area_percentage_collect(own[1])
     g = make(backend, "visual", opts=opts, feature_len=d, batch=batch)
@@ -303,6 +303,14 @@ def run_visual_sequence(metric, positional, seed, frames=8, n=40, d=64, batch=Fa
 @UPKEEP
 def test_visual_cosine_sequence_matches_oracle(backend):
     run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=21, backend=backend)
+
+
+@pytest.mark.gpu
+@UPKEEP
+def test_visual_cosine_single_observation_sequence_matches_oracle(backend):
+    """One observation per track: the engine's contraction emits the BestFit partials itself (no weight matrix) and, with a
+    feature length that is a multiple of 32, the first phase is the heterogeneous launch — the path of the default bench line."""
+    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=29, n=70, d=64, backend=backend, bank=1)
 
 
 @pytest.mark.gpu
