@@ -401,7 +401,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     const SaEdge SA_G* row = S.e_edge + (size_t)(q < N ? q : 0) * S.estride;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bool in = !VISUAL && q < N && (uint32_t)k < S.estride;
+      const bool in = !VISUAL && q < N && (uint32_t)k < T;  // T == 0: the lists have no capacity at all
       const SaEdge ed = in ? sa_ldg(row + k) : SaEdge{0, 0u, 0u};
       sj[k] = ed.col;
       sg[k] = ed.gain;
