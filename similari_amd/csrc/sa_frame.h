@@ -125,25 +125,33 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
 // UNION: also fold each edge into the row dual and the global union-find forest (needed by the many-workgroup assignment
 // tail).  When the whole scene is solved by ONE workgroup (k_assign_small) that workgroup builds both from the edge lists in
 // LDS instead — the chain of dependent global atomics per edge would otherwise sit at the tail of every block here.
-template <int NSUB>
+template <int NSUB, int WORKERS = 64>
 struct PosSmem {
-  double poly[4 * SA_POLY_CAP * 64];   // 24 KB: Sutherland–Hodgman ping-pong lists, [list][vertex][worker lane]
+  double poly[4 * SA_POLY_CAP * WORKERS];   // 24 KB at 64 workers: Sutherland–Hodgman ping-pong lists, [list][vertex][worker lane]
   double cv[POS_TI][8];                // candidate polygons, derived here from the raw boxes (see frame_prep_block)
   sa_geo cg[POS_TI];
   float cconf[POS_TI], cz[POS_TI][5];
   float thha[64 * NSUB];
-  uint32_t cnt;
+  uint32_t cnt, cnt2;
   uint16_t list[POS_TI * 64 * NSUB];   // (li << 8) | lj
 };
-template <bool DENSE, bool EDGES, int NSUB, bool UNION>
+// PROOF: drop the pairs whose clip is provably empty (sa_clip_is_empty) before the clipper runs; WORKERS: lanes of the clipping
+// wave (their vertex lists are the bulk of the tile's LDS).  As a kernel of its own a tile is a chain of latencies and the extra
+// phase only lengthens it (measured: C2 k_frame 9.5 -> 10.0 us).  In the heterogeneous launch the tiles have slack, but every f64
+// wave instruction they issue is time the matrix-core waves on the same SIMD do not get (3.7 us of a 22 us launch at C2, where
+// ~80 % of the bounding-circle neighbours do not overlap) — and a clip round costs the same instructions for 12 live lanes as
+// for 60, so proofs alone make it worse (24.6 us).  There the tiles are 16 x 128 (~120 surviving pairs): the threads of two
+// waves prove what they can and the ~25 pairs that are left take ONE clip round where two 16 x 64 tiles took two: 21.2 us.
+// (16 x 192 and 16 x 256 tiles: 25 us — the tile itself then outlasts the contraction.)
+template <bool DENSE, bool EDGES, int NSUB, bool UNION, bool PROOF = false, int WORKERS = 64>
 __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem, uint32_t tid) {
-  constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = 64u;
+  constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = (uint32_t)WORKERS;
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
   // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
   // static LDS with the contraction's stages instead of adding to it
-  PosSmem<NSUB>& sm = *reinterpret_cast<PosSmem<NSUB>*>(smem);
+  PosSmem<NSUB, WORKERS>& sm = *reinterpret_cast<PosSmem<NSUB, WORKERS>*>(smem);
   auto& s_cg = sm.cg; auto& s_cv = sm.cv; auto& s_cconf = sm.cconf; auto& s_cz = sm.cz; auto& s_list = sm.list;
   uint32_t& s_cnt = sm.cnt; auto& s_poly = sm.poly; auto& s_thha = sm.thha;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
@@ -159,7 +167,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
       s_cg[tid] = sa_geo{0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) { s_cnt = 0; sm.cnt2 = 0; }
   // this thread's 4 tracks (one per 64-wide sub-tile): loads in flight while the candidate tile lands in LDS
   sa_geo tg[NSUB];
   uint64_t te[NSUB];
@@ -192,7 +200,35 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     }
   }
   __syncthreads();
-  const uint32_t cnt = s_cnt;
+  uint32_t cnt = s_cnt;
+  if (PROOF && p.positional_kind != SA_POS_MAHALANOBIS) {
+    // one thread per surviving pair proves, where it can, that the polygons do not overlap; the rest are compacted in place
+    // (every thread holds its entries in registers while the list is rewritten)
+    uint32_t keep = 0;
+    uint16_t mine[4 * NSUB];
+#pragma unroll
+    for (int k = 0; k < 4 * NSUB; ++k) {
+      const uint32_t sidx = tid + 256u * k;
+      mine[k] = 0;
+      if (sidx < cnt) {
+        const uint32_t c = s_list[sidx];
+        const uint32_t li = c >> 8, lj = c & 255u;
+        double cv[8], tv[8];
+        const double SA_G* tp = S.t_verts + (size_t)(j0 + lj) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { cv[q] = s_cv[li][q]; tv[q] = tp[q]; }
+        mine[k] = (uint16_t)c;
+        if (!sa_clip_is_empty(cv, tv)) keep |= 1u << k;
+        else if (DENSE) S.pos[(size_t)(i0 + li) * T + j0 + lj] = nanv;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4 * NSUB; ++k)
+      if ((keep >> k) & 1u) s_list[atomicAdd(&sm.cnt2, 1u)] = mine[k];
+    __syncthreads();
+    cnt = sm.cnt2;
+  }
   // one surviving cell -> (optionally) the dense matrix, and its edge
   auto emit = [&](uint32_t i, uint32_t j, float w, bool present) {
     if (DENSE) S.pos[(size_t)i * T + j] = present ? w : nanv;

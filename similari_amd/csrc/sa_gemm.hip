@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
 //   n_gemm            : a 64x64 tile of the feature contraction (matrix cores; raw-feature mode, see visual_cosine_tile)
 //   n_gemm + n_prep   : a frame-preparation block (padded features + norms for the upkeep and the taps, vote-state reset)
-//   ...               : a 16x64 positional tile (f64 VALU + LDS: pair pre-filter, polygon clipping, edges of the vote)
+//   ...               : a 16x256 positional tile (f64 VALU + LDS: pair pre-filter, disjointness proofs, polygon clipping, edges)
 // The three kinds are independent of each other, so the positional tiles and the preparation blocks fill the issue slots and
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
@@ -752,7 +752,8 @@ template <int KG, bool PART>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py, uint32_t nprep) {
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
-  static_assert(sizeof(PosSmem<1>) <= sizeof(float) * KG * 2 * 128 * BK, "the positional tile must fit the contraction's LDS");
+  using FusedPos = PosSmem<2, 64>;  // the wide, proof-filtered positional tile of this launch (sa_frame.h)
+  static_assert(sizeof(FusedPos) <= sizeof(float) * 2 * 128 * BK, "the positional tile must fit one k-group's stages");
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   // Contraction tiles first in blockIdx order: the dispatcher hands blocks out in that order, breadth-first over the CUs, so
   // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // LDS buffer.  Their barriers are the block's; units pair up barrier for barrier (same kind: same count), and a unit that has
   // nothing to do, or none, simply ends — ended waves do not take part in s_barrier.
   const uint32_t unit = b * KG + (threadIdx.x >> 8), tid = threadIdx.x & 255u;
-  constexpr uint32_t POS_LDS = (sizeof(PosSmem<1>) + 15u) & ~15u;
+  constexpr uint32_t POS_LDS = (sizeof(FusedPos) + 15u) & ~15u;
   static_assert(KG * POS_LDS <= sizeof(float) * KG * 2 * 128 * BK, "the positional tiles must fit the contraction's LDS");
 #ifdef SA_GEMM_TRACE
   uint64_t* tr2 = g_trace_dev && blockIdx.x < 65536 ? g_trace_dev + 8 * blockIdx.x : nullptr;  // entry / exit of the other kinds
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // preparation blocks (short) before the positional tiles (long): the tiles alone fill every slot the contraction leaves, and
   // preparation blocks queued behind them started only when the first tiles retired — the last thing to finish in the launch
   if (unit < nprep) frame_prep_block(S, p, unit, tid);
-  else if (unit - nprep < px * py) positional_tile<false, true, 1, false>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+  else if (unit - nprep < px * py) positional_tile<false, true, 2, false, true, 64>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
 #ifdef SA_GEMM_TRACE
   if (tr2 && threadIdx.x == 0) tr2[5] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1049,7 +1050,7 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
   if (plan != 2 && plan != 4) return hipErrorNotSupported;
-  const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 64), py = cdiv(maxN, POS_TI);
+  const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
   sa_trace_hook(st, gx * gy + px * py + prep_blocks);

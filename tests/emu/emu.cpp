@@ -156,6 +156,19 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
   return 0;
 }
 
+// The positional tiles' pre-filter (heterogeneous launch): 1 when sa_clip_is_empty proves the clip of (cand, track) empty.
+int emu_clip_is_empty(const sa_box* cand, const sa_box* track) {
+  double cv[8], tv[8];
+  const sa_box* bs[2] = {cand, track};
+  double* vs[2] = {cv, tv};
+  for (int k = 0; k < 2; ++k) {
+    double a = (double)(bs[k]->has_angle ? bs[k]->angle : 0.0f);
+    double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+    sa_vertices(bs[k]->xc, bs[k]->yc, bs[k]->aspect, bs[k]->height, c, s, vs[k]);
+  }
+  return sa_clip_is_empty(cv, tv) ? 1 : 0;
+}
+
 // k_own_area for every box of a frame, as the kernel sequences it (neighbour scan, relative coordinates, one call of
 // sa_own_edge per polygon edge, the reference's f32 epilogue).  Returns the status bits the kernel would raise.
 int emu_own_areas(uint32_t n, const sa_box* boxes, float* out_share, uint32_t max_nb, uint32_t cap) {

@@ -36,6 +36,8 @@ def emu():
     L.emu_key_f32.argtypes = [C.c_uint32]
     L.emu_assign.restype = C.c_int
     L.emu_assign.argtypes = [C.c_uint32, C.c_uint32, fp, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.emu_clip_is_empty.restype = C.c_int
+    L.emu_clip_is_empty.argtypes = [B, B]
     return L
 
 
@@ -233,3 +235,31 @@ def test_mahalanobis_scale_weights():
         total, ref, _ = dense_reference(pos, 1000000)
         assert gain + N * 1000000 == total
         np.testing.assert_array_equal(rm, ref)
+
+
+@pytest.mark.parametrize("oriented", [False, True])
+def test_clip_prefilter_only_skips_empty_intersections(oriented):
+    """sa_clip_is_empty (the positional tiles' pre-filter in the heterogeneous launch) may only fire where the reference's clip
+    returns exactly 0.0 — and it should fire for a good share of the bounding-circle neighbours, or it is useless."""
+    rng = np.random.default_rng(40 + oriented)
+    n = 300
+    a = random_boxes(rng, n, canvas=700.0, oriented=oriented)
+    b = random_boxes(rng, n, canvas=700.0, oriented=oriented)
+    # near-touching pairs: boxes placed edge to edge with gaps from 1e-9 to 1 px, the band where a wrong margin would show
+    t = a[:100].copy()
+    gap = 10.0 ** rng.uniform(-9, 0, 100)
+    t["xc"] = (a[:100]["xc"] + (a[:100]["aspect"] * a[:100]["height"] + t["aspect"] * t["height"]) / 2 + gap * rng.choice([-1, 1], 100)).astype(np.float32)
+    b[:100] = t
+    near = skipped = wrong = 0
+    B = C.POINTER(abi.sa_box)
+    for i in range(n):
+        for j in range(n):
+            pa, pb = a[i : i + 1].ctypes.data_as(B), b[j : j + 1].ctypes.data_as(B)
+            if OL.or_too_far(pa, pb):
+                continue
+            near += 1
+            if E.emu_clip_is_empty(pa, pb):
+                skipped += 1
+                wrong += OL.or_intersection(pa, pb) != 0.0
+    assert wrong == 0
+    assert skipped > 0.3 * near, (skipped, near)
