@@ -601,14 +601,9 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   // the two lane halves by one exchange, the waves stacked on each other by a 64-bit LDS minimum.  (A first version reduced every
   // accumulator register across the wave with DPP + ballot: 30 instructions per cell, 10.7 k cycles of epilogue for the
   // one-k-group tile where each lane holds 16 cells.)
-  uint32_t* s_wmax = s_key + 64 * KS;  // [16] wave maxima for the max_dist slot
-  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 16) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile + wave maxima must fit the stages");
-  auto rows_to_partials = [&](uint32_t m, bool last) {
-    if (last) {  // the waves' maxima for the max_dist slot and the column minima ride on this barrier too
-      const uint32_t wmx = wave_max_u32(kmax);
-      if (lane == 0) s_wmax[tid >> 6] = wmx;
-    }
-    __syncthreads();  // the key tile is complete
+  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile must fit the stages");
+  auto rows_to_partials = [&](uint32_t m) {
+    __syncthreads();  // the key tile (and, in the last pass, the column minima) complete
     const uint32_t nthr = blockDim.x, TPR = nthr >> 6, CPT = BN / TPR;  // threads per row, columns per thread
     const uint32_t rr = tid / TPR, seg = tid % TPR;
     const uint32_t* kp = s_key + rr * KS + seg * CPT;
@@ -665,7 +660,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       cb = ob < cb ? ob : cb;
       if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);
       SA_STAMP(tr, 6);
-      rows_to_partials(0, true);
+      rows_to_partials(0);
       SA_STAMP(tr, 7);
     }
   } else {
@@ -705,19 +700,14 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
             if (lh == 0 && (uint32_t)(b2 >> 32) != 0xffffffffu) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
           }
         }
-        rows_to_partials(m, m + 1 == TM);
+        rows_to_partials(m);
         if (m + 1 < TM) __syncthreads();  // the next pass overwrites the key tile
       }
     }
   }
   if constexpr (PART) {
-    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles), and the
-    // max_dist slot: complete since the barrier of the last row pass
-    if (tid == 0) {
-      uint32_t bmx = 0;
-      for (uint32_t w2 = 0; w2 < (blockDim.x >> 6); ++w2) bmx = s_wmax[w2] > bmx ? s_wmax[w2] : bmx;
-      S.vis_max_key[key_slot] = bmx;
-    }
+    // column partials, in k_bestfit_tile's layout with this plan's tile grid (S.CT = column tiles, S.RT = row tiles): complete
+    // since the barrier of the last row pass.  (No max_dist slot in this mode: k_bestfit_resolve compares the weights themselves.)
     for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) {
       const uint32_t gj = n0 + i;
       if (gj >= TK) continue;

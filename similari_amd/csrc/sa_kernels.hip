@@ -229,54 +229,44 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
 
 // One wave per candidate: lanes fold the CT row partials, then the RT column partials of the winning column.
 // RAW_W: the partials come from the contraction's own epilogue (visual_cosine_tile PART, bank depth 1) and hold the lightest
-// WEIGHT of a row / column inside a tile; the group weight the vote compares is W = 0.0 + f64(max_dist - w), formed here once
-// max_dist — the largest present weight of the frame, the per-tile slots folded — is known.
+// WEIGHT of a row / column inside a tile.  The vote compares W = 0.0 + f64(max_dist - w): with one observation per group that
+// is decreasing in w, so the heaviest group is the lightest weight and max_dist never has to be formed — the same reading of the
+// rounding ties as inside the tiles (see visual_cosine_tile): weights that differ by less than an ulp of the difference.
 template <bool RAW_W>
 __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t q = blockIdx.x * 4 + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (q >= S.N) return;
-  float max_dist = 0.0f;
-  if (RAW_W) {
-    uint32_t mk = 0;
-    for (uint32_t i = lane; i < S.nkeys; i += WAVE) {
-      const uint32_t v = S.vis_max_key[i];
-      mk = v > mk ? v : mk;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t ok = __shfl_xor(mk, o);
-      mk = ok > mk ? ok : mk;
-    }
-    max_dist = mk ? sa_key_f32(mk) : -1.0f;  // voting/best.rs:59: -1.0 when there is no weight at all
-  }
-  auto group_weight = [&](double part) { return RAW_W ? 0.0 + (double)(max_dist - (float)part) : part; };
-  double bw = -1.0;
+  // score: greater is better
+  auto score = [&](double part) { return RAW_W ? -part : part; };
+  const double none = RAW_W ? -__builtin_huge_val() : -1.0;
+  double bw = none;
   uint32_t bt = SA_NONE;
   for (uint32_t ct = lane; ct < S.CT; ct += WAVE) {
     const double part = S.row_part_w[(size_t)q * S.CT + ct];
     const int32_t tt = S.row_part_t[(size_t)q * S.CT + ct];
-    const double w = group_weight(part);
-    if (tt >= 0 && w > bw) { bw = w; bt = (uint32_t)tt; }  // a lane's tiles ascend with t
+    const double w = score(part);
+    if (tt >= 0 && (bt == SA_NONE || w > bw)) { bw = w; bt = (uint32_t)tt; }  // a lane's tiles ascend with t
   }
   for (int o = 32; o > 0; o >>= 1) {
     double ow = __shfl_xor(bw, o);
     uint32_t ot = __shfl_xor(bt, o);
-    if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
+    if (ot != SA_NONE && (bt == SA_NONE || ow > bw || (ow == bw && ot < bt))) { bw = ow; bt = ot; }
   }
   if (bt == SA_NONE) return;  // no group at all: the candidate goes to the positional vote (wave-uniform)
-  double cw = -1.0;
+  double cw = none;
   uint32_t cq = SA_NONE;
   for (uint32_t rt = lane; rt < S.RT; rt += WAVE) {
     const double part = S.col_part_w[(size_t)rt * S.T + bt];
     const uint32_t qq = S.col_part_q[(size_t)rt * S.T + bt];
-    const double w = group_weight(part);
-    if (qq != SA_NONE && w > cw) { cw = w; cq = qq; }  // a lane's tiles ascend with q
+    const double w = score(part);
+    if (qq != SA_NONE && (cq == SA_NONE || w > cw)) { cw = w; cq = qq; }  // a lane's tiles ascend with q
   }
   for (int o = 32; o > 0; o >>= 1) {
     double ow = __shfl_xor(cw, o);
     uint32_t oq = __shfl_xor(cq, o);
-    if (ow > cw || (ow == cw && oq < cq)) { cw = ow; cq = oq; }
+    if (oq != SA_NONE && (cq == SA_NONE || ow > cw || (ow == cw && oq < cq))) { cw = ow; cq = oq; }
   }
   if (lane == 0) {
     S.row_has[q] = 1;  // feature_winners.contains_key(q)
@@ -389,6 +379,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
   const bool has_verdict = VISUAL && q < N && S.row_has[q];
+  const int32_t vw0 = (VISUAL && q < N) ? S.vis_winner[q] : -1;  // with the first round trip, not after the scan
   // Plain SORT (with a visual vote most rows arrive decided and their lists are never read): the first four edges of the row
   // are fetched before their count is known (what lies beyond the count is stale but
   // addressable), so that this round trip — the lists were written by other XCDs a moment ago, it goes to memory — overlaps the
@@ -435,7 +426,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     if (q < N) {
       uint64_t id = 0;
       uint8_t vt = SA_VOTE_NONE;
-      int32_t vw = VISUAL ? S.vis_winner[q] : -1;
+      const int32_t vw = vw0;
       if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
       S.out_track_id[q] = id;
       S.out_vote[q] = vt;
@@ -574,7 +565,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     uint64_t id = 0;
     uint8_t vt = SA_VOTE_NONE;
     int32_t win = -1;
-    const int32_t vw = VISUAL ? S.vis_winner[q] : -1;
+    const int32_t vw = vw0;
     if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
     else if (!has_verdict) {
       int32_t c = s_rmatch[q];
