@@ -481,8 +481,8 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // PART (bank depth 1 only): instead of the N x T weight matrix the tile emits what k_bestfit_tile would derive from it — per row
 // the lightest weight over the tile's columns (lowest column on ties), per column the lightest over its rows (lowest row) — as
 // the BestFit partials k_bestfit_resolve folds.  BestFit ranks groups by W = sum_k f64(max_dist - w_k); with one observation per
-// track that is decreasing in w, so the heaviest group of a row or column inside a tile is its lightest weight and max_dist
-// (known only when every tile is done) is not needed here: the resolve kernel applies it to the handful of partials.  Where two
+// track that is decreasing in w, so the heaviest group of a row or column is its lightest weight and max_dist (known only when
+// every tile is done) is needed neither here nor in k_bestfit_resolve, which folds the partials on the weights.  Where two
 // DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
