@@ -242,7 +242,7 @@ def test_clip_prefilter_only_skips_empty_intersections(oriented):
     """sa_clip_is_empty (the positional tiles' pre-filter in the heterogeneous launch) may only fire where the reference's clip
     returns exactly 0.0 — and it should fire for a good share of the bounding-circle neighbours, or it is useless."""
     rng = np.random.default_rng(40 + oriented)
-    n = 300
+    n = 180
     a = random_boxes(rng, n, canvas=700.0, oriented=oriented)
     b = random_boxes(rng, n, canvas=700.0, oriented=oriented)
     # near-touching pairs: boxes placed edge to edge with gaps from 1e-9 to 1 px, the band where a wrong margin would show
