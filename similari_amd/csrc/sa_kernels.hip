@@ -159,13 +159,33 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
       double w = 0.0 + (double)(max_dist - x[r]);  // the reference's sum starts from 0.0
       Wr[r] = (x[r] == x[r] && 1u >= p.min_votes) ? w : -1.0;
     }
+  } else if (K <= 4) {
+    // shallow banks (the reference's benches use 3): all 16 x K loads of the lane in flight before the first sum
+    float x[16][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t q = q0 + r;
+      const bool in = q < N && t < T;
+      const float SA_G* v = S.vis + ((size_t)(in ? q : 0) * T + (in ? t : 0)) * K;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[r][k] = (in && (uint32_t)k < K) ? v[k] : __builtin_nanf("");
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      uint32_t cnt = 0;
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x[r][k] == x[r][k]) { ++cnt; w += (double)(max_dist - x[r][k]); }  // k ascending: the reference's summation order
+      Wr[r] = (cnt >= 1 && cnt >= p.min_votes) ? w : -1.0;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const uint32_t q = q0 + r;
       double W = -1.0;
       if (q < N && t < T) {
-        const float* v = S.vis + ((size_t)q * T + t) * K;
+        const float SA_G* v = S.vis + ((size_t)q * T + t) * K;
         uint32_t cnt = 0;
         double w = 0.0;
         for (uint32_t k = 0; k < K; ++k) {
