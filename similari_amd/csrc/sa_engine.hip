@@ -351,7 +351,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->c_raw = (decltype(d->c_raw))(s->raw.p); d->c_quality = (decltype(d->c_quality))(s->quality.p); d->c_own = (decltype(d->c_own))(s->own.p);
   d->c_fpresent_in = (decltype(d->c_fpresent_in))(s->fpresent_in.p); d->c_feat_raw = (decltype(d->c_feat_raw))(s->feat_raw.p);
   d->c_geo = (decltype(d->c_geo))(s->geo.p); d->c_verts = (decltype(d->c_verts))(s->verts.p); d->c_z = (decltype(d->c_z))(s->z.p);
-  d->c_conf = (decltype(d->c_conf))(s->conf.p); d->c_feat = (decltype(d->c_feat))(s->feat.p); d->c_fnorm = (decltype(d->c_fnorm))(s->fnorm.p);
+  d->c_conf = (decltype(d->c_conf))(s->conf.p); d->c_feat = (decltype(d->c_feat))((e->D == e->Dp && s->has_feats) ? s->feat_raw.p : s->feat.p); /* D == Dp: no padding, one copy */ d->c_fnorm = (decltype(d->c_fnorm))(s->fnorm.p);
   d->c_usable = (decltype(d->c_usable))(s->usable.p);
   d->pos = (decltype(d->pos))(s->pos.p); d->vis = (decltype(d->vis))(s->vis.p);
   d->vis_max_key = (decltype(d->vis_max_key))(s->vis_max_key.p);
@@ -1009,7 +1009,7 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   if (e->visual) {
     TRY(dev_ensure(e, s->bank_tmp, (size_t)n * K * e->Dp * 4));
     b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.n = n; b.K = K; b.Dp = e->Dp;
-    b.c_feat = s->has_feats ? (const float*)s->feat.p : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
+    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->feat_raw.p : s->feat.p) : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
     b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->fpresent_in.p : nullptr;
     b.c_quality = s->has_quality ? (const float*)s->quality.p : nullptr;
     b.c_own = s->has_own ? (const float*)s->own.p : nullptr;

@@ -21,19 +21,20 @@ __device__ __forceinline__ void prep_box_common(const BoxRaw& r, sa_geo* geo, do
 // One wave per feature row: zero-pad D -> Dp (Feature::from_vec, track/utils.rs:45-71; the extra zero lanes
 // add +0.0 to every sum), scatter, squared norm (the per-pair norms of distance.rs:36-44 hoisted to once
 // per vector).
-__device__ __forceinline__ void pad_feature_row(const float* __restrict__ s, float* __restrict__ d, uint32_t D, uint32_t Dp,
+__device__ __forceinline__ void pad_feature_row(const float* s, float* d, uint32_t D, uint32_t Dp,
                                                 bool pres, uint32_t lane, float* norm_out) {
   float acc = 0.0f;
+  const bool alias = d == s;  // D == Dp: the uploaded rows ARE the padded rows (the engine points c_feat at them): norms only
   if (pres && (D & 3u) == 0 && ((uintptr_t)s & 15u) == 0) {
     for (uint32_t k = lane * 4; k < Dp; k += WAVE * 4) {
       float4 x = k < D ? *(const float4*)(s + k) : float4{0.f, 0.f, 0.f, 0.f};
-      *(float4*)(d + k) = x;
+      if (!alias) *(float4*)(d + k) = x;
       acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     }
   } else {
     for (uint32_t k = lane; k < Dp; k += WAVE) {
       float x = (pres && k < D) ? s[k] : 0.0f;
-      d[k] = x;
+      if (!alias || !pres) d[k] = x;  // a row without a feature is zeroed in place (nothing reads its uploaded content)
       acc += x * x;
     }
   }
