@@ -475,6 +475,39 @@ def test_batched_scenes_match_single_scene_runs():
         eng.close()
 
 
+@pytest.mark.parametrize("k,d,flags", [(1, 64, 0), (1, 64, abi.SA_FLAG_SEPARATE_FRAME), (1, 40, 0), (3, 64, 0)],
+                         ids=["partials_fused", "partials_separate", "partials_padded", "bank3"])
+def test_batched_visual_scenes_match_single_scene_runs(k, d, flags):
+    """Scenes of different sizes in ONE set of launches (grid.z = scene): every scene has its own tile grid of BestFit partials,
+    tiles past a small scene's edge do nothing, and the answers are those of the oracle scene by scene."""
+    rng = np.random.default_rng(91 + k + d)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5, flags=flags)
+    sizes = [(150, 170), (5, 3), (257, 70), (64, 300), (1, 1)]
+    scenes = [synth.visual_scene(rng, t, n, d, k, canvas=(1200.0, 800.0), new_fraction=0.1) for n, t in sizes]
+    eng = Engine(cfg)
+    try:
+        tracks = []
+        for s, sc in enumerate(scenes):
+            tr = abi.make_tracks(sc["track_ids"] + 1000 * s, sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"],
+                                 feat_present=sc["track_present"])
+            eng.upsert(20 + s, tr)
+            tracks.append(tr)
+        eng.batch_begin()
+        dets = [abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"]) for sc in scenes]
+        slots = [eng.batch_add(20 + s, 1, dd) for s, dd in enumerate(dets)]
+        eng.batch_run()
+        eng.batch_sync()
+        for s in range(len(scenes)):
+            ids, votes = eng.batch_fetch(slots[s], dets[s].n)
+            ref = O.associate(cfg, tracks[s], 1, dets[s], want_matrices=False)
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"scene {s}")
+            np.testing.assert_array_equal(votes, ref["voting_type"], err_msg=f"scene {s}")
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("kind", ["cosine", "euclidean"])
 @pytest.mark.parametrize("n,t,d", [(100, 130, 512), (257, 129, 72), (64, 64, 33), (1, 1, 5)])
 def test_distance_matrix_vs_numpy_f64(kind, n, t, d):
