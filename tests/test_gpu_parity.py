@@ -310,6 +310,20 @@ def test_visual_cosine_parity(k, n, t, d, fused):
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 0
 
 
+def test_visual_cosine_more_than_1024_detections():
+    """N > 1024: the contraction's partials feed the resolve kernel, the positional vote goes through the many-workgroup tail, and
+    the first phase is two launches (the heterogeneous launch is for frames of at most 1024 detections)."""
+    rng = np.random.default_rng(1300)
+    sc = synth.visual_scene(rng, 900, 1100, 64, 1, canvas=(3000.0, 2000.0), new_fraction=0.15)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.5,
+                          positional_min_confidence=0.1, max_idle_epochs=5)
+    dp = (rng.uniform(size=1100) > 0.2).astype(np.uint8)   # a fifth of the detections come without a feature: positional vote
+    ids, votes, ref = check_visual(cfg, sc, det_present=dp)
+    assert (votes == abi.SA_VOTE_VISUAL).sum() > 300
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50
+
+
 def test_visual_euclid_parity():
     rng = np.random.default_rng(77)
     sc = synth.visual_scene(rng, 120, 140, 256, 3, canvas=(1500.0, 900.0), new_fraction=0.1)
