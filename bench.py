@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=50)
-    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own)")
+    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own; 64 f16-split operands on the f16 matrix cores)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate of sa_associate from host buffers")
     args = ap.parse_args()
 
@@ -310,7 +310,7 @@ def main():
         prof = {}
     else:
         cfg_p = cfg
-        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME))  # same launches as the timed pass
+        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME | abi.SA_FLAG_F16_SPLIT))  # same launches as the timed pass
         engp = Engine(cfg_p)
         keep2 = stage(engp, cfg_p, scenes)
         for _ in range(5):
@@ -377,7 +377,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16-split operands (22 bit), f32 accumulate — NOT f32 arithmetic" if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else "f32",
             "data": "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
             "config": {"workload": desc, "scenes_per_gpu": len(scenes), "pairs_per_step_per_gpu": cells,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},

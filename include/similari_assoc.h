@@ -117,6 +117,8 @@ typedef struct sa_config {
  * feature length a multiple of 32) — one dependent launch less per frame — and otherwise runs them as two launches. */
 #define SA_FLAG_FUSED_FRAME 0x10u     /* ask for the heterogeneous launch explicitly (same as the default) */
 #define SA_FLAG_SEPARATE_FRAME 0x20u  /* always two launches: the contraction runs as a kernel of its own (per-kernel measurements) */
+#define SA_FLAG_F16_SPLIT 0x40u      /* cosine contraction with f16-split operands on the f16 matrix cores (22-bit operands, f32 accumulate:
+                                         |error| < 1e-6 on a cosine, several times the f32 rate; NOT f32 arithmetic — opt-in) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
 /* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,

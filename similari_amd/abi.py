@@ -36,6 +36,7 @@ SA_FLAG_PROFILE = 0x2
 SA_FLAG_GRAPH = 0x8
 SA_FLAG_FUSED_FRAME = 0x10
 SA_FLAG_SEPARATE_FRAME = 0x20
+SA_FLAG_F16_SPLIT = 0x40
 
 
 class sa_box(C.Structure):

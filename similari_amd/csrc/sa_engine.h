@@ -183,7 +183,7 @@ hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uin
 hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                       const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
-                            const SaParams& p, hipStream_t st, bool partials);
+                            const SaParams& p, hipStream_t st, bool partials, bool f16_split);
 // heterogeneous first phase of a VisualSORT frame (contraction tiles + positional tiles + preparation blocks in one launch);
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,

@@ -87,6 +87,7 @@ struct sa_engine {
   bool descs_changed = true;
   uint32_t K = 1, D = 0, Dp = 0;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
+  bool f16_split = false;               // SA_FLAG_F16_SPLIT: the contraction's operands as f16 pairs (separate launches only)
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
@@ -395,7 +396,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
   // launch; otherwise positional tiles + preparation blocks, then the contraction
   bool fused = false;
-  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME)) {
+  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->f16_split) {
     ProfScope ps(e, KID_FRAME_VISUAL);
     bool all_feats = true;
     for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && e->slots[i]->has_feats;
@@ -406,7 +407,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   }
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
   if (e->visual) {
-    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st, e->bf_partials)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st, e->bf_partials, e->f16_split)); }
     if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
     { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, e->bf_partials ? 2 : 1)); }
   }
@@ -561,6 +562,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
   e->profile = (cfg->flags & SA_FLAG_PROFILE) != 0;
+  e->f16_split = (cfg->flags & SA_FLAG_F16_SPLIT) != 0 && cfg->visual_kind == SA_VIS_COSINE;
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else {
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1208,7 +1210,7 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
     DevBuf tmp;
     TRY(dev_ensure(e, tmp, sizeof h));
     HIPCHK(e, hipMemcpy(tmp.p, &h, sizeof h, hipMemcpyHostToDevice));
-    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, e->P, e->stream, false));
+    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, e->P, e->stream, false, e->f16_split));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     hipFree(tmp.p);
   }

@@ -245,6 +245,118 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
   SA_STAMP(tr, 2);
 }
 
+// ---- f16-split operands (SA_FLAG_F16_SPLIT) ---------------------------------------------------------------------
+// Every feature element is split, x * s = hi + lo / 2048 with hi, lo in f16 (22 bits of x; s = a power of two that brings the
+// row's norm to ~1, so that neither half leaves the f16 range), and the contraction runs as three products on the f16 matrix
+// cores — hi.hi into one f32 accumulator, hi.lo + lo.hi into a second that is scaled by 1/2048 at the end — at sixteen times the
+// rate of v_mfma_f32_32x32x2_f32.  Products of two 11-bit significands are exact in f32; what is lost against f32 operands is
+// the 2 bits below the split and the lo.lo term: < 1e-6 on a cosine (measured 4e-7 at K = 512, 9e-7 at K = 4096) against the
+// 1e-5 gate.  It is NOT f32 arithmetic, hence an option with its own dtype in the bench line.
+// The accumulators come back scaled by s_row * s_col; the caller feeds the equally scaled norms to the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float sa_pow2_scale(float nrm) {  // power of two ~ 1 / sqrt(nrm); 1 for 0 / inf / NaN
+  if (!(nrm > 0.0f) || !(nrm < 3.0e38f)) return 1.0f;
+  int e;
+  frexpf(nrm, &e);
+  return ldexpf(1.0f, -(e >> 1));
+}
+// byte offset of 16-byte slot q (8 halves of k) of row r in a [rows][32 halves] tile; the XOR spreads 8 consecutive rows over
+// 8 different 16-byte bank groups for the fragment reads
+__device__ __forceinline__ uint32_t h2_slot(uint32_t r, uint32_t q) { return r * 64u + ((q ^ ((r >> 1) & 3u)) << 4); }
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const float SA_G* an, const float SA_G* bn, uint32_t M,
+                                                 uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds_f,
+                                                 f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256, L_CH = A_CH + B_CH;
+  constexpr uint32_t STAGE = (BM + BN) * 128u;  // bytes: A_hi | A_lo | B_hi | B_lo, 64 B per row each — the f32 stage's size
+  unsigned char* lds = (unsigned char*)lds_f;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = tid >> 6, wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  const uint32_t nchunks = Dp / BK;
+  uint32_t goff[L_CH], soff[L_CH];
+  float scl[L_CH];
+#pragma unroll
+  for (int r = 0; r < L_CH; ++r) {
+    const bool isA = r < A_CH;
+    const uint32_t c = tid + 256u * (isA ? r : r - A_CH), row = c >> 3, kc = c & 7u;
+    uint32_t gr = (isA ? m0 : n0) + row;
+    const uint32_t lim = isA ? M : Ncols;
+    gr = gr < lim ? gr : lim - 1;
+    goff[r] = gr * Dp + kc * 4u;
+    soff[r] = (isA ? 0u : (uint32_t)BM * 128u) + h2_slot(row, kc >> 1) + (kc & 1u) * 8u;  // hi part; lo part at + rows * 64
+    scl[r] = sa_pow2_scale(isA ? an[gr] : bn[gr]);
+  }
+  f32x4 rg[L_CH];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int r = 0; r < L_CH; ++r) rg[r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + k0));
+  };
+  auto split_store = [&](uint32_t st) {
+    unsigned char* base = lds + st * STAGE;
+#pragma unroll
+    for (int r = 0; r < L_CH; ++r) {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = rg[r][e] * scl[r];
+        hi[e] = (_Float16)x;
+        lo[e] = (_Float16)((x - (float)hi[e]) * 2048.0f);
+      }
+      *(f16x4*)(base + soff[r]) = hi;
+      *(f16x4*)(base + soff[r] + (r < A_CH ? (uint32_t)BM : (uint32_t)BN) * 64u) = lo;
+    }
+  };
+  f32x16 accx[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.f; accx[m][n][e] = 0.f; }
+  if (nchunks > 0) { gload(0); split_store(0); }
+  if (nchunks > 1) gload(BK);
+  __syncthreads();
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const uint32_t st = c & 1u;
+    if (c + 1 < nchunks) split_store(st ^ 1u);   // chunk c+1 (in registers) -> the other stage
+    if (c + 2 < nchunks) gload((c + 2) * BK);    // chunk c+2 -> registers
+    const unsigned char* sA = lds + st * STAGE;
+    const unsigned char* sB = sA + (uint32_t)BM * 128u;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const uint32_t o = h2_slot(wm * (BM / 2) + m * 32 + lr, 2 * ks + lh);
+        ah[m] = *(const f16x8*)(sA + o);
+        al[m] = *(const f16x8*)(sA + (uint32_t)BM * 64u + o);
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const uint32_t o = h2_slot(wn * (BN / 2) + n * 32 + lr, 2 * ks + lh);
+        bh[n] = *(const f16x8*)(sB + o);
+        bl[n] = *(const f16x8*)(sB + (uint32_t)BN * 64u + o);
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accx[m][n], 0, 0, 0);
+          accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accx[m][n], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] += accx[m][n][e] * (1.0f / 2048.0f);
+}
+
 // Ring variant (KG == 0 in the kernel templates): ONE wave per SIMD, a 3-stage LDS ring, nothing left for a partner wave
 // to cover.  Used where a frame yields about one workgroup per CU (C2: 16 x 16 tiles of 64x64 on 256 CUs), so that the
 // k-group trick above would put the two waves of a SIMD behind the SAME barrier — they then stall together (measured:
@@ -486,7 +598,7 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
-template <int BM, int BN, int KGT, bool RAW, bool PART>
+template <int BM, int BN, int KGT, bool RAW, bool PART, bool H2 = false>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
   constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
@@ -498,6 +610,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   static_assert(!RAW || (TM == 1 && TN == 1 && KGT != 0), "raw mode: 64x64 tiles with k-groups");
+  static_assert(!H2 || (KGT == 1 && !RAW), "f16-split operands: one k-group, padded features with their norms");
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
@@ -526,6 +639,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       pre_us = usable ? 1.f : 0.f;
     } else {
       pre_na = S.c_fnorm[gi];
+      if constexpr (H2) { const float sc = sa_pow2_scale(pre_na); pre_na *= sc * sc; }  // the accumulators come back scaled alike
       pre_us = S.c_usable[gi] ? 1.f : 0.f;
       pre_g = sa_ldg(S.c_geo + gi);
     }
@@ -547,6 +661,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       const uint64_t te = S.t_epoch[t];
       col[n].g = sa_ldg(S.t_geo + t);
       col[n].nb = nb;
+      if constexpr (H2) { const float sc = sa_pow2_scale(nb); col[n].nb = nb * (sc * sc); }
       const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
       col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
       for (uint32_t i = 0; i < p.cons.n; ++i)
@@ -556,7 +671,8 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 
   f32x16 acc[TM][TN];
   float nsq = 0.f;
-  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+  if constexpr (H2) gemm_mainloop_h2<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, S.c_fnorm, S.t_fnorm, N, TK, S.Dp, m0, n0, lds, acc);
+  else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
   else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
 
@@ -722,12 +838,12 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   SA_STAMP(tr, 5);
 }
 
-template <int BM, int BN, int KGT, bool PART = false>
+template <int BM, int BN, int KGT, bool PART = false, bool H2 = false>
 __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  visual_cosine_tile<BM, BN, KGT, false, PART>(S, p, blockIdx.x, blockIdx.y, lds);
+  visual_cosine_tile<BM, BN, KGT, false, PART, H2>(S, p, blockIdx.x, blockIdx.y, lds);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1063,12 +1179,30 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
 }
 
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
-                            hipStream_t st, bool partials) {
+                            hipStream_t st, bool partials, bool f16_split) {
   if (!maxN || !maxTK) return hipSuccess;
   sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     int plan = tile_plan(maxN, maxTK, ns, Dp);
+    if (f16_split) {  // one k-group per tile; the k-group and ring plans run as the plain plan of their tile size
+      const dim3 g128x128(cdiv(maxTK, 128), cdiv(maxN, 128), ns), g64x128(cdiv(maxTK, 128), cdiv(maxN, 64), ns),
+          g128x64(cdiv(maxTK, 64), cdiv(maxN, 128), ns), g64x64(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
+      if (plan == 0 || plan == 8) {
+        if (partials) SA_LAUNCH((k_visual_cosine<128, 128, 1, true, true>), g128x128, dim3(256), 0, st, scenes, p);
+        else SA_LAUNCH((k_visual_cosine<128, 128, 1, false, true>), g128x128, dim3(256), 0, st, scenes, p);
+      } else if (plan == 5) {
+        if (partials) SA_LAUNCH((k_visual_cosine<64, 128, 1, true, true>), g64x128, dim3(256), 0, st, scenes, p);
+        else SA_LAUNCH((k_visual_cosine<64, 128, 1, false, true>), g64x128, dim3(256), 0, st, scenes, p);
+      } else if (plan == 6) {
+        if (partials) SA_LAUNCH((k_visual_cosine<128, 64, 1, true, true>), g128x64, dim3(256), 0, st, scenes, p);
+        else SA_LAUNCH((k_visual_cosine<128, 64, 1, false, true>), g128x64, dim3(256), 0, st, scenes, p);
+      } else {
+        if (partials) SA_LAUNCH((k_visual_cosine<64, 64, 1, true, true>), g64x64, dim3(256), 0, st, scenes, p);
+        else SA_LAUNCH((k_visual_cosine<64, 64, 1, false, true>), g64x64, dim3(256), 0, st, scenes, p);
+      }
+      return hipGetLastError();
+    }
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {

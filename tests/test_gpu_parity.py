@@ -324,6 +324,24 @@ def test_visual_cosine_more_than_1024_detections():
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50
 
 
+@pytest.mark.parametrize("k,n,t,d", [(1, 150, 170, 512), (3, 129, 257, 36), (1, 300, 280, 64), (1, 70, 33, 100), (2, 600, 900, 256)])
+def test_visual_cosine_f16_split_operands(k, n, t, d):
+    """SA_FLAG_F16_SPLIT: the contraction on the f16 matrix cores with every operand split into two f16 halves (22 bits) — not
+    f32 arithmetic, but inside the same 1e-5 gate on the distances (measured < 1e-6), with the same votes as the oracle."""
+    rng = np.random.default_rng(2000 + n + t + d + k)
+    sc = synth.visual_scene(rng, t, n, d, k, canvas=(1500.0, 900.0), new_fraction=0.1)
+    pres = sc["track_present"]
+    pres[rng.uniform(size=pres.shape) < 0.15] = 0
+    # rows of very different magnitude: the split scales every row by a power of two first
+    sc["track_feats"] = (sc["track_feats"] * (10.0 ** rng.uniform(-3, 3, size=(t, 1, 1)))).astype(np.float32)
+    sc["det_feats"] = (sc["det_feats"] * (10.0 ** rng.uniform(-3, 3, size=(n, 1)))).astype(np.float32)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.55,
+                          positional_min_confidence=0.1, max_idle_epochs=5, flags=abi.SA_FLAG_F16_SPLIT)
+    ids, votes, ref = check_visual(cfg, sc)
+    assert (votes == abi.SA_VOTE_VISUAL).sum() > 0
+
+
 def test_visual_euclid_parity():
     rng = np.random.default_rng(77)
     sc = synth.visual_scene(rng, 120, 140, 256, 3, canvas=(1500.0, 900.0), new_fraction=0.1)
@@ -567,6 +585,20 @@ def test_every_tile_plan_of_the_contraction(plan, n, t, d, monkeypatch):
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
                           max_observations=2, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
                           max_idle_epochs=5)
+    check_visual(cfg, sc)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+@pytest.mark.parametrize("plan", [0, 1, 5, 6])
+def test_f16_split_tile_plans(plan, k, monkeypatch):
+    """The f16-split contraction in each of its tile shapes (128x128, 64x64, 64x128, 128x64), emitting the weight matrix (k = 2)
+    or the BestFit partials (k = 1), ragged edges included."""
+    monkeypatch.setenv("SA_GEMM_PLAN", str(plan))
+    n, t, d = 300, 333, 160
+    sc = synth.visual_scene(np.random.default_rng(30 + plan + k), t, n, d, k, canvas=(1500.0, 900.0), new_fraction=0.1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5, flags=abi.SA_FLAG_F16_SPLIT)
     check_visual(cfg, sc)
 
 
