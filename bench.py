@@ -29,6 +29,7 @@ from similari_amd import abi, synth  # noqa: E402
 DEFAULT_FLAGS = 0            # engine flags of the timed pass
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md); the f16-split option issues 3 products per flop
 
 
 def workload(name: str, seed: int):
@@ -344,8 +345,11 @@ def main():
             dur_s = kern[dom]["avg_us"] * 1e-6
             if bound == "mfma":
                 a = per_launch / dur_s / 1e12
-                roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+                mfma_peak = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
+                roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": a / mfma_peak, "traffic": None}
+                if cfg.flags & abi.SA_FLAG_F16_SPLIT:
+                    roof["peak_note"] = "f16 MFMA dense peak / 3: the f16-split contraction issues three f16 products per algorithmic product"
             else:
                 a = per_launch / dur_s / 1e9
                 roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -365,7 +369,8 @@ def main():
             if k in kern and kern[k]["avg_us"] > 0:
                 per_launch = amount * args.profile_iters / prof[k][0]
                 rate = per_launch / (kern[k]["avg_us"] * 1e-6)
-                kern[k]["roofline_frac"] = rate / 1e12 / MFMA_F32_PEAK_TFLOPS if bound == "mfma" else rate / 1e9 / HBM_PEAK_GBS
+                mp = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
+                kern[k]["roofline_frac"] = rate / 1e12 / mp if bound == "mfma" else rate / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "assoc-pairs/sec (NxM cost+assign) VisualSORT 512-d",
             "value": total_cells * args.steps / dt,

@@ -296,12 +296,19 @@ __device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const f
     unsigned char* base = lds + st * STAGE;
 #pragma unroll
     for (int r = 0; r < L_CH; ++r) {
+      // two elements per instruction where the ISA has it: packed f32 multiply / subtract, packed f32 -> f16 conversion.  (The
+      // split is the VALU cost of this kernel: with scalar conversions the main loop was VALU-bound, not matrix-core-bound.)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
       f16x4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = rg[r][e] * scl[r];
-        hi[e] = (_Float16)x;
-        lo[e] = (_Float16)((x - (float)hi[e]) * 2048.0f);
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 x = f32x2{rg[r][e], rg[r][e + 1]} * scl[r];
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 back = __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector((x - back) * 2048.0f, f16x2);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
       }
       *(f16x4*)(base + soff[r]) = hi;
       *(f16x4*)(base + soff[r] + (r < A_CH ? (uint32_t)BM : (uint32_t)BN) * 64u) = lo;
