@@ -261,9 +261,11 @@ __device__ __forceinline__ float sa_pow2_scale(float nrm) {  // power of two ~ 1
   frexpf(nrm, &e);
   return ldexpf(1.0f, -(e >> 1));
 }
-// byte offset of 16-byte slot q (8 halves of k) of row r in a [rows][32 halves] tile; the XOR spreads 8 consecutive rows over
-// 8 different 16-byte bank groups for the fragment reads
-__device__ __forceinline__ uint32_t h2_slot(uint32_t r, uint32_t q) { return r * 64u + ((q ^ ((r >> 1) & 3u)) << 4); }
+// byte offset of 16-byte slot q (8 halves of k) of row r in a [rows][32 halves] tile.  A 64-byte row covers a quarter of the 64
+// banks and rows r, r + 4, r + 8, r + 12 share that quarter: the XOR with (r >> 2) & 3 gives those four rows four different
+// slots, so that the 16 rows a fragment read touches at a time cover all 64 banks (with (r >> 1) & 3 — the f32 tile's pattern,
+// whose rows are 128 bytes — rows r and r + 8 collided: SQ_LDS_BANK_CONFLICT a third of the LDS cycles)
+__device__ __forceinline__ uint32_t h2_slot(uint32_t r, uint32_t q) { return r * 64u + ((q ^ ((r >> 2) & 3u)) << 4); }
 template <int BM, int BN>
 __device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const float SA_G* an, const float SA_G* bn, uint32_t M,
                                                  uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds_f,
@@ -321,40 +323,50 @@ __device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const f
     for (int n = 0; n < TN; ++n)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.f; accx[m][n][e] = 0.f; }
-  if (nchunks > 0) { gload(0); split_store(0); }
-  if (nchunks > 1) gload(BK);
-  __syncthreads();
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const uint32_t st = c & 1u;
-    if (c + 1 < nchunks) split_store(st ^ 1u);   // chunk c+1 (in registers) -> the other stage
-    if (c + 2 < nchunks) gload((c + 2) * BK);    // chunk c+2 -> registers
+  // One barrier per 32-deep chunk, between its two 16-deep k-steps (the f32 loop's arrangement, §3 item 7): the first k-step
+  // runs on fragments fetched during the previous iteration while this one splits and stores chunk c+1 and fetches the second
+  // k-step's fragments; after the barrier the second k-step runs while the first fragments of chunk c+1 and the global rows of
+  // chunk c+2 are fetched.
+  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+  auto frags = [&](int set, uint32_t st, uint32_t ks) {
     const unsigned char* sA = lds + st * STAGE;
     const unsigned char* sB = sA + (uint32_t)BM * 128u;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    for (int m = 0; m < TM; ++m) {
+      const uint32_t o = h2_slot(wm * (BM / 2) + m * 32 + lr, 2 * ks + lh);
+      ah[set][m] = *(const f16x8*)(sA + o);
+      al[set][m] = *(const f16x8*)(sA + (uint32_t)BM * 64u + o);
+    }
 #pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        const uint32_t o = h2_slot(wm * (BM / 2) + m * 32 + lr, 2 * ks + lh);
-        ah[m] = *(const f16x8*)(sA + o);
-        al[m] = *(const f16x8*)(sA + (uint32_t)BM * 64u + o);
-      }
+    for (int n = 0; n < TN; ++n) {
+      const uint32_t o = h2_slot(wn * (BN / 2) + n * 32 + lr, 2 * ks + lh);
+      bh[set][n] = *(const f16x8*)(sB + o);
+      bl[set][n] = *(const f16x8*)(sB + (uint32_t)BN * 64u + o);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const uint32_t o = h2_slot(wn * (BN / 2) + n * 32 + lr, 2 * ks + lh);
-        bh[n] = *(const f16x8*)(sB + o);
-        bl[n] = *(const f16x8*)(sB + (uint32_t)BN * 64u + o);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
+        accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bl[set][n], accx[m][n], 0, 0, 0);
+        accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][m], bh[set][n], accx[m][n], 0, 0, 0);
       }
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-          accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accx[m][n], 0, 0, 0);
-          accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accx[m][n], 0, 0, 0);
-        }
-    }
+  };
+  if (nchunks > 0) { gload(0); split_store(0); }
+  if (nchunks > 1) gload(BK);
+  __syncthreads();
+  if (nchunks > 0) frags(0, 0, 0);
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const uint32_t st = c & 1u;
+    if (c + 1 < nchunks) split_store(st ^ 1u);   // chunk c+1 (in registers) -> the other stage
+    frags(1, st, 1);
+    mfmas(0);
     __syncthreads();
+    if (c + 2 < nchunks) gload((c + 2) * BK);    // chunk c+2 -> registers
+    if (c + 1 < nchunks) frags(0, st ^ 1u, 0);
+    mfmas(1);
   }
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -845,12 +857,42 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   SA_STAMP(tr, 5);
 }
 
+// Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin in launch order (block b -> XCD b % 8, observed;
+// MI355X_MICROARCH.md), every XCD has its own 4 MB L2, and the operands of a big frame (C5: 32 MB of candidates, 82 MB of bank)
+// are re-read by every tile that shares a row or a column panel.  With tiles numbered row by row, the ~100 tiles an XCD holds at
+// any time touch a dozen candidate panels and every bank panel: the L2s thrash and the contraction pulls ~9.7 TB/s through the
+// fabric (f16-split operands at C5: bound by exactly that).  Here each XCD gets a CONTIGUOUS stretch of a band order instead —
+// bands of `band` tile rows, walked column by column — so its tiles share one small set of candidate panels that stays in its L2
+// while the bank streams through once per band.
+__device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t band, uint32_t* bx, uint32_t* by) {
+  const uint32_t n = gx * gy, L = blockIdx.x + gx * blockIdx.y;
+  const uint32_t x = L & 7u, j = L >> 3;
+  const uint32_t i = x * (n >> 3) + (x < (n & 7u) ? x : (n & 7u)) + j;  // XCD x owns [start_x, start_x + count_x) of the band order
+  const uint32_t per_band = band * gx;
+  const uint32_t b = i / per_band, i2 = i - b * per_band;
+  const uint32_t rows = (b + 1) * band <= gy ? band : gy - b * band;       // the last band may be shorter
+  *bx = i2 / rows;
+  *by = b * band + i2 % rows;
+}
+// f16-split operands: the matrix instructions are short (32 cycles) and there is more load / store work between them than in the
+// f32 loop, so two waves per SIMD leave the matrix pipe idle 70 % of the time; the register cap buys a third.
+template <int BM, int BN, bool PART>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_visual_cosine_h2(const SceneDev* __restrict__ scenes, SaParams p,
+                                                                                                      uint32_t band) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  const SceneDev S = scenes[blockIdx.z];
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
+  visual_cosine_tile<BM, BN, 1, false, PART, true>(S, p, bx, by, lds);
+}
 template <int BM, int BN, int KGT, bool PART = false, bool H2 = false>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  visual_cosine_tile<BM, BN, KGT, false, PART, H2>(S, p, blockIdx.x, blockIdx.y, lds);
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
+  visual_cosine_tile<BM, BN, KGT, false, PART, H2>(S, p, bx, by, lds);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1192,44 +1234,60 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     int plan = tile_plan(maxN, maxTK, ns, Dp);
+    // band height of the XCD-aware tile order (xcd_tile): the candidate panels of a band should fit an XCD's L2 beside the bank
+    // panels streaming through (~2 MB of the 4); 0 = row-by-row order (small frames: everything fits anyway).  SA_GEMM_BAND overrides.
+    uint32_t band = 0;
+    {
+      const uint32_t bm = (plan == 0 || plan == 8 || plan == 6) ? 128u : 64u;
+      const uint32_t gy = cdiv(maxN, bm);
+      const size_t panel = (size_t)bm * Dp * 4;
+      if ((size_t)maxN * Dp * 4 + (size_t)maxTK * Dp * 4 > (8u << 20) && gy >= 2) {
+        uint32_t r = (uint32_t)((2u << 20) / (panel ? panel : 1));
+        r = r < 1 ? 1 : r;
+        const uint32_t even = gy / 8 ? gy / 8 : 1;
+        band = r < even ? r : even;
+      }
+      static const char* env = getenv("SA_GEMM_BAND");
+      if (env) band = (uint32_t)atoi(env);
+    }
     if (f16_split) {  // one k-group per tile; the k-group and ring plans run as the plain plan of their tile size
       const dim3 g128x128(cdiv(maxTK, 128), cdiv(maxN, 128), ns), g64x128(cdiv(maxTK, 128), cdiv(maxN, 64), ns),
           g128x64(cdiv(maxTK, 64), cdiv(maxN, 128), ns), g64x64(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
       if (plan == 0 || plan == 8) {
-        if (partials) SA_LAUNCH((k_visual_cosine<128, 128, 1, true, true>), g128x128, dim3(256), 0, st, scenes, p);
-        else SA_LAUNCH((k_visual_cosine<128, 128, 1, false, true>), g128x128, dim3(256), 0, st, scenes, p);
+        if (partials) SA_LAUNCH((k_visual_cosine_h2<128, 128, true>), g128x128, dim3(256), 0, st, scenes, p, band);
+        else SA_LAUNCH((k_visual_cosine_h2<128, 128, false>), g128x128, dim3(256), 0, st, scenes, p, band);
       } else if (plan == 5) {
-        if (partials) SA_LAUNCH((k_visual_cosine<64, 128, 1, true, true>), g64x128, dim3(256), 0, st, scenes, p);
-        else SA_LAUNCH((k_visual_cosine<64, 128, 1, false, true>), g64x128, dim3(256), 0, st, scenes, p);
+        if (partials) SA_LAUNCH((k_visual_cosine_h2<64, 128, true>), g64x128, dim3(256), 0, st, scenes, p, band);
+        else SA_LAUNCH((k_visual_cosine_h2<64, 128, false>), g64x128, dim3(256), 0, st, scenes, p, band);
       } else if (plan == 6) {
-        if (partials) SA_LAUNCH((k_visual_cosine<128, 64, 1, true, true>), g128x64, dim3(256), 0, st, scenes, p);
-        else SA_LAUNCH((k_visual_cosine<128, 64, 1, false, true>), g128x64, dim3(256), 0, st, scenes, p);
+        if (partials) SA_LAUNCH((k_visual_cosine_h2<128, 64, true>), g128x64, dim3(256), 0, st, scenes, p, band);
+        else SA_LAUNCH((k_visual_cosine_h2<128, 64, false>), g128x64, dim3(256), 0, st, scenes, p, band);
       } else {
-        if (partials) SA_LAUNCH((k_visual_cosine<64, 64, 1, true, true>), g64x64, dim3(256), 0, st, scenes, p);
-        else SA_LAUNCH((k_visual_cosine<64, 64, 1, false, true>), g64x64, dim3(256), 0, st, scenes, p);
+        if (partials) SA_LAUNCH((k_visual_cosine_h2<64, 64, true>), g64x64, dim3(256), 0, st, scenes, p, band);
+        else SA_LAUNCH((k_visual_cosine_h2<64, 64, false>), g64x64, dim3(256), 0, st, scenes, p, band);
       }
       return hipGetLastError();
     }
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {
-        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
-        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
+        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
+        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
+        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p, band); break;
+        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
       }
       return hipGetLastError();
     }
     switch (plan) {
-      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
-      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
-      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p, band); break;
+      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p, band); break;
+      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
     }
   } else {
     SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
