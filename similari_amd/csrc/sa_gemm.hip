@@ -1234,19 +1234,10 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     int plan = tile_plan(maxN, maxTK, ns, Dp);
-    // band height of the XCD-aware tile order (xcd_tile): the candidate panels of a band should fit an XCD's L2 beside the bank
-    // panels streaming through (~2 MB of the 4); 0 = row-by-row order (small frames: everything fits anyway).  SA_GEMM_BAND overrides.
+    // band height of the XCD-aware tile order (xcd_tile); 0 = tiles in row order.  Measured at C5 with bands of 1, 2 and 4 tile rows:
+    // no difference for either contraction (the working set sits in the Infinity Cache), so row order stays the default.
     uint32_t band = 0;
     {
-      const uint32_t bm = (plan == 0 || plan == 8 || plan == 6) ? 128u : 64u;
-      const uint32_t gy = cdiv(maxN, bm);
-      const size_t panel = (size_t)bm * Dp * 4;
-      if ((size_t)maxN * Dp * 4 + (size_t)maxTK * Dp * 4 > (8u << 20) && gy >= 2) {
-        uint32_t r = (uint32_t)((2u << 20) / (panel ? panel : 1));
-        r = r < 1 ? 1 : r;
-        const uint32_t even = gy / 8 ? gy / 8 : 1;
-        band = r < even ? r : even;
-      }
       static const char* env = getenv("SA_GEMM_BAND");
       if (env) band = (uint32_t)atoi(env);
     }
