@@ -122,6 +122,94 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
 // CU that way — fewer, longer-lived blocks amortise the fixed cost of a block (C4: 62 500 blocks of 16 x 64 took 25 us, 1000
 // blocks of 16 x 256 take 15) — else 1 (16 x 64 cells, 64 clip lanes), which keeps every CU busy on small or dense frames
 // where the clip rounds, not the pre-filter, set the time (C2: ~60 surviving pairs per candidate).
+// LDS written by some lanes of a wave and read by others of the SAME wave: program order is enough for the hardware (one
+// wave's DS operations complete in order); the fences keep the compiler from reordering across the hand-over.
+#define SA_WAVE_LDS_SYNC()                                   \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+// sa_clip_area_ws (sa_device.h) spread over L lanes per pair: the same Sutherland–Hodgman passes and the same shoelace sum, value
+// for value and in the same order, but L vertices of a pass are tested (and their crossings computed) side by side, one per lane.
+// A lone wave issues a dependent instruction every 8-9 cycles, so the serial clip's time is its step count (ten two-vertex steps
+// of ~100 instructions for an axis-aligned pair); with four lanes per pair the 64 pairs of a crowded tile occupy all four waves
+// and a pass is one or two steps.  Output positions come from two ballots (which lanes emit a crossing, which keep their
+// vertex): vertex j writes [crossing,] [itself] after everything lanes < j emit — the sequential order.  subj is indexed by lane
+// (keep it in LDS, not in registers); clip is indexed statically.  ws = this group's LDS: two ping-pong lists of SA_POLY_CAP
+// (x, y) pairs.  l = lane within the group, gshift = position of the group's lane 0 within the wave.  Every lane returns the area.
+template <int L>
+__device__ __forceinline__ double clip_area_lanes(const double* subj, const double* clip, double* ws, uint32_t l, uint32_t gshift) {
+  double* px = ws;
+  double* py = ws + SA_POLY_CAP;
+  double* qx = ws + 2 * SA_POLY_CAP;
+  double* qy = ws + 3 * SA_POLY_CAP;
+  for (uint32_t v = l; v < 4; v += L) { px[v] = subj[2 * v]; py[v] = subj[2 * v + 1]; }
+  SA_WAVE_LDS_SYNC();
+  uint32_t n = 4;
+  const uint32_t below = (1u << l) - 1u, gmask = (1u << L) - 1u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = i == 0 ? 3 : i - 1;
+    const double csx = clip[2 * ii], csy = clip[2 * ii + 1];
+    const double cex = clip[2 * i], cey = clip[2 * i + 1];
+    const double dpx = csx - cex, dpy = csy - cey;
+    const double n2 = csx * cey - csy * cex;
+    uint32_t m = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += L) {
+      const uint32_t j = c0 + l;
+      const bool act = j < n;
+      const uint32_t jp = j == 0 ? n - 1 : j - 1;
+      double sex = 0.0, sey = 0.0, ssx = 0.0, ssy = 0.0;
+      if (act) { sex = px[j]; sey = py[j]; ssx = px[jp]; ssy = py[jp]; }
+      const bool in_e = act && ((cex - csx) * (sey - csy) - (cey - csy) * (sex - csx)) <= 0.0;
+      const bool in_s = act && ((cex - csx) * (ssy - csy) - (cey - csy) * (ssx - csx)) <= 0.0;
+      const bool cross = in_e != in_s;
+      const uint32_t gc = (uint32_t)(__ballot(cross) >> gshift) & gmask;
+      const uint32_t ge = (uint32_t)(__ballot(in_e) >> gshift) & gmask;
+      uint32_t off = m + __popc(gc & below) + __popc(ge & below);
+      // compute_intersection(cp1 = s_edge_start, cp2 = s_edge_end, s = c_edge_start, e = c_edge_end)  clipping.rs:17-38
+      const double dcx = ssx - sex, dcy = ssy - sey;
+      const double n1 = ssx * sey - ssy * sex;
+      const double n3 = 1.0 / (dcx * dpy - dcy * dpx);
+      const double ix = (n1 * dpx - n2 * dcx) * n3, iy = (n1 * dpy - n2 * dcy) * n3;
+      if (cross) {
+        if (off < SA_POLY_CAP) { qx[off] = ix; qy[off] = iy; }
+        ++off;
+      }
+      if (in_e && off < SA_POLY_CAP) { qx[off] = sex; qy[off] = sey; }
+      m += __popc(gc) + __popc(ge);
+    }
+    n = m < SA_POLY_CAP ? m : SA_POLY_CAP;
+    double* t = px; px = qx; qx = t;
+    t = py; py = qy; qy = t;
+    SA_WAVE_LDS_SYNC();
+  }
+  if (n == 0) return 0.0;
+  // Polygon::new closes the ring unless first == last; < 3 coordinates -> 0; shoelace with the first vertex as the shift
+  const double shx = px[0], shy = py[0];
+  const bool closed = shx == px[n - 1] && shy == py[n - 1];
+  const uint32_t mm = closed ? n : n + 1;
+  if (mm < 3) return 0.0;
+  // the terms side by side (qx is free now), the sum in the reference's order by every lane
+  for (uint32_t c0 = 0; c0 + 1 < mm; c0 += L) {
+    const uint32_t i = c0 + l;
+    if (i + 1 < mm) {
+      const uint32_t i1 = (i + 1 == n) ? 0 : i + 1;
+      const double x0 = px[i] - shx, y0 = py[i] - shy;
+      const double x1 = px[i1] - shx, y1 = py[i1] - shy;
+      qx[i] = x0 * y1 - y0 * x1;
+    }
+  }
+  SA_WAVE_LDS_SYNC();
+  double tmp = 0.0;
+  for (uint32_t i = 0; i + 1 < mm; ++i) tmp = tmp + qx[i];
+  SA_WAVE_LDS_SYNC();  // the lists are reused by the group's next clip
+  const double area = tmp / (1.0 + 1.0);
+  return fabs(area);
+}
+
 #define POS_TI 16
 // UNION: also fold each edge into the row dual and the global union-find forest (needed by the many-workgroup assignment
 // tail).  When the whole scene is solved by ONE workgroup (k_assign_small) that workgroup builds both from the edge lists in
@@ -144,7 +232,7 @@ struct PosSmem {
 // for 60, so proofs alone make it worse (24.6 us).  There the tiles are 16 x 128 (~120 surviving pairs): the threads of two
 // waves prove what they can and the ~25 pairs that are left take ONE clip round where two 16 x 64 tiles took two: 21.2 us.
 // (16 x 192 and 16 x 256 tiles: 25 us — the tile itself then outlasts the contraction.)
-template <bool DENSE, bool EDGES, int NSUB, bool UNION, bool PROOF = false, int WORKERS = 64>
+template <bool DENSE, bool EDGES, int NSUB, bool UNION, bool PROOF = false, int WORKERS = 64, bool COOP = false>
 __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem, uint32_t tid) {
   constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = (uint32_t)WORKERS;
   const uint32_t N = S.N, T = S.T;
@@ -257,6 +345,29 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
 #pragma unroll
       for (int k = 0; k < 5; ++k) z5[k] = s_cz[li][k];
       emit(i, j, sa_maha_cell(m20, z5, s_cconf[li]), true);
+    }
+  } else if (COOP) {
+    // four lanes per pair (clip_area_lanes): 64 pairs at a time over the four waves; the vertex lists are the same 24 KB
+    const uint32_t grp = tid >> 2, gl = tid & 3u, gshift = lane & 60u;
+    double* ws = s_poly + grp * (4 * SA_POLY_CAP);
+    for (uint32_t sidx = grp; sidx < cnt; sidx += 64) {
+      const uint32_t c = s_list[sidx];
+      const uint32_t li = c >> 8, lj = c & 255u;
+      const uint32_t i = i0 + li, j = j0 + lj;
+      double tv[8];
+      const double SA_G* tp = S.t_verts + (size_t)j * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tv[k] = tp[k];
+      const double inter = clip_area_lanes<4>(s_cv[li], tv, ws, gl, gshift);
+      if (gl == 0) {
+        float iou, out = nanv;
+        bool present = false;
+        if (sa_iou_from_area(inter, s_cg[li].hha, s_thha[lj], &iou)) {
+          const float e = iou * s_cconf[li];
+          if (e >= p.positional_threshold) { out = e; present = true; }
+        }
+        emit(i, j, out, present);
+      }
     }
   } else if (tid < POS_WORKERS) {
     // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS

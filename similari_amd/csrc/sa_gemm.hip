@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // preparation blocks (short) before the positional tiles (long): the tiles alone fill every slot the contraction leaves, and
   // preparation blocks queued behind them started only when the first tiles retired — the last thing to finish in the launch
   if (unit < nprep) frame_prep_block(S, p, unit, tid);
-  else if (unit - nprep < px * py) positional_tile<false, true, 2, false, true, 64>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+  else if (unit - nprep < px * py) positional_tile<false, true, 2, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
 #ifdef SA_GEMM_TRACE
   if (tr2 && threadIdx.x == 0) tr2[5] = __builtin_amdgcn_s_memtime();
 #endif

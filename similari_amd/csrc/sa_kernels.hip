@@ -86,7 +86,7 @@ template <int NSUB, bool UNION>
 __global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
-  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, false, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
   else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.
