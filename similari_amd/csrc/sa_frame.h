@@ -203,8 +203,14 @@ __device__ __forceinline__ double clip_area_lanes(const double* subj, const doub
     }
   }
   SA_WAVE_LDS_SYNC();
+  // all SA_POLY_CAP slots are fetched at once (one LDS latency instead of one per term); a slot past the last term adds +0.0,
+  // which leaves every partial sum as it was except -0.0 -> +0.0, and the fabs below does not see that
+  double term[SA_POLY_CAP];
+#pragma unroll
+  for (int i = 0; i < SA_POLY_CAP; ++i) term[i] = qx[i];
   double tmp = 0.0;
-  for (uint32_t i = 0; i + 1 < mm; ++i) tmp = tmp + qx[i];
+#pragma unroll
+  for (int i = 0; i < SA_POLY_CAP; ++i) tmp = tmp + ((uint32_t)i + 1 < mm ? term[i] : 0.0);
   SA_WAVE_LDS_SYNC();  // the lists are reused by the group's next clip
   const double area = tmp / (1.0 + 1.0);
   return fabs(area);
