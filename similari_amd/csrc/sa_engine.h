@@ -83,10 +83,12 @@ struct SceneDev {
   float SA_G* vis;
   // BestFit vote
   uint32_t SA_G* vis_max_key;   // [nkeys] order-preserving key of the largest present weight per cost-kernel workgroup (0 = none)
-  double SA_G* row_part_w;   // [N][CT] best weight of the row inside column tile ct (-1 = none)
-  int32_t SA_G* row_part_t;  // [N][CT]
+  double SA_G* row_part_w;   // [CT][N] best weight of the row inside column tile ct (-1 = none)
+  int32_t SA_G* row_part_t;  // [CT][N]
   double SA_G* col_part_w;   // [RT][T] best weight of the column inside row tile rt
   uint32_t SA_G* col_part_q; // [RT][T] lowest row attaining it
+  unsigned long long SA_G* row_best;  // [SA_SMALL_N] vote words (SaParams::vote_words): min over the row of (weight key << 32 | column); all ones = none
+  unsigned long long SA_G* col_best;  // [SA_SMALL_N] min over the column of (weight key << 32 | row)
   uint8_t SA_G* row_has;
   int32_t SA_G* vis_winner;
   uint8_t SA_G* col_excluded;
@@ -138,6 +140,8 @@ struct SaParams {
   uint32_t Dp;                  // feature row stride of this engine (D rounded up to 32)
   uint64_t max_idle;
   sa_constraints cons;
+  uint32_t vote_words;          // per launch: the contraction's BestFit epilogue reduces into row_best / col_best (64-bit atomic minima)
+                                // instead of writing per-tile partials; the one-workgroup tail reads and re-arms them
 };
 
 // Profile mode (SA_FLAG_PROFILE): while sa_prof_start is set, the per-frame launches go through hipExtLaunchKernelGGL,

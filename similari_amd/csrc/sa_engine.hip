@@ -56,7 +56,7 @@ struct Slot {  // one scene of the current batch
   DevBuf geo, verts, z, conf, usable, feat, fnorm;
   // matrices + vote + assignment state
   DevBuf pos, vis, quant;
-  DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded;
+  DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
   HostBuf h_apply, h_pred;
@@ -301,6 +301,11 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->col_part_w, RT * t * 8));
     TRY(dev_ensure(e, s->col_part_q, RT * t * 4));
   }
+  {
+    void* before = s->vote_best.p;
+    TRY(dev_ensure(e, s->vote_best, 2 * SA_SMALL_N * 8));
+    if (s->vote_best.p != before) s->needs_init = true;
+  }
   TRY(dev_ensure(e, s->row_has, n));
   TRY(dev_ensure(e, s->vis_winner, n * 4));
   TRY(dev_ensure(e, s->col_excluded, t));
@@ -358,6 +363,7 @@ void fill_scene_dev(sa_engine* e, Slot* s, SceneDev* d) {
   d->vis_max_key = (decltype(d->vis_max_key))(s->vis_max_key.p);
   d->row_part_w = (decltype(d->row_part_w))(s->row_part_w.p); d->row_part_t = (decltype(d->row_part_t))(s->row_part_t.p);
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
+  d->row_best = (decltype(d->row_best))(s->vote_best.p); d->col_best = (decltype(d->col_best))((unsigned long long*)s->vote_best.p + SA_SMALL_N);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
   d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
   d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_edge = (decltype(d->e_edge))(s->e_edge.p);
@@ -393,6 +399,20 @@ int upload_scene_descs(sa_engine* e) {
 // the side stream between two events).  Also the body of the captured graph.
 int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
   hipStream_t st = e->stream;
+  // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
+  // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own, SA_RESOLVE=fold folds it into the one-workgroup tail
+  // with the per-tile partials (measured: no gain, the fold's loads cost one CU what the launch cost)
+  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
+  static const bool fold_partials = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "fold");
+  const bool small_tail = maxN <= SA_SMALL_N && !force_general;
+  // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
+  // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
+  // tail reads its two words per thread — the resolve launch disappears
+  const bool words = e->visual && e->bf_partials && small_tail && maxT <= SA_SMALL_N && !separate_resolve && !fold_partials;
+  const bool folded = words || (e->visual && small_tail && maxT <= SA_SMALL_N && fold_partials);
+  SaParams P = e->P;
+  P.vote_words = words ? 1u : 0u;
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
   // launch; otherwise positional tiles + preparation blocks, then the contraction
   bool fused = false;
@@ -400,25 +420,23 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
     ProfScope ps(e, KID_FRAME_VISUAL);
     bool all_feats = true;
     for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && e->slots[i]->has_feats;
-    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, e->P, st, e->bf_partials) : hipErrorNotSupported;
+    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, e->bf_partials) : hipErrorNotSupported;
     if (fe == hipSuccess) fused = true;
     else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
     else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
-  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, e->P, st)); }
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
   if (e->visual) {
-    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, e->P, st, e->bf_partials, e->f16_split)); }
-    if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, 0)); }
-    { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, e->P, st, e->bf_partials ? 2 : 1)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, e->bf_partials, e->f16_split)); }
+    if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
   }
-  // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle)
-  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-  if (maxN <= SA_SMALL_N && !force_general) {
+  if (e->visual && !folded) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, e->bf_partials ? 2 : 1)); }
+  if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
-    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 5));
+    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : folded ? (e->bf_partials ? 7 : 6) : 5));
   } else {
-    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 1)); }
-    { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, e->P, st, 3)); }
+    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
+    { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }
   }
   return SA_OK;
 }
@@ -446,6 +464,7 @@ int run_pipeline(sa_engine* e) {
     if (!s->needs_init) continue;
     HIPCHK(e, sa_launch_slot_init((uint32_t*)s->e_cnt.p, (int64_t*)s->u.p, (uint32_t)(s->e_cnt.cap / 4 < s->u.cap / 8 ? s->e_cnt.cap / 4 : s->u.cap / 8),
                                   (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
+    HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, 2 * SA_SMALL_N * 8, st));  // vote words: all ones = no group
     s->needs_init = false;
     e->descs_changed = true;  // a captured graph must not skip this
   }
@@ -589,6 +608,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.kf_position_weight = cfg->kf_position_weight;
   P.kf_velocity_weight = cfg->kf_velocity_weight;
   P.max_idle = cfg->max_idle_epochs;
+  P.vote_words = 0;  // set per frame by enqueue_frame
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
   for (uint32_t i = 0; i < cfg->n_constraints; ++i) {

@@ -756,10 +756,13 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     take((uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0x4E, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)bc, 0x4E, 0xF, 0xF, true));
     if (TPR == 8) take(__shfl_xor(bk, 4), __shfl_xor(bc, 4));  // the other quad of the 8-thread group
     const uint32_t gi = m0 + (rr >> 5) * (BM / 2) + m * 32 + (rr & 31u);
-    if (seg == 0 && gi < N) {
+    if (seg == 0 && gi < N && p.vote_words) {
+      if (bk != 0xffffffffu)
+        __hip_atomic_fetch_min(S.row_best + gi, ((unsigned long long)bk << 32) | (n0 + bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (seg == 0 && gi < N) {
       const bool has = bk != 0xffffffffu;
-      S.row_part_w[(size_t)gi * S.CT + bx] = has ? (double)sa_key_f32(bk) : -1.0;
-      S.row_part_t[(size_t)gi * S.CT + bx] = has ? (int32_t)(n0 + bc) : -1;
+      S.row_part_w[(size_t)bx * S.N + gi] = has ? (double)sa_key_f32(bk) : -1.0;
+      S.row_part_t[(size_t)bx * S.N + gi] = has ? (int32_t)(n0 + bc) : -1;
     }
   };
   // The row operands of a lane's cells: accumulator registers 4g .. 4g+3 hold four consecutive tile rows (acc_row), so one
@@ -848,6 +851,10 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       if (gj >= TK) continue;
       const unsigned long long k2 = s_ck[i];
       const bool has = k2 != ~0ull;
+      if (p.vote_words) {
+        if (has) __hip_atomic_fetch_min(S.col_best + gj, k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       S.col_part_w[(size_t)by * TK + gj] = has ? (double)sa_key_f32((uint32_t)(k2 >> 32)) : -1.0;
       S.col_part_q[(size_t)by * TK + gj] = has ? (uint32_t)k2 : SA_NONE;
     }

@@ -160,6 +160,56 @@ def test_state_kept_clean_across_frames_of_changing_size():
         eng.close()
 
 
+def test_vote_words_rearmed_across_frames():
+    """One observation per track, at most 1024 candidates and tracks: the contraction reduces the BestFit vote into one 64-bit word
+    per candidate and per track (atomic minima) and the one-workgroup tail reads AND re-arms them; bigger frames go through the
+    per-tile partials and the resolve launch.  One engine, frames that cross both boundaries in both directions, every frame run
+    twice: each answer must match the oracle (a word left dirty would leak a verdict into the next frame)."""
+    rng = np.random.default_rng(4242)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=96,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        prev_t = 0
+        for f, (n, t) in enumerate([(200, 220), (1100, 300), (300, 320), (400, 1100), (64, 1100), (1024, 1024), (10, 700), (900, 1000)]):
+            sc = synth.visual_scene(rng, t, n, 96, 1, canvas=(2400.0, 1600.0), new_fraction=0.15)
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+            det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+            eng.upsert(0, tracks)
+            if t < prev_t:
+                eng.remove(0, np.arange(t + 1, prev_t + 1, dtype=np.uint64))
+            prev_t = t
+            assert eng.count(0) == t
+            ids, votes = eng.associate(0, 1, det)
+            ref = O.associate(cfg, tracks, 1, det)
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"frame {f} ({n} x {t})")
+            np.testing.assert_array_equal(votes, ref["voting_type"])
+            eng.batch_run()
+            eng.batch_sync()
+            ids2, votes2 = eng.batch_fetch(0, n)
+            np.testing.assert_array_equal(ids2, ref["track_id"], err_msg=f"frame {f} rerun")
+            np.testing.assert_array_equal(votes2, ref["voting_type"])
+    finally:
+        eng.close()
+
+
+def test_resolve_as_its_own_launch_matches_oracle_too():
+    """SA_RESOLVE=separate keeps k_bestfit_resolve a launch of its own on small frames (no vote words); SA_RESOLVE=fold folds the
+    per-tile partials into the one-workgroup tail.  Same tests, same oracle."""
+    import os
+    import subprocess
+    import sys
+
+    for mode in ("separate", "fold"):
+        env = dict(os.environ, SA_RESOLVE=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                            "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_zero_feature or "
+                            "test_vote_words_rearmed or test_batched_visual"],
+                           env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, mode + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_graph_replay_gives_the_same_answers():
     """SA_FLAG_GRAPH: the per-frame launches are captured once and replayed while the staged set is unchanged, re-captured when
     it changes (new frame size, re-allocated buffers).  Same answers as the eager pipeline, frame after frame."""
