@@ -400,17 +400,14 @@ int upload_scene_descs(sa_engine* e) {
 int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
   hipStream_t st = e->stream;
   // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
-  // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own, SA_RESOLVE=fold folds it into the one-workgroup tail
-  // with the per-tile partials (measured: no gain, the fold's loads cost one CU what the launch cost)
+  // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own (no vote words)
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
-  static const bool fold_partials = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "fold");
   const bool small_tail = maxN <= SA_SMALL_N && !force_general;
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
-  const bool words = e->visual && e->bf_partials && small_tail && maxT <= SA_SMALL_N && !separate_resolve && !fold_partials;
-  const bool folded = words || (e->visual && small_tail && maxT <= SA_SMALL_N && fold_partials);
+  const bool words = e->visual && e->bf_partials && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
   SaParams P = e->P;
   P.vote_words = words ? 1u : 0u;
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
@@ -430,10 +427,10 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, e->bf_partials, e->f16_split)); }
     if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
   }
-  if (e->visual && !folded) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, e->bf_partials ? 2 : 1)); }
+  if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, e->bf_partials ? 2 : 1)); }
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
-    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : folded ? (e->bf_partials ? 7 : 6) : 5));
+    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5));
   } else {
     { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
     { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }

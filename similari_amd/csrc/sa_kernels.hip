@@ -375,12 +375,11 @@ static inline void sa_tail_trace_hook(hipStream_t, uint32_t) {}
 // flight across the LDS phases, so only the LDS counter is drained.
 __device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// RESOLVE (1: partials of k_bestfit_tile, 2: raw-weight partials of the contraction's epilogue, 3: the contraction's vote words) folds k_bestfit_resolve into
-// this kernel — one dependent launch less per frame (~2.9 us of floor + its ramp): thread q folds candidate q's CT row partials,
-// then the RT column partials of its best column, exactly as the stand-alone kernel's wave does (ascending tiles, strict
-// improvement: the lowest index wins a tie); the verdicts stay in registers (has / winner) and in an LDS byte per column
-// (excluded) instead of going through row_has / vis_winner / col_excluded.  Needs T <= SA_SMALL_N (launcher).
-template <bool VISUAL, int RESOLVE = 0>
+// WORDS: the contraction's tiles reduced the BestFit vote into one 64-bit word per candidate and per track (SaParams::vote_words,
+// visual_cosine_tile): thread q reads candidate q's word and track q's word, re-arms both, and the verdicts stay in registers
+// (has / winner) and two LDS tables instead of going through k_bestfit_resolve's row_has / vis_winner / col_excluded — one
+// dependent launch less per frame.  Needs T <= SA_SMALL_N (launcher).
+template <bool VISUAL, bool WORDS = false>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
@@ -403,61 +402,20 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   const bool uf_in_lds = T <= SA_SMALL_N;
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
-  __shared__ uint8_t s_cexcl[RESOLVE ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
-  __shared__ uint32_t s_bt[RESOLVE ? SA_SMALL_N : 1];     // candidate -> its best column (SA_NONE: no group at all)
-  __shared__ uint32_t s_cq[RESOLVE ? SA_SMALL_N : 1];     // column -> its best candidate (SA_NONE: no group at all)
+  __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
+  __shared__ uint32_t s_bt[WORDS ? SA_SMALL_N : 1];     // candidate -> its best column (SA_NONE: no group at all)
+  __shared__ uint32_t s_cq[WORDS ? SA_SMALL_N : 1];     // column -> its best candidate (SA_NONE: no group at all)
   bool has_verdict;
   int32_t vw0 = -1;
   uint32_t bt = SA_NONE;
-  if constexpr (RESOLVE != 0) {
-    // thread q folds row q's partials AND column q's: both arrays are [tile][index], so every load below is one coalesced
-    // 512-byte segment per wave (a single workgroup cannot afford scattered lines: one CU's address path serves them all)
-    constexpr bool RAW_W = RESOLVE >= 2;
-    auto score = [&](double part) { return RAW_W ? -part : part; };  // greater is better
-    const double none = RAW_W ? -__builtin_huge_val() : -1.0;
-    double bw = none;
-    const uint32_t qi = q < N ? q : 0u, ti = q < T ? q : 0u;
-    for (uint32_t c0 = 0; RESOLVE != 3 && c0 < S.CT; c0 += 16) {
-      double pw[16];
-      int32_t pt[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const bool in = c0 + k < S.CT && q < N;
-        pw[k] = in ? S.row_part_w[(size_t)(c0 + k) * N + qi] : 0.0;
-        pt[k] = in ? S.row_part_t[(size_t)(c0 + k) * N + qi] : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double w = score(pw[k]);
-        if (pt[k] >= 0 && (bt == SA_NONE || w > bw)) { bw = w; bt = (uint32_t)pt[k]; }  // tiles ascend with t
-      }
-    }
-    double cw = none;
-    uint32_t cq = SA_NONE;
-    for (uint32_t r0 = 0; RESOLVE != 3 && r0 < S.RT; r0 += 16) {
-      double pw[16];
-      uint32_t pq[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const bool in = r0 + k < S.RT && q < T;
-        pw[k] = in ? S.col_part_w[(size_t)(r0 + k) * T + ti] : 0.0;
-        pq[k] = in ? S.col_part_q[(size_t)(r0 + k) * T + ti] : SA_NONE;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double w = score(pw[k]);
-        if (pq[k] != SA_NONE && (cq == SA_NONE || w > cw)) { cw = w; cq = pq[k]; }  // tiles ascend with q
-      }
-    }
-    if constexpr (RESOLVE == 3) {
-      // vote words: the tiles already reduced (weight key << 32 | index) per candidate and per track; read them and re-arm them
-      const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
-      const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
-      if (q < N) S.row_best[q] = ~0ull;
-      if (q < T) S.col_best[q] = ~0ull;
-      bt = rb != ~0ull ? (uint32_t)rb : SA_NONE;
-      cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
-    }
+  if constexpr (WORDS) {
+    // (weight key << 32 | index), all ones = no group at all; lowest weight wins, lowest index on ties — k_bestfit_resolve's order
+    const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
+    const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
+    if (q < N) S.row_best[q] = ~0ull;
+    if (q < T) S.col_best[q] = ~0ull;
+    bt = rb != ~0ull ? (uint32_t)rb : SA_NONE;
+    const uint32_t cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
     has_verdict = bt != SA_NONE;  // feature_winners.contains_key(q)
     s_bt[q] = bt;
     s_cq[q] = cq;
@@ -467,7 +425,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
   // excluded_tracks: column j was won by the candidate that is best in it iff that candidate's own best column is j
   auto excluded = [&](uint32_t j) -> bool {
-    if constexpr (RESOLVE != 0) {
+    if constexpr (WORDS) {
       const uint32_t c = s_cq[j];
       return c != SA_NONE && s_bt[c] == j;
     } else return S.col_excluded[j] != 0;
@@ -508,7 +466,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     if (lane == WAVE - 1) s_wsum[q / WAVE] = incl;
   }
   sa_lds_barrier();
-  if constexpr (RESOLVE != 0) {
+  if constexpr (WORDS) {
     if (has_verdict && s_cq[bt] == q) vw0 = (int32_t)bt;  // the candidate that is best in its own best column wins it
     s_cexcl[q] = q < T && excluded(q);
   }
@@ -638,7 +596,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.e_off = s_eoff; w.excluded = nullptr; }
       else {
         w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.e_off = nullptr;
-        if constexpr (RESOLVE != 0) w.excluded = s_cexcl;
+        if constexpr (WORDS) w.excluded = s_cexcl;
         else w.excluded = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
       }
       w.next_row = s_next;
@@ -910,9 +868,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       break;
     default:
       sa_tail_trace_hook(st, ns);
-      if (stage == 6) SA_LAUNCH((k_assign_small<true, 1>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else if (stage == 7) SA_LAUNCH((k_assign_small<true, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else if (stage == 8) SA_LAUNCH((k_assign_small<true, 3>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      if (stage == 8) SA_LAUNCH((k_assign_small<true, true>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
       else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_small<true>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
       else SA_LAUNCH(k_assign_small<false>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
       break;

@@ -195,13 +195,13 @@ def test_vote_words_rearmed_across_frames():
 
 
 def test_resolve_as_its_own_launch_matches_oracle_too():
-    """SA_RESOLVE=separate keeps k_bestfit_resolve a launch of its own on small frames (no vote words); SA_RESOLVE=fold folds the
-    per-tile partials into the one-workgroup tail.  Same tests, same oracle."""
+    """SA_RESOLVE=separate keeps k_bestfit_resolve a launch of its own on small frames (per-tile partials, no vote words).  Same
+    tests, same oracle."""
     import os
     import subprocess
     import sys
 
-    for mode in ("separate", "fold"):
+    for mode in ("separate",):
         env = dict(os.environ, SA_RESOLVE=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
                             "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_zero_feature or "
