@@ -210,17 +210,19 @@ def test_resolve_as_its_own_launch_matches_oracle_too():
         assert r.returncode == 0, mode + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_graph_replay_gives_the_same_answers():
+@pytest.mark.parametrize("k", [2, 1])
+def test_graph_replay_gives_the_same_answers(k):
     """SA_FLAG_GRAPH: the per-frame launches are captured once and replayed while the staged set is unchanged, re-captured when
-    it changes (new frame size, re-allocated buffers).  Same answers as the eager pipeline, frame after frame."""
+    it changes (new frame size, re-allocated buffers).  Same answers as the eager pipeline, frame after frame.  k = 1: the vote
+    words (re-armed by the tail inside the captured graph) instead of partials + resolve."""
     rng = np.random.default_rng(9)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,
-                          max_observations=2, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
                           max_idle_epochs=5, flags=abi.SA_FLAG_GRAPH)
     eng = Engine(cfg)
     try:
         for n, t in [(120, 150), (120, 150), (300, 310), (80, 310)]:
-            sc = synth.visual_scene(rng, t, n, 64, 2, canvas=(1200.0, 800.0), new_fraction=0.1)
+            sc = synth.visual_scene(rng, t, n, 64, k, canvas=(1200.0, 800.0), new_fraction=0.1)
             tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
             det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
             eng.upsert(0, tracks)
