@@ -29,6 +29,7 @@ from similari_amd import abi, synth  # noqa: E402
 DEFAULT_FLAGS = 0            # engine flags of the timed pass
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+VALU_F32_PEAK_TFLOPS = 157.3  # f32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md); the f16-split option issues 3 products per flop
 
 
@@ -51,6 +52,14 @@ def workload(name: str, seed: int):
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
         return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K=3 observations per track (BASELINE C2, deeper bank)"
+    if name == "c2e":
+        n = t = 1000
+        d, k = 512, 1
+        sc = synth.visual_scene(rng, t, n, d, k)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=0.5, feature_len=d,
+                              max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
+                              positional_min_confidence=0.1, max_idle_epochs=5)
+        return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d EUCLIDEAN + IoU(0.3), K=1 (the C2 frame with the other visual metric)"
     if name == "c5":
         t, n, d, k = 5000, 2000, 4096, 1
         sc = synth.visual_scene(rng, t, n, d, k, canvas=(7680.0, 4320.0))
@@ -140,8 +149,10 @@ def kernel_models(cfg, scenes):
         "k_bestfit_tile": ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0),
     }
     if visual:
-        flops = sum(2.0 * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
-        m["k_visual_cost"] = ("mfma", flops)
+        euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
+        # euclidean: sub, mul, add per element on the f32 vector pipe (no matrix-core form without catastrophic cancellation)
+        flops = sum((3.0 if euclid else 2.0) * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
+        m["k_visual_cost"] = ("valu" if euclid else "mfma", flops)
         # small frames: contraction tiles + positional tiles + preparation blocks in one heterogeneous launch — the matrix-core
         # work is what bounds it; the other two kinds fill the issue slots it leaves idle
         m["k_frame_visual"] = ("mfma", flops)
@@ -343,7 +354,12 @@ def main():
             bound, amount = models[dom]
             per_launch = amount * (prof[dom][0] and args.profile_iters / prof[dom][0])
             dur_s = kern[dom]["avg_us"] * 1e-6
-            if bound == "mfma":
+            if bound == "valu":
+                a = per_launch / dur_s / 1e12
+                roof = {"kernel": dom, "bound": "valu", "achieved": a, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": a / VALU_F32_PEAK_TFLOPS, "traffic": None,
+                        "peak_note": "f32 vector peak (the same 157.3 TFLOP/s as the f32 matrix cores); sub + mul + add per element, 2 of 3 fuse"}
+            elif bound == "mfma":
                 a = per_launch / dur_s / 1e12
                 mfma_peak = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
                 roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": mfma_peak, "unit": "TFLOP/s",
@@ -363,14 +379,14 @@ def main():
                 roof["traffic"], roof["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH + WRITE bytes per launch)"
             if dom in models:
                 roof["algorithmic"] = models[dom][1] * args.profile_iters / prof[dom][0]
-                roof["algorithmic_unit"] = "flop per launch" if models[dom][0] == "mfma" else "bytes per launch"
+                roof["algorithmic_unit"] = "flop per launch" if models[dom][0] in ("mfma", "valu") else "bytes per launch"
         # secondary roofline lines for every modelled kernel
         for k, (bound, amount) in models.items():
             if k in kern and kern[k]["avg_us"] > 0:
                 per_launch = amount * args.profile_iters / prof[k][0]
                 rate = per_launch / (kern[k]["avg_us"] * 1e-6)
                 mp = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
-                kern[k]["roofline_frac"] = rate / 1e12 / mp if bound == "mfma" else rate / 1e9 / HBM_PEAK_GBS
+                kern[k]["roofline_frac"] = rate / 1e12 / mp if bound == "mfma" else rate / 1e12 / VALU_F32_PEAK_TFLOPS if bound == "valu" else rate / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "assoc-pairs/sec (NxM cost+assign) VisualSORT 512-d",
             "value": total_cells * args.steps / dt,

@@ -294,7 +294,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->fnorm, n * 4));
     TRY(dev_ensure(e, s->vis, n * t * K * 4));
   }
-  TRY(dev_ensure(e, s->vis_max_key, ((n + 63) / 64) * ((t * K + 63) / 64) * 4));  // 64x64 tiles: the most slots any plan needs
+  TRY(dev_ensure(e, s->vis_max_key, ((n + 31) / 32) * ((t * K + 63) / 64) * 4));  // covers 64x64 (cosine) and 32x128 (euclidean) tiles: the most slots any plan needs
   if (e->visual) {
     TRY(dev_ensure(e, s->row_part_w, n * CT * 8));
     TRY(dev_ensure(e, s->row_part_t, n * CT * 4));

@@ -27,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Pointers that reach a kernel through the SceneDev descriptor are generic ("flat") to the compiler: their loads become
 // flat_load, which counts on BOTH vmcnt and lgkmcnt — every s_waitcnt lgkmcnt for an LDS fragment then also drains the
 // feature loads in flight and the software pipeline collapses (C2: 20 -> 41 us).  The feature operands are therefore
@@ -300,7 +301,6 @@ __device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const f
     for (int r = 0; r < L_CH; ++r) {
       // two elements per instruction where the ISA has it: packed f32 multiply / subtract, packed f32 -> f16 conversion.  (The
       // split is the VALU cost of this kernel: with scalar conversions the main loop was VALU-bound, not matrix-core-bound.)
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
       f16x4 hi, lo;
 #pragma unroll
@@ -945,95 +945,177 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
 #endif
 }
 
-// Direct sum (a-b)^2: 64x64 outputs per 256-thread block, 4x4 per thread, k staged through the same
-// swizzled LDS tiles.  Column c of a thread is tx + 16*c so a wave's stores cover 64-B row segments.
+// Direct sum (a-b)^2 on the vector pipe.  A 512-thread block computes 32 rows x 128 columns: wave w owns rows 4w .. 4w+3, lane l
+// the columns l and l + 64 — 8 cells per thread, two partial sums per cell (even / odd k) so that every step is one packed
+// subtract and one packed fused multiply-add (v_pk_add_f32 / v_pk_fma_f32: two f32 per lane per issue, 4-5 cycles per wave
+// instruction measured, scripts/micro/pk_fma_rate.hip; the pipe's 157 TF/s is quoted on these).  What bounds such a kernel is
+// operand delivery, not arithmetic: the first version (64 x 64 tile, 4 x 4 cells per thread, both operands through LDS) needs
+// 8 ds_read_b128 per 64 packed instructions — exactly the 128 B/clk the LDS has when the vector pipe runs at full rate, so
+// neither did (61.7 us at C2's size with scalar arithmetic, 38.7 packed; two LDS stages with fragment prefetch: 49.5).  Here the
+// A operand never touches LDS or a vector register: a wave's 4 rows are the same for all its lanes, so their k-runs come through
+// the SCALAR cache (s_load_dwordx8 from the constant address space) and enter the packed subtract as SGPR pairs (inline asm:
+// left to itself the compiler subtracts the halves separately); only B goes through LDS, four ds_read_b128 per 64 packed
+// instructions.  (Eight rows per wave halve that again but need 128 SGPRs for the two operand buffers: spilled through
+// v_writelane.)  Eight waves per block: two per SIMD even when the frame is one block per CU.  Column stores of a wave cover
+// 256-byte row segments.  35.3 us at C2's size (0.28 of the vector peak); with the scalar loads or the LDS reads taken out
+// (wrong answers) 25.5 either way — what is left over the ~16 us of issue time is the two operand streams' round trips, which
+// share one counter (lgkmcnt) and can only be awaited together; one column per lane (four waves per SIMD) 37.0, 4-float steps 35.7.
+constexpr int EU_C = 2;                                          // columns per lane
+constexpr int EU_BM = 32, EU_BN = 64 * EU_C, EU_R = 4, EU_THREADS = 512;  // EU_R rows per wave, EU_BM / EU_R waves
+constexpr int EU_LDS_FLOATS = 2 * EU_BN * BK;
+typedef const f32x4 __attribute__((address_space(4)))* kf32x4_p;
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef const f32x8 __attribute__((address_space(4)))* kf32x8_p;
 __device__ __forceinline__ void euclid_mainloop(gfloat_p A, gfloat_p B, uint32_t M,
                                                 uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds,
-                                                float (&acc)[4][4]) {
-  constexpr int BM = 64, BN = 64;
-  float* As = lds;
-  float* Bs = lds + BM * BK;
-  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
+                                                float (&acc)[EU_R][EU_C]) {
+  constexpr int STAGE = EU_BN * BK;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  f32x2 acc2[EU_R][EU_C];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < EU_R; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  gfloat_p pa[2];
-  gfloat_p pb[2];
-  uint32_t so[2];
+    for (int j = 0; j < EU_C; ++j) acc2[i][j] = f32x2{0.f, 0.f};
+  // B rows of this block: 128 columns x 32 k per chunk = 1024 16-byte pieces, two per thread
+  constexpr int NL = EU_BN * 8 / EU_THREADS;  // 16-byte pieces per thread per chunk
+  gfloat_p pb[NL];
+  uint32_t so[NL];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    uint32_t c = tid + 256u * r, row = c >> 3, kc = c & 7u;
-    uint32_t ga = m0 + row, gb = n0 + row;
-    ga = ga < M ? ga : M - 1;
+  for (int r = 0; r < NL; ++r) {
+    const uint32_t c = tid + 512u * r, row = c >> 3, kc = c & 7u;
+    uint32_t gb = n0 + row;
     gb = gb < Ncols ? gb : Ncols - 1;
-    pa[r] = A + (size_t)ga * Dp + kc * 4u;
     pb[r] = B + (size_t)gb * Dp + kc * 4u;
     so[r] = lds_off(row, kc);
   }
-  f32x4 ra[2], rb[2];
+  // A rows of this wave (rows past the edge are clamped; their results are never stored)
+  kf32x4_p ka[EU_R];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) { ra[r] = *(gf32x4_p)pa[r]; rb[r] = *(gf32x4_p)pb[r]; }
-  for (uint32_t k0 = 0; k0 < Dp; k0 += BK) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) { *(f32x4*)(As + so[r]) = ra[r]; *(f32x4*)(Bs + so[r]) = rb[r]; }
-    __syncthreads();
-    if (k0 + BK < Dp) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) { ra[r] = *(gf32x4_p)(pa[r] + k0 + BK); rb[r] = *(gf32x4_p)(pb[r] + k0 + BK); }
-    }
-#pragma unroll
-    for (uint32_t kc = 0; kc < 8; ++kc) {
-      f32x4 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const f32x4*)(As + lds_off(ty * 4 + i, kc));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const f32x4*)(Bs + lds_off(tx + 16 * j, kc));
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float df = fa[i][e] - fb[j][e];
-            acc[i][j] += df * df;
-          }
-    }
-    __syncthreads();
+  for (int i = 0; i < EU_R; ++i) {
+    uint32_t ga = m0 + (uint32_t)EU_R * w + i;
+    ga = ga < M ? ga : M - 1;
+    ka[i] = (kf32x4_p)(uintptr_t)(A + (size_t)ga * Dp);
   }
+  const uint32_t nchunks = Dp / BK;
+  f32x4 rb[NL];
+#pragma unroll
+  for (int r = 0; r < NL; ++r) rb[r] = *(gf32x4_p)pb[r];
+#pragma unroll
+  for (int r = 0; r < NL; ++r) *(f32x4*)(lds + so[r]) = rb[r];
+  if (nchunks > 1) {
+#pragma unroll
+    for (int r = 0; r < NL; ++r) rb[r] = *(gf32x4_p)(pb[r] + BK);
+  }
+  __syncthreads();
+  // one step = 8 k: four rows' runs as s_load_dwordx8 (32 SGPRs per buffer), two ds_read_b128 per column, 16 * EU_C packed
+  // subtract / multiply-add pairs — long enough (~300 cycles) to cover the LDS and scalar-cache round trips of the next step's
+  // operands, which share one counter (lgkmcnt) and can only be awaited together
+  f32x4 fb[2][EU_C][2];
+  f32x8 sa[2][EU_R];
+  auto fetch = [&](auto buf_tag, const float* Bs, uint32_t k8) {  // k8 = index of the 8-float run along k (global)
+    constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+    for (int j = 0; j < EU_C; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fb[buf][j][h] = *(const f32x4*)(Bs + lds_off(lane + 64u * j, (2u * k8 + h) & 7u));
+#pragma unroll
+    for (int i = 0; i < EU_R; ++i) sa[buf][i] = ((kf32x8_p)ka[i])[k8];
+  };
+  auto compute = [&](auto cur_tag) {
+    constexpr int cur = decltype(cur_tag)::value;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+#pragma unroll
+      for (int i = 0; i < EU_R; ++i)
+#pragma unroll
+        for (int j = 0; j < EU_C; ++j) {
+          // a - b as ONE packed instruction with the SGPR pair as a source (left to itself the compiler subtracts the two
+          // halves separately: 96 instructions per step instead of 64)
+          const f32x2 av = f32x2{sa[cur][i][e], sa[cur][i][e + 1]};
+          const f32x2 bv = f32x2{fb[cur][j][e >> 2][e & 3], fb[cur][j][e >> 2][(e & 3) + 1]};
+          f32x2 df;
+          asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(df) : "s"(av), "v"(bv));
+          acc2[i][j] = __builtin_elementwise_fma(df, df, acc2[i][j]);
+        }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  fetch(B0{}, lds, 0);
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const float* Bs = lds + (c & 1u) * STAGE;
+    float* nxt = lds + ((c + 1u) & 1u) * STAGE;
+    const bool store = c + 1 < nchunks, load = c + 2 < nchunks;
+    // two steps per trip of a ROLLED loop: the operand buffers stay compile-time constants, and the scheduler cannot hoist a
+    // whole chunk's reads to the top
+#pragma unroll 1
+    for (uint32_t ks = 0; ks < 4; ks += 2) {
+      fetch(B1{}, Bs, c * 4u + ks + 1);
+      compute(B0{});
+      if (ks == 0 && store) {
+#pragma unroll
+        for (int r = 0; r < NL; ++r) *(f32x4*)(nxt + so[r]) = rb[r];
+        if (load) {
+#pragma unroll
+          for (int r = 0; r < NL; ++r) rb[r] = *(gf32x4_p)(pb[r] + (c + 2) * BK);
+        }
+      }
+      if (ks + 2 < 4) fetch(B0{}, Bs, c * 4u + ks + 2);
+      compute(B1{});
+    }
+    __syncthreads();  // the other stage is complete, and everyone is done reading this one
+    if (store) fetch(B0{}, nxt, (c + 1) * 4u);
+  }
+#pragma unroll
+  for (int i = 0; i < EU_R; ++i)
+#pragma unroll
+    for (int j = 0; j < EU_C; ++j) acc[i][j] = acc2[i][j][0] + acc2[i][j][1];
 }
 
-__global__ __launch_bounds__(256) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
-  constexpr int BM = 64, BN = 64;
+__global__ __launch_bounds__(EU_THREADS) void k_visual_euclid(const SceneDev* __restrict__ scenes, SaParams p) {
+  constexpr int BM = EU_BM, BN = EU_BN;
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, TK = S.TK, K = S.K;
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= N || n0 >= TK) return;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
-  float acc[4][4];
+  __shared__ __attribute__((aligned(16))) float lds[EU_LDS_FLOATS];
+  float acc[EU_R][EU_C];
   euclid_mainloop((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc);
-  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
   uint32_t kmax = 0;
+  // the two columns of this lane: their gates once, not once per row
+  bool col_ok[EU_C];
+  sa_geo tg[EU_C];
+  uint64_t tep[EU_C];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint32_t gi = m0 + ty * 4 + i;
+  for (int j = 0; j < EU_C; ++j) {
+    const uint32_t gj = n0 + lane + 64u * j;
+    col_ok[j] = false;
+    if (gj < TK) {
+      const uint32_t t = gj / K;
+      col_ok[j] = S.t_fpresent[gj] && S.t_fcount[t] >= p.min_track_len;
+      tg[j] = sa_ldg(S.t_geo + t);
+      tep[j] = S.t_epoch[t];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EU_R; ++i) {
+    const uint32_t gi = m0 + (uint32_t)EU_R * w + i;
     if (gi >= N) continue;
-    bool us = S.c_usable[gi] != 0;
-    sa_geo cg = sa_ldg(S.c_geo + gi);
+    const bool us = S.c_usable[gi] != 0;
+    const sa_geo cg = sa_ldg(S.c_geo + gi);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t gj = n0 + tx + 16 * j;
+    for (int j = 0; j < EU_C; ++j) {
+      const uint32_t gj = n0 + lane + 64u * j;
       if (gj >= TK) continue;
-      uint32_t t = gj / K;
       float out = nanv;
-      if (us && S.t_fpresent[gj] && S.t_fcount[t] >= p.min_track_len &&
-          sa_compatible(cg, epoch, sa_ldg(S.t_geo + t), S.t_epoch[t], p.max_idle, p.cons)) {
-        float d = sqrtf(acc[i][j]);
+      if (us && col_ok[j] && sa_compatible(cg, epoch, tg[j], tep[j], p.max_idle, p.cons)) {
+        const float d = sqrtf(acc[i][j]);
         if (d <= p.visual_threshold) {
           out = d;
-          uint32_t key = sa_f32_key(out);
+          const uint32_t key = sa_f32_key(out);
           kmax = key > kmax ? key : kmax;
         }
       }
@@ -1109,21 +1191,20 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_cosine_matrix(const f
   SA_STAMP(tr, 4);
 }
 
-__global__ __launch_bounds__(256) void k_euclid_matrix(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
+__global__ __launch_bounds__(EU_THREADS) void k_euclid_matrix(const float* __restrict__ A, const float* __restrict__ B, uint32_t M,
                                                        uint32_t Ncols, uint32_t Dp, float* __restrict__ out) {
-  constexpr int BM = 64, BN = 64;
-  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
-  float acc[4][4];
+  const uint32_t m0 = blockIdx.y * EU_BM, n0 = blockIdx.x * EU_BN;
+  __shared__ __attribute__((aligned(16))) float lds[EU_LDS_FLOATS];
+  float acc[EU_R][EU_C];
   euclid_mainloop((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc);
-  const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15u;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint32_t gi = m0 + ty * 4 + i;
+  for (int i = 0; i < EU_R; ++i) {
+    const uint32_t gi = m0 + (uint32_t)EU_R * w + i;
     if (gi >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t gj = n0 + tx + 16 * j;
+    for (int j = 0; j < EU_C; ++j) {
+      const uint32_t gj = n0 + lane + 64u * j;
       if (gj < Ncols) out[(size_t)gi * Ncols + gj] = sqrtf(acc[i][j]);
     }
   }
@@ -1192,6 +1273,7 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
 // max-key slots, SceneDev::nkeys).
 void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn) {
   *bm = 64; *bn = 64;
+  if (visual_kind == SA_VIS_EUCLIDEAN) { *bm = EU_BM; *bn = EU_BN; return; }  // k_visual_euclid's block tile (vis_max_key slots)
   if (visual_kind != SA_VIS_COSINE || !maxN || !maxTK) return;
   switch (tile_plan(maxN, maxTK, ns, Dp)) {
     case 0: case 8: *bm = 128; *bn = 128; break;
@@ -1288,7 +1370,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
     }
   } else {
-    SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p);
+    SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, EU_BN), cdiv(maxN, EU_BM), ns), dim3(EU_THREADS), 0, st, scenes, p);
   }
   return hipGetLastError();
 }
@@ -1309,7 +1391,7 @@ hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, 
       default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
     }
   } else {
-    hipLaunchKernelGGL(k_euclid_matrix, dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, b, n, t, dp, out);
+    hipLaunchKernelGGL(k_euclid_matrix, dim3(cdiv(t, EU_BN), cdiv(n, EU_BM)), dim3(EU_THREADS), 0, st, a, b, n, t, dp, out);
   }
   return hipGetLastError();
 }
