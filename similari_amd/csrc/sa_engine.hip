@@ -88,6 +88,7 @@ struct sa_engine {
   uint32_t K = 1, D = 0, Dp = 0;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
   bool f16_split = false;               // SA_FLAG_F16_SPLIT: the contraction's operands as f16 pairs (separate launches only)
+  bool bf_words_euclid = false;         // euclidean, bank depth 1: k_visual_euclid can reduce the vote into the vote words (frames up to 1024 x 1024)
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
@@ -407,7 +408,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
-  const bool words = e->visual && e->bf_partials && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
+  const bool words = e->visual && (e->bf_partials || e->bf_words_euclid) && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
   SaParams P = e->P;
   P.vote_words = words ? 1u : 0u;
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
@@ -425,7 +426,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
   if (e->visual) {
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, e->bf_partials, e->f16_split)); }
-    if (!e->bf_partials) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
+    if (!e->bf_partials && !words) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, e->bf_partials ? 2 : 1)); }
   if (small_tail) {
@@ -574,6 +575,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
     // SA_BESTFIT=tile keeps the two-kernel BestFit (weight matrix + k_bestfit_tile) for A/B runs and for the tests of that path
     const char* bf = getenv("SA_BESTFIT");
     e->bf_partials = cfg->visual_kind == SA_VIS_COSINE && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
+    e->bf_words_euclid = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
   }
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
@@ -1220,8 +1222,8 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
   size_t bytes = (size_t)s->N * s->T * e->K * 4;
   if (!bytes) return SA_OK;
-  if (e->bf_partials) {
-    // the product path never wrote the weight matrix: run the contraction once more, in matrix mode, on the slot's resident inputs
+  if (e->bf_partials || e->bf_words_euclid) {
+    // the product path never wrote the weight matrix (euclidean: not on frames that used the vote words — re-running is harmless otherwise): run the contraction once more, in matrix mode, on the slot's resident inputs
     SceneDev h;
     fill_scene_dev(e, s, &h);
     DevBuf tmp;

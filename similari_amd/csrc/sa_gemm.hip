@@ -1085,6 +1085,20 @@ __global__ __launch_bounds__(EU_THREADS) void k_visual_euclid(const SceneDev* __
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
   uint32_t kmax = 0;
+  // vote words (SaParams::vote_words; one observation per track, frame up to 1024 x 1024): no weight matrix — every row's and every
+  // column's lightest weight, (order-preserving key << 32) | index, goes into S.row_best / S.col_best by 64-bit atomic minima, as
+  // from the cosine contraction's epilogue.  Rows: a wave holds whole row segments (64 lanes x EU_C columns), so one wave
+  // reduction per row; columns: in-lane over the wave's rows, then the eight waves meet in LDS (the stages are free now).
+  const bool words = p.vote_words != 0;
+  unsigned long long* s_col = (unsigned long long*)lds;
+  unsigned long long cbest[EU_C];
+#pragma unroll
+  for (int j = 0; j < EU_C; ++j) cbest[j] = ~0ull;
+  if (words) {
+    __syncthreads();  // every wave is done with the stages
+    for (uint32_t i = tid; i < (uint32_t)EU_BN; i += EU_THREADS) s_col[i] = ~0ull;
+    __syncthreads();
+  }
   // the two columns of this lane: their gates once, not once per row
   bool col_ok[EU_C];
   sa_geo tg[EU_C];
@@ -1119,10 +1133,44 @@ __global__ __launch_bounds__(EU_THREADS) void k_visual_euclid(const SceneDev* __
           kmax = key > kmax ? key : kmax;
         }
       }
-      S.vis[(size_t)gi * TK + gj] = out;
+      if (!words) S.vis[(size_t)gi * TK + gj] = out;
+      else acc[i][j] = out;
     }
   }
-  block_max_key(S.vis_max_key, blockIdx.y * ((TK + BN - 1) / BN) + blockIdx.x, kmax);
+  if (!words) {
+    block_max_key(S.vis_max_key, blockIdx.y * ((TK + BN - 1) / BN) + blockIdx.x, kmax);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < EU_R; ++i) {
+    const uint32_t gi = m0 + (uint32_t)EU_R * w + i;  // wave-uniform
+    unsigned long long rbest = ~0ull;
+    if (gi < N) {
+#pragma unroll
+      for (int j = 0; j < EU_C; ++j) {
+        const uint32_t gj = n0 + lane + 64u * j;
+        const float o = acc[i][j];
+        if (gj < TK && o == o) {
+          const unsigned long long k = (unsigned long long)sa_f32_key(o) << 32;
+          rbest = (k | gj) < rbest ? (k | gj) : rbest;        // lowest column on ties
+          cbest[j] = (k | gi) < cbest[j] ? (k | gi) : cbest[j];  // rows ascend with i: lowest row on ties
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(rbest, o);
+      rbest = other < rbest ? other : rbest;
+    }
+    if (lane == 0 && rbest != ~0ull) __hip_atomic_fetch_min(S.row_best + gi, rbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int j = 0; j < EU_C; ++j)
+    if (cbest[j] != ~0ull) atomicMin(&s_col[lane + 64u * j], cbest[j]);
+  __syncthreads();
+  for (uint32_t i = tid; i < (uint32_t)EU_BN; i += EU_THREADS) {
+    const unsigned long long v = s_col[i];
+    if (v != ~0ull && n0 + i < TK) __hip_atomic_fetch_min(S.col_best + n0 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----

@@ -160,13 +160,14 @@ def test_state_kept_clean_across_frames_of_changing_size():
         eng.close()
 
 
-def test_vote_words_rearmed_across_frames():
+@pytest.mark.parametrize("visual,thr", [("cosine", 0.2), ("euclidean", 0.5)])
+def test_vote_words_rearmed_across_frames(visual, thr):
     """One observation per track, at most 1024 candidates and tracks: the contraction reduces the BestFit vote into one 64-bit word
-    per candidate and per track (atomic minima) and the one-workgroup tail reads AND re-arms them; bigger frames go through the
-    per-tile partials and the resolve launch.  One engine, frames that cross both boundaries in both directions, every frame run
+    per candidate and per track (atomic minima; the euclidean kernel does the same) and the one-workgroup tail reads AND re-arms
+    them; bigger frames go through the per-tile partials (euclidean: the weight matrix and k_bestfit_tile) and the resolve launch.  One engine, frames that cross both boundaries in both directions, every frame run
     twice: each answer must match the oracle (a word left dirty would leak a verdict into the next frame)."""
     rng = np.random.default_rng(4242)
-    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=96,
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual=visual, visual_threshold=thr, feature_len=96,
                           max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
                           max_idle_epochs=5)
     eng = Engine(cfg)
