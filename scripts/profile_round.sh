@@ -6,7 +6,7 @@ TAG=${1:-r01_e}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-for w in c1 c2k3 c3 c3m c4 c5 sd; do python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
+for w in c1 c2e c2k3 c3 c3m c4 c5 sd; do python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 python bench.py --flags 32 --no-cpu-baseline > $O/bench_c2_separate.json 2> $O/bench_c2_separate.err
 for w in c2 c2k3 c5; do python bench.py --workload $w --flags 64 --no-cpu-baseline > $O/bench_${w}_f16split.json 2> $O/bench_${w}_f16split.err; done
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_mfma_c2sep -o p -- python $OLDPWD/bench.py --workload c2 --flags 32 --steps 20 --warmup 3 --no-cpu-baseline --profile-iters 5 > $O/pmc_mfma_c2sep.log 2>&1)
