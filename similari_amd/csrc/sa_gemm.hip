@@ -503,7 +503,7 @@ __device__ __forceinline__ void gemm_mainloop_ring(gfloat_p A, gfloat_p B, uint3
   uint32_t c = 0, st = 0;
   auto adv = [&]() { ++c; st = st == 2 ? 0u : st + 1u; __syncthreads(); };
   // steady state, two iterations per trip so that the register-set parity is static
-  for (; c + 5 < nchunks; ) { body(c, st, P0{}, T_{}, T_{}, T_{}); adv(); body(c, st, P1{}, T_{}, T_{}, T_{}); adv(); }
+  while (c + 5 < nchunks) { body(c, st, P0{}, T_{}, T_{}, T_{}); adv(); body(c, st, P1{}, T_{}, T_{}, T_{}); adv(); }
   // c is even here.  Remaining chunks: at most 5.
   if (c + 4 < nchunks) { body(c, st, P0{}, T_{}, T_{}, T_{}); adv(); }          // c+4 exists
   // from here no more loads; parity alternates from (c & 1)
@@ -891,6 +891,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   uint32_t bx = blockIdx.x, by = blockIdx.y;
   if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
   visual_cosine_tile<BM, BN, 1, false, PART, true>(S, p, bx, by, lds);
+}
+// the 128 x 128 tile holds two 64-register accumulator sets: no register cap to ask for (one wave per SIMD either way)
+template <bool PART>
+__global__ __launch_bounds__(256) void k_visual_cosine_h2_128(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (128 + 128) * BK];
+  const SceneDev S = scenes[blockIdx.z];
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
+  visual_cosine_tile<128, 128, 1, false, PART, true>(S, p, bx, by, lds);
 }
 template <int BM, int BN, int KGT, bool PART = false, bool H2 = false>
 __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
@@ -1382,8 +1391,8 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const dim3 g128x128(cdiv(maxTK, 128), cdiv(maxN, 128), ns), g64x128(cdiv(maxTK, 128), cdiv(maxN, 64), ns),
           g128x64(cdiv(maxTK, 64), cdiv(maxN, 128), ns), g64x64(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
       if (plan == 0 || plan == 8) {
-        if (partials) SA_LAUNCH((k_visual_cosine_h2<128, 128, true>), g128x128, dim3(256), 0, st, scenes, p, band);
-        else SA_LAUNCH((k_visual_cosine_h2<128, 128, false>), g128x128, dim3(256), 0, st, scenes, p, band);
+        if (partials) SA_LAUNCH((k_visual_cosine_h2_128<true>), g128x128, dim3(256), 0, st, scenes, p, band);
+        else SA_LAUNCH((k_visual_cosine_h2_128<false>), g128x128, dim3(256), 0, st, scenes, p, band);
       } else if (plan == 5) {
         if (partials) SA_LAUNCH((k_visual_cosine_h2<64, 128, true>), g64x128, dim3(256), 0, st, scenes, p, band);
         else SA_LAUNCH((k_visual_cosine_h2<64, 128, false>), g64x128, dim3(256), 0, st, scenes, p, band);
