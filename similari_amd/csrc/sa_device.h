@@ -457,7 +457,8 @@ struct sa_assign_ws {
   const uint32_t* e_cnt;   // [N]
   const uint32_t* e_col;   // edge e of a row at e_col[e * ecs] / e_gain[e * egs]: two packed arrays (ecs = egs = 1: the LDS pool) or
   const int64_t* e_gain;   // both pointing into one array of 16-byte {gain, col} records (ecs = 4, egs = 2: the lists in HBM)
-  uint32_t ecs, egs;
+  uint32_t ecs, egs;       // distance between consecutive edges of a row, in u32 / i64 words
+  uint32_t rcs, rgs;       // words per record (1 / 1: packed arrays, 4 / 2: SaEdge): where a row's first edge is, first * rcs / first * rgs
   uint32_t estride;        // records per row
   const uint32_t* e_off;   // nullptr: row r starts at r * estride; else at e_off[r] (edge lists packed into an LDS pool)
   const uint8_t* excluded;   // [T] or nullptr: columns already taken by the visual vote (visual_sort/voting.rs:62-79);
@@ -479,8 +480,8 @@ struct sa_assign_ws {
 SA_HD void sa_assign_relax_row(const sa_assign_ws& w, uint32_t row, int64_t base, uint32_t stamp, int32_t* list_head) {
   uint32_t cnt = w.e_cnt[row];
   const size_t first = w.e_off ? (size_t)w.e_off[row] : (size_t)row * w.estride;
-  const uint32_t* cols = w.e_col + first * w.ecs;
-  const int64_t* gains = w.e_gain + first * w.egs;
+  const uint32_t* cols = w.e_col + first * w.rcs;
+  const int64_t* gains = w.e_gain + first * w.rgs;
   int64_t ur = w.u[row];
   for (uint32_t e = 0; e < cnt; ++e) {
     uint32_t j = cols[(size_t)e * w.ecs];
@@ -508,8 +509,8 @@ SA_HD void sa_assign_relax_row(const sa_assign_ws& w, uint32_t row, int64_t base
 SA_HD void sa_assign_first_row(const sa_assign_ws& w, uint32_t root) {
   const uint32_t cnt = w.e_cnt[root];
   const size_t first = w.e_off ? (size_t)w.e_off[root] : (size_t)root * w.estride;
-  const uint32_t* cols = w.e_col + first * w.ecs;
-  const int64_t* gains = w.e_gain + first * w.egs;
+  const uint32_t* cols = w.e_col + first * w.rcs;
+  const int64_t* gains = w.e_gain + first * w.rgs;
   int32_t bj = -1;
   int64_t bg = 0;
   for (uint32_t e = 0; e < cnt; ++e) {

@@ -98,7 +98,7 @@ struct SceneDev {
   uint32_t SA_G* next_row;
   uint32_t SA_G* e_cnt;      // [N] edges appended by the positional tiles; zero between frames (the tail leaves it clean)
   uint32_t SA_G* e_use;      // [N] many-workgroup tail: the counts the solver works on
-  SaEdge SA_G* e_edge;       // [N][estride] edge records (one 16-byte store per edge, one cache line per short row)
+  SaEdge SA_G* e_edge;       // edge records: [N][estride] (general tail) or [estride][N] (one-workgroup tail), see positional_tile
   int64_t SA_G* u;           // [N] -max gain per row, folded by the positional tiles (UNION); zero between frames
   int64_t SA_G* u_use;       // [N] many-workgroup tail: the solver's row duals
   int64_t SA_G* v;

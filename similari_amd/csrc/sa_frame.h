@@ -331,7 +331,10 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
       const int64_t gain = sa_quantise(w) - p.threshold_q;  // (w * 1e6f) as i64 vs the diagonal of SortVoting's matrix
       if (gain > 0) {
         const uint32_t slot = atomicAdd((uint32_t*)(S.e_cnt + i), 1u);
-        sa_stg(S.e_edge + (size_t)i * S.estride + slot, SaEdge{gain, j, 0u});
+        // general tail (UNION): row-major lists, a short row is one cache line for the thread that gathers its component;
+        // one-workgroup tail: SLOT-major — its 1024 threads fetch "edge k of my row" side by side, 64 lanes = one contiguous
+        // kilobyte (row-major: 64 lines per wave-load through ONE compute unit's address path, 4 k cycles of the tail)
+        sa_stg(S.e_edge + (UNION ? (size_t)i * S.estride + slot : (size_t)slot * N + i), SaEdge{gain, j, 0u});
         if (UNION) {
           __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
           sa_uf_union((uint32_t*)S.parent, i, N + j);

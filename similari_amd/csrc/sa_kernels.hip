@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // =====================================================================================================
 __device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
   sa_assign_ws w;
-  w.e_cnt = S.e_use; w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2;
+  w.e_cnt = S.e_use; w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.rcs = 4; w.rgs = 2;
   w.estride = S.estride; w.e_off = nullptr;
   w.excluded = S.col_excluded;
   w.next_row = S.next_row;
@@ -439,11 +439,11 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   uint32_t sj[4];
   int64_t sg[4];
   {
-    const SaEdge SA_G* row = S.e_edge + (size_t)(q < N ? q : 0) * S.estride;
+    const SaEdge SA_G* row = S.e_edge + (q < N ? q : 0);  // slot-major: edge k of row q at [k * N + q]
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const bool in = !VISUAL && q < N && (uint32_t)k < T;  // T == 0: the lists have no capacity at all
-      const SaEdge ed = in ? sa_ldg(row + k) : SaEdge{0, 0u, 0u};
+      const SaEdge ed = in ? sa_ldg(row + (size_t)k * N) : SaEdge{0, 0u, 0u};
       sj[k] = ed.col;
       sg[k] = ed.gain;
     }
@@ -490,10 +490,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
   TAIL_STAMP(1);
   if (VISUAL) {
-    const SaEdge SA_G* row = S.e_edge + (size_t)(q < N ? q : 0) * S.estride;
+    const SaEdge SA_G* row = S.e_edge + (q < N ? q : 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const SaEdge ed = (uint32_t)k < mycnt ? sa_ldg(row + k) : SaEdge{0, 0u, 0u};
+      const SaEdge ed = (uint32_t)k < mycnt ? sa_ldg(row + (size_t)k * N) : SaEdge{0, 0u, 0u};
       sj[k] = ed.col;
       sg[k] = ed.gain;
     }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   int64_t maxg = 0;
   uint32_t usable = 0;
   if (mycnt) {
-    const SaEdge SA_G* row = S.e_edge + (size_t)q * S.estride;
+    const SaEdge SA_G* row = S.e_edge + q;
     // four edges per step: all their loads (and, with a visual vote, the dependent excluded-column flags) are in flight together
     for (uint32_t e0 = 0; e0 < mycnt; e0 += 4) {
       uint32_t jj[4];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const bool in = e0 + k < mycnt;
-          const SaEdge ed = in ? sa_ldg(row + e0 + k) : SaEdge{0, 0u, 0u};
+          const SaEdge ed = in ? sa_ldg(row + (size_t)(e0 + k) * N) : SaEdge{0, 0u, 0u};
           jj[k] = ed.col;
           gg[k] = ed.gain;
           skip[k] = !in;
@@ -593,9 +593,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       sa_assign_ws w;
       w.estride = S.estride;
       w.e_cnt = s_ecnt;
-      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.e_off = s_eoff; w.excluded = nullptr; }
+      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.e_off = s_eoff; w.excluded = nullptr; }
       else {
-        w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.e_off = nullptr;
+        // slot-major lists: row r starts at record r, consecutive edges are N records apart
+        w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4 * N; w.egs = 2 * N; w.rcs = 4; w.rgs = 2; w.e_off = nullptr; w.estride = 1;
         if constexpr (WORDS) w.excluded = s_cexcl;
         else w.excluded = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
       }
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict_
     for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
     for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
     sa_assign_ws w;
-    w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.estride = 0; w.e_off = L.e_off;
+    w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = L.e_off;
     w.excluded = nullptr;
     w.next_row = L.next_row;
     w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;

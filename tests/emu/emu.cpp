@@ -116,7 +116,7 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
       if (label[r] == label[q]) { next_row[q] = r; not_first[r] = 1; break; }
   }
   sa_assign_ws w;
-  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.ecs = 1; w.egs = 1; w.estride = estride; w.e_off = nullptr;
+  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = estride; w.e_off = nullptr;
   w.excluded = col_skip;
   w.next_row = next_row.data();
   w.u = u.data(); w.v = v.data(); w.rmatch = rmatch.data(); w.cmatch = cmatch.data();
