@@ -114,6 +114,21 @@ def test_general_assignment_tail_matches_oracle_too():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_GEMM_BAND": "4"}])
+def test_first_phase_tile_variants_match_oracle_too(env):
+    """SA_FRAME_KG=2: the heterogeneous first phase with two k-groups per contraction tile (512-thread blocks); SA_GEMM_BAND=n: the
+    XCD-aware band order of the contraction's tiles.  Neither is the default (both measured slower or equal); both must still give
+    the oracle's answers."""
+    import os
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_batched_visual"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, str(env) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_two_kernel_bestfit_matches_oracle_too():
     """With one observation per track the contraction emits the BestFit partials itself (no weight matrix, no k_bestfit_tile).
     SA_BESTFIT=tile keeps the matrix + k_bestfit_tile path for those frames as well: same tests, same oracle."""
