@@ -586,14 +586,29 @@ __device__ __forceinline__ void block_max_key(uint32_t SA_G* slots, uint32_t slo
 // compares the candidate's epoch — the same for every row of a scene-frame — with the track's, so its epoch part and the
 // choice of the constraint (spatio_temporal_constraints.rs:48-59) are per-COLUMN facts, folded into GemmCols before the
 // main loop; what is left per cell is dist_in_2r <= max_dist when a constraint applies.
-__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, const sa_geo* row_geo, const GemmCols& col,
+// Bit c of the result: cell c of this lane fails the spatio-temporal constraint of its column (dist_in_2r > max_dist).  One
+// pass, entered only when some lane of the wave has a constrained column at all.
+template <int CELLS, typename RowGeo>
+__device__ __forceinline__ uint32_t constraint_mask(const GemmCols& col, RowGeo row_geo) {
+  uint32_t failed = 0;
+  if (__ballot(col.cmax >= 0.0f) != 0ull) {
+    if (col.cmax >= 0.0f) {
+#pragma unroll
+      for (int c = 0; c < CELLS; ++c) failed |= (sa_dist_in_2r(*row_geo(c), col.g) <= col.cmax) ? 0u : (1u << c);
+    }
+  }
+  return failed;
+}
+__device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, bool cons_failed, const GemmCols& col,
                                              uint32_t* kmax) {
   // Straight-line on purpose: with a short-circuit chain (usable? column ok? ...) the compiler sinks every operand load into the
   // branch that first needs it, and the row operands come from LDS — each cell then pays two or three LDS round trips one after
   // the other.  na = squared norm of the candidate's feature, NaN when feature_can_be_used() says no (the distance is then NaN
-  // and fails is_ok like any NaN).  Only the spatio-temporal constraint, rare and expensive, branches and reads the row geometry.
-  bool ok = col.ok;
-  if (col.cmax >= 0.0f) ok = ok && sa_dist_in_2r(*row_geo, col.g) <= col.cmax;
+  // and fails is_ok like any NaN).  The spatio-temporal constraint, rare and expensive, is evaluated by the caller in a pass of
+  // its own (constraint_mask) and arrives as one bit: a branch per cell made every cell a basic block of its own, and a lone
+  // wave then walks 16 dependent chains (multiply, v_rsq, multiply, compare, key ...) one after the other — 4 k cycles.
+  const bool ok0 = col.ok && !cons_failed;
+  bool ok = ok0;
   // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
   // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
   const float d = dot * __frsqrt_rn(na * col.nb);
@@ -779,11 +794,12 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       nav[g] = *(const f32x4*)(s_na + rbase[g]);
     }
     uint32_t ckey = 0xffffffffu, crow = 0;
+    const uint32_t cfail = constraint_mask<R>(col[0], [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const uint32_t li = rbase[i >> 2] + (i & 3);
       const uint32_t gi = m0 + li;
-      const float w = visual_cell(p, part[i], nav[i >> 2][i & 3], s_g + li, col[0], &kmax);  // rows / columns past the edge: ok = false
+      const float w = visual_cell(p, part[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax);  // rows / columns past the edge: ok = false
       if constexpr (PART) {
         const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
         s_key[li * KS + lc] = key;
@@ -810,6 +826,10 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       f32x4 nav[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) nav[g] = *(const f32x4*)(s_na + wm * (BM / 2) + m * 32 + 8 * g + 4 * lh);
+      uint32_t cfail[TN];
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        cfail[n] = constraint_mask<16>(col[n], [&](int c) { return s_g + wm * (BM / 2) + m * 32 + acc_row(c, lh); });
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t lrow = wm * 32 + acc_row(r, lh);          // row of the 64-row key tile of this pass
@@ -818,7 +838,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           const uint32_t lc = wn * (BN / 2) + n * 32 + lr, gj = n0 + lc;
-          const float w = visual_cell(p, acc[m][n][r], nav[r >> 2][r & 3], s_g + li, col[n], &kmax);
+          const float w = visual_cell(p, acc[m][n][r], nav[r >> 2][r & 3], (cfail[n] >> r) & 1u, col[n], &kmax);
           if constexpr (PART) {
             const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
             s_key[lrow * KS + lc] = key;
