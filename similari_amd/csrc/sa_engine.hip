@@ -439,7 +439,7 @@ int enqueue_frame(sa_engine* e, const SceneDev* ds, uint32_t ns, uint32_t maxN, 
   return SA_OK;
 }
 
-// The whole per-frame device pipeline for the staged scenes.  One stream, ~13 launches, no host decisions.
+// The whole per-frame device pipeline for the staged scenes.  One stream, 2-6 launches (enqueue_frame), no host decisions.
 int run_pipeline(sa_engine* e) {
   const uint32_t ns = e->n_slots;
   if (!ns) return SA_OK;

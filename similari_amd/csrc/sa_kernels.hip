@@ -107,7 +107,8 @@ __global__ void k_quant_tap(const SceneDev* __restrict__ scenes) {
 }
 
 // =====================================================================================================
-// BestFit vote (track/voting/best.rs:52-128) without the sort and without atomics.  Candidate q wins track
+// BestFit vote (track/voting/best.rs:52-128) without the sort (these two kernels: without atomics; frames of one observation per
+// track and at most 1024 x 1024 do not come here at all — vote words, k_assign_small<.., WORDS>).  Candidate q wins track
 // t*(q) — its heaviest group — iff (q, t*) is the first group of column t* in (weight desc, q asc, t asc)
 // order; that is the order the reference's stable sort gives a canonically ordered list.
 //   k_bestfit_tile   : 64 x 64 cells per block, lane = column, wave = 16 rows.  W[q,t] = sum_k f64(max_dist -
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // rows that already hold a visual decision take no part (feature_winners.contains_key(from), visual_sort/voting.rs:77) and
 // columns won visually are skipped while relaxing (excluded_tracks, :62-71).  A component may therefore be larger than
 // strictly needed — harmless, it is still solved exactly.
-//   N <= SA_SMALL_N: k_assign_small — ONE workgroup per scene does labels -> per-component row order (bitonic sort of
-//            (label, row) keys in LDS) -> solve (one thread per component, duals in LDS) -> results,
+//   N <= SA_SMALL_N: k_assign_small — ONE workgroup per scene does labels -> per-component row lists (every row pushes itself
+//            onto its root's LDS list) -> solve (one thread per component, duals in LDS) -> results,
 //   else: k_assign_label (component root per row, rows pushed onto their root's list), k_assign_solve (one thread per
 //            component: orders its rows, solves, writes their results).
 // =====================================================================================================
