@@ -250,6 +250,16 @@ int sa_tap_positional(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_visual(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out);
 
+/* ---- pinned host blocks (optional) --------------------------------------------------------
+ * sa_detections.feats (N x D f32: 2 MB at 1000 x 512) is normally copied into the engine's own pinned staging buffer before it
+ * goes to the device.  A block obtained from sa_host_alloc is pinned already: sa_batch_add / sa_associate* recognise a feats
+ * pointer inside one and the DMA reads it in place.  The caller must leave the block untouched until that frame's results have
+ * been fetched (sa_associate* return after that point; with sa_batch_add: until sa_batch_sync).  A reference-side binding keeps
+ * one block per tracker and writes the candidates' features straight into it — in place of the per-frame Vec<f32> -> Feature
+ * copies of sort-family predict (visual_sort/simple_api.rs:156-158).  Process-wide, thread-safe, independent of any engine. */
+void* sa_host_alloc(uint64_t bytes); /* NULL: no device, or out of memory */
+void sa_host_free(void* block);      /* a pointer returned by sa_host_alloc, or NULL */
+
 /* ---- measurement -------------------------------------------------------------------------- */
 typedef struct sa_kernel_stat {
   char name[48];

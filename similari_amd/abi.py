@@ -354,6 +354,8 @@ PROTOTYPES = {
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_nms": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float), C.c_float, C.c_float, P(u32), P(u32)]),
     "sa_own_areas": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float)]),
+    "sa_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "sa_host_free": (None, [C.c_void_p]),
     "sa_tap_dims": (C.c_int, [ENGINE, u32, P(u32), P(u32), P(u32)]),
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -858,6 +859,33 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
   return sa_batch_add_rows(e, scene_id, epoch, d, nullptr, out_slot);
 }
 
+// ---- pinned host blocks handed out to callers (sa_host_alloc): process-wide registry, looked up per staged frame ----
+static std::mutex g_pin_mu;
+static std::vector<std::pair<const char*, size_t>> g_pins;
+extern "C" void* sa_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (!bytes || hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pins.emplace_back((const char*)p, (size_t)bytes);
+  return p;
+}
+extern "C" void sa_host_free(void* block) {
+  if (!block) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pins.size(); ++i)
+      if (g_pins[i].first == (const char*)block) { g_pins.erase(g_pins.begin() + i); break; }
+  }
+  (void)hipHostFree(block);
+}
+static bool in_pinned_block(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  const char* q = (const char*)p;
+  for (const auto& b : g_pins)
+    if (q >= b.first && q + bytes <= b.first + b.second) return true;
+  return false;
+}
+
 // sa_batch_add with the feature rows given one pointer per detection (nullptr = no feature) instead of one N x D block: the
 // tracker facade receives its observations that way (VisualSortObservation.feature) and would otherwise assemble the block only
 // for it to be copied again into the pinned staging buffer — 2 MB twice per frame at C2.  Not part of the C ABI.
@@ -911,8 +939,14 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
           if (feat_rows[i]) std::memcpy(dst, feat_rows[i], (size_t)D * 4);
           else std::memset(dst, 0, (size_t)D * 4);
         }
-      } else std::memcpy(h + o_feat, d->feats, (size_t)N * D * 4);
-      HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, h + o_feat, (size_t)N * D * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, h + o_feat, (size_t)N * D * 4, hipMemcpyHostToDevice, st));
+      } else if (in_pinned_block(d->feats, (size_t)N * D * 4)) {
+        // the caller's block is pinned (sa_host_alloc): the DMA reads it in place, no staging copy
+        HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, d->feats, (size_t)N * D * 4, hipMemcpyHostToDevice, st));
+      } else {
+        std::memcpy(h + o_feat, d->feats, (size_t)N * D * 4);
+        HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, h + o_feat, (size_t)N * D * 4, hipMemcpyHostToDevice, st));
+      }
     }
     e->synced = false;
   }

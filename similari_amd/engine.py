@@ -82,6 +82,24 @@ class Engine:
         )
         return ids, votes
 
+    def host_block(self, shape, dtype=np.float32):
+        """A numpy array over a pinned block from sa_host_alloc: detections' features written here go to the device without the
+        staging copy.  Keep the returned array (and call host_free on it) — the block is not garbage collected."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.sa_host_alloc(n)
+        if not p:
+            raise MemoryError("sa_host_alloc failed")
+        buf = (C.c_char * n).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._blocks = getattr(self, "_blocks", {})
+        self._blocks[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_blocks", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.sa_host_free(p)
+
     def batch_begin(self):
         self._chk(self.lib.sa_batch_begin(self.h))
 

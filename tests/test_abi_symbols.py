@@ -28,7 +28,7 @@ def lib():
 @pytest.mark.parametrize("header", ["similari_assoc.h", "similari_tracker.h"])
 def test_every_declared_function_is_exported(lib, header):
     names = declared(header)
-    assert len(names) == (29 if header == "similari_assoc.h" else 15), names
+    assert len(names) == (31 if header == "similari_assoc.h" else 15), names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"{header} declares functions the library does not export: {missing}"
 
@@ -64,3 +64,17 @@ def test_engine_refuses_to_run_without_a_gpu(lib):
     rc = lib.sa_engine_create(C.byref(cfg), C.byref(h))
     assert rc == abi.SA_ERR_NO_DEVICE, rc
     assert b"no CPU fallback" in lib.sa_last_error(None)
+
+
+def test_pinned_blocks_need_a_device_too(lib):
+    """sa_host_alloc hands out pinned host memory for zero-staging uploads: NULL without a GPU (no silent malloc fallback), and
+    sa_host_free(NULL) is a no-op."""
+    import torch
+
+    p = lib.sa_host_alloc(4096)
+    if torch.cuda.is_available():
+        assert p
+        lib.sa_host_free(p)
+    else:
+        assert not p
+    lib.sa_host_free(None)

@@ -226,6 +226,35 @@ def test_resolve_as_its_own_launch_matches_oracle_too():
         assert r.returncode == 0, mode + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_features_from_a_pinned_block_give_the_same_answers():
+    """sa_host_alloc: a feats pointer inside such a block is DMA'd in place (no staging copy).  Same answers as from pageable
+    memory, frame after frame, also when the block is rewritten between frames and when only part of it is used."""
+    rng = np.random.default_rng(31)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    eng = Engine(cfg)
+    block = eng.host_block((400, 64))
+    try:
+        for n, t in [(300, 320), (400, 320), (17, 330)]:
+            sc = synth.visual_scene(rng, t, n, 64, 1, canvas=(1600.0, 900.0), new_fraction=0.1)
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+            eng.upsert(0, tracks)
+            block[:n] = sc["det_feats"]
+            pinned = abi.make_detections(sc["det_boxes"], feats=block[:n], feat_quality=sc["det_quality"])
+            pageable = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+            ids_p, votes_p = eng.associate(0, 1, pinned)
+            ids, votes = eng.associate(0, 1, pageable)
+            ref = O.associate(cfg, tracks, 1, pageable)
+            np.testing.assert_array_equal(ids_p, ref["track_id"])
+            np.testing.assert_array_equal(votes_p, ref["voting_type"])
+            np.testing.assert_array_equal(ids, ids_p)
+            np.testing.assert_array_equal(votes, votes_p)
+    finally:
+        eng.host_free(block)
+        eng.close()
+
+
 @pytest.mark.parametrize("k", [2, 1])
 def test_graph_replay_gives_the_same_answers(k):
     """SA_FLAG_GRAPH: the per-frame launches are captured once and replayed while the staged set is unchanged, re-captured when
