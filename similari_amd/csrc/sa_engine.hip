@@ -650,7 +650,7 @@ void sa_engine_destroy(sa_engine* e) {
   for (Slot* s : e->slots) {
     for (DevBuf* b : {&s->raw, &s->quality, &s->own, &s->fpresent_in, &s->feat_raw, &s->geo, &s->verts, &s->z, &s->conf,
                       &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
-                      &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded,
+                      &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                       &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                       &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
                       &s->bank_tmp})
