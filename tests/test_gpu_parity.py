@@ -755,6 +755,100 @@ def test_full_size_sort_oriented_c4_properties():
         eng.close()
 
 
+def test_full_size_batch_c3_against_the_oracle():
+    """BASELINE config C3's per-GPU share (8 scenes x 500 x 500, axis-aligned IoU) as ONE batch: every scene's answers are the
+    oracle's (500 x 500 is still affordable on the host), and the same as that scene's alone."""
+    rng = np.random.default_rng(33)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    scs = [synth.sort_scene(rng, 500, 500, canvas=(4096.0, 4096.0)) for _ in range(8)]
+    eng = Engine(cfg)
+    try:
+        dets, tracks = [], []
+        for s, sc in enumerate(scs):
+            tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+            eng.upsert(s, tr)
+            tracks.append(tr)
+            dets.append(abi.make_detections(sc["det_boxes"]))
+        eng.batch_begin()
+        slots = [eng.batch_add(s, 1, d) for s, d in enumerate(dets)]
+        eng.batch_run()
+        eng.batch_sync()
+        got = [eng.batch_fetch(sl, 500) for sl in slots]
+        for s, sc in enumerate(scs):
+            ref = O.associate(cfg, tracks[s], 1, dets[s], want_matrices=False)
+            np.testing.assert_array_equal(got[s][0], ref["track_id"], err_msg=f"scene {s}")
+            np.testing.assert_array_equal(got[s][1], ref["voting_type"])
+            assert (got[s][0] == sc["truth"]).mean() > 0.9
+        alone, _ = eng.associate(3, 1, dets[3])
+        np.testing.assert_array_equal(alone, got[3][0])
+    finally:
+        eng.close()
+
+
+def test_full_size_properties_c5():
+    """BASELINE config C5 (5000 tracks x 2000 detections x 4096-d cosine): size-independent properties — identities re-found,
+    idempotence, permutation equivariance, and the weights of a sample of candidates against an f64 numpy contraction."""
+    rng = np.random.default_rng(5)
+    t, n, d = 5000, 2000, 4096
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(7680.0, 4320.0))
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"]))
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ids, votes = eng.associate(0, 1, det)
+        np.testing.assert_array_equal(ids, sc["truth"])
+        assert (votes == abi.SA_VOTE_VISUAL).all()
+        ids2, _ = eng.associate(0, 1, det)
+        np.testing.assert_array_equal(ids, ids2)
+        p = rng.permutation(n)
+        det_p = abi.make_detections(sc["det_boxes"][p], feats=sc["det_feats"][p], feat_quality=sc["det_quality"][p])
+        ids3, _ = eng.associate(0, 1, det_p)
+        np.testing.assert_array_equal(ids3, ids[p])
+        vis = eng.tap_visual()[:, :, 0]
+        rows = np.arange(0, n, 16)  # 125 candidates of the permuted frame against all 5000 tracks
+        a64, b64 = sc["det_feats"][p][rows].astype(np.float64), sc["track_feats"][:, 0].astype(np.float64)
+        ref = 1.0 - (a64 @ b64.T) / np.sqrt((a64 * a64).sum(1)[:, None] * (b64 * b64).sum(1)[None, :])
+        m = ~np.isnan(vis[rows])
+        assert m.mean() > 0.2
+        assert np.abs(vis[rows][m] - ref[m]).max() <= 1e-5
+    finally:
+        eng.close()
+
+
+def test_full_size_properties_c2_euclidean():
+    """The C2 frame with the euclidean metric (vector-pipe kernel, vote words): identities re-found, idempotence, permutation
+    equivariance, distances against f64 numpy within 1e-5 relative."""
+    rng = np.random.default_rng(6)
+    n = t = 1000
+    d = 512
+    sc = synth.visual_scene(rng, t, n, d, 1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=0.5, feature_len=d,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"]))
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ids, votes = eng.associate(0, 1, det)
+        np.testing.assert_array_equal(ids, sc["truth"])
+        assert (votes == abi.SA_VOTE_VISUAL).all()
+        p = rng.permutation(n)
+        det_p = abi.make_detections(sc["det_boxes"][p], feats=sc["det_feats"][p], feat_quality=sc["det_quality"][p])
+        ids3, _ = eng.associate(0, 1, det_p)
+        np.testing.assert_array_equal(ids3, ids[p])
+        vis = eng.tap_visual()[:, :, 0]
+        a64, b64 = sc["det_feats"][p].astype(np.float64), sc["track_feats"][:, 0].astype(np.float64)
+        ref = np.sqrt(np.maximum(((a64 * a64).sum(1)[:, None] + (b64 * b64).sum(1)[None, :] - 2.0 * (a64 @ b64.T)), 0.0))
+        m = ~np.isnan(vis)
+        assert m.sum() >= n  # at least the true pairs are within the threshold
+        assert (np.abs(vis[m] - ref[m]) <= 1e-5 * ref[m] + 1e-6).all()
+    finally:
+        eng.close()
+
+
 # ---- randomized sweep over the configuration space --------------------------------------------------------------------
 def _fuzz_case(seed):
     """One random (config, scene): sizes around the tile edges (16, 64, 128, 256), every metric pair, ragged banks, missing
