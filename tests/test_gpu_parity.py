@@ -785,6 +785,18 @@ def test_full_size_batch_c3_against_the_oracle():
         eng.close()
 
 
+def test_full_size_maha_c3_against_the_oracle():
+    """BASELINE config C3's Mahalanobis half at its full per-scene size (500 x 500, Kalman states from three oracle cycles): every
+    cost cell and the quantised matrix bit-identical to the oracle, equal assignment total (cost-0 ties leave the ids free)."""
+    rng = np.random.default_rng(35)
+    sc = synth.sort_scene(rng, 500, 500, canvas=(4096.0, 4096.0))
+    kf = kf_states(rng, sc["track_boxes"])
+    sc["det_boxes"] = synth.jitter_boxes(rng, kf[0], 2.0)[rng.permutation(500)]
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.05, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc, kf=kf, require_ids=False)
+    assert (ids != 0).sum() > 400
+
+
 def test_full_size_properties_c5():
     """BASELINE config C5 (5000 tracks x 2000 detections x 4096-d cosine): size-independent properties — identities re-found,
     idempotence, permutation equivariance, and the weights of a sample of candidates against an f64 numpy contraction."""
