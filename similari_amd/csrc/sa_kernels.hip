@@ -824,7 +824,8 @@ hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uin
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
                            hipStream_t st) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-  const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
+  static const char* wide_env = getenv("SA_POS_WIDE");  // measurements: 0 / 1 force the narrow / wide positional tiles
+  const bool wide = wide_env ? wide_env[0] == '1' : (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
   const bool uni = maxN > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT) ? cdiv(maxN, POS_TI) : 0u;
