@@ -114,17 +114,18 @@ def test_general_assignment_tail_matches_oracle_too():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_GEMM_BAND": "4"}])
+@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_GEMM_BAND": "4"}, {"SA_POS_WIDE": "0"}, {"SA_POS_WIDE": "1"}])
 def test_first_phase_tile_variants_match_oracle_too(env):
     """SA_FRAME_KG=2: the heterogeneous first phase with two k-groups per contraction tile (512-thread blocks); SA_GEMM_BAND=n: the
-    XCD-aware band order of the contraction's tiles.  Neither is the default (both measured slower or equal); both must still give
-    the oracle's answers."""
+    XCD-aware band order of the contraction's tiles; SA_POS_WIDE=0|1: narrow / wide positional tiles regardless of the frame.  None
+    is the default rule (all measured slower or equal); all must still give the oracle's answers."""
     import os
     import subprocess
     import sys
 
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_batched_visual"],
+                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_batched_visual or "
+                        "test_sort_iou_parity or test_sort_maha_parity or test_batched_scenes or test_full_size_sort_oriented"],
                        env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, str(env) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
 
