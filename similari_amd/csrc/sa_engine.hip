@@ -84,8 +84,7 @@ struct sa_engine {
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the staged set changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  uint32_t graph_key[4] = {0, 0, 0, 0};  // ns, maxN, maxT, valid
-  bool descs_changed = true;
+  uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};  // launch geometry + kernel selection of the captured frame (run_pipeline)
   uint32_t K = 1, D = 0, Dp = 0;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for the current batch (sa_visual_tile)
   bool f16_split = false;               // SA_FLAG_F16_SPLIT: the contraction's operands as f16 pairs (separate launches only)
@@ -387,7 +386,6 @@ int upload_scene_descs(sa_engine* e) {
   for (uint32_t i = 0; i < ns; ++i) fill_scene_dev(e, e->slots[i], &b[i]);
   if (e->desc_last.size() == bytes && bytes && std::memcmp(e->desc_last.data(), e->desc_build.data(), bytes) == 0 && e->d_scenes.p)
     return SA_OK;
-  e->descs_changed = true;
   if (!e->synced) TRY(engine_sync(e));
   TRY(host_ensure(e, e->h_scenes, bytes));
   TRY(dev_ensure(e, e->d_scenes, bytes));
@@ -465,24 +463,37 @@ int run_pipeline(sa_engine* e) {
                                   (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
     HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, 2 * SA_SMALL_N * 8, st));  // vote words: all ones = no group
     s->needs_init = false;
-    e->descs_changed = true;  // a captured graph must not skip this
   }
   if ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile) {
-    const uint32_t key[4] = {ns, maxN, maxT, 1u};
-    if (!e->graph_exec || e->descs_changed || std::memcmp(key, e->graph_key, sizeof key) != 0) {
+    // The captured launches read every per-frame value (epoch, pointers, sizes of each scene) from the descriptor array in device
+    // memory at replay; what is baked into the graph is the launch geometry and the kernel selection.  Recapture only when one
+    // of those changes: a tracker that bumps the epoch every frame replays the same graph.
+    uint32_t feats_mask = 0;
+    for (uint32_t i = 0; i < ns; ++i) feats_mask = feats_mask * 31u + (e->slots[i]->has_feats ? 1u : 0u) + 7u;
+    const uint64_t key[6] = {((uint64_t)ns << 32) | 1u, ((uint64_t)maxN << 32) | maxT, ((uint64_t)e->tile_bm << 32) | e->tile_bn,
+                             (uint64_t)(uintptr_t)e->d_scenes.p, feats_mask, 0};
+    if (!e->graph_exec || std::memcmp(key, e->graph_key, sizeof key) != 0) {
       if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
       if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+      std::memset(e->graph_key, 0, sizeof e->graph_key);
       HIPCHK(e, hipStreamSynchronize(st));  // the descriptor upload must not be part of the capture
       HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_frame(e, ds, ns, maxN, maxT);
       hipError_t ce = hipStreamEndCapture(st, &e->graph);
-      if (rc != SA_OK) return rc;
-      if (ce != hipSuccess) return fail(e, SA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      if (rc != SA_OK || ce != hipSuccess) {
+        if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+        for (uint32_t i = 0; i < ns; ++i) e->slots[i]->needs_init = true;  // nothing ran, but keep the rule of the eager path
+        if (rc != SA_OK) return rc;
+        return fail(e, SA_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      }
       HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
       std::memcpy(e->graph_key, key, sizeof key);
-      e->descs_changed = false;
     }
-    HIPCHK(e, hipGraphLaunch(e->graph_exec, st));
+    hipError_t ge = hipGraphLaunch(e->graph_exec, st);
+    if (ge != hipSuccess) {
+      for (uint32_t i = 0; i < ns; ++i) e->slots[i]->needs_init = true;
+      return fail(e, SA_ERR_HIP, "hipGraphLaunch failed: %s", hipGetErrorString(ge));
+    }
   } else {
     int rc = enqueue_frame(e, ds, ns, maxN, maxT);
     if (rc != SA_OK) {  // a frame that died half-way may leave the self-cleaning state dirty
@@ -691,6 +702,13 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
     if (t->ids[i] == 0) return fail(e, SA_ERR_BAD_ARG, "track id must be > 0 (sort/voting.rs:57)");
     TRY(check_box(e, t->boxes[i], "tracks.boxes", i));
   }
+  {  // one row per id and call: two entries for the same id would be written to the same table row by different threads
+    std::vector<uint64_t> sorted_ids(t->ids, t->ids + n);
+    std::sort(sorted_ids.begin(), sorted_ids.end());
+    for (uint32_t i = 1; i < n; ++i)
+      if (sorted_ids[i] == sorted_ids[i - 1])
+        return fail(e, SA_ERR_BAD_ARG, "sa_tracks_upsert: track id %llu given twice in one call", (unsigned long long)sorted_ids[i]);
+  }
   HIPCHK(e, hipSetDevice(e->device));
   SceneTable* sc = get_scene(e, scene_id, true);
   std::vector<uint32_t> slots(n);
@@ -807,12 +825,22 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
       arrs.push_back({&sc->fcount, 4u});
       arrs.push_back({&sc->fquality, K * 4u});
     }
-    for (auto& a : arrs) {
-      DevBuf nb;
-      TRY(dev_ensure(e, nb, a.b->cap));
-      HIPCHK(e, sa_launch_gather_rows(a.b->p, nb.p, (const uint32_t*)e->up_index.p, nT, a.row, e->stream));
-      e->garbage.push_back(a.b->p);
-      *a.b = nb;
+    // every new array is built before any is swapped in: a failure half-way leaves the table as it was
+    std::vector<DevBuf> fresh(arrs.size());
+    int rc = SA_OK;
+    for (size_t k = 0; k < arrs.size() && rc == SA_OK; ++k) {
+      rc = dev_ensure(e, fresh[k], arrs[k].b->cap);
+      if (rc == SA_OK && sa_launch_gather_rows(arrs[k].b->p, fresh[k].p, (const uint32_t*)e->up_index.p, nT, arrs[k].row, e->stream) != hipSuccess)
+        rc = fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc != SA_OK) {
+      hipStreamSynchronize(e->stream);
+      for (DevBuf& b : fresh) if (b.p) hipFree(b.p);
+      return rc;
+    }
+    for (size_t k = 0; k < arrs.size(); ++k) {
+      e->garbage.push_back(arrs[k].b->p);
+      *arrs[k].b = fresh[k];
     }
   }
   {

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
   const uint32_t i = blockIdx.x;
   if (i >= a.n) return;
   __shared__ uint8_t s_src[SA_MAX_BANK];
-  __shared__ float s_q[SA_MAX_BANK], s_nrm[SA_MAX_BANK];
+  __shared__ float s_q[SA_MAX_BANK + 1], s_nrm[SA_MAX_BANK];  // s_q[K] = the new observation's quality (K may be SA_MAX_BANK)
   __shared__ uint32_t s_newfeat;
   const uint32_t K = a.K, Dp = a.Dp, tid = threadIdx.x;
   const int32_t col = a.win_col[i];

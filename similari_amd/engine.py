@@ -96,8 +96,14 @@ class Engine:
         return arr
 
     def host_free(self, arr):
+        """Frees a block from host_block().  `arr` (and every view of it) points at freed pinned memory afterwards and must not
+        be touched again; the array is made read-only so that a stray write raises instead of corrupting the heap."""
         p = getattr(self, "_blocks", {}).pop(arr.ctypes.data, None)
         if p:
+            try:
+                arr.flags.writeable = False
+            except ValueError:
+                pass
             self.lib.sa_host_free(p)
 
     def batch_begin(self):

@@ -211,6 +211,10 @@ class _Tracker:
                 box, cid = it
                 feat, q, own = None, None, None
             o = arr[i]
+            if isinstance(box, BoundingBox):  # bbox.rs:246-257: ltwh -> xyaah in f32; bbox.rs:123-126: confidence in [0, 1]
+                if not (0.0 <= box.confidence <= 1.0):
+                    raise TrackerError(f"confidence {box.confidence} must lie within [0.0, 1.0] (bbox.rs:123-126)")
+                box = box.as_xyaah()
             o.bbox = box.to_c() if isinstance(box, Universal2DBox) else box
             if feat is not None and self.opts.visual:
                 assert len(feat) == D, f"feature length {len(feat)} != {D}"

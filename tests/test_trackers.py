@@ -315,6 +315,13 @@ def test_visual_cosine_single_observation_sequence_matches_oracle(backend):
 
 @pytest.mark.gpu
 @UPKEEP
+def test_visual_cosine_deepest_bank_sequence_matches_oracle(backend):
+    """visual_max_observations = SA_MAX_BANK (16): k_apply_bank keeps the new observation's quality one slot past the bank."""
+    run_visual_sequence(TR.VisualSortMetricType.cosine(0.5), IoU(0.3), seed=31, frames=20, n=24, d=32, backend=backend, bank=16)
+
+
+@pytest.mark.gpu
+@UPKEEP
 def test_visual_euclid_maha_sequence_matches_oracle(backend):
     run_visual_sequence(TR.VisualSortMetricType.euclidean(0.5), TR.PositionalMetricType.maha(), seed=23, batch=True, backend=backend)
 
