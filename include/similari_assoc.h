@@ -121,8 +121,8 @@ typedef struct sa_config {
                                          |error| < 1e-6 on a cosine, several times the f32 rate; NOT f32 arithmetic — opt-in) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 
-/* Fill *cfg with the reference's defaults (IoU(0.3), min confidence 0.05, no visual part,
- * max_idle_epochs 5? -> no: caller must set it; KF weights 1/20, 1/160). */
+/* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,
+ * one observation per track, max_idle_epochs 5, Kalman weights 1/20 and 1/160 (kalman_2d_box.rs:26), device -1. */
 void sa_config_default(sa_config* cfg);
 
 typedef struct sa_engine sa_engine;
@@ -180,13 +180,19 @@ int sa_associate(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
  * time only the device work:
  *   sa_batch_begin  — waits for the previous batch (the reference's "busy monitor",
  *                     sort/batch_api.rs:233-241), clears the staged list
- *   sa_batch_add    — stage one scene's detections (async H2D); returns its slot in *out_slot
- *   sa_batch_run    — enqueue the whole pipeline on the engine's stream; does not synchronise
+ *   sa_batch_add    — stage one scene's detections in the pinned staging arena; returns its slot in *out_slot
+ *   sa_batch_run    — one H2D copy of the staged set (first run only), then the whole pipeline on the engine's stream; does not
+ *                     synchronise
  *   sa_batch_sync   — wait for the stream
  *   sa_batch_fetch  — copy one scene's result back (synchronises if needed)
  * sa_batch_run may be called repeatedly on the same staged inputs (benchmark loop). */
 int sa_batch_begin(sa_engine* e);
 int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, uint32_t* out_slot);
+/* sa_batch_add with the feature rows given one pointer per detection (feat_rows[i] == NULL: detection i has no feature; d->feats is
+ * ignored) — the shape the reference hands them over in, VisualSortObservation.feature: Option<&[f32]>
+ * (visual_sort/simple_api.rs:130-170): the rows go straight into the pinned staging block, no N x D assembly on the caller's side. */
+int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
+                      uint32_t* out_slot);
 int sa_batch_run(sa_engine* e);
 int sa_batch_sync(sa_engine* e);
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type);
@@ -239,6 +245,48 @@ typedef struct sa_scene_result {
 } sa_scene_result;
 int sa_associate_batch(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, const sa_scene_result* res);
 
+/* ---- pipelined request sets: H2D of frame n+1 beside the kernels of frame n ------------------------------------
+ * The reference's predict() takes its detections (boxes + 512..4096-d features) from host memory every frame
+ * (visual_sort/simple_api.rs:130-170).  sa_associate* does stage -> DMA -> kernels -> results one after the other; the calls
+ * below keep TWO request sets in flight on two streams, so that the DMA of the next set (2 MB at 1000 x 512-d) runs beside
+ * the kernels of the current one and a stream of frames costs max(DMA, kernels) instead of their sum:
+ *   sa_pipe_stage   lays the request set out in a pinned staging arena (features inside a sa_host_alloc block are not copied:
+ *                   the DMA reads them in place) and queues ONE host-to-device copy on the copy stream; returns a ticket
+ *   sa_pipe_launch  queues the kernels behind that copy on the compute stream; the track tables are read as they are at THIS
+ *                   call, so sa_tracks_upsert / sa_tracks_apply of the previous frame may sit between stage and launch
+ *   sa_pipe_submit  = stage + launch
+ *   sa_pipe_wait    blocks until the ticket's kernels have retired and copies its results out (res[i] belongs to req[i]);
+ *                   afterwards slot numbers of sa_tracks_apply / sa_batch_fetch / the taps refer to this ticket's scenes
+ * At most two tickets are outstanding (SA_ERR_STATE otherwise).  Buffers handed to sa_pipe_stage may be reused as soon as it
+ * returns, except feature blocks from sa_host_alloc, which must stay untouched until the ticket has been waited for.
+ * A tracker loop with device-side upkeep:  stage(n+1); wait(n); apply(n); launch(n+1). */
+int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, uint64_t* out_ticket);
+int sa_pipe_launch(sa_engine* e, uint64_t ticket);
+int sa_pipe_submit(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, uint64_t* out_ticket);
+int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res);
+
+/* ---- one process, several GPUs: scenes sharded over one engine per device -------------------------------------
+ * BatchSort / BatchVisualSort fan the scenes of a request out to voting threads of one process (sort/batch_api.rs:197-207,
+ * 278-288; visual_sort/batch_api.rs:296-315); scenes never interact (compatible() is false across scene ids, sort.rs:251).
+ * A cluster owns one engine per device and one worker thread per engine and routes by  scene_id % n_shards  (sticky: a scene's
+ * track table stays resident on its GPU).  sa_cluster_associate_batch = scatter the request set by shard, every shard runs ONE
+ * sa_associate_batch on its GPU concurrently with the others, gather — res[i] belongs to req[i].  No collective, no copy
+ * between GPUs.  devices: n_shards HIP ordinals, or NULL for 0..n_shards-1 (an ordinal may repeat: several shards on one GPU).
+ * sa_cluster_last_ms(shard): wall time the shard's worker spent inside its last call (for load-balance / scaling reports).
+ * sa_cluster_engine(shard): the shard's engine, for the per-engine entry points (taps, sa_tracks_apply, ...) — not while a
+ * cluster call is running. */
+typedef struct sa_cluster sa_cluster;
+int sa_cluster_create(const sa_config* cfg, uint32_t n_shards, const int32_t* devices, sa_cluster** out);
+void sa_cluster_destroy(sa_cluster* c);
+const char* sa_cluster_last_error(const sa_cluster* c); /* c may be NULL: last create() error of this thread */
+uint32_t sa_cluster_size(const sa_cluster* c);
+uint32_t sa_cluster_shard_of(const sa_cluster* c, uint64_t scene_id);
+sa_engine* sa_cluster_engine(sa_cluster* c, uint32_t shard);
+int sa_cluster_tracks_upsert(sa_cluster* c, uint64_t scene_id, const sa_tracks* t);
+int sa_cluster_tracks_remove(sa_cluster* c, uint64_t scene_id, uint32_t n, const uint64_t* ids);
+int sa_cluster_associate_batch(sa_cluster* c, uint32_t n_scenes, const sa_scene_request* req, const sa_scene_result* res);
+double sa_cluster_last_ms(const sa_cluster* c, uint32_t shard);
+
 /* ---- parity taps (debug / test): the matrices of the last run of batch slot `slot` --------
  * Row = candidate in input order, column = track in sa_tracks_order() order.
  *   positional: N x T f32, NaN = absent (SortMetric::metric / VisualMetric::positional_metric)
@@ -271,10 +319,10 @@ int sa_profile_read(sa_engine* e, sa_kernel_stat* out, uint32_t cap, uint32_t* o
 /* hipEvent-timed wall time of `iters` back-to-back sa_batch_run()s on the engine's stream. */
 int sa_batch_time(sa_engine* e, uint32_t iters, double* out_ms_total);
 
-/* Standalone cost-matrix entry point (config C5 / MFMA roofline): out[n x t] f32 of
- * cosine (kind 1) or euclidean (kind 2) distance between device-resident?  No: host pointers;
- * the call copies, runs the contraction kernel `iters` times, reports the hipEvent time of the
- * kernel alone, and copies the matrix back when out != NULL. */
+/* Standalone cost-matrix entry point (config C5 / MFMA roofline): out[n x t] f32 of cosine (kind 1) or euclidean (kind 2)
+ * distance (src/distance.rs:9-47) between the rows of a[n x d] and b[t x d], both HOST pointers.  The call copies them to the
+ * device, runs the contraction kernel once untimed and `iters` times between two hipEvents (the kernel alone), and copies the
+ * matrix back when out != NULL. */
 int sa_feature_distance_matrix(sa_engine* e, int32_t visual_kind, uint32_t n, uint32_t t, uint32_t d,
                                const float* a, const float* b, float* out, uint32_t iters, double* out_ms_total);
 

@@ -10,6 +10,7 @@
 #include <limits>
 #include <map>
 #include <unordered_map>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -656,6 +657,16 @@ int or_visual_voting(float positional_threshold, float max_feature_distance, uin
 // Orchestration follows sort/simple_api.rs:110-196 and visual_sort/simple_api.rs:99-230.
 int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_tracks* tracks, uint64_t epoch,
                  const sa_detections* det, or_frame_out* out) {
+  return or_associate_sharded(cfg, total_tracks_in_store, tracks, epoch, det, out, 1);
+}
+
+// The same with the distance stage spread over `shards` host threads the way the reference's TrackStore spreads it
+// (store.rs:490-493: a track lives in shard id % shards; store.rs:199-241: every shard's worker computes the distances of ALL
+// candidates against ITS tracks), followed by ONE vote over the merged distances (sort/simple_api.rs:147-162).  The merged list
+// is put back into the canonical order (candidates in input order, tracks in table order, observations in bank order), so the
+// result is the single-thread result, cell for cell and id for id.
+int or_associate_sharded(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_tracks* tracks, uint64_t epoch,
+                         const sa_detections* det, or_frame_out* out, uint32_t shards) {
   const uint32_t N = det->n, T = tracks->n;
   const bool visual = cfg->visual_kind != SA_VIS_NONE;
   const uint32_t K = visual ? std::max(1u, cfg->max_observations) : 1u;
@@ -686,8 +697,12 @@ int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_
 
   std::vector<Dist> dists;
   std::vector<uint64_t> cand_ids(N);
+  for (uint32_t i = 0; i < N; ++i) cand_ids[i] = CAND | (uint64_t)(i + 1);
+  if (shards < 1) shards = 1;
+  struct Keyed { uint64_t key; Dist d; };
+  // one shard's share of foreign_track_distances: every candidate against the tracks with id % shards == shard
+  auto shard_work = [&](uint32_t shard, std::vector<Keyed>& sink) {
   for (uint32_t i = 0; i < N; ++i) {
-    cand_ids[i] = CAND | (uint64_t)(i + 1);
     const sa_box* cb = &det->boxes[i];
     bool can_use = false;
     if (visual) {
@@ -701,6 +716,7 @@ int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_
       can_use = bbox_ok && quality_ok && perc_ok;
     }
     for (uint32_t j = 0; j < T; ++j) {
+      if (shards > 1 && tracks->ids[j] % shards != shard) continue;
       const sa_box* tb = &tracks->boxes[j];
       if (!or_compatible(cfg, cb, epoch, tb, tracks->epochs[j])) continue;
       if (out->compatible) out->compatible[(size_t)i * T + j] = 1;
@@ -727,9 +743,29 @@ int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_
         if (out->quantised && k == 0) out->quantised[(size_t)i * T + j] = or_quantise(some(pos) ? pos : 0.0f);
         if (out->visual) out->visual[((size_t)i * T + j) * K + k] = vis;
         bool keep = visual ? (some(pos) || some(vis)) : some(pos);
-        if (keep) dists.push_back({cand_ids[i], tracks->ids[j], pos, vis});
+        if (keep) sink.push_back({((uint64_t)i * T + j) * K + k, {cand_ids[i], tracks->ids[j], pos, vis}});
       }
     }
+  }
+  };
+  if (shards == 1) {
+    std::vector<Keyed> all;
+    shard_work(0, all);
+    dists.reserve(all.size());
+    for (const Keyed& kd : all) dists.push_back(kd.d);
+  } else {
+    std::vector<std::vector<Keyed>> part(shards);
+    std::vector<std::thread> th;
+    for (uint32_t sh = 0; sh < shards; ++sh) th.emplace_back([&, sh] { shard_work(sh, part[sh]); });
+    for (auto& t : th) t.join();
+    std::vector<Keyed> all;
+    size_t total = 0;
+    for (auto& p : part) total += p.size();
+    all.reserve(total);
+    for (auto& p : part) { all.insert(all.end(), p.begin(), p.end()); std::vector<Keyed>().swap(p); }
+    std::sort(all.begin(), all.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });  // keys are unique
+    dists.reserve(all.size());
+    for (const Keyed& kd : all) dists.push_back(kd.d);
   }
   out->n_distances = dists.size();
   out->total_weight = 0;

@@ -106,6 +106,10 @@ typedef struct or_frame_out {
 } or_frame_out;
 int or_associate(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_tracks* tracks,
                  uint64_t epoch, const sa_detections* det, or_frame_out* out);
+/* The same, with the distance stage on `shards` host threads partitioned track id % shards like the reference's TrackStore
+ * (store.rs:490-493) and one vote after the shards (sort/simple_api.rs:147-162).  Same results as or_associate. */
+int or_associate_sharded(const sa_config* cfg, uint32_t total_tracks_in_store, const sa_tracks* tracks,
+                         uint64_t epoch, const sa_detections* det, or_frame_out* out, uint32_t shards);
 
 #ifdef __cplusplus
 }

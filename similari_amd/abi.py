@@ -345,10 +345,25 @@ PROTOTYPES = {
     "sa_associate": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u64), P(C.c_uint8)]),
     "sa_batch_begin": (C.c_int, [ENGINE]),
     "sa_batch_add": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u32)]),
+    "sa_batch_add_rows": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(P(C.c_float)), P(u32)]),
     "sa_batch_run": (C.c_int, [ENGINE]),
     "sa_batch_sync": (C.c_int, [ENGINE]),
     "sa_batch_fetch": (C.c_int, [ENGINE, u32, P(u64), P(C.c_uint8)]),
     "sa_associate_batch": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(sa_scene_result)]),
+    "sa_pipe_stage": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(u64)]),
+    "sa_pipe_launch": (C.c_int, [ENGINE, u64]),
+    "sa_pipe_submit": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(u64)]),
+    "sa_pipe_wait": (C.c_int, [ENGINE, u64, P(sa_scene_result)]),
+    "sa_cluster_create": (C.c_int, [P(sa_config), u32, P(i32), P(C.c_void_p)]),
+    "sa_cluster_destroy": (None, [C.c_void_p]),
+    "sa_cluster_last_error": (C.c_char_p, [C.c_void_p]),
+    "sa_cluster_size": (u32, [C.c_void_p]),
+    "sa_cluster_shard_of": (u32, [C.c_void_p, u64]),
+    "sa_cluster_engine": (C.c_void_p, [C.c_void_p, u32]),
+    "sa_cluster_tracks_upsert": (C.c_int, [C.c_void_p, u64, P(sa_tracks)]),
+    "sa_cluster_tracks_remove": (C.c_int, [C.c_void_p, u64, u32, P(u64)]),
+    "sa_cluster_associate_batch": (C.c_int, [C.c_void_p, u32, P(sa_scene_request), P(sa_scene_result)]),
+    "sa_cluster_last_ms": (C.c_double, [C.c_void_p, u32]),
     "sa_tracks_apply": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),

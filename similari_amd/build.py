@@ -10,11 +10,11 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libsimilari_assoc.so"
-SOURCES = ["sa_kernels.hip", "sa_gemm.hip", "sa_upkeep.hip", "sa_engine.hip", "sa_tracker.cpp"]
+SOURCES = ["sa_kernels.hip", "sa_gemm.hip", "sa_upkeep.hip", "sa_engine.hip", "sa_tracker.cpp", "sa_cluster.cpp"]
 HEADERS = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "similari_assoc.h", PKG.parent / "include" / "similari_tracker.h"]
 # -ffp-contract=off: the reference (rustc) never fuses a*b+c; the bit-exact IoU / assignment gates rely on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wno-unused-value", "-Wno-unused-result", "-pthread"]
 
 
 def hipcc() -> str:

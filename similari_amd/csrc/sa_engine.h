@@ -244,9 +244,6 @@ hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams
 // NMS: mask[n][ceil(n/64)] words + keep[n] flags for rank-sorted boxes (at most SA_NMS_MAX)
 #define SA_NMS_MAX 16384u
 hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st);
-// engine-internal entry point shared with the tracker facade (sa_engine.hip)
-extern "C" int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
-                      uint32_t* out_slot);
 hipError_t sa_launch_own_areas(const BoxRaw* raw, uint32_t n, float* share, uint32_t* status, hipStream_t st);
 
 const char* sa_kernel_name(int id);

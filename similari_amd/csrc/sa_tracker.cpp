@@ -24,10 +24,6 @@
 #include "../../include/similari_tracker.h"
 #include "sa_kalman.h"
 
-// engine-internal entry point (sa_engine.hip): detections with one feature pointer per row
-extern "C" int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
-                                 uint32_t* out_slot);
-
 namespace {
 
 thread_local std::string g_err;

@@ -131,6 +131,45 @@ class Engine:
         self._chk(self.lib.sa_batch_time(self.h, iters, C.byref(ms)))
         return ms.value
 
+    # ---- whole request sets (BatchSort / BatchVisualSort::predict) ----
+    @staticmethod
+    def make_requests(items):
+        """items: [(scene_id, epoch, sa_detections)] -> (sa_scene_request array, sa_scene_result array, [(ids, votes)] numpy outputs).
+        The arrays can be handed to associate_batch / pipe_* any number of times (the outputs are overwritten)."""
+        n = len(items)
+        req = (abi.sa_scene_request * max(1, n))()
+        res = (abi.sa_scene_result * max(1, n))()
+        outs = []
+        for i, (scene, epoch, det) in enumerate(items):
+            req[i].scene_id, req[i].epoch, req[i].detections = scene, epoch, det
+            ids, votes = np.zeros(det.n, np.uint64), np.zeros(det.n, np.uint8)
+            res[i].out_track_id = ids.ctypes.data_as(C.POINTER(C.c_uint64))
+            res[i].out_voting_type = votes.ctypes.data_as(C.POINTER(C.c_uint8))
+            outs.append((ids, votes))
+        req._keep = [d for _, _, d in items]
+        res._keep = outs
+        return req, res, outs
+
+    def associate_batch(self, req, res, n=None):
+        self._chk(self.lib.sa_associate_batch(self.h, len(req) if n is None else n, req, res))
+
+    # ---- pipelined request sets: H2D of set n+1 beside the kernels of set n ----
+    def pipe_stage(self, req, n=None) -> int:
+        t = C.c_uint64()
+        self._chk(self.lib.sa_pipe_stage(self.h, len(req) if n is None else n, req, C.byref(t)))
+        return t.value
+
+    def pipe_launch(self, ticket: int):
+        self._chk(self.lib.sa_pipe_launch(self.h, ticket))
+
+    def pipe_submit(self, req, n=None) -> int:
+        t = C.c_uint64()
+        self._chk(self.lib.sa_pipe_submit(self.h, len(req) if n is None else n, req, C.byref(t)))
+        return t.value
+
+    def pipe_wait(self, ticket: int, res):
+        self._chk(self.lib.sa_pipe_wait(self.h, ticket, res))
+
     # ---- NMS (src/utils/nms.rs) ----
     def nms(self, boxes: np.ndarray, scores=None, nms_threshold: float = 0.5, score_threshold=None) -> np.ndarray:
         """Indices of the surviving boxes in the reference's output order (rank descending)."""
@@ -203,3 +242,59 @@ class Engine:
                 b.ctypes.data_as(fp), out.ctypes.data_as(fp) if want_out else None, iters, C.byref(ms))
         )
         return out, ms.value
+
+
+class Cluster:
+    """One process, one engine per GPU (include/similari_assoc.h: sa_cluster_*): scenes routed by scene_id % n_shards, every shard's
+    share of a request set running on its own device concurrently with the others."""
+
+    def __init__(self, cfg: abi.sa_config, devices=None, n_shards=None, lib: C.CDLL | None = None):
+        self.lib = lib or abi.load_library()
+        if devices is None:
+            devices = list(range(n_shards or 1))
+        self.devices = list(devices)
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        rc = self.lib.sa_cluster_create(C.byref(cfg), len(self.devices), arr, C.byref(self.h))
+        if rc != abi.SA_OK:
+            msg = self.lib.sa_cluster_last_error(None)
+            raise EngineError(rc, msg.decode() if msg else "")
+        self.cfg = cfg
+
+    def close(self):
+        if self.h:
+            self.lib.sa_cluster_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != abi.SA_OK:
+            msg = self.lib.sa_cluster_last_error(self.h)
+            raise EngineError(rc, msg.decode() if msg else "")
+
+    def __len__(self):
+        return self.lib.sa_cluster_size(self.h)
+
+    def shard_of(self, scene: int) -> int:
+        return self.lib.sa_cluster_shard_of(self.h, scene)
+
+    def engine(self, shard: int) -> Engine:
+        return Engine.borrowed(self.lib, self.lib.sa_cluster_engine(self.h, shard), self.cfg)
+
+    def upsert(self, scene: int, tracks: abi.sa_tracks):
+        self._chk(self.lib.sa_cluster_tracks_upsert(self.h, scene, C.byref(tracks)))
+
+    def remove(self, scene: int, ids):
+        ids = np.ascontiguousarray(ids, np.uint64)
+        self._chk(self.lib.sa_cluster_tracks_remove(self.h, scene, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def associate_batch(self, req, res, n=None):
+        self._chk(self.lib.sa_cluster_associate_batch(self.h, len(req) if n is None else n, req, res))
+
+    def last_ms(self):
+        return [self.lib.sa_cluster_last_ms(self.h, k) for k in range(len(self))]

@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         "or_nms": (C.c_int, [u32, B, fp, f32, f32, P(u32), P(u32)]),
         "or_own_area_shares": (C.c_int, [u32, B, fp]),
         "or_associate": (C.c_int, [P(abi.sa_config), u32, P(abi.sa_tracks), u64, P(abi.sa_detections), P(or_frame_out)]),
+        "or_associate_sharded": (C.c_int, [P(abi.sa_config), u32, P(abi.sa_tracks), u64, P(abi.sa_detections), P(or_frame_out), u32]),
     }
     T = C.c_void_p
     OBS, TRK = P(abi.sa_observation), P(abi.sa_sort_track)
@@ -138,8 +139,9 @@ def own_area_shares(boxes):
     return out[: len(boxes)].copy()
 
 
-def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True):
-    """Run the oracle on one scene-frame; returns dict of numpy arrays."""
+def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True, shards=1):
+    """Run the oracle on one scene-frame; returns dict of numpy arrays.  shards > 1: the distance stage on that many host threads
+    partitioned like the reference's TrackStore (track id % shards), one vote after them — same results."""
     L = lib()
     N, T = det.n, tracks.n
     K = max(1, cfg.max_observations) if cfg.visual_kind != abi.SA_VIS_NONE else 1
@@ -159,7 +161,8 @@ def associate(cfg, tracks, epoch, det, total_tracks=None, want_matrices=True):
         out.compatible = res["compatible"].ctypes.data_as(P(C.c_uint8))
     out.track_id = res["track_id"].ctypes.data_as(P(u64))
     out.voting_type = res["voting_type"].ctypes.data_as(P(C.c_uint8))
-    rc = L.or_associate(C.byref(cfg), T if total_tracks is None else total_tracks, C.byref(tracks), epoch, C.byref(det), C.byref(out))
+    rc = L.or_associate_sharded(C.byref(cfg), T if total_tracks is None else total_tracks, C.byref(tracks), epoch, C.byref(det), C.byref(out),
+                                max(1, int(shards)))
     assert rc == 0
     res["total_weight"] = int(out.total_weight)
     res["n_distances"] = int(out.n_distances)

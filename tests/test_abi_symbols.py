@@ -11,7 +11,7 @@ import pytest
 from similari_amd import abi, build
 
 ROOT = Path(__file__).resolve().parent.parent
-DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|sa_engine\s*\*|const char\s*\*)\s*\*?\s*(sa_[a-z0-9_]+)\s*\(", re.M)
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|double|sa_engine\s*\*|const char\s*\*)\s*\*?\s*(sa_[a-z0-9_]+)\s*\(", re.M)
 
 
 def declared(header: str):
@@ -28,7 +28,7 @@ def lib():
 @pytest.mark.parametrize("header", ["similari_assoc.h", "similari_tracker.h"])
 def test_every_declared_function_is_exported(lib, header):
     names = declared(header)
-    assert len(names) == (31 if header == "similari_assoc.h" else 15), names
+    assert len(names) == (46 if header == "similari_assoc.h" else 15), names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"{header} declares functions the library does not export: {missing}"
 
@@ -78,3 +78,25 @@ def test_pinned_blocks_need_a_device_too(lib):
     else:
         assert not p
     lib.sa_host_free(None)
+
+
+def test_cluster_refuses_to_run_without_a_gpu(lib):
+    """The multi-GPU dispatcher is a router over engines: no device, no cluster (and no CPU fallback behind it either)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    cfg = abi.make_config()
+    h = C.c_void_p()
+    rc = lib.sa_cluster_create(C.byref(cfg), 2, None, C.byref(h))
+    assert rc == abi.SA_ERR_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in lib.sa_cluster_last_error(None)
+    lib.sa_cluster_destroy(None)
+
+
+def test_every_prototype_of_the_python_binding_is_declared_in_a_header():
+    """abi.PROTOTYPES (what tests and bench.py call) and the two headers name the same functions: nothing is bound that a C
+    caller could not see, nothing declared is left unbound."""
+    bound = set(abi.PROTOTYPES)
+    decl = set(declared("similari_assoc.h")) | set(declared("similari_tracker.h"))
+    assert bound == decl, (sorted(bound - decl), sorted(decl - bound))

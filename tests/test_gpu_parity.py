@@ -368,8 +368,13 @@ def visual_run(cfg, sc, epoch=1, kf=None, own_area=None, det_present=None):
     return ids, votes, pos, vis, ref
 
 
-def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
-    ids, votes, pos, vis, ref = visual_run(cfg, sc, **kw)
+# Borderline bookkeeping of check_visual: a visual cell within tolerance of the is_ok threshold may be present on one side and absent
+# on the other; the vote can then legitimately differ in the rows / columns that cell touches.  Every such case is counted, bounded
+# per frame, and the id comparison is narrowed to the untouched rows instead of being skipped (test_borderline_cells_stay_rare).
+BORDERLINE = {"frames": 0, "frames_with_borderline": 0, "cells": 0, "rows_excused": 0, "rows_checked": 0}
+
+
+def compare_visual(cfg, ids, votes, pos, vis, ref, tol_abs=1e-5, tol_rel=0.0):
     np.testing.assert_array_equal(np.isnan(pos), np.isnan(ref["positional"]))
     np.testing.assert_array_equal(pos.view(np.uint32)[~np.isnan(pos)], ref["positional"].view(np.uint32)[~np.isnan(pos)])
     rv = ref["visual"]
@@ -378,15 +383,36 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     assert (err <= tol_abs + tol_rel * np.abs(rv[both])).all(), err.max()
     # cells present on one side only must sit within tolerance of the is_ok threshold
     mism = np.isnan(vis) != np.isnan(rv)
-    borderline = 0
+    BORDERLINE["frames"] += 1
+    n = len(ids)
+    excused = np.zeros(n, bool)
     if mism.any():
         thr_w = 1.0 - cfg.visual_threshold if cfg.visual_kind == abi.SA_VIS_COSINE else cfg.visual_threshold
         v = np.where(np.isnan(vis), rv, vis)[mism]
         assert (np.abs(v - thr_w) <= 2 * tol_abs + tol_rel * abs(thr_w)).all(), "present/absent mask differs away from the threshold"
-        borderline = int(mism.sum())
-    if borderline == 0:
-        np.testing.assert_array_equal(ids, ref["track_id"])
-        np.testing.assert_array_equal(votes, ref["voting_type"])
+        cells = int(mism.sum())
+        assert cells <= 2 + 1e-5 * mism.size, f"{cells} borderline cells of {mism.size}: the threshold is not a tolerance problem any more"
+        BORDERLINE["frames_with_borderline"] += 1
+        BORDERLINE["cells"] += cells
+        # a borderline cell (row q, track t) may move the verdict of row q, of every row whose winner (on either side) is t, and
+        # — through the exclusion of t from the positional vote — of the rows of t's positional component: excuse the rows that
+        # touch the cell's row or column on either side; everything else must still be identical
+        rows, cols = np.nonzero(mism.any(axis=2) if mism.ndim == 3 else mism)
+        excused[np.unique(rows)] = True
+        for c in np.unique(cols):
+            tid = ref["_track_ids"][c]
+            excused |= (ids == tid) | (ref["track_id"] == tid)
+            excused |= ~np.isnan(pos[:, c])
+    BORDERLINE["rows_excused"] += int(excused.sum())
+    BORDERLINE["rows_checked"] += int((~excused).sum())
+    np.testing.assert_array_equal(ids[~excused], ref["track_id"][~excused])
+    np.testing.assert_array_equal(votes[~excused], ref["voting_type"][~excused])
+
+
+def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
+    ids, votes, pos, vis, ref = visual_run(cfg, sc, **kw)
+    ref["_track_ids"] = sc["track_ids"]
+    compare_visual(cfg, ids, votes, pos, vis, ref, tol_abs, tol_rel)
     return ids, votes, ref
 
 
@@ -862,6 +888,93 @@ def test_full_size_properties_c2_euclidean():
         eng.close()
 
 
+# ---- the headline configurations at FULL size against the oracle -------------------------------------------------------
+# The oracle's distance stage runs on host threads partitioned like the reference's TrackStore (or_associate_sharded: track id %
+# shards, one vote after the shards) — cell for cell the single-thread oracle, in a fraction of its time.
+def _full_size_visual(cfg, sc, shards=32):
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+    det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+    ref = O.associate(cfg, tracks, 1, det, shards=shards)
+    ref["_track_ids"] = sc["track_ids"]
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        ids, votes = eng.associate(0, 1, det)
+        pos, vis, q = eng.tap_positional(), eng.tap_visual(), eng.tap_quantised()
+    finally:
+        eng.close()
+    np.testing.assert_array_equal(q, ref["quantised"])  # IoU: the i64 matrix of SortVoting bit for bit
+    return ids, votes, pos, vis, ref
+
+
+def test_full_size_c2_against_the_oracle():
+    """BASELINE C2 (1000 x 1000 x 512-d cosine + IoU): IoU cells and the quantised matrix bit for bit, every cosine weight within
+    1e-5, ids and vote types identical."""
+    sc = synth.visual_scene(np.random.default_rng(2), 1000, 1000, 512, 1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=512,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    compare_visual(cfg, ids, votes, pos, vis, ref)
+    assert (~np.isnan(pos)).sum() > 1000 and (~np.isnan(vis)).mean() > 0.5
+
+
+def test_full_size_c2_with_new_and_featureless_detections_against_the_oracle():
+    """The C2 frame with 15 % new objects and 10 % of the detections without a usable feature: the positional (Hungarian) stage has
+    real work after the visual vote.  Same gates."""
+    rng = np.random.default_rng(12)
+    sc = synth.visual_scene(rng, 1000, 1000, 512, 1, new_fraction=0.15)
+    sc["det_quality"][rng.uniform(size=1000) < 0.10] = 0.05
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=512,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          visual_minimal_quality_use=0.3, max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    compare_visual(cfg, ids, votes, pos, vis, ref)
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 20 and (votes == abi.SA_VOTE_VISUAL).sum() > 600
+
+
+def test_full_size_c2_three_observations_against_the_oracle():
+    """C2 with the bank three observations deep (weight matrix + BestFit tile + resolve path)."""
+    sc = synth.visual_scene(np.random.default_rng(13), 1000, 1000, 512, 3)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=512,
+                          max_observations=3, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    compare_visual(cfg, ids, votes, pos, vis, ref)
+
+
+def test_full_size_c2_euclidean_against_the_oracle():
+    """The C2 frame under the reference's DEFAULT visual metric: every euclidean distance within 1e-5 relative."""
+    sc = synth.visual_scene(np.random.default_rng(6), 1000, 1000, 512, 1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=0.5, feature_len=512,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    compare_visual(cfg, ids, votes, pos, vis, ref, tol_abs=0.0, tol_rel=1e-5)
+    assert (~np.isnan(vis)).sum() >= 1000
+
+
+def test_full_size_c4_against_the_oracle():
+    """BASELINE C4 (oriented SORT 2000 x 2000): all 4 M cells — present/absent mask, f32 IoU bit patterns, quantised i64 matrix —
+    and the assignment against the oracle."""
+    sc = synth.sort_scene(np.random.default_rng(4), 2000, 2000, canvas=(8192.0, 8192.0), oriented=True, pos_sigma=1.0)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    assert (ids == sc["truth"]).mean() > 0.97
+
+
+def test_full_size_c5_against_the_oracle():
+    """BASELINE C5 (5000 tracks x 2000 detections x 4096-d cosine): all 10 M cosine weights within 1e-5, all IoU cells bit for
+    bit, ids and vote types identical.  (The oracle's distance stage takes ~100 s on one host thread: sharded over 32.)"""
+    sc = synth.visual_scene(np.random.default_rng(5), 5000, 2000, 4096, 1, canvas=(7680.0, 4320.0))
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=4096,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc, shards=48)
+    compare_visual(cfg, ids, votes, pos, vis, ref)
+    np.testing.assert_array_equal(ids, sc["truth"])
+
+
 # ---- randomized sweep over the configuration space --------------------------------------------------------------------
 def _fuzz_case(seed):
     """One random (config, scene): sizes around the tile edges (16, 64, 128, 256), every metric pair, ragged banks, missing
@@ -930,3 +1043,14 @@ def test_random_configurations(seed):
             np.testing.assert_array_equal(votes == abi.SA_VOTE_VISUAL, ref["voting_type"] == abi.SA_VOTE_VISUAL)
         else:
             check_visual(cfg, sc, tol_abs=1e-5 if visual == "cosine" else 0.0, tol_rel=tol_rel, epoch=epoch, kf=kf, own_area=own, det_present=dp)
+
+
+def test_borderline_cells_stay_rare():
+    """Runs last in this module: over every frame compare_visual saw, cells that sat on the is_ok threshold (present on one side
+    only) and the rows whose id comparison they excused must be a vanishing share — otherwise the id gate is not a gate."""
+    b = BORDERLINE
+    print("borderline bookkeeping:", b)
+    if b["frames"] == 0:
+        pytest.skip("no visual frame was compared in this session")
+    assert b["frames_with_borderline"] <= max(2, 0.05 * b["frames"]), b
+    assert b["rows_excused"] <= 0.002 * max(1, b["rows_checked"]) + 4, b

@@ -1,0 +1,215 @@
+"""The request-set entry points of the C ABI on the GPU: sa_associate_batch (BatchSort / BatchVisualSort::predict's seam,
+sort/batch_api.rs:222-290), the pipelined sa_pipe_* (two request sets in flight: H2D of set n+1 beside the kernels of set n),
+sa_batch_time, and hipGraph replay under a tracker's ever-changing epoch — every answer against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from similari_amd import abi, synth
+from similari_amd.engine import Engine, EngineError
+
+pytestmark = pytest.mark.gpu
+
+
+def visual_cfg(d, k=1, **kw):
+    return abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                           max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                           max_idle_epochs=5, **kw)
+
+
+def upsert_scene(eng, scene, sc, visual):
+    kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
+    tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw)
+    eng.upsert(scene, tr)
+    return tr
+
+
+def test_associate_batch_matches_oracle_per_scene():
+    """sa_associate_batch: ragged scenes (one empty) in one call; res[i] belongs to req[i]."""
+    rng = np.random.default_rng(71)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    sizes = [(120, 100), (0, 40), (33, 65), (257, 200)]
+    scs = [synth.sort_scene(rng, t, n, canvas=(1200.0, 900.0)) for n, t in sizes]
+    eng = Engine(cfg)
+    try:
+        trs = [upsert_scene(eng, 10 + s, sc, False) for s, sc in enumerate(scs)]
+        dets = [abi.make_detections(sc["det_boxes"]) for sc in scs]
+        req, res, outs = Engine.make_requests([(10 + s, 1, d) for s, d in enumerate(dets)])
+        eng.associate_batch(req, res)
+        for s, sc in enumerate(scs):
+            ref = O.associate(cfg, trs[s], 1, dets[s], want_matrices=False)
+            np.testing.assert_array_equal(outs[s][0], ref["track_id"], err_msg=f"scene {s}")
+            np.testing.assert_array_equal(outs[s][1], ref["voting_type"])
+        # the same scene twice in one request set is a caller error, reported, not undefined behaviour
+        req2, res2, _ = Engine.make_requests([(10, 1, dets[0]), (10, 1, dets[0])])
+        with pytest.raises(EngineError) as ei:
+            eng.associate_batch(req2, res2)
+        assert ei.value.code == abi.SA_ERR_STATE
+    finally:
+        eng.close()
+
+
+def test_batch_time_replays_the_staged_set():
+    """sa_batch_time: hipEvent time of `iters` back-to-back pipelines over the staged set; results stay the oracle's."""
+    rng = np.random.default_rng(72)
+    d = 64
+    cfg = visual_cfg(d)
+    sc = synth.visual_scene(rng, 200, 180, d, 1, canvas=(1500.0, 900.0), new_fraction=0.1)
+    eng = Engine(cfg)
+    try:
+        tr = upsert_scene(eng, 0, sc, True)
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        eng.batch_begin()
+        slot = eng.batch_add(0, 1, det)
+        ms1 = eng.batch_time(1)
+        ms20 = eng.batch_time(20)
+        assert ms1 > 0.0 and ms20 > ms1 * 2, (ms1, ms20)
+        ids, votes = eng.batch_fetch(slot, det.n)
+        ref = O.associate(cfg, tr, 1, det, want_matrices=False)
+        np.testing.assert_array_equal(ids, ref["track_id"])
+        np.testing.assert_array_equal(votes, ref["voting_type"])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned_block"])
+def test_pipelined_tickets_match_the_synchronous_path(pinned):
+    """A stream of different frames through sa_pipe_submit / sa_pipe_wait with two tickets in flight: every frame's answer equals
+    the oracle's (and therefore sa_associate's); features from pageable memory or DMA'd in place from sa_host_alloc blocks."""
+    rng = np.random.default_rng(73)
+    d, n, t = 128, 150, 170
+    cfg = visual_cfg(d)
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(1500.0, 900.0), new_fraction=0.1)
+    eng = Engine(cfg)
+    blocks = []
+    try:
+        tr = upsert_scene(eng, 3, sc, True)
+        frames = []
+        for f in range(6):
+            p = rng.permutation(n)[: n - 7 * f]  # ragged: every frame another size
+            feats = sc["det_feats"][p]
+            if pinned:
+                blk = eng.host_block(feats.shape)
+                blk[...] = feats
+                blocks.append(blk)
+                feats = blk
+            det = abi.make_detections(sc["det_boxes"][p], feats=feats, feat_quality=sc["det_quality"][p])
+            req, res, outs = Engine.make_requests([(3, 1, det)])
+            frames.append((det, req, res, outs))
+        tickets = []
+        for f, (det, req, res, outs) in enumerate(frames):
+            tickets.append(eng.pipe_submit(req))
+            if f >= 1:
+                eng.pipe_wait(tickets[f - 1], frames[f - 1][2])
+        eng.pipe_wait(tickets[-1], frames[-1][2])
+        for det, req, res, outs in frames:
+            ref = O.associate(cfg, tr, 1, det, want_matrices=False)
+            np.testing.assert_array_equal(outs[0][0], ref["track_id"])
+            np.testing.assert_array_equal(outs[0][1], ref["voting_type"])
+        # a third ticket without waiting is refused, and so is a synchronous batch while tickets are outstanding
+        t1 = eng.pipe_submit(frames[0][1])
+        t2 = eng.pipe_submit(frames[1][1])
+        with pytest.raises(EngineError) as ei:
+            eng.pipe_submit(frames[2][1])
+        assert ei.value.code == abi.SA_ERR_STATE
+        with pytest.raises(EngineError):
+            eng.batch_begin()
+        eng.pipe_wait(t1, frames[0][2])
+        eng.pipe_wait(t2, frames[1][2])
+        with pytest.raises(EngineError):
+            eng.pipe_wait(12345, frames[0][2])
+        # the synchronous path still works afterwards and agrees
+        ids, votes = eng.associate(3, 1, frames[2][0])
+        np.testing.assert_array_equal(ids, frames[2][3][0][0])
+    finally:
+        for b in blocks:
+            eng.host_free(b)
+        eng.close()
+
+
+def test_pipelined_tracker_loop_with_device_upkeep():
+    """stage(n+1); wait(n); apply(n); launch(n+1): the H2D of the next frame overlaps the current frame's kernels, and the track
+    table the next frame meets is the one sa_tracks_apply left (new tracks appended, Kalman steps taken).  Same ids, frame by
+    frame, as the plain synchronous loop on a second engine."""
+    rng = np.random.default_rng(74)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    n = 60
+    world = synth.dense_boxes(rng, n, (900.0, 700.0))
+    frames = []
+    for f in range(6):
+        world = synth.jitter_boxes(rng, world, 1.5)
+        extra = synth.dense_boxes(rng, 3, (900.0, 700.0))  # a few objects appear every frame
+        frames.append(np.concatenate([world, extra]))
+        world = frames[-1]
+    a, b = Engine(cfg), Engine(cfg)
+    try:
+        next_id = [1, 1]
+
+        def new_ids(k, ids):
+            out = np.zeros(len(ids), np.uint64)
+            for i, w in enumerate(ids):
+                if w == 0:
+                    out[i] = next_id[k]
+                    next_id[k] += 1
+            return out
+
+        def apply(eng, k, ids):
+            nid = new_ids(k, ids)
+            pred = np.zeros(len(ids), abi.BOX_DTYPE)
+            eng._chk(eng.lib.sa_tracks_apply(eng.h, 0, nid.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(pred.ctypes.data, C.POINTER(abi.sa_box))))
+            return pred
+
+        # reference loop: synchronous
+        sync_ids, sync_pred = [], []
+        for f, boxes in enumerate(frames):
+            det = abi.make_detections(boxes)
+            a.batch_begin()
+            a.batch_add(0, f + 1, det)
+            a.batch_run()
+            a.batch_sync()
+            ids, _ = a.batch_fetch(0, det.n)
+            sync_ids.append(ids)
+            sync_pred.append(apply(a, 0, ids))
+        # pipelined loop
+        sets = [Engine.make_requests([(0, f + 1, abi.make_detections(boxes))]) for f, boxes in enumerate(frames)]
+        tk = b.pipe_stage(sets[0][0])
+        b.pipe_launch(tk)
+        for f in range(len(frames)):
+            nxt = b.pipe_stage(sets[f + 1][0]) if f + 1 < len(frames) else None
+            b.pipe_wait(tk, sets[f][1])
+            ids = sets[f][2][0][0]
+            np.testing.assert_array_equal(ids, sync_ids[f], err_msg=f"frame {f}")
+            pred = apply(b, 1, ids)
+            np.testing.assert_array_equal(pred.view(np.uint8), sync_pred[f].view(np.uint8))
+            if nxt is not None:
+                b.pipe_launch(nxt)
+                tk = nxt
+        assert b.count(0) == a.count(0) > n
+        assert (sync_ids[-1] != 0).sum() >= n  # continuing tracks are re-found on the table the device maintains
+    finally:
+        a.close()
+        b.close()
+
+
+def test_graph_replay_survives_a_changing_epoch():
+    """SA_FLAG_GRAPH under a tracker: the epoch (and the detections) change every frame, the launch geometry does not — the
+    captured graph is replayed, and every frame's answer is the oracle's for THAT epoch (idle tracks drop out as it advances)."""
+    rng = np.random.default_rng(75)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=2, flags=abi.SA_FLAG_GRAPH)
+    sc = synth.sort_scene(rng, 150, 150, canvas=(1200.0, 900.0))
+    sc["track_epochs"] = rng.integers(0, 4, 150).astype(np.uint64)
+    eng = Engine(cfg)
+    try:
+        tr = upsert_scene(eng, 0, sc, False)
+        matched = []
+        for epoch in (1, 2, 3, 4, 5):
+            det = abi.make_detections(synth.jitter_boxes(rng, sc["det_boxes"], 0.5))
+            ids, votes = eng.associate(0, epoch, det)
+            ref = O.associate(cfg, tr, epoch, det, want_matrices=False)
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"epoch {epoch}")
+            matched.append(int((ids != 0).sum()))
+        assert matched[0] > matched[-1] > 0, matched  # compatible() really followed the epoch
+    finally:
+        eng.close()

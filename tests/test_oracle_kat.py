@@ -462,3 +462,34 @@ def test_associate_identity_sort_iou():
     # idle tracks are masked
     r = O.associate(cfg, tracks, 7, det)
     assert (r["track_id"] == 0).all()
+
+
+# ---- the sharded oracle (or_associate_sharded): distance stage on host threads partitioned like store.rs:490-493, one vote after
+# the shards — must be the single-thread oracle, cell for cell and id for id ---------------------------------------------------
+@pytest.mark.parametrize("visual", [None, "cosine", "euclidean"])
+def test_sharded_oracle_equals_the_single_thread_oracle(visual):
+    from similari_amd import synth
+
+    rng = np.random.default_rng(77)
+    n, t, d, k = 90, 110, 48, 2
+    if visual:
+        sc = synth.visual_scene(rng, t, n, d, k, canvas=(900.0, 700.0), new_fraction=0.2)
+        sc["track_present"][rng.uniform(size=(t, k)) < 0.2] = 0
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual=visual, visual_threshold=0.4 if visual == "cosine" else 0.6,
+                              feature_len=d, max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, max_idle_epochs=5)
+        tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+    else:
+        sc = synth.sort_scene(rng, t, n, canvas=(700.0, 500.0))
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+        tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+        det = abi.make_detections(sc["det_boxes"])
+    one = O.associate(cfg, tr, 1, det)
+    for shards in (2, 7):
+        many = O.associate(cfg, tr, 1, det, shards=shards)
+        for key, v in one.items():
+            if isinstance(v, np.ndarray):
+                np.testing.assert_array_equal(v, many[key], err_msg=f"{key}, {shards} shards")
+            else:
+                assert v == many[key], (key, shards)
+    assert (one["track_id"] != 0).sum() > 30
