@@ -30,6 +30,7 @@ DEFAULT_FLAGS = 0            # engine flags of the timed pass
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 VALU_F32_PEAK_TFLOPS = 157.3  # f32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+VALU_F64_PEAK_TFLOPS = 78.6  # f64 vector peak (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md); the f16-split option issues 3 products per flop
 
 
@@ -85,6 +86,23 @@ def workload(name: str, seed: int):
         sc = synth.sort_scene(rng, 1000, 1000, canvas=(1920.0, 1080.0))
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
         return cfg, [sc], "SORT IoU 1000 x 1000 on the C2 canvas (crowd: large components in the positional vote)"
+    if name == "c2n":
+        # C2 with 15 % new objects and 10 % of the detections below the quality gate: the positional (Hungarian) stage has real
+        # work after the visual vote inside the timed region
+        n = t = 1000
+        d, k = 512, 1
+        sc = synth.visual_scene(rng, t, n, d, k, new_fraction=0.15)
+        sc["det_quality"][rng.uniform(size=n) < 0.10] = 0.05
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                              max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.3,
+                              positional_min_confidence=0.1, max_idle_epochs=5)
+        return cfg, [sc], "VisualSORT 1000 x 1000 x 512-d cosine + IoU(0.3), 15 % new objects, 10 % featureless detections (non-empty Hungarian stage)"
+    if name == "giant":
+        # not a BASELINE config: ONE connected component — 640 boxes piled on each other, IoU threshold 0.05 — the case a CPU
+        # kuhn_munkres handles at its own speed whatever the density (sort/voting.rs:86)
+        sc = synth.sort_scene(rng, 640, 640, canvas=(150.0, 150.0), pos_sigma=10.0)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.05, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU(0.05) 640 x 640, all boxes on one pile, 10 px of jitter: one connected component of the positional vote, ~140 k usable edges, a third of the rows lose their greedy bid"
     if name == "c3m":
         # BASELINE C3's Mahalanobis half: the Kalman states come from the product's own device-side upkeep (three frames through
         # the BatchSort facade), see maha_engine() below — no synthetic scene dict
@@ -131,36 +149,6 @@ def stage(eng, cfg, scenes):
     return keep, dets
 
 
-# Algorithmic work per launch of each kernel, as (bound, amount, unit-per-second divisor).
-def kernel_models(cfg, scenes):
-    visual = cfg.visual_kind != abi.SA_VIS_NONE
-    K = cfg.max_observations if visual else 1
-    D8 = (cfg.feature_len + 31) // 32 * 32
-    cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
-    nt = sum(len(s["det_boxes"]) + len(s["track_boxes"]) for s in scenes)
-    n_ = sum(len(s["det_boxes"]) for s in scenes)
-    t_ = sum(len(s["track_boxes"]) for s in scenes)
-    # k_frame = positional tiles + frame-preparation blocks in one launch.  SURVEY §8d figure for the positional cells: f32 cost
-    # out (4 B/cell) + 64 B vertices + 16 B geometry per box — effective bandwidth, the kernel no longer writes the dense matrix
-    # (it emits the edges of the vote directly); plus what the preparation blocks really move (features in and out, 160 B/box).
-    frame_bytes = 4.0 * cells + 80.0 * nt + 160.0 * n_
-    m = {
-        # one read of the visual weights (4 B per cell and bank slot) + the per-tile partials
-        "k_bestfit_tile": ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0),
-    }
-    if visual:
-        euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
-        # euclidean: sub, mul, add per element on the f32 vector pipe (no matrix-core form without catastrophic cancellation)
-        flops = sum((3.0 if euclid else 2.0) * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
-        m["k_visual_cost"] = ("valu" if euclid else "mfma", flops)
-        # small frames: contraction tiles + positional tiles + preparation blocks in one heterogeneous launch — the matrix-core
-        # work is what bounds it; the other two kinds fill the issue slots it leaves idle
-        m["k_frame_visual"] = ("mfma", flops)
-        frame_bytes += 4.0 * n_ * (cfg.feature_len + D8)
-    m["k_frame"] = ("hbm", frame_bytes)
-    return m, cells
-
-
 def pmc_traffic(workload: str, kernel: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_*_pmc_traffic.json, written by
     scripts/pmc_traffic.sh on the GPU box: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as the gfx950 guide says).
@@ -205,90 +193,200 @@ def cpu_baseline(cfg, scenes, budget_s=12.0):
     dt = min(times)
     return {
         "value": n * T / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-        "sample": f"oracle or_associate (oracle/oracle.cpp, -O2 -ffp-contract=off), {n} of {n_all} detections x {T} tracks of scene 0, "
+        "sample": f"oracle or_associate (oracle/oracle.cpp, g++ {ORACLE_FLAGS}), {n} of {n_all} detections x {T} tracks of scene 0, "
                   f"best of {len(times)} runs ({sum(times):.1f} s of CPU work, 1 thread; host has {os.cpu_count()} cores)",
     }
 
 
+ORACLE_FLAGS = "-O3 -march=x86-64-v3 -ffp-contract=off (the reference's own target-cpu, .cargo/config.toml)"
+
+
 def cpu_baseline_threads(cfg, scenes, budget_s=6.0):
-    """The same oracle on `shards` host threads, tracks partitioned track_id % shards the way the reference's TrackStore shards them
-    (store.rs:490-493).  Every shard runs the whole per-frame path on its tracks (ctypes releases the GIL), votes included — the
-    reference votes once, on one thread, after the shards have produced their distances — so this favours the CPU.  Reported
-    beside cpu_baseline (BASELINE.md section 2 asks for both variants); it is not the judged baseline object."""
+    """The same oracle with its distance stage on `shards` host threads partitioned track_id % shards the way the reference's
+    TrackStore shards it (store.rs:490-493) and ONE vote after the shards (sort/simple_api.rs:147-162) — or_associate_sharded.
+    Reported beside cpu_baseline (BASELINE.md section 2 asks for both variants); it is not the judged baseline object."""
     import oracle_lib as O
-    from concurrent.futures import ThreadPoolExecutor
 
     sc = scenes[0]
     visual = cfg.visual_kind != abi.SA_VIS_NONE
     T, N = len(sc["track_boxes"]), len(sc["det_boxes"])
     shards = int(max(1, min(os.cpu_count() or 1, 64, T)))
-    parts = []
-    for sh in range(shards):
-        m = (sc["track_ids"] % np.uint64(shards)) == sh
-        if not m.any():
-            continue
-        kw = dict(feats=sc["track_feats"][m], feat_present=sc["track_present"][m]) if visual else {}
-        parts.append(abi.make_tracks(sc["track_ids"][m], sc["track_boxes"][m], sc["track_epochs"][m], **kw))
+    kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw)
     kw = dict(feats=sc["det_feats"], feat_quality=sc["det_quality"]) if visual else {}
     det = abi.make_detections(sc["det_boxes"], **kw)
-
-    def one(tr):
-        O.associate(cfg, tr, 1, det, want_matrices=False)
-
     times = []
-    with ThreadPoolExecutor(max_workers=len(parts)) as ex:
-        t_end = time.perf_counter() + budget_s
-        while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 50):
-            t0 = time.perf_counter()
-            list(ex.map(one, parts))
-            times.append(time.perf_counter() - t0)
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 50):
+        t0 = time.perf_counter()
+        O.associate(cfg, tracks, 1, det, want_matrices=False, shards=shards)
+        times.append(time.perf_counter() - t0)
     return {
-        "value": N * T / min(times), "unit": "pairs/s", "cores": len(parts), "kind": "port",
-        "sample": f"oracle or_associate on {len(parts)} threads, tracks of scene 0 partitioned id % {shards} (store.rs:490-493), all {N} detections x {T} "
-                  f"tracks per frame, per-shard votes run in parallel (favours the CPU), best of {len(times)} frames; host has {os.cpu_count()} cores",
+        "value": N * T / min(times), "unit": "pairs/s", "cores": shards, "kind": "port",
+        "sample": f"oracle or_associate_sharded (g++ {ORACLE_FLAGS}): distances on {shards} threads, tracks of scene 0 partitioned id % {shards} "
+                  f"(store.rs:490-493), one vote after the shards, all {N} detections x {T} tracks per frame, best of {len(times)} frames; "
+                  f"host has {os.cpu_count()} cores",
     }
 
 
-def h2d_inclusive(eng, cfg, scenes, iters=30):
-    """sa_associate from HOST buffers (stage + H2D + pipeline + results): the PCIe-inclusive rate.  Reported, never `value`."""
+def oracle_answers(cfg, scenes):
+    """The oracle's ids / vote types for every scene of the timed frame (distance stage sharded over the host's cores)."""
+    import oracle_lib as O
+
     visual = cfg.visual_kind != abi.SA_VIS_NONE
-    dets = []
+    shards = int(max(1, min(os.cpu_count() or 1, 64)))
+    out = []
     for sc in scenes:
+        kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
+        tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw)
         kw = dict(feats=sc["det_feats"], feat_quality=sc["det_quality"]) if visual else {}
-        dets.append(abi.make_detections(sc["det_boxes"], **kw))
-    for _ in range(3):
-        for s, d in enumerate(dets):
-            eng.associate(s, 1, d)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        for s, d in enumerate(dets):
-            eng.associate(s, 1, d)
-    dt = time.perf_counter() - t0
-    cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
-    out = {"pairs_per_s": cells * iters / dt, "ms_per_frame_set": 1e3 * dt / iters,
-           "note": "sa_associate per scene from pageable host buffers, synchronous: staging copy + H2D + pipeline + result fetch"}
-    if visual:
-        # the same from pinned blocks (sa_host_alloc): the DMA reads the caller's features in place
-        blocks, pdets = [], []
-        for sc in scenes:
+        det = abi.make_detections(sc["det_boxes"], **kw)
+        r = O.associate(cfg, tracks, 1, det, want_matrices=False, shards=shards)
+        out.append((r["track_id"], r["voting_type"]))
+    return out
+
+
+def f64_clip_model(scenes, sample=1500, seed=0):
+    """Algorithmic f64 work of the positional tiles: the pairs that survive too_far() (bbox.rs:452-474) go through
+    Sutherland-Hodgman (clipping.rs:12-91) and the shoelace area.  Counts the f64 operations of a restatement of that algorithm on a
+    random sample of surviving pairs of scene 0 (side tests 7 flop, crossing points 18 flop incl. the division, shoelace 5 flop per
+    vertex) and scales to all surviving pairs of the frame.  Returns (surviving pairs of the frame, mean flop per surviving pair)."""
+    import math
+
+    rng = np.random.default_rng(seed)
+    total_pairs, flops_per_pair = 0, []
+    for si, sc in enumerate(scenes):
+        c, t = sc["det_boxes"], sc["track_boxes"]
+        def rad(b):
+            hw = (b["aspect"] * b["height"] / np.float32(2)).astype(np.float32)
+            hh = (b["height"] / np.float32(2)).astype(np.float32)
+            return np.sqrt(hw * hw + hh * hh)
+        rc, rt = rad(c), rad(t)
+        dx = c["xc"][:, None] - t["xc"][None, :]
+        dy = c["yc"][:, None] - t["yc"][None, :]
+        near = dx * dx + dy * dy <= (rc[:, None] + rt[None, :]) ** 2
+        total_pairs += int(near.sum())
+        if si:
+            continue
+        ii, jj = np.nonzero(near)
+        if not len(ii):
+            continue
+        pick = rng.choice(len(ii), min(sample, len(ii)), replace=False)
+
+        def verts(b):
+            a = float(b["angle"]) if b["has_angle"] else 0.0
+            cs, sn = math.cos(a), math.sin(a)
+            hw, hh = float(b["height"]) * float(b["aspect"]) / 2.0, float(b["height"]) / 2.0
+            x, y = float(b["xc"]), float(b["yc"])
+            r1 = (-hw * cs - hh * sn, -hw * sn + hh * cs)
+            r2 = (hw * cs - hh * sn, hw * sn + hh * cs)
+            return [(x + r1[0], y + r1[1]), (x + r2[0], y + r2[1]), (x - r1[0], y - r1[1]), (x - r2[0], y - r2[1])]
+
+        for k in pick:
+            poly, clip, fl = verts(c[ii[k]]), verts(t[jj[k]]), 0
+            for e in range(4):
+                cs_, ce_ = clip[e - 1], clip[e]
+                out = []
+                if not poly:
+                    break
+                inside = lambda p: (ce_[0] - cs_[0]) * (p[1] - cs_[1]) - (ce_[1] - cs_[1]) * (p[0] - cs_[0]) <= 0.0
+                for v in range(len(poly)):
+                    s_, e_ = poly[v - 1], poly[v]
+                    fl += 7  # one side test per vertex (its predecessor's is reused)
+                    ie, is_ = inside(e_), inside(s_)
+                    if ie != is_:
+                        fl += 18  # compute_intersection: 3 differences, 2 cross products, 1 determinant, 1 division, 2 x (2 mul + 1 sub + 1 mul)
+                        dcx, dcy, dpx, dpy = s_[0] - e_[0], s_[1] - e_[1], cs_[0] - ce_[0], cs_[1] - ce_[1]
+                        n1, n2 = s_[0] * e_[1] - s_[1] * e_[0], cs_[0] * ce_[1] - cs_[1] * ce_[0]
+                        n3 = dcx * dpy - dcy * dpx
+                        if n3 != 0.0:
+                            out.append(((n1 * dpx - n2 * dcx) / n3, (n1 * dpy - n2 * dcy) / n3))
+                    if ie:
+                        out.append(e_)
+                poly = out
+            fl += 5 * len(poly) + 4  # shoelace with the shift, halving, IoU epilogue
+            flops_per_pair.append(fl)
+    return total_pairs, (float(np.mean(flops_per_pair)) if flops_per_pair else 0.0)
+
+
+def kernel_bytes_model(cfg, scenes, matched_edges):
+    """Bytes the positional launch has to move whatever its implementation: the raw detection records in (48 B/box + the optional
+    per-detection arrays), the track geometry + polygon (16 + 64 B/track), the derived candidate arrays out (16 + 64 + 4 B), one
+    16-byte edge record per surviving cell of the vote, and for VisualSORT the candidates' feature rows in (and out, when padded)."""
+    n_ = sum(len(s["det_boxes"]) for s in scenes)
+    t_ = sum(len(s["track_boxes"]) for s in scenes)
+    b = 48.0 * n_ + 80.0 * t_ + 84.0 * n_ + 16.0 * matched_edges
+    return b
+
+
+def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
+    """The reference's predict() ingests host buffers every frame (visual_sort/simple_api.rs:130-170): the same frame through
+    sa_pipe_submit / sa_pipe_wait, two request sets in flight, features in a block from sa_host_alloc (DMA'd in place), results
+    copied out — H2D and D2H inside the timed region."""
+    visual = cfg.visual_kind != abi.SA_VIS_NONE
+    blocks, items = [], []
+    for s, sc in enumerate(scenes):
+        kw = {}
+        if visual:
             b = eng.host_block(sc["det_feats"].shape)
             b[...] = sc["det_feats"]
             blocks.append(b)
-            pdets.append(abi.make_detections(sc["det_boxes"], feats=b, feat_quality=sc["det_quality"]))
-        for _ in range(3):
-            for s, d in enumerate(pdets):
-                eng.associate(s, 1, d)
+            kw = dict(feats=b, feat_quality=sc["det_quality"])
+        items.append((s, 1, abi.make_detections(sc["det_boxes"], **kw)))
+    sets = [eng.make_requests(items) for _ in range(2)]
+    lib, h = eng.lib, eng.h
+    import ctypes as C
+
+    tk = [C.c_uint64(), C.c_uint64()]
+    ns = len(items)
+
+    def loop(k):
+        rc = lib.sa_pipe_submit(h, ns, sets[0][0], C.byref(tk[0]))
+        for i in range(1, k):
+            rc |= lib.sa_pipe_submit(h, ns, sets[i & 1][0], C.byref(tk[i & 1]))
+            rc |= lib.sa_pipe_wait(h, tk[(i - 1) & 1], sets[(i - 1) & 1][1])
+        rc |= lib.sa_pipe_wait(h, tk[(k - 1) & 1], sets[(k - 1) & 1][1])
+        assert rc == 0, eng.lib.sa_last_error(h)
+
+    loop(10)
+    t0 = time.perf_counter()
+    loop(iters)
+    dt = time.perf_counter() - t0
+    # the synchronous form for comparison (stage -> DMA -> kernels -> results, nothing overlapped)
+    req, res, outs = sets[0]
+    for _ in range(5):
+        eng.associate_batch(req, res)
+    t1 = time.perf_counter()
+    for _ in range(max(10, iters // 4)):
+        eng.associate_batch(req, res)
+    dts = (time.perf_counter() - t1) / max(10, iters // 4)
+    ids = [o[0].copy() for o in sets[(iters - 1) & 1][2]]
+    for b in blocks:
+        eng.host_free(b)
+    cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
+    h2d_bytes = sum(len(s["det_boxes"]) * (48 + (4 * cfg.feature_len + 4 if visual else 0)) for s in scenes)
+    return {"pairs_per_s": cells * iters / dt, "ms_per_step": 1e3 * dt / iters, "steps": iters,
+            "h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": 9 * sum(len(s["det_boxes"]) for s in scenes),
+            "synchronous_ms_per_step": 1e3 * dts,
+            "note": "sa_pipe_submit / sa_pipe_wait, two request sets in flight (H2D of frame n+1 beside the kernels of frame n), features in a "
+                    "sa_host_alloc block, results copied out; synchronous_ms_per_step = sa_associate_batch on the same buffers"}, ids
+
+
+def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400):
+    """EXACTLY K steps per timed region, bracketed by barrier + synchronize on both sides; the region is repeated until at least
+    min_total_s has been measured (a 20-step region of a 25 us step is 0.5 ms of signal: one region is a noisy sample) and the
+    MEDIAN region is reported."""
+    times = []
+    total = 0.0
+    while len(times) < min_rounds or (total < min_total_s and len(times) < max_rounds):
+        barrier()
         t0 = time.perf_counter()
-        for _ in range(iters):
-            for s, d in enumerate(pdets):
-                eng.associate(s, 1, d)
-        dt2 = time.perf_counter() - t0
-        out["pinned"] = {"pairs_per_s": cells * iters / dt2, "ms_per_frame_set": 1e3 * dt2 / iters,
-                         "note": "features in a block from sa_host_alloc: no staging copy"}
-        pdets = None
-        for b in blocks:
-            eng.host_free(b)
-    return out
+        run_k()
+        barrier()
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        total += dt
+    return float(np.median(times)), times
 
 
 def main():
@@ -300,7 +398,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own; 64 f16-split operands on the f16 matrix cores)")
-    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate of sa_associate from host buffers")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive pass (value_h2d)")
+    ap.add_argument("--cluster", type=int, default=0, help="single process: also time the workload's scenes through sa_cluster over this many shards (one engine per device; --cluster-devices to place several shards on one GPU)")
+    ap.add_argument("--cluster-devices", default="", help="comma-separated HIP ordinals for --cluster (default 0..n-1)")
     args = ap.parse_args()
 
     import torch
@@ -332,13 +432,12 @@ def main():
     facade = None
     if cfg is None:  # c3m: tracks with Kalman states built by the product itself
         facade, eng, cells, acc0 = maha_engine(local_rank, 1234 + rank)
-        models = {"k_frame": ("hbm", 4.0 * cells + 80.0 * 2 * 8 * 500 + 160.0 * 8 * 500)}
     else:
         cfg.device = local_rank
         cfg.flags = DEFAULT_FLAGS if args.flags < 0 else args.flags
         eng = Engine(cfg)
         keep = stage(eng, cfg, scenes)
-        models, cells = kernel_models(cfg, scenes)
+        cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
 
     def barrier():
         torch.cuda.synchronize()
@@ -346,16 +445,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_k():
+        for _ in range(args.steps):
+            eng.batch_run()
+        eng.batch_sync()
+
     for _ in range(args.warmup):
         eng.batch_run()
     eng.batch_sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.batch_run()
-    eng.batch_sync()
-    barrier()  # barrier + synchronize on both sides of the timed region: every rank's dt covers the slowest rank
-    dt = time.perf_counter() - t0
+    dt, regions = timed_rounds(run_k, barrier)
     if dist is not None:
         cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -366,22 +464,43 @@ def main():
         total_cells = float(ct.item())
     else:
         total_cells = float(cells)
-    # sanity: the timed work produced the right answer
+    # the timed work produced the right answer: against the synthetic truth, and (below, rank 0 at N = 1) against the oracle
     if facade is None:
-        ids, votes = eng.batch_fetch(0, len(scenes[0]["det_boxes"]))
-        acc = float((ids == scenes[0]["truth"]).mean())
+        got = [eng.batch_fetch(s, len(sc["det_boxes"])) for s, sc in enumerate(scenes)]
+        acc = float(np.mean(np.concatenate([g[0] == sc["truth"] for g, sc in zip(got, scenes)])))
     else:
+        got = None
         ids, votes = eng.batch_fetch(0, 500)
         acc = float((ids != 0).mean())  # every detection of the staged frame continues a track
 
-    h2d = h2d_inclusive(eng, cfg, scenes) if (args.h2d and rank == 0 and facade is None) else None
+    # PCIe-inclusive: the same frame from host buffers every step, pipelined (detections H2D and assignments D2H included)
+    h2d, h2d_ids = None, None
+    if not args.no_h2d and facade is None:
+        h2d, h2d_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50))
+        if dist is not None:
+            th = torch.tensor([h2d["ms_per_step"]], dtype=torch.float64, device=cdev)
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            h2d["ms_per_step"] = float(th.item())
+            h2d["pairs_per_s"] = total_cells / (1e-3 * h2d["ms_per_step"])
+        h2d["matches_resident_run"] = bool(all(np.array_equal(a, g[0]) for a, g in zip(h2d_ids, got)))
+
     # per-kernel durations: hipEvents stamped with each dispatch's own begin / end on the engine's stream (hipExtLaunchKernelGGL),
     # same staged inputs, separate pass so that the timed region above stays free of instrumentation
-    eng.close()
     if facade is not None:
+        eng.profile_enable(True)
+        for _ in range(5):
+            eng.batch_run()
+        eng.batch_sync()
+        eng.profile_reset()
+        for _ in range(args.profile_iters):
+            eng.batch_run()
+        eng.batch_sync()
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        eng.close()
         facade.close()
-        prof = {}
     else:
+        eng.close()
         cfg_p = cfg
         cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME | abi.SA_FLAG_F16_SPLIT))  # same launches as the timed pass
         engp = Engine(cfg_p)
@@ -396,24 +515,66 @@ def main():
         prof = engp.profile_read()
         engp.close()
 
+    # the scenes of this workload through the in-process dispatcher (sa_cluster): one ingest point, scatter by scene_id % shards,
+    # every shard's share on its own engine concurrently, gather — host buffers in, host buffers out
+    cluster = None
+    if args.cluster and rank == 0 and facade is None:
+        from similari_amd.engine import Cluster
+
+        devs = [int(x) for x in args.cluster_devices.split(",")] if args.cluster_devices else list(range(args.cluster))
+        visual = cfg.visual_kind != abi.SA_VIS_NONE
+        cfg.flags = 0
+        cl = Cluster(cfg, devices=devs)
+        many = scenes * max(1, (len(devs) * max(1, 8 // max(1, len(scenes)))))  # every shard gets as many scenes as one GPU had
+        items = []
+        for s, sc in enumerate(many):
+            kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
+            cl.upsert(s, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw))
+            kw = dict(feats=sc["det_feats"], feat_quality=sc["det_quality"]) if visual else {}
+            items.append((s, 1, abi.make_detections(sc["det_boxes"], **kw)))
+        req, res, outs = Engine.make_requests(items)
+        for _ in range(5):
+            cl.associate_batch(req, res)
+        t0 = time.perf_counter()
+        shard_ms = np.zeros(len(devs))
+        for _ in range(50):
+            cl.associate_batch(req, res)
+            shard_ms += np.array(cl.last_ms())
+        dtc = (time.perf_counter() - t0) / 50
+        ccells = sum(len(sc["det_boxes"]) * len(sc["track_boxes"]) for sc in many)
+        cluster = {"shards": len(devs), "devices": devs, "scenes": len(many), "pairs_per_s": ccells / dtc, "ms_per_batch": 1e3 * dtc,
+                   "shard_ms_per_batch": [float(x) / 50 for x in shard_ms],
+                   "note": "sa_cluster_associate_batch from host buffers (pageable): split by scene_id % shards, one sa_associate_batch per shard on its "
+                           "worker thread, all shards concurrently, results in the caller's arrays; shard_ms = wall time inside each worker"}
+        cl.close()
+
     if rank == 0:
         kern = {k: {"launches": int(n), "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
         gpu_kernels = {k: v for k, v in kern.items() if k != "d2h_results"}
-        if not gpu_kernels:  # c3m: the engine belongs to the facade, no instrumented second pass
-            print(json.dumps({"metric": "assoc-pairs/sec (NxM cost+assign)", "value": total_cells * args.steps / dt, "unit": "pairs/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": desc, "scenes_per_gpu": 8, "pairs_per_step_per_gpu": cells}, "match_accuracy": acc,
-                              "roofline": None}))
-            if dist is not None:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
+        visual = facade is None and cfg.visual_kind != abi.SA_VIS_NONE
+        f16 = facade is None and bool(cfg.flags & abi.SA_FLAG_F16_SPLIT)
+        per_step = lambda k: prof[k][0] / float(args.profile_iters)  # launches of kernel k per step
+        # ---- algorithmic work per launch, stated in DESIGN.md section 4 ----
+        models = {}
+        if visual:
+            euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
+            K = cfg.max_observations
+            flops = sum((3.0 if euclid else 2.0) * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
+            models["k_visual_cost"] = ("valu" if euclid else "mfma", flops)
+            models["k_frame_visual"] = ("mfma", flops)
+            models["k_bestfit_tile"] = ("hbm", 4.0 * K * cells + 12.0 * (cells / 64.0) * 2.0)
+        pairs_near, flop_pair = (0, 0.0)
+        if facade is None:
+            pairs_near, flop_pair = f64_clip_model(scenes)
+            edges = sum(int((g[0] != 0).sum()) for g in got) if got else 0
+            models["k_frame"] = ("hbm", kernel_bytes_model(cfg, scenes, edges) + (sum(len(s["det_boxes"]) for s in scenes) * 4.0 * cfg.feature_len * 2 if visual else 0.0))
+        else:
+            models["k_frame"] = ("hbm", (48.0 + 84.0 + 80.0 + 16.0) * 8 * 500)
         dom = max(gpu_kernels, key=lambda k: gpu_kernels[k]["avg_us"] * gpu_kernels[k]["launches"])
         roof = None
         if dom in models:
             bound, amount = models[dom]
-            per_launch = amount * (prof[dom][0] and args.profile_iters / prof[dom][0])
+            per_launch = amount / per_step(dom)
             dur_s = kern[dom]["avg_us"] * 1e-6
             if bound == "valu":
                 a = per_launch / dur_s / 1e12
@@ -422,15 +583,18 @@ def main():
                         "peak_note": "f32 vector peak (the same 157.3 TFLOP/s as the f32 matrix cores); sub + mul + add per element, 2 of 3 fuse"}
             elif bound == "mfma":
                 a = per_launch / dur_s / 1e12
-                mfma_peak = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
+                mfma_peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16 else MFMA_F32_PEAK_TFLOPS
                 roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": mfma_peak, "unit": "TFLOP/s",
                         "frac": a / mfma_peak, "traffic": None}
-                if cfg.flags & abi.SA_FLAG_F16_SPLIT:
+                if f16:
                     roof["peak_note"] = "f16 MFMA dense peak / 3: the f16-split contraction issues three f16 products per algorithmic product"
             else:
                 a = per_launch / dur_s / 1e9
                 roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": a / HBM_PEAK_GBS, "traffic": None}
+                if dom == "k_frame":
+                    roof["note"] = ("the positional launch is an elementwise map, HBM-bound by SURVEY 8(d)'s definition, but it moves kilobytes per microsecond: "
+                                    "what bounds it is the f64 vector work of the clip (valu_f64 below) and the latency chain of a tile")
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "note": "latency-bound helper kernel; no algorithmic-byte model"}
@@ -439,15 +603,24 @@ def main():
             if tr:
                 roof["traffic"], roof["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH + WRITE bytes per launch)"
             if dom in models:
-                roof["algorithmic"] = models[dom][1] * args.profile_iters / prof[dom][0]
+                roof["algorithmic"] = models[dom][1] / per_step(dom)
                 roof["algorithmic_unit"] = "flop per launch" if models[dom][0] in ("mfma", "valu") else "bytes per launch"
         # secondary roofline lines for every modelled kernel
         for k, (bound, amount) in models.items():
             if k in kern and kern[k]["avg_us"] > 0:
-                per_launch = amount * args.profile_iters / prof[k][0]
+                per_launch = amount / per_step(k)
                 rate = per_launch / (kern[k]["avg_us"] * 1e-6)
-                mp = MFMA_F16_PEAK_TFLOPS / 3.0 if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else MFMA_F32_PEAK_TFLOPS
+                mp = MFMA_F16_PEAK_TFLOPS / 3.0 if f16 else MFMA_F32_PEAK_TFLOPS
                 kern[k]["roofline_frac"] = rate / 1e12 / mp if bound == "mfma" else rate / 1e12 / VALU_F32_PEAK_TFLOPS if bound == "valu" else rate / 1e9 / HBM_PEAK_GBS
+        # the positional tiles' f64 vector work (they run inside k_frame, or inside k_frame_visual beside the contraction)
+        pk = "k_frame" if "k_frame" in kern else ("k_frame_visual" if "k_frame_visual" in kern else None)
+        valu_f64 = None
+        if pk and pairs_near:
+            fl = pairs_near * flop_pair / per_step(pk)
+            valu_f64 = {"kernel": pk, "surviving_pairs_per_launch": pairs_near / per_step(pk), "f64_flop_per_pair": flop_pair, "f64_flop_per_launch": fl,
+                        "achieved": fl / (kern[pk]["avg_us"] * 1e-6) / 1e12, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": fl / (kern[pk]["avg_us"] * 1e-6) / 1e12 / VALU_F64_PEAK_TFLOPS,
+                        "note": "pairs that pass too_far() x the f64 operations Sutherland-Hodgman + shoelace spend on them (counted on a sample by a host restatement)"}
         out = {
             "metric": "assoc-pairs/sec (NxM cost+assign) VisualSORT 512-d",
             "value": total_cells * args.steps / dt,
@@ -459,17 +632,28 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16-split operands (22 bit), f32 accumulate — NOT f32 arithmetic" if (cfg.flags & abi.SA_FLAG_F16_SPLIT) else "f32",
+            "dtype": "f16-split operands (22 bit), f32 accumulate — NOT f32 arithmetic" if f16 else "f32",
             "data": "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
-            "config": {"workload": desc, "scenes_per_gpu": len(scenes), "pairs_per_step_per_gpu": cells,
+            "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "pairs_per_step_per_gpu": cells,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},
+            "timed_regions": {"count": len(regions), "steps_each": args.steps, "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
+                              "max_ms_per_step": 1e3 * max(regions) / args.steps},
+            "value_resident": total_cells * args.steps / dt,
+            "value_h2d": h2d["pairs_per_s"] if h2d else None,
             "match_accuracy": acc,
             "roofline": roof,
             "kernels": kern,
         }
+        if valu_f64:
+            out["valu_f64"] = valu_f64
         if h2d is not None:
             out["h2d_inclusive"] = h2d
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
+        if cluster is not None:
+            out["cluster"] = cluster
+        if not args.no_cpu_baseline and world == 1 and facade is None:  # rank 0 at N = 1 only
+            ans = oracle_answers(cfg, scenes)
+            same = np.concatenate([(g[0] == a[0]) & (g[1] == a[1]) for g, a in zip(got, ans)])
+            out["match_vs_oracle"] = float(same.mean())
             out["cpu_baseline"] = cpu_baseline(cfg, scenes)
             try:
                 out["cpu_baseline_threads"] = cpu_baseline_threads(cfg, scenes)

@@ -314,6 +314,9 @@ typedef struct sa_kernel_stat {
   uint64_t launches;
   double total_ms;   /* sum of hipEvent-bracketed durations on the engine's stream */
 } sa_kernel_stat;
+/* Per-kernel dispatch timing on an engine that was not created with SA_FLAG_PROFILE (e.g. the one inside a tracker facade,
+ * sa_tracker_engine): on != 0 stamps every following kernel with its dispatch begin / end (and disables hipGraph replay), 0 stops. */
+int sa_profile_enable(sa_engine* e, int on);
 int sa_profile_reset(sa_engine* e);
 int sa_profile_read(sa_engine* e, sa_kernel_stat* out, uint32_t cap, uint32_t* out_n);
 /* hipEvent-timed wall time of `iters` back-to-back sa_batch_run()s on the engine's stream. */

@@ -375,6 +375,7 @@ PROTOTYPES = {
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_quantised": (C.c_int, [ENGINE, u32, P(C.c_int64)]),
+    "sa_profile_enable": (C.c_int, [ENGINE, C.c_int]),
     "sa_profile_reset": (C.c_int, [ENGINE]),
     "sa_profile_read": (C.c_int, [ENGINE, P(sa_kernel_stat), u32, P(u32)]),
     "sa_batch_time": (C.c_int, [ENGINE, u32, f64p]),

@@ -580,3 +580,226 @@ SA_HD void sa_assign_component(const sa_assign_ws& w, uint32_t first_row) {
     }
   }
 }
+
+// =====================================================================================================================
+// Group-cooperative solve: the same shortest-augmenting-path search as sa_assign_component, with its two inner loops — "nearest
+// labelled, unscanned column" and "relax the edges of the row that just entered the tree" — spread over the G lanes of a group
+// (a whole wavefront, or a 16-lane quarter of one), per-row minima by lane reductions, all state in LDS.  One group solves one
+// connected component at a time; a component of hundreds of rows (a dense crowd under a low IoU threshold) costs
+// O(path steps x (columns + edges) / G) instead of one lane's chain of dependent LDS round trips.
+//
+// The source below is written once for both worlds: on the device a "lane loop" runs its body once, for this lane; in the host
+// emulation (tests/emu) it runs G times, so the very same statements are checked against the dense kuhn_munkres on a machine
+// without a GPU.  Per-lane values that cross a reduction sit in arrays of SA_COOP_SLOTS(G) elements (1 on the device).
+// Choices are made on (distance, column index) exactly like the serial search, rows are relaxed one at a time in the order they
+// enter the tree, so the result is the serial solver's, whatever G is.
+// =====================================================================================================================
+#if defined(__HIPCC__)  // both passes of hipcc: device functions (the host pass only parses them)
+#define SA_COOP_FN __device__ __forceinline__
+#define SA_COOP_SLOTS(G) 1
+#define SA_COOP_SLOT(l) 0
+#define SA_COOP_FOR(G, l) for (uint32_t l = (uint32_t)(__lane_id() & ((G)-1)), _sa_once = 1; _sa_once; _sa_once = 0)
+template <int G>
+__device__ __forceinline__ void sa_coop_sync() {  // LDS traffic of one wave is processed in order: only the compiler has to be held
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// lexicographic minimum of (d, j) over the group; every lane receives it
+template <int G>
+__device__ __forceinline__ void sa_coop_min(const int64_t* d, const int32_t* j, int64_t* od, int32_t* oj) {
+  int64_t bd = d[0];
+  int32_t bj = j[0];
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    const int64_t xd = __shfl_xor(bd, o, G);
+    const int32_t xj = __shfl_xor(bj, o, G);
+    const bool take = xj >= 0 && (bj < 0 || xd < bd || (xd == bd && xj < bj));
+    bd = take ? xd : bd;
+    bj = take ? xj : bj;
+  }
+  *od = bd;
+  *oj = bj;
+}
+// rank of this lane among the lanes of its group that raise `flag`, and how many do
+template <int G>
+__device__ __forceinline__ uint32_t sa_coop_rank(const bool* flag, uint32_t l, uint32_t* total) {
+  const unsigned long long m = __ballot(flag[0]);
+  const uint32_t base = (uint32_t)__lane_id() & ~(uint32_t)(G - 1);
+  const unsigned long long gm = G == 64 ? m : (m >> base) & ((1ull << (G & 63)) - 1ull);
+  *total = (uint32_t)__popcll(gm);
+  return (uint32_t)__popcll(gm & ((1ull << l) - 1ull));
+}
+template <int G, class T>
+__device__ __forceinline__ T sa_coop_bcast(const T* v) {  // lane 0's value to the whole group
+  return __shfl(v[0], 0, G);
+}
+#else
+#define SA_COOP_FN inline
+#define SA_COOP_SLOTS(G) (G)
+#define SA_COOP_SLOT(l) (l)
+#define SA_COOP_FOR(G, l) for (uint32_t l = 0; l < (uint32_t)(G); ++l)
+template <int G>
+inline void sa_coop_sync() {}
+template <int G>
+inline void sa_coop_min(const int64_t* d, const int32_t* j, int64_t* od, int32_t* oj) {
+  int64_t bd = 0;
+  int32_t bj = -1;
+  for (int l = 0; l < G; ++l)
+    if (j[l] >= 0 && (bj < 0 || d[l] < bd || (d[l] == bd && j[l] < bj))) { bd = d[l]; bj = j[l]; }
+  *od = bd;
+  *oj = bj;
+}
+template <int G>
+inline uint32_t sa_coop_rank(const bool* flag, uint32_t l, uint32_t* total) {
+  uint32_t r = 0, t = 0;
+  for (uint32_t k = 0; k < (uint32_t)G; ++k) {
+    if (flag[k]) { if (k < l) ++r; ++t; }
+  }
+  *total = t;
+  return r;
+}
+template <int G, class T>
+inline T sa_coop_bcast(const T* v) { return v[0]; }
+#endif
+
+struct sa_coop_ws {
+  // usable edges of the rows: as in sa_assign_ws (packed LDS pool, or the 16-byte records the positional tiles left in HBM)
+  const uint32_t* e_cnt;
+  const uint32_t* e_col;
+  const int64_t* e_gain;
+  uint32_t ecs, egs, rcs, rgs, estride;
+  const uint32_t* e_off;
+  const uint8_t* excluded;
+  int64_t* u;        // [N] row duals: -(heaviest usable gain) on entry
+  int64_t* v;        // [T] column duals: 0 on entry
+  int32_t* rmatch;   // [N] -1, or the column the greedy start gave the row
+  int32_t* cmatch;   // [T]
+  int64_t* dist;     // [T]
+  int32_t* pred;     // [T]
+  uint32_t* cstamp;  // [T] 0 on entry
+  uint32_t* cscan;   // [T] 0 on entry
+  uint32_t* clist;   // room for every column of the component: the labelled columns of the running search
+};
+
+// Relax the usable edges of `row` (which entered the tree at distance `base`): G edges per step.  Columns labelled for the first
+// time in this search are appended to clist (ballot + prefix: append order = edge order, irrelevant to any decision).
+template <int G>
+SA_COOP_FN void sa_coop_relax(const sa_coop_ws& w, uint32_t row, int64_t base, uint32_t stamp, uint32_t* len) {
+  const uint32_t cnt = w.e_cnt[row];
+  const size_t first = w.e_off ? (size_t)w.e_off[row] : (size_t)row * w.estride;
+  const uint32_t* cols = w.e_col + first * w.rcs;
+  const int64_t* gains = w.e_gain + first * w.rgs;
+  const int64_t ur = w.u[row];
+  for (uint32_t e0 = 0; e0 < cnt; e0 += G) {
+    bool fresh[SA_COOP_SLOTS(G)];
+    uint32_t col[SA_COOP_SLOTS(G)];
+    SA_COOP_FOR(G, l) {
+      const uint32_t e = e0 + l;
+      bool f = false;
+      uint32_t j = 0;
+      if (e < cnt) {
+        j = cols[(size_t)e * w.ecs];
+        if (!(w.excluded && w.excluded[j]) && w.cscan[j] != stamp) {
+          const int64_t d = base + (-gains[(size_t)e * w.egs] - ur - w.v[j]);
+          if (w.cstamp[j] != stamp) {
+            w.cstamp[j] = stamp;
+            w.dist[j] = d;
+            w.pred[j] = (int32_t)row;
+            f = true;
+          } else if (d < w.dist[j]) {
+            w.dist[j] = d;
+            w.pred[j] = (int32_t)row;
+          }
+        }
+      }
+      fresh[SA_COOP_SLOT(l)] = f;
+      col[SA_COOP_SLOT(l)] = j;
+    }
+    uint32_t added = 0;
+    SA_COOP_FOR(G, l) {
+      uint32_t tot;
+      const uint32_t r = sa_coop_rank<G>(fresh, l, &tot);
+      if (fresh[SA_COOP_SLOT(l)]) w.clist[*len + r] = col[SA_COOP_SLOT(l)];
+      added = tot;
+    }
+    *len += added;
+    sa_coop_sync<G>();
+  }
+}
+
+// Solves one component: `roots` = its rows the greedy start left unmatched (ascending), n_roots of them.  Rows matched by the
+// greedy start hold their heaviest usable edge (tight under u = -max gain, v = 0), so the duals are feasible on entry.
+template <int G>
+SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* roots, uint32_t n_roots) {
+  for (uint32_t ri = 0; ri < n_roots; ++ri) {
+    const uint32_t root = roots[ri];
+    const uint32_t stamp = root + 1u;
+    uint32_t len = 0;
+    int64_t best_term = -w.u[root];  // reduced cost of the root's own self column
+    int32_t term_row = (int32_t)root;
+    int32_t end_col = -1;
+    int64_t delta;
+    sa_coop_relax<G>(w, root, 0, stamp, &len);
+    for (;;) {
+      // nearest labelled, unscanned column (ties: lowest column index): one strided pass + a lane reduction
+      int64_t pd[SA_COOP_SLOTS(G)];
+      int32_t pj[SA_COOP_SLOTS(G)];
+      SA_COOP_FOR(G, l) {
+        int64_t bd = 0;
+        int32_t bj = -1;
+        for (uint32_t k = l; k < len; k += G) {
+          const int32_t j = (int32_t)w.clist[k];
+          if (w.cscan[j] == stamp) continue;
+          const int64_t d = w.dist[j];
+          if (bj < 0 || d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+        }
+        pd[SA_COOP_SLOT(l)] = bd;
+        pj[SA_COOP_SLOT(l)] = bj;
+      }
+      int64_t bd;
+      int32_t bj;
+      sa_coop_min<G>(pd, pj, &bd, &bj);
+      if (bj < 0 || bd >= best_term) { delta = best_term; break; }  // a self column ends the path
+      w.cscan[bj] = stamp;
+      const int32_t i = w.cmatch[bj];
+      if (i < 0) { end_col = bj; delta = bd; break; }               // free real column
+      const int64_t t = bd + (-w.u[i]);
+      if (t < best_term) { best_term = t; term_row = i; }
+      sa_coop_sync<G>();
+      sa_coop_relax<G>(w, (uint32_t)i, bd, stamp, &len);
+    }
+    sa_coop_sync<G>();
+    // dual update.  A tree row other than the root entered through the scanned column it is matched to, at that column's
+    // distance: u[cmatch[j]] += delta - dist[j], v[j] += dist[j] - delta over the scanned columns; the root moves by delta.
+    SA_COOP_FOR(G, l) {
+      for (uint32_t k = l; k < len; k += G) {
+        const uint32_t j = w.clist[k];
+        if (w.cscan[j] != stamp) continue;
+        const int64_t dj = w.dist[j];
+        w.v[j] += dj - delta;
+        const int32_t i = w.cmatch[j];
+        if (i >= 0) w.u[i] += delta - dj;
+      }
+      if (l == 0) w.u[root] += delta;
+    }
+    sa_coop_sync<G>();
+    // augment (a short dependent chain: every lane walks it, lane 0 writes)
+    int32_t j;
+    if (end_col >= 0) j = end_col;
+    else {
+      if (term_row == (int32_t)root) continue;  // root keeps its self column
+      j = w.rmatch[term_row];                   // term_row falls back to self and frees its column
+      sa_coop_sync<G>();
+      SA_COOP_FOR(G, l) { if (l == 0) w.rmatch[term_row] = -1; }
+    }
+    for (;;) {
+      const int32_t i = w.pred[j];
+      const int32_t prev = w.rmatch[i];
+      sa_coop_sync<G>();
+      SA_COOP_FOR(G, l) { if (l == 0) { w.rmatch[i] = j; w.cmatch[j] = i; } }
+      if (i == (int32_t)root) break;
+      j = prev;
+    }
+    sa_coop_sync<G>();
+  }
+}

@@ -468,7 +468,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own (no vote words)
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
-  const bool small_tail = maxN <= SA_SMALL_N && !force_general;
+  const bool small_tail = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general;
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
@@ -1501,6 +1501,12 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------
+int sa_profile_enable(sa_engine* e, int on) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(engine_sync(e));
+  e->profile = on != 0;
+  return SA_OK;
+}
 int sa_profile_reset(sa_engine* e) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(engine_sync(e));

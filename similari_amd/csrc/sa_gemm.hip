@@ -1368,7 +1368,7 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
                                   const SaParams& p, hipStream_t st, bool partials) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
-  if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
+  if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
   if (plan != 2 && plan != 4) return hipErrorNotSupported;
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);

@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // rows that already hold a visual decision take no part (feature_winners.contains_key(from), visual_sort/voting.rs:77) and
 // columns won visually are skipped while relaxing (excluded_tracks, :62-71).  A component may therefore be larger than
 // strictly needed — harmless, it is still solved exactly.
-//   N <= SA_SMALL_N: k_assign_small — ONE workgroup per scene does labels -> per-component row lists (every row pushes itself
-//            onto its root's LDS list) -> solve (one thread per component, duals in LDS) -> results,
+//   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
+//            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
 //   else: k_assign_label (component root per row, rows pushed onto their root's list), k_assign_solve (one thread per
 //            component: orders its rows, solves, writes their results).
 // =====================================================================================================
@@ -379,28 +379,50 @@ __device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // WORDS: the contraction's tiles reduced the BestFit vote into one 64-bit word per candidate and per track (SaParams::vote_words,
 // visual_cosine_tile): thread q reads candidate q's word and track q's word, re-arms both, and the verdicts stay in registers
 // (has / winner) and two LDS tables instead of going through k_bestfit_resolve's row_has / vis_winner / col_excluded — one
-// dependent launch less per frame.  Needs T <= SA_SMALL_N (launcher).
-template <bool VISUAL, bool WORDS = false>
+// dependent launch less per frame.
+//
+// The solve ("batched Jonker-Volgenant with per-row minima in LDS"):
+//   1. greedy start, one thread per row, all rows at once: a row bids for the column of its heaviest usable edge (lowest column
+//      on ties), a column goes to the lowest row that bids for it.  Under the duals u = -(heaviest gain), v = 0 those edges are
+//      tight, so this is a feasible primal-dual start (what the shortest-path search would do for a row whose nearest column is
+//      free, for every such row in ONE step).  In tracking frames almost every row keeps its bid.
+//   2. the rows that lost their bid are the search roots of their connected component; every component that has any goes onto a
+//      work queue;
+//   3. the workgroup's 1024 / G groups of G lanes take components off the queue; a group orders the component's roots
+//      (ascending: the canonical augmentation order) and runs sa_assign_component_coop<G> (sa_device.h): the search's two inner
+//      loops — nearest labelled column, relax a row's edges — spread over the lanes, minima by lane reductions.
+// A component of hundreds of rows (a crowd under a low IoU threshold) is then a few hundred microseconds of group work instead
+// of seconds of one lane's dependent LDS chain; the usual one- and two-row components never reach step 3.
+// Needs N <= SA_SMALL_N and T <= SA_SMALL_N (launcher): rows, columns and the usable edges (up to POOL of them; more stay in the
+// HBM lists and are read from there) live in LDS.
+template <bool VISUAL, bool WORDS, int G>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
-  __shared__ uint32_t s_head[SA_SMALL_N];  // per component root: the rows of the component (pushed in any order)
+  __shared__ uint32_t s_head[SA_SMALL_N];  // per component root: the rows that lost their greedy bid (pushed in any order)
   __shared__ uint32_t s_next[SA_SMALL_N];
-  __shared__ int64_t s_u[SA_SMALL_N], s_rdist[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
-  __shared__ int32_t s_rmatch[SA_SMALL_N], s_rnext[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N], s_cnext[SA_SMALL_N];
+  __shared__ int64_t s_u[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
+  __shared__ int32_t s_rmatch[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N];
   __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
+  __shared__ uint32_t s_lab[SA_SMALL_N];     // component root of a row with usable edges
+  __shared__ uint32_t s_cwin[SA_SMALL_N];    // per column: lowest row bidding for it
+  __shared__ uint32_t s_rcount[SA_SMALL_N];  // per component root: search roots
+  __shared__ uint32_t s_ccount[SA_SMALL_N];  // per component root: columns
+  __shared__ uint32_t s_clist[SA_SMALL_N];   // labelled columns of the running searches, one segment per component
+  __shared__ uint32_t s_rlist[SA_SMALL_N];   // search roots in ascending order, one segment per component
+  __shared__ uint32_t s_queue[SA_SMALL_N];   // components waiting for a group
+  __shared__ uint32_t s_ctr[4];              // queue length | next queue entry | top of s_clist | top of s_rlist
   // The edge lists the positional tiles left behind live in HBM, one strided row per candidate: every access from here on would be
   // a dependent, uncoalesced round trip (the solve is a chain of them).  They are packed ONCE into an LDS pool — an
   // exclusive scan of the row counts gives the offsets — and the row duals, the connected components of the usable graph
   // (rows without a visual verdict) and the solve itself then run out of LDS.  A scene whose lists do not fit (dense
-  // Mahalanobis frames) works on the HBM lists.
+  // Mahalanobis frames, crowds under a low threshold) keeps the HBM lists as the solver's edge storage.
   constexpr uint32_t POOL = 3072;
   __shared__ uint32_t s_parent[2 * SA_SMALL_N];
   __shared__ uint32_t s_ecnt[SA_SMALL_N], s_eoff[SA_SMALL_N], s_wsum[SA_SMALL_N / WAVE];
   __shared__ uint32_t s_ecol[POOL];
   __shared__ int64_t s_egain[POOL];
-  const bool uf_in_lds = T <= SA_SMALL_N;
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
   __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
@@ -455,7 +477,11 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   s_ecnt[q] = mycnt;
   s_head[q] = SA_NONE;
   s_next[q] = SA_NONE;
-  if (uf_in_lds) { s_parent[q] = q; s_parent[q + SA_SMALL_N] = q + SA_SMALL_N; }
+  s_parent[q] = q;
+  s_parent[q + SA_SMALL_N] = q + SA_SMALL_N;
+  s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0;
+  s_cwin[q] = SA_NONE; s_rcount[q] = 0; s_ccount[q] = 0; s_lab[q] = SA_NONE;
+  if (q < 4) s_ctr[q] = 0;
   // exclusive scan of mycnt over the 1024 threads: wave scan, then the 16 wave totals
   uint32_t incl = mycnt;
   {
@@ -511,6 +537,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   const uint32_t myoff = woff + incl - mycnt;
   s_eoff[q] = myoff;
   int64_t maxg = 0;
+  uint32_t bcol = SA_NONE;  // the column of the heaviest usable edge, lowest column on ties: this row's bid
   uint32_t usable = 0;
   if (mycnt) {
     const SaEdge SA_G* row = S.e_edge + q;
@@ -543,80 +570,98 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
         const uint32_t j = jj[k];
         if (pool) { s_ecol[myoff + usable] = j; s_egain[myoff + usable] = gg[k]; }
         ++usable;
-        maxg = gg[k] > maxg ? gg[k] : maxg;
-        if (uf_in_lds) sa_uf_union(s_parent, q, N + j);
-        else sa_uf_union((uint32_t*)S.parent, q, N + j);
+        if (gg[k] > maxg || (gg[k] == maxg && j < bcol)) { maxg = gg[k]; bcol = j; }
+        sa_uf_union(s_parent, q, N + j);
       }
     }
-    if (pool) s_ecnt[q] = usable;  // the packed list holds usable edges only (the HBM list keeps them all: solve skips there)
+    if (pool) s_ecnt[q] = usable;  // the packed list holds usable edges only (the HBM list keeps them all: the solver skips there)
   }
-  if (uf_in_lds) sa_lds_barrier();
-  else __syncthreads();  // the forest is in HBM: its updates must be visible too
-  TAIL_STAMP(2);
-  // component label = root of the union-find tree = the lowest vertex = the component's first row; every row pushes itself
-  // onto that row's list (LDS atomics, any order)
-  uint32_t lab = SA_NONE;
-  if (usable) lab = uf_in_lds ? sa_uf_find(s_parent, q) : sa_uf_find((uint32_t*)S.parent, q);
-  const bool cols_in_lds = T <= SA_SMALL_N;
   s_u[q] = -maxg;
-  if (cols_in_lds) { s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0; }
-  if (lab != SA_NONE) s_next[q] = atomicExch(&s_head[lab], q);
-  if (uf_in_lds) sa_lds_barrier();
-  else {
-    // the forest in HBM is shared with the next frame: give it back clean (a stale tree would hand out labels that are not
-    // rows of this frame)
-    __syncthreads();
-    for (uint32_t i = q; i < N + T; i += SA_SMALL_N) S.parent[i] = i;
-  }
-  TAIL_STAMP(3);
-  TAIL_STAMP(4);
-  TAIL_STAMP(5);
-  // the first row of a component orders the component's rows (ascending: the canonical augmentation order — lists are a
-  // handful of rows in tracking frames) and solves it
-  if (lab == q) {
-    uint32_t sorted = SA_NONE;
-    for (uint32_t cur = s_head[q]; cur != SA_NONE;) {
-      const uint32_t nxt = s_next[cur];
-      if (sorted == SA_NONE || cur < sorted) { s_next[cur] = sorted; sorted = cur; }
-      else {
-        uint32_t pr = sorted;
-        for (uint32_t pn = s_next[pr]; pn != SA_NONE && pn < cur; pn = s_next[pr]) pr = pn;
-        s_next[cur] = s_next[pr];
-        s_next[pr] = cur;
-      }
-      cur = nxt;
+  if (usable) atomicMin(&s_cwin[bcol], q);  // the bid (bcol is set whenever a usable edge exists: gains are > 0)
+  sa_lds_barrier();
+  TAIL_STAMP(2);
+  // component label = root of the union-find tree = the lowest vertex = the component's first row.  Columns count themselves
+  // into their component (the room a search's list of labelled columns can need); rows learn whether their bid held.
+  uint32_t lab = SA_NONE;
+  if (usable) {
+    lab = sa_uf_find(s_parent, q);
+    s_lab[q] = lab;
+    if (s_cwin[bcol] == q) { s_rmatch[q] = (int32_t)bcol; s_cmatch[bcol] = (int32_t)q; }
+    else {
+      s_next[q] = atomicExch(&s_head[lab], q);
+      atomicAdd(&s_rcount[lab], 1u);
     }
-    const uint32_t first = sorted;
-    // one call site per combination of address spaces (edge lists: LDS pool or HBM; column state: LDS or HBM), so that every
-    // pointer of the work set has ONE known address space after inlining — "LDS or global, decided at run time" compiles
-    // to flat_* accesses
-    auto solve = [&](auto pool_tag, auto cols_tag) {
-      sa_assign_ws w;
-      w.estride = S.estride;
-      w.e_cnt = s_ecnt;
-      if constexpr (decltype(pool_tag)::value) { w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.e_off = s_eoff; w.excluded = nullptr; }
-      else {
+  }
+  if (q < T) {
+    const uint32_t r = sa_uf_find(s_parent, N + q);
+    if (r < N) atomicAdd(&s_ccount[r], 1u);  // a column without usable edges is its own root (>= N)
+  }
+  sa_lds_barrier();
+  TAIL_STAMP(3);
+  if (lab == q && s_head[q] != SA_NONE) s_queue[atomicAdd(&s_ctr[0], 1u)] = q;
+  sa_lds_barrier();
+  TAIL_STAMP(4);
+  // groups of G lanes take components off the queue
+  {
+    const uint32_t lane = q % G;
+    const uint32_t nq = s_ctr[0];
+    sa_coop_ws w;
+    w.e_cnt = s_ecnt;
+    w.u = s_u; w.v = s_v; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan;
+    for (;;) {
+      uint32_t take[1], seg[2];
+      if (lane == 0) take[0] = atomicAdd(&s_ctr[1], 1u);
+      const uint32_t k = sa_coop_bcast<G>(take);
+      if (k >= nq) break;
+      const uint32_t root = s_queue[k];
+      const uint32_t R = s_rcount[root], C = s_ccount[root];
+      if (lane == 0) { seg[0] = atomicAdd(&s_ctr[2], C); seg[1] = atomicAdd(&s_ctr[3], R); }
+      const uint32_t cbase = sa_coop_bcast<G>(seg), rbase = sa_coop_bcast<G>(seg + 1);
+      uint32_t* roots = s_rlist + rbase;
+      if (R <= (uint32_t)G) {
+        // a short list: every lane walks it, lane l keeps element l, ranks by comparison, one store each
+        uint32_t cur = s_head[root], mine = SA_NONE;
+        for (uint32_t st = 0; st < R; ++st) {
+          if (st == lane) mine = cur;
+          cur = s_next[cur];
+        }
+        uint32_t rank = 0;
+        for (uint32_t st = 0; st < R; ++st) {
+          const uint32_t other = __shfl(mine, st, G);
+          rank += other < mine ? 1u : 0u;
+        }
+        if (lane < R) roots[rank] = mine;
+      } else {
+        // a long list: compact the scene's rows (lab == root, bid lost) in row order, G rows per step
+        uint32_t cnt = 0;
+        for (uint32_t r0 = 0; r0 < N; r0 += G) {
+          const uint32_t row = r0 + lane;
+          bool f[1];
+          f[0] = row < N && s_lab[row] == root && s_rmatch[row] < 0;
+          uint32_t tot;
+          const uint32_t rk = sa_coop_rank<G>(f, lane, &tot);
+          if (f[0]) roots[cnt + rk] = row;
+          cnt += tot;
+        }
+      }
+      sa_coop_sync<G>();
+      w.clist = s_clist + cbase;
+      // one call site per address space of the edge storage (LDS pool or the HBM lists), so that every pointer of the work set has
+      // ONE known address space after inlining — "LDS or global, decided at run time" compiles to flat_* accesses
+      if (pool) {
+        w.e_col = s_ecol; w.e_gain = s_egain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = s_eoff; w.excluded = nullptr;
+        sa_assign_component_coop<G>(w, roots, R);
+      } else {
         // slot-major lists: row r starts at record r, consecutive edges are N records apart
         w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4 * N; w.egs = 2 * N; w.rcs = 4; w.rgs = 2; w.e_off = nullptr; w.estride = 1;
         if constexpr (WORDS) w.excluded = s_cexcl;
         else w.excluded = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
+        sa_assign_component_coop<G>(w, roots, R);
       }
-      w.next_row = s_next;
-      w.u = s_u; w.rmatch = s_rmatch; w.rdist = s_rdist; w.rnext = s_rnext;
-      if constexpr (decltype(cols_tag)::value) {
-        w.v = s_v; w.cmatch = s_cmatch; w.dist = s_dist; w.pred = s_pred; w.cstamp = s_cstamp; w.cscan = s_cscan; w.cnext = s_cnext;
-      } else {
-        w.v = (int64_t*)S.v; w.cmatch = (int32_t*)S.cmatch; w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred;
-        w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan; w.cnext = (int32_t*)S.cnext;
-      }
-      sa_assign_component(w, first);
-    };
-    if (pool && cols_in_lds) solve(std::true_type{}, std::true_type{});
-    else if (pool) solve(std::true_type{}, std::false_type{});
-    else if (cols_in_lds) solve(std::false_type{}, std::true_type{});
-    else solve(std::false_type{}, std::false_type{});
+    }
   }
-  sa_lds_barrier();  // rmatch is in LDS in every variant
+  TAIL_STAMP(5);
+  sa_lds_barrier();  // rmatch is in LDS
   TAIL_STAMP(6);
   if (q < N) {
     uint64_t id = 0;
@@ -826,7 +871,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   static const char* wide_env = getenv("SA_POS_WIDE");  // measurements: 0 / 1 force the narrow / wide positional tiles
   const bool wide = wide_env ? wide_env[0] == '1' : (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
-  const bool uni = maxN > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
+  const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
@@ -871,9 +916,13 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       break;
     default:
       sa_tail_trace_hook(st, ns);
-      if (stage == 8) SA_LAUNCH((k_assign_small<true, true>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_small<true>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else SA_LAUNCH(k_assign_small<false>, dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      {
+        // SA_COOP_G=16: quarter-wave groups (four components per wavefront side by side) instead of whole wavefronts — measurements
+        static const bool g16 = getenv("SA_COOP_G") && atoi(getenv("SA_COOP_G")) == 16;
+        if (stage == 8) { if (g16) SA_LAUNCH((k_assign_small<true, true, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
+        else if (p.visual_kind != SA_VIS_NONE) { if (g16) SA_LAUNCH((k_assign_small<true, false, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
+        else { if (g16) SA_LAUNCH((k_assign_small<false, false, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
+      }
       break;
   }
   return hipGetLastError();

@@ -218,6 +218,9 @@ class Engine:
         return out
 
     # ---- measurement ----
+    def profile_enable(self, on: bool = True):
+        self._chk(self.lib.sa_profile_enable(self.h, 1 if on else 0))
+
     def profile_reset(self):
         self._chk(self.lib.sa_profile_reset(self.h))
 

@@ -252,3 +252,180 @@ class ShardedBatchTracker:
     def shutdown(self):
         assert self.rank == self.root
         self._step(None, True)
+
+
+# ---- array-level sharding of the association itself (no per-observation Python) ------------------------------------------
+# The tracker-level wrapper above moves Python objects; this one moves the arrays the C ABI takes.  One request set =
+# [(scene_id, epoch, boxes[N] (abi.BOX_DTYPE), feats[N, D] | None, quality[N] | None)]; the root packs every rank's share into one
+# byte buffer with numpy concatenations, ONE scatter delivers them, every rank hands its share to its engine as one
+# sa_associate_batch (one DMA + one set of launches), ONE gather returns ids[N] + votes[N] per scene.  Buffers have a fixed
+# capacity agreed at construction (collectives want equal shapes), so there is no size exchange per call.
+ASSOC_HEAD = 4  # int64 words: n_scenes, D, total N, flags (1 = shutdown)
+
+
+def pack_share(items, D: int) -> np.ndarray:
+    """[(scene, epoch, boxes, feats, quality)] -> uint8 buffer: int64 head[4] | int64 table[n][4] (scene, epoch, N, has_feats |
+    has_quality << 1) | boxes | quality | feats."""
+    from . import abi
+
+    n = len(items)
+    table = np.zeros((n, 4), np.int64)
+    for i, (scene, epoch, boxes, feats, quality) in enumerate(items):
+        table[i] = (scene, epoch, len(boxes), (1 if feats is not None else 0) | (2 if quality is not None else 0))
+    total = int(table[:, 2].sum()) if n else 0
+    head = np.array([n, D, total, 0], np.int64)
+    parts = [head.view(np.uint8), table.reshape(-1).view(np.uint8)]
+    parts += [np.ascontiguousarray(it[2], abi.BOX_DTYPE).view(np.uint8).reshape(-1) for it in items]
+    parts += [np.ascontiguousarray(it[4], np.float32).view(np.uint8).reshape(-1) for it in items if it[4] is not None]
+    parts += [np.ascontiguousarray(it[3], np.float32).view(np.uint8).reshape(-1) for it in items if it[3] is not None]
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
+
+def unpack_share(buf: np.ndarray):
+    """Inverse of pack_share: views into `buf` (no copies)."""
+    from . import abi
+
+    n, D, total, flags = (int(x) for x in buf[:32].view(np.int64))
+    o = 32
+    table = buf[o:o + 32 * n].view(np.int64).reshape(n, 4)
+    o += 32 * n
+    items = []
+    counts = [int(c) for c in table[:, 2]]
+    boxes = []
+    for c in counts:
+        boxes.append(buf[o:o + c * abi.BOX_DTYPE.itemsize].view(abi.BOX_DTYPE))
+        o += c * abi.BOX_DTYPE.itemsize
+    quality = []
+    for i, c in enumerate(counts):
+        if table[i, 3] & 2:
+            quality.append(buf[o:o + 4 * c].view(np.float32))
+            o += 4 * c
+        else:
+            quality.append(None)
+    for i, c in enumerate(counts):
+        ft = None
+        if table[i, 3] & 1:
+            ft = buf[o:o + 4 * c * D].view(np.float32).reshape(c, D)
+            o += 4 * c * D
+        items.append((int(table[i, 0]), int(table[i, 1]), boxes[i], ft, quality[i]))
+    return items, flags
+
+
+class ShardedAssociator:
+    """SPMD wrapper around one Engine per rank.  Root: associate(request set) -> [(ids, votes)] in request order; other ranks:
+    serve_forever() (or associate(None) in lockstep).  `capacity_bytes` bounds one rank's share of a request set, `capacity_rows` its
+    detections.  Tracks are upserted per scene on the owning rank (upsert is a collective too: the root passes the arrays)."""
+
+    def __init__(self, engine, capacity_bytes: int, capacity_rows: int, group=None, root: int = 0, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.eng, self.group, self.root = engine, group, root
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.device = device
+        self.cap_b = int(capacity_bytes) + 64
+        self.cap_r = int(capacity_rows)
+        pin = device.type == "cuda"
+        self.h_req = torch.zeros(self.cap_b, dtype=torch.uint8, pin_memory=pin)       # this rank's share, host side
+        self.h_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, pin_memory=pin)   # ids[rows] (u64) then votes[rows]
+        self.d_req = torch.zeros(self.cap_b, dtype=torch.uint8, device=device)
+        self.d_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device)
+        if self.rank == root:
+            self.h_all = torch.zeros((self.world, self.cap_b), dtype=torch.uint8, pin_memory=pin)
+            self.d_all = [torch.zeros(self.cap_b, dtype=torch.uint8, device=device) for _ in range(self.world)]
+            self.d_gather = [torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device) for _ in range(self.world)]
+        self.last_local_ms = 0.0
+
+    def _run_share(self, buf: np.ndarray):
+        """This rank's share -> its engine (one sa_associate_batch) -> ids | votes packed into h_res."""
+        import time
+
+        from . import abi
+        from .engine import Engine
+
+        items, flags = unpack_share(buf)
+        if flags & 1:
+            return False
+        t0 = time.perf_counter()
+        dets = [abi.make_detections(b, feats=f, feat_quality=q) for (_, _, b, f, q) in items]
+        req, res, outs = Engine.make_requests([(it[0], it[1], d) for it, d in zip(items, dets)])
+        if items:
+            self.eng.associate_batch(req, res)
+        self.last_local_ms = 1e3 * (time.perf_counter() - t0)
+        total = sum(len(o[0]) for o in outs)
+        assert total <= self.cap_r, f"{total} detections exceed capacity_rows {self.cap_r}"
+        out = self.h_res.numpy()
+        if total:
+            out[: 8 * total] = np.concatenate([o[0] for o in outs]).view(np.uint8)
+            out[8 * self.cap_r: 8 * self.cap_r + total] = np.concatenate([o[1] for o in outs])
+        return True
+
+    def associate(self, items=None, shutdown: bool = False):
+        torch, dist = self.torch, self.dist
+        is_root = self.rank == self.root
+        if is_root:
+            shares = [[] for _ in range(self.world)]
+            where = []
+            if not shutdown:
+                for it in items:
+                    r = owner(it[0], self.world)
+                    where.append((r, len(shares[r])))
+                    shares[r].append(it)
+            D = self.eng.cfg.feature_len if self.eng.cfg is not None else 0
+            ha = self.h_all.numpy()
+            for r in range(self.world):
+                b = pack_share(shares[r], D)
+                if shutdown:
+                    b[24:32].view(np.int64)[0] = 1
+                assert len(b) <= self.cap_b, f"rank {r}'s share ({len(b)} B) exceeds capacity_bytes {self.cap_b}"
+                ha[r, : len(b)] = b
+        if self.world > 1:
+            if is_root:
+                for r in range(self.world):
+                    self.d_all[r].copy_(self.h_all[r], non_blocking=True)
+            dist.scatter(self.d_req, self.d_all if is_root else None, src=self.root, group=self.group)
+            self.h_req.copy_(self.d_req)
+            mine = self.h_req.numpy()
+        else:
+            mine = self.h_all.numpy()[0]
+        alive = self._run_share(mine)
+        if not alive:
+            return None
+        if self.world > 1:
+            self.d_res.copy_(self.h_res, non_blocking=True)
+            dist.gather(self.d_res, self.d_gather if is_root else None, dst=self.root, group=self.group)
+        if not is_root:
+            return ()
+        out = []
+        per_rank = [self.d_gather[r].cpu().numpy() if self.world > 1 else self.h_res.numpy() for r in range(self.world)]
+        offs = [[0] for _ in range(self.world)]
+        for r in range(self.world):
+            for it in shares[r]:
+                offs[r].append(offs[r][-1] + len(it[2]))
+        for (r, k) in where:
+            a, b = offs[r][k], offs[r][k + 1]
+            out.append((per_rank[r][8 * a: 8 * b].view(np.uint64).copy(), per_rank[r][8 * self.cap_r + a: 8 * self.cap_r + b].copy()))
+        return out
+
+    def upsert_arrays(self, scene_id: int, **arrays):
+        """Collective: arrays as for abi.make_tracks (ids, boxes, epochs, kf_mean, kf_cov, feats, feat_present); given on the root,
+        None elsewhere."""
+        from . import abi
+
+        obj = [arrays if self.rank == self.root else None]
+        if self.world > 1:
+            self.dist.broadcast_object_list(obj, src=self.root, group=self.group)
+        if owner(scene_id, self.world) == self.rank:
+            self.eng.upsert(scene_id, abi.make_tracks(**obj[0]))
+
+    def serve_forever(self):
+        assert self.rank != self.root
+        while self.associate(None) is not None:
+            pass
+
+    def shutdown(self):
+        assert self.rank == self.root
+        self.associate(None, shutdown=True)

@@ -30,6 +30,11 @@ sa_constraints make_cons(const sa_config* cfg) {
   }
   return c;
 }
+template <int G>
+void coop_solve_all(const sa_coop_ws& w, const std::vector<std::vector<uint32_t>>& comps) {
+  for (const auto& roots : comps)
+    if (!roots.empty()) sa_assign_component_coop<G>(w, roots.data(), (uint32_t)roots.size());
+}
 }  // namespace
 
 extern "C" {
@@ -152,6 +157,102 @@ int emu_assign(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, co
   }
   for (uint32_t t = 0; t < T; ++t)
     if (cmatch[t] < 0 && v[t] != 0) return -6;  // free columns keep their initial dual
+  if (total_gain) *total_gain = tot;
+  return 0;
+}
+
+// The one-workgroup tail with the group-cooperative solver, as k_assign_small sequences it: usable edges (rows the visual vote
+// decided take no part; edges to excluded columns are dropped while packing, or — hbm_lists — stay in the lists and are skipped
+// through w.excluded), union-find, duals u = -(heaviest usable gain), GREEDY START (every row bids for the column of its heaviest
+// usable edge, lowest column on ties; a column goes to the lowest row that bids for it), the rows left unmatched become the search
+// roots of their component (ascending), and sa_assign_component_coop<G> runs once per component that has any.
+int emu_assign_coop(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip, const uint8_t* col_skip,
+                    int G, int hbm_lists, int32_t* rmatch_out, int64_t* total_gain) {
+  std::vector<uint32_t> parent(N + T), e_cnt(N, 0), e_off(N, 0);
+  std::vector<uint32_t> e_col;
+  std::vector<int64_t> e_gain;
+  std::vector<int64_t> u(N, 0), v(T, 0), dist(T, 0);
+  std::vector<int32_t> rmatch(N, -1), cmatch(T, -1), pred(T, 0), bcol(N, -1);
+  std::vector<uint32_t> cstamp(T, 0), cscan(T, 0), clist(T ? T : 1, 0), cwin(T, SA_NONE);
+  for (uint32_t i = 0; i < N + T; ++i) parent[i] = i;
+  uint64_t lcg = 0x2545f4914f6cdd1dull;
+  for (uint32_t q = 0; q < N; ++q) {
+    e_off[q] = (uint32_t)e_col.size();
+    if (row_skip && row_skip[q]) continue;
+    int64_t maxg = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      float wv = pos[(size_t)q * T + t];
+      if (!(wv == wv)) continue;
+      int64_t gain = sa_quantise(wv) - threshold_q;
+      if (gain <= 0) continue;
+      const bool excl = col_skip && col_skip[t];
+      if (excl && !hbm_lists) continue;       // dropped while packing the LDS pool
+      e_col.push_back(t);
+      e_gain.push_back(gain);
+      if (excl) continue;                      // stays in the list, takes no part
+      if (gain > maxg || (gain == maxg && (bcol[q] < 0 || (int32_t)t < bcol[q]))) { maxg = gain; bcol[q] = (int32_t)t; }
+      sa_uf_union(parent.data(), q, N + t);
+    }
+    const uint32_t cnt = (uint32_t)e_col.size() - e_off[q];
+    for (uint32_t a = cnt; a > 1; --a) {  // arbitrary append order
+      lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      uint32_t b = (uint32_t)((lcg >> 33) % a);
+      std::swap(e_col[e_off[q] + a - 1], e_col[e_off[q] + b]);
+      std::swap(e_gain[e_off[q] + a - 1], e_gain[e_off[q] + b]);
+    }
+    e_cnt[q] = cnt;
+    u[q] = -maxg;
+  }
+  // greedy start
+  for (uint32_t q = 0; q < N; ++q)
+    if (bcol[q] >= 0 && q < cwin[bcol[q]]) cwin[bcol[q]] = q;
+  std::vector<std::vector<uint32_t>> comps(N);
+  for (uint32_t q = 0; q < N; ++q) {
+    if (bcol[q] < 0) continue;
+    if (cwin[bcol[q]] == q) { rmatch[q] = bcol[q]; cmatch[bcol[q]] = (int32_t)q; }
+    else comps[sa_uf_find(parent.data(), q)].push_back(q);  // ascending: q runs upwards
+  }
+  sa_coop_ws w;
+  w.e_cnt = e_cnt.data(); w.e_col = e_col.data(); w.e_gain = e_gain.data(); w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0;
+  w.e_off = e_off.data();
+  w.excluded = hbm_lists ? col_skip : nullptr;
+  w.u = u.data(); w.v = v.data(); w.rmatch = rmatch.data(); w.cmatch = cmatch.data(); w.dist = dist.data(); w.pred = pred.data();
+  w.cstamp = cstamp.data(); w.cscan = cscan.data(); w.clist = clist.data();  // one search at a time here: the whole array is its segment
+  switch (G) {
+    case 4: coop_solve_all<4>(w, comps); break;
+    case 16: coop_solve_all<16>(w, comps); break;
+    case 64: coop_solve_all<64>(w, comps); break;
+    default: return -20;
+  }
+  int64_t tot = 0;
+  for (uint32_t q = 0; q < N; ++q) {
+    rmatch_out[q] = rmatch[q];
+    if (rmatch[q] >= 0) {
+      if (row_skip && row_skip[q]) return -7;
+      if (col_skip && col_skip[rmatch[q]]) return -8;
+      bool found = false;
+      for (uint32_t e = 0; e < e_cnt[q]; ++e)
+        if ((int32_t)e_col[e_off[q] + e] == rmatch[q]) { tot += e_gain[e_off[q] + e]; found = true; }
+      if (!found) return -9;
+      if (cmatch[rmatch[q]] != (int32_t)q) return -1;
+    }
+  }
+  for (uint32_t q = 0; q < N; ++q) {  // dual feasibility + complementary slackness over the usable graph = proof of optimality
+    if (row_skip && row_skip[q]) continue;
+    if (u[q] > 0) return -2;
+    bool usable = false;
+    for (uint32_t e = 0; e < e_cnt[q]; ++e) {
+      uint32_t t = e_col[e_off[q] + e];
+      if (col_skip && col_skip[t]) continue;
+      usable = true;
+      int64_t rc = -e_gain[e_off[q] + e] - u[q] - v[t];
+      if (rc < 0) return -3;
+      if (rmatch[q] == (int32_t)t && rc != 0) return -4;
+    }
+    if (rmatch[q] < 0 && usable && u[q] != 0) return -5;
+  }
+  for (uint32_t t = 0; t < T; ++t)
+    if (cmatch[t] < 0 && v[t] != 0) return -6;
   if (total_gain) *total_gain = tot;
   return 0;
 }

@@ -36,6 +36,9 @@ def emu():
     L.emu_key_f32.argtypes = [C.c_uint32]
     L.emu_assign.restype = C.c_int
     L.emu_assign.argtypes = [C.c_uint32, C.c_uint32, fp, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.emu_assign_coop.restype = C.c_int
+    L.emu_assign_coop.argtypes = [C.c_uint32, C.c_uint32, fp, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.emu_clip_is_empty.restype = C.c_int
     L.emu_clip_is_empty.argtypes = [B, B]
     return L
@@ -263,3 +266,92 @@ def test_clip_prefilter_only_skips_empty_intersections(oriented):
                 wrong += OL.or_intersection(pa, pb) != 0.0
     assert wrong == 0
     assert skipped > 0.3 * near, (skipped, near)
+
+
+# ---- the group-cooperative solver (sa_assign_component_coop: greedy start + lane-parallel shortest augmenting paths) ----------
+def run_emu_assign_coop(pos, thr_q, G, row_skip=None, col_skip=None, hbm_lists=0):
+    N, T = pos.shape
+    pos = np.ascontiguousarray(pos, np.float32)
+    rm = np.zeros(max(N, 1), np.int32)
+    tot = C.c_int64()
+    rs = None if row_skip is None else row_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    cs = None if col_skip is None else col_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    rc = E.emu_assign_coop(N, T, O.fptr(pos), thr_q, rs, cs, G, hbm_lists, rm.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tot))
+    assert rc == 0, f"optimality certificate failed: {rc}"
+    return rm[:N], tot.value
+
+
+@pytest.mark.parametrize("G", [4, 16, 64])
+@pytest.mark.parametrize("density", [0.02, 0.1, 0.5, 1.0])
+def test_cooperative_assignment_reaches_dense_optimum(density, G):
+    rng = np.random.default_rng(int(density * 100) + G)
+    thr_q = 300000
+    for trial in range(25):
+        N = int(rng.integers(1, 70))
+        T = int(rng.integers(1, 70))
+        pos = rng.uniform(0.05, 1.0, (N, T)).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > density] = np.nan
+        rm, gain = run_emu_assign_coop(pos, thr_q, G)
+        total, ref, w = dense_reference(pos, thr_q)
+        assert gain + N * thr_q == total
+        np.testing.assert_array_equal(rm, ref)  # unique optimum (random f32 weights)
+        rm_serial, gain_serial = run_emu_assign(pos, thr_q)
+        np.testing.assert_array_equal(rm, rm_serial)
+
+
+@pytest.mark.parametrize("G", [16, 64])
+def test_cooperative_assignment_one_giant_component(G):
+    """All boxes on one pile under a low threshold: one component of 200 rows, every row with ~100 usable edges, most bids of the
+    greedy start colliding — the case the one-thread-per-component solver cannot afford."""
+    rng = np.random.default_rng(7 + G)
+    n = t = 200
+    pos = rng.uniform(0.06, 0.9, (n, t)).astype(np.float32)
+    pos[rng.uniform(size=(n, t)) > 0.5] = np.nan
+    rm, gain = run_emu_assign_coop(pos, 50000, G)
+    total, ref, _ = dense_reference(pos, 50000)
+    assert gain + n * 50000 == total
+    np.testing.assert_array_equal(rm, ref)
+
+
+@pytest.mark.parametrize("hbm_lists", [0, 1])
+@pytest.mark.parametrize("G", [4, 64])
+def test_cooperative_assignment_chains_exclusions_and_ties(G, hbm_lists):
+    n = 60
+    pos = np.full((n, n), np.nan, np.float32)
+    rng = np.random.default_rng(9)
+    for i in range(n):
+        pos[i, i] = 0.5 + 0.001 * i
+        if i + 1 < n:
+            pos[i + 1, i] = 0.9 - 0.002 * i
+    rm, gain = run_emu_assign_coop(pos, 300000, G, hbm_lists=hbm_lists)
+    total, ref, _ = dense_reference(pos, 300000)
+    assert gain + n * 300000 == total
+    np.testing.assert_array_equal(rm, ref)
+    row_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    col_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    rm2, gain2 = run_emu_assign_coop(pos, 300000, G, row_skip, col_skip, hbm_lists=hbm_lists)
+    p2 = pos.copy()
+    p2[row_skip.astype(bool), :] = np.nan
+    p2[:, col_skip.astype(bool)] = np.nan
+    total2, ref2, _ = dense_reference(p2, 300000)
+    assert gain2 + n * 300000 == total2
+    np.testing.assert_array_equal(rm2, ref2)
+    # integer-valued weights -> many ties: the total still agrees, every column is used once (indices are unpinned on ties)
+    for _ in range(30):
+        N, T = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        pt = (rng.integers(1, 6, (N, T)) / 5.0).astype(np.float32)
+        pt[rng.uniform(size=(N, T)) > 0.4] = np.nan
+        rm3, gain3 = run_emu_assign_coop(pt, 300000, G, hbm_lists=hbm_lists)
+        total3, _, _ = dense_reference(pt, 300000)
+        assert gain3 + N * 300000 == total3
+        used = [c for c in rm3 if c >= 0]
+        assert len(used) == len(set(used))
+    # Mahalanobis-scale weights: i64 end to end
+    for _ in range(10):
+        N, T = int(rng.integers(2, 30)), int(rng.integers(2, 30))
+        pm = (rng.uniform(88.0, 100.0, (N, T)) / rng.uniform(0.05, 1.0, (N, 1))).astype(np.float32)
+        pm[rng.uniform(size=(N, T)) > 0.3] = np.nan
+        rm4, gain4 = run_emu_assign_coop(pm, 1000000, G, hbm_lists=hbm_lists)
+        total4, ref4, _ = dense_reference(pm, 1000000)
+        assert gain4 + N * 1000000 == total4
+        np.testing.assert_array_equal(rm4, ref4)

@@ -888,6 +888,61 @@ def test_full_size_properties_c2_euclidean():
         eng.close()
 
 
+# ---- the positional vote on graphs that do NOT fall apart into tiny components ---------------------------------------------
+def test_one_giant_component_against_the_oracle():
+    """640 boxes piled on each other under IoU(0.05): ONE connected component, ~100 k usable edges (they stay in the HBM lists: the
+    LDS pool holds 3072), most greedy bids colliding.  kuhn_munkres does not care about density (sort/voting.rs:86); the
+    group-cooperative solver must reach its optimum — equal total always, identical ids on this seeded (tie-free) frame."""
+    for sigma, floor in ((2.0, 636), (10.0, 600), (25.0, 560)):  # 13 / 218 / 255 rows lose their greedy bid
+        sc = synth.sort_scene(np.random.default_rng(64), 640, 640, canvas=(150.0, 150.0), pos_sigma=sigma)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.05, max_idle_epochs=5)
+        ids, ref = check_sort(cfg, sc)
+        assert (ids != 0).sum() > floor
+        assert (~np.isnan(ref["positional"])).sum() > 50_000
+
+
+@pytest.mark.parametrize("sigma", [2.0, 12.0])
+@pytest.mark.parametrize("n,t,canvas", [(1000, 1000, (1920.0, 1080.0)), (1024, 1024, (700.0, 500.0)), (300, 900, (500.0, 400.0))])
+def test_crowds_against_the_oracle(n, t, canvas, sigma):
+    """Plain SORT on crowded frames (the C2 canvas without features, and denser): components of tens to hundreds of rows, pool and
+    HBM-list edge storage; with 12 px of jitter dozens to hundreds of rows lose their greedy bid and need real augmenting paths."""
+    sc = synth.sort_scene(np.random.default_rng(n + t), t, n, canvas=canvas, pos_sigma=sigma)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3 if canvas[0] > 1000 else 0.15, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    assert (ids != 0).sum() > 0.4 * min(n, t)
+
+
+@pytest.mark.parametrize("visual", ["cosine", "euclidean"])
+def test_dense_positional_stage_behind_a_visual_vote(visual):
+    """VisualSORT on a pile: 35 % of the detections are new or below the quality gate, so the positional stage inherits hundreds of
+    rows whose edges (IoU threshold 0.05, everything overlaps) overflow the LDS pool and run to columns the visual vote has
+    excluded — the HBM-list variant of the cooperative solver with the exclusion table."""
+    rng = np.random.default_rng(66)
+    n = t = 600
+    d = 64
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(300.0, 250.0), new_fraction=0.25)
+    sc["det_quality"][rng.uniform(size=n) < 0.15] = 0.05
+    cfg = abi.make_config(positional="iou", positional_threshold=0.05, visual=visual, visual_threshold=0.2 if visual == "cosine" else 0.5,
+                          feature_len=d, max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.3,
+                          positional_min_confidence=0.1, max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc, tol_abs=1e-5 if visual == "cosine" else 0.0, tol_rel=0.0 if visual == "cosine" else 1e-5)
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50 and (votes == abi.SA_VOTE_VISUAL).sum() > 200
+
+
+def test_quarter_wave_groups_match_oracle_too():
+    """SA_COOP_G=16: the cooperative solver with 16-lane groups (four components per wavefront side by side) instead of whole
+    wavefronts.  Same tests, same oracle."""
+    import os
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "test_one_giant_component or test_crowds_against or test_dense_positional_stage or test_sort_iou_parity or "
+                        "test_sort_maha_parity or test_batched_scenes or test_visual_cosine_parity"],
+                       env=dict(os.environ, SA_COOP_G="16"), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---- the headline configurations at FULL size against the oracle -------------------------------------------------------
 # The oracle's distance stage runs on host threads partitioned like the reference's TrackStore (or_associate_sharded: track id %
 # shards, one vote after the shards) — cell for cell the single-thread oracle, in a fraction of its time.

@@ -164,3 +164,112 @@ def test_wire_roundtrip_and_partition():
     assert sharding.global_id(1, 0, 1) == 1 and sharding.global_id(5, 3, 8) == 36 and sharding.global_id(0, 3, 8) == 0
     # empty request encodes and decodes
     assert sharding.decode_request(sharding.encode_request({}, 0)).scenes == {}
+
+
+# ---- array-level sharding (ShardedAssociator): the association itself, scattered as arrays ------------------------------------
+class OracleEngine:
+    """Engine-shaped shim over the oracle for the CPU run (the sharding layer computes nothing; on a GPU box the same class wraps
+    similari_amd.engine.Engine — see tests/test_gpu_cluster.py)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.tracks = {}
+
+    def upsert(self, scene, tracks):
+        self.tracks[scene] = tracks
+
+    def associate_batch(self, req, res, n=None):
+        import ctypes as C
+
+        import oracle_lib as O
+
+        for i in range(len(req) if n is None else n):
+            r = O.associate(self.cfg, self.tracks[req[i].scene_id], req[i].epoch, req[i].detections, want_matrices=False)
+            m = req[i].detections.n
+            np.ctypeslib.as_array(res[i].out_track_id, (m,))[:] = r["track_id"] if m else []
+            np.ctypeslib.as_array(res[i].out_voting_type, (m,))[:] = r["voting_type"] if m else []
+
+
+def assoc_scenes(seed):
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    from similari_amd import abi, synth
+
+    rng = np.random.default_rng(seed)
+    d = 24
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.3, feature_len=d, max_observations=2,
+                          visual_min_votes=1, visual_minimal_track_length=1, max_idle_epochs=5)
+    scenes = {}
+    for s, (n, t) in zip((2, 5, 8, 9, 12), ((30, 40), (0, 10), (25, 25), (41, 33), (17, 60))):
+        scenes[s] = synth.visual_scene(rng, t, n, d, 2, canvas=(700.0, 500.0), new_fraction=0.15)
+    return cfg, scenes
+
+
+def assoc_worker(rank: int, port: int, outfile: str):
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import torch.distributed as dist
+
+    from similari_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        cfg, scenes = assoc_scenes(9)
+        sh = sharding.ShardedAssociator(OracleEngine(cfg), capacity_bytes=1 << 16, capacity_rows=256)
+        for s, sc in scenes.items():  # collective: every rank takes part, the owner keeps the rows
+            sh.upsert_arrays(s, **(dict(ids=sc["track_ids"], boxes=sc["track_boxes"], epochs=sc["track_epochs"], feats=sc["track_feats"],
+                                        feat_present=sc["track_present"]) if rank == 0 else {}))
+        if rank != 0:
+            sh.serve_forever()
+            return
+        out = {}
+        for f in range(3):  # the same scenes in another request order every time, one scene absent from one batch
+            order = [s for s in (list(scenes) if f != 1 else list(scenes)[::-1]) if not (f == 2 and s == 8)]
+            items = [(s, 1, scenes[s]["det_boxes"], scenes[s]["det_feats"], scenes[s]["det_quality"]) for s in order]
+            res = sh.associate(items)
+            assert len(res) == len(items)
+            for s, (ids, votes) in zip(order, res):
+                out[f"f{f}_s{s}_ids"], out[f"f{f}_s{s}_votes"] = ids, votes
+        sh.shutdown()
+        np.savez(outfile, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_array_sharding_matches_the_oracle_per_scene(tmp_path):
+    import torch.multiprocessing as mp
+
+    import oracle_lib as O
+    from similari_amd import abi
+
+    outfile = str(tmp_path / "assoc.npz")
+    mp.spawn(assoc_worker, args=(free_port(), outfile), nprocs=WORLD, join=True)
+    got = dict(np.load(outfile))
+    cfg, scenes = assoc_scenes(9)
+    assert len(got) == 2 * (5 + 5 + 4)
+    for s, sc in scenes.items():
+        tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ref = O.associate(cfg, tr, 1, det, want_matrices=False)
+        for f in range(3):
+            if f == 2 and s == 8:
+                continue
+            np.testing.assert_array_equal(got[f"f{f}_s{s}_ids"], ref["track_id"], err_msg=f"frame {f} scene {s}")
+            np.testing.assert_array_equal(got[f"f{f}_s{s}_votes"], ref["voting_type"])
+
+
+def test_share_pack_roundtrip():
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    from similari_amd import sharding
+
+    cfg, scenes = assoc_scenes(3)
+    items = [(s, 7 + s, sc["det_boxes"], sc["det_feats"] if s != 9 else None, sc["det_quality"] if s != 12 else None) for s, sc in scenes.items()]
+    back, flags = sharding.unpack_share(sharding.pack_share(items, 24))
+    assert flags == 0 and len(back) == len(items)
+    for a, b in zip(items, back):
+        assert a[0] == b[0] and a[1] == b[1]
+        np.testing.assert_array_equal(a[2], b[2])
+        for x, y in ((a[3], b[3]), (a[4], b[4])):
+            assert (x is None) == (y is None)
+            if x is not None:
+                np.testing.assert_array_equal(x, y)
+    assert sharding.unpack_share(sharding.pack_share([], 0)) == ([], 0)
