@@ -738,9 +738,12 @@ SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* ro
     int64_t best_term = -w.u[root];  // reduced cost of the root's own self column
     int32_t term_row = (int32_t)root;
     int32_t end_col = -1;
-    int64_t delta;
+    int64_t delta = best_term;
     sa_coop_relax<G>(w, root, 0, stamp, &len);
-    for (;;) {
+    // (every pass of the loop scans one more column of the component, every step of the augmentation walks one more tree row: the
+    // caps below can only bite if the state were corrupted — then the kernel ends with a wrong answer the tests catch instead of
+    // spinning on a GPU box)
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
       // nearest labelled, unscanned column (ties: lowest column index): one strided pass + a lane reduction
       int64_t pd[SA_COOP_SLOTS(G)];
       int32_t pj[SA_COOP_SLOTS(G)];
@@ -792,12 +795,12 @@ SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* ro
       sa_coop_sync<G>();
       SA_COOP_FOR(G, l) { if (l == 0) w.rmatch[term_row] = -1; }
     }
-    for (;;) {
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
       const int32_t i = w.pred[j];
       const int32_t prev = w.rmatch[i];
       sa_coop_sync<G>();
       SA_COOP_FOR(G, l) { if (l == 0) { w.rmatch[i] = j; w.cmatch[j] = i; } }
-      if (i == (int32_t)root) break;
+      if (i == (int32_t)root || prev < 0) break;
       j = prev;
     }
     sa_coop_sync<G>();
