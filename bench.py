@@ -340,15 +340,24 @@ def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
     tk = [C.c_uint64(), C.c_uint64()]
     ns = len(items)
 
+    host = [0.0, 0.0]  # seconds of host time inside sa_pipe_submit / sa_pipe_wait
+
     def loop(k):
+        pc = time.perf_counter
         rc = lib.sa_pipe_submit(h, ns, sets[0][0], C.byref(tk[0]))
         for i in range(1, k):
+            a = pc()
             rc |= lib.sa_pipe_submit(h, ns, sets[i & 1][0], C.byref(tk[i & 1]))
+            b = pc()
             rc |= lib.sa_pipe_wait(h, tk[(i - 1) & 1], sets[(i - 1) & 1][1])
+            c = pc()
+            host[0] += b - a
+            host[1] += c - b
         rc |= lib.sa_pipe_wait(h, tk[(k - 1) & 1], sets[(k - 1) & 1][1])
         assert rc == 0, eng.lib.sa_last_error(h)
 
     loop(10)
+    host[0] = host[1] = 0.0
     t0 = time.perf_counter()
     loop(iters)
     dt = time.perf_counter() - t0
@@ -368,6 +377,7 @@ def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
     return {"pairs_per_s": cells * iters / dt, "ms_per_step": 1e3 * dt / iters, "steps": iters,
             "h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": 9 * sum(len(s["det_boxes"]) for s in scenes),
             "synchronous_ms_per_step": 1e3 * dts,
+            "host_us_in_submit": 1e6 * host[0] / max(1, iters - 1), "host_us_in_wait": 1e6 * host[1] / max(1, iters - 1),
             "note": "sa_pipe_submit / sa_pipe_wait, two request sets in flight (H2D of frame n+1 beside the kernels of frame n), features in a "
                     "sa_host_alloc block, results copied out; synchronous_ms_per_step = sa_associate_batch on the same buffers"}, ids
 

@@ -115,6 +115,8 @@ struct SceneDev {
   uint64_t SA_G* out_track_id;
   uint8_t SA_G* out_vote;
   int32_t SA_G* win_col;     // [N] winning track as a column of the table, -1 = none: what the device-side upkeep consumes
+  uint32_t SA_G* stats;      // [4] device words the first phase raises: [0] = 1 when the frame was ill-conditioned for the euclidean expansion
+  uint32_t SA_G* out_stats;  // [4] the same, moved next to the results (mapped host memory) and re-armed by the assignment tail
   int64_t SA_G* quant;  // optional N x T tap
 };
 #define SCN_HAS_FEATS 1u
@@ -142,6 +144,8 @@ struct SaParams {
   sa_constraints cons;
   uint32_t vote_words;          // per launch: the contraction's BestFit epilogue reduces into row_best / col_best (64-bit atomic minima)
                                 // instead of writing per-tile partials; the one-workgroup tail reads and re-arms them
+  uint32_t eu_mfma;             // per launch: euclidean distances through the matrix-core contraction (expansion + flagged direct recompute)
+  float eu_rho;                 // a cell with d^2 < eu_rho (|a|^2 + |b|^2) is recomputed directly
 };
 
 // Profile mode (SA_FLAG_PROFILE): while sa_prof_start is set, the per-frame launches go through hipExtLaunchKernelGGL,
@@ -177,6 +181,13 @@ hipError_t sa_launch_prep_tracks(const PrepTrackArgs& a, const SaParams& p, hipS
 hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                   const uint32_t* slots, const uint8_t* present, float* dst, float* norms,
                                   uint8_t* dst_present, uint32_t* fcount, hipStream_t st);
+// one launch of the ingest kernel moves up to SA_COPY_SEGS pinned-host -> HBM segments (device-visible source addresses)
+#define SA_COPY_SEGS 12
+struct SaCopySegs {
+  struct Seg { const void* src; void* dst; size_t bytes; } s[SA_COPY_SEGS];
+  uint32_t n;
+};
+hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st);
 hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* index, uint32_t rows, uint32_t row_bytes,
                                  hipStream_t st);
 
@@ -192,7 +203,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p, hipStream_t st, bool partials);
-void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
+void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
 // stage 1 label + push, 3 solve + results; stage 5 = the whole tail in ONE workgroup per

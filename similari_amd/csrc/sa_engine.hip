@@ -55,6 +55,7 @@ struct Slot {  // one scene of a request set
   // the arena is on the device, the device addresses
   size_t o_raw = 0, o_q = 0, o_own = 0, o_fp = 0, o_feat = 0;
   const float* feats_inplace = nullptr;  // the caller's features lie in a pinned block (sa_host_alloc): DMA'd from there into feat_raw
+  const float* feats_inplace_dev = nullptr;  // the same rows through the block's device mapping (the ingest kernel reads them)
   void *p_raw = nullptr, *p_quality = nullptr, *p_own = nullptr, *p_fpresent = nullptr, *p_feat_raw = nullptr;
   DevBuf feat_raw;                        // destination of an in-place feature upload
   // derived candidates
@@ -64,6 +65,7 @@ struct Slot {  // one scene of a request set
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
+  DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   HostBuf h_apply, h_pred;
   void* d_pred = nullptr;
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
@@ -82,12 +84,15 @@ struct Bank {
   std::vector<Slot*> slots;  // pool; the first n_slots are live
   uint32_t n_slots = 0;
   HostBuf h_arena;
+  void* h_arena_dev = nullptr;  // the pinned arena as the device sees it
   DevBuf d_arena;
   size_t used = 0;           // bytes of scene inputs appended to the host arena so far
   size_t desc_off = 0;       // where the descriptor array went (set by bank_upload)
   bool uploaded = false;     // the scene inputs are on the device (a replayed frame uploads nothing)
   std::vector<uint8_t> desc_last;
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for this set (sa_visual_tile)
+  bool eu_mfma = false;                 // this set's euclidean distances go through the matrix-core contraction
+  bool partials = false;                // this set's contraction votes itself (no weight matrix): cosine or matrix-core euclidean, bank depth 1
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -121,6 +126,9 @@ struct sa_engine {
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
+  bool eu_mfma_ok = false;              // euclidean engines: the expansion is usable at this feature length (eu_rho < 1/3)
+  float eu_rho = 0.f;
+  uint32_t eu_valu_left = 0;            // frames still to run on the vector-pipe kernel after an ill-conditioned frame was reported
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
@@ -316,6 +324,7 @@ int arena_reserve(sa_engine* e, Bank* b, size_t bytes) {
   }
   b->h_arena.p = np;
   b->h_arena.cap = ncap;
+  if (hipHostGetDevicePointer(&b->h_arena_dev, np, 0) != hipSuccess) { (void)hipGetLastError(); b->h_arena_dev = nullptr; }
   return SA_OK;
 }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
@@ -371,8 +380,13 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->rnext, n * 4));
   TRY(dev_ensure(e, s->win_col, n * 4));
   {
+    void* before = s->stats.p;
+    TRY(dev_ensure(e, s->stats, 256));
+    if (s->stats.p != before) s->needs_init = true;
+  }
+  {
     void* before = s->h_out.p;
-    TRY(host_ensure(e, s->h_out, n * 9));
+    TRY(host_ensure(e, s->h_out, n * 9 + 32));  // ids[n] | votes[n] | (8-byte aligned) stats[4]
     if (s->h_out.p != before || !s->d_out) HIPCHK(e, hipHostGetDevicePointer(&s->d_out, s->h_out.p, 0));
   }
   return SA_OK;
@@ -388,7 +402,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
              (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
-  if (e->bf_partials) { d->CT = (s->T + bk->tile_bn - 1) / bk->tile_bn; d->RT = (s->N + bk->tile_bm - 1) / bk->tile_bm; }  // the contraction's own tile grid
+  if (bk->partials) { d->CT = (s->T + bk->tile_bn - 1) / bk->tile_bn; d->RT = (s->N + bk->tile_bm - 1) / bk->tile_bm; }  // the contraction's own tile grid
   d->nkeys = e->visual ? ((s->N + bk->tile_bm - 1) / bk->tile_bm) * ((s->T * e->K + bk->tile_bn - 1) / bk->tile_bn) : 0;
   d->epoch = s->epoch;
   d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
@@ -413,6 +427,8 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->out_track_id = (decltype(d->out_track_id))(s->d_out); d->out_vote = (decltype(d->out_vote))((uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8);
   d->quant = (decltype(d->quant))(s->quant.p);
   d->win_col = (decltype(d->win_col))(s->win_col.p);
+  d->stats = (decltype(d->stats))(s->stats.p);
+  d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
 }
 
 // Brings a bank's request set onto the device through stream `st`: the scene inputs appended to the staging arena (once per
@@ -446,12 +462,34 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
   b->desc_off = desc_off;
   b->desc_last.swap(build);
   if (!b->uploaded) {
-    HIPCHK(e, hipMemcpyAsync(dbase, h, total, hipMemcpyHostToDevice, st));
+    // SA_INGEST=sdma: hipMemcpyAsync per segment (one SDMA engine: 2 MB in 57 us); default: the ingest kernel (40 us), which needs
+    // the device mapping of every source and 16-byte alignment
+    static const bool sdma = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma");
+    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 48u;
+    SaCopySegs segs;
+    segs.n = 0;
+    auto flush = [&]() -> int {
+      if (segs.n) HIPCHK(e, sa_launch_ingest(segs, blocks, st));
+      segs.n = 0;
+      return SA_OK;
+    };
+    auto move = [&](const void* src_host, const void* src_dev, void* dst, size_t bytes) -> int {
+      if (!bytes) return SA_OK;
+      if (sdma || !src_dev || (((uintptr_t)src_dev | (uintptr_t)dst) & 15u)) {
+        HIPCHK(e, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, st));
+        return SA_OK;
+      }
+      if (segs.n == SA_COPY_SEGS) TRY(flush());
+      segs.s[segs.n].src = src_dev; segs.s[segs.n].dst = dst; segs.s[segs.n].bytes = bytes;
+      ++segs.n;
+      return SA_OK;
+    };
+    TRY(move(h, b->h_arena_dev, dbase, total));
     for (uint32_t i = 0; i < ns; ++i) {
       Slot* s = b->slots[i];
-      if (s->feats_inplace && s->N)
-        HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, s->feats_inplace, (size_t)s->N * e->D * 4, hipMemcpyHostToDevice, st));
+      if (s->feats_inplace && s->N) TRY(move(s->feats_inplace, s->feats_inplace_dev, s->feat_raw.p, (size_t)s->N * e->D * 4));
     }
+    TRY(flush());
     b->uploaded = true;
   } else {
     HIPCHK(e, hipMemcpyAsync(dbase + desc_off, h + desc_off, dbytes, hipMemcpyHostToDevice, st));
@@ -472,9 +510,12 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
-  const bool words = e->visual && (e->bf_partials || e->bf_words_euclid) && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
+  const bool partials = b->partials;
+  const bool words = e->visual && (partials || e->bf_words_euclid) && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
   SaParams P = e->P;
   P.vote_words = words ? 1u : 0u;
+  P.eu_mfma = b->eu_mfma ? 1u : 0u;
+  P.eu_rho = e->eu_rho;
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
   // launch; otherwise positional tiles + preparation blocks, then the contraction
   bool fused = false;
@@ -482,17 +523,17 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     ProfScope ps(e, KID_FRAME_VISUAL);
     bool all_feats = true;
     for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
-    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, e->bf_partials) : hipErrorNotSupported;
+    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials) : hipErrorNotSupported;
     if (fe == hipSuccess) fused = true;
     else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
     else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
   if (e->visual) {
-    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, e->bf_partials, e->f16_split)); }
-    if (!e->bf_partials && !words) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
+    if (!partials && !words) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
   }
-  if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, e->bf_partials ? 2 : 1)); }
+  if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
     HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5));
@@ -516,7 +557,16 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out) 
     maxT = s->T > maxT ? s->T : maxT;
   }
   for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, b->slots[i], b->slots[i]->N, b->slots[i]->T));
-  if (e->visual) sa_visual_tile(e->cfg.visual_kind, maxN, maxT * e->K, ns, e->Dp, &b->tile_bm, &b->tile_bn);
+  // Euclidean engines: the matrix-core path unless a recent frame reported itself ill-conditioned for the expansion (most of its
+  // cells needed the direct recompute: features far from the origin compared with their spread) — then the vector-pipe kernel for
+  // the next 256 frames, and another try.
+  const bool euclid = e->cfg.visual_kind == SA_VIS_EUCLIDEAN;
+  static const bool eu_off = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "valu");   // measurements / tests: always the vector-pipe kernel
+  static const bool eu_force = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "mfma");  // ... always the contraction
+  b->eu_mfma = euclid && e->eu_mfma_ok && !eu_off && (e->eu_valu_left == 0 || eu_force);
+  if (euclid && e->eu_valu_left) --e->eu_valu_left;
+  b->partials = e->bf_partials || (b->eu_mfma && e->bf_words_euclid);
+  if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, &b->tile_bm, &b->tile_bn);
   *maxN_out = maxN;
   *maxT_out = maxT;
   return SA_OK;
@@ -534,6 +584,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT) {
     HIPCHK(e, sa_launch_slot_init((uint32_t*)s->e_cnt.p, (int64_t*)s->u.p, (uint32_t)(s->e_cnt.cap / 4 < s->u.cap / 8 ? s->e_cnt.cap / 4 : s->u.cap / 8),
                                   (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
     HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, 2 * SA_SMALL_N * 8, st));  // vote words: all ones = no group
+    HIPCHK(e, hipMemsetAsync(s->stats.p, 0, 256, st));
     s->needs_init = false;
   }
   if ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile) {
@@ -543,7 +594,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT) {
     uint32_t feats_mask = 0;
     for (uint32_t i = 0; i < ns; ++i) feats_mask = feats_mask * 31u + (b->slots[i]->has_feats ? 1u : 0u) + 7u;
     const uint64_t key[6] = {((uint64_t)ns << 32) | 1u, ((uint64_t)maxN << 32) | maxT, ((uint64_t)b->tile_bm << 32) | b->tile_bn,
-                             (uint64_t)(uintptr_t)ds, feats_mask, 0};
+                             (uint64_t)(uintptr_t)ds, feats_mask, (uint64_t)(b->eu_mfma ? 1u : 0u) | (b->partials ? 2u : 0u)};
     if (!b->graph_exec || std::memcmp(key, b->graph_key, sizeof key) != 0) {
       if (b->graph_exec) { hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
       if (b->graph) { hipGraphDestroy(b->graph); b->graph = nullptr; }
@@ -672,6 +723,10 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   }
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
+  // matrix-core euclidean: a cell is trusted to 1e-5 relative when d^2 >= rho (|a|^2 + |b|^2); rho = twice the largest error of the
+  // f32 expansion observed (3.8e-8 sqrt(D) of |a|^2 + |b|^2, scripts/euclid_error_model.py) over the 2e-5 the gate leaves for d^2
+  e->eu_rho = 5e-3f * std::sqrt((float)(e->Dp ? e->Dp : 32u));
+  e->eu_mfma_ok = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->eu_rho < 0.3334f;
   e->profile = (cfg->flags & SA_FLAG_PROFILE) != 0;
   e->f16_split = (cfg->flags & SA_FLAG_F16_SPLIT) != 0 && cfg->visual_kind == SA_VIS_COSINE;
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
@@ -752,7 +807,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                         &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
-                        &s->bank_tmp})
+                        &s->bank_tmp, &s->stats})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_pred);
@@ -992,12 +1047,15 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
 
 // ---- pinned host blocks handed out to callers (sa_host_alloc): process-wide registry, looked up per staged frame ----
 static std::mutex g_pin_mu;
-static std::vector<std::pair<const char*, size_t>> g_pins;
+struct PinBlock { const char* host; size_t bytes; const char* dev; };
+static std::vector<PinBlock> g_pins;
 extern "C" void* sa_host_alloc(uint64_t bytes) {
   void* p = nullptr;
   if (!bytes || hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
   std::lock_guard<std::mutex> lk(g_pin_mu);
-  g_pins.emplace_back((const char*)p, (size_t)bytes);
+  g_pins.push_back({(const char*)p, (size_t)bytes, (const char*)d});
   return p;
 }
 extern "C" void sa_host_free(void* block) {
@@ -1005,15 +1063,19 @@ extern "C" void sa_host_free(void* block) {
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pins.size(); ++i)
-      if (g_pins[i].first == (const char*)block) { g_pins.erase(g_pins.begin() + i); break; }
+      if (g_pins[i].host == (const char*)block) { g_pins.erase(g_pins.begin() + i); break; }
   }
   (void)hipHostFree(block);
 }
-static bool in_pinned_block(const void* p, size_t bytes) {
+// is [p, p + bytes) inside a block from sa_host_alloc?  *dev = the same range as the device sees it (nullptr: not mapped)
+static bool in_pinned_block(const void* p, size_t bytes, const void** dev = nullptr) {
   std::lock_guard<std::mutex> lk(g_pin_mu);
   const char* q = (const char*)p;
   for (const auto& b : g_pins)
-    if (q >= b.first && q + bytes <= b.first + b.second) return true;
+    if (q >= b.host && q + bytes <= b.host + b.bytes) {
+      if (dev) *dev = b.dev ? b.dev + (q - b.host) : nullptr;
+      return true;
+    }
   return false;
 }
 
@@ -1027,6 +1089,11 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
       return fail(e, SA_ERR_STATE, "scene %llu is already part of this batch", (unsigned long long)scene_id);
   SceneTable* sc = get_scene(e, scene_id, true);
   Slot* s = get_slot(b, b->n_slots);
+  if (s->ran && s->h_out.p && e->cfg.visual_kind == SA_VIS_EUCLIDEAN) {
+    // what the slot's previous frame reported (the bank is idle: that frame has retired)
+    const uint32_t* st4 = (const uint32_t*)((const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
+    if (st4[0]) e->eu_valu_left = 256;
+  }
   s->scene = sc;
   s->epoch = epoch;
   s->N = N;
@@ -1039,13 +1106,17 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   const uint32_t D = e->D;
   const size_t fbytes = (size_t)N * D * 4;
   // the caller's block is pinned (sa_host_alloc): the DMA reads it in place, no staging copy
-  s->feats_inplace = (s->has_feats && !feat_rows && N && in_pinned_block(d->feats, fbytes)) ? d->feats : nullptr;
+  const void* feats_dev = nullptr;
+  s->feats_inplace = (s->has_feats && !feat_rows && N && in_pinned_block(d->feats, fbytes, &feats_dev)) ? d->feats : nullptr;
+  s->feats_inplace_dev = s->feats_inplace ? (const float*)feats_dev : nullptr;
   // every sub-array on a 256-byte boundary of the arena (16-byte loads of features and boxes, whole cache lines per scene)
   s->o_raw = align_up(b->used, 256);
   s->o_q = align_up(s->o_raw + (size_t)N * sizeof(BoxRaw), 256);
   s->o_own = align_up(s->o_q + (size_t)N * 4, 256);
   s->o_fp = align_up(s->o_own + (size_t)N * 4, 256);
-  s->o_feat = align_up(s->o_fp + N, 256);
+  // features on a boundary of their own (SA_FEAT_ALIGN, default 4 KB): the contraction streams them as 16-byte loads of Dp-float rows
+  static const size_t feat_align = getenv("SA_FEAT_ALIGN") ? (size_t)atol(getenv("SA_FEAT_ALIGN")) : 4096;
+  s->o_feat = align_up(s->o_fp + N, feat_align >= 256 ? feat_align : 256);
   const size_t end = s->o_feat + ((s->has_feats && !s->feats_inplace) ? fbytes : 0);
   TRY(arena_reserve(e, b, end + 256));
   uint8_t* h = (uint8_t*)b->h_arena.p;
@@ -1465,14 +1536,17 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
   size_t bytes = (size_t)s->N * s->T * e->K * 4;
   if (!bytes) return SA_OK;
-  if (e->bf_partials || e->bf_words_euclid) {
+  if (e->B->partials || e->bf_words_euclid) {
     // the product path never wrote the weight matrix (euclidean: not on frames that used the vote words — re-running is harmless otherwise): run the contraction once more, in matrix mode, on the slot's resident inputs
     SceneDev h;
     fill_scene_dev(e, e->B, s, &h);
     DevBuf tmp;
     TRY(dev_ensure(e, tmp, sizeof h));
     HIPCHK(e, hipMemcpy(tmp.p, &h, sizeof h, hipMemcpyHostToDevice));
-    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, e->P, e->stream, false, e->f16_split));
+    SaParams P = e->P;
+    P.eu_mfma = e->B->eu_mfma ? 1u : 0u;  // the kernel the slot's descriptor (tile grid) was laid out for
+    P.eu_rho = e->eu_rho;
+    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, P, e->stream, false, e->f16_split));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     hipFree(tmp.p);
   }

@@ -599,8 +599,14 @@ __device__ __forceinline__ uint32_t constraint_mask(const GemmCols& col, RowGeo 
   }
   return failed;
 }
+// EU: distance::euclidean (distance.rs:9-19) on the matrix cores.  sqrt(|a|^2 + |b|^2 - 2 a.b) cancels on near-identical vectors —
+// exactly the true matches — so a cell whose expansion is not trustworthy to 1e-5 relative, d^2 < rho (|a|^2 + |b|^2) with
+// rho = 5e-3 sqrt(Dp) (twice the largest error of the f32 expansion seen over 10^6 pairs, scripts/euclid_error_model.py), is FLAGGED
+// instead of evaluated: the tile recomputes it afterwards as the direct sum of (a - b)^2 (euclid_fixup).  In tracking frames that is
+// about one cell per candidate; everything else rides the contraction at the cosine kernel's speed.
+template <bool EU>
 __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float na, bool cons_failed, const GemmCols& col,
-                                             uint32_t* kmax) {
+                                             uint32_t* kmax, bool* flagged) {
   // Straight-line on purpose: with a short-circuit chain (usable? column ok? ...) the compiler sinks every operand load into the
   // branch that first needs it, and the row operands come from LDS — each cell then pays two or three LDS round trips one after
   // the other.  na = squared norm of the candidate's feature, NaN when feature_can_be_used() says no (the distance is then NaN
@@ -609,11 +615,23 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
   // wave then walks 16 dependent chains (multiply, v_rsq, multiply, compare, key ...) one after the other — 4 k cycles.
   const bool ok0 = col.ok && !cons_failed;
   bool ok = ok0;
-  // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
-  // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
-  const float d = dot * __frsqrt_rn(na * col.nb);
-  ok = ok & (d >= p.visual_threshold);  // VisualSortMetricType::is_ok (NaN fails)
-  const float w = 1.0f - d;             // distance_to_weight
+  float w;
+  if constexpr (EU) {
+    const float s = na + col.nb;
+    const float d2 = s - 2.0f * dot;
+    const bool f = ok0 & (d2 < p.eu_rho * s);        // NaN norms (unusable candidate): never flagged, never present
+    *flagged = f;
+    const float d = __fsqrt_rn(d2 < 0.0f ? 0.0f : d2);  // NaN stays NaN
+    ok = ok & !f & (d <= p.visual_threshold);         // VisualSortMetricType::is_ok for Euclidean (NaN fails)
+    w = d;                                            // distance_to_weight: the distance itself
+  } else {
+    // divided / (f1_divisor * f2_divisor).sqrt(): v_rsq_f32 + multiply, <= 2 ulp from the reference's sqrt + divide,
+    // two orders of magnitude inside the 1e-5 gate and ~25 instructions cheaper per cell
+    const float d = dot * __frsqrt_rn(na * col.nb);
+    ok = ok & (d >= p.visual_threshold);  // VisualSortMetricType::is_ok (NaN fails)
+    w = 1.0f - d;                         // distance_to_weight
+    *flagged = false;
+  }
   const uint32_t key = ok ? sa_f32_key(w) : 0u;
   *kmax = key > *kmax ? key : *kmax;
   return ok ? w : __builtin_nanf("");
@@ -632,8 +650,9 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
-template <int BM, int BN, int KGT, bool RAW, bool PART, bool H2 = false>
+template <int BM, int BN, int KGT, bool RAW, bool PART, bool H2 = false, bool EU = false>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
+  static_assert(!(H2 && EU), "the f16-split operands are a cosine option");
   constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
@@ -722,6 +741,12 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   unsigned long long* s_ck = (unsigned long long*)(lds + (6 + KG) * BM);  // [BN] PART: (weight key << 32) | row, minimum per column
   constexpr uint32_t KS = BN + 4;                                          // row stride of the key tile (words)
   uint32_t* s_key = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN);             // [64][KS] PART: order-preserving keys of 64 tile rows
+  constexpr uint32_t FW = BN / 32;                                         // EU: words of flag bits per tile row
+  uint32_t* s_flag = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN + 64 * KS);  // [64][FW] EU: cells of the current 64-row pass to recompute directly
+  static_assert(!EU || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 64 * (BN / 32)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "flag words must fit the stages");
+  if constexpr (EU) {
+    for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
+  }
   if (tid < (uint32_t)BM) {
     s_na[tid] = pre_us != 0.f ? pre_na : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
     s_g[tid] = pre_g;
@@ -780,6 +805,59 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       S.row_part_t[(size_t)bx * S.N + gi] = has ? (int32_t)(n0 + bc) : -1;
     }
   };
+  // EU: the flagged cells of the 64-row pass `m`, recomputed as the direct sum of (a - b)^2: a wave per tile row, the lanes along k
+  // (16-byte loads of both rows, L2-resident: the tile has just streamed them), a wave reduction, one result per cell — into the
+  // key tile and the column minima (PART) or the weight matrix.  A wave that meets more than 16 such cells reports the frame as
+  // ill-conditioned for the expansion (S.stats[0], read by the host after the frame: it switches the scene's engine to the
+  // vector-pipe kernel for a while); the answers of THIS frame are exact either way.
+  auto euclid_fixup = [&](uint32_t m) {
+    if constexpr (EU) {
+      __syncthreads();  // flag words (and the keys / matrix cells of the pass) complete
+      const uint32_t wave = tid >> 6, nw = blockDim.x >> 6;
+      const float SA_G* Ab = RAW ? S.c_feat_raw : (const float SA_G*)S.c_feat;
+      uint32_t fixed = 0;
+      for (uint32_t lrow = wave; lrow < 64u; lrow += nw) {
+        const uint32_t li = (lrow >> 5) * (BM / 2) + m * 32 + (lrow & 31u), gi = m0 + li;
+        for (uint32_t wd = 0; wd < FW; ++wd) {
+          uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flag[lrow * FW + wd]);
+          while (bits) {
+            const uint32_t lc = wd * 32u + (uint32_t)__builtin_ctz(bits), gj = n0 + lc;
+            bits &= bits - 1u;
+            const float SA_G* a = Ab + (size_t)gi * S.Dp;
+            const float SA_G* b = S.t_feat + (size_t)gj * S.Dp;
+            float acc2 = 0.f;
+            for (uint32_t k = lane * 4u; k < S.Dp; k += 256u) {
+              const f32x4 x = *(const f32x4 SA_G*)(a + k), y = *(const f32x4 SA_G*)(b + k);
+              const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+              acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o);
+            ++fixed;
+            if (lane == 0) {
+              const float d = __fsqrt_rn(acc2);
+              const bool ok = d <= p.visual_threshold;
+              const uint32_t key = ok ? sa_f32_key(d) : 0u;
+              if constexpr (PART) {
+                const uint32_t k2 = ok ? key : 0xffffffffu;
+                s_key[lrow * KS + lc] = k2;
+                if (ok) atomicMin(&s_ck[lc], ((unsigned long long)k2 << 32) | gi);
+              } else {
+                S.vis[(size_t)gi * TK + gj] = ok ? d : __builtin_nanf("");
+                kmax = key > kmax ? key : kmax;
+              }
+            }
+          }
+        }
+      }
+      if (fixed > 16u && lane == 0) S.stats[0] = 1u;
+      if (m + 1 < (uint32_t)TM) {  // the next pass reuses the flag words
+        __syncthreads();
+        for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
+        __syncthreads();
+      }
+    }
+  };
   // The row operands of a lane's cells: accumulator registers 4g .. 4g+3 hold four consecutive tile rows (acc_row), so one
   // 16-byte LDS read per group of four cells, all issued before the first cell is evaluated.
   if constexpr (TM == 1 && TN == 1) {
@@ -799,7 +877,11 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     for (int i = 0; i < R; ++i) {
       const uint32_t li = rbase[i >> 2] + (i & 3);
       const uint32_t gi = m0 + li;
-      const float w = visual_cell(p, part[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax);  // rows / columns past the edge: ok = false
+      bool flagged;
+      const float w = visual_cell<EU>(p, part[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax, &flagged);  // rows / columns past the edge: ok = false
+      if constexpr (EU) {
+        if (flagged && gi < N) atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));  // BM = 64: the tile row is the pass row
+      }
       if constexpr (PART) {
         const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
         s_key[li * KS + lc] = key;
@@ -814,9 +896,10 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       cb = ob < cb ? ob : cb;
       if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);
       SA_STAMP(tr, 6);
+      euclid_fixup(0);
       rows_to_partials(0);
       SA_STAMP(tr, 7);
-    }
+    } else euclid_fixup(0);
   } else {
     uint32_t ckey[TN], crow[TN];
 #pragma unroll
@@ -838,7 +921,11 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           const uint32_t lc = wn * (BN / 2) + n * 32 + lr, gj = n0 + lc;
-          const float w = visual_cell(p, acc[m][n][r], nav[r >> 2][r & 3], (cfail[n] >> r) & 1u, col[n], &kmax);
+          bool flagged;
+          const float w = visual_cell<EU>(p, acc[m][n][r], nav[r >> 2][r & 3], (cfail[n] >> r) & 1u, col[n], &kmax, &flagged);
+          if constexpr (EU) {
+            if (flagged && gi < N) atomicOr(&s_flag[lrow * FW + (lc >> 5)], 1u << (lc & 31u));
+          }
           if constexpr (PART) {
             const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
             s_key[lrow * KS + lc] = key;
@@ -858,9 +945,10 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
             if (lh == 0 && (uint32_t)(b2 >> 32) != 0xffffffffu) atomicMin(&s_ck[wn * (BN / 2) + n * 32 + lr], b2);
           }
         }
+        euclid_fixup(m);
         rows_to_partials(m);
         if (m + 1 < TM) __syncthreads();  // the next pass overwrites the key tile
-      }
+      } else euclid_fixup(m);
     }
   }
   if constexpr (PART) {
@@ -921,14 +1009,14 @@ __global__ __launch_bounds__(256) void k_visual_cosine_h2_128(const SceneDev* __
   if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
   visual_cosine_tile<128, 128, 1, false, PART, true>(S, p, bx, by, lds);
 }
-template <int BM, int BN, int KGT, bool PART = false, bool H2 = false>
+template <int BM, int BN, int KGT, bool PART = false, bool H2 = false, bool EU = false>
 __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t bx = blockIdx.x, by = blockIdx.y;
   if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
-  visual_cosine_tile<BM, BN, KGT, false, PART, H2>(S, p, bx, by, lds);
+  visual_cosine_tile<BM, BN, KGT, false, PART, H2, EU>(S, p, bx, by, lds);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -939,7 +1027,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
-template <int KG, bool PART>
+template <int KG, bool PART, bool EU = false>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py, uint32_t nprep) {
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
@@ -951,7 +1039,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6.
   uint32_t b = blockIdx.x;
   if (b < gx * gy) {
-    visual_cosine_tile<64, 64, KG, true, PART>(S, p, b % gx, b / gx, lds);
+    visual_cosine_tile<64, 64, KG, true, PART, false, EU>(S, p, b % gx, b / gx, lds);
     return;
   }
   b -= gx * gy;
@@ -1348,10 +1436,10 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
 
 // Tile extents the visual cost kernel will use for a batch with these maxima (the host needs them for the per-scene number of
 // max-key slots, SceneDev::nkeys).
-void sa_visual_tile(int visual_kind, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn) {
+void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn) {
   *bm = 64; *bn = 64;
-  if (visual_kind == SA_VIS_EUCLIDEAN) { *bm = EU_BM; *bn = EU_BN; return; }  // k_visual_euclid's block tile (vis_max_key slots)
-  if (visual_kind != SA_VIS_COSINE || !maxN || !maxTK) return;
+  if (visual_kind == SA_VIS_EUCLIDEAN && !eu_mfma) { *bm = EU_BM; *bn = EU_BN; return; }  // k_visual_euclid's block tile (vis_max_key slots)
+  if ((visual_kind != SA_VIS_COSINE && visual_kind != SA_VIS_EUCLIDEAN) || !maxN || !maxTK) return;
   switch (tile_plan(maxN, maxTK, ns, Dp)) {
     case 0: case 8: *bm = 128; *bn = 128; break;
     case 5: *bm = 64; *bn = 128; break;
@@ -1368,7 +1456,8 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
                                   const SaParams& p, hipStream_t st, bool partials) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
-  if (force_general || p.visual_kind != SA_VIS_COSINE || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
+  const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
+  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
   if (plan != 2 && plan != 4) return hipErrorNotSupported;
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
@@ -1383,9 +1472,13 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   static const bool one_group = !(getenv("SA_FRAME_KG") && atoi(getenv("SA_FRAME_KG")) == 2);
   if (one_group) {
     const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
-    if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    if (eu) {
+      if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+      else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
     else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
   } else {
+    if (eu) return hipErrorNotSupported;  // the two-k-group form of the launch is a cosine measurement variant
     const dim3 grid(gx * gy + cdiv(px * py + prep_blocks, 2), 1, ns);
     if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
     else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
@@ -1397,6 +1490,21 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
                             hipStream_t st, bool partials, bool f16_split) {
   if (!maxN || !maxTK) return hipSuccess;
   sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
+  if (p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma) {
+    // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
+    int plan = tile_plan(maxN, maxTK, ns, p.Dp);
+    plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6) ? plan : 1;
+    const uint32_t band = 0;
+#define SA_EU_LAUNCH(BM_, BN_, PART_) SA_LAUNCH((k_visual_cosine<BM_, BN_, 1, PART_, false, true>), dim3(cdiv(maxTK, BN_), cdiv(maxN, BM_), ns), dim3(256), 0, st, scenes, p, band)
+    switch (plan) {
+      case 0: if (partials) SA_EU_LAUNCH(128, 128, true); else SA_EU_LAUNCH(128, 128, false); break;
+      case 5: if (partials) SA_EU_LAUNCH(64, 128, true); else SA_EU_LAUNCH(64, 128, false); break;
+      case 6: if (partials) SA_EU_LAUNCH(128, 64, true); else SA_EU_LAUNCH(128, 64, false); break;
+      default: if (partials) SA_EU_LAUNCH(64, 64, true); else SA_EU_LAUNCH(64, 64, false); break;
+    }
+#undef SA_EU_LAUNCH
+    return hipGetLastError();
+  }
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     int plan = tile_plan(maxN, maxTK, ns, Dp);

@@ -61,6 +61,27 @@ __global__ void k_prep_tracks(PrepTrackArgs a, SaParams p) {
   if (a.kf_mean && a.kf_cov) sa_maha_prepare(p.kf_position_weight, a.kf_mean + (size_t)i * 5, a.kf_cov + (size_t)i * 25, a.maha + (size_t)s * 20);
 }
 
+// Ingest of one request set: the shader engines pull the pinned host blocks (the staging arena, and the feature blocks callers keep
+// pinned themselves) over PCIe through their device mapping and store them to HBM.  One launch moves every segment; a few dozen
+// workgroups keep enough 16-byte reads in flight to fill the link (scripts/micro/h2d_rate.hip: 2 MB in 40 us = 52 GB/s with 32-64
+// workgroups, against 57 us for one hipMemcpyAsync on one SDMA engine), and it shares a stream with nothing but other ingests, so
+// it runs beside the previous set's kernels.  Segments are 16-byte aligned on both sides (the launcher checks).
+__global__ __launch_bounds__(256) void k_ingest(SaCopySegs segs) {
+  for (uint32_t k = 0; k < segs.n; ++k) {
+    const uint4* __restrict__ src = (const uint4*)segs.s[k].src;
+    uint4* __restrict__ dst = (uint4*)segs.s[k].dst;
+    const size_t n16 = segs.s[k].bytes >> 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const uint32_t tail = (uint32_t)(segs.s[k].bytes & 15u);
+    if (blockIdx.x == 0 && threadIdx.x < tail) ((uint8_t*)dst)[(n16 << 4) + threadIdx.x] = ((const uint8_t*)src)[(n16 << 4) + threadIdx.x];
+  }
+}
+hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st) {
+  if (!segs.n) return hipSuccess;
+  hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, st, segs);
+  return hipGetLastError();
+}
+
 __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                               const uint32_t* __restrict__ index, uint32_t rows, uint32_t row_bytes) {
   uint32_t row = blockIdx.x;
@@ -425,6 +446,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ int64_t s_egain[POOL];
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
+  if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
+    S.out_stats[0] = S.stats[0];
+    S.stats[0] = 0u;
+  }
   __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
   __shared__ uint32_t s_bt[WORDS ? SA_SMALL_N : 1];     // candidate -> its best column (SA_NONE: no group at all)
   __shared__ uint32_t s_cq[WORDS ? SA_SMALL_N : 1];     // column -> its best candidate (SA_NONE: no group at all)
@@ -742,6 +767,10 @@ __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict_
   __shared__ SolveLocal s_local[64];
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
   for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * blockDim.x) S.parent[i] = i;
+  if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
+    S.out_stats[0] = S.stats[0];
+    S.stats[0] = 0u;
+  }
   if (q >= S.N) return;
   const uint32_t head = S.label[q];
   if (!S.e_use[q] || (VISUAL && S.row_has[q])) finalize_row_with<VISUAL>(S, q, -1);

@@ -59,7 +59,8 @@ def test_cluster_routes_scenes_and_matches_the_oracle(visual, shards):
                 np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"scene {s}")
                 np.testing.assert_array_equal(votes, ref["voting_type"])
         ms = cl.last_ms()
-        assert len(ms) == shards and all(m > 0.0 for m in ms)
+        busy = {s % shards for s in scs}
+        assert len(ms) == shards and all((m > 0.0) == (k in busy) for k, m in enumerate(ms)), ms
         # every scene's table lives on exactly one shard
         for s in scs:
             counts = [cl.engine(k).count(s) for k in range(shards)]

@@ -490,6 +490,72 @@ def test_visual_euclid_reference_bench_distribution():
     np.testing.assert_array_equal(ids, sc["truth"])
 
 
+def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_conditioned():
+    """The matrix-core path for euclidean distances recomputes directly every cell its f32 expansion cannot hold to 1e-5; on the
+    reference's own bench distribution (features 10 * idx +- 0.01: norms ~ 10^4 x the spread) that is nearly every cell, the frame
+    reports it, and the engine runs the next frames on the vector-pipe kernel.  Every frame — the slow first one too — gives the
+    oracle's distances and ids; and an ordinary ReID-like scene on a fresh engine stays on the matrix cores."""
+    rng = np.random.default_rng(79)
+    t = n = 192
+    d = 128
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(3000.0, 3000.0))
+    base = (10.0 * np.arange(t, dtype=np.float32))[:, None, None]
+    sc["track_feats"] = (base + rng.uniform(-0.01, 0.01, (t, 1, d))).astype(np.float32)
+    perm = (sc["truth"].astype(np.int64) - 1)
+    cfg = abi.make_config(positional="iou", visual="euclidean", visual_threshold=3.4e38, feature_len=d, max_observations=1,
+                          visual_min_votes=1, positional_min_confidence=0.1, max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        kernels = []
+        for f in range(4):
+            sc["det_feats"] = (10.0 * perm[:, None] + rng.uniform(-0.01, 0.01, (n, d))).astype(np.float32)
+            det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+            eng.profile_reset()
+            ids, votes = eng.associate(0, 1, det)
+            kernels.append(set(eng.profile_read()))
+            vis = eng.tap_visual()
+            ref = O.associate(cfg, tracks, 1, det)
+            both = ~np.isnan(vis) & ~np.isnan(ref["visual"])
+            assert both.all()
+            assert (np.abs(vis - ref["visual"]) <= 1e-5 * np.abs(ref["visual"])).all(), f"frame {f}"
+            np.testing.assert_array_equal(ids, ref["track_id"])
+            np.testing.assert_array_equal(ids, sc["truth"])
+        assert "k_frame_visual" in kernels[0], kernels          # the first frames: contraction tiles inside the heterogeneous launch
+        assert "k_visual_cost" in kernels[-1] and "k_frame_visual" not in kernels[-1], kernels  # after the report: the vector-pipe kernel
+    finally:
+        eng.close()
+    sc2 = synth.visual_scene(rng, t, n, d, 1, canvas=(3000.0, 3000.0))
+    cfg2 = abi.make_config(positional="iou", visual="euclidean", visual_threshold=0.6, feature_len=d, max_observations=1,
+                           visual_min_votes=1, positional_min_confidence=0.1, max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
+    eng = Engine(cfg2)
+    try:
+        eng.upsert(0, abi.make_tracks(sc2["track_ids"], sc2["track_boxes"], sc2["track_epochs"], feats=sc2["track_feats"], feat_present=sc2["track_present"]))
+        det = abi.make_detections(sc2["det_boxes"], feats=sc2["det_feats"], feat_quality=sc2["det_quality"])
+        for _ in range(4):
+            eng.profile_reset()
+            eng.associate(0, 1, det)
+            assert "k_frame_visual" in eng.profile_read()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("mode", ["valu", "mfma"])
+def test_both_euclidean_kernels_match_oracle(mode):
+    """SA_EUCLID=valu: always the vector-pipe kernel (direct sums); SA_EUCLID=mfma: always the contraction + flagged recompute, also on
+    frames that report themselves ill-conditioned.  The euclidean tests of this module under each."""
+    import os
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "test_visual_euclid_parity or test_visual_euclid_reference_bench or test_full_size_c2_euclidean_against or "
+                        "test_dense_positional_stage or test_vote_words_rearmed or test_random_configurations"],
+                       env=dict(os.environ, SA_EUCLID=mode), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_visual_maha_with_constraints_and_own_area():
     rng = np.random.default_rng(79)
     sc = synth.visual_scene(rng, 100, 110, 64, 2, canvas=(1200.0, 800.0), new_fraction=0.1)
