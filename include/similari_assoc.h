@@ -231,7 +231,8 @@ int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, f
  * any other box of the frame / (area_i + EPS), clamped to 1.0 — the value VisualSORT's own-area gates read
  * (visual_sort/simple_api.rs:111-127); feed it to sa_detections.own_area.  The reference builds the difference polygons with
  * geo's BooleanOps; the device integrates the boundary of the same region in f64 (agreement to the reference test's EPS = 1e-5).
- * SA_ERR_UNSUPPORTED when one box overlaps more than 127 others. */
+ * A box in the middle of a crowd (more than 127 overlapping neighbours) takes a slower path with its lists in HBM; the only limit left
+ * is 512 DISJOINT covered stretches on one edge of one box (SA_ERR_UNSUPPORTED). */
 int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share);
 
 typedef struct sa_scene_request {

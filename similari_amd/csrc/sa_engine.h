@@ -123,6 +123,7 @@ struct SceneDev {
 #define SCN_HAS_QUALITY 2u
 #define SCN_HAS_OWN 4u
 #define SCN_HAS_FPRESENT 8u
+#define SCN_WORDS10 16u   // the vote words of this frame carry a 10-bit index below a 54-bit weight key (k_bestfit_tile, deeper banks)
 
 // Engine-wide constants, passed to kernels by value.
 struct SaParams {
@@ -256,5 +257,9 @@ hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams
 #define SA_NMS_MAX 16384u
 hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st);
 hipError_t sa_launch_own_areas(const BoxRaw* raw, uint32_t n, float* share, uint32_t* status, hipStream_t st);
+// spill path: the `count` boxes listed (indices into raw) with neighbour polygons and interval lists in HBM scratch
+size_t sa_own_big_scratch_bytes(uint32_t n, uint32_t batch);
+hipError_t sa_launch_own_areas_big(const BoxRaw* raw, uint32_t n, const uint32_t* list, uint32_t count, float* share, uint32_t* status,
+                                   void* scratch, hipStream_t st);
 
 const char* sa_kernel_name(int id);

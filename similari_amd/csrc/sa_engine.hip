@@ -93,6 +93,7 @@ struct Bank {
   uint32_t tile_bm = 64, tile_bn = 64;  // tile of the visual cost kernel for this set (sa_visual_tile)
   bool eu_mfma = false;                 // this set's euclidean distances go through the matrix-core contraction
   bool partials = false;                // this set's contraction votes itself (no weight matrix): cosine or matrix-core euclidean, bank depth 1
+  int words = 0;                        // vote words instead of partials + resolve: 0 no, 1 = (key32 << 32 | index) from the cost kernel, 2 = (key54 << 10 | index) from k_bestfit_tile
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -117,6 +118,8 @@ struct sa_engine {
   hipStream_t stream2 = nullptr;  // side stream: the positional cost kernel runs beside the feature contraction
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t copy_stream = nullptr;  // sa_pipe_*: H2D of the next request set beside the kernels of the current one
+  hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // SA_INGEST=sdma4: a large block split over four SDMA engines
+  hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
   Bank banks[SA_BANKS];
   Bank* B = &banks[0];               // the bank the synchronous entry points, the taps and sa_tracks_apply refer to
   uint64_t next_ticket = 1;
@@ -202,6 +205,8 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
   } while (0)
 
 int engine_sync(sa_engine* e) {
+  for (int k = 0; k < 3; ++k)
+    if (e->aux_stream[k]) HIPCHK(e, hipStreamSynchronize(e->aux_stream[k]));
   if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   for (void* p : e->garbage) hipFree(p);
@@ -400,7 +405,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->TK = s->T * e->K; d->estride = s->T ? s->T : 1;
   d->D = e->D;
   d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
-             (s->has_fpresent ? SCN_HAS_FPRESENT : 0u);
+             (s->has_fpresent ? SCN_HAS_FPRESENT : 0u) | (bk->words == 2 ? SCN_WORDS10 : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
   if (bk->partials) { d->CT = (s->T + bk->tile_bn - 1) / bk->tile_bn; d->RT = (s->N + bk->tile_bm - 1) / bk->tile_bm; }  // the contraction's own tile grid
   d->nkeys = e->visual ? ((s->N + bk->tile_bm - 1) / bk->tile_bm) * ((s->T * e->K + bk->tile_bn - 1) / bk->tile_bn) : 0;
@@ -464,7 +469,8 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
   if (!b->uploaded) {
     // SA_INGEST=sdma: hipMemcpyAsync per segment (one SDMA engine: 2 MB in 57 us); default: the ingest kernel (40 us), which needs
     // the device mapping of every source and 16-byte alignment
-    static const bool sdma = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma");
+    static const bool sdma4 = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4");
+    static const bool sdma = sdma4 || (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma"));
     static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 48u;
     SaCopySegs segs;
     segs.n = 0;
@@ -475,6 +481,17 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
     };
     auto move = [&](const void* src_host, const void* src_dev, void* dst, size_t bytes) -> int {
       if (!bytes) return SA_OK;
+      if (sdma4 && bytes >= (1u << 20) && e->aux_stream[0] && e->aux_stream[1] && e->aux_stream[2]) {
+        // four quarters on four streams (four SDMA engines: 2 MB in 39 us against 57 on one); `st` resumes when all have landed
+        const size_t q4 = (bytes / 4) & ~(size_t)255;
+        for (int k = 0; k < 3; ++k) {
+          HIPCHK(e, hipMemcpyAsync((char*)dst + (k + 1) * q4, (const char*)src_host + (k + 1) * q4, k == 2 ? bytes - 3 * q4 : q4, hipMemcpyHostToDevice, e->aux_stream[k]));
+          HIPCHK(e, hipEventRecord(e->aux_ev[k], e->aux_stream[k]));
+        }
+        HIPCHK(e, hipMemcpyAsync(dst, src_host, q4, hipMemcpyHostToDevice, st));
+        for (int k = 0; k < 3; ++k) HIPCHK(e, hipStreamWaitEvent(st, e->aux_ev[k], 0));
+        return SA_OK;
+      }
       if (sdma || !src_dev || (((uintptr_t)src_dev | (uintptr_t)dst) & 15u)) {
         HIPCHK(e, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, st));
         return SA_OK;
@@ -505,13 +522,12 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
   // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own (no vote words)
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-  static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
   const bool small_tail = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general;
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
   const bool partials = b->partials;
-  const bool words = e->visual && (partials || e->bf_words_euclid) && small_tail && maxT <= SA_SMALL_N && !separate_resolve;
+  const bool words = b->words != 0;
   SaParams P = e->P;
   P.vote_words = words ? 1u : 0u;
   P.eu_mfma = b->eu_mfma ? 1u : 0u;
@@ -531,7 +547,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
   if (e->visual) {
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
-    if (!partials && !words) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
+    if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
   if (small_tail) {
@@ -567,6 +583,15 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out) 
   if (euclid && e->eu_valu_left) --e->eu_valu_left;
   b->partials = e->bf_partials || (b->eu_mfma && e->bf_words_euclid);
   if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, &b->tile_bm, &b->tile_bn);
+  {
+    // vote words (frames of at most 1024 x 1024 on the one-workgroup tail): the first phase reduces the BestFit vote into one 64-bit
+    // word per candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip) and the tail reads its
+    // two words per thread — no resolve launch.  One observation per track: the cost kernel itself; deeper banks: k_bestfit_tile.
+    static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+    static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
+    const bool small = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general && !separate_resolve;
+    b->words = !(e->visual && small) ? 0 : (b->partials || e->bf_words_euclid) ? 1 : 2;
+  }
   *maxN_out = maxN;
   *maxT_out = maxT;
   return SA_OK;
@@ -594,7 +619,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT) {
     uint32_t feats_mask = 0;
     for (uint32_t i = 0; i < ns; ++i) feats_mask = feats_mask * 31u + (b->slots[i]->has_feats ? 1u : 0u) + 7u;
     const uint64_t key[6] = {((uint64_t)ns << 32) | 1u, ((uint64_t)maxN << 32) | maxT, ((uint64_t)b->tile_bm << 32) | b->tile_bn,
-                             (uint64_t)(uintptr_t)ds, feats_mask, (uint64_t)(b->eu_mfma ? 1u : 0u) | (b->partials ? 2u : 0u)};
+                             (uint64_t)(uintptr_t)ds, feats_mask, (uint64_t)(b->eu_mfma ? 1u : 0u) | (b->partials ? 2u : 0u) | ((uint64_t)b->words << 2)};
     if (!b->graph_exec || std::memcmp(key, b->graph_key, sizeof key) != 0) {
       if (b->graph_exec) { hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
       if (b->graph) { hipGraphDestroy(b->graph); b->graph = nullptr; }
@@ -765,6 +790,11 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   hipEventCreate(&e->ev_t0);
   hipEventCreate(&e->ev_t1);
   if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) e->copy_stream = nullptr;
+  if (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4"))
+    for (int k = 0; k < 3; ++k) {
+      if (hipStreamCreateWithFlags(&e->aux_stream[k], hipStreamNonBlocking) != hipSuccess) e->aux_stream[k] = nullptr;
+      hipEventCreateWithFlags(&e->aux_ev[k], hipEventDisableTiming);
+    }
   for (Bank& bk : e->banks) {
     hipEventCreateWithFlags(&bk.ev_staged, hipEventDisableTiming);
     hipEventCreateWithFlags(&bk.ev_done, hipEventDisableTiming);
@@ -833,6 +863,10 @@ void sa_engine_destroy(sa_engine* e) {
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+  for (int k = 0; k < 3; ++k) {
+    if (e->aux_stream[k]) { hipStreamSynchronize(e->aux_stream[k]); hipStreamDestroy(e->aux_stream[k]); }
+    if (e->aux_ev[k]) hipEventDestroy(e->aux_ev[k]);
+  }
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1479,8 +1513,34 @@ int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share
   TRY(engine_sync(e));
   uint32_t status;
   memcpy(&status, hout + (size_t)n * 4, 4);
-  if (status & 1u) return fail(e, SA_ERR_UNSUPPORTED, "sa_own_areas: a box overlaps more than 127 other boxes");
-  if (status & 2u) return fail(e, SA_ERR_UNSUPPORTED, "sa_own_areas: more than 24 disjoint stretches of one box edge are covered by other boxes");
+  if (status & 3u) {
+    // Boxes the LDS-resident kernel gave up on (NaN shares: more than 127 overlapping neighbours, or more than 24 disjoint covered
+    // stretches on one edge): the spill path, in batches that share one block of HBM scratch.  bbox_own_areas.rs has no limit.
+    std::vector<uint32_t> todo;
+    const float* hs = (const float*)hout;
+    for (uint32_t i = 0; i < n; ++i)
+      if (hs[i] != hs[i]) todo.push_back(i);
+    const uint32_t batch = 64;
+    DevBuf scratch, dlist;
+    int rc = dev_ensure(e, scratch, sa_own_big_scratch_bytes(n, batch));
+    if (rc == SA_OK) rc = dev_ensure(e, dlist, (size_t)todo.size() * 4 + 4);
+    if (rc == SA_OK && hipMemcpyAsync(dlist.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(e, SA_ERR_HIP, "sa_own_areas: list upload failed");
+    if (rc == SA_OK && hipMemsetAsync(dstatus, 0, 4, st) != hipSuccess) rc = fail(e, SA_ERR_HIP, "sa_own_areas: status reset failed");
+    for (size_t o = 0; rc == SA_OK && o < todo.size(); o += batch) {
+      const uint32_t cnt = (uint32_t)std::min<size_t>(batch, todo.size() - o);
+      if (sa_launch_own_areas_big((const BoxRaw*)e->up_raw.p, n, (const uint32_t*)dlist.p + o, cnt, dshare, dstatus, scratch.p, st) != hipSuccess)
+        rc = fail(e, SA_ERR_HIP, "sa_own_areas: spill launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc == SA_OK && hipMemcpyAsync(hout, dshare, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(e, SA_ERR_HIP, "sa_own_areas: result copy failed");
+    e->synced = false;
+    const int rs = engine_sync(e);
+    if (scratch.p) hipFree(scratch.p);
+    if (dlist.p) hipFree(dlist.p);
+    if (rc != SA_OK) return rc;
+    if (rs != SA_OK) return rs;
+    memcpy(&status, hout + (size_t)n * 4, 4);
+    if (status & 4u) return fail(e, SA_ERR_UNSUPPORTED, "sa_own_areas: more than 512 disjoint stretches of one box edge are covered by other boxes");
+  }
   memcpy(out_share, hout, (size_t)n * 4);
   return SA_OK;
 }

@@ -71,7 +71,15 @@ __global__ __launch_bounds__(256) void k_ingest(SaCopySegs segs) {
     const uint4* __restrict__ src = (const uint4*)segs.s[k].src;
     uint4* __restrict__ dst = (uint4*)segs.s[k].dst;
     const size_t n16 = segs.s[k].bytes >> 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    // four 16-byte reads in flight per lane: a read over PCIe takes microseconds, and the waves of this kernel share the CUs with
+    // the previous request set's kernels — fewer, longer-lived waves with more requests each are less sensitive to that
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+      const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+      dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
     const uint32_t tail = (uint32_t)(segs.s[k].bytes & 15u);
     if (blockIdx.x == 0 && threadIdx.x < tail) ((uint8_t*)dst)[(n16 << 4) + threadIdx.x] = ((const uint8_t*)src)[(n16 << 4) + threadIdx.x];
   }
@@ -138,6 +146,15 @@ __global__ void k_quant_tap(const SceneDev* __restrict__ scenes) {
 //   k_bestfit_resolve: one thread per candidate folds its CT row partials, then the RT column partials of
 //                      the winning column, and decides; winners mark excluded_tracks (visual_sort/voting.rs:62-71).
 // =====================================================================================================
+// Deeper banks on frames of at most 1024 x 1024: the tile's row / column winners go straight into the vote words as well (no
+// resolve launch).  A group weight W = sum_k f64(max_dist - w_k) >= 0 does not fit beside an index in 32 bits, so the word is
+// (2^54 - 1 - key54(W)) << 10 | index with key54 = the leading 54 bits of the f64 pattern + 1: the 64-bit minimum is the heaviest
+// group, lowest index among groups whose weights agree to 2^-43 relative — the reference breaks EXACT ties by index; weights that
+// close differ by 1e-13 of themselves, eight orders of magnitude below what the f32 distances carry.  Never all ones (= no group).
+__device__ __forceinline__ unsigned long long sa_vote_word10(double W, uint32_t index) {
+  const unsigned long long key = ((unsigned long long)__double_as_longlong(W) >> 9) + 1ull;
+  return ((((1ull << 54) - 1ull) - key) << 10) | (unsigned long long)(index & 1023u);
+}
 __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict__ scenes, SaParams p) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T, K = S.K;
@@ -251,7 +268,9 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
       if (ow > bw || (ow == bw && ot < bt)) { bw = ow; bt = ot; }
     }
     const uint32_t q = rt * 64 + row;
-    if (quarter == 0 && q < N) {
+    if (quarter == 0 && q < N && p.vote_words) {
+      if (bw >= 0.0) __hip_atomic_fetch_min(S.row_best + q, sa_vote_word10(bw, bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (quarter == 0 && q < N) {
       S.row_part_w[(size_t)ct * S.N + q] = bw;
       S.row_part_t[(size_t)ct * S.N + q] = bw >= 0.0 ? (int32_t)bt : -1;
     }
@@ -264,8 +283,12 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
       double ow = s_w[w2][lane];
       if (ow > bw) { bw = ow; bq = s_q[w2][lane]; }  // wave index ascends with q
     }
-    S.col_part_w[(size_t)rt * T + t] = bw;
-    S.col_part_q[(size_t)rt * T + t] = bq;
+    if (p.vote_words) {
+      if (bw >= 0.0) __hip_atomic_fetch_min(S.col_best + t, sa_vote_word10(bw, bq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      S.col_part_w[(size_t)rt * T + t] = bw;
+      S.col_part_q[(size_t)rt * T + t] = bq;
+    }
   }
 }
 
@@ -462,8 +485,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
     if (q < N) S.row_best[q] = ~0ull;
     if (q < T) S.col_best[q] = ~0ull;
-    bt = rb != ~0ull ? (uint32_t)rb : SA_NONE;
-    const uint32_t cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
+    const uint32_t imask = (S.flags & SCN_WORDS10) ? 1023u : 0xffffffffu;  // deeper banks: (inverted weight key << 10) | index, k_bestfit_tile
+    bt = rb != ~0ull ? ((uint32_t)rb & imask) : SA_NONE;
+    const uint32_t cq = cb != ~0ull ? ((uint32_t)cb & imask) : SA_NONE;
     has_verdict = bt != SA_NONE;  // feature_winners.contains_key(q)
     s_bt[q] = bt;
     s_cq[q] = cq;

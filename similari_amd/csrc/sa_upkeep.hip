@@ -319,8 +319,74 @@ __global__ __launch_bounds__(64) void k_own_area(const BoxRaw* __restrict__ raw,
     if (acc != acc) atomicOr(status, 2u);
     const double own = fabs(acc) * 0.5;
     const float e = (float)(own / (double)(sa_area(me.box.aspect, me.box.height) + SA_EPS));
-    share[i] = e >= 1.0f ? 1.0f : e;
+    share[i] = acc != acc ? NAN : (e >= 1.0f ? 1.0f : e);  // NaN = "not done here": the spill path takes the box
   }
+}
+
+// Spill path for the boxes k_own_area gave up on (more than SA_OWN_MAXNB overlapping neighbours, or more than SA_OWN_CAP disjoint
+// covered stretches on one edge: a box in the middle of a dense crowd).  The reference has no such limit
+// (bbox_own_areas.rs:8-46), so neither does the engine: the same boundary integral with the neighbour polygons and the interval
+// storage in HBM scratch — one wave per listed box, room for every other box of the frame as a neighbour and SA_OWN_BIGCAP disjoint
+// stretches per edge (status bit 2 beyond that).  Slower per box (the lists live in L2, not LDS), and rare.
+#define SA_OWN_BIGCAP 512
+__global__ __launch_bounds__(64) void k_own_area_big(const BoxRaw* __restrict__ raw, uint32_t n, const uint32_t* __restrict__ list,
+                                                     float* __restrict__ share, uint32_t* __restrict__ status, double* __restrict__ polys,
+                                                     double* __restrict__ iv) {
+  const uint32_t i = list[blockIdx.x], lane = threadIdx.x;
+  double* s_poly = polys + (size_t)blockIdx.x * (size_t)(n + 1) * 8;
+  double* s_iva = iv + (size_t)blockIdx.x * 2 * SA_OWN_BIGCAP * 64;
+  double* s_ivb = s_iva + (size_t)SA_OWN_BIGCAP * 64;
+  __shared__ uint32_t s_cnt;
+  const BoxRaw me = raw[i];
+  sa_geo mg;
+  mg.xc = me.box.xc; mg.yc = me.box.yc; mg.r = sa_radius(me.box.aspect, me.box.height); mg.hha = 0.f;
+  double mv[8];
+  sa_vertices(me.box.xc, me.box.yc, me.box.aspect, me.box.height, me.c, me.s, mv);
+  const double ox = (double)me.box.xc, oy = (double)me.box.yc;
+  if (lane < 8) s_poly[lane] = mv[lane] - ((lane & 1u) ? oy : ox);
+  if (lane == 0) s_cnt = 1;
+  __syncthreads();
+  for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    if (j < n && j != i) {
+      const BoxRaw r = raw[j];
+      sa_geo g;
+      g.xc = r.box.xc; g.yc = r.box.yc; g.r = sa_radius(r.box.aspect, r.box.height); g.hha = 0.f;
+      if (!sa_too_far(mg, g)) {
+        double v[8];
+        sa_vertices(r.box.xc, r.box.yc, r.box.aspect, r.box.height, r.c, r.s, v);
+        if (!sa_quads_separated(mv, v)) {
+          const uint32_t slot = atomicAdd(&s_cnt, 1u);  // at most n - 1 neighbours: always room
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s_poly[(size_t)slot * 8 + k] = v[k] - ((k & 1) ? oy : ox);
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t m1 = s_cnt;
+  double acc = 0.0;
+  for (uint32_t e = lane; e < m1 * 4; e += 64)
+    acc += sa_own_edge(s_poly, m1, e >> 2, e & 3u, s_iva + lane, s_ivb + lane, 64, SA_OWN_BIGCAP);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    if (acc != acc) atomicOr(status, 4u);
+    const double own = fabs(acc) * 0.5;
+    const float e = (float)(own / (double)(sa_area(me.box.aspect, me.box.height) + SA_EPS));
+    share[i] = acc != acc ? NAN : (e >= 1.0f ? 1.0f : e);
+  }
+}
+size_t sa_own_big_scratch_bytes(uint32_t n, uint32_t batch) {
+  return (size_t)batch * ((size_t)(n + 1) * 8 + 2 * (size_t)SA_OWN_BIGCAP * 64) * sizeof(double);
+}
+hipError_t sa_launch_own_areas_big(const BoxRaw* raw, uint32_t n, const uint32_t* list, uint32_t count, float* share, uint32_t* status,
+                                   void* scratch, hipStream_t st) {
+  if (!count) return hipSuccess;
+  double* polys = (double*)scratch;
+  double* iv = polys + (size_t)count * (size_t)(n + 1) * 8;
+  hipLaunchKernelGGL(k_own_area_big, dim3(count), dim3(64), 0, st, raw, n, list, share, status, polys, iv);
+  return hipGetLastError();
 }
 
 hipError_t sa_launch_own_areas(const BoxRaw* raw, uint32_t n, float* share, uint32_t* status, hipStream_t st) {

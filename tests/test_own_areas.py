@@ -167,8 +167,31 @@ def test_gpu_against_oracle(oriented, n):
         assert np.abs(s - ref).max() < EPS, np.abs(s - ref).max()
         emu, _ = emu_shares(b)
         assert np.abs(s - emu).max() < 1e-6          # same arithmetic, different summation order over the edges
-    # loud refusal beyond the kernel's neighbour budget
-    many = np.repeat(abi.ltwh([0.0], [0.0], [10.0], [10.0]), 200)
-    with pytest.raises(Exception):
-        e.own_areas(many)
     e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_dense_crowd_takes_the_spill_path():
+    """bbox_own_areas.rs:8-46 has no limit on the number of overlapping neighbours; the engine's LDS-resident kernel holds 127 and 24
+    disjoint covered stretches per edge, and hands every box beyond that to the spill path (lists in HBM).  200 identical boxes
+    (every share 0), a pile of 400 random boxes on a 300 x 300 canvas (150-390 neighbours each), and a long bar cut by 40 posts
+    (40 disjoint stretches on one edge) against the oracle's piece-by-piece difference."""
+    from similari_amd.engine import Engine
+    e = Engine(abi.make_config())
+    try:
+        many = np.repeat(abi.ltwh([0.0], [0.0], [10.0], [10.0]), 200)
+        s = e.own_areas(many)
+        assert np.abs(s - O.own_area_shares(many)).max() < EPS and s.max() < EPS
+        rng = np.random.default_rng(5)
+        pile = synth.dense_boxes(rng, 400, (300.0, 300.0), oriented=True)
+        s = e.own_areas(pile)
+        ref = O.own_area_shares(pile)
+        assert np.abs(s - ref).max() < EPS, np.abs(s - ref).max()
+        posts = abi.ltwh(list(np.arange(40) * 3.0), [0.0] * 40, [1.0] * 40, [10.0] * 40)
+        bar = abi.ltwh([-1.0], [4.0], [125.0], [2.0])
+        sc = np.concatenate([bar, posts])
+        s = e.own_areas(sc)
+        assert np.abs(s - O.own_area_shares(sc)).max() < EPS
+        assert abs(float(s[0]) - (125.0 - 40.0) / 125.0) < 1e-4
+    finally:
+        e.close()
