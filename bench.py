@@ -567,7 +567,7 @@ def main():
         # timed region above (dependent launches back to back on one stream: the step time is their sum); avg_us_instrumented = raw.
         raw = {k: 1e3 * ms / max(n, 1) for k, (n, ms) in prof.items()}
         step_instr = sum(raw[k] * prof[k][0] / float(args.profile_iters) for k in raw)
-        scale = min(1.0, (1e3 * dt / args.steps) / step_instr) if step_instr > 0 else 1.0
+        scale = min(1.0, (1e6 * dt / args.steps) / step_instr) if step_instr > 0 else 1.0  # both in microseconds per step
         kern = {k: {"launches": int(prof[k][0]), "avg_us": raw[k] * scale, "avg_us_instrumented": raw[k]} for k in raw}
         gpu_kernels = {k: v for k, v in kern.items() if k != "d2h_results"}
         visual = facade is None and cfg.visual_kind != abi.SA_VIS_NONE

@@ -471,7 +471,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
     // the device mapping of every source and 16-byte alignment
     static const bool sdma4 = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4");
     static const bool sdma = sdma4 || (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma"));
-    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 48u;
+    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 24u;
     SaCopySegs segs;
     segs.n = 0;
     auto flush = [&]() -> int {
@@ -529,9 +529,11 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   const bool partials = b->partials;
   const bool words = b->words != 0;
   SaParams P = e->P;
-  P.vote_words = words ? 1u : 0u;
+  P.vote_words = b->words == 1 ? 1u : 0u;  // the cost kernels reduce into the words only when they vote themselves (one observation per track)
   P.eu_mfma = b->eu_mfma ? 1u : 0u;
   P.eu_rho = e->eu_rho;
+  SaParams Pt = P;                         // k_bestfit_tile: the words of deeper banks
+  Pt.vote_words = b->words == 2 ? 1u : 0u;
   // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
   // launch; otherwise positional tiles + preparation blocks, then the contraction
   bool fused = false;
@@ -547,7 +549,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
   if (e->visual) {
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
-    if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, 0)); }
+    if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
   if (small_tail) {
@@ -789,7 +791,14 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   }
   hipEventCreate(&e->ev_t0);
   hipEventCreate(&e->ev_t1);
-  if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) e->copy_stream = nullptr;
+  {
+    // the copy stream at the highest priority the device offers: its few ingest workgroups should be dispatched ahead of the
+    // compute stream's thousands, or the DMA of the next request set queues behind the current set's tiles (SA_COPY_PRIO=0: default priority)
+    int lo = 0, hi = 0;
+    const bool prio = !(getenv("SA_COPY_PRIO") && atoi(getenv("SA_COPY_PRIO")) == 0);
+    if (!prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    if (hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, hi) != hipSuccess) e->copy_stream = nullptr;
+  }
   if (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4"))
     for (int k = 0; k < 3; ++k) {
       if (hipStreamCreateWithFlags(&e->aux_stream[k], hipStreamNonBlocking) != hipSuccess) e->aux_stream[k] = nullptr;

@@ -71,15 +71,8 @@ __global__ __launch_bounds__(256) void k_ingest(SaCopySegs segs) {
     const uint4* __restrict__ src = (const uint4*)segs.s[k].src;
     uint4* __restrict__ dst = (uint4*)segs.s[k].dst;
     const size_t n16 = segs.s[k].bytes >> 4;
-    // four 16-byte reads in flight per lane: a read over PCIe takes microseconds, and the waves of this kernel share the CUs with
-    // the previous request set's kernels — fewer, longer-lived waves with more requests each are less sensitive to that
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-      const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-      dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    // (four reads in flight per lane and fewer workgroups: measured slower beside the contraction, 59-61 us against 54-55)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
     const uint32_t tail = (uint32_t)(segs.s[k].bytes & 15u);
     if (blockIdx.x == 0 && threadIdx.x < tail) ((uint8_t*)dst)[(n16 << 4) + threadIdx.x] = ((const uint8_t*)src)[(n16 << 4) + threadIdx.x];
   }
