@@ -333,27 +333,29 @@ def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
             blocks.append(b)
             kw = dict(feats=b, feat_quality=sc["det_quality"])
         items.append((s, 1, abi.make_detections(sc["det_boxes"], **kw)))
-    sets = [eng.make_requests(items) for _ in range(2)]
+    depth = int(os.environ.get("SA_PIPE_DEPTH", "3"))  # tickets outstanding (the engine holds three banks)
+    sets = [eng.make_requests(items) for _ in range(depth)]
     lib, h = eng.lib, eng.h
     import ctypes as C
 
-    tk = [C.c_uint64(), C.c_uint64()]
+    tk = [C.c_uint64() for _ in range(depth)]
     ns = len(items)
-
     host = [0.0, 0.0]  # seconds of host time inside sa_pipe_submit / sa_pipe_wait
 
     def loop(k):
         pc = time.perf_counter
-        rc = lib.sa_pipe_submit(h, ns, sets[0][0], C.byref(tk[0]))
-        for i in range(1, k):
+        rc = 0
+        for i in range(k + depth - 1):
             a = pc()
-            rc |= lib.sa_pipe_submit(h, ns, sets[i & 1][0], C.byref(tk[i & 1]))
+            if i < k:
+                rc |= lib.sa_pipe_submit(h, ns, sets[i % depth][0], C.byref(tk[i % depth]))
             b = pc()
-            rc |= lib.sa_pipe_wait(h, tk[(i - 1) & 1], sets[(i - 1) & 1][1])
+            j = i - (depth - 1)
+            if j >= 0:
+                rc |= lib.sa_pipe_wait(h, tk[j % depth], sets[j % depth][1])
             c = pc()
             host[0] += b - a
             host[1] += c - b
-        rc |= lib.sa_pipe_wait(h, tk[(k - 1) & 1], sets[(k - 1) & 1][1])
         assert rc == 0, eng.lib.sa_last_error(h)
 
     loop(10)
@@ -369,7 +371,7 @@ def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
     for _ in range(max(10, iters // 4)):
         eng.associate_batch(req, res)
     dts = (time.perf_counter() - t1) / max(10, iters // 4)
-    ids = [o[0].copy() for o in sets[(iters - 1) & 1][2]]
+    ids = [o[0].copy() for o in sets[(iters - 1) % depth][2]]
     for b in blocks:
         eng.host_free(b)
     cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
@@ -377,8 +379,8 @@ def h2d_pipelined(eng, cfg, scenes, iters, depth2=True):
     return {"pairs_per_s": cells * iters / dt, "ms_per_step": 1e3 * dt / iters, "steps": iters,
             "h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": 9 * sum(len(s["det_boxes"]) for s in scenes),
             "synchronous_ms_per_step": 1e3 * dts,
-            "host_us_in_submit": 1e6 * host[0] / max(1, iters - 1), "host_us_in_wait": 1e6 * host[1] / max(1, iters - 1),
-            "note": "sa_pipe_submit / sa_pipe_wait, two request sets in flight (H2D of frame n+1 beside the kernels of frame n), features in a "
+            "tickets_in_flight": depth, "host_us_in_submit": 1e6 * host[0] / max(1, iters), "host_us_in_wait": 1e6 * host[1] / max(1, iters),
+            "note": "sa_pipe_submit / sa_pipe_wait, three request sets in flight (H2D of frame n+1 beside the kernels of frame n, frame n+2 queued), features in a "
                     "sa_host_alloc block, results copied out; synchronous_ms_per_step = sa_associate_batch on the same buffers"}, ids
 
 

@@ -249,8 +249,9 @@ int sa_associate_batch(sa_engine* e, uint32_t n_scenes, const sa_scene_request* 
 /* ---- pipelined request sets: H2D of frame n+1 beside the kernels of frame n ------------------------------------
  * The reference's predict() takes its detections (boxes + 512..4096-d features) from host memory every frame
  * (visual_sort/simple_api.rs:130-170).  sa_associate* does stage -> DMA -> kernels -> results one after the other; the calls
- * below keep TWO request sets in flight on two streams, so that the DMA of the next set (2 MB at 1000 x 512-d) runs beside
- * the kernels of the current one and a stream of frames costs max(DMA, kernels) instead of their sum:
+ * below keep up to THREE request sets in flight on two streams, so that the DMA of the next set (2 MB at 1000 x 512-d) runs beside
+ * the kernels of the current one — and the one after is already queued — and a stream of frames costs max(DMA, kernels) instead of
+ * their sum:
  *   sa_pipe_stage   lays the request set out in a pinned staging arena (features inside a sa_host_alloc block are not copied:
  *                   the DMA reads them in place) and queues ONE host-to-device copy on the copy stream; returns a ticket
  *   sa_pipe_launch  queues the kernels behind that copy on the compute stream; the track tables are read as they are at THIS
@@ -258,7 +259,7 @@ int sa_associate_batch(sa_engine* e, uint32_t n_scenes, const sa_scene_request* 
  *   sa_pipe_submit  = stage + launch
  *   sa_pipe_wait    blocks until the ticket's kernels have retired and copies its results out (res[i] belongs to req[i]);
  *                   afterwards slot numbers of sa_tracks_apply / sa_batch_fetch / the taps refer to this ticket's scenes
- * At most two tickets are outstanding (SA_ERR_STATE otherwise).  Buffers handed to sa_pipe_stage may be reused as soon as it
+ * At most three tickets are outstanding (SA_ERR_STATE otherwise).  Buffers handed to sa_pipe_stage may be reused as soon as it
  * returns, except feature blocks from sa_host_alloc, which must stay untouched until the ticket has been waited for.
  * A tracker loop with device-side upkeep:  stage(n+1); wait(n); apply(n); launch(n+1). */
 int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, uint64_t* out_ticket);

@@ -76,7 +76,8 @@ struct Slot {  // one scene of a request set
 
 // One request set (the scenes of one sa_associate_batch / one pipelined ticket) and everything that has to exist once per set in
 // flight.  The engine owns SA_BANKS of them: the synchronous entry points work on the current one; the pipelined entry points
-// (sa_pipe_*) alternate, so that the H2D copies of set n+1 (copy stream) overlap the kernels of set n (compute stream).
+// (sa_pipe_*) rotate through them, so that the H2D copies of set n+1 (copy stream) overlap the kernels of set n (compute stream) and
+// the copy of set n+2 is already queued behind it when the host comes back from waiting for set n.
 // Staging arena: ONE pinned host block and its device twin per bank — every scene's raw | quality | own | fpresent | features,
 // then the SceneDev descriptor array — so that a whole request set crosses PCIe in one DMA (plus one per scene whose features the
 // caller keeps in a pinned block of its own).
@@ -103,7 +104,7 @@ struct Bank {
   uint64_t ticket = 0;       // 0 = none
   int state = 0;             // 0 idle, 1 staged (H2D queued), 2 launched (pipeline queued), 3 done and waited
 };
-#define SA_BANKS 2
+#define SA_BANKS 3
 
 }  // namespace
 
@@ -1245,8 +1246,9 @@ int sa_associate(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
 }
 
 // ---- pipelined request sets ---------------------------------------------------------------------------------
-// Two banks, two streams: the H2D of ticket n+1 (copy stream) runs beside the kernels of ticket n (compute stream); the results
-// land in mapped host memory, so sa_pipe_wait is one event wait and a few-kilobyte memcpy.
+// SA_BANKS banks, two streams: the H2D of ticket n+1 (copy stream) runs beside the kernels of ticket n (compute stream), and with a
+// third ticket outstanding the copy stream never waits for the host; the results land in mapped host memory, so sa_pipe_wait is one
+// event wait and a few-kilobyte memcpy.
 static Bank* bank_of_ticket(sa_engine* e, uint64_t ticket) {
   if (!ticket) return nullptr;
   for (Bank& bk : e->banks)

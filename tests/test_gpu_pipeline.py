@@ -76,7 +76,7 @@ def test_batch_time_replays_the_staged_set():
 
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned_block"])
 def test_pipelined_tickets_match_the_synchronous_path(pinned):
-    """A stream of different frames through sa_pipe_submit / sa_pipe_wait with two tickets in flight: every frame's answer equals
+    """A stream of different frames through sa_pipe_submit / sa_pipe_wait with two (then three) tickets in flight: every frame's answer equals
     the oracle's (and therefore sa_associate's); features from pageable memory or DMA'd in place from sa_host_alloc blocks."""
     rng = np.random.default_rng(73)
     d, n, t = 128, 150, 170
@@ -108,16 +108,21 @@ def test_pipelined_tickets_match_the_synchronous_path(pinned):
             ref = O.associate(cfg, tr, 1, det, want_matrices=False)
             np.testing.assert_array_equal(outs[0][0], ref["track_id"])
             np.testing.assert_array_equal(outs[0][1], ref["voting_type"])
-        # a third ticket without waiting is refused, and so is a synchronous batch while tickets are outstanding
+        # three tickets may be outstanding (one per bank); a fourth is refused, and so is a synchronous batch meanwhile
         t1 = eng.pipe_submit(frames[0][1])
         t2 = eng.pipe_submit(frames[1][1])
+        t3 = eng.pipe_submit(frames[3][1])
         with pytest.raises(EngineError) as ei:
             eng.pipe_submit(frames[2][1])
         assert ei.value.code == abi.SA_ERR_STATE
         with pytest.raises(EngineError):
             eng.batch_begin()
+        eng.pipe_wait(t2, frames[1][2])  # any order
         eng.pipe_wait(t1, frames[0][2])
-        eng.pipe_wait(t2, frames[1][2])
+        eng.pipe_wait(t3, frames[3][2])
+        for k in (0, 1, 3):
+            ref = O.associate(cfg, tr, 1, frames[k][0], want_matrices=False)
+            np.testing.assert_array_equal(frames[k][3][0][0], ref["track_id"])
         with pytest.raises(EngineError):
             eng.pipe_wait(12345, frames[0][2])
         # the synchronous path still works afterwards and agrees
