@@ -188,7 +188,7 @@ struct SaCopySegs {
   struct Seg { const void* src; void* dst; size_t bytes; } s[SA_COPY_SEGS];
   uint32_t n;
 };
-hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st);
+hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st, hipEvent_t done = nullptr);
 hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* index, uint32_t rows, uint32_t row_bytes,
                                  hipStream_t st);
 

@@ -442,7 +442,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
 // descriptor array, which is appended to the arena so that it travels in the same DMA; a run that finds inputs and descriptors
 // unchanged (a benchmark loop) copies nothing.  `may_be_busy`: an earlier copy out of the host arena may still be queued (the
 // synchronous entry points; a pipelined bank is idle by construction).
-int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
+int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEvent_t done = nullptr, bool* done_recorded = nullptr) {
   const uint32_t ns = b->n_slots;
   const size_t dbytes = (size_t)ns * sizeof(SceneDev);
   const size_t desc_off = align_up(b->used, 256);
@@ -475,8 +475,12 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
     static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 24u;
     SaCopySegs segs;
     segs.n = 0;
-    auto flush = [&]() -> int {
-      if (segs.n) HIPCHK(e, sa_launch_ingest(segs, blocks, st));
+    auto flush = [&](bool last = false) -> int {
+      // the last launch of the upload carries the hand-over event as its own completion signal
+      static const bool own_event = getenv("SA_INGEST_EVENT") && !strcmp(getenv("SA_INGEST_EVENT"), "record");
+      const bool attach = last && done && !own_event && segs.n;
+      if (segs.n) HIPCHK(e, sa_launch_ingest(segs, blocks, st, attach ? done : nullptr));
+      if (attach && done_recorded) *done_recorded = true;
       segs.n = 0;
       return SA_OK;
     };
@@ -507,7 +511,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy) {
       Slot* s = b->slots[i];
       if (s->feats_inplace && s->N) TRY(move(s->feats_inplace, s->feats_inplace_dev, s->feat_raw.p, (size_t)s->N * e->D * 4));
     }
-    TRY(flush());
+    TRY(flush(true));
     b->uploaded = true;
   } else {
     HIPCHK(e, hipMemcpyAsync(dbase + desc_off, h + desc_off, dbytes, hipMemcpyHostToDevice, st));
@@ -806,7 +810,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
       hipEventCreateWithFlags(&e->aux_ev[k], hipEventDisableTiming);
     }
   for (Bank& bk : e->banks) {
-    hipEventCreateWithFlags(&bk.ev_staged, hipEventDisableTiming);
+    hipEventCreate(&bk.ev_staged);  // also handed to hipExtLaunchKernelGGL as the ingest dispatch's completion event
     hipEventCreateWithFlags(&bk.ev_done, hipEventDisableTiming);
   }
   if (e->visual) {
@@ -1277,8 +1281,9 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
   uint32_t maxN = 0, maxT = 0;
   TRY(bank_prepare(e, b, &maxN, &maxT));
   hipStream_t cs = e->copy_stream ? e->copy_stream : e->stream;
-  TRY(bank_upload(e, b, cs, false));
-  HIPCHK(e, hipEventRecord(b->ev_staged, cs));
+  bool recorded = false;
+  TRY(bank_upload(e, b, cs, false, b->ev_staged, &recorded));
+  if (!recorded) HIPCHK(e, hipEventRecord(b->ev_staged, cs));
   b->state = 1;
   b->ticket = e->next_ticket++;
   *out_ticket = b->ticket;

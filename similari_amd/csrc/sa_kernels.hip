@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void k_ingest(SaCopySegs segs) {
     if (blockIdx.x == 0 && threadIdx.x < tail) ((uint8_t*)dst)[(n16 << 4) + threadIdx.x] = ((const uint8_t*)src)[(n16 << 4) + threadIdx.x];
   }
 }
-hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st) {
+// `done` (optional): signalled by the dispatch's own completion — no marker packet of its own behind the kernel (a separate
+// hipEventRecord costs the copy stream ~4 us per request set: the next set's ingest is queued right behind)
+hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st, hipEvent_t done) {
   if (!segs.n) return hipSuccess;
-  hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, st, segs);
+  if (done) hipExtLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, st, nullptr, done, 0, segs);
+  else hipLaunchKernelGGL(k_ingest, dim3(blocks), dim3(256), 0, st, segs);
   return hipGetLastError();
 }
 

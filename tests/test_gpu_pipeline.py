@@ -63,9 +63,10 @@ def test_batch_time_replays_the_staged_set():
         det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
         eng.batch_begin()
         slot = eng.batch_add(0, 1, det)
-        ms1 = eng.batch_time(1)
+        ms1 = eng.batch_time(1)    # includes the one-time upload of the staged set
         ms20 = eng.batch_time(20)
-        assert ms1 > 0.0 and ms20 > ms1 * 2, (ms1, ms20)
+        ms200 = eng.batch_time(200)
+        assert ms1 > 0.0 and ms20 > 0.0 and ms200 > 3.0 * ms20, (ms1, ms20, ms200)  # replays cost time in proportion
         ids, votes = eng.batch_fetch(slot, det.n)
         ref = O.associate(cfg, tr, 1, det, want_matrices=False)
         np.testing.assert_array_equal(ids, ref["track_id"])
