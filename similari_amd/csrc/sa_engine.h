@@ -158,6 +158,14 @@ extern thread_local hipEvent_t sa_prof_start, sa_prof_stop;
     if (sa_prof_start) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                        \
   } while (0)
+// The same with hipExtAnyOrderLaunch: the dispatch does not wait for the packets queued before it on the stream (no barrier bit),
+// so it runs BESIDE the kernel launched just before it — two independent kernels of one frame side by side without a second stream
+// and its two cross-stream event waits (those cost more than the overlap gains: SA_FLAG_FORK, +5.7 us).  The next ordinary launch
+// waits for both.
+#define SA_LAUNCH_ANY_ORDER(kern, grid, block, shmem, st, ...)                                                 \
+  do {                                                                                                         \
+    hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, hipExtAnyOrderLaunch, __VA_ARGS__); \
+  } while (0)
 
 // ---- launchers (sa_kernels.hip / sa_gemm.hip).  All enqueue on `st` and return the launch status. ----
 
@@ -194,7 +202,11 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
 
 // first launch of a frame: positional tiles + frame-preparation blocks
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
-                           hipStream_t st);
+                           hipStream_t st, bool any_order = false);
+// the contraction of a small VisualSORT frame on the RAW uploaded rows (needs nothing the preparation blocks produce), so that
+// sa_launch_frame(any_order) can run beside it; hipErrorNotSupported = not applicable (same conditions as sa_launch_frame_visual)
+hipError_t sa_launch_visual_raw(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
+                                const SaParams& p, hipStream_t st, bool partials);
 hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices, hipStream_t st);
 hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                       const SaParams& p, hipStream_t st);

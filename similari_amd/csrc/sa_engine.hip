@@ -20,11 +20,11 @@ thread_local std::string g_create_error;
 
 enum KernelId {
   KID_FRAME = 0, KID_FRAME_VISUAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
-  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_COUNT
+  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_VISUAL_RAW, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
     "k_frame", "k_frame_visual", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
-    "k_assign_label", "k_assign_solve", "d2h_results"};
+    "k_assign_label", "k_assign_solve", "d2h_results", "k_visual_raw"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -539,21 +539,34 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   P.eu_rho = e->eu_rho;
   SaParams Pt = P;                         // k_bestfit_tile: the words of deeper banks
   Pt.vote_words = b->words == 2 ? 1u : 0u;
-  // launch 1 (VisualSORT, small frames): contraction tiles + positional tiles + frame-preparation blocks in ONE heterogeneous
-  // launch; otherwise positional tiles + preparation blocks, then the contraction
-  bool fused = false;
-  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->f16_split) {
-    ProfScope ps(e, KID_FRAME_VISUAL);
-    bool all_feats = true;
-    for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
-    hipError_t fe = all_feats ? sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials) : hipErrorNotSupported;
-    if (fe == hipSuccess) fused = true;
-    else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
-    else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
+  // First phase of a small VisualSORT frame (at most 1024 x 1024, feature length a multiple of 32): the contraction on the raw rows
+  // with two k-groups per tile, and k_frame (positional tiles + preparation blocks) launched right behind it without the barrier bit:
+  // the two kernels run side by side on one stream (SA_FIRST_PHASE=fused: the ONE heterogeneous launch of round 1, whose contraction
+  // tiles had to run one k-group; =serial: one after the other).  Bigger or padded frames: k_frame, then the contraction.
+  static const char* fp_env = getenv("SA_FIRST_PHASE");
+  const bool want_fused = fp_env ? !strcmp(fp_env, "fused") : (e->cfg.flags & SA_FLAG_FUSED_FRAME) != 0;
+  const bool want_serial = (fp_env && !strcmp(fp_env, "serial")) || ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile);  // (a captured graph keeps the launches in order)
+  bool fused = false, side_by_side = false;
+  bool all_feats = e->visual;
+  for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
+  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->f16_split && all_feats && !want_serial) {
+    if (want_fused) {
+      ProfScope ps(e, KID_FRAME_VISUAL);
+      hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials);
+      if (fe == hipSuccess) fused = true;
+      else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
+      else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
+    } else {
+      ProfScope ps(e, KID_VISUAL_RAW);
+      hipError_t fe = sa_launch_visual_raw(ds, ns, maxN, maxT, e->K, e->D, P, st, partials);
+      if (fe == hipSuccess) side_by_side = true;
+      else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
+      else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
+    }
   }
-  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st)); }
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, side_by_side)); }
   if (e->visual) {
-    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
+    if (!fused && !side_by_side) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
     if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }

@@ -1019,6 +1019,18 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
   visual_cosine_tile<BM, BN, KGT, false, PART, H2, EU>(S, p, bx, by, lds);
 }
 
+// The contraction of a small frame on the RAW uploaded rows with two k-groups per 64 x 64 tile (512 threads, 64 KB: two waves per
+// SIMD), as a kernel of its own that needs nothing the preparation blocks produce: k_frame is then launched right behind it WITHOUT
+// the barrier bit (hipExtAnyOrderLaunch) and the two run side by side — the contraction keeps its two-k-group main loop (what the
+// heterogeneous launch below had to give up: every block of ONE launch shares one LDS size), the positional tiles and the
+// preparation blocks fill what it leaves, and there is still no second stream.
+template <int KG, bool PART, bool EU>
+__global__ __launch_bounds__(256 * KG) void k_visual_cosine_raw(const SceneDev* __restrict__ scenes, SaParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  visual_cosine_tile<64, 64, KG, true, PART, false, EU>(S, p, blockIdx.x, blockIdx.y, lds);
+}
+
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
 //   n_gemm            : a 64x64 tile of the feature contraction (matrix cores; raw-feature mode, see visual_cosine_tile)
 //   n_gemm + n_prep   : a frame-preparation block (padded features + norms for the upkeep and the taps, vote-state reset)
@@ -1483,6 +1495,24 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
     if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
     else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
   }
+  return hipGetLastError();
+}
+
+hipError_t sa_launch_visual_raw(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
+                                const SaParams& p, hipStream_t st, bool partials) {
+  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const uint32_t maxTK = maxT * K;
+  const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
+  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
+  const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
+  if (plan != 2 && plan != 4) return hipErrorNotSupported;
+  sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
+  const dim3 grid(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
+  if (eu) {
+    if (partials) SA_LAUNCH((k_visual_cosine_raw<2, true, true>), grid, dim3(512), 0, st, scenes, p);
+    else SA_LAUNCH((k_visual_cosine_raw<2, false, true>), grid, dim3(512), 0, st, scenes, p);
+  } else if (partials) SA_LAUNCH((k_visual_cosine_raw<2, true, false>), grid, dim3(512), 0, st, scenes, p);
+  else SA_LAUNCH((k_visual_cosine_raw<2, false, false>), grid, dim3(512), 0, st, scenes, p);
   return hipGetLastError();
 }
 
