@@ -158,10 +158,10 @@ extern thread_local hipEvent_t sa_prof_start, sa_prof_stop;
     if (sa_prof_start) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                        \
   } while (0)
-// The same with hipExtAnyOrderLaunch: the dispatch does not wait for the packets queued before it on the stream (no barrier bit),
-// so it runs BESIDE the kernel launched just before it — two independent kernels of one frame side by side without a second stream
-// and its two cross-stream event waits (those cost more than the overlap gains: SA_FLAG_FORK, +5.7 us).  The next ordinary launch
-// waits for both.
+// The same with hipExtAnyOrderLaunch: documented as "the dispatch does not wait for the packets queued before it on the stream",
+// which would let two independent kernels of one frame run side by side without a second stream and its two cross-stream event
+// waits (those cost more than the overlap gains: SA_FLAG_FORK, +5.7 us).  Measured on this stack (ROCm 7.2, MI355X): the second
+// dispatch still starts when the first ends.  Kept for SA_FIRST_PHASE=any_order (measurement).
 #define SA_LAUNCH_ANY_ORDER(kern, grid, block, shmem, st, ...)                                                 \
   do {                                                                                                         \
     hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, hipExtAnyOrderLaunch, __VA_ARGS__); \

@@ -539,13 +539,16 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   P.eu_rho = e->eu_rho;
   SaParams Pt = P;                         // k_bestfit_tile: the words of deeper banks
   Pt.vote_words = b->words == 2 ? 1u : 0u;
-  // First phase of a small VisualSORT frame (at most 1024 x 1024, feature length a multiple of 32): the contraction on the raw rows
-  // with two k-groups per tile, and k_frame (positional tiles + preparation blocks) launched right behind it without the barrier bit:
-  // the two kernels run side by side on one stream (SA_FIRST_PHASE=fused: the ONE heterogeneous launch of round 1, whose contraction
-  // tiles had to run one k-group; =serial: one after the other).  Bigger or padded frames: k_frame, then the contraction.
+  // First phase of a small VisualSORT frame (at most 1024 x 1024, feature length a multiple of 32): contraction tiles + positional
+  // tiles + frame-preparation blocks in ONE heterogeneous launch; otherwise positional tiles + preparation blocks, then the
+  // contraction.  SA_FIRST_PHASE=any_order (measurement): the contraction on the raw rows with two k-groups per tile as a kernel of
+  // its own and k_frame launched right behind it with hipExtAnyOrderLaunch — meant to run side by side on one stream; on this stack
+  // (ROCm 7.2) the second dispatch still starts when the first ends (rocprofv3 timeline), so it is not the default.
+  // SA_FIRST_PHASE=serial: k_frame, then the contraction (what SA_FLAG_SEPARATE_FRAME asks for per engine).
   static const char* fp_env = getenv("SA_FIRST_PHASE");
-  const bool want_fused = fp_env ? !strcmp(fp_env, "fused") : (e->cfg.flags & SA_FLAG_FUSED_FRAME) != 0;
-  const bool want_serial = (fp_env && !strcmp(fp_env, "serial")) || ((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile);  // (a captured graph keeps the launches in order)
+  const bool want_any_order = fp_env && !strcmp(fp_env, "any_order") && !((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile);
+  const bool want_fused = !want_any_order;
+  const bool want_serial = fp_env && !strcmp(fp_env, "serial");
   bool fused = false, side_by_side = false;
   bool all_feats = e->visual;
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;

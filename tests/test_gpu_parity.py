@@ -114,11 +114,12 @@ def test_general_assignment_tail_matches_oracle_too():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2", "SA_FIRST_PHASE": "fused"}, {"SA_FIRST_PHASE": "fused"}, {"SA_FIRST_PHASE": "serial"}, {"SA_GEMM_BAND": "4"},
+@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_FIRST_PHASE": "any_order"}, {"SA_FIRST_PHASE": "serial"}, {"SA_GEMM_BAND": "4"},
                                  {"SA_POS_WIDE": "0"}, {"SA_POS_WIDE": "1"}])
 def test_first_phase_tile_variants_match_oracle_too(env):
-    """SA_FIRST_PHASE=fused: the ONE heterogeneous launch of round 1 instead of the contraction and k_frame side by side (=serial: one
-    after the other); SA_FRAME_KG=2: that launch with two k-groups per contraction tile (512-thread blocks); SA_GEMM_BAND=n: the
+    """SA_FIRST_PHASE=any_order: the raw two-k-group contraction as a kernel of its own with k_frame launched behind it without the
+    barrier bit (=serial: k_frame, then the contraction) instead of the ONE heterogeneous launch; SA_FRAME_KG=2: that launch with two
+    k-groups per contraction tile (512-thread blocks); SA_GEMM_BAND=n: the
     XCD-aware band order of the contraction's tiles; SA_POS_WIDE=0|1: narrow / wide positional tiles regardless of the frame.  None
     is the default rule (all measured slower or equal); all must still give the oracle's answers."""
     import os
@@ -418,7 +419,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
-@pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "side_by_side"])
+@pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "default"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
 def test_visual_cosine_parity(k, n, t, d, fused):
@@ -524,8 +525,8 @@ def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_cond
             assert (np.abs(vis - ref["visual"]) <= 1e-5 * np.abs(ref["visual"])).all(), f"frame {f}"
             np.testing.assert_array_equal(ids, ref["track_id"])
             np.testing.assert_array_equal(ids, sc["truth"])
-        assert "k_visual_raw" in kernels[0], kernels            # the first frames: the matrix-core contraction (beside k_frame)
-        assert "k_visual_cost" in kernels[-1] and "k_visual_raw" not in kernels[-1], kernels    # after the report: the vector-pipe kernel
+        assert "k_frame_visual" in kernels[0], kernels          # the first frames: contraction tiles inside the heterogeneous launch
+        assert "k_visual_cost" in kernels[-1] and "k_frame_visual" not in kernels[-1], kernels  # after the report: the vector-pipe kernel
     finally:
         eng.close()
     sc2 = synth.visual_scene(rng, t, n, d, 1, canvas=(3000.0, 3000.0))
@@ -538,7 +539,7 @@ def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_cond
         for _ in range(4):
             eng.profile_reset()
             eng.associate(0, 1, det)
-            assert "k_visual_raw" in eng.profile_read()
+            assert "k_frame_visual" in eng.profile_read()
     finally:
         eng.close()
 
