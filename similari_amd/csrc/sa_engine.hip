@@ -472,7 +472,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
     // the device mapping of every source and 16-byte alignment
     static const bool sdma4 = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4");
     static const bool sdma = sdma4 || (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma"));
-    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 24u;
+    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") && atoi(getenv("SA_INGEST_BLOCKS")) > 0 ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 24u;
     SaCopySegs segs;
     segs.n = 0;
     auto flush = [&](bool last = false) -> int {
@@ -586,7 +586,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
 // The whole per-frame device pipeline for a bank's request set: upload (through `up`: the compute stream itself, or the copy
 // stream with the hand-over event of the pipelined entry points) and 2-6 launches (enqueue_frame) on the compute stream, no
 // host decisions in between.
-int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out) {
+int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, bool count_frame = true) {
   const uint32_t ns = b->n_slots;
   uint32_t maxN = 0, maxT = 0;
   for (uint32_t i = 0; i < ns; ++i) {
@@ -603,7 +603,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out) 
   static const bool eu_off = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "valu");   // measurements / tests: always the vector-pipe kernel
   static const bool eu_force = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "mfma");  // ... always the contraction
   b->eu_mfma = euclid && e->eu_mfma_ok && !eu_off && (e->eu_valu_left == 0 || eu_force);
-  if (euclid && e->eu_valu_left) --e->eu_valu_left;
+  if (euclid && e->eu_valu_left && count_frame) --e->eu_valu_left;
   b->partials = e->bf_partials || (b->eu_mfma && e->bf_words_euclid);
   if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, &b->tile_bm, &b->tile_bn);
   {
@@ -1295,7 +1295,7 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
     if (rc != SA_OK) { bank_clear(b); return rc; }
   }
   uint32_t maxN = 0, maxT = 0;
-  TRY(bank_prepare(e, b, &maxN, &maxT));
+  TRY(bank_prepare(e, b, &maxN, &maxT, false));  // sa_pipe_launch prepares again (the tables may change in between) and counts the frame
   hipStream_t cs = e->copy_stream ? e->copy_stream : e->stream;
   bool recorded = false;
   TRY(bank_upload(e, b, cs, false, b->ev_staged, &recorded));
