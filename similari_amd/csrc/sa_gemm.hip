@@ -1471,10 +1471,16 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
-  if (plan != 2 && plan != 4) return hipErrorNotSupported;
+  // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
+  // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
+  if (plan != 1 && plan != 2 && plan != 4 && plan != 7) return hipErrorNotSupported;
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  {
+    static const bool skip_prep = getenv("SA_SKIP_PREP") != nullptr;  // MEASUREMENT ONLY (vote-words frames: nothing on the hot path reads what the preparation blocks write)
+    if (skip_prep) prep_blocks = 0;
+  }
   sa_trace_hook(st, gx * gy + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is

@@ -214,6 +214,29 @@ __global__ __launch_bounds__(256) void k_bestfit_tile(const SceneDev* __restrict
         if (x[r][k] == x[r][k]) { ++cnt; w += (double)(max_dist - x[r][k]); }  // k ascending: the reference's summation order
       Wr[r] = (cnt >= 1 && cnt >= p.min_votes) ? w : -1.0;
     }
+  } else if (K <= 8) {
+    // the reference's default depth is 5 (visual_sort/options.rs:194-205): the same, eight rows at a time (64 loads in flight per lane)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float x[8][8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t q = q0 + h * 8 + r;
+        const bool in = q < N && t < T;
+        const float SA_G* v = S.vis + ((size_t)(in ? q : 0) * T + (in ? t : 0)) * K;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[r][k] = (in && (uint32_t)k < K) ? v[k] : __builtin_nanf("");
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t cnt = 0;
+        double w = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (x[r][k] == x[r][k]) { ++cnt; w += (double)(max_dist - x[r][k]); }  // k ascending: the reference's summation order
+        Wr[h * 8 + r] = (cnt >= 1 && cnt >= p.min_votes) ? w : -1.0;
+      }
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
