@@ -201,8 +201,10 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
                                  hipStream_t st);
 
 // first launch of a frame: positional tiles + frame-preparation blocks
+// prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame), 2 = preparation blocks only (what a lean
+// frame left out, on demand: sa_tracks_apply, the visual tap)
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
-                           hipStream_t st, bool any_order = false);
+                           hipStream_t st, bool any_order = false, int prep = 1);
 // the contraction of a small VisualSORT frame on the RAW uploaded rows (needs nothing the preparation blocks produce), so that
 // sa_launch_frame(any_order) can run beside it; hipErrorNotSupported = not applicable (same conditions as sa_launch_frame_visual)
 hipError_t sa_launch_visual_raw(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
@@ -215,7 +217,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 // heterogeneous first phase of a VisualSORT frame (contraction tiles + positional tiles + preparation blocks in one launch);
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials);
+                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep = true);
 void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);

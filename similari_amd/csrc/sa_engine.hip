@@ -71,6 +71,7 @@ struct Slot {  // one scene of a request set
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   bool ran = false;
+  bool prepped = true;     // the frame-preparation blocks ran with the frame (false: a lean frame left them out; ensure_prepped runs them on demand)
   bool needs_init = true;  // e_cnt / u / parent were (re)allocated, or a run may have died half-way: k_slot_init before the next frame
 };
 
@@ -520,6 +521,24 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   return SA_OK;
 }
 
+// What a lean frame left out (enqueue_frame), on demand: the preparation blocks of the bank's scenes as a launch of their own.
+int ensure_prepped(sa_engine* e, Bank* b) {
+  bool need = false;
+  uint32_t maxN = 0, maxT = 0;
+  for (uint32_t i = 0; i < b->n_slots; ++i) {
+    Slot* s = b->slots[i];
+    need = need || (s->ran && !s->prepped);
+    maxN = s->N > maxN ? s->N : maxN;
+    maxT = s->T > maxT ? s->T : maxT;
+  }
+  if (!need) return SA_OK;
+  const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
+  HIPCHK(e, sa_launch_frame(ds, b->n_slots, maxN, maxT, e->visual ? 1 : 0, e->P, e->stream, false, 2));
+  for (uint32_t i = 0; i < b->n_slots; ++i) b->slots[i]->prepped = true;
+  e->synced = false;
+  return SA_OK;
+}
+
 // The per-frame launches for the staged scenes, in order, on the engine's stream (and, when `fork`, the positional kernel on
 // the side stream between two events).  Also the body of the captured graph.
 int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
@@ -549,13 +568,21 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   const bool want_any_order = fp_env && !strcmp(fp_env, "any_order") && !((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile);
   const bool want_fused = !want_any_order;
   const bool want_serial = fp_env && !strcmp(fp_env, "serial");
+  // A LEAN frame leaves the preparation blocks out of its first phase (C2: 23.0 -> 20.8 us per frame).  They derive the candidates'
+  // geometry / usability / padded features + norms and reset the state of the general tail and of the resolve kernel; the positional
+  // tiles and the raw-row contraction derive what they need from the uploaded records themselves, the one-workgroup tail with vote
+  // words keeps its state in LDS — so on such frames nothing reads them.  What does (sa_tracks_apply's feature-bank step, the
+  // visual tap) calls ensure_prepped first.
+  static const bool never_lean = getenv("SA_LEAN") && !strcmp(getenv("SA_LEAN"), "0");
+  const bool lean_ok = small_tail && !never_lean && (!e->visual || words);
+  bool with_prep = !lean_ok;
   bool fused = false, side_by_side = false;
   bool all_feats = e->visual;
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
   if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->f16_split && all_feats && !want_serial) {
     if (want_fused) {
       ProfScope ps(e, KID_FRAME_VISUAL);
-      hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials);
+      hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep);
       if (fe == hipSuccess) fused = true;
       else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
       else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
@@ -567,7 +594,9 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
       else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
     }
   }
-  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, side_by_side)); }
+  if (e->visual && !fused && !side_by_side) with_prep = true;  // the stand-alone contraction reads the padded features, norms and gates
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, side_by_side, with_prep ? 1 : 0)); }
+  for (uint32_t i = 0; i < ns; ++i) b->slots[i]->prepped = with_prep;
   if (e->visual) {
     if (!fused && !side_by_side) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
     if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
@@ -1359,6 +1388,7 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   const uint32_t n = s->N, K = e->K;
   if (!n) return SA_OK;
   if (s->T != sc->T) return fail(e, SA_ERR_STATE, "the scene's track table changed since the slot ran");
+  if (e->visual) TRY(ensure_prepped(e, e->B));  // the feature-bank step reads the candidates' padded rows and norms
   const uint64_t* winners = (const uint64_t*)s->h_out.p;
   sc->full.resize(sc->T, 0);
   uint32_t n_new = 0;
@@ -1628,6 +1658,7 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
   if (!out) return fail(e, SA_ERR_BAD_ARG, "null output");
   size_t bytes = (size_t)s->N * s->T * e->K * 4;
   if (!bytes) return SA_OK;
+  TRY(ensure_prepped(e, e->B));
   if (e->B->partials || e->bf_words_euclid) {
     // the product path never wrote the weight matrix (euclidean: not on frames that used the vote words — re-running is harmless otherwise): run the contraction once more, in matrix mode, on the slot's resident inputs
     SceneDev h;

@@ -1465,7 +1465,7 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 // one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
 // it does not apply: the caller falls back to k_frame + k_visual_cost.
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials) {
+                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
@@ -1477,10 +1477,7 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
-  {
-    static const bool skip_prep = getenv("SA_SKIP_PREP") != nullptr;  // MEASUREMENT ONLY (vote-words frames: nothing on the hot path reads what the preparation blocks write)
-    if (skip_prep) prep_blocks = 0;
-  }
+  if (!with_prep) prep_blocks = 0;  // lean frame: nothing on its path reads what the preparation blocks write (enqueue_frame)
   sa_trace_hook(st, gx * gy + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is

@@ -939,15 +939,17 @@ hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uin
 }
 // First launch of a frame: positional tiles + frame-preparation blocks (see k_frame).
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
-                           hipStream_t st, bool any_order) {
+                           hipStream_t st, bool any_order, int prep) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   static const char* wide_env = getenv("SA_POS_WIDE");  // measurements: 0 / 1 force the narrow / wide positional tiles
   const bool wide = wide_env ? wide_env[0] == '1' : (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
   const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
-  const uint32_t pos_rows = (maxN && maxT) ? cdiv(maxN, POS_TI) : 0u;
+  const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (visual && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  if (prep == 0) prep_blocks = 0;
+  if (!pos_rows && !prep_blocks) return hipSuccess;
   const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
   if (any_order) {  // beside the contraction launched just before (enqueue_frame): small frames, one-workgroup tail
     if (wide) SA_LAUNCH_ANY_ORDER((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);

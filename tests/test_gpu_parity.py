@@ -114,11 +114,12 @@ def test_general_assignment_tail_matches_oracle_too():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_FIRST_PHASE": "any_order"}, {"SA_FIRST_PHASE": "serial"}, {"SA_GEMM_BAND": "4"},
+@pytest.mark.parametrize("env", [{"SA_FRAME_KG": "2"}, {"SA_FIRST_PHASE": "any_order"}, {"SA_FIRST_PHASE": "serial"}, {"SA_LEAN": "0"}, {"SA_GEMM_BAND": "4"},
                                  {"SA_POS_WIDE": "0"}, {"SA_POS_WIDE": "1"}])
 def test_first_phase_tile_variants_match_oracle_too(env):
     """SA_FIRST_PHASE=any_order: the raw two-k-group contraction as a kernel of its own with k_frame launched behind it without the
-    barrier bit (=serial: k_frame, then the contraction) instead of the ONE heterogeneous launch; SA_FRAME_KG=2: that launch with two
+    barrier bit (=serial: k_frame, then the contraction) instead of the ONE heterogeneous launch; SA_LEAN=0: the preparation blocks in
+    every frame (by default frames whose path does not read them leave them out); SA_FRAME_KG=2: that launch with two
     k-groups per contraction tile (512-thread blocks); SA_GEMM_BAND=n: the
     XCD-aware band order of the contraction's tiles; SA_POS_WIDE=0|1: narrow / wide positional tiles regardless of the frame.  None
     is the default rule (all measured slower or equal); all must still give the oracle's answers."""
