@@ -681,15 +681,36 @@ struct sa_coop_ws {
   uint32_t* clist;   // room for every column of the component: the labelled columns of the running search
 };
 
+// Where the solver's state lives.  sa_mem_plain: LDS (or host memory in the emulation) — a wave's LDS traffic is processed in order,
+// only the compiler has to be held.  sa_mem_agent (device only): HBM shared by the lanes of ONE wave — every access goes to L2
+// (relaxed, agent scope: never a stale line of the CU's L1) and a sync point waits for the wave's outstanding stores.
+template <int G>
+struct sa_mem_plain {
+  template <class T> static SA_COOP_FN T ld(const T* p) { return *p; }
+  template <class T> static SA_COOP_FN void st(T* p, T v) { *p = v; }
+  static SA_COOP_FN void sync() { sa_coop_sync<G>(); }
+};
+#if defined(__HIPCC__)
+template <int G>
+struct sa_mem_agent {
+  template <class T> static __device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  template <class T> static __device__ __forceinline__ void st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  static __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+#endif
+
 // Relax the usable edges of `row` (which entered the tree at distance `base`): G edges per step.  Columns labelled for the first
 // time in this search are appended to clist (ballot + prefix: append order = edge order, irrelevant to any decision).
-template <int G>
+template <int G, class M = sa_mem_plain<G>>
 SA_COOP_FN void sa_coop_relax(const sa_coop_ws& w, uint32_t row, int64_t base, uint32_t stamp, uint32_t* len) {
   const uint32_t cnt = w.e_cnt[row];
   const size_t first = w.e_off ? (size_t)w.e_off[row] : (size_t)row * w.estride;
   const uint32_t* cols = w.e_col + first * w.rcs;
   const int64_t* gains = w.e_gain + first * w.rgs;
-  const int64_t ur = w.u[row];
+  const int64_t ur = M::ld(w.u + row);
   for (uint32_t e0 = 0; e0 < cnt; e0 += G) {
     bool fresh[SA_COOP_SLOTS(G)];
     uint32_t col[SA_COOP_SLOTS(G)];
@@ -699,16 +720,16 @@ SA_COOP_FN void sa_coop_relax(const sa_coop_ws& w, uint32_t row, int64_t base, u
       uint32_t j = 0;
       if (e < cnt) {
         j = cols[(size_t)e * w.ecs];
-        if (!(w.excluded && w.excluded[j]) && w.cscan[j] != stamp) {
-          const int64_t d = base + (-gains[(size_t)e * w.egs] - ur - w.v[j]);
-          if (w.cstamp[j] != stamp) {
-            w.cstamp[j] = stamp;
-            w.dist[j] = d;
-            w.pred[j] = (int32_t)row;
+        if (!(w.excluded && w.excluded[j]) && M::ld(w.cscan + j) != stamp) {
+          const int64_t d = base + (-gains[(size_t)e * w.egs] - ur - M::ld(w.v + j));
+          if (M::ld(w.cstamp + j) != stamp) {
+            M::st(w.cstamp + j, stamp);
+            M::st(w.dist + j, d);
+            M::st(w.pred + j, (int32_t)row);
             f = true;
-          } else if (d < w.dist[j]) {
-            w.dist[j] = d;
-            w.pred[j] = (int32_t)row;
+          } else if (d < M::ld(w.dist + j)) {
+            M::st(w.dist + j, d);
+            M::st(w.pred + j, (int32_t)row);
           }
         }
       }
@@ -719,31 +740,31 @@ SA_COOP_FN void sa_coop_relax(const sa_coop_ws& w, uint32_t row, int64_t base, u
     SA_COOP_FOR(G, l) {
       uint32_t tot;
       const uint32_t r = sa_coop_rank<G>(fresh, l, &tot);
-      if (fresh[SA_COOP_SLOT(l)]) w.clist[*len + r] = col[SA_COOP_SLOT(l)];
+      if (fresh[SA_COOP_SLOT(l)]) M::st(w.clist + (*len + r), col[SA_COOP_SLOT(l)]);
       added = tot;
     }
     *len += added;
-    sa_coop_sync<G>();
+    M::sync();
   }
 }
 
 // Solves one component: `roots` = its rows the greedy start left unmatched (ascending), n_roots of them.  Rows matched by the
 // greedy start hold their heaviest usable edge (tight under u = -max gain, v = 0), so the duals are feasible on entry.
-template <int G>
+template <int G, class M = sa_mem_plain<G>>
 SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* roots, uint32_t n_roots) {
   for (uint32_t ri = 0; ri < n_roots; ++ri) {
     const uint32_t root = roots[ri];
     const uint32_t stamp = root + 1u;
     uint32_t len = 0;
-    int64_t best_term = -w.u[root];  // reduced cost of the root's own self column
+    int64_t best_term = -M::ld(w.u + root);  // reduced cost of the root's own self column
     int32_t term_row = (int32_t)root;
     int32_t end_col = -1;
     int64_t delta = best_term;
-    sa_coop_relax<G>(w, root, 0, stamp, &len);
+    sa_coop_relax<G, M>(w, root, 0, stamp, &len);
     // (every pass of the loop scans one more column of the component, every step of the augmentation walks one more tree row: the
     // caps below can only bite if the state were corrupted — then the kernel ends with a wrong answer the tests catch instead of
     // spinning on a GPU box)
-    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+    for (uint32_t guard = 0; guard < 65536u; ++guard) {
       // nearest labelled, unscanned column (ties: lowest column index): one strided pass + a lane reduction
       int64_t pd[SA_COOP_SLOTS(G)];
       int32_t pj[SA_COOP_SLOTS(G)];
@@ -751,9 +772,9 @@ SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* ro
         int64_t bd = 0;
         int32_t bj = -1;
         for (uint32_t k = l; k < len; k += G) {
-          const int32_t j = (int32_t)w.clist[k];
-          if (w.cscan[j] == stamp) continue;
-          const int64_t d = w.dist[j];
+          const int32_t j = (int32_t)M::ld(w.clist + k);
+          if (M::ld(w.cscan + j) == stamp) continue;
+          const int64_t d = M::ld(w.dist + j);
           if (bj < 0 || d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
         }
         pd[SA_COOP_SLOT(l)] = bd;
@@ -763,46 +784,46 @@ SA_COOP_FN void sa_assign_component_coop(const sa_coop_ws& w, const uint32_t* ro
       int32_t bj;
       sa_coop_min<G>(pd, pj, &bd, &bj);
       if (bj < 0 || bd >= best_term) { delta = best_term; break; }  // a self column ends the path
-      w.cscan[bj] = stamp;
-      const int32_t i = w.cmatch[bj];
+      SA_COOP_FOR(G, l) { if (l == 0) M::st(w.cscan + bj, stamp); }
+      const int32_t i = M::ld(w.cmatch + bj);
       if (i < 0) { end_col = bj; delta = bd; break; }               // free real column
-      const int64_t t = bd + (-w.u[i]);
+      const int64_t t = bd + (-M::ld(w.u + i));
       if (t < best_term) { best_term = t; term_row = i; }
-      sa_coop_sync<G>();
-      sa_coop_relax<G>(w, (uint32_t)i, bd, stamp, &len);
+      M::sync();
+      sa_coop_relax<G, M>(w, (uint32_t)i, bd, stamp, &len);
     }
-    sa_coop_sync<G>();
+    M::sync();
     // dual update.  A tree row other than the root entered through the scanned column it is matched to, at that column's
     // distance: u[cmatch[j]] += delta - dist[j], v[j] += dist[j] - delta over the scanned columns; the root moves by delta.
     SA_COOP_FOR(G, l) {
       for (uint32_t k = l; k < len; k += G) {
-        const uint32_t j = w.clist[k];
-        if (w.cscan[j] != stamp) continue;
-        const int64_t dj = w.dist[j];
-        w.v[j] += dj - delta;
-        const int32_t i = w.cmatch[j];
-        if (i >= 0) w.u[i] += delta - dj;
+        const uint32_t j = M::ld(w.clist + k);
+        if (M::ld(w.cscan + j) != stamp) continue;
+        const int64_t dj = M::ld(w.dist + j);
+        M::st(w.v + j, M::ld(w.v + j) + (dj - delta));
+        const int32_t i = M::ld(w.cmatch + j);
+        if (i >= 0) M::st(w.u + i, M::ld(w.u + i) + (delta - dj));
       }
-      if (l == 0) w.u[root] += delta;
+      if (l == 0) M::st(w.u + root, M::ld(w.u + root) + delta);
     }
-    sa_coop_sync<G>();
+    M::sync();
     // augment (a short dependent chain: every lane walks it, lane 0 writes)
     int32_t j;
     if (end_col >= 0) j = end_col;
     else {
       if (term_row == (int32_t)root) continue;  // root keeps its self column
-      j = w.rmatch[term_row];                   // term_row falls back to self and frees its column
-      sa_coop_sync<G>();
-      SA_COOP_FOR(G, l) { if (l == 0) w.rmatch[term_row] = -1; }
+      j = M::ld(w.rmatch + term_row);           // term_row falls back to self and frees its column
+      M::sync();
+      SA_COOP_FOR(G, l) { if (l == 0) M::st(w.rmatch + term_row, (int32_t)-1); }
     }
-    for (uint32_t guard = 0; guard < 4096u; ++guard) {
-      const int32_t i = w.pred[j];
-      const int32_t prev = w.rmatch[i];
-      sa_coop_sync<G>();
-      SA_COOP_FOR(G, l) { if (l == 0) { w.rmatch[i] = j; w.cmatch[j] = i; } }
+    for (uint32_t guard = 0; guard < 65536u; ++guard) {
+      const int32_t i = M::ld(w.pred + j);
+      const int32_t prev = M::ld(w.rmatch + i);
+      M::sync();
+      SA_COOP_FOR(G, l) { if (l == 0) { M::st(w.rmatch + i, j); M::st(w.cmatch + j, i); } }
       if (i == (int32_t)root || prev < 0) break;
       j = prev;
     }
-    sa_coop_sync<G>();
+    M::sync();
   }
 }

@@ -110,7 +110,13 @@ struct SceneDev {
   uint32_t SA_G* cscan;
   int32_t SA_G* cnext;
   int64_t SA_G* rdist;
-  int32_t SA_G* rnext;
+  int32_t SA_G* rnext;       // [N] general tail: rows in the component rooted at this row
+  uint32_t SA_G* lab;        // [N] general tail: component root of the row (SA_NONE: takes no part)
+  uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column
+  uint32_t SA_G* big_rows;   // [N] rows of the big components, one ascending segment each
+  uint32_t SA_G* big_roots;  // [N] their search roots
+  uint32_t SA_G* big_bcol;   // [N] the column a row bids for
+  uint32_t SA_G* big_clist;  // [waves of k_assign_solve][T] labelled columns of a wave's running search
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t SA_G* out_track_id;
   uint8_t SA_G* out_vote;

@@ -66,6 +66,7 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
     S.cmatch[i] = -1;
     S.cstamp[i] = 0;
     S.cscan[i] = 0;
+    S.cwin[i] = SA_NONE;   // greedy bids of the big-component solver (k_assign_solve)
   }
   if (i < N) {
     S.vis_winner[i] = -1;
@@ -73,6 +74,7 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
     S.rmatch[i] = -1;
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
+    S.rnext[i] = 0;        // rows per component, counted by k_assign_label
     BoxRaw r = sa_ldg(S.c_raw + i);
     prep_box_common(r, (sa_geo*)(S.c_geo + i), (double*)(S.c_verts + (size_t)i * 8));
     const sa_box& b = r.box;

@@ -370,22 +370,10 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // strictly needed — harmless, it is still solved exactly.
 //   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
 //            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
-//   else: k_assign_label (component root per row, rows pushed onto their root's list), k_assign_solve (one thread per
-//            component: orders its rows, solves, writes their results).
+//   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a component of
+//            at most 8 rows: one lane in a private block of LDS; larger: the whole wavefront, greedy start + cooperative
+//            augmenting paths on state in HBM).
 // =====================================================================================================
-__device__ __forceinline__ sa_assign_ws make_ws(const SceneDev& S) {
-  sa_assign_ws w;
-  w.e_cnt = S.e_use; w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.rcs = 4; w.rgs = 2;
-  w.estride = S.estride; w.e_off = nullptr;
-  w.excluded = S.col_excluded;
-  w.next_row = S.next_row;
-  w.u = S.u_use; w.v = S.v; w.rmatch = S.rmatch; w.cmatch = S.cmatch;
-  w.dist = S.dist; w.pred = S.pred; w.cstamp = S.cstamp; w.cscan = S.cscan; w.cnext = S.cnext;
-  w.rdist = S.rdist; w.rnext = S.rnext;
-  return w;
-}
-
-
 // In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
 // thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
 #ifdef SA_TAIL_TRACE
@@ -769,8 +757,11 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   S.e_cnt[q] = 0;
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (!cnt || S.row_has[q]) return;
+  if (q == 0) { S.stats[1] = 0u; S.stats[2] = 0u; }  // tops of the big-component row / root lists of k_assign_solve
+  if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
+  S.lab[q] = root;
+  atomicAdd((uint32_t*)(S.rnext + root), 1u);  // rows in the component (rnext is zeroed by the preparation blocks)
   S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
 }
 
@@ -803,6 +794,85 @@ __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q,
   S.out_vote[q] = vt;
   S.win_col[q] = win;
 }
+// A component too large for a lane's private block: the whole wavefront solves it, state in HBM (every access through L2,
+// sa_mem_agent), the same greedy start + cooperative shortest augmenting paths as the one-workgroup tail:
+//   rows of the component in ascending order by ballot compaction of the scene's row labels; every row bids for the column of its
+//   heaviest usable edge (global atomic minimum on cwin, reset by the preparation blocks); rows that lost are the search roots;
+//   sa_assign_component_coop<64, sa_mem_agent>; results.  Slower per step than LDS (an L2 round trip per dependent access) but a
+//   crowd of thousands costs milliseconds, where one lane's chain of those round trips cost seconds.
+template <bool VISUAL>
+__device__ __forceinline__ void solve_big_component(const SceneDev& S, uint32_t root, uint32_t lane) {
+  using M = sa_mem_agent<64>;
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t R = (uint32_t)S.rnext[root];
+  uint32_t seg[2];
+  if (lane == 0) { seg[0] = atomicAdd((uint32_t*)(S.stats + 1), R); seg[1] = atomicAdd((uint32_t*)(S.stats + 2), R); }
+  const uint32_t rbase = sa_coop_bcast<64>(seg), qbase = sa_coop_bcast<64>(seg + 1);
+  uint32_t* rows = (uint32_t*)S.big_rows + rbase;
+  uint32_t* roots = (uint32_t*)S.big_roots + qbase;
+  uint32_t cnt = 0;
+  for (uint32_t r0 = 0; r0 < N; r0 += 64) {
+    const uint32_t row = r0 + lane;
+    bool f[1];
+    f[0] = row < N && S.lab[row] == root;
+    uint32_t tot;
+    const uint32_t rk = sa_coop_rank<64>(f, lane, &tot);
+    if (f[0]) M::st(rows + cnt + rk, row);
+    cnt += tot;
+  }
+  M::sync();
+  const uint8_t* excl = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
+  // greedy start: the bids
+  for (uint32_t k = lane; k < cnt; k += 64) {
+    const uint32_t row = M::ld(rows + k);
+    const uint32_t ne = S.e_use[row];
+    const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+    int64_t maxg = 0;
+    uint32_t bcol = SA_NONE;
+    for (uint32_t e = 0; e < ne; ++e) {
+      const SaEdge ed = sa_ldg(ep + e);
+      if (excl && excl[ed.col]) continue;
+      if (ed.gain > maxg || (ed.gain == maxg && ed.col < bcol)) { maxg = ed.gain; bcol = ed.col; }
+    }
+    M::st((uint32_t*)S.big_bcol + row, bcol);
+    if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
+  }
+  M::sync();
+  uint32_t nroots = 0;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    bool pend[1];
+    pend[0] = false;
+    uint32_t row = 0;
+    if (k < cnt) {
+      row = M::ld(rows + k);
+      const uint32_t bc = M::ld((uint32_t*)S.big_bcol + row);
+      if (bc != SA_NONE) {
+        if (M::ld((uint32_t*)(S.cwin + bc)) == row) { M::st((int32_t*)S.rmatch + row, (int32_t)bc); M::st((int32_t*)S.cmatch + bc, (int32_t)row); }
+        else pend[0] = true;
+      }
+    }
+    uint32_t tot;
+    const uint32_t rk = sa_coop_rank<64>(pend, lane, &tot);
+    if (pend[0]) M::st(roots + nroots + rk, row);
+    nroots += tot;
+  }
+  M::sync();
+  sa_coop_ws w;
+  w.e_cnt = (const uint32_t*)S.e_use;
+  w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.rcs = 4; w.rgs = 2;
+  w.estride = S.estride; w.e_off = nullptr;
+  w.excluded = excl;
+  w.u = (int64_t*)S.u_use; w.v = (int64_t*)S.v; w.rmatch = (int32_t*)S.rmatch; w.cmatch = (int32_t*)S.cmatch;
+  w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred; w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan;
+  w.clist = (uint32_t*)S.big_clist + (size_t)blockIdx.x * T;  // one list of T entries per wavefront of the launch
+  sa_assign_component_coop<64, M>(w, roots, nroots);
+  for (uint32_t k = lane; k < cnt; k += 64) {
+    const uint32_t row = M::ld(rows + k);
+    finalize_row_with<VISUAL>(S, row, M::ld((int32_t*)S.rmatch + row));
+  }
+}
+
 template <bool VISUAL>
 __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -814,91 +884,81 @@ __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict_
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
   }
-  if (q >= S.N) return;
-  const uint32_t head = S.label[q];
-  if (!S.e_use[q] || (VISUAL && S.row_has[q])) finalize_row_with<VISUAL>(S, q, -1);
-  if (head == SA_NONE) return;
-  SolveLocal& L = s_local[threadIdx.x];
-  // rows of the component, ascending
-  uint32_t R = 0;
-  for (uint32_t cur = head; cur != SA_NONE; cur = S.next_row[cur]) {
-    if (R < SL_R) {
-      uint32_t k = R;
-      while (k > 0 && L.rows[k - 1] > cur) { L.rows[k] = L.rows[k - 1]; --k; }
-      L.rows[k] = cur;
-    }
-    ++R;
-  }
-  bool fits = R <= SL_R;
-  uint32_t E = 0, C = 0;
-  if (fits) {
-    for (uint32_t r = 0; r < R && fits; ++r) {
-      const uint32_t row = L.rows[r];
-      const uint32_t cnt = S.e_use[row];
-      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-      L.e_off[r] = E;
-      uint32_t n = 0;
-      int64_t maxg = 0;
-      for (uint32_t e = 0; e < cnt; ++e) {
-        const SaEdge ed = sa_ldg(ep + e);
-        if (VISUAL && S.col_excluded[ed.col]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71)
-        uint32_t c = 0;
-        while (c < C && L.colmap[c] != ed.col) ++c;
-        if (E >= SL_E || (c == C && C >= SL_C)) { fits = false; break; }
-        if (c == C) L.colmap[C++] = ed.col;
-        L.e_col[E] = c;
-        L.e_gain[E] = ed.gain;
-        ++E; ++n;
-        maxg = ed.gain > maxg ? ed.gain : maxg;
+  bool big = false;
+  if (q < S.N) {
+    const uint32_t head = S.label[q];
+    if (!S.e_use[q] || (VISUAL && S.row_has[q])) finalize_row_with<VISUAL>(S, q, -1);
+    if (head != SA_NONE) {
+      SolveLocal& L = s_local[threadIdx.x];
+      const uint32_t R = (uint32_t)S.rnext[q];  // rows in the component rooted here (k_assign_label)
+      bool fits = R <= SL_R;
+      uint32_t E = 0, C = 0;
+      if (fits) {
+        // rows of the component, ascending
+        uint32_t n = 0;
+        for (uint32_t cur = head; cur != SA_NONE && n < SL_R; cur = S.next_row[cur]) {
+          uint32_t k = n;
+          while (k > 0 && L.rows[k - 1] > cur) { L.rows[k] = L.rows[k - 1]; --k; }
+          L.rows[k] = cur;
+          ++n;
+        }
+        for (uint32_t r = 0; r < R && fits; ++r) {
+          const uint32_t row = L.rows[r];
+          const uint32_t cnt = S.e_use[row];
+          const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+          L.e_off[r] = E;
+          uint32_t n2 = 0;
+          int64_t maxg = 0;
+          for (uint32_t e = 0; e < cnt; ++e) {
+            const SaEdge ed = sa_ldg(ep + e);
+            if (VISUAL && S.col_excluded[ed.col]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71)
+            uint32_t c = 0;
+            while (c < C && L.colmap[c] != ed.col) ++c;
+            if (E >= SL_E || (c == C && C >= SL_C)) { fits = false; break; }
+            if (c == C) L.colmap[C++] = ed.col;
+            L.e_col[E] = c;
+            L.e_gain[E] = ed.gain;
+            ++E; ++n2;
+            maxg = ed.gain > maxg ? ed.gain : maxg;
+          }
+          L.e_cnt[r] = n2;
+          L.u[r] = -maxg;
+          L.rmatch[r] = -1;
+          L.next_row[r] = r + 1 < R ? r + 1 : SA_NONE;
+        }
       }
-      L.e_cnt[r] = n;
-      L.u[r] = -maxg;
-      L.rmatch[r] = -1;
-      L.next_row[r] = r + 1 < R ? r + 1 : SA_NONE;
+      if (fits) {
+        // columns in ascending order of their track index: rank, permute, renumber the edges
+        for (uint32_t c = 0; c < C; ++c) {
+          uint32_t rank = 0;
+          for (uint32_t d = 0; d < C; ++d) rank += L.colmap[d] < L.colmap[c];
+          L.cnext[c] = (int32_t)rank;
+        }
+        for (uint32_t c = 0; c < C; ++c) L.pred[L.cnext[c]] = (int32_t)L.colmap[c];
+        for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
+        for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
+        sa_assign_ws w;
+        w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = L.e_off;
+        w.excluded = nullptr;
+        w.next_row = L.next_row;
+        w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;
+        w.cstamp = L.cstamp; w.cscan = L.cscan; w.cnext = L.cnext; w.rdist = L.rdist; w.rnext = L.rnext;
+        sa_assign_component(w, 0);
+        for (uint32_t r = 0; r < R; ++r) {
+          const int32_t c = L.rmatch[r];
+          finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
+        }
+      } else big = true;
     }
   }
-  if (fits) {
-    // columns in ascending order of their track index: rank, permute, renumber the edges
-    for (uint32_t c = 0; c < C; ++c) {
-      uint32_t rank = 0;
-      for (uint32_t d = 0; d < C; ++d) rank += L.colmap[d] < L.colmap[c];
-      L.cnext[c] = (int32_t)rank;
-    }
-    for (uint32_t c = 0; c < C; ++c) L.pred[L.cnext[c]] = (int32_t)L.colmap[c];
-    for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
-    for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
-    sa_assign_ws w;
-    w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = L.e_off;
-    w.excluded = nullptr;
-    w.next_row = L.next_row;
-    w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;
-    w.cstamp = L.cstamp; w.cscan = L.cscan; w.cnext = L.cnext; w.rdist = L.rdist; w.rnext = L.rnext;
-    sa_assign_component(w, 0);
-    for (uint32_t r = 0; r < R; ++r) {
-      const int32_t c = L.rmatch[r];
-      finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
-    }
-    return;
+  // components that did not fit a lane's private block: one after the other, all 64 lanes on each
+  unsigned long long todo = __ballot(big);
+  while (todo) {
+    const uint32_t L2 = (uint32_t)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const uint32_t root = __shfl(q, (int)L2);
+    solve_big_component<VISUAL>(S, root, threadIdx.x);
   }
-  // a large component: order the list on its links and solve on the work set in HBM
-  uint32_t first = SA_NONE;
-  for (uint32_t cur = head; cur != SA_NONE;) {
-    const uint32_t nxt = S.next_row[cur];
-    if (first == SA_NONE || cur < first) {
-      S.next_row[cur] = first;
-      first = cur;
-    } else {
-      uint32_t p = first, pn = S.next_row[p];
-      while (pn != SA_NONE && pn < cur) { p = pn; pn = S.next_row[p]; }
-      S.next_row[cur] = pn;
-      S.next_row[p] = cur;
-    }
-    cur = nxt;
-  }
-  sa_assign_ws w = make_ws(S);
-  if (!VISUAL) w.excluded = nullptr;
-  sa_assign_component(w, first);
-  for (uint32_t r = first; r != SA_NONE; r = S.next_row[r]) finalize_row_with<VISUAL>(S, r, S.rmatch[r]);
 }
 
 // =====================================================================================================

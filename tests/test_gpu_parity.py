@@ -999,6 +999,34 @@ def test_dense_positional_stage_behind_a_visual_vote(visual):
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50 and (votes == abi.SA_VOTE_VISUAL).sum() > 200
 
 
+@pytest.mark.parametrize("case", ["crowd", "pile", "rect"])
+def test_big_frames_with_big_components_against_the_oracle(case):
+    """More than 1024 detections or tracks AND components of tens to a thousand rows: the general tail's wave-cooperative solver
+    (state in HBM).  A crowd of 1500 x 1500 with 12 px of jitter, ONE pile of 1200 boxes under IoU(0.05) with most bids colliding,
+    and 700 detections against 1800 tracks."""
+    n, t, canvas, thr, sigma = {"crowd": (1500, 1500, (1000.0, 800.0), 0.15, 12.0), "pile": (1200, 1200, (200.0, 200.0), 0.05, 10.0),
+                                "rect": (700, 1800, (600.0, 500.0), 0.1, 8.0)}[case]
+    sc = synth.sort_scene(np.random.default_rng(n + t), t, n, canvas=canvas, pos_sigma=sigma)
+    cfg = abi.make_config(positional="iou", positional_threshold=thr, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    assert (ids != 0).sum() > 0.4 * min(n, t)
+
+
+def test_big_visual_frame_with_a_dense_positional_stage():
+    """1300 x 1300 VisualSORT on a small canvas, a third of the detections new or featureless: partials + resolve (no vote words
+    beyond 1024), exclusions, and a positional stage whose components are hundreds of rows — the general tail end to end."""
+    rng = np.random.default_rng(67)
+    n = t = 1300
+    d = 64
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(400.0, 300.0), new_fraction=0.2)
+    sc["det_quality"][rng.uniform(size=n) < 0.15] = 0.05
+    cfg = abi.make_config(positional="iou", positional_threshold=0.05, visual="cosine", visual_threshold=0.2, feature_len=d, max_observations=1,
+                          visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.3, positional_min_confidence=0.1,
+                          max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc)
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 100 and (votes == abi.SA_VOTE_VISUAL).sum() > 500
+
+
 def test_quarter_wave_groups_match_oracle_too():
     """SA_COOP_G=16: the cooperative solver with 16-lane groups (four components per wavefront side by side) instead of whole
     wavefronts.  Same tests, same oracle."""
