@@ -835,6 +835,9 @@ __device__ __forceinline__ void solve_big_component(const SceneDev& S, uint32_t 
       if (ed.gain > maxg || (ed.gain == maxg && ed.col < bcol)) { maxg = ed.gain; bcol = ed.col; }
     }
     M::st((uint32_t*)S.big_bcol + row, bcol);
+    // the row dual over the USABLE edges (the positional tiles folded the maximum over all of them, excluded columns included: with
+    // that value the edge the row bids for would not be tight, and the start not a feasible primal-dual pair)
+    M::st((int64_t*)S.u_use + row, -maxg);
     if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
   }
   M::sync();
