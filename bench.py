@@ -113,6 +113,16 @@ def workload(name: str, seed: int):
         sc = synth.sort_scene(rng, 640, 640, canvas=(150.0, 150.0), pos_sigma=10.0)
         cfg = abi.make_config(positional="iou", positional_threshold=0.05, max_idle_epochs=5)
         return cfg, [sc], "SORT IoU(0.05) 640 x 640, all boxes on one pile, 10 px of jitter: one connected component of the positional vote, ~140 k usable edges, a third of the rows lose their greedy bid"
+    if name == "bigcrowd":
+        # beyond the one-workgroup tail: 1500 detections in a crowd, 12 px of jitter (345 rows lose their greedy bid; components of
+        # tens to hundreds of rows go to the general tail's wave-cooperative solver, state in HBM)
+        sc = synth.sort_scene(rng, 1500, 1500, canvas=(1000.0, 800.0), pos_sigma=12.0)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.15, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU(0.15) 1500 x 1500 in a crowd, 12 px of jitter: the general assignment tail with big components"
+    if name == "bigpile":
+        sc = synth.sort_scene(rng, 1200, 1200, canvas=(200.0, 200.0), pos_sigma=10.0)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.05, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU(0.05) 1200 x 1200 on one pile: ONE component of 1200 rows and ~340 k edges in the general assignment tail"
     if name == "c3m":
         # BASELINE C3's Mahalanobis half: the Kalman states come from the product's own device-side upkeep (three frames through
         # the BatchSort facade), see maha_engine() below — no synthetic scene dict
