@@ -487,6 +487,15 @@ def main():
         eng.batch_run()
     eng.batch_sync()
     dt, regions = timed_rounds(run_k, barrier)
+    # the pure per-step time: a region carries a fixed cost (the first launch's latency, the final synchronisation: ~20 us, 5 % of a
+    # 20-step region) — regions of 4 K steps give the slope; `value` stays the K-step region, the slope only rescales the
+    # instrumented per-kernel durations below
+    def run_4k():
+        for _ in range(4 * args.steps):
+            eng.batch_run()
+        eng.batch_sync()
+    dt4, _r4 = timed_rounds(run_4k, barrier, min_total_s=0.2, min_rounds=3, max_rounds=60)
+    step_s = max(0.0, (dt4 - dt) / (3.0 * args.steps)) or dt / args.steps
     if dist is not None:
         cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -629,11 +638,11 @@ def main():
         # Per-kernel durations come from an INSTRUMENTED pass: every launch carries two events stamped with the dispatch's begin / end,
         # and a dispatch that signals completion also ends with a system-scope release, which the same kernel inside the plain
         # pipeline does not pay (rocprofv3's kernel trace of the timed region: k_frame_visual 18.4 us against 20.0 us instrumented).
-        # avg_us = the instrumented durations rescaled so that one step's launches add up to the UN-instrumented step time of the
-        # timed region above (dependent launches back to back on one stream: the step time is their sum); avg_us_instrumented = raw.
+        # avg_us = the instrumented durations rescaled so that one step's launches add up to the UN-instrumented per-step time (the
+        # slope between K-step and 4K-step regions: dependent launches back to back on one stream); avg_us_instrumented = raw.
         raw = {k: 1e3 * ms / max(n, 1) for k, (n, ms) in prof.items()}
         step_instr = sum(raw[k] * prof[k][0] / float(args.profile_iters) for k in raw)
-        scale = min(1.0, (1e6 * dt / args.steps) / step_instr) if step_instr > 0 else 1.0  # both in microseconds per step
+        scale = min(1.0, (1e6 * step_s) / step_instr) if step_instr > 0 else 1.0  # both in microseconds per step
         if "k_visual_raw" in raw:
             scale = 1.0  # k_frame runs BESIDE the contraction (no barrier bit): the launches of a step do not add up to the step time
         kern = {k: {"launches": int(prof[k][0]), "avg_us": raw[k] * scale, "avg_us_instrumented": raw[k]} for k in raw}
@@ -728,7 +737,7 @@ def main():
             "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "pairs_per_step_per_gpu": cells,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
-                              "max_ms_per_step": 1e3 * max(regions) / args.steps},
+                              "max_ms_per_step": 1e3 * max(regions) / args.steps, "ms_per_step_slope": 1e3 * step_s},
             "value_resident": total_cells * args.steps / dt,
             "value_h2d": h2d["pairs_per_s"] if h2d else None,
             "match_accuracy": acc,
