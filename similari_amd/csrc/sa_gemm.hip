@@ -743,9 +743,12 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   uint32_t* s_key = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN);             // [64][KS] PART: order-preserving keys of 64 tile rows
   constexpr uint32_t FW = BN / 32;                                         // EU: words of flag bits per tile row
   uint32_t* s_flag = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN + 64 * KS);  // [64][FW] EU: cells of the current 64-row pass to recompute directly
-  static_assert(!EU || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 64 * (BN / 32)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "flag words must fit the stages");
+  constexpr uint32_t FL_CAP = 255;                                         // EU: the same cells as a list (a tracking frame has a handful per tile); [FL_CAP] = their count
+  uint32_t* s_flist = s_flag + 64 * FW;
+  static_assert(!EU || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 64 * (BN / 32) + 256) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "flag words and list must fit the stages");
   if constexpr (EU) {
     for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
+    if (tid == 0) s_flist[FL_CAP] = 0u;
   }
   if (tid < (uint32_t)BM) {
     s_na[tid] = pre_us != 0.f ? pre_na : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
@@ -807,53 +810,64 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   };
   // EU: the flagged cells of the 64-row pass `m`, recomputed as the direct sum of (a - b)^2: a wave per tile row, the lanes along k
   // (16-byte loads of both rows, L2-resident: the tile has just streamed them), a wave reduction, one result per cell — into the
-  // key tile and the column minima (PART) or the weight matrix.  A wave that meets more than 16 such cells reports the frame as
+  // key tile and the column minima (PART) or the weight matrix.  A tile with more than 64 such cells reports the frame as
   // ill-conditioned for the expansion (S.stats[0], read by the host after the frame: it switches the scene's engine to the
   // vector-pipe kernel for a while); the answers of THIS frame are exact either way.
   auto euclid_fixup = [&](uint32_t m) {
     if constexpr (EU) {
-      __syncthreads();  // flag words (and the keys / matrix cells of the pass) complete
+      __syncthreads();  // flag words / list (and the keys / matrix cells of the pass) complete
       const uint32_t wave = tid >> 6, nw = blockDim.x >> 6;
       const float SA_G* Ab = RAW ? S.c_feat_raw : (const float SA_G*)S.c_feat;
-      uint32_t fixed = 0;
-      for (uint32_t lrow = wave; lrow < 64u; lrow += nw) {
-        const uint32_t li = (lrow >> 5) * (BM / 2) + m * 32 + (lrow & 31u), gi = m0 + li;
-        for (uint32_t wd = 0; wd < FW; ++wd) {
-          uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flag[lrow * FW + wd]);
-          while (bits) {
-            const uint32_t lc = wd * 32u + (uint32_t)__builtin_ctz(bits), gj = n0 + lc;
-            bits &= bits - 1u;
-            const float SA_G* a = Ab + (size_t)gi * S.Dp;
-            const float SA_G* b = S.t_feat + (size_t)gj * S.Dp;
-            float acc2 = 0.f;
-            for (uint32_t k = lane * 4u; k < S.Dp; k += 256u) {
-              const f32x4 x = *(const f32x4 SA_G*)(a + k), y = *(const f32x4 SA_G*)(b + k);
-              const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
-              acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
-            }
+      auto recompute = [&](uint32_t lrow, uint32_t lc) {
+        const uint32_t li = (lrow >> 5) * (BM / 2) + m * 32 + (lrow & 31u), gi = m0 + li, gj = n0 + lc;
+        const float SA_G* a = Ab + (size_t)gi * S.Dp;
+        const float SA_G* b = S.t_feat + (size_t)gj * S.Dp;
+        float acc2 = 0.f;
+        for (uint32_t k = lane * 4u; k < S.Dp; k += 256u) {
+          const f32x4 x = *(const f32x4 SA_G*)(a + k), y = *(const f32x4 SA_G*)(b + k);
+          const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+          acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o);
-            ++fixed;
-            if (lane == 0) {
-              const float d = __fsqrt_rn(acc2);
-              const bool ok = d <= p.visual_threshold;
-              const uint32_t key = ok ? sa_f32_key(d) : 0u;
-              if constexpr (PART) {
-                const uint32_t k2 = ok ? key : 0xffffffffu;
-                s_key[lrow * KS + lc] = k2;
-                if (ok) atomicMin(&s_ck[lc], ((unsigned long long)k2 << 32) | gi);
-              } else {
-                S.vis[(size_t)gi * TK + gj] = ok ? d : __builtin_nanf("");
-                kmax = key > kmax ? key : kmax;
-              }
-            }
+        for (int o = 32; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o);
+        if (lane == 0) {
+          const float d = __fsqrt_rn(acc2);
+          const bool ok = d <= p.visual_threshold;
+          const uint32_t key = ok ? sa_f32_key(d) : 0u;
+          if constexpr (PART) {
+            const uint32_t k2 = ok ? key : 0xffffffffu;
+            s_key[lrow * KS + lc] = k2;
+            if (ok) atomicMin(&s_ck[lc], ((unsigned long long)k2 << 32) | gi);
+          } else {
+            S.vis[(size_t)gi * TK + gj] = ok ? d : __builtin_nanf("");
+            kmax = key > kmax ? key : kmax;
           }
         }
+      };
+      const uint32_t nf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flist[FL_CAP]);
+      if (nf <= FL_CAP) {
+        // the usual case: a handful of cells, dealt round-robin to the waves straight from the list
+        for (uint32_t i = wave; i < nf; i += nw) {
+          const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flist[i]);
+          recompute(ent >> 8, ent & 255u);
+        }
+      } else {
+        // more than the list holds (an ill-conditioned frame): every wave walks the flag words of its rows
+        for (uint32_t lrow = wave; lrow < 64u; lrow += nw)
+          for (uint32_t wd = 0; wd < FW; ++wd) {
+            uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flag[lrow * FW + wd]);
+            while (bits) {
+              const uint32_t lc = wd * 32u + (uint32_t)__builtin_ctz(bits);
+              bits &= bits - 1u;
+              recompute(lrow, lc);
+            }
+          }
       }
-      if (fixed > 16u && lane == 0) S.stats[0] = 1u;
-      if (m + 1 < (uint32_t)TM) {  // the next pass reuses the flag words
+      if (nf > 64u && tid == 0) S.stats[0] = 1u;  // more than 1.5 % of a tile's cells: the frame is ill-conditioned for the expansion
+      if (m + 1 < (uint32_t)TM) {  // the next pass reuses the flag words and the list
         __syncthreads();
         for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
+        if (tid == 0) s_flist[FL_CAP] = 0u;
         __syncthreads();
       }
     }
@@ -880,7 +894,11 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       bool flagged;
       const float w = visual_cell<EU>(p, part[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax, &flagged);  // rows / columns past the edge: ok = false
       if constexpr (EU) {
-        if (flagged && gi < N) atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));  // BM = 64: the tile row is the pass row
+        if (flagged && gi < N) {  // BM = 64: the tile row is the pass row
+          atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));
+          const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
+          if (pos < FL_CAP) s_flist[pos] = (li << 8) | lc;
+        }
       }
       if constexpr (PART) {
         const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
@@ -924,7 +942,11 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
           bool flagged;
           const float w = visual_cell<EU>(p, acc[m][n][r], nav[r >> 2][r & 3], (cfail[n] >> r) & 1u, col[n], &kmax, &flagged);
           if constexpr (EU) {
-            if (flagged && gi < N) atomicOr(&s_flag[lrow * FW + (lc >> 5)], 1u << (lc & 31u));
+            if (flagged && gi < N) {
+              atomicOr(&s_flag[lrow * FW + (lc >> 5)], 1u << (lc & 31u));
+              const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
+              if (pos < FL_CAP) s_flist[pos] = (lrow << 8) | lc;
+            }
           }
           if constexpr (PART) {
             const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
