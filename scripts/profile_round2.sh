@@ -4,12 +4,13 @@
 # MFMA-utilisation PMC passes, HBM-traffic PMC passes, the two-rank dispatch rehearsal, the in-process cluster, the side benches.
 #   scripts/profile_round2.sh <tag>     -> gpurun_out/<tag>/ ; copy what is to be judged into profiles/<tag>_*
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-TAG=${1:-r02_r}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+TAG=${1:-r02_t}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c2_driver_command.json 2> $O/bench_c2_driver_command.err   # the driver's own command line
-for w in c1 c2n c2e c2k3 c2d c3 c3m c4 sd giant bigcrowd bigpile; do timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
+for w in c1 c2n c2e c2k3 c2d c3 c3m c4 sd; do timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
+for w in giant bigcrowd bigpile; do timeout 300 python bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 3 --profile-iters 10 > $O/bench_$w.json 2> $O/bench_$w.err; done   # milliseconds per step: short regions
 timeout 600 python bench.py --workload c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
 timeout 300 python bench.py --flags 32 --no-cpu-baseline --no-oracle > $O/bench_c2_separate.json 2> $O/bench_c2_separate.err
 SA_EUCLID=valu timeout 300 python bench.py --workload c2e --no-cpu-baseline --no-oracle > $O/bench_c2e_valu.json 2> $O/bench_c2e_valu.err
