@@ -781,7 +781,10 @@ struct SolveLocal {
   uint32_t e_cnt[SL_R], e_off[SL_R], next_row[SL_R], rows[SL_R];
   int32_t rmatch[SL_R], rnext[SL_R], cmatch[SL_C], pred[SL_C], cnext[SL_C];
   uint32_t cstamp[SL_C], cscan[SL_C], colmap[SL_C], e_col[SL_E];
+  uint32_t bank_pad[2];  // 1088 -> 1096 bytes: lane i's block starts 274 i words into LDS — 32 distinct banks for a wave's 64 lanes instead
+                         // of 4 (272 i: every access of the gather, the solve and the scatter was a 16-way bank conflict)
 };
+static_assert(sizeof(SolveLocal) == 1096, "SolveLocal: one lane's block must not start a multiple of 16 words after its neighbour's");
 template <bool VISUAL>
 __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q, int32_t c) {
   uint64_t id = 0;
