@@ -310,6 +310,20 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out);
 void* sa_host_alloc(uint64_t bytes); /* NULL: no device, or out of memory */
 void sa_host_free(void* block);      /* a pointer returned by sa_host_alloc, or NULL */
 
+/* ---- detection features that are already in device memory (optional) ----------------------
+ * In the reference every observation carries its feature as a host slice (VisualSortObservation.feature: Option<&[f32]>,
+ * visual_sort/simple_api.rs:130-170, visual_sort.rs:34-56) — whatever produced it.  When the producer is a ReID model on the SAME
+ * GPU, the rows are in HBM already and the round trip device -> host -> device (2 MB per frame at 1000 x 512-d, the largest part of
+ * an ingested frame's cost) is pure overhead: register the producer's output buffer once, then pass pointers INTO it as
+ * sa_detections.feats (N x D f32, row-major, as on the host).  sa_batch_add / sa_associate* / sa_pipe_stage recognise such a pointer
+ * and the kernels read the rows where they lie (a base that is not 16-byte aligned costs one device-to-device copy); boxes,
+ * qualities and the other per-detection arrays still come from host memory.  The rows must be FINAL when the call is made
+ * (synchronise the producing stream first: the engine's streams do not know about it) and must stay untouched until that frame's
+ * results have been fetched.  `device` = the HIP device the block lives on (< 0: the calling thread's current device); a request that reaches an engine on another device is
+ * refused (SA_ERR_BAD_ARG).  Process-wide, thread-safe, independent of any engine; registering a base pointer again updates its size. */
+int sa_device_block_register(const void* dev_ptr, uint64_t bytes, int device);
+void sa_device_block_unregister(const void* dev_ptr);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 typedef struct sa_kernel_stat {
   char name[48];

@@ -314,13 +314,19 @@ def make_tracks(ids, boxes, epochs, kf_mean=None, kf_cov=None, feats=None, feat_
     return t
 
 
-def make_detections(boxes, feats=None, feat_present=None, feat_quality=None, own_area=None):
+def make_detections(boxes, feats=None, feat_present=None, feat_quality=None, own_area=None, feats_device_ptr=None):
+    """feats: N x D float32 in host memory, or feats_device_ptr: the address of such rows inside a block registered with
+    sa_device_block_register (e.g. tensor.data_ptr() of a CUDA/HIP tensor the caller keeps alive and does not write to meanwhile)."""
     keep = Keep()
     d = sa_detections()
     boxes = keep.arr(boxes, BOX_DTYPE)
     d.n = len(boxes)
     d.boxes = C.cast(boxes.ctypes.data, C.POINTER(sa_box)) if d.n else C.cast(None, C.POINTER(sa_box))
-    d.feats = _ptr(keep.arr(feats, np.float32), C.c_float)
+    if feats_device_ptr is not None:
+        assert feats is None
+        d.feats = C.cast(C.c_void_p(int(feats_device_ptr)), C.POINTER(C.c_float))
+    else:
+        d.feats = _ptr(keep.arr(feats, np.float32), C.c_float)
     d.feat_present = _ptr(keep.arr(feat_present, np.uint8), C.c_uint8)
     d.feat_quality = _ptr(keep.arr(feat_quality, np.float32), C.c_float)
     d.own_area = _ptr(keep.arr(own_area, np.float32), C.c_float)
@@ -371,6 +377,8 @@ PROTOTYPES = {
     "sa_own_areas": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float)]),
     "sa_host_alloc": (C.c_void_p, [C.c_uint64]),
     "sa_host_free": (None, [C.c_void_p]),
+    "sa_device_block_register": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "sa_device_block_unregister": (None, [C.c_void_p]),
     "sa_tap_dims": (C.c_int, [ENGINE, u32, P(u32), P(u32), P(u32)]),
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),

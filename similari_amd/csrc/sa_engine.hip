@@ -56,6 +56,8 @@ struct Slot {  // one scene of a request set
   size_t o_raw = 0, o_q = 0, o_own = 0, o_fp = 0, o_feat = 0;
   const float* feats_inplace = nullptr;  // the caller's features lie in a pinned block (sa_host_alloc): DMA'd from there into feat_raw
   const float* feats_inplace_dev = nullptr;  // the same rows through the block's device mapping (the ingest kernel reads them)
+  const float* feats_device = nullptr;   // the caller's features lie in DEVICE memory (sa_device_block_register): read where they are
+                                         // when 16-byte aligned, else copied device-to-device into feat_raw
   void *p_raw = nullptr, *p_quality = nullptr, *p_own = nullptr, *p_fpresent = nullptr, *p_feat_raw = nullptr;
   DevBuf feat_raw;                        // destination of an in-place feature upload
   // derived candidates
@@ -346,7 +348,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->conf, n * 4));
   TRY(dev_ensure(e, s->usable, n));
   if (e->visual) {
-    if (s->feats_inplace) TRY(dev_ensure(e, s->feat_raw, n * (e->D ? e->D : 1) * 4));
+    if (s->feats_inplace || (s->feats_device && ((uintptr_t)s->feats_device & 15u))) TRY(dev_ensure(e, s->feat_raw, n * (e->D ? e->D : 1) * 4));
     TRY(dev_ensure(e, s->feat, n * Dp * 4));
     TRY(dev_ensure(e, s->fnorm, n * 4));
     TRY(dev_ensure(e, s->vis, n * t * K * 4));
@@ -467,7 +469,8 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   for (uint32_t i = 0; i < ns; ++i) {
     Slot* s = b->slots[i];
     s->p_raw = dbase + s->o_raw; s->p_quality = dbase + s->o_q; s->p_own = dbase + s->o_own; s->p_fpresent = dbase + s->o_fp;
-    s->p_feat_raw = s->feats_inplace ? s->feat_raw.p : (void*)(dbase + s->o_feat);
+    if (s->feats_device) s->p_feat_raw = ((uintptr_t)s->feats_device & 15u) ? s->feat_raw.p : (void*)s->feats_device;
+    else s->p_feat_raw = s->feats_inplace ? s->feat_raw.p : (void*)(dbase + s->o_feat);
   }
   std::vector<uint8_t> build(dbytes);
   SceneDev* bd = (SceneDev*)build.data();
@@ -522,6 +525,8 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
     for (uint32_t i = 0; i < ns; ++i) {
       Slot* s = b->slots[i];
       if (s->feats_inplace && s->N) TRY(move(s->feats_inplace, s->feats_inplace_dev, s->feat_raw.p, (size_t)s->N * e->D * 4));
+      if (s->feats_device && s->N && ((uintptr_t)s->feats_device & 15u))  // the kernels read rows with 16-byte loads
+        HIPCHK(e, hipMemcpyAsync(s->feat_raw.p, s->feats_device, (size_t)s->N * e->D * 4, hipMemcpyDeviceToDevice, st));
     }
     TRY(flush(true));
     b->uploaded = true;
@@ -1183,6 +1188,32 @@ static bool in_pinned_block(const void* p, size_t bytes, const void** dev = null
   return false;
 }
 
+// ---- device blocks the caller's own producers write detection features into (sa_device_block_register) ----
+struct DevBlock { const char* base; size_t bytes; int device; };
+static std::vector<DevBlock> g_dev_blocks;
+extern "C" int sa_device_block_register(const void* dev_ptr, uint64_t bytes, int device) {
+  if (!dev_ptr || !bytes) return SA_ERR_BAD_ARG;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return SA_ERR_NO_DEVICE; }  // < 0: the calling thread's current device
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  for (auto& b : g_dev_blocks)
+    if (b.base == (const char*)dev_ptr) { b.bytes = (size_t)bytes; b.device = device; return SA_OK; }
+  g_dev_blocks.push_back({(const char*)dev_ptr, (size_t)bytes, device});
+  return SA_OK;
+}
+extern "C" void sa_device_block_unregister(const void* dev_ptr) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  for (size_t i = 0; i < g_dev_blocks.size(); ++i)
+    if (g_dev_blocks[i].base == (const char*)dev_ptr) { g_dev_blocks.erase(g_dev_blocks.begin() + i); return; }
+}
+// is [p, p + bytes) inside a registered device block?  *device = the block's device
+static bool in_device_block(const void* p, size_t bytes, int* device) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  const char* q = (const char*)p;
+  for (const auto& b : g_dev_blocks)
+    if (q >= b.base && q + bytes <= b.base + b.bytes) { *device = b.device; return true; }
+  return false;
+}
+
 // Appends one scene of a request set to bank `b`: host work only — the boxes (with libm's cos / sin of their angles), the optional
 // per-detection arrays and the features are laid out in the bank's pinned staging arena; bank_upload moves the arena in one DMA.
 static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
@@ -1211,7 +1242,13 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   const size_t fbytes = (size_t)N * D * 4;
   // the caller's block is pinned (sa_host_alloc): the DMA reads it in place, no staging copy
   const void* feats_dev = nullptr;
-  s->feats_inplace = (s->has_feats && !feat_rows && N && in_pinned_block(d->feats, fbytes, &feats_dev)) ? d->feats : nullptr;
+  int feats_on = -1;
+  s->feats_device = (s->has_feats && !feat_rows && N && in_device_block(d->feats, fbytes, &feats_on)) ? d->feats : nullptr;
+  if (s->feats_device && feats_on != e->device) {
+    s->feats_device = nullptr;
+    return fail(e, SA_ERR_BAD_ARG, "detections.feats lies in a block registered for device %d, this engine runs on device %d", feats_on, e->device);
+  }
+  s->feats_inplace = (s->has_feats && !feat_rows && N && !s->feats_device && in_pinned_block(d->feats, fbytes, &feats_dev)) ? d->feats : nullptr;
   s->feats_inplace_dev = s->feats_inplace ? (const float*)feats_dev : nullptr;
   // every sub-array on a 256-byte boundary of the arena (16-byte loads of features and boxes, whole cache lines per scene)
   s->o_raw = align_up(b->used, 256);
@@ -1221,7 +1258,7 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   // features on a boundary of their own (SA_FEAT_ALIGN, default 4 KB): the contraction streams them as 16-byte loads of Dp-float rows
   static const size_t feat_align = getenv("SA_FEAT_ALIGN") ? (size_t)atol(getenv("SA_FEAT_ALIGN")) : 4096;
   s->o_feat = align_up(s->o_fp + N, feat_align >= 256 ? feat_align : 256);
-  const size_t end = s->o_feat + ((s->has_feats && !s->feats_inplace) ? fbytes : 0);
+  const size_t end = s->o_feat + ((s->has_feats && !s->feats_inplace && !s->feats_device) ? fbytes : 0);
   TRY(arena_reserve(e, b, end + 256));
   uint8_t* h = (uint8_t*)b->h_arena.p;
   if (N) {
@@ -1229,7 +1266,7 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
     if (s->has_quality) std::memcpy(h + s->o_q, d->feat_quality, (size_t)N * 4);
     if (s->has_own) std::memcpy(h + s->o_own, d->own_area, (size_t)N * 4);
     if (s->has_fpresent) std::memcpy(h + s->o_fp, d->feat_present, N);
-    if (s->has_feats && !s->feats_inplace) {
+    if (s->has_feats && !s->feats_inplace && !s->feats_device) {
       float* dst0 = (float*)(h + s->o_feat);
       if (feat_rows) {
         for (uint32_t i = 0; i < N; ++i) {

@@ -106,6 +106,15 @@ class Engine:
                 pass
             self.lib.sa_host_free(p)
 
+    def register_device_block(self, ptr, nbytes, device=None):
+        """sa_device_block_register: detections' features inside [ptr, ptr + nbytes) of device memory are read where they lie
+        (pass their address as make_detections(..., feats_device_ptr=...)).  The caller keeps the memory alive, final before every
+        call and untouched until the results are back."""
+        self._chk(self.lib.sa_device_block_register(C.c_void_p(int(ptr)), int(nbytes), int(self.cfg.device if device is None else device)))
+
+    def unregister_device_block(self, ptr):
+        self.lib.sa_device_block_unregister(C.c_void_p(int(ptr)))
+
     def batch_begin(self):
         self._chk(self.lib.sa_batch_begin(self.h))
 

@@ -219,3 +219,18 @@ def test_graph_replay_survives_a_changing_epoch():
         assert matched[0] > matched[-1] > 0, matched  # compatible() really followed the epoch
     finally:
         eng.close()
+
+
+def test_detection_features_read_in_place_from_device_memory():
+    """sa_device_block_register: the candidates' feature rows are already in HBM (a ReID model on the same GPU wrote them) — the
+    engine reads them where they lie.  Same answers as from host memory and as the oracle, through sa_associate, through the
+    pipelined tickets, from a base that is not 16-byte aligned (one device-to-device copy), with ragged frames out of one block;
+    a block registered for another device is refused.  Runs tests/devfeat_child.py: the stand-in for the ReID model's output is a
+    torch tensor, and torch's HIP context wants to be the first one of its process."""
+    import os
+    import subprocess
+    import sys
+
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "devfeat_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DEVICE-FEATURES-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
