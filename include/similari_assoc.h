@@ -319,7 +319,8 @@ void sa_host_free(void* block);      /* a pointer returned by sa_host_alloc, or 
  * and the kernels read the rows where they lie (a base that is not 16-byte aligned costs one device-to-device copy); boxes,
  * qualities and the other per-detection arrays still come from host memory.  The rows must be FINAL when the call is made
  * (synchronise the producing stream first: the engine's streams do not know about it) and must stay untouched until that frame's
- * results have been fetched.  `device` = the HIP device the block lives on (< 0: the calling thread's current device); a request that reaches an engine on another device is
+ * results have been fetched — and, when the engine also maintains the feature banks (sa_tracks_apply), until that call has returned:
+ * it takes the winners' rows from the same place.  A producer that writes frame n+1 while frame n is in flight alternates two regions.  `device` = the HIP device the block lives on (< 0: the calling thread's current device); a request that reaches an engine on another device is
  * refused (SA_ERR_BAD_ARG).  Process-wide, thread-safe, independent of any engine; registering a base pointer again updates its size. */
 int sa_device_block_register(const void* dev_ptr, uint64_t bytes, int device);
 void sa_device_block_unregister(const void* dev_ptr);
