@@ -45,14 +45,14 @@ def workload(name: str, seed: int):
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
         return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K=1 (BASELINE C2)"
-    if name == "c2k3":
+    if name in ("c2k3", "c2k2"):
         n = t = 1000
-        d, k = 512, 3
+        d, k = 512, int(name[-1])
         sc = synth.visual_scene(rng, t, n, d, k)
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
-        return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K=3 observations per track (BASELINE C2, deeper bank)"
+        return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K=" + str(k) + " observations per track (BASELINE C2, deeper bank)"
     if name == "c2e":
         n = t = 1000
         d, k = 512, 1

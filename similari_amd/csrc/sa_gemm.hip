@@ -1070,7 +1070,8 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   // Contraction tiles first in blockIdx order: the dispatcher hands blocks out in that order, breadth-first over the CUs, so
   // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
-  // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6.
+  // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6; the other kinds FIRST (so that the positional tiles of a
+  // frame with several rounds of contraction tiles do not queue behind them): C2 16.8 -> 17.5 us, three observations per track 40.9 -> 48.1.
   uint32_t b = blockIdx.x;
   if (b < gx * gy) {
     visual_cosine_tile<64, 64, KG, true, PART, false, EU>(S, p, b % gx, b / gx, lds);
@@ -1463,8 +1464,10 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
   if (best != 1) return best;
   const size_t b64 = (size_t)cdiv(M, 64) * cdiv(Ncols, 64) * ns;
   const uint32_t nchunks = Dp / BK;
+  // two k-groups per tile only while a CU holds ONE tile (a lone wave per SIMD loses a third of the matrix pipe to its own LDS and memory
+  // instructions, scripts/micro/mfma_side_mix.hip); from two co-resident tiles on, the second wave is there anyway and the split only adds the
+  // reduction: 512 tiles (1000 x 2000 columns) 25.5 us with one group against 27.1 with two, 752 tiles (1000 x 3000) 33.0 against 40.3
   if (b64 <= 320 && nchunks >= 8) return 2;
-  if (b64 <= 768 && nchunks >= 4) return 2;
   return 1;
 }
 
