@@ -159,10 +159,17 @@ struct SaParams {
 // which stamps the two events with the dispatch's OWN begin / end timestamps — the same clock rocprofv3's kernel trace
 // reads — instead of bracketing the launch with hipEventRecord (that adds ~2 us of command-processor time per kernel).
 extern thread_local hipEvent_t sa_prof_start, sa_prof_stop;
+// sa_done_event: set by the caller of a launcher for ONE launch — the dispatch carries the event as its own completion signal (the
+// frame's last kernel signals "results are in" itself, instead of a marker packet queued behind it: one command-processor round trip
+// less per pipelined frame).  Consumed (reset to nullptr) by the launch that takes it; ignored while profiling.
+extern thread_local hipEvent_t sa_done_event;
 #define SA_LAUNCH(kern, grid, block, shmem, st, ...)                                                           \
   do {                                                                                                         \
     if (sa_prof_start) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, 0, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                        \
+    else if (sa_done_event) {                                                                                  \
+      hipExtLaunchKernelGGL(kern, grid, block, shmem, st, nullptr, sa_done_event, 0, __VA_ARGS__);             \
+      sa_done_event = nullptr;                                                                                 \
+    } else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                      \
   } while (0)
 // The same with hipExtAnyOrderLaunch: documented as "the dispatch does not wait for the packets queued before it on the stream",
 // which would let two independent kernels of one frame run side by side without a second stream and its two cross-stream event

@@ -557,7 +557,7 @@ int ensure_prepped(sa_engine* e, Bank* b) {
 
 // The per-frame launches for the staged scenes, in order, on the engine's stream (and, when `fork`, the positional kernel on
 // the side stream between two events).  Also the body of the captured graph.
-int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT) {
+int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT, hipEvent_t done = nullptr, bool* done_attached = nullptr) {
   hipStream_t st = e->stream;
   // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
   // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own (no vote words)
@@ -618,13 +618,20 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
+  // the frame's LAST launch carries the caller's completion event as its own completion signal (sa_pipe_launch), unless the frame is
+  // being profiled (the launch then stamps the profile's events) or captured into a graph (the caller does not ask then)
+  static const bool done_by_marker = getenv("SA_DONE_EVENT") && !strcmp(getenv("SA_DONE_EVENT"), "record");
+  const bool attach = done && maxN && !e->profile && !done_by_marker;
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
+    if (attach) sa_done_event = done;
     HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5));
   } else {
     { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
-    { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }
+    { ProfScope ps(e, KID_ASSIGN_SOLVE); if (attach) sa_done_event = done; HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }
   }
+  if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
+  sa_done_event = nullptr;
   return SA_OK;
 }
 
@@ -665,7 +672,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
   return SA_OK;
 }
 
-int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT) {
+int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t done = nullptr, bool* done_attached = nullptr) {
   const uint32_t ns = b->n_slots;
   e->synced = false;
   const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
@@ -711,7 +718,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT) {
       return fail(e, SA_ERR_HIP, "hipGraphLaunch failed: %s", hipGetErrorString(ge));
     }
   } else {
-    int rc = enqueue_frame(e, b, ds, ns, maxN, maxT);
+    int rc = enqueue_frame(e, b, ds, ns, maxN, maxT, done, done_attached);
     if (rc != SA_OK) {  // a frame that died half-way may leave the self-cleaning state dirty
       for (uint32_t i = 0; i < ns; ++i) b->slots[i]->needs_init = true;
       return rc;
@@ -872,7 +879,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
     }
   for (Bank& bk : e->banks) {
     hipEventCreate(&bk.ev_staged);  // also handed to hipExtLaunchKernelGGL as the ingest dispatch's completion event
-    hipEventCreateWithFlags(&bk.ev_done, hipEventDisableTiming);
+    hipEventCreate(&bk.ev_done);    // handed to hipExtLaunchKernelGGL as the completion event of a frame's last dispatch (enqueue_frame)
   }
   if (e->visual) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) e->stream2 = nullptr;
@@ -1392,8 +1399,9 @@ int sa_pipe_launch(sa_engine* e, uint64_t ticket) {
   TRY(bank_prepare(e, b, &maxN, &maxT));  // the track tables as they are NOW (an upsert / sa_tracks_apply may have come in between)
   HIPCHK(e, hipStreamWaitEvent(e->stream, b->ev_staged, 0));
   TRY(bank_upload(e, b, e->stream, false));  // nothing, unless the descriptors changed since staging (then: the descriptors only)
-  if (b->n_slots) TRY(bank_launch(e, b, maxN, maxT));
-  HIPCHK(e, hipEventRecord(b->ev_done, e->stream));
+  bool done_rides = false;  // the frame's last dispatch signals ev_done itself
+  if (b->n_slots) TRY(bank_launch(e, b, maxN, maxT, b->ev_done, &done_rides));
+  if (!done_rides) HIPCHK(e, hipEventRecord(b->ev_done, e->stream));
   b->state = 2;
   return SA_OK;
 }

@@ -16,6 +16,7 @@
 #define WAVE 64
 
 thread_local hipEvent_t sa_prof_start = nullptr, sa_prof_stop = nullptr;
+thread_local hipEvent_t sa_done_event = nullptr;
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
