@@ -105,6 +105,7 @@ struct Bank {
   uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};  // launch geometry + kernel selection of the captured frame (run_pipeline)
   // pipelined tickets
   hipEvent_t ev_staged = nullptr, ev_done = nullptr;
+  bool staged_inline = false;  // the request set was uploaded on the compute stream itself (no hand-over event to wait for)
   uint64_t ticket = 0;       // 0 = none
   int state = 0;             // 0 idle, 1 staged (H2D queued), 2 launched (pipeline queued), 3 done and waited
 };
@@ -1380,10 +1381,20 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
   }
   uint32_t maxN = 0, maxT = 0;
   TRY(bank_prepare(e, b, &maxN, &maxT, false));  // sa_pipe_launch prepares again (the tables may change in between) and counts the frame
-  hipStream_t cs = e->copy_stream ? e->copy_stream : e->stream;
-  bool recorded = false;
-  TRY(bank_upload(e, b, cs, false, b->ev_staged, &recorded));
-  if (!recorded) HIPCHK(e, hipEventRecord(b->ev_staged, cs));
+  // A request set without bulk (plain SORT, or features that are in device memory already: tens of KB) goes up on the COMPUTE stream, in
+  // order in front of its kernels: the copy stream buys nothing there and its hand-over costs a barrier packet per frame
+  // (SA_SMALL_INGEST=copy_stream | inline: measurements).
+  static const char* small_env = getenv("SA_SMALL_INGEST");
+  const bool small_inline = small_env ? small_env[0] == 'i' : b->used <= (128u << 10);
+  b->staged_inline = !e->copy_stream || small_inline;
+  hipStream_t cs = b->staged_inline ? e->stream : e->copy_stream;
+  if (b->staged_inline) {
+    TRY(bank_upload(e, b, cs, false));
+  } else {
+    bool recorded = false;
+    TRY(bank_upload(e, b, cs, false, b->ev_staged, &recorded));
+    if (!recorded) HIPCHK(e, hipEventRecord(b->ev_staged, cs));
+  }
   b->state = 1;
   b->ticket = e->next_ticket++;
   *out_ticket = b->ticket;
@@ -1397,7 +1408,7 @@ int sa_pipe_launch(sa_engine* e, uint64_t ticket) {
   HIPCHK(e, hipSetDevice(e->device));
   uint32_t maxN = 0, maxT = 0;
   TRY(bank_prepare(e, b, &maxN, &maxT));  // the track tables as they are NOW (an upsert / sa_tracks_apply may have come in between)
-  HIPCHK(e, hipStreamWaitEvent(e->stream, b->ev_staged, 0));
+  if (!b->staged_inline) HIPCHK(e, hipStreamWaitEvent(e->stream, b->ev_staged, 0));
   TRY(bank_upload(e, b, e->stream, false));  // nothing, unless the descriptors changed since staging (then: the descriptors only)
   bool done_rides = false;  // the frame's last dispatch signals ev_done itself
   if (b->n_slots) TRY(bank_launch(e, b, maxN, maxT, b->ev_done, &done_rides));
