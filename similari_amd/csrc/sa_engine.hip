@@ -623,16 +623,20 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // being profiled (the launch then stamps the profile's events) or captured into a graph (the caller does not ask then)
   static const bool done_by_marker = getenv("SA_DONE_EVENT") && !strcmp(getenv("SA_DONE_EVENT"), "record");
   const bool attach = done && maxN && !e->profile && !done_by_marker;
+  hipError_t le;
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
     if (attach) sa_done_event = done;
-    HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5));
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
   } else {
     { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
-    { ProfScope ps(e, KID_ASSIGN_SOLVE); if (attach) sa_done_event = done; HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }
+    ProfScope ps(e, KID_ASSIGN_SOLVE);
+    if (attach) sa_done_event = done;
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, 3);
   }
   if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
-  sa_done_event = nullptr;
+  sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
+  HIPCHK(e, le);
   return SA_OK;
 }
 
