@@ -1389,7 +1389,10 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
   // order in front of its kernels: the copy stream buys nothing there and its hand-over costs a barrier packet per frame
   // (SA_SMALL_INGEST=copy_stream | inline: measurements).
   static const char* small_env = getenv("SA_SMALL_INGEST");
-  const bool small_inline = small_env ? small_env[0] == 'i' : b->used <= (128u << 10);
+  size_t moved = b->used;  // the arena, plus the feature rows the upload reads in place from a pinned block
+  for (uint32_t i = 0; i < b->n_slots; ++i)
+    if (b->slots[i]->feats_inplace) moved += (size_t)b->slots[i]->N * e->D * 4;
+  const bool small_inline = small_env ? small_env[0] == 'i' : moved <= (128u << 10);
   b->staged_inline = !e->copy_stream || small_inline;
   hipStream_t cs = b->staged_inline ? e->stream : e->copy_stream;
   if (b->staged_inline) {
