@@ -4,7 +4,7 @@
 # MFMA-utilisation PMC passes, HBM-traffic PMC passes, the two-rank dispatch rehearsal, the in-process cluster, the side benches.
 #   scripts/profile_round2.sh <tag>     -> gpurun_out/<tag>/ ; copy what is to be judged into profiles/<tag>_*
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-TAG=${1:-r02_x}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+TAG=${1:-r02_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
