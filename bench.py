@@ -61,14 +61,15 @@ def workload(name: str, seed: int):
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
         return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d EUCLIDEAN + IoU(0.3), K=1 (the C2 frame with the other visual metric)"
-    if name == "c2d":
+    if name in ("c2d", "c2dd"):
         # the C2 frame under the reference's DEFAULT VisualSortOptions (visual_sort/options.rs:194-205, metric/builder.rs:26-42):
         # euclidean metric, five observations per track, visual_minimal_track_length 3 (the threshold stays finite so that is_ok prunes)
         n = t = 1000
         d, k = 512, 5
         sc = synth.visual_scene(rng, t, n, d, k)
-        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=0.5, feature_len=d,
-                              max_observations=k, visual_min_votes=1, visual_minimal_track_length=3,
+        # c2dd: the literal default threshold as well (f32::MAX: every cell present, every pair a group of the vote)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=0.5 if name == "c2d" else 3.4028234663852886e38,
+                              feature_len=d, max_observations=k, visual_min_votes=1, visual_minimal_track_length=3,
                               positional_min_confidence=0.1, max_idle_epochs=2)
         return cfg, [sc], "VisualSORT 1000 x 1000 x 512-d under the reference's default options: EUCLIDEAN, 5 observations per track, minimal track length 3"
     if name == "c5":

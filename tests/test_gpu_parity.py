@@ -494,6 +494,26 @@ def test_visual_euclid_reference_bench_distribution():
     np.testing.assert_array_equal(ids, sc["truth"])
 
 
+def test_reference_default_visual_options():
+    """The literal defaults of the reference (visual_sort/metric/builder.rs:26-42, options.rs:194-205): euclidean metric with threshold
+    f32::MAX — EVERY cell with a usable feature pair is present and every (candidate, track) pair is a group of the BestFit vote —
+    five observations per track, visual_minimal_track_length 3, one vote.  Ragged banks: a fifth of the observations missing, so some
+    tracks are too short to vote at all."""
+    rng = np.random.default_rng(83)
+    n, t, d, k = 300, 280, 128, 5
+    sc = synth.visual_scene(rng, t, n, d, k, canvas=(1500.0, 900.0), new_fraction=0.1)
+    pres = sc["track_present"]
+    pres[rng.uniform(size=pres.shape) < 0.2] = 0
+    pres[:12] = 0
+    pres[:12, :2] = 1  # twelve tracks with two observations: below the minimal track length
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="euclidean", visual_threshold=3.4028234663852886e38, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=3, positional_min_confidence=0.1, max_idle_epochs=2)
+    ids, votes, ref = check_visual(cfg, sc, tol_abs=1e-6, tol_rel=1e-5)
+    assert (votes == abi.SA_VOTE_VISUAL).sum() > 0.5 * n
+    short = set(sc["track_ids"][:12].tolist())
+    assert not (set(ids[votes == abi.SA_VOTE_VISUAL].tolist()) & short)  # a track below the minimal length wins nothing visually
+
+
 def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_conditioned():
     """The matrix-core path for euclidean distances recomputes directly every cell its f32 expansion cannot hold to 1e-5; on the
     reference's own bench distribution (features 10 * idx +- 0.01: norms ~ 10^4 x the spread) that is nearly every cell, the frame
