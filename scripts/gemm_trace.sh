@@ -21,6 +21,9 @@ if isother.any():
         if len(o): print("   %s: %d blocks, entry %.0f .. %.0f (median %.0f), exit %.0f .. %.0f, mean life %.0f cycles" % (name,len(o),o[:,1].min(),o[:,1].max(),np.median(o[:,1]),o[:,6].min(),o[:,6].max(),(o[:,6]-o[:,1]).mean()))
     g=rel[~isother]
     print("   contraction tiles: entry %.0f .. %.0f, exit %.0f .. %.0f" % (g[:,1].min(),g[:,1].max(),g[:,6].min(),g[:,6].max()))
+    pct=lambda v: " / ".join("%.0f" % np.percentile(v,q) for q in (10,50,90,99,100))
+    o=rel[a[:,2]==1]
+    if len(o): print("   exit percentiles 10/50/90/99/100: positional tiles", pct(o[:,6]), "| contraction tiles", pct(g[:,6]), "| positional life", pct(o[:,6]-o[:,1]))
 a=a[~isother]
 t=a[:,1:7]
 d=np.diff(t,axis=1)
