@@ -120,6 +120,9 @@ typedef struct sa_config {
 #define SA_FLAG_F16_SPLIT 0x40u      /* cosine contraction with f16-split operands on the f16 matrix cores (22-bit operands, f32 accumulate:
                                          |error| < 1e-6 on a cosine, several times the f32 rate; NOT f32 arithmetic — opt-in) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
+#define SA_FLAG_TAP 0x80u           /* parity tests: the assignment tail copies out what the frame's OWN launches produced — the BestFit vote
+                                       words of the first phase and the edge counts of the positional tiles — before it consumes them, for
+                                       sa_tap_votes / sa_tap_edges.  Same kernels, same launches; three more stores per candidate. */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,
  * one observation per track, max_idle_epochs 5, Kalman weights 1/20 and 1/160 (kalman_2d_box.rs:26), device -1. */
@@ -299,6 +302,21 @@ int sa_tap_dims(sa_engine* e, uint32_t slot, uint32_t* n, uint32_t* t, uint32_t*
 int sa_tap_positional(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_visual(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out);
+/* What the frame's own (timed) launches produced, as opposed to the matrices above, which the taps recompute on demand.  Engines created
+ * with SA_FLAG_TAP only (SA_ERR_STATE otherwise).
+ *   sa_tap_votes: the BestFit vote (track/voting/best.rs:52-128) as the first phase reduced it — per candidate its best track
+ *     (row_idx, -1 = the row has no group at all) and per track its best candidate (col_idx), with the weight that won:
+ *       *kind == 1  bank depth 1: the LIGHTEST visual weight of the row / column (the heaviest group is the lightest weight,
+ *                   VisualMetric::visual_metric after distance_to_weight, visual_sort/metric.rs:200-225), exactly as the kernel formed it (f32)
+ *       *kind == 2  deeper banks: the HEAVIEST group weight W = sum_k f64(max_dist - w_k) of the row / column, truncated to the 54 leading
+ *                   bits the vote word carries (relative error < 2^-43)
+ *     Frames up to 1024 x 1024 decode the vote words, larger ones fold the per-tile partials the resolve kernel reads.
+ *   sa_tap_edges: the input of the positional vote (SortVoting::winners, sort/voting.rs:30-100) as the positional tiles emitted it:
+ *     counts[i] edges for candidate i, then cols / gains in CSR order (row after row, arbitrary order inside a row), gain = quantised
+ *     weight - quantised new-track threshold > 0.  cap = capacity of cols / gains in edges; *out_total = edges in all (call with
+ *     cap = 0 to size the arrays). */
+int sa_tap_votes(sa_engine* e, uint32_t slot, double* row_w, int32_t* row_idx, double* col_w, int32_t* col_idx, int32_t* kind);
+int sa_tap_edges(sa_engine* e, uint32_t slot, uint32_t* counts, uint32_t cap, uint32_t* cols, int64_t* gains, uint32_t* out_total);
 
 /* ---- pinned host blocks (optional) --------------------------------------------------------
  * sa_detections.feats (N x D f32: 2 MB at 1000 x 512) is normally copied into the engine's own pinned staging buffer before it

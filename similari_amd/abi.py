@@ -37,6 +37,7 @@ SA_FLAG_GRAPH = 0x8
 SA_FLAG_FUSED_FRAME = 0x10
 SA_FLAG_SEPARATE_FRAME = 0x20
 SA_FLAG_F16_SPLIT = 0x40
+SA_FLAG_TAP = 0x80
 
 
 class sa_box(C.Structure):
@@ -383,6 +384,8 @@ PROTOTYPES = {
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_quantised": (C.c_int, [ENGINE, u32, P(C.c_int64)]),
+    "sa_tap_votes": (C.c_int, [ENGINE, u32, f64p, P(i32), f64p, P(i32), P(i32)]),
+    "sa_tap_edges": (C.c_int, [ENGINE, u32, P(u32), u32, P(u32), P(C.c_int64), P(u32)]),
     "sa_profile_enable": (C.c_int, [ENGINE, C.c_int]),
     "sa_profile_reset": (C.c_int, [ENGINE]),
     "sa_profile_read": (C.c_int, [ENGINE, P(sa_kernel_stat), u32, P(u32)]),

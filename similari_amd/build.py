@@ -32,14 +32,40 @@ def needs_build() -> bool:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    """One object per source (compiled side by side, kept under similari_amd/lib/obj and reused while neither the source nor any
+    header is newer), then one link."""
     if not force and not needs_build():
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
+    obj_dir = LIB.parent / "obj"
+    obj_dir.mkdir(exist_ok=True)
     extra = os.environ.get("SA_EXTRA_FLAGS", "").split()   # e.g. -DSA_GEMM_TRACE / -DSA_POS_TRACE (in-kernel timelines)
-    cmd = [hipcc(), *FLAGS, *extra, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+    cflags = [f for f in FLAGS if f != "-shared"]
+    stamp = obj_dir / "flags.txt"
+    flag_text = " ".join(cflags + extra)
+    if force or not stamp.exists() or stamp.read_text() != flag_text:
+        for o in obj_dir.glob("*.o"):
+            o.unlink()
+        stamp.write_text(flag_text)
+    newest_header = max(p.stat().st_mtime for p in HEADERS)
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        o = obj_dir / (src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if o.exists() and o.stat().st_mtime > max((CSRC / src).stat().st_mtime, newest_header):
+            continue
+        cmd = [hipcc(), *cflags, *extra, "-c", str(CSRC / src), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((src, subprocess.Popen(cmd, cwd=str(CSRC))))
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *[str(o) for o in objs], "-o", str(LIB)]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=str(CSRC))
+        print(" ".join(link), file=sys.stderr)
+    subprocess.run(link, check=True, cwd=str(CSRC))
     return LIB
 
 

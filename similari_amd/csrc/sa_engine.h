@@ -124,6 +124,12 @@ struct SceneDev {
   uint32_t SA_G* stats;      // [4] device words the first phase raises: [0] = 1 when the frame was ill-conditioned for the euclidean expansion
   uint32_t SA_G* out_stats;  // [4] the same, moved next to the results (mapped host memory) and re-armed by the assignment tail
   int64_t SA_G* quant;  // optional N x T tap
+  // SA_FLAG_TAP (parity tests): what the timed launches themselves produced, copied out by the assignment tail before it re-arms /
+  // consumes it — the vote words as the first phase left them and the edge counts of the positional tiles (the edge records stay in
+  // e_edge).  Null otherwise: the tails test one wave-uniform pointer.
+  unsigned long long SA_G* tap_row_best;  // [N]
+  unsigned long long SA_G* tap_col_best;  // [T]
+  uint32_t SA_G* tap_ecnt;                // [N]
 };
 #define SCN_HAS_FEATS 1u
 #define SCN_HAS_QUALITY 2u

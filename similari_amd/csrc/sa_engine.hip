@@ -69,6 +69,7 @@ struct Slot {  // one scene of a request set
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
   DevBuf lab, cwin, big_rows, big_roots, big_bcol, big_clist;  // general tail: component labels, the cooperative solver's lists
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
+  DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
   HostBuf h_apply, h_pred;
   void* d_pred = nullptr;
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
@@ -99,6 +100,9 @@ struct Bank {
   bool eu_mfma = false;                 // this set's euclidean distances go through the matrix-core contraction
   bool partials = false;                // this set's contraction votes itself (no weight matrix): cosine or matrix-core euclidean, bank depth 1
   int words = 0;                        // vote words instead of partials + resolve: 0 no, 1 = (key32 << 32 | index) from the cost kernel, 2 = (key54 << 10 | index) from k_bestfit_tile
+  bool frame_with_prep = true;          // what enqueue_frame decided for this set's launches: the preparation blocks ride in the first phase
+                                        // (a replayed graph runs no host code of enqueue_frame: bank_launch re-applies it to the slots)
+  bool frame_small_tail = false;        // the set's last launches went through the one-workgroup tail (slot-major edge lists, vote words)
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -128,6 +132,8 @@ struct sa_engine {
   hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
   Bank banks[SA_BANKS];
   Bank* B = &banks[0];               // the bank the synchronous entry points, the taps and sa_tracks_apply refer to
+  uint64_t B_ticket = 0;             // != 0: B was bound by sa_pipe_wait(ticket); slot numbers mean THAT ticket's scenes for as long as its bank
+                                     // has not been recycled by a later sa_pipe_stage (bound_bank_ok)
   uint64_t next_ticket = 1;
   uint32_t K = 1, D = 0, Dp = 0;
   bool f16_split = false;               // SA_FLAG_F16_SPLIT: the contraction's operands as f16 pairs (separate launches only)
@@ -141,7 +147,11 @@ struct sa_engine {
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
-  std::vector<void*> garbage;  // device buffers to free at the next sync
+  // device buffers that were replaced while work that may still read them was queued: freed at the next full sync, or — pipelined
+  // loops never reach one — by sa_pipe_wait once every ticket issued before the replacement has been waited for (tag = the ticket
+  // number that was next when the buffer was replaced)
+  struct Garbage { void* p; uint64_t tag; };
+  std::vector<Garbage> garbage;
   // upload scratch for upserts
   DevBuf nms_mask, nms_keep;
   DevBuf up_raw, up_slots, up_epochs, up_ids, up_mean, up_cov, up_feats, up_present, up_index;
@@ -187,7 +197,7 @@ int dev_ensure(sa_engine* e, DevBuf& b, size_t bytes, bool keep = false) {
   if (s != hipSuccess) return fail(e, SA_ERR_OOM, "hipMalloc(%zu) failed: %s", ncap, hipGetErrorString(s));
   if (b.p) {
     if (keep && b.cap) HIPCHK(e, hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, e->stream));
-    e->garbage.push_back(b.p);  // freed after the next stream sync: queued work may still read it
+    e->garbage.push_back({b.p, e->next_ticket});  // freed once nothing queued can still read it
   }
   b.p = np;
   b.cap = ncap;
@@ -215,7 +225,7 @@ int engine_sync(sa_engine* e) {
     if (e->aux_stream[k]) HIPCHK(e, hipStreamSynchronize(e->aux_stream[k]));
   if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (void* p : e->garbage) hipFree(p);
+  for (auto& g : e->garbage) hipFree(g.p);
   e->garbage.clear();
   e->synced = true;
   // resolve open profile records
@@ -229,6 +239,23 @@ int engine_sync(sa_engine* e) {
     e->ev_pool.push_back(r.b);
   }
   e->prof_open.clear();
+  return SA_OK;
+}
+
+// The compute stream alone (sa_tracks_apply: its kernels and the mapped results are all on it): the copy stream may be busy with the
+// ingest of the NEXT request set — that is the overlap the pipelined entry points exist for — and is left alone.
+int compute_sync(sa_engine* e) {
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return SA_OK;
+}
+
+// Slot numbers of sa_tracks_apply / sa_batch_fetch / the taps mean the scenes of the bank e->B points at.  After sa_pipe_wait(ticket)
+// that is the ticket's bank — until a later sa_pipe_stage recycles it for another request set: from then on the slots would silently
+// mean the NEW set's scenes with the caller's OLD winners and new_ids.  Refuse instead.
+int bound_bank_ok(sa_engine* e, const char* who) {
+  if (e->B_ticket && (e->B->ticket != e->B_ticket || e->B->state != 3))
+    return fail(e, SA_ERR_STATE, "%s: the request set of ticket %llu is gone (its bank was recycled by a later sa_pipe_stage); "
+                "call it right after sa_pipe_wait, before staging %d more sets", who, (unsigned long long)e->B_ticket, SA_BANKS - 1);
   return SA_OK;
 }
 
@@ -403,6 +430,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->stats, 256));
     if (s->stats.p != before) s->needs_init = true;
   }
+  if (e->cfg.flags & SA_FLAG_TAP) TRY(dev_ensure(e, s->tap, n * 8 + t * 8 + n * 4));
   {
     void* before = s->h_out.p;
     TRY(host_ensure(e, s->h_out, n * 9 + 32));  // ids[n] | votes[n] | (8-byte aligned) stats[4]
@@ -450,6 +478,12 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->big_roots = (decltype(d->big_roots))(s->big_roots.p); d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->big_clist = (decltype(d->big_clist))(s->big_clist.p);
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
+  if (s->tap.p) {  // SA_FLAG_TAP: [N] row words | [T] column words | [N] edge counts (sizes as slot_reserve laid them out)
+    const size_t n = s->N ? s->N : 1, t = s->T ? s->T : 1;
+    d->tap_row_best = (decltype(d->tap_row_best))(s->tap.p);
+    d->tap_col_best = (decltype(d->tap_col_best))((unsigned long long*)s->tap.p + n);
+    d->tap_ecnt = (decltype(d->tap_ecnt))((unsigned long long*)s->tap.p + n + t);
+  }
 }
 
 // Brings a bank's request set onto the device through stream `st`: the scene inputs appended to the staging arena (once per
@@ -613,7 +647,8 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   }
   if (e->visual && !fused && !side_by_side) with_prep = true;  // the stand-alone contraction reads the padded features, norms and gates
   if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, side_by_side, with_prep ? 1 : 0)); }
-  for (uint32_t i = 0; i < ns; ++i) b->slots[i]->prepped = with_prep;
+  b->frame_with_prep = with_prep;
+  b->frame_small_tail = small_tail;
   if (e->visual) {
     if (!fused && !side_by_side) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
     if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
@@ -729,7 +764,8 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t 
       return rc;
     }
   }
-  for (uint32_t i = 0; i < ns; ++i) b->slots[i]->ran = true;
+  // per launch, replays of a captured graph included: what the frame's launches did (not) prepare
+  for (uint32_t i = 0; i < ns; ++i) { b->slots[i]->ran = true; b->slots[i]->prepped = b->frame_with_prep; }
   return SA_OK;
 }
 
@@ -911,7 +947,7 @@ void sa_engine_destroy(sa_engine* e) {
   hipSetDevice(e->device);
   if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
   hipStreamSynchronize(e->stream);
-  for (void* p : e->garbage) hipFree(p);
+  for (auto& g : e->garbage) hipFree(g.p);
   for (auto& kv : e->scenes) {
     SceneTable* s = kv.second;
     for (DevBuf* b : {&s->geo, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
@@ -924,7 +960,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                         &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
-                        &s->bank_tmp, &s->stats, &s->lab, &s->cwin, &s->big_rows, &s->big_roots, &s->big_bcol, &s->big_clist})
+                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_roots, &s->big_bcol, &s->big_clist})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_pred);
@@ -1107,7 +1143,7 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
       return rc;
     }
     for (size_t k = 0; k < arrs.size(); ++k) {
-      e->garbage.push_back(arrs[k].b->p);
+      e->garbage.push_back({arrs[k].b->p, e->next_ticket});
       *arrs[k].b = fresh[k];
     }
   }
@@ -1158,6 +1194,7 @@ int sa_batch_begin(sa_engine* e) {
     if (bk.state == 1 || bk.state == 2)
       return fail(e, SA_ERR_STATE, "ticket %llu is still outstanding: sa_pipe_wait it before a synchronous batch", (unsigned long long)bk.ticket);
   TRY(engine_sync(e));  // "busy monitor": the previous batch must have drained (sort/batch_api.rs:233-241)
+  e->B_ticket = 0;      // the synchronous entry points own e->B from here on
   bank_clear(e->B);
   return SA_OK;
 }
@@ -1321,6 +1358,7 @@ int sa_batch_sync(sa_engine* e) {
 
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type) {
   if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_batch_fetch"));
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch before sa_batch_run");
@@ -1373,11 +1411,20 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
     if (d->n && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
     for (uint32_t k = 0; k < d->n; ++k) TRY(check_box(e, d->boxes[k], "detections.boxes", k));
   }
-  Bank* b = nullptr;  // an idle bank, the one whose ticket is older
-  for (Bank& bk : e->banks)
-    if ((bk.state == 0 || bk.state == 3) && (!b || bk.ticket < b->ticket)) b = &bk;
+  // an idle bank, the one whose ticket is older — but not the bank sa_tracks_apply / the taps are still bound to (the ticket waited
+  // for last) while another one is idle: `stage(n+1); wait(n); apply(n); launch(n+1)` must find ticket n's scenes in place
+  Bank* b = nullptr;
+  bool outstanding = false;
+  for (Bank& bk : e->banks) {
+    outstanding = outstanding || bk.state == 1 || bk.state == 2;
+    if ((bk.state == 0 || bk.state == 3) && !(e->B_ticket && &bk == e->B) && (!b || bk.ticket < b->ticket)) b = &bk;
+  }
+  if (!b && e->B_ticket && (e->B->state == 0 || e->B->state == 3)) b = e->B;
   if (!b) return fail(e, SA_ERR_STATE, "%d tickets are outstanding: sa_pipe_wait one of them first", SA_BANKS);
   HIPCHK(e, hipSetDevice(e->device));
+  // first ticket after synchronous work (sa_batch_run without a sync, an upsert): the idle bank may be the one whose launches are
+  // still queued — drain once; with tickets in flight the banks' own states say what is busy
+  if (!outstanding && !e->synced) TRY(engine_sync(e));
   bank_clear(b);
   for (uint32_t i = 0; i < n_scenes; ++i) {
     int rc = bank_add(e, b, req[i].scene_id, req[i].epoch, &req[i].detections, nullptr, nullptr);
@@ -1447,17 +1494,34 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
   }
   b->state = 3;
   e->B = b;  // slots of taps / sa_tracks_apply / sa_batch_fetch now mean this ticket's scenes
+  e->B_ticket = ticket;
+  // A pipelined loop never reaches engine_sync: buffers replaced on the way (a track table that grew, a slot that met a larger frame)
+  // are freed here, once every ticket that was launched before the replacement has been waited for.
+  if (!e->garbage.empty()) {
+    uint64_t oldest = ~0ull;  // oldest ticket still launched and not waited for
+    for (const Bank& bk : e->banks)
+      if (bk.state == 2 && bk.ticket < oldest) oldest = bk.ticket;
+    size_t keep = 0;
+    for (size_t i = 0; i < e->garbage.size(); ++i) {
+      if (e->garbage[i].tag <= oldest) hipFree(e->garbage[i].p);
+      else e->garbage[keep++] = e->garbage[i];
+    }
+    e->garbage.resize(keep);
+  }
   return SA_OK;
 }
 
 // ---- device-side track upkeep ---------------------------------------------------------------------------
 int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted) {
   if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_tracks_apply"));
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_tracks_apply before sa_batch_run");
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->synced) TRY(engine_sync(e));
+  // the slot's winners must be in: a waited ticket's are (sa_pipe_wait); after a synchronous run the compute stream has to drain.
+  // Never the copy stream: it may be carrying the NEXT request set's ingest, which is exactly what this call is meant to overlap.
+  if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
   SceneTable* sc = s->scene;
   const uint32_t n = s->N, K = e->K;
   if (!n) return SA_OK;
@@ -1525,7 +1589,8 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   }
   HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
   e->synced = false;
-  TRY(engine_sync(e));
+  if (e->B_ticket) TRY(compute_sync(e));  // pipelined: leave the copy stream (the next set's ingest) alone
+  else TRY(engine_sync(e));
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
   // host side of the table: the new rows
   for (uint32_t i = 0; i < n; ++i)
@@ -1684,6 +1749,7 @@ int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share
 // ---- parity taps ----------------------------------------------------------------------------------------
 static int tap_slot(sa_engine* e, uint32_t slot, Slot** out) {
   if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "tap"));
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   if (!e->B->slots[slot]->ran) return fail(e, SA_ERR_STATE, "tap before sa_batch_run");
   HIPCHK(e, hipSetDevice(e->device));
@@ -1768,6 +1834,109 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipMemcpy(out, s->quant.p, cells * 8, hipMemcpyDeviceToHost));
   hipFree(tmp.p);
+  return SA_OK;
+}
+
+// What the frame's OWN launches produced (SA_FLAG_TAP): the BestFit vote as the first phase reduced it.
+int sa_tap_votes(sa_engine* e, uint32_t slot, double* row_w, int32_t* row_idx, double* col_w, int32_t* col_idx, int32_t* kind) {
+  Slot* s;
+  TRY(tap_slot(e, slot, &s));
+  if (!e->visual) return fail(e, SA_ERR_UNSUPPORTED, "engine has no visual part");
+  if (!(e->cfg.flags & SA_FLAG_TAP) || !s->tap.p) return fail(e, SA_ERR_STATE, "sa_tap_votes needs an engine created with SA_FLAG_TAP");
+  if (!row_w || !row_idx || !col_w || !col_idx || !kind) return fail(e, SA_ERR_BAD_ARG, "null output");
+  const Bank* b = e->B;
+  const uint32_t N = s->N, T = s->T;
+  *kind = (b->partials || b->words == 1) ? 1 : 2;
+  if (!N || !T) return SA_OK;
+  if (b->words) {
+    std::vector<unsigned long long> w((size_t)N + T);
+    HIPCHK(e, hipMemcpy(w.data(), s->tap.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(w.data() + N, (unsigned long long*)s->tap.p + (N ? N : 1), (size_t)T * 8, hipMemcpyDeviceToHost));
+    auto decode = [&](unsigned long long word, double* wt, int32_t* idx) {
+      if (word == ~0ull) { *wt = NAN; *idx = -1; return; }
+      if (b->words == 1) {  // (order-preserving key of the f32 weight << 32) | index
+        *wt = (double)sa_key_f32((uint32_t)(word >> 32));
+        *idx = (int32_t)(uint32_t)word;
+      } else {              // ((2^54 - 1 - key54) << 10) | index, key54 = (f64 bits >> 9) + 1   (sa_vote_word10, sa_kernels.hip)
+        const unsigned long long key = ((1ull << 54) - 1ull) - (word >> 10);
+        const unsigned long long bits = (key - 1ull) << 9;
+        double v;
+        std::memcpy(&v, &bits, 8);
+        *wt = v;
+        *idx = (int32_t)(word & 1023u);
+      }
+    };
+    for (uint32_t i = 0; i < N; ++i) decode(w[i], &row_w[i], &row_idx[i]);
+    for (uint32_t j = 0; j < T; ++j) decode(w[(size_t)N + j], &col_w[j], &col_idx[j]);
+    return SA_OK;
+  }
+  // beyond the vote words: the per-tile partials, folded the way k_bestfit_resolve folds them (tiles ascend with the index; the first
+  // tile that attains the best weight keeps it).  RAW (bank depth 1): lightest weight wins; else heaviest group weight.
+  const bool raw = b->partials;
+  const uint32_t CT = raw ? (T + b->tile_bn - 1) / b->tile_bn : (T + 63) / 64, RT = raw ? (N + b->tile_bm - 1) / b->tile_bm : (N + 63) / 64;
+  std::vector<double> rw((size_t)CT * N), cw((size_t)RT * T);
+  std::vector<int32_t> rt_((size_t)CT * N);
+  std::vector<uint32_t> cq((size_t)RT * T);
+  HIPCHK(e, hipMemcpy(rw.data(), s->row_part_w.p, rw.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(rt_.data(), s->row_part_t.p, rt_.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(cw.data(), s->col_part_w.p, cw.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(cq.data(), s->col_part_q.p, cq.size() * 4, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < N; ++i) {
+    double bw = 0.0;
+    int32_t bi = -1;
+    for (uint32_t ct = 0; ct < CT; ++ct) {
+      const int32_t t = rt_[(size_t)ct * N + i];
+      const double w = rw[(size_t)ct * N + i];
+      if (t >= 0 && (bi < 0 || (raw ? w < bw : w > bw))) { bw = w; bi = t; }
+    }
+    row_w[i] = bi >= 0 ? bw : NAN;
+    row_idx[i] = bi;
+  }
+  for (uint32_t j = 0; j < T; ++j) {
+    double bw = 0.0;
+    int32_t bi = -1;
+    for (uint32_t rt = 0; rt < RT; ++rt) {
+      const uint32_t q = cq[(size_t)rt * T + j];
+      const double w = cw[(size_t)rt * T + j];
+      if (q != SA_NONE && (bi < 0 || (raw ? w < bw : w > bw))) { bw = w; bi = (int32_t)q; }
+    }
+    col_w[j] = bi >= 0 ? bw : NAN;
+    col_idx[j] = bi;
+  }
+  return SA_OK;
+}
+
+// ... and the edges the positional tiles emitted (the records stay in e_edge; the tail copied the counts out before it cleared them).
+int sa_tap_edges(sa_engine* e, uint32_t slot, uint32_t* counts, uint32_t cap, uint32_t* cols, int64_t* gains, uint32_t* out_total) {
+  Slot* s;
+  TRY(tap_slot(e, slot, &s));
+  if (!(e->cfg.flags & SA_FLAG_TAP) || !s->tap.p) return fail(e, SA_ERR_STATE, "sa_tap_edges needs an engine created with SA_FLAG_TAP");
+  if (!counts || !out_total) return fail(e, SA_ERR_BAD_ARG, "null output");
+  const uint32_t N = s->N, T = s->T;
+  *out_total = 0;
+  if (!N) return SA_OK;
+  HIPCHK(e, hipMemcpy(counts, (unsigned long long*)s->tap.p + (size_t)(N ? N : 1) + (T ? T : 1), (size_t)N * 4, hipMemcpyDeviceToHost));
+  uint64_t total = 0;
+  uint32_t maxc = 0;
+  for (uint32_t i = 0; i < N; ++i) { total += counts[i]; maxc = counts[i] > maxc ? counts[i] : maxc; }
+  if (total > 0xffffffffull || maxc > T) return fail(e, SA_ERR_STATE, "sa_tap_edges: implausible edge counts (the slot did not run with the tap?)");
+  *out_total = (uint32_t)total;
+  if (!total || cap < total) return SA_OK;
+  if (!cols || !gains) return fail(e, SA_ERR_BAD_ARG, "null output");
+  // the first maxc records of every row: slot-major lists (one-workgroup tail) are maxc contiguous runs of N records,
+  // row-major lists (general tail) N runs of maxc records, `estride` records apart
+  const bool slot_major = e->B->frame_small_tail;
+  const size_t estride = T ? T : 1;
+  std::vector<SaEdge> h((size_t)maxc * N);
+  if (slot_major) HIPCHK(e, hipMemcpy(h.data(), s->e_edge.p, h.size() * sizeof(SaEdge), hipMemcpyDeviceToHost));
+  else HIPCHK(e, hipMemcpy2D(h.data(), (size_t)maxc * sizeof(SaEdge), s->e_edge.p, estride * sizeof(SaEdge), (size_t)maxc * sizeof(SaEdge), N, hipMemcpyDeviceToHost));
+  size_t o = 0;
+  for (uint32_t i = 0; i < N; ++i)
+    for (uint32_t k = 0; k < counts[i]; ++k, ++o) {
+      const SaEdge& ed = slot_major ? h[(size_t)k * N + i] : h[(size_t)i * maxc + k];
+      cols[o] = ed.col;
+      gains[o] = ed.gain;
+    }
   return SA_OK;
 }
 

@@ -493,6 +493,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
     if (q < N) S.row_best[q] = ~0ull;
     if (q < T) S.col_best[q] = ~0ull;
+    if (S.tap_row_best) {  // SA_FLAG_TAP: the words as the first phase left them
+      if (q < N) S.tap_row_best[q] = rb;
+      if (q < T) S.tap_col_best[q] = cb;
+    }
     const uint32_t imask = (S.flags & SCN_WORDS10) ? 1023u : 0xffffffffu;  // deeper banks: (inverted weight key << 10) | index, k_bestfit_tile
     bt = rb != ~0ull ? ((uint32_t)rb & imask) : SA_NONE;
     const uint32_t cq = cb != ~0ull ? ((uint32_t)cb & imask) : SA_NONE;
@@ -529,6 +533,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     }
   }
   if (q < N) S.e_cnt[q] = 0;  // left clean for the next frame's positional tiles (nothing below reads the global counter)
+  if (S.tap_ecnt && q < N) S.tap_ecnt[q] = rawcnt;  // SA_FLAG_TAP: how many edge records the positional tiles appended to this row
   const uint32_t mycnt = (q < N && !has_verdict) ? rawcnt : 0u;
   s_rmatch[q] = -1;
   s_ecnt[q] = mycnt;
@@ -756,6 +761,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const uint32_t cnt = S.e_cnt[q];
   S.e_use[q] = cnt;
   S.e_cnt[q] = 0;
+  if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
   if (q == 0) { S.stats[1] = 0u; S.stats[2] = 0u; }  // tops of the big-component row / root lists of k_assign_solve

@@ -226,6 +226,31 @@ class Engine:
         self._chk(self.lib.sa_tap_quantised(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 
+    def tap_votes(self, slot: int = 0):
+        """The BestFit vote as the frame's own first phase reduced it (engines created with SA_FLAG_TAP): (row_w, row_idx, col_w,
+        col_idx, kind); kind 1 = lightest visual weight per row / column, 2 = heaviest group weight W."""
+        n, t, _ = self.tap_dims(slot)
+        rw, ri = np.full(n, np.nan), np.full(n, -1, np.int32)
+        cw, ci = np.full(t, np.nan), np.full(t, -1, np.int32)
+        kind = C.c_int32()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        self._chk(self.lib.sa_tap_votes(self.h, slot, rw.ctypes.data_as(dp), ri.ctypes.data_as(ip), cw.ctypes.data_as(dp),
+                                        ci.ctypes.data_as(ip), C.byref(kind)))
+        return rw, ri, cw, ci, kind.value
+
+    def tap_edges(self, slot: int = 0):
+        """The positional vote's input as the positional tiles emitted it (SA_FLAG_TAP): (counts[N], cols[E], gains[E]) in CSR order."""
+        n, _, _ = self.tap_dims(slot)
+        counts = np.zeros(max(n, 1), np.uint32)
+        total = C.c_uint32()
+        u32p = C.POINTER(C.c_uint32)
+        self._chk(self.lib.sa_tap_edges(self.h, slot, counts.ctypes.data_as(u32p), 0, None, None, C.byref(total)))
+        cols = np.zeros(max(total.value, 1), np.uint32)
+        gains = np.zeros(max(total.value, 1), np.int64)
+        self._chk(self.lib.sa_tap_edges(self.h, slot, counts.ctypes.data_as(u32p), total.value, cols.ctypes.data_as(u32p),
+                                        gains.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total)))
+        return counts[:n], cols[: total.value], gains[: total.value]
+
     # ---- measurement ----
     def profile_enable(self, on: bool = True):
         self._chk(self.lib.sa_profile_enable(self.h, 1 if on else 0))

@@ -50,6 +50,97 @@ def total_gain(res_ids, quant, track_ids, thr_q):
     return g
 
 
+
+# ---- the timed launches themselves under the gates ---------------------------------------------------------------------
+# The matrix taps above RECOMPUTE the positional / visual matrices on demand (dense kernels on padded rows); the product path never
+# writes them.  With SA_FLAG_TAP the assignment tail copies out what the frame's OWN launches produced before it consumes it — the
+# edge records of the positional tiles and the BestFit vote words (or per-tile partials) of the first phase — and these two helpers
+# hold THAT to the same gates: edges bit for bit, vote weights within the distance tolerance.
+def check_edges(eng, quant_ref, thr_q, slot=0):
+    """Edge set == the oracle's survivor set {(i, j): quantised[i, j] - threshold > 0}, every gain == the oracle's quantised cell."""
+    counts, cols, gains = eng.tap_edges(slot)
+    gain_ref = quant_ref.astype(np.int64) - int(thr_q)
+    mask = gain_ref > 0
+    np.testing.assert_array_equal(counts, mask.sum(axis=1).astype(np.uint32))
+    rows = np.repeat(np.arange(len(counts)), counts)
+    order = np.lexsort((cols, rows))
+    ref_rows, ref_cols = np.nonzero(mask)
+    np.testing.assert_array_equal(rows[order], ref_rows)
+    np.testing.assert_array_equal(cols[order], ref_cols.astype(np.uint32))
+    np.testing.assert_array_equal(gains[order], gain_ref[mask])
+    return int(mask.sum())
+
+
+def thr_q_of(cfg):
+    return 1000000 if cfg.positional_kind == abi.SA_POS_MAHALANOBIS else int(O.lib().or_quantise(cfg.positional_threshold))
+
+
+def check_votes(cfg, eng, ref_visual, tol_abs=1e-5, tol_rel=0.0, slot=0):
+    """The BestFit vote as the first phase reduced it against the oracle's weight matrix ref_visual[N, T, K] (NaN = absent):
+    every row's / column's winning weight within the distance tolerance of the oracle's best, the winning index (near-)optimal in
+    the oracle's matrix — exactly the argmin / argmax wherever the runner-up is more than 2 tolerances away.  A cell within
+    tolerance of the is_ok threshold may exist on one side only: a winner that IS such a cell (or a row whose oracle best is one)
+    is excused and counted."""
+    rw, ri, cw, ci, kind = eng.tap_votes(slot)
+    rv = ref_visual
+    n, t, k = rv.shape
+    present = ~np.isnan(rv)
+    thr_w = (1.0 - cfg.visual_threshold) if cfg.visual_kind == abi.SA_VIS_COSINE else float(cfg.visual_threshold)
+    excused = 0
+    if kind == 1:
+        assert k == 1
+        w = np.where(present[:, :, 0], rv[:, :, 0].astype(np.float64), np.inf)   # lightest weight wins
+        tol = lambda x: tol_abs + tol_rel * abs(x)                              # noqa: E731
+        near_thr = lambda x: abs(x - thr_w) <= 2 * tol(thr_w)                    # noqa: E731
+        for axis, (gw, gi) in enumerate(((rw, ri), (cw, ci))):
+            m = w if axis == 0 else w.T
+            best = m.min(axis=1)
+            for q in range(m.shape[0]):
+                if gi[q] < 0:
+                    if np.isfinite(best[q]):
+                        assert near_thr(best[q]), (axis, q, best[q])
+                        excused += 1
+                    continue
+                if not np.isfinite(best[q]) or abs(gw[q] - best[q]) > tol(best[q]):
+                    # the kernel's winner may be a threshold cell the oracle does not have, or the oracle's best one the kernel lacks
+                    assert near_thr(gw[q]) or (np.isfinite(best[q]) and near_thr(best[q])), (axis, q, gw[q], best[q])
+                    excused += 1
+                    continue
+                assert m[q, gi[q]] <= best[q] + 2 * tol(best[q]), (axis, q, gi[q], m[q, gi[q]], best[q])
+    else:
+        # deeper banks: W[q, t] = sum_k f64(max_dist - w_k) over the present k (>= min_votes of them), max_dist = the frame's largest
+        # present weight (voting/best.rs:59); heaviest group wins.  The kernel's max_dist and every w_k carry the distance tolerance.
+        if not present.any():
+            assert (ri < 0).all() and (ci < 0).all()
+            return 0
+        max_dist = np.float32(np.nanmax(rv))
+        diff = (max_dist - rv).astype(np.float32).astype(np.float64)   # f32 subtraction, then f64 (the reference's order)
+        cnt = present.sum(axis=2)
+        W = np.where(present, diff, 0.0).sum(axis=2)
+        ok = (cnt >= 1) & (cnt >= cfg.visual_min_votes)
+        W = np.where(ok, W, -np.inf)
+        tolw = 4 * k * (tol_abs + tol_rel * float(max_dist)) + 1e-9   # k weights + k times the frame-wide max_dist, each within tolerance
+        thr_cells = present & (np.abs(rv - thr_w) <= 2 * (tol_abs + tol_rel * abs(thr_w)))
+        thr_any = thr_cells.any(axis=2)
+        for axis, (gw, gi) in enumerate(((rw, ri), (cw, ci))):
+            m = W if axis == 0 else W.T
+            ta = thr_any if axis == 0 else thr_any.T
+            best = m.max(axis=1)
+            for q in range(m.shape[0]):
+                on_threshold = bool(ta[q].any())   # a cell of this row / column may exist on one side only
+                if gi[q] < 0:
+                    if np.isfinite(best[q]):
+                        assert on_threshold, (axis, q, best[q])
+                        excused += 1
+                    continue
+                good = np.isfinite(best[q]) and abs(gw[q] - best[q]) <= tolw and m[q, gi[q]] >= best[q] - 2 * tolw
+                if not good:
+                    assert on_threshold, (axis, q, gw[q], best[q], gi[q])
+                    excused += 1
+    assert excused <= 2 + 1e-3 * (n + t), f"{excused} vote winners sit on the is_ok threshold"
+    return excused
+
+
 def check_sort(cfg, sc, epoch=1, kf=None, require_ids=True):
     tb = sc["track_boxes"]
     kw = {}
@@ -59,10 +150,12 @@ def check_sort(cfg, sc, epoch=1, kf=None, require_ids=True):
     tracks = abi.make_tracks(sc["track_ids"], tb, sc["track_epochs"], **kw)
     det = abi.make_detections(sc["det_boxes"])
     ref = O.associate(cfg, tracks, epoch, det)
+    cfg.flags |= abi.SA_FLAG_TAP
     eng = Engine(cfg)
     try:
         eng.upsert(0, tracks)
         ids, votes = eng.associate(0, epoch, det)
+        check_edges(eng, ref["quantised"], thr_q_of(cfg))  # what the timed positional tiles emitted (before any tap re-launches a kernel)
         pos = eng.tap_positional()
         q = eng.tap_quantised()
     finally:
@@ -289,6 +382,61 @@ def test_graph_replay_gives_the_same_answers(k):
         eng.close()
 
 
+def test_graph_replay_with_device_upkeep_of_a_visual_engine():
+    """SA_FLAG_GRAPH on a VisualSORT engine whose frames are LEAN (one observation per track, vote words: the preparation blocks stay
+    out of the first phase) with sa_tracks_apply after every frame: the feature-bank step reads the candidates' padded rows and norms,
+    which a replayed lean frame has NOT prepared — the engine must prepare them on demand on EVERY frame, replays included (round 2
+    skipped that from the second replay on and wrote the norms of an older frame into the bank).  Against an eager engine fed the same
+    frames: ids, predicted boxes and the banks' rows + squared norms (through the next frame's cosines) identical."""
+    import ctypes as C
+
+    rng = np.random.default_rng(41)
+    d, n = 64, 90
+    engines = []
+    try:
+        for flags in (abi.SA_FLAG_GRAPH, 0):
+            cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.3, feature_len=d,
+                                  max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                                  max_idle_epochs=5, flags=flags)
+            engines.append((cfg, Engine(cfg)))
+        ident = synth.reid_identities(rng, n, d)
+        world = synth.dense_boxes(rng, n, (1500.0, 1000.0))
+        u64p, bp = C.POINTER(C.c_uint64), C.POINTER(abi.sa_box)
+        next_id = 1
+        for frame in range(7):
+            world = synth.jitter_boxes(rng, world, 1.5)
+            feats = synth.observe(rng, ident, 0.02) * np.float32(1.0 + 0.1 * frame)  # the norms change from frame to frame
+            det = abi.make_detections(world, feats=feats, feat_quality=np.full(n, 0.9, np.float32))
+            outs = []
+            for cfg, eng in engines:
+                ids, votes = eng.associate(7, frame + 1, det)
+                new_ids = np.where(ids == 0, next_id + np.arange(n), 0).astype(np.uint64)
+                pred = np.zeros(n, abi.BOX_DTYPE)
+                rc = eng.lib.sa_tracks_apply(eng.h, 0, new_ids.ctypes.data_as(u64p), C.cast(pred.ctypes.data, bp))
+                assert rc == 0, eng.lib.sa_last_error(eng.h)
+                outs.append((ids, votes, pred, eng.order(7)))
+            next_id += n
+            (ia, va, pa, oa), (ib, vb, pb, ob) = outs
+            np.testing.assert_array_equal(ia, ib, err_msg=f"frame {frame}")
+            np.testing.assert_array_equal(va, vb)
+            np.testing.assert_array_equal(pa, pb)
+            np.testing.assert_array_equal(oa, ob)
+            if frame >= 2:
+                assert (va == abi.SA_VOTE_VISUAL).sum() > 0.8 * n   # the banks work: the visual vote decides
+        # the banks themselves, row for row
+        fp = C.POINTER(C.c_float)
+        for tid in engines[0][1].order(7)[:40]:
+            rows = []
+            for cfg, eng in engines:
+                ft = np.zeros((1, d), np.float32)
+                assert eng.lib.sa_tracks_get_state(eng.h, 7, int(tid), None, None, None, None, ft.ctypes.data_as(fp)) == 0
+                rows.append(ft)
+            np.testing.assert_array_equal(rows[0], rows[1])
+    finally:
+        for _, eng in engines:
+            eng.close()
+
+
 def test_device_upkeep_refuses_tracks_without_state():
     """sa_tracks_apply steps the Kalman filter of the winner: a track that was upserted with the 5 x 5 projection only has no
     full state on the device — the call must say so instead of stepping garbage; after sa_tracks_set_state it works."""
@@ -361,10 +509,15 @@ def visual_run(cfg, sc, epoch=1, kf=None, own_area=None, det_present=None):
     tracks = abi.make_tracks(sc["track_ids"], tb, sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"], **kw)
     det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"], own_area=own_area, feat_present=det_present)
     ref = O.associate(cfg, tracks, epoch, det)
+    cfg.flags |= abi.SA_FLAG_TAP
     eng = Engine(cfg)
     try:
         eng.upsert(0, tracks)
         ids, votes = eng.associate(0, epoch, det)
+        # the timed launches' own output first (the matrix taps below re-launch kernels)
+        check_edges(eng, ref["quantised"], thr_q_of(cfg))
+        euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
+        check_votes(cfg, eng, ref["visual"], tol_abs=0.0 if euclid else 1e-5, tol_rel=1e-5 if euclid else 0.0)
         pos = eng.tap_positional()
         vis = eng.tap_visual()
     finally:
@@ -1069,10 +1222,17 @@ def _full_size_visual(cfg, sc, shards=32):
     det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
     ref = O.associate(cfg, tracks, 1, det, shards=shards)
     ref["_track_ids"] = sc["track_ids"]
+    cfg.flags |= abi.SA_FLAG_TAP
     eng = Engine(cfg)
     try:
         eng.upsert(0, tracks)
         ids, votes = eng.associate(0, 1, det)
+        # the frame's own launches (the fused raw-row first phase + the tail at C2): edge records bit for bit, vote weights within
+        # the distance tolerance — before the matrix taps re-launch anything
+        n_edges = check_edges(eng, ref["quantised"], thr_q_of(cfg))
+        euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
+        check_votes(cfg, eng, ref["visual"], tol_abs=0.0 if euclid else 1e-5, tol_rel=1e-5 if euclid else 0.0)
+        assert n_edges > 0
         pos, vis, q = eng.tap_positional(), eng.tap_visual(), eng.tap_quantised()
     finally:
         eng.close()
@@ -1125,6 +1285,75 @@ def test_full_size_c2_euclidean_against_the_oracle():
     ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
     compare_visual(cfg, ids, votes, pos, vis, ref, tol_abs=0.0, tol_rel=1e-5)
     assert (~np.isnan(vis)).sum() >= 1000
+
+
+def hard_margin_scene(rng, metric, pairs=500, d=512, gap=(3e-5, 1e-4)):
+    """A C2-sized frame built so that the BestFit vote is SENSITIVE to the 1e-5 distance tolerance: every one of `pairs` tracks is seen
+    by TWO detections whose distances to it differ by only `gap` (uniform; absolute for the cosine, relative for the euclidean
+    distance) — a kernel whose distances were off by a few 1e-5 would hand columns to the wrong candidate, where the plain synthetic
+    frame (winner at cos ~1.0, runner-up at ~0.6) would not notice an error of 1e-3.  The other tracks see nothing."""
+    t = n = 2 * pairs
+    ident = synth.reid_identities(rng, t, d).astype(np.float64)
+    bank = ident + rng.uniform(-0.01, 0.01, ident.shape)
+    det = np.empty((n, d), np.float64)
+    for i in range(pairs):
+        f = bank[i]
+        a = ident[i] + rng.uniform(-0.01, 0.01, d)
+        g = rng.uniform(*gap)
+        if metric == "euclidean":
+            b = f + (a - f) * (1.0 + g)   # |b - f| = (1 + g) |a - f| exactly
+        else:
+            # a + s r with r orthogonal to f lowers the cosine monotonically in s: bisection for a drop of g
+            ca = a @ f / np.sqrt((a @ a) * (f @ f))
+            r = rng.standard_normal(d)
+            r -= (r @ f) / (f @ f) * f
+            r *= np.linalg.norm(a) / np.linalg.norm(r)
+            lo, hi = 0.0, 1.0
+            for _ in range(60):
+                mid = 0.5 * (lo + hi)
+                b = a + mid * r
+                cb = b @ f / np.sqrt((b @ b) * (f @ f))
+                lo, hi = (mid, hi) if cb > ca - g else (lo, mid)
+            b = a + 0.5 * (lo + hi) * r
+        det[2 * i], det[2 * i + 1] = a, b
+    perm = rng.permutation(n)
+    tboxes = synth.dense_boxes(rng, t, (6000.0, 4000.0))
+    dboxes = synth.dense_boxes(rng, n, (6000.0, 4000.0))   # positions unrelated to the tracks: the visual vote alone decides
+    return dict(track_ids=np.arange(1, t + 1, dtype=np.uint64), track_boxes=tboxes, track_epochs=np.zeros(t, np.uint64),
+                track_feats=bank.astype(np.float32)[:, None, :].copy(), track_present=np.ones((t, 1), np.uint8),
+                det_boxes=dboxes, det_feats=det.astype(np.float32)[perm].copy(), det_quality=np.full(n, 0.9, np.float32))
+
+
+@pytest.mark.parametrize("visual", ["cosine", "euclidean"])
+def test_full_size_c2_hard_margins_against_the_oracle(visual):
+    """C2 size with runner-ups within 1e-4 of the winners (hard_margin_scene): ids and vote types of the DEFAULT path (lean fused
+    raw-row first phase, vote words) must equal the oracle's on every row whose decision the oracle makes with a margin above
+    2.5 times the tolerance — i.e. on nearly all of them — and the vote words themselves pass check_votes."""
+    sc = hard_margin_scene(np.random.default_rng(77), visual)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual=visual, visual_threshold=0.2 if visual == "cosine" else 0.5,
+                          feature_len=512, max_observations=1, visual_min_votes=1, visual_minimal_track_length=1,
+                          positional_min_confidence=0.1, max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    rv = ref["visual"][:, :, 0].astype(np.float64)
+    w = np.where(np.isnan(rv), np.inf, rv)
+    # margin of every column's decision in the ORACLE's matrix: lightest against second lightest weight of the column, in units of
+    # the metric's tolerance (absolute for the cosine, relative for the euclidean distance)
+    part = np.partition(w, 1, axis=0)
+    scale = np.ones(w.shape[1]) if visual == "cosine" else np.where(np.isfinite(part[0]), np.abs(part[0]), 1.0)
+    with np.errstate(invalid="ignore"):
+        margin = (part[1] - part[0]) / scale
+    has = np.isfinite(w.min(axis=1))
+    best_col = np.argmin(w, axis=1)
+    used = np.unique(best_col[has])                      # the columns somebody competes for: the 500 tracks with two detections each
+    assert len(used) >= 450 and np.isfinite(margin[used]).all()
+    assert np.median(margin[used]) < 1.5e-4 and margin[used].max() < 1e-3, "the scene lost its hard margins"
+    safe_cols = ~np.isfinite(margin) | (margin > 2.5e-5)
+    assert safe_cols[used].mean() > 0.97
+    # a row is checked unless it competes for an unsafe column (its own best column)
+    checked = ~has | safe_cols[best_col]
+    np.testing.assert_array_equal(ids[checked], ref["track_id"][checked])
+    np.testing.assert_array_equal(votes[checked], ref["voting_type"][checked])
+    assert (votes[checked] == abi.SA_VOTE_VISUAL).sum() >= 450
 
 
 def test_full_size_c4_against_the_oracle():

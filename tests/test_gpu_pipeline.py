@@ -251,3 +251,44 @@ def test_pipeline_variants_match_the_oracle_too(env):
                         "test_pipelined_tickets or test_pipelined_tracker_loop or test_associate_batch_matches"],
                        env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, str(env) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_recycled_ticket_is_refused_not_misread():
+    """sa_pipe_wait binds the slot numbers of sa_tracks_apply / sa_batch_fetch / the taps to the waited ticket's scenes.  Staging more
+    request sets afterwards may recycle that ticket's bank: the engine then refuses those calls (SA_ERR_STATE) instead of applying the
+    caller's old winners to the new set's scenes; and while another bank is idle the bound one is left alone."""
+    rng = np.random.default_rng(75)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    eng = Engine(cfg)
+    try:
+        scs = [synth.sort_scene(rng, 60, 50 + 5 * i, canvas=(900.0, 700.0)) for i in range(5)]
+        for i, sc in enumerate(scs):
+            upsert_scene(eng, 20 + i, sc, False)
+        sets = [Engine.make_requests([(20 + i, 1, abi.make_detections(sc["det_boxes"]))]) for i, sc in enumerate(scs)]
+        t1 = eng.pipe_submit(sets[0][0])
+        t2 = eng.pipe_submit(sets[1][0])
+        eng.pipe_wait(t1, sets[0][1])
+        ids1 = sets[0][2][0][0].copy()
+        # one more set: a bank other than ticket 1's is idle, so slot 0 still means scene 20
+        t3 = eng.pipe_submit(sets[2][0])
+        np.testing.assert_array_equal(eng.batch_fetch(0, len(ids1))[0], ids1)
+        assert eng.tap_dims(0)[0] == len(ids1)
+        # a fourth set has to take ticket 1's bank: from now on its slots are gone
+        t4 = eng.pipe_submit(sets[3][0])
+        for call in (lambda: eng.batch_fetch(0, len(ids1)), lambda: eng.tap_dims(0), lambda: eng.tap_positional(0)):
+            with pytest.raises(EngineError) as ei:
+                call()
+            assert ei.value.code == abi.SA_ERR_STATE
+        new_ids = np.arange(1000, 1000 + len(ids1), dtype=np.uint64)
+        pred = np.zeros(len(ids1), abi.BOX_DTYPE)
+        rc = eng.lib.sa_tracks_apply(eng.h, 0, new_ids.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(pred.ctypes.data, C.POINTER(abi.sa_box)))
+        assert rc == abi.SA_ERR_STATE and b"recycled" in eng.lib.sa_last_error(eng.h)
+        # the tickets themselves are fine, and waiting rebinds
+        for t, k in ((t2, 1), (t3, 2), (t4, 3)):
+            eng.pipe_wait(t, sets[k][1])
+            ref = O.associate(cfg, abi.make_tracks(scs[k]["track_ids"], scs[k]["track_boxes"], scs[k]["track_epochs"]), 1,
+                              abi.make_detections(scs[k]["det_boxes"]), want_matrices=False)
+            np.testing.assert_array_equal(sets[k][2][0][0], ref["track_id"])
+        assert eng.tap_dims(0)[0] == len(scs[3]["det_boxes"])
+    finally:
+        eng.close()
