@@ -112,11 +112,11 @@ struct SceneDev {
   int64_t SA_G* rdist;
   int32_t SA_G* rnext;       // [N] general tail: rows in the component rooted at this row
   uint32_t SA_G* lab;        // [N] general tail: component root of the row (SA_NONE: takes no part)
-  uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column
-  uint32_t SA_G* big_rows;   // [N] rows of the big components, one ascending segment each
-  uint32_t SA_G* big_roots;  // [N] their search roots
+  uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column (SA_NONE between frames)
+  uint32_t SA_G* big_rows;   // [N] rows, then search roots, of the big components: one ascending segment each
+  uint32_t SA_G* dq;         // [N] general tail: roots of the components queued for the dense solver (stats[3] of them)
   uint32_t SA_G* big_bcol;   // [N] the column a row bids for
-  uint32_t SA_G* big_clist;  // [waves of k_assign_solve][T] labelled columns of a wave's running search
+  int64_t SA_G* dense;       // [N][T] gains of the components the dense solver (sa_dense.h) is working on; all zero between frames
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t SA_G* out_track_id;
   uint8_t SA_G* out_vote;

@@ -8,6 +8,7 @@
 // grid.z = scene so a whole batch of scenes goes through one launch.  No MFMA here on purpose.
 #include "sa_engine.h"
 #include "sa_frame.h"
+#include "sa_dense.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -447,6 +448,11 @@ __device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // of seconds of one lane's dependent LDS chain; the usual one- and two-row components never reach step 3.
 // Needs N <= SA_SMALL_N and T <= SA_SMALL_N (launcher): rows, columns and the usable edges (up to POOL of them; more stay in the
 // HBM lists and are read from there) live in LDS.
+// the dense solver (sa_dense.h): SA_DENSE_NT threads, each owning T / SA_DENSE_NT columns; components with at least SA_DENSE_MIN_ROOTS
+// search roots on at least SA_DENSE_MIN_COLS columns (or whose edge lists stayed in HBM) go to it
+#define SA_DENSE_NT 256
+#define SA_DENSE_MIN_ROOTS 8u
+#define SA_DENSE_MIN_COLS 128u
 template <bool VISUAL, bool WORDS, int G>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -464,7 +470,8 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ uint32_t s_clist[SA_SMALL_N];   // labelled columns of the running searches, one segment per component
   __shared__ uint32_t s_rlist[SA_SMALL_N];   // search roots in ascending order, one segment per component
   __shared__ uint32_t s_queue[SA_SMALL_N];   // components waiting for a group
-  __shared__ uint32_t s_ctr[4];              // queue length | next queue entry | top of s_clist | top of s_rlist
+  __shared__ uint32_t s_ctr[8];              // queue length | next queue entry | top of s_clist | top of s_rlist | dense queue length
+  __shared__ unsigned long long s_part[2 * (SA_DENSE_NT / 64)];  // the dense solver's per-wave minima (sa_wg_min_u64)
   // The edge lists the positional tiles left behind live in HBM, one strided row per candidate: every access from here on would be
   // a dependent, uncoalesced round trip (the solve is a chain of them).  They are packed ONCE into an LDS pool — an
   // exclusive scan of the row counts gives the offsets — and the row duals, the connected components of the usable graph
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   s_parent[q + SA_SMALL_N] = q + SA_SMALL_N;
   s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0;
   s_cwin[q] = SA_NONE; s_rcount[q] = 0; s_ccount[q] = 0; s_lab[q] = SA_NONE;
-  if (q < 4) s_ctr[q] = 0;
+  if (q < 8) s_ctr[q] = 0;
   // exclusive scan of mycnt over the 1024 threads: wave scan, then the 16 wave totals
   uint32_t incl = mycnt;
   {
@@ -660,7 +667,16 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
   sa_lds_barrier();
   TAIL_STAMP(3);
-  if (lab == q && s_head[q] != SA_NONE) s_queue[atomicAdd(&s_ctr[0], 1u)] = q;
+  // A component with search roots goes onto one of two queues: the wavefronts' (bottom of s_queue) or — many roots on many columns,
+  // or edge lists that did not fit the LDS pool: every relax step would walk HBM — the dense solver's (top of s_queue; the mark
+  // in s_ccount tells its rows that their results come later).  sa_dense.h has the why.
+  if (lab == q && s_head[q] != SA_NONE) {
+    const bool dense = s_rcount[q] >= SA_DENSE_MIN_ROOTS && (s_ccount[q] >= SA_DENSE_MIN_COLS || !pool);
+    if (dense) {
+      s_queue[SA_SMALL_N - 1u - atomicAdd(&s_ctr[4], 1u)] = q;
+      s_ccount[q] |= 0x80000000u;
+    } else s_queue[atomicAdd(&s_ctr[0], 1u)] = q;
+  }
   sa_lds_barrier();
   TAIL_STAMP(4);
   // groups of G lanes take components off the queue
@@ -725,7 +741,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   TAIL_STAMP(5);
   sa_lds_barrier();  // rmatch is in LDS
   TAIL_STAMP(6);
-  if (q < N) {
+  const uint32_t nd = s_ctr[4];  // components waiting for the dense solver (tracking frames: none)
+  const bool mine_later = nd && usable && (s_ccount[lab] & 0x80000000u);
+  if (q < N && !mine_later) {
     uint64_t id = 0;
     uint8_t vt = SA_VOTE_NONE;
     int32_t win = -1;
@@ -747,6 +765,69 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     S.out_vote[q] = vt;
     S.win_col[q] = win;
   }
+  if (nd) {
+    // The dense solver runs on SA_DENSE_NT threads (one wave per SIMD: a search step is a chain of dependent instructions, more
+    // waves per SIMD only stretch it): the other waves are done — a barrier waits for the surviving waves only.
+    if (q >= SA_DENSE_NT) return;
+    uint32_t rtop = s_ctr[3];
+    for (uint32_t k = 0; k < nd; ++k) {
+      const uint32_t root = s_queue[SA_SMALL_N - 1u - k];
+      const uint32_t R = s_rcount[root];
+      uint32_t* roots = s_rlist + rtop;
+      rtop += R;
+      // the search roots, ascending (wave 0: ballot compaction of the scene's rows), and the component's gains into the dense matrix
+      if (q < WAVE) {
+        uint32_t cnt = 0;
+        for (uint32_t r0 = 0; r0 < N; r0 += WAVE) {
+          const uint32_t row = r0 + q;
+          const bool f = row < N && s_lab[row] == root && s_rmatch[row] < 0;
+          const unsigned long long m = __ballot(f);
+          if (f) roots[cnt + (uint32_t)__popcll(m & ((1ull << q) - 1ull))] = row;
+          cnt += (uint32_t)__popcll(m);
+        }
+      }
+      for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
+        if (s_lab[row] != root) continue;
+        int64_t SA_G* drow = S.dense + (size_t)row * T;
+        const uint32_t cnt = s_ecnt[row];
+        if (pool) {
+          const uint32_t off = s_eoff[row];
+          for (uint32_t e = 0; e < cnt; ++e) drow[s_ecol[off + e]] = s_egain[off + e];
+        } else {
+          const SaEdge SA_G* ep = S.e_edge + row;  // slot-major lists, excluded columns still inside
+          for (uint32_t e = 0; e < cnt; ++e) {
+            const SaEdge ed = sa_ldg(ep + (size_t)e * N);
+            if (!(VISUAL && excluded(ed.col))) drow[ed.col] = ed.gain;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        sa_dense_ws w;
+        w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
+        w.u = s_u; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.pred = s_pred; w.part = s_part;
+        sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT>(w, roots, R);
+      }
+      // results of the component's rows (none of them holds a visual verdict), and the matrix left clean for the next frame
+      for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
+        if (s_lab[row] != root) continue;
+        const int32_t c = s_rmatch[row];
+        S.out_track_id[row] = c >= 0 ? S.t_ids[c] : 0ull;
+        S.out_vote[row] = c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+        S.win_col[row] = c;
+        int64_t SA_G* drow = S.dense + (size_t)row * T;
+        const uint32_t cnt = s_ecnt[row];
+        if (pool) {
+          const uint32_t off = s_eoff[row];
+          for (uint32_t e = 0; e < cnt; ++e) drow[s_ecol[off + e]] = 0;
+        } else {
+          const SaEdge SA_G* ep = S.e_edge + row;
+          for (uint32_t e = 0; e < cnt; ++e) drow[sa_ldg(ep + (size_t)e * N).col] = 0;
+        }
+      }
+      __syncthreads();
+    }
+  }
   TAIL_STAMP(7);
 }
 
@@ -764,7 +845,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (q == 0) { S.stats[1] = 0u; S.stats[2] = 0u; }  // tops of the big-component row / root lists of k_assign_solve
+  if (q == 0) { S.stats[1] = 0u; S.stats[3] = 0u; S.stats[4] = 0u; }  // the dense solver's: top of its row lists | queue length | next queue entry
   if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
@@ -804,88 +885,6 @@ __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q,
   S.out_vote[q] = vt;
   S.win_col[q] = win;
 }
-// A component too large for a lane's private block: the whole wavefront solves it, state in HBM (every access through L2,
-// sa_mem_agent), the same greedy start + cooperative shortest augmenting paths as the one-workgroup tail:
-//   rows of the component in ascending order by ballot compaction of the scene's row labels; every row bids for the column of its
-//   heaviest usable edge (global atomic minimum on cwin, reset by the preparation blocks); rows that lost are the search roots;
-//   sa_assign_component_coop<64, sa_mem_agent>; results.  Slower per step than LDS (an L2 round trip per dependent access) but a
-//   crowd of thousands costs milliseconds, where one lane's chain of those round trips cost seconds.
-template <bool VISUAL>
-__device__ __forceinline__ void solve_big_component(const SceneDev& S, uint32_t root, uint32_t lane) {
-  using M = sa_mem_agent<64>;
-  const uint32_t N = S.N, T = S.T;
-  const uint32_t R = (uint32_t)S.rnext[root];
-  uint32_t seg[2];
-  if (lane == 0) { seg[0] = atomicAdd((uint32_t*)(S.stats + 1), R); seg[1] = atomicAdd((uint32_t*)(S.stats + 2), R); }
-  const uint32_t rbase = sa_coop_bcast<64>(seg), qbase = sa_coop_bcast<64>(seg + 1);
-  uint32_t* rows = (uint32_t*)S.big_rows + rbase;
-  uint32_t* roots = (uint32_t*)S.big_roots + qbase;
-  uint32_t cnt = 0;
-  for (uint32_t r0 = 0; r0 < N; r0 += 64) {
-    const uint32_t row = r0 + lane;
-    bool f[1];
-    f[0] = row < N && S.lab[row] == root;
-    uint32_t tot;
-    const uint32_t rk = sa_coop_rank<64>(f, lane, &tot);
-    if (f[0]) M::st(rows + cnt + rk, row);
-    cnt += tot;
-  }
-  M::sync();
-  const uint8_t* excl = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
-  // greedy start: the bids
-  for (uint32_t k = lane; k < cnt; k += 64) {
-    const uint32_t row = M::ld(rows + k);
-    const uint32_t ne = S.e_use[row];
-    const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-    int64_t maxg = 0;
-    uint32_t bcol = SA_NONE;
-    for (uint32_t e = 0; e < ne; ++e) {
-      const SaEdge ed = sa_ldg(ep + e);
-      if (excl && excl[ed.col]) continue;
-      if (ed.gain > maxg || (ed.gain == maxg && ed.col < bcol)) { maxg = ed.gain; bcol = ed.col; }
-    }
-    M::st((uint32_t*)S.big_bcol + row, bcol);
-    // the row dual over the USABLE edges (the positional tiles folded the maximum over all of them, excluded columns included: with
-    // that value the edge the row bids for would not be tight, and the start not a feasible primal-dual pair)
-    M::st((int64_t*)S.u_use + row, -maxg);
-    if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
-  }
-  M::sync();
-  uint32_t nroots = 0;
-  for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
-    const uint32_t k = k0 + lane;
-    bool pend[1];
-    pend[0] = false;
-    uint32_t row = 0;
-    if (k < cnt) {
-      row = M::ld(rows + k);
-      const uint32_t bc = M::ld((uint32_t*)S.big_bcol + row);
-      if (bc != SA_NONE) {
-        if (M::ld((uint32_t*)(S.cwin + bc)) == row) { M::st((int32_t*)S.rmatch + row, (int32_t)bc); M::st((int32_t*)S.cmatch + bc, (int32_t)row); }
-        else pend[0] = true;
-      }
-    }
-    uint32_t tot;
-    const uint32_t rk = sa_coop_rank<64>(pend, lane, &tot);
-    if (pend[0]) M::st(roots + nroots + rk, row);
-    nroots += tot;
-  }
-  M::sync();
-  sa_coop_ws w;
-  w.e_cnt = (const uint32_t*)S.e_use;
-  w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4; w.egs = 2; w.rcs = 4; w.rgs = 2;
-  w.estride = S.estride; w.e_off = nullptr;
-  w.excluded = excl;
-  w.u = (int64_t*)S.u_use; w.v = (int64_t*)S.v; w.rmatch = (int32_t*)S.rmatch; w.cmatch = (int32_t*)S.cmatch;
-  w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred; w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan;
-  w.clist = (uint32_t*)S.big_clist + (size_t)blockIdx.x * T;  // one list of T entries per wavefront of the launch
-  sa_assign_component_coop<64, M>(w, roots, nroots);
-  for (uint32_t k = lane; k < cnt; k += 64) {
-    const uint32_t row = M::ld(rows + k);
-    finalize_row_with<VISUAL>(S, row, M::ld((int32_t*)S.rmatch + row));
-  }
-}
-
 template <bool VISUAL>
 __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -964,13 +963,122 @@ __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict_
       } else big = true;
     }
   }
-  // components that did not fit a lane's private block: one after the other, all 64 lanes on each
-  unsigned long long todo = __ballot(big);
-  while (todo) {
-    const uint32_t L2 = (uint32_t)__builtin_ctzll(todo);
-    todo &= todo - 1ull;
-    const uint32_t root = __shfl(q, (int)L2);
-    solve_big_component<VISUAL>(S, root, threadIdx.x);
+  // components that did not fit a lane's private block go onto the dense solver's queue (k_assign_dense, the next launch)
+  if (big) S.dq[atomicAdd((uint32_t*)(S.stats + 3), 1u)] = q;
+}
+
+// General tail, kernel 3 of 3: the components k_assign_solve queued (more than 8 rows, 12 columns or 24 usable edges), one workgroup
+// per component at a time, by the dense solver of sa_dense.h.  NT threads, CPT columns per thread (T <= NT * CPT).  Per component:
+//   rows ascending (ballot compaction of the scene's row labels) -> greedy start: every row bids for the column of its heaviest
+//   usable edge (global atomic minimum on cwin, SA_NONE between frames), its gains go into the dense matrix, u = -(heaviest gain)
+//   -> rows that lost their bid are the search roots (ascending) -> sa_assign_component_dense -> results, matrix and bids wiped.
+// Per-row duals / matches and per-column matches / predecessors: LDS when 12 N + 8 T bytes fit (LDS_STATE), else the scene's
+// arrays in HBM — the workgroup's own L1 keeps them coherent between its waves, __syncthreads orders them.
+template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
+__global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict__ scenes) {
+  const SceneDev S = scenes[blockIdx.z];
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t nq = S.stats[3];
+  if (nq == 0) return;
+  extern __shared__ unsigned char s_dyn[];
+  __shared__ unsigned long long s_part[2 * (NT / 64)];
+  __shared__ uint32_t s_take, s_base[2], s_cnt[2];
+  const uint32_t q = threadIdx.x, lane = q & 63u;
+  int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
+  int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
+  int32_t* cmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12) : (int32_t*)S.cmatch;
+  int32_t* pred = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12 + (size_t)T * 4) : (int32_t*)S.pred;
+  if (LDS_STATE) {  // (the HBM arrays were reset by the frame's preparation blocks)
+    for (uint32_t i = q; i < N; i += NT) rmatch[i] = -1;
+    for (uint32_t i = q; i < T; i += NT) cmatch[i] = -1;
+  }
+  const uint8_t SA_G* excl = VISUAL ? S.col_excluded : nullptr;
+  for (;;) {
+    __syncthreads();
+    if (q == 0) s_take = atomicAdd((uint32_t*)(S.stats + 4), 1u);
+    __syncthreads();
+    const uint32_t k = s_take;
+    if (k >= nq) break;
+    const uint32_t root = S.dq[k];
+    const uint32_t R = (uint32_t)S.rnext[root];  // rows of the component (k_assign_label)
+    if (q == 0) s_base[0] = atomicAdd((uint32_t*)(S.stats + 1), R);
+    __syncthreads();
+    uint32_t* rows = (uint32_t*)S.big_rows + s_base[0];   // the component's rows, then (in place of the matched ones) its search roots
+    if (q < 64) {
+      uint32_t cnt = 0;
+      for (uint32_t r0 = 0; r0 < N; r0 += 64) {
+        const uint32_t row = r0 + lane;
+        const bool f = row < N && S.lab[row] == root;
+        const unsigned long long m = __ballot(f);
+        if (f) rows[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
+        cnt += (uint32_t)__popcll(m);
+      }
+    }
+    __syncthreads();
+    // greedy start: bids, duals, gains into the dense matrix
+    for (uint32_t i = q; i < R; i += NT) {
+      const uint32_t row = rows[i];
+      const uint32_t ne = S.e_use[row];
+      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+      int64_t SA_G* drow = S.dense + (size_t)row * T;
+      int64_t maxg = 0;
+      uint32_t bcol = SA_NONE;
+      for (uint32_t e = 0; e < ne; ++e) {
+        const SaEdge ed = sa_ldg(ep + e);
+        if (excl && excl[ed.col]) continue;
+        drow[ed.col] = ed.gain;
+        if (ed.gain > maxg || (ed.gain == maxg && ed.col < bcol)) { maxg = ed.gain; bcol = ed.col; }
+      }
+      u[row] = -maxg;
+      S.big_bcol[row] = bcol;
+      if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
+    }
+    __syncthreads();
+    if (q < 64) {  // matched rows keep their bid; the others become the search roots, ascending, compacted in place
+      uint32_t nroots = 0;
+      for (uint32_t i0 = 0; i0 < R; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool pend = false;
+        uint32_t row = 0;
+        if (i < R) {
+          row = rows[i];
+          const uint32_t bc = S.big_bcol[row];
+          if (bc != SA_NONE) {
+            if (__hip_atomic_load((uint32_t*)(S.cwin + bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == row) { rmatch[row] = (int32_t)bc; cmatch[bc] = (int32_t)row; }
+            else pend = true;
+          }
+        }
+        const unsigned long long m = __ballot(pend);
+        // (position nroots + rank <= i: a root never overwrites an entry that has not been read yet; all lanes of this step have read theirs)
+        if (pend) rows[nroots + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
+        nroots += (uint32_t)__popcll(m);
+      }
+      if (lane == 0) s_cnt[0] = nroots;
+    }
+    __syncthreads();
+    {
+      sa_dense_ws w;
+      w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
+      w.u = u; w.rmatch = rmatch; w.cmatch = cmatch; w.pred = pred; w.part = s_part;
+      sa_assign_component_dense<NT, CPT>(w, rows, s_cnt[0]);
+    }
+    // results; matrix, bids and (LDS) matches wiped for the next component / frame.  The rows list was overwritten by the roots:
+    // walk the scene's labels again.
+    for (uint32_t row = q; row < N; row += NT) {
+      if (S.lab[row] != root) continue;
+      const int32_t c = rmatch[row];
+      finalize_row_with<VISUAL>(S, row, c);
+      const uint32_t ne = S.e_use[row];
+      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+      int64_t SA_G* drow = S.dense + (size_t)row * T;
+      for (uint32_t e = 0; e < ne; ++e) drow[sa_ldg(ep + e).col] = 0;
+      const uint32_t bc = S.big_bcol[row];
+      if (bc != SA_NONE) S.cwin[bc] = SA_NONE;
+      if (LDS_STATE) {
+        if (c >= 0) cmatch[c] = -1;
+        rmatch[row] = -1;
+      }
+    }
   }
 }
 
@@ -1055,6 +1163,25 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
   else SA_LAUNCH(k_bestfit_resolve<false>, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
+// one instantiation of the dense kernel: the dynamic LDS limit is raised once per size class (above 64 KB it has to be asked for)
+template <bool VIS, int NT, int CPT, bool LDS_STATE>
+static void launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
+  if (LDS_STATE) {
+    static size_t allowed = 0;
+    if (lds > allowed) {
+      hipFuncSetAttribute((const void*)k_assign_dense<VIS, NT, CPT, LDS_STATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      allowed = lds;
+    }
+  }
+  SA_LAUNCH((k_assign_dense<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes);
+}
+template <int NT, int CPT>
+static void launch_dense(bool vis, bool in_lds, dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
+  if (vis && in_lds) launch_dense_one<true, NT, CPT, true>(grid, lds, st, scenes);
+  else if (vis) launch_dense_one<true, NT, CPT, false>(grid, lds, st, scenes);
+  else if (in_lds) launch_dense_one<false, NT, CPT, true>(grid, lds, st, scenes);
+  else launch_dense_one<false, NT, CPT, false>(grid, lds, st, scenes);
+}
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                             hipStream_t st, int stage) {
   if (!maxN) return hipSuccess;
@@ -1064,6 +1191,23 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_solve<true>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
       else SA_LAUNCH(k_assign_solve<false>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
       break;
+    case 4: {
+      // the dense solver for the components k_assign_solve queued: a few workgroups per scene take them off the queue (a frame
+      // without any: every workgroup reads one word and leaves).  Columns per thread by the widest scene; the per-row / per-column
+      // state in LDS when it fits, else in the scene's HBM arrays.
+      if (!maxT) return hipSuccess;
+      const bool vis = p.visual_kind != SA_VIS_NONE;
+      const size_t lds = (size_t)maxN * 12 + (size_t)maxT * 8;
+      const bool in_lds = lds <= 144u * 1024u;
+      const dim3 grid(ns >= 16 ? 4u : 16u, 1, ns);
+      if (maxT <= 256u * 4u) launch_dense<256, 4>(vis, in_lds, grid, lds, st, scenes);
+      else if (maxT <= 256u * 8u) launch_dense<256, 8>(vis, in_lds, grid, lds, st, scenes);
+      else if (maxT <= 256u * 16u) launch_dense<256, 16>(vis, in_lds, grid, lds, st, scenes);
+      else if (maxT <= 256u * 32u) launch_dense<256, 32>(vis, in_lds, grid, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) launch_dense<1024, 32>(vis, in_lds, grid, lds, st, scenes);
+      else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
+      break;
+    }
     default:
       sa_tail_trace_hook(st, ns);
       {

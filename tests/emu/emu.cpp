@@ -9,6 +9,7 @@
 
 #include "../../include/similari_assoc.h"
 #include "../../similari_amd/csrc/sa_device.h"
+#include "../../similari_amd/csrc/sa_dense.h"
 
 namespace {
 void prep(const sa_box& b, sa_geo* g, double* verts) {
@@ -34,6 +35,14 @@ template <int G>
 void coop_solve_all(const sa_coop_ws& w, const std::vector<std::vector<uint32_t>>& comps) {
   for (const auto& roots : comps)
     if (!roots.empty()) sa_assign_component_coop<G>(w, roots.data(), (uint32_t)roots.size());
+}
+template <int NT, int CPT>
+void dense_solve_all(const sa_dense_ws& w, const sa_coop_ws& cw, const std::vector<std::vector<uint32_t>>& comps, uint32_t min_roots) {
+  for (const auto& roots : comps) {
+    if (roots.empty()) continue;
+    if (roots.size() >= min_roots) sa_assign_component_dense<NT, CPT>(w, roots.data(), (uint32_t)roots.size());
+    else sa_assign_component_coop<64>(cw, roots.data(), (uint32_t)roots.size());
+  }
 }
 }  // namespace
 
@@ -253,6 +262,80 @@ int emu_assign_coop(uint32_t N, uint32_t T, const float* pos, int64_t threshold_
   }
   for (uint32_t t = 0; t < T; ++t)
     if (cmatch[t] < 0 && v[t] != 0) return -6;
+  if (total_gain) *total_gain = tot;
+  return 0;
+}
+
+
+// The workgroup-cooperative DENSE solver (sa_dense.h), sequenced the way the assignment tails do for a component they hand to it:
+// usable edges, union-find, duals u = -(heaviest usable gain), greedy start, and then — for EVERY component with search roots
+// (min_roots = 1) or only those with at least min_roots of them (the others go to the wavefront-cooperative solver, as on the
+// device) — the component's gains scattered into a dense N x T matrix (excluded columns never written), its roots ascending,
+// sa_assign_component_dense<NT, CPT>, and the matrix wiped again.  nt_cpt: 1 = 256 threads x 4 columns, 2 = 16 x 8, 3 = 256 x 8.
+int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip, const uint8_t* col_skip,
+                     int nt_cpt, uint32_t min_roots, int32_t* rmatch_out, int64_t* total_gain) {
+  std::vector<uint32_t> parent(N + T), e_cnt(N, 0), e_off(N, 0);
+  std::vector<uint32_t> e_col;
+  std::vector<int64_t> e_gain;
+  std::vector<int64_t> u(N, 0), v(T, 0), dist(T, 0);
+  std::vector<int32_t> rmatch(N, -1), cmatch(T, -1), pred(T, 0), bcol(N, -1);
+  std::vector<uint32_t> cstamp(T, 0), cscan(T, 0), clist(T ? T : 1, 0), cwin(T, SA_NONE);
+  std::vector<int64_t> dense((size_t)N * (T ? T : 1), 0);
+  for (uint32_t i = 0; i < N + T; ++i) parent[i] = i;
+  for (uint32_t q = 0; q < N; ++q) {
+    e_off[q] = (uint32_t)e_col.size();
+    if (row_skip && row_skip[q]) continue;
+    int64_t maxg = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      float wv = pos[(size_t)q * T + t];
+      if (!(wv == wv)) continue;
+      int64_t gain = sa_quantise(wv) - threshold_q;
+      if (gain <= 0 || (col_skip && col_skip[t])) continue;
+      e_col.push_back(t);
+      e_gain.push_back(gain);
+      dense[(size_t)q * T + t] = gain;
+      if (gain > maxg || (gain == maxg && (bcol[q] < 0 || (int32_t)t < bcol[q]))) { maxg = gain; bcol[q] = (int32_t)t; }
+      sa_uf_union(parent.data(), q, N + t);
+    }
+    e_cnt[q] = (uint32_t)e_col.size() - e_off[q];
+    u[q] = -maxg;
+  }
+  for (uint32_t q = 0; q < N; ++q)
+    if (bcol[q] >= 0 && q < cwin[bcol[q]]) cwin[bcol[q]] = q;
+  std::vector<std::vector<uint32_t>> comps(N);
+  for (uint32_t q = 0; q < N; ++q) {
+    if (bcol[q] < 0) continue;
+    if (cwin[bcol[q]] == q) { rmatch[q] = bcol[q]; cmatch[bcol[q]] = (int32_t)q; }
+    else comps[sa_uf_find(parent.data(), q)].push_back(q);
+  }
+  sa_dense_ws w;
+  w.gain = dense.data(); w.ld = T; w.T = T;
+  w.u = u.data(); w.rmatch = rmatch.data(); w.cmatch = cmatch.data(); w.pred = pred.data(); w.part = nullptr;
+  sa_coop_ws cw;
+  cw.e_cnt = e_cnt.data(); cw.e_col = e_col.data(); cw.e_gain = e_gain.data(); cw.ecs = 1; cw.egs = 1; cw.rcs = 1; cw.rgs = 1; cw.estride = 0;
+  cw.e_off = e_off.data(); cw.excluded = nullptr;
+  cw.u = u.data(); cw.v = v.data(); cw.rmatch = rmatch.data(); cw.cmatch = cmatch.data(); cw.dist = dist.data(); cw.pred = pred.data();
+  cw.cstamp = cstamp.data(); cw.cscan = cscan.data(); cw.clist = clist.data();
+  switch (nt_cpt) {
+    case 1: if (T > 256 * 4) return -21; dense_solve_all<256, 4>(w, cw, comps, min_roots); break;
+    case 2: if (T > 16 * 8) return -21; dense_solve_all<16, 8>(w, cw, comps, min_roots); break;
+    case 3: if (T > 256 * 8) return -21; dense_solve_all<256, 8>(w, cw, comps, min_roots); break;
+    default: return -20;
+  }
+  int64_t tot = 0;
+  for (uint32_t q = 0; q < N; ++q) {
+    rmatch_out[q] = rmatch[q];
+    if (rmatch[q] >= 0) {
+      if (row_skip && row_skip[q]) return -7;
+      if (col_skip && col_skip[rmatch[q]]) return -8;
+      const int64_t g = dense[(size_t)q * T + rmatch[q]];
+      if (g <= 0) return -9;
+      tot += g;
+      if (cmatch[rmatch[q]] != (int32_t)q) return -1;
+    }
+  }
+  // primal feasibility is checked above; the duals of the dense solver's columns live in its threads' registers, so optimality is
+  // checked by the caller against the dense kuhn_munkres (total and, on unique optima, the matching itself)
   if (total_gain) *total_gain = tot;
   return 0;
 }

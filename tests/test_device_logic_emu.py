@@ -17,7 +17,7 @@ EMU_DIR = ROOT / "tests" / "emu"
 
 def emu():
     so = EMU_DIR / "libemu.so"
-    srcs = [EMU_DIR / "emu.cpp", ROOT / "similari_amd" / "csrc" / "sa_device.h"]
+    srcs = [EMU_DIR / "emu.cpp", ROOT / "similari_amd" / "csrc" / "sa_device.h", ROOT / "similari_amd" / "csrc" / "sa_dense.h"]
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(
             ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", str(so), str(EMU_DIR / "emu.cpp")],
@@ -41,6 +41,9 @@ def emu():
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.emu_clip_is_empty.restype = C.c_int
     L.emu_clip_is_empty.argtypes = [B, B]
+    L.emu_assign_dense.restype = C.c_int
+    L.emu_assign_dense.argtypes = [C.c_uint32, C.c_uint32, fp, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_uint32,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     return L
 
 
@@ -352,6 +355,99 @@ def test_cooperative_assignment_chains_exclusions_and_ties(G, hbm_lists):
         pm = (rng.uniform(88.0, 100.0, (N, T)) / rng.uniform(0.05, 1.0, (N, 1))).astype(np.float32)
         pm[rng.uniform(size=(N, T)) > 0.3] = np.nan
         rm4, gain4 = run_emu_assign_coop(pm, 1000000, G, hbm_lists=hbm_lists)
+        total4, ref4, _ = dense_reference(pm, 1000000)
+        assert gain4 + N * 1000000 == total4
+        np.testing.assert_array_equal(rm4, ref4)
+
+
+# ---- the workgroup-cooperative DENSE solver (sa_dense.h: one thread per column strip, dense row reads, packed-key minima) -------
+def run_emu_assign_dense(pos, thr_q, shape=1, min_roots=1, row_skip=None, col_skip=None):
+    N, T = pos.shape
+    pos = np.ascontiguousarray(pos, np.float32)
+    rm = np.zeros(max(N, 1), np.int32)
+    tot = C.c_int64()
+    rs = None if row_skip is None else row_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    cs = None if col_skip is None else col_skip.ctypes.data_as(C.POINTER(C.c_uint8))
+    rc = E.emu_assign_dense(N, T, O.fptr(pos), thr_q, rs, cs, shape, min_roots, rm.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tot))
+    assert rc == 0, f"dense solver: inconsistent matching ({rc})"
+    return rm[:N], tot.value
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("density", [0.02, 0.1, 0.5, 1.0])
+def test_dense_assignment_reaches_dense_optimum(density, shape):
+    rng = np.random.default_rng(int(density * 100) + 1000 * shape)
+    thr_q = 300000
+    for trial in range(25):
+        N = int(rng.integers(1, 90))
+        T = int(rng.integers(1, 90))
+        pos = rng.uniform(0.05, 1.0, (N, T)).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > density] = np.nan
+        rm, gain = run_emu_assign_dense(pos, thr_q, shape)
+        total, ref, w = dense_reference(pos, thr_q)
+        assert gain + N * thr_q == total
+        np.testing.assert_array_equal(rm, ref)  # unique optimum (random f32 weights)
+        rm_coop, gain_coop = run_emu_assign_coop(pos, thr_q, 64)
+        np.testing.assert_array_equal(rm, rm_coop)
+        # mixed, as on the device: small components to the wavefront solver, the others to the dense one
+        rm_mix, gain_mix = run_emu_assign_dense(pos, thr_q, shape, min_roots=3)
+        np.testing.assert_array_equal(rm_mix, ref)
+
+
+@pytest.mark.parametrize("shape,n,t", [(1, 300, 320), (3, 640, 700), (1, 1024, 1024)])
+def test_dense_assignment_one_giant_component(shape, n, t):
+    """All boxes on one pile under a low threshold: one component of hundreds of rows, half of all cells usable, most greedy bids
+    colliding (the `giant` / `bigpile` bench frames).  Same matching as the dense kuhn_munkres and as the wavefront solver."""
+    rng = np.random.default_rng(7 + n)
+    pos = rng.uniform(0.06, 0.9, (n, t)).astype(np.float32)
+    pos[rng.uniform(size=(n, t)) > 0.5] = np.nan
+    rm, gain = run_emu_assign_dense(pos, 50000, shape)
+    total, ref, _ = dense_reference(pos, 50000)
+    assert gain + n * 50000 == total
+    np.testing.assert_array_equal(rm, ref)
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+def test_dense_assignment_chains_exclusions_and_ties(shape):
+    n = 60
+    pos = np.full((n, n), np.nan, np.float32)
+    rng = np.random.default_rng(9)
+    for i in range(n):
+        pos[i, i] = 0.5 + 0.001 * i
+        if i + 1 < n:
+            pos[i + 1, i] = 0.9 - 0.002 * i
+    rm, gain = run_emu_assign_dense(pos, 300000, shape)
+    total, ref, _ = dense_reference(pos, 300000)
+    assert gain + n * 300000 == total
+    np.testing.assert_array_equal(rm, ref)
+    row_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    col_skip = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    rm2, gain2 = run_emu_assign_dense(pos, 300000, shape, row_skip=row_skip, col_skip=col_skip)
+    p2 = pos.copy()
+    p2[row_skip.astype(bool), :] = np.nan
+    p2[:, col_skip.astype(bool)] = np.nan
+    total2, ref2, _ = dense_reference(p2, 300000)
+    assert gain2 + n * 300000 == total2
+    np.testing.assert_array_equal(rm2, ref2)
+    # integer-valued weights -> many ties: the total still agrees, every column is used once (indices are unpinned on ties), and
+    # the tie-breaks are the wavefront solver's (same (distance, column) order): identical matchings
+    for _ in range(30):
+        N, T = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        pt = (rng.integers(1, 6, (N, T)) / 5.0).astype(np.float32)
+        pt[rng.uniform(size=(N, T)) > 0.4] = np.nan
+        rm3, gain3 = run_emu_assign_dense(pt, 300000, shape)
+        total3, _, _ = dense_reference(pt, 300000)
+        assert gain3 + N * 300000 == total3
+        used = [c for c in rm3 if c >= 0]
+        assert len(used) == len(set(used))
+        rm3c, _ = run_emu_assign_coop(pt, 300000, 64)
+        np.testing.assert_array_equal(rm3, rm3c)
+    # Mahalanobis-scale weights: i64 end to end, keys beyond 32 bits
+    for _ in range(10):
+        N, T = int(rng.integers(2, 30)), int(rng.integers(2, 30))
+        pm = (rng.uniform(88.0, 100.0, (N, T)) / rng.uniform(0.05, 1.0, (N, 1))).astype(np.float32)
+        pm[rng.uniform(size=(N, T)) > 0.3] = np.nan
+        rm4, gain4 = run_emu_assign_dense(pm, 1000000, shape)
         total4, ref4, _ = dense_reference(pm, 1000000)
         assert gain4 + N * 1000000 == total4
         np.testing.assert_array_equal(rm4, ref4)
