@@ -21,6 +21,7 @@
 // in the host emulation it runs NT times, per-thread values live in arrays of SA_WG_SLOTS(NT) elements.
 #pragma once
 #include "sa_device.h"
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define SA_WG_FN __device__ __forceinline__
@@ -43,6 +44,17 @@
 SA_HD unsigned long long sa_dense_key(int64_t d, uint32_t j) {
   const int64_t c = d > SA_DENSE_DIST_SAT ? SA_DENSE_DIST_SAT : d;
   return ((unsigned long long)c << 16) | (unsigned long long)(j & 0xffffu);
+}
+
+// The 32-bit variant (K32): when every gain of the component is below 2^21 - 1 (IoU weights: at most 1e6) and the scene has at most
+// 2048 tracks, every quantity of the search — duals, reduced costs, distances — stays below 2^24 and a key is (distance << 11 |
+// column) in ONE 32-bit word: half the vector instructions in the relax step and a one-pass minimum.
+#define SA_DENSE_K32_MAXGAIN ((1 << 21) - 2)
+#define SA_DENSE_K32_MAXT 2048u
+#define SA_DENSE_KEY32_NONE 0xffffffffu
+SA_HD uint32_t sa_dense_key32(int32_t d, uint32_t j) {
+  const uint32_t c = d > (1 << 21) - 1 ? (1u << 21) - 1u : (uint32_t)d;
+  return (c << 11) | (j & 2047u);
 }
 
 #if defined(__HIPCC__)
@@ -69,8 +81,8 @@ __device__ __forceinline__ unsigned long long sa_wave_min_u64(unsigned long long
   const uint32_t ml = sa_wave_min_u32(hi == mh ? lo : 0xffffffffu);
   return ((unsigned long long)mh << 32) | ml;
 }
-// Workgroup minimum, every thread receives it.  part: [2][NT / 64] slots in LDS, alternated by `parity` so that ONE barrier per
-// call is enough (a wave that races ahead into the next call writes the other half).
+// Workgroup minimum, every thread receives it.  part: [2][NT / 64] 64-bit slots in LDS, alternated by `parity` so that ONE barrier
+// per call is enough (a wave that races ahead into the next call writes the other half).
 template <int NT>
 __device__ __forceinline__ unsigned long long sa_wg_min_u64(const unsigned long long* key, unsigned long long* part, uint32_t parity) {
   constexpr int W = NT / 64;
@@ -87,6 +99,22 @@ __device__ __forceinline__ unsigned long long sa_wg_min_u64(const unsigned long 
   return m;
 }
 template <int NT>
+__device__ __forceinline__ uint32_t sa_wg_min_u32(const uint32_t* key, unsigned long long* part, uint32_t parity) {
+  constexpr int W = NT / 64;
+  const uint32_t k = sa_wave_min_u32(key[0]);
+  if constexpr (W == 1) return k;
+  uint32_t* p32 = (uint32_t*)(part + parity * W);
+  if ((threadIdx.x & 63u) == 0) p32[threadIdx.x >> 6] = k;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  uint32_t m = p32[0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) {
+    const uint32_t o = p32[w];
+    m = o < m ? o : m;
+  }
+  return m;
+}
+template <int NT>
 __device__ __forceinline__ void sa_wg_sync() { __syncthreads(); }
 #else
 template <int NT>
@@ -96,7 +124,17 @@ inline unsigned long long sa_wg_min_u64(const unsigned long long* key, unsigned 
   return m;
 }
 template <int NT>
+inline uint32_t sa_wg_min_u32(const uint32_t* key, unsigned long long*, uint32_t) {
+  uint32_t m = SA_DENSE_KEY32_NONE;
+  for (int t = 0; t < NT; ++t) m = key[t] < m ? key[t] : m;
+  return m;
+}
+template <int NT>
 inline void sa_wg_sync() {}
+#endif
+
+#if !defined(__HIPCC__)
+static uint64_t sa_dense_emu_steps = 0, sa_dense_emu_searches = 0, sa_dense_emu_comps = 0;  // emulation statistics (tests/emu)
 #endif
 
 struct sa_dense_ws {
@@ -106,87 +144,133 @@ struct sa_dense_ws {
   int64_t* u;              // [N] row duals: -(heaviest usable gain) on entry
   int32_t* rmatch;         // [N] -1, or the column the greedy start gave the row
   int32_t* cmatch;         // [T] -1, or the row the greedy start gave the column
-  int32_t* pred;           // [T] scratch: the tree row that labelled the column
+  int32_t* pred;           // [T] scratch: the tree row through which a SCANNED column was reached (published when the column is scanned)
   unsigned long long* part;  // device: [2][NT / 64] reduction slots in LDS
 };
 
 // Solves one component: `roots` = its rows the greedy start left unmatched (ascending), n_roots of them.  NT threads, thread t owns
-// the columns t, t + NT, ... (CPT of them: T <= NT * CPT).  Every thread must call it; control flow is uniform.
-template <int NT, int CPT>
+// the columns t, t + NT, ... (CPT of them: T <= NT * CPT).  Every thread must call it; control flow is uniform.  K32: the 32-bit
+// variant (the caller has checked SA_DENSE_K32_MAXGAIN and SA_DENSE_K32_MAXT).
+// wave-uniform values the compiler cannot prove uniform (they come out of LDS): into a scalar register, so that the row's address and the
+// comparisons against it are scalar arithmetic
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SA_WG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define SA_WG_UNIFORM(x) (x)
+#endif
+
+template <int NT, int CPT, bool K32>
 SA_WG_FN void sa_assign_component_dense(const sa_dense_ws& w, const uint32_t* roots, uint32_t n_roots) {
-  int64_t v[SA_WG_SLOTS(NT)][CPT];      // column duals of this thread's columns (0 on entry: a component's columns are untouched)
-  int64_t dist[SA_WG_SLOTS(NT)][CPT];
-  uint32_t lab[SA_WG_SLOTS(NT)], scn[SA_WG_SLOTS(NT)];  // bit c: column c of this thread is labelled / scanned in the running search
+  using D = typename std::conditional<K32, int32_t, int64_t>::type;              // duals, distances
+  using KEY = typename std::conditional<K32, uint32_t, unsigned long long>::type;
+  // "not labelled yet" is a distance no relaxation can reach (every real one is below 2^24 / 2^48 by the bounds above); its key
+  // saturates, so it can only win the minimum when nothing real is left, and then bd >= best_term ends the search
+  const D INF = K32 ? (D)(1 << 28) : (D)(1ll << 56);
+  const KEY NONE = K32 ? (KEY)SA_DENSE_KEY32_NONE : (KEY)SA_DENSE_KEY_NONE;
+  D v[SA_WG_SLOTS(NT)][CPT];      // column duals of this thread's columns (0 on entry: a component's columns are untouched)
+  D dist[SA_WG_SLOTS(NT)][CPT];
+  int32_t pred[SA_WG_SLOTS(NT)][CPT];
+  uint32_t scn[SA_WG_SLOTS(NT)];  // bit c: column c of this thread is scanned in the running search
   SA_WG_FOR(NT, t) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int c = 0; c < CPT; ++c) { v[SA_WG_SLOT(t)][c] = 0; dist[SA_WG_SLOT(t)][c] = 0; }
+    for (int c = 0; c < CPT; ++c) { v[SA_WG_SLOT(t)][c] = 0; dist[SA_WG_SLOT(t)][c] = INF; pred[SA_WG_SLOT(t)][c] = -1; }
   }
   uint32_t parity = 0;
+#if !defined(__HIPCC__)
+  sa_dense_emu_comps += 1;
+  sa_dense_emu_searches += n_roots;
+#endif
   for (uint32_t ri = 0; ri < n_roots; ++ri) {
     const uint32_t root = roots[ri];
-    int64_t best_term = -w.u[root];  // reduced cost of the root's own self column
+    D best_term = (D)(-w.u[root]);  // reduced cost of the root's own self column
     int32_t term_row = (int32_t)root;
     int32_t end_col = -1;
-    int64_t delta = best_term;
-    SA_WG_FOR(NT, t) { lab[SA_WG_SLOT(t)] = 0; scn[SA_WG_SLOT(t)] = 0; }
+    D delta = best_term;
+    SA_WG_FOR(NT, t) {
+      scn[SA_WG_SLOT(t)] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int c = 0; c < CPT; ++c) dist[SA_WG_SLOT(t)][c] = INF;
+    }
     uint32_t row = root;
-    int64_t base = 0;
+    D base = 0;
+    D ur = (D)w.u[root];
     // (every pass scans one more column of the component: the cap can only bite on corrupted state — a wrong answer the tests catch
     // instead of a kernel spinning on a GPU box)
     for (uint32_t guard = 0; guard < 65536u; ++guard) {
-      // relax `row` (entered the tree at distance `base`) and form this thread's best key
-      const int64_t ur = w.u[row];
-      unsigned long long key[SA_WG_SLOTS(NT)];
+#if !defined(__HIPCC__)
+      sa_dense_emu_steps += 1;
+#endif
+      // relax `row` (entered the tree at distance `base`, dual ur) and form this thread's best key — straight-line code
+      KEY key[SA_WG_SLOTS(NT)];
       SA_WG_FOR(NT, t) {
-        int64_t g[CPT];
+        D g[CPT];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int c = 0; c < CPT; ++c) {
           const uint32_t j = t + (uint32_t)c * NT;
-          g[c] = j < w.T ? w.gain[(size_t)row * w.ld + j] : 0;
+          const size_t at = (size_t)row * w.ld + (j < w.T ? j : 0u);
+          const D gv = K32 ? (D)((const int32_t*)w.gain)[2 * at] : (D)w.gain[at];   // (little endian: the low word of the i64 cell)
+          g[c] = j < w.T ? gv : (D)0;
         }
-        unsigned long long k = SA_DENSE_KEY_NONE;
-        uint32_t lb = lab[SA_WG_SLOT(t)];
+        KEY k = NONE;
         const uint32_t sc = scn[SA_WG_SLOT(t)];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int c = 0; c < CPT; ++c) {
           const uint32_t j = t + (uint32_t)c * NT;
-          const uint32_t bit = 1u << c;
-          if (g[c] > 0 && !(sc & bit)) {
-            const int64_t d = base + (-g[c] - ur - v[SA_WG_SLOT(t)][c]);
-            if (!(lb & bit) || d < dist[SA_WG_SLOT(t)][c]) {
-              dist[SA_WG_SLOT(t)][c] = d;
-              w.pred[j] = (int32_t)row;
-              lb |= bit;
-            }
-          }
-          if ((lb & bit) && !(sc & bit)) {
-            const unsigned long long kc = sa_dense_key(dist[SA_WG_SLOT(t)][c], j);
-            k = kc < k ? kc : k;
-          }
+          const bool open = !(sc & (1u << c));
+          const D d = base + (-g[c] - ur - v[SA_WG_SLOT(t)][c]);
+          const bool better = g[c] > 0 && open && d < dist[SA_WG_SLOT(t)][c];
+          dist[SA_WG_SLOT(t)][c] = better ? d : dist[SA_WG_SLOT(t)][c];
+          pred[SA_WG_SLOT(t)][c] = better ? (int32_t)row : pred[SA_WG_SLOT(t)][c];
+          KEY kc;
+          if constexpr (K32) kc = sa_dense_key32((int32_t)dist[SA_WG_SLOT(t)][c], j);
+          else kc = sa_dense_key((int64_t)dist[SA_WG_SLOT(t)][c], j);
+          kc = open ? kc : NONE;
+          k = kc < k ? kc : k;
         }
-        lab[SA_WG_SLOT(t)] = lb;
         key[SA_WG_SLOT(t)] = k;
       }
-      const unsigned long long m = sa_wg_min_u64<NT>(key, w.part, parity);
+      D bd;
+      uint32_t bj;
+      if constexpr (K32) {
+        const uint32_t m = sa_wg_min_u32<NT>(key, w.part, parity);
+        bd = (D)(m >> 11);
+        bj = m & 2047u;
+      } else {
+        const unsigned long long m = sa_wg_min_u64<NT>(key, w.part, parity);
+        bd = (D)(m >> 16);
+        bj = (uint32_t)(m & 0xffffu);
+      }
       parity ^= 1u;
-      const int64_t bd = (int64_t)(m >> 16);
-      if (m == SA_DENSE_KEY_NONE || bd >= best_term) { delta = best_term; break; }  // a self column ends the path
-      const uint32_t bj = (uint32_t)(m & 0xffffu);
-      SA_WG_FOR(NT, t) { if (t == bj % NT) scn[SA_WG_SLOT(t)] |= 1u << (bj / NT); }
-      const int32_t i = w.cmatch[bj];
+      if (bd >= best_term) { delta = best_term; break; }  // a self column ends the path (also: nothing labelled is left)
+      // the column's owner marks it scanned and publishes the tree row it was reached through (the augmentation walks these)
+      SA_WG_FOR(NT, t) {
+        if (t == bj % NT) {
+          int32_t pr = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+          for (int c = 0; c < CPT; ++c) pr = (uint32_t)c == bj / NT ? pred[SA_WG_SLOT(t)][c] : pr;
+          scn[SA_WG_SLOT(t)] |= 1u << (bj / NT);
+          w.pred[bj] = pr;
+        }
+      }
+      const int32_t i = SA_WG_UNIFORM(w.cmatch[bj]);
       if (i < 0) { end_col = (int32_t)bj; delta = bd; break; }               // free real column
-      const int64_t tt = bd + (-w.u[i]);
+      ur = (D)w.u[i];
+      const D tt = bd - ur;
       if (tt < best_term) { best_term = tt; term_row = i; }
       row = (uint32_t)i;
       base = bd;
     }
-    sa_wg_sync<NT>();  // every thread has read u[] for this search before the dual update rewrites it
+    sa_wg_sync<NT>();  // every thread has read u[] for this search before the dual update rewrites it; pred[] is published
     // dual update.  A tree row other than the root entered through the scanned column it is matched to, at that column's
     // distance: u[cmatch[j]] += delta - dist[j], v[j] += dist[j] - delta over the scanned columns; the root moves by delta.
     SA_WG_FOR(NT, t) {
@@ -197,12 +281,12 @@ SA_WG_FN void sa_assign_component_dense(const sa_dense_ws& w, const uint32_t* ro
       for (int c = 0; c < CPT; ++c) {
         if (!(sc & (1u << c))) continue;
         const uint32_t j = t + (uint32_t)c * NT;
-        const int64_t dj = dist[SA_WG_SLOT(t)][c];
+        const D dj = dist[SA_WG_SLOT(t)][c];
         v[SA_WG_SLOT(t)][c] += dj - delta;
         const int32_t i = w.cmatch[j];
-        if (i >= 0) w.u[i] += delta - dj;
+        if (i >= 0) w.u[i] += (int64_t)(delta - dj);
       }
-      if (t == 0) w.u[root] += delta;
+      if (t == 0) w.u[root] += (int64_t)delta;
     }
     sa_wg_sync<NT>();
     // augment (a short dependent chain: thread 0 walks it; nobody else reads the matches before the barrier below)

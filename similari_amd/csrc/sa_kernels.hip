@@ -786,27 +786,39 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
           cnt += (uint32_t)__popcll(m);
         }
       }
+      if (q == 0) s_ctr[5] = 0;  // the component's heaviest gain (32-bit variant of the solver when it is small enough)
+      sa_lds_barrier();
+      uint32_t mg = 0;
       for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
         if (s_lab[row] != root) continue;
+        const int64_t heaviest = -s_u[row];
+        const uint32_t h32 = heaviest > 0x7fffffffll ? 0x7fffffffu : (uint32_t)heaviest;
+        mg = h32 > mg ? h32 : mg;
         int64_t SA_G* drow = S.dense + (size_t)row * T;
         const uint32_t cnt = s_ecnt[row];
         if (pool) {
           const uint32_t off = s_eoff[row];
           for (uint32_t e = 0; e < cnt; ++e) drow[s_ecol[off + e]] = s_egain[off + e];
         } else {
-          const SaEdge SA_G* ep = S.e_edge + row;  // slot-major lists, excluded columns still inside
-          for (uint32_t e = 0; e < cnt; ++e) {
-            const SaEdge ed = sa_ldg(ep + (size_t)e * N);
-            if (!(VISUAL && excluded(ed.col))) drow[ed.col] = ed.gain;
+          const SaEdge SA_G* ep = S.e_edge + row;  // slot-major lists, excluded columns still inside; four records per round trip
+          for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
+            SaEdge ed[4];
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < cnt ? sa_ldg(ep + (size_t)(e0 + k2) * N) : SaEdge{0, 0u, 0u};
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+              if (e0 + k2 < cnt && !(VISUAL && excluded(ed[k2].col))) drow[ed[k2].col] = ed[k2].gain;
           }
         }
       }
+      if (mg) atomicMax(&s_ctr[5], mg);
       __syncthreads();
       {
         sa_dense_ws w;
         w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
         w.u = s_u; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.pred = s_pred; w.part = s_part;
-        sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT>(w, roots, R);
+        if (s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN) sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT, true>(w, roots, R);
+        else sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT, false>(w, roots, R);
       }
       // results of the component's rows (none of them holds a visual verdict), and the matrix left clean for the next frame
       for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
@@ -822,7 +834,14 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
           for (uint32_t e = 0; e < cnt; ++e) drow[s_ecol[off + e]] = 0;
         } else {
           const SaEdge SA_G* ep = S.e_edge + row;
-          for (uint32_t e = 0; e < cnt; ++e) drow[sa_ldg(ep + (size_t)e * N).col] = 0;
+          for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
+            uint32_t cj[4];
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) cj[k2] = e0 + k2 < cnt ? sa_ldg(ep + (size_t)(e0 + k2) * N).col : 0u;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+              if (e0 + k2 < cnt) drow[cj[k2]] = 0;
+          }
         }
       }
       __syncthreads();
@@ -1004,16 +1023,26 @@ __global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict_
     if (q == 0) s_base[0] = atomicAdd((uint32_t*)(S.stats + 1), R);
     __syncthreads();
     uint32_t* rows = (uint32_t*)S.big_rows + s_base[0];   // the component's rows, then (in place of the matched ones) its search roots
-    if (q < 64) {
+    if (q < 64) {  // eight label loads in flight per lane: the scan is a chain of L2 round trips otherwise
       uint32_t cnt = 0;
-      for (uint32_t r0 = 0; r0 < N; r0 += 64) {
-        const uint32_t row = r0 + lane;
-        const bool f = row < N && S.lab[row] == root;
-        const unsigned long long m = __ballot(f);
-        if (f) rows[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
-        cnt += (uint32_t)__popcll(m);
+      for (uint32_t r0 = 0; r0 < N; r0 += 512) {
+        uint32_t lb8[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+          const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+          lb8[k2] = row < N ? S.lab[row] : SA_NONE;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+          const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+          const bool f = row < N && lb8[k2] == root;
+          const unsigned long long m = __ballot(f);
+          if (f) rows[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
+          cnt += (uint32_t)__popcll(m);
+        }
       }
     }
+    if (q == 0) s_cnt[1] = 0;  // the component's heaviest gain
     __syncthreads();
     // greedy start: bids, duals, gains into the dense matrix
     for (uint32_t i = q; i < R; i += NT) {
@@ -1023,15 +1052,24 @@ __global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict_
       int64_t SA_G* drow = S.dense + (size_t)row * T;
       int64_t maxg = 0;
       uint32_t bcol = SA_NONE;
-      for (uint32_t e = 0; e < ne; ++e) {
-        const SaEdge ed = sa_ldg(ep + e);
-        if (excl && excl[ed.col]) continue;
-        drow[ed.col] = ed.gain;
-        if (ed.gain > maxg || (ed.gain == maxg && ed.col < bcol)) { maxg = ed.gain; bcol = ed.col; }
+      for (uint32_t e0 = 0; e0 < ne; e0 += 4) {  // four records (and their exclusion flags) per round trip
+        SaEdge ed[4];
+        bool use[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(excl && excl[ed[k2].col]);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+          if (!use[k2]) continue;
+          drow[ed[k2].col] = ed[k2].gain;
+          if (ed[k2].gain > maxg || (ed[k2].gain == maxg && ed[k2].col < bcol)) { maxg = ed[k2].gain; bcol = ed[k2].col; }
+        }
       }
       u[row] = -maxg;
       S.big_bcol[row] = bcol;
       if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
+      if (maxg > 0) atomicMax(&s_cnt[1], maxg > 0x7fffffffll ? 0x7fffffffu : (uint32_t)maxg);
     }
     __syncthreads();
     if (q < 64) {  // matched rows keep their bid; the others become the search roots, ascending, compacted in place
@@ -1060,7 +1098,12 @@ __global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict_
       sa_dense_ws w;
       w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
       w.u = u; w.rmatch = rmatch; w.cmatch = cmatch; w.pred = pred; w.part = s_part;
-      sa_assign_component_dense<NT, CPT>(w, rows, s_cnt[0]);
+      bool k32 = false;
+      if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) k32 = s_cnt[1] <= (uint32_t)SA_DENSE_K32_MAXGAIN;
+      if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) {
+        if (k32) sa_assign_component_dense<NT, CPT, true>(w, rows, s_cnt[0]);
+      }
+      if (!k32) sa_assign_component_dense<NT, CPT, false>(w, rows, s_cnt[0]);
     }
     // results; matrix, bids and (LDS) matches wiped for the next component / frame.  The rows list was overwritten by the roots:
     // walk the scene's labels again.
@@ -1071,7 +1114,14 @@ __global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict_
       const uint32_t ne = S.e_use[row];
       const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
       int64_t SA_G* drow = S.dense + (size_t)row * T;
-      for (uint32_t e = 0; e < ne; ++e) drow[sa_ldg(ep + e).col] = 0;
+      for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+        uint32_t cj[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) cj[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2).col : 0u;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+          if (e0 + k2 < ne) drow[cj[k2]] = 0;
+      }
       const uint32_t bc = S.big_bcol[row];
       if (bc != SA_NONE) S.cwin[bc] = SA_NONE;
       if (LDS_STATE) {
@@ -1199,7 +1249,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const bool vis = p.visual_kind != SA_VIS_NONE;
       const size_t lds = (size_t)maxN * 12 + (size_t)maxT * 8;
       const bool in_lds = lds <= 144u * 1024u;
-      const dim3 grid(ns >= 16 ? 4u : 16u, 1, ns);
+      const dim3 grid(ns >= 16 ? 8u : ns >= 4 ? 16u : 64u, 1, ns);
       if (maxT <= 256u * 4u) launch_dense<256, 4>(vis, in_lds, grid, lds, st, scenes);
       else if (maxT <= 256u * 8u) launch_dense<256, 8>(vis, in_lds, grid, lds, st, scenes);
       else if (maxT <= 256u * 16u) launch_dense<256, 16>(vis, in_lds, grid, lds, st, scenes);

@@ -37,11 +37,13 @@ void coop_solve_all(const sa_coop_ws& w, const std::vector<std::vector<uint32_t>
     if (!roots.empty()) sa_assign_component_coop<G>(w, roots.data(), (uint32_t)roots.size());
 }
 template <int NT, int CPT>
-void dense_solve_all(const sa_dense_ws& w, const sa_coop_ws& cw, const std::vector<std::vector<uint32_t>>& comps, uint32_t min_roots) {
+void dense_solve_all(const sa_dense_ws& w, const sa_coop_ws& cw, const std::vector<std::vector<uint32_t>>& comps, uint32_t min_roots, bool k32) {
   for (const auto& roots : comps) {
     if (roots.empty()) continue;
-    if (roots.size() >= min_roots) sa_assign_component_dense<NT, CPT>(w, roots.data(), (uint32_t)roots.size());
-    else sa_assign_component_coop<64>(cw, roots.data(), (uint32_t)roots.size());
+    if (roots.size() >= min_roots) {
+      if (k32) sa_assign_component_dense<NT, CPT, true>(w, roots.data(), (uint32_t)roots.size());
+      else sa_assign_component_dense<NT, CPT, false>(w, roots.data(), (uint32_t)roots.size());
+    } else sa_assign_component_coop<64>(cw, roots.data(), (uint32_t)roots.size());
   }
 }
 }  // namespace
@@ -271,7 +273,8 @@ int emu_assign_coop(uint32_t N, uint32_t T, const float* pos, int64_t threshold_
 // usable edges, union-find, duals u = -(heaviest usable gain), greedy start, and then — for EVERY component with search roots
 // (min_roots = 1) or only those with at least min_roots of them (the others go to the wavefront-cooperative solver, as on the
 // device) — the component's gains scattered into a dense N x T matrix (excluded columns never written), its roots ascending,
-// sa_assign_component_dense<NT, CPT>, and the matrix wiped again.  nt_cpt: 1 = 256 threads x 4 columns, 2 = 16 x 8, 3 = 256 x 8.
+// sa_assign_component_dense<NT, CPT, K32>, and the matrix wiped again.  nt_cpt: 1 = 256 threads x 4 columns, 2 = 16 x 8, 3 = 256 x 8;
+// + 16 = the 64-bit variant even where the 32-bit one applies.
 int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip, const uint8_t* col_skip,
                      int nt_cpt, uint32_t min_roots, int32_t* rmatch_out, int64_t* total_gain) {
   std::vector<uint32_t> parent(N + T), e_cnt(N, 0), e_off(N, 0);
@@ -316,10 +319,15 @@ int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold
   cw.e_off = e_off.data(); cw.excluded = nullptr;
   cw.u = u.data(); cw.v = v.data(); cw.rmatch = rmatch.data(); cw.cmatch = cmatch.data(); cw.dist = dist.data(); cw.pred = pred.data();
   cw.cstamp = cstamp.data(); cw.cscan = cscan.data(); cw.clist = clist.data();
-  switch (nt_cpt) {
-    case 1: if (T > 256 * 4) return -21; dense_solve_all<256, 4>(w, cw, comps, min_roots); break;
-    case 2: if (T > 16 * 8) return -21; dense_solve_all<16, 8>(w, cw, comps, min_roots); break;
-    case 3: if (T > 256 * 8) return -21; dense_solve_all<256, 8>(w, cw, comps, min_roots); break;
+  // the 32-bit variant wherever the device would take it (every gain below SA_DENSE_K32_MAXGAIN, at most 2048 tracks), unless
+  // nt_cpt asks for the 64-bit one regardless (+ 16)
+  int64_t maxgain = 0;
+  for (int64_t g : e_gain) maxgain = g > maxgain ? g : maxgain;
+  const bool k32 = !(nt_cpt & 16) && maxgain <= SA_DENSE_K32_MAXGAIN && T <= SA_DENSE_K32_MAXT;
+  switch (nt_cpt & 15) {
+    case 1: if (T > 256 * 4) return -21; dense_solve_all<256, 4>(w, cw, comps, min_roots, k32); break;
+    case 2: if (T > 16 * 8) return -21; dense_solve_all<16, 8>(w, cw, comps, min_roots, k32); break;
+    case 3: if (T > 256 * 8) return -21; dense_solve_all<256, 8>(w, cw, comps, min_roots, k32); break;
     default: return -20;
   }
   int64_t tot = 0;
@@ -338,6 +346,12 @@ int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold
   // checked by the caller against the dense kuhn_munkres (total and, on unique optima, the matching itself)
   if (total_gain) *total_gain = tot;
   return 0;
+}
+
+// emulation statistics of the dense solver since the last call: search steps, searches (roots), components
+void emu_dense_stats(uint64_t* out3) {
+  out3[0] = sa_dense_emu_steps; out3[1] = sa_dense_emu_searches; out3[2] = sa_dense_emu_comps;
+  sa_dense_emu_steps = sa_dense_emu_searches = sa_dense_emu_comps = 0;
 }
 
 // The positional tiles' pre-filter (heterogeneous launch): 1 when sa_clip_is_empty proves the clip of (cand, track) empty.

@@ -373,7 +373,7 @@ def run_emu_assign_dense(pos, thr_q, shape=1, min_roots=1, row_skip=None, col_sk
     return rm[:N], tot.value
 
 
-@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("shape", [1, 2, 17, 18])
 @pytest.mark.parametrize("density", [0.02, 0.1, 0.5, 1.0])
 def test_dense_assignment_reaches_dense_optimum(density, shape):
     rng = np.random.default_rng(int(density * 100) + 1000 * shape)
@@ -394,7 +394,7 @@ def test_dense_assignment_reaches_dense_optimum(density, shape):
         np.testing.assert_array_equal(rm_mix, ref)
 
 
-@pytest.mark.parametrize("shape,n,t", [(1, 300, 320), (3, 640, 700), (1, 1024, 1024)])
+@pytest.mark.parametrize("shape,n,t", [(1, 300, 320), (3, 640, 700), (19, 640, 700), (1, 1024, 1024)])
 def test_dense_assignment_one_giant_component(shape, n, t):
     """All boxes on one pile under a low threshold: one component of hundreds of rows, half of all cells usable, most greedy bids
     colliding (the `giant` / `bigpile` bench frames).  Same matching as the dense kuhn_munkres and as the wavefront solver."""
@@ -407,7 +407,7 @@ def test_dense_assignment_one_giant_component(shape, n, t):
     np.testing.assert_array_equal(rm, ref)
 
 
-@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("shape", [1, 2, 18])
 def test_dense_assignment_chains_exclusions_and_ties(shape):
     n = 60
     pos = np.full((n, n), np.nan, np.float32)
