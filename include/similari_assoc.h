@@ -199,6 +199,9 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
 int sa_batch_run(sa_engine* e);
 int sa_batch_sync(sa_engine* e);
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type);
+/* The same winners as COLUMNS of the scene's track table (the order of sa_tracks_order), -1 = none: a host that keeps its tracks in
+ * table order — rows are appended in upsert / apply order, sa_tracks_remove closes the gaps — finds the winner without a lookup by id. */
+int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols);
 
 /* ---- device-side track upkeep: the step either side of the association ------------
  * Applies the result of the last run of batch slot `slot` to that scene's device-resident track table, the way

@@ -1,5 +1,10 @@
 """End-to-end tracker loop (facade predict() per frame): host upkeep (Kalman + bank on the host, sa_tracks_upsert every frame)
-against device upkeep (sa_tracks_apply).  Times the C call only (observations are built once).
+against device upkeep (sa_tracks_apply).  The observations of every frame are built BEFORE the timed loop and the C calls run back
+to back (the way the reference's criterion benches call predict(), benches/simple_visual_sort_tracker.rs) — a loop that leaves the
+GPU idle for milliseconds between frames measures the wake-up of an idle queue (~100 us per frame on this stack), not the tracker.
+VisualSORT features three ways: one host array per observation (`rows`: the facade gathers them), one pinned N x D block per frame
+from sa_host_alloc (`pinned`: read in place over the link), one N x D block per frame in device memory registered with
+sa_device_block_register (`device`: the ReID model's output buffer on the same GPU, read where it lies).
    python scripts/bench_tracker.py [n_objects] [feature_len] [frames]"""
 import ctypes as C
 import json
@@ -8,6 +13,9 @@ import time
 from pathlib import Path
 
 import numpy as np
+import torch
+
+torch.zeros(1, device="cuda:0")  # torch's HIP context first (it stands in for the detector / ReID model that owns the feature buffers)
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from similari_amd import abi, synth  # noqa: E402
@@ -25,37 +33,62 @@ def u2d(b):
     return TR.Universal2DBox(float(b["xc"]), float(b["yc"]), None, float(b["aspect"]), float(b["height"]), float(b["confidence"]))
 
 
-def run(kind, device_upkeep):
+def run(kind, device_upkeep, feats_mode="rows"):
     if kind == "visual":
         opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.2))
                 .positional_metric(TR.PositionalMetricType.iou(0.3)).visual_minimal_track_length(1).visual_max_observations(3))
         trk = TR.VisualSort(opts=opts, feature_len=d, device_upkeep=device_upkeep)
     else:
         trk = TR.Sort(bbox_history=3, max_idle_epochs=3, device_upkeep=device_upkeep)
+    lib = trk.lib
     world = world0.copy()
     r = np.random.default_rng(1)
-    times = []
+    keep, arrs, blocks = [], [], []
+    dev = None
+    if kind == "visual" and feats_mode == "device":
+        dev = torch.empty((frames, n, d), dtype=torch.float32, device="cuda:0")
+        lib.sa_device_block_register(C.c_void_p(dev.data_ptr()), dev.numel() * 4, 0)
     for f in range(frames):
         world = synth.jitter_boxes(r, world, 2.0)
         feats = synth.observe(r, ident, 0.01)
         if kind == "visual":
+            if feats_mode == "pinned":
+                p = lib.sa_host_alloc(n * d * 4)
+                blk = np.frombuffer((C.c_char * (n * d * 4)).from_address(p), dtype=np.float32).reshape(n, d)
+                blk[...] = feats
+                blocks.append(p)
+                feats = blk
             items = [TR.VisualSortObservation(feats[k], 0.9, u2d(world[k]), None) for k in range(n)]
         else:
             items = [(u2d(world[k]), None) for k in range(n)]
-        keep = []
         arr = trk._obs_array(items, keep)
-        out = (abi.sa_sort_track * n)()
+        if dev is not None:
+            dev[f].copy_(torch.from_numpy(feats))
+            base = dev.data_ptr() + f * n * d * 4
+            for k in range(n):
+                arr[k].feature = C.cast(C.c_void_p(base + k * d * 4), C.POINTER(C.c_float))
+        arrs.append(arr)
+    if dev is not None:
+        torch.cuda.synchronize()
+    out = (abi.sa_sort_track * n)()
+    times = []
+    for f in range(frames):  # back to back: nothing but the C call inside the loop
         t0 = time.perf_counter()
-        rc = trk.lib.sa_tracker_predict(trk.h, 0, n, arr, out)
+        rc = lib.sa_tracker_predict(trk.h, 0, n, arrs[f], out)
         times.append(time.perf_counter() - t0)
-        assert rc == 0
+        assert rc == 0, lib.sa_tracker_last_error(trk.h)
     matched = sum(1 for i in range(n) if out[i].length > 1)
     trk.close()
+    if dev is not None:
+        lib.sa_device_block_unregister(C.c_void_p(dev.data_ptr()))
+    for p in blocks:
+        lib.sa_host_free(p)
     return 1e3 * float(np.median(times[3:])), matched
 
 
-for kind in ("sort", "visual"):
-    for dev in (False, True):
-        ms, matched = run(kind, dev)
-        print(json.dumps({"tracker": kind, "objects": n, "feature_len": d if kind == "visual" else 0, "upkeep": "device" if dev else "host",
-                          "ms_per_frame_median": round(ms, 3), "tracks_continued_last_frame": matched}))
+for kind, dev, mode in (("sort", False, "rows"), ("sort", True, "rows"), ("visual", False, "rows"), ("visual", True, "rows"),
+                        ("visual", True, "pinned"), ("visual", True, "device")):
+    ms, matched = run(kind, dev, mode)
+    print(json.dumps({"tracker": kind, "objects": n, "feature_len": d if kind == "visual" else 0, "upkeep": "device" if dev else "host",
+                      "features": mode if kind == "visual" else None, "ms_per_frame_median": round(ms, 3),
+                      "tracks_continued_last_frame": matched}), flush=True)

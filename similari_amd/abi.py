@@ -356,6 +356,7 @@ PROTOTYPES = {
     "sa_batch_run": (C.c_int, [ENGINE]),
     "sa_batch_sync": (C.c_int, [ENGINE]),
     "sa_batch_fetch": (C.c_int, [ENGINE, u32, P(u64), P(C.c_uint8)]),
+    "sa_batch_fetch_cols": (C.c_int, [ENGINE, u32, P(i32)]),
     "sa_associate_batch": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(sa_scene_result)]),
     "sa_pipe_stage": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(u64)]),
     "sa_pipe_launch": (C.c_int, [ENGINE, u64]),

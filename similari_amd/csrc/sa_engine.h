@@ -121,6 +121,8 @@ struct SceneDev {
   uint64_t SA_G* out_track_id;
   uint8_t SA_G* out_vote;
   int32_t SA_G* win_col;     // [N] winning track as a column of the table, -1 = none: what the device-side upkeep consumes
+  int32_t SA_G* out_win;     // [N] the same, next to the results in mapped host memory (sa_batch_fetch_cols: a host that keeps its tracks in
+                             // table order finds the winner without a hash lookup per candidate)
   uint32_t SA_G* stats;      // [4] device words the first phase raises: [0] = 1 when the frame was ill-conditioned for the euclidean expansion
   uint32_t SA_G* out_stats;  // [4] the same, moved next to the results (mapped host memory) and re-armed by the assignment tail
   int64_t SA_G* quant;  // optional N x T tap

@@ -5,6 +5,7 @@
 #include "sa_kalman.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,7 +72,7 @@ struct Slot {  // one scene of a request set
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
   HostBuf h_apply, h_pred;
-  void* d_pred = nullptr;
+  void *d_pred = nullptr, *d_apply = nullptr;  // device views of the two
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   bool ran = false;
@@ -220,11 +221,40 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
     if (_r != SA_OK) return _r;  \
   } while (0)
 
+// Waits for a stream.  hipStreamSynchronize parks the calling thread on an interrupt after a short spin, and the wake-up costs ~60 us on
+// this stack — three times the kernels of a SORT frame: a frame-latency API polls instead (hipStreamQuery, about a microsecond a
+// call) for as long as a frame can plausibly take, and only then parks.  SA_SYNC=block: always park (measurements).
+hipError_t stream_wait(hipStream_t st) {
+  static const bool park = getenv("SA_SYNC") && !strcmp(getenv("SA_SYNC"), "block");
+  if (!park) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q != hipErrorNotReady) return q;
+      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  return hipStreamSynchronize(st);
+}
+
+hipError_t event_wait(hipEvent_t ev) {  // the same for an event (sa_pipe_wait)
+  static const bool park = getenv("SA_SYNC") && !strcmp(getenv("SA_SYNC"), "block");
+  if (!park) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      const hipError_t q = hipEventQuery(ev);
+      if (q != hipErrorNotReady) return q;
+      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  return hipEventSynchronize(ev);
+}
+
 int engine_sync(sa_engine* e) {
   for (int k = 0; k < 3; ++k)
     if (e->aux_stream[k]) HIPCHK(e, hipStreamSynchronize(e->aux_stream[k]));
-  if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->copy_stream) HIPCHK(e, stream_wait(e->copy_stream));
+  HIPCHK(e, stream_wait(e->stream));
   for (auto& g : e->garbage) hipFree(g.p);
   e->garbage.clear();
   e->synced = true;
@@ -245,7 +275,7 @@ int engine_sync(sa_engine* e) {
 // The compute stream alone (sa_tracks_apply: its kernels and the mapped results are all on it): the copy stream may be busy with the
 // ingest of the NEXT request set — that is the overlap the pipelined entry points exist for — and is left alone.
 int compute_sync(sa_engine* e) {
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, stream_wait(e->stream));
   return SA_OK;
 }
 
@@ -437,7 +467,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   if (e->cfg.flags & SA_FLAG_TAP) TRY(dev_ensure(e, s->tap, n * 8 + t * 8 + n * 4));
   {
     void* before = s->h_out.p;
-    TRY(host_ensure(e, s->h_out, n * 9 + 32));  // ids[n] | votes[n] | (8-byte aligned) stats[4]
+    TRY(host_ensure(e, s->h_out, n * 13 + 48));  // ids[n] | votes[n] | (8-byte aligned) stats[4] | winning columns[n]
     if (s->h_out.p != before || !s->d_out) HIPCHK(e, hipHostGetDevicePointer(&s->d_out, s->h_out.p, 0));
   }
   return SA_OK;
@@ -482,6 +512,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->dq = (decltype(d->dq))(s->dq.p); d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dense = (decltype(d->dense))(s->dense.p);
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
+  d->out_win = (decltype(d->out_win))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16);
   if (s->tap.p) {  // SA_FLAG_TAP: [N] row words | [T] column words | [N] edge counts (sizes as slot_reserve laid them out)
     const size_t n = s->N ? s->N : 1, t = s->T ? s->T : 1;
     d->tap_row_best = (decltype(d->tap_row_best))(s->tap.p);
@@ -1376,6 +1407,20 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
   return SA_OK;
 }
 
+// The winners of a slot as COLUMNS of the scene's track table (sa_tracks_order), -1 = none: out of the same mapped block as the ids.
+int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_batch_fetch_cols"));
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!out_cols && s->N) return fail(e, SA_ERR_BAD_ARG, "sa_batch_fetch_cols: null argument");
+  if (!s->N) return SA_OK;
+  if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch_cols before sa_batch_run");
+  if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
+  std::memcpy(out_cols, (const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16, (size_t)s->N * 4);
+  return SA_OK;
+}
+
 int sa_associate_batch(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, const sa_scene_result* res) {
   if (!e || (n_scenes && (!req || !res))) return fail(e, SA_ERR_BAD_ARG, "sa_associate_batch: null argument");
   TRY(sa_batch_begin(e));
@@ -1490,8 +1535,8 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
     return fail(e, SA_ERR_STATE, "ticket %llu has not been launched (or is unknown)", (unsigned long long)ticket);
   if (b->n_slots && !res) return fail(e, SA_ERR_BAD_ARG, "sa_pipe_wait: null result array");
   if (b->state == 2) {
-    hipError_t s = hipEventSynchronize(b->ev_done);
-    if (s != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(s));
+    hipError_t s = event_wait(b->ev_done);
+    if (s != hipSuccess) return fail(e, SA_ERR_HIP, "waiting for the ticket's completion event failed: %s", hipGetErrorString(s));
   }
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     const Slot* s = b->slots[i];
@@ -1535,50 +1580,58 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   if (s->T != sc->T) return fail(e, SA_ERR_STATE, "the scene's track table changed since the slot ran");
   if (e->visual) TRY(ensure_prepped(e, e->B));  // the feature-bank step reads the candidates' padded rows and norms
   const uint64_t* winners = (const uint64_t*)s->h_out.p;
+  // the same winners as rows of the table (written next to the ids by the assignment tail): no lookup by id per candidate
+  const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
   sc->full.resize(sc->T, 0);
   uint32_t n_new = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (winners[i] == 0) {
       if (!new_ids || new_ids[i] == 0) return fail(e, SA_ERR_BAD_ARG, "candidate %u starts a track and needs new_ids[%u] > 0", i, i);
       if (sc->slot_of.count(new_ids[i])) return fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)new_ids[i]);
-      for (uint32_t j = 0; j < i; ++j)
-        if (winners[j] == 0 && new_ids[j] == new_ids[i]) return fail(e, SA_ERR_BAD_ARG, "new id %llu given twice", (unsigned long long)new_ids[i]);
       ++n_new;
     } else {
-      auto it = sc->slot_of.find(winners[i]);
-      if (it == sc->slot_of.end()) return fail(e, SA_ERR_STATE, "winner %llu is not in the table", (unsigned long long)winners[i]);
-      if (!sc->full[it->second])
+      const int32_t c = wcol[i];
+      if (c < 0 || (uint32_t)c >= sc->T || sc->ids[c] != winners[i]) return fail(e, SA_ERR_STATE, "winner %llu is not in the table", (unsigned long long)winners[i]);
+      if (!sc->full[c])
         return fail(e, SA_ERR_STATE, "track %llu was upserted without a Kalman state: device-side upkeep needs tracks created by "
                     "sa_tracks_apply or seeded with sa_tracks_set_state", (unsigned long long)winners[i]);
     }
   }
+  if (n_new > 1) {  // one row per new id
+    std::vector<uint64_t> fresh;
+    fresh.reserve(n_new);
+    for (uint32_t i = 0; i < n; ++i)
+      if (winners[i] == 0) fresh.push_back(new_ids[i]);
+    std::sort(fresh.begin(), fresh.end());
+    for (size_t k = 1; k < fresh.size(); ++k)
+      if (fresh[k] == fresh[k - 1]) return fail(e, SA_ERR_BAD_ARG, "new id %llu given twice", (unsigned long long)fresh[k]);
+  }
   const uint32_t T0 = sc->T;
   TRY(scene_reserve(e, sc, T0 + n_new));
-  // staging: table row + id of every candidate that starts a track
-  TRY(host_ensure(e, s->h_apply, (size_t)n * 12));
+  // staging: table row + id of every candidate that starts a track — in mapped pinned memory the kernel reads in place (12 KB at
+  // 1000 candidates: two runtime copy calls and their DMA launches would cost more than the reads over the link)
+  const size_t ids_off = ((size_t)n * 4 + 7) & ~(size_t)7;
+  {
+    void* before = s->h_apply.p;
+    TRY(host_ensure(e, s->h_apply, ids_off + (size_t)n * 8));
+    if (s->h_apply.p != before || !s->d_apply) HIPCHK(e, hipHostGetDevicePointer(&s->d_apply, s->h_apply.p, 0));
+  }
   uint32_t* h_row = (uint32_t*)s->h_apply.p;
-  uint64_t* h_ids = (uint64_t*)((uint8_t*)s->h_apply.p + (((size_t)n * 4 + 7) & ~(size_t)7));
-  TRY(host_ensure(e, s->h_apply, (((size_t)n * 4 + 7) & ~(size_t)7) + (size_t)n * 8));
-  h_row = (uint32_t*)s->h_apply.p;
-  h_ids = (uint64_t*)((uint8_t*)s->h_apply.p + (((size_t)n * 4 + 7) & ~(size_t)7));
+  uint64_t* h_ids = (uint64_t*)((uint8_t*)s->h_apply.p + ids_off);
   uint32_t next = T0;
   for (uint32_t i = 0; i < n; ++i) {
     h_row[i] = winners[i] == 0 ? next++ : SA_NONE;
     h_ids[i] = winners[i] == 0 ? new_ids[i] : 0;
   }
-  TRY(dev_ensure(e, s->new_row, (size_t)n * 4));
-  TRY(dev_ensure(e, s->new_ids, (size_t)n * 8));
   {
     void* before = s->h_pred.p;
     TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
     if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
   }
   hipStream_t st = e->stream;
-  HIPCHK(e, hipMemcpyAsync(s->new_row.p, h_row, (size_t)n * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(e, hipMemcpyAsync(s->new_ids.p, h_ids, (size_t)n * 8, hipMemcpyHostToDevice, st));
   ApplyArgs a{};
-  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = (const uint32_t*)s->new_row.p;
-  a.new_ids = (const uint64_t*)s->new_ids.p; a.n = n; a.epoch = s->epoch;
+  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = (const uint32_t*)s->d_apply;
+  a.new_ids = (const uint64_t*)((const uint8_t*)s->d_apply + ids_off); a.n = n; a.epoch = s->epoch;
   a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
   a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
   BankArgs b{};
@@ -1606,9 +1659,7 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
       sc->ids.push_back(new_ids[i]);
     }
   sc->T = T0 + n_new;
-  sc->full.resize(sc->T, 1);
-  for (uint32_t i = 0; i < n; ++i)
-    if (winners[i] != 0) sc->full[sc->slot_of[winners[i]]] = 1;
+  sc->full.resize(sc->T, 1);  // (the winners' rows held a full state already: checked above)
   s->ran = false;  // the table the slot ran against is gone
   return SA_OK;
 }

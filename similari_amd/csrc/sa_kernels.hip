@@ -581,6 +581,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       S.out_track_id[q] = id;
       S.out_vote[q] = vt;
       S.win_col[q] = vw >= 0 ? vw : -1;
+      S.out_win[q] = vw >= 0 ? vw : -1;
     }
     return;
   }
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     S.out_track_id[q] = id;
     S.out_vote[q] = vt;
     S.win_col[q] = win;
+    S.out_win[q] = win;
   }
   if (nd) {
     // The dense solver runs on SA_DENSE_NT threads (one wave per SIMD: a search step is a chain of dependent instructions, more
@@ -827,6 +829,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
         S.out_track_id[row] = c >= 0 ? S.t_ids[c] : 0ull;
         S.out_vote[row] = c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
         S.win_col[row] = c;
+        S.out_win[row] = c;
         int64_t SA_G* drow = S.dense + (size_t)row * T;
         const uint32_t cnt = s_ecnt[row];
         if (pool) {
@@ -903,6 +906,7 @@ __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q,
   S.out_track_id[q] = id;
   S.out_vote[q] = vt;
   S.win_col[q] = win;
+  S.out_win[q] = win;
 }
 template <bool VISUAL>
 __global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict__ scenes) {

@@ -42,7 +42,21 @@ struct Obs {  // one stored observation of a VisualSORT track; index 0 carries t
   bool has_own = false;
   float own = 0.0f;
   bool has_feat = false;
-  std::vector<float> feat;
+  std::vector<float> feat;   // host upkeep only: with device upkeep the vectors live in the device bank
+};
+
+// The last `cap` boxes of a track (SortAttributes::observed_boxes / predicted_boxes are VecDeques trimmed to the history length,
+// sort.rs:160-176): a fixed ring — no allocation per frame.
+struct Ring {
+  std::vector<sa_box> v;
+  uint32_t head = 0, count = 0;
+  void push(const sa_box& b, uint32_t cap) {
+    if (v.size() != cap) { v.resize(cap); head = 0; count = 0; }
+    if (count < cap) v[(head + count++) % cap] = b;
+    else { v[head] = b; head = (head + 1) % cap; }
+  }
+  const sa_box& back() const { return v[(head + count - 1) % (uint32_t)v.size()]; }
+  uint32_t size() const { return count; }
 };
 
 struct Track {
@@ -52,7 +66,7 @@ struct Track {
   int32_t voting = -1;  // VisualAttributes::voting_type: None
   bool has_state = false;
   KF kf;
-  std::deque<sa_box> predicted, observed;
+  Ring predicted, observed;
   std::vector<Obs> obs;
   uint32_t feat_count = 0;
 };
@@ -67,8 +81,11 @@ struct sa_tracker {
   std::string err;
   uint64_t track_id = 0;
   std::map<uint64_t, uint64_t> epochs;            // scene -> current epoch
-  std::unordered_map<uint64_t, Track> store;      // main store
-  std::map<uint64_t, std::vector<uint64_t>> by_scene;  // scene -> ids (ascending)
+  std::unordered_map<uint64_t, Track> store;      // main store (node-based: a Track's address is stable while it lives)
+  // scene -> its tracks in the order of the engine's table for that scene: rows are appended in creation order (ids ascend) and
+  // removals close the gaps on both sides, so the winner the engine reports as a COLUMN (sa_batch_fetch_cols) is rows[column] —
+  // no lookup by id on the per-candidate path
+  std::map<uint64_t, std::vector<Track*>> by_scene;
   std::vector<Track> wasted_store;
   uint32_t waste_counter = 0;
 };
@@ -92,12 +109,8 @@ bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, 
 
 void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
   tr.length += 1;                                     // sort.rs:160-176, track_attributes.rs:60-78
-  tr.observed.push_back(observed);
-  tr.predicted.push_back(predicted);
-  if (o.history_length > 0 && tr.observed.size() > o.history_length) {
-    tr.observed.pop_front();
-    tr.predicted.pop_front();
-  }
+  tr.observed.push(observed, o.history_length);
+  tr.predicted.push(predicted, o.history_length);
 }
 
 sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
@@ -132,11 +145,12 @@ int auto_waste(sa_tracker* t) {
     std::sort(kv.second.begin(), kv.second.end());
     int rc = sa_tracks_remove(t->eng, kv.first, (uint32_t)kv.second.size(), kv.second.data());
     if (rc != SA_OK) return tfail(t, rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
-    auto& ids = t->by_scene[kv.first];
+    auto& rows = t->by_scene[kv.first];
+    rows.erase(std::remove_if(rows.begin(), rows.end(), [&](const Track* tr) { return std::binary_search(kv.second.begin(), kv.second.end(), tr->id); }),
+               rows.end());
     for (uint64_t id : kv.second) {
       t->wasted_store.push_back(std::move(t->store[id]));
       t->store.erase(id);
-      ids.erase(std::find(ids.begin(), ids.end(), id));
     }
   }
   return SA_OK;
@@ -176,14 +190,32 @@ int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids)
   return SA_OK;
 }
 
-struct Cand {  // the throw-away candidate track of one detection (simple_api.rs:125-145)
+struct Cand {  // the throw-away candidate track of one detection (simple_api.rs:125-145); the feature stays the caller's until a track stores it
   sa_box raw;      // detection as passed
   sa_box box;      // after its own Kalman no-op step: angle 0.0 -> None, confidence kept
-  Obs obs;                  // bookkeeping only: the feature itself is borrowed from the caller (fptr) until a track stores it
-  const float* fptr = nullptr;
-  bool has_custom;
+  float quality, own;
+  bool has_own, has_feat, has_custom;
+  const float* fptr;
   int64_t custom;
 };
+
+// optimize_observations  visual_sort/metric.rs:129-154 on a track's stored observations: keep those with a feature, stable sort by
+// quality (descending), drop the worst when the bank is full, push the new one and bring it to the front.  At most SA_MAX_BANK + 1
+// entries: an insertion sort in place, no allocation per merged track.
+void optimize_observations(std::vector<Obs>& obs, Obs&& nw, uint32_t max_observations) {
+  size_t n = 0;
+  for (size_t k = 0; k < obs.size(); ++k)
+    if (obs[k].has_feat) {
+      if (n != k) obs[n] = std::move(obs[k]);
+      ++n;
+    }
+  obs.resize(n);
+  for (size_t a = 1; a < n; ++a)  // stable: an element moves left only past strictly smaller qualities
+    for (size_t c = a; c > 0 && obs[c - 1].quality < obs[c].quality; --c) std::swap(obs[c - 1], obs[c]);
+  if (n >= max_observations && n > 0) obs.pop_back();
+  obs.push_back(std::move(nw));
+  std::swap(obs.front(), obs.back());
+}
 
 int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
                    const sa_observation* const* obs, sa_sort_track* const* out) {
@@ -193,8 +225,11 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   for (uint32_t s = 0; s < n_scenes; ++s)
     for (uint32_t s2 = 0; s2 < s; ++s2)
       if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
+  // SA_TRACKER_TRACE=1: where a predict() spends its time, in microseconds on stderr
+  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
+  using clk = std::chrono::steady_clock;
+  const auto t_entry = clk::now();
   // auto waste (simple_api.rs:115-120)
-  const auto t_entry = std::chrono::steady_clock::now();
   if (t->waste_counter == 0) {
     int rc = auto_waste(t);
     if (rc != SA_OK) return rc;
@@ -204,12 +239,13 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   std::vector<std::vector<Cand>> cands(n_scenes);
   std::vector<uint64_t> epoch(n_scenes);
   std::vector<sa_scene_request> req(n_scenes);
-  std::vector<sa_scene_result> res(n_scenes);
   std::vector<std::vector<sa_box>> cboxes(n_scenes);
   std::vector<std::vector<float>> cq(n_scenes), cown(n_scenes);
-  std::vector<std::vector<const float*>> cfeat(n_scenes);   // one pointer per detection: the engine gathers the rows itself
+  std::vector<std::vector<const float*>> cfeat(n_scenes);   // one pointer per detection: the engine gathers the rows itself ...
+  std::vector<uint8_t> contiguous(n_scenes, 0);             // ... unless they already ARE one N x D block (then: no gather at all)
   std::vector<std::vector<uint8_t>> cpres(n_scenes), votes(n_scenes);
   std::vector<std::vector<uint64_t>> winners(n_scenes);
+  std::vector<std::vector<int32_t>> wcols(n_scenes);
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint32_t n = counts[s];
     epoch[s] = ++t->epochs[scene_ids[s]];  // next_epoch  epoch_db.rs:35-49
@@ -236,6 +272,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
       }
     }
+    const float* block = nullptr;  // where row 0 of an N x D block would lie, if the features form one
+    bool one_block = o.visual && n > 0;
     for (uint32_t i = 0; i < n; ++i) {
       const sa_observation& ob = obs[s][i];
       Cand& c = cs[i];
@@ -252,21 +290,26 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       c.box.reserved = 0;
       c.has_custom = ob.has_custom_object_id != 0;
       c.custom = ob.custom_object_id;
-      c.obs.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
-      c.obs.has_own = ob.own_area == ob.own_area || !shares.empty();
-      c.obs.own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
-      c.obs.has_feat = o.visual && ob.feature != nullptr;
-      c.fptr = c.obs.has_feat ? ob.feature : nullptr;
+      c.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
+      c.has_own = ob.own_area == ob.own_area || !shares.empty();
+      c.own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
+      c.has_feat = o.visual && ob.feature != nullptr;
+      c.fptr = c.has_feat ? ob.feature : nullptr;
       cboxes[s][i] = c.box;
       if (o.visual) {
-        cq[s][i] = c.obs.quality;
-        cown[s][i] = c.obs.has_own ? c.obs.own : NAN;
-        cpres[s][i] = c.obs.has_feat ? 1 : 0;
-        if (c.obs.has_feat) cfeat[s][i] = ob.feature;
+        cq[s][i] = c.quality;
+        cown[s][i] = c.has_own ? c.own : NAN;
+        cpres[s][i] = c.has_feat ? 1 : 0;
+        if (c.has_feat) {
+          cfeat[s][i] = ob.feature;
+          if (!block) block = ob.feature - (size_t)i * D;
+          one_block = one_block && ob.feature == block + (size_t)i * D;
+        }
       }
     }
     winners[s].assign(n, 0);
     votes[s].assign(n, 0);
+    wcols[s].assign(n, -1);
     sa_scene_request& r = req[s];
     std::memset(&r, 0, sizeof r);
     r.scene_id = scene_ids[s];
@@ -277,71 +320,97 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       r.detections.feat_present = cpres[s].data();
       r.detections.feat_quality = cq[s].data();
       r.detections.own_area = cown[s].data();
+      // The observations' features as ONE block (a producer that writes its N x D output contiguously — a ReID head's output buffer,
+      // host or device): handed over as such — read in place when the block is pinned (sa_host_alloc) or registered device memory
+      // (sa_device_block_register), one memcpy otherwise — instead of one gather per row.  Rows of detections without a feature are
+      // never dereferenced by the host (flagged absent).  Only when every row lies inside a block the engine knows: rows of
+      // absent detections may otherwise be unmapped memory.
+      if (one_block && block) {
+        bool all_present = true;
+        for (uint32_t i = 0; i < n; ++i) all_present = all_present && cs[i].has_feat;
+        contiguous[s] = all_present ? 1 : 0;
+        if (all_present) r.detections.feats = block;
+      }
     }
-    res[s].out_track_id = winners[s].data();
-    res[s].out_voting_type = votes[s].data();
   }
-  // SA_TRACKER_TRACE=1: where a predict() spends its time (request assembly | association on the GPU | device upkeep |
-  // host bookkeeping), in microseconds on stderr
-  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
-  using clk = std::chrono::steady_clock;
   const auto t_built = clk::now();
   double us_apply = 0.0;
   // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
   int rc = sa_batch_begin(t->eng);
+  const auto t_begun = clk::now();
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
-    rc = sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? cfeat[s].data() : nullptr, nullptr);
+    rc = contiguous[s] ? sa_batch_add(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, nullptr)
+                       : sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? cfeat[s].data() : nullptr, nullptr);
+  const auto t_added = clk::now();
   if (rc == SA_OK) rc = sa_batch_run(t->eng);
+  const auto t_run = clk::now();
   if (rc == SA_OK) rc = sa_batch_sync(t->eng);
-  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) rc = sa_batch_fetch(t->eng, s, res[s].out_track_id, res[s].out_voting_type);
+  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) {
+    rc = sa_batch_fetch(t->eng, s, winners[s].data(), votes[s].data());
+    if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, s, wcols[s].data());
+  }
   if (rc != SA_OK) return tfail(t, rc, "association: %s", sa_last_error(t->eng));
   const auto t_assoc = clk::now();
 
+  std::vector<uint64_t> touched, tids, new_ids;
+  std::vector<sa_box> dev_pred;
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint64_t scene = scene_ids[s];
-    std::vector<uint64_t> touched;
+    const uint32_t n = counts[s];
+    touched.clear();
     // ids first (same order the reference draws them in), so that the device-side upkeep can create the new tracks
-    std::vector<uint64_t> tids(counts[s]), new_ids(counts[s], 0);
-    for (uint32_t i = 0; i < counts[s]; ++i) {
+    tids.assign(n, 0);
+    new_ids.assign(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
       const uint64_t dest = winners[s][i];
       uint64_t drawn = 0;
       if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
       if (dest == 0) { tids[i] = o.batch_ids ? drawn : ++t->track_id; new_ids[i] = tids[i]; }
       else tids[i] = dest;
     }
-    std::vector<sa_box> dev_pred;
     if (o.device_upkeep) {
       // Kalman step, table refresh and feature-bank policy on the GPU: nothing but the predicted boxes comes back
-      dev_pred.resize(counts[s]);
+      dev_pred.resize(n);
       const auto ta = clk::now();
       rc = sa_tracks_apply(t->eng, s, new_ids.data(), dev_pred.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
     }
-    for (uint32_t i = 0; i < counts[s]; ++i) {
-      Cand& c = cands[s][i];
-      uint64_t dest = winners[s][i];
-      const uint64_t tid = tids[i];
+    std::vector<Track*>& rows = t->by_scene[scene];
+    const size_t rows_before = rows.size();  // the table the engine voted against: columns refer to these rows
+    for (uint32_t i = 0; i < n; ++i) {
+      const Cand& c = cands[s][i];
+      const uint64_t dest = winners[s][i];
+      Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        Track tr;
-        tr.id = tid; tr.scene = scene; tr.epoch = epoch[s];
+        Track& tr = t->store[tids[i]];
+        trp = &tr;
+        tr.id = tids[i]; tr.scene = scene; tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
         tr.has_state = true;
         if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, c.raw); }  // with device upkeep the state is born on the GPU
         tr.length = 0;
         update_history(o, tr, c.raw, c.box);
         if (o.visual) {
-          tr.obs.push_back(c.obs);                     // is_merge = false: the feature is kept as is
-          if (!o.device_upkeep && c.fptr) tr.obs.back().feat.assign(c.fptr, c.fptr + D);  // device upkeep: the vectors live in the device bank only
-          tr.feat_count = c.obs.has_feat ? 1 : 0;
+          tr.obs.reserve(o.visual_max_observations + 1);
+          tr.obs.emplace_back();                         // is_merge = false: the feature is kept as is
+          Obs& ob = tr.obs.back();
+          ob.quality = c.quality; ob.has_own = c.has_own; ob.own = c.own; ob.has_feat = c.has_feat;
+          if (!o.device_upkeep && c.fptr) ob.feat.assign(c.fptr, c.fptr + D);  // device upkeep: the vectors live in the device bank only
+          tr.feat_count = c.has_feat ? 1 : 0;
         }
-        t->store[tid] = std::move(tr);
-        t->by_scene[scene].push_back(tid);
+        rows.push_back(trp);
       } else {
-        auto it = t->store.find(dest);
-        if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
-        Track& tr = it->second;
+        // the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
+        const int32_t col = wcols[s][i];
+        if (col >= 0 && (size_t)col < rows_before && rows[col]->id == dest) trp = rows[col];
+        else {
+          auto it = t->store.find(dest);
+          if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
+          trp = &it->second;
+        }
+        Track& tr = *trp;
         // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215
         tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
@@ -350,26 +419,20 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         sa_box predicted = o.device_upkeep ? dev_pred[i] : make_prediction(pw, vw, tr.has_state, tr.kf, c.box);
         update_history(o, tr, c.box, predicted);
         if (o.visual) {
-          Obs nw = c.obs;
+          Obs nw;
+          nw.quality = c.quality; nw.has_own = c.has_own; nw.own = c.own; nw.has_feat = c.has_feat;
           if (!feature_can_be_used(o, c.box, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
                                    o.visual_minimal_own_area_percentage_collect))
             nw.has_feat = false;
           if (!o.device_upkeep && nw.has_feat) nw.feat.assign(c.fptr, c.fptr + D);
-          // optimize_observations  visual_sort/metric.rs:129-154 (with device upkeep: the bookkeeping only — the same
-          // policy moves the feature rows inside the device bank, sa_upkeep.hip)
-          std::vector<Obs> kept;
-          for (auto& ob : tr.obs) if (ob.has_feat) kept.push_back(std::move(ob));
-          std::stable_sort(kept.begin(), kept.end(), [](const Obs& a, const Obs& b) { return a.quality > b.quality; });
-          if (kept.size() >= o.visual_max_observations && !kept.empty()) kept.pop_back();
-          kept.push_back(std::move(nw));
-          std::swap(kept.front(), kept.back());
-          tr.obs = std::move(kept);
+          // (with device upkeep: the bookkeeping only — the same policy moves the feature rows inside the device bank, sa_upkeep.hip)
+          optimize_observations(tr.obs, std::move(nw), o.visual_max_observations);
           tr.feat_count = 0;
           for (auto& ob : tr.obs) tr.feat_count += ob.has_feat ? 1u : 0u;
         }
       }
-      touched.push_back(tid);
-      out[s][i] = to_sort_track(o, t->store[tid]);
+      if (!o.device_upkeep) touched.push_back(tids[i]);
+      out[s][i] = to_sort_track(o, *trp);
     }
     if (o.device_upkeep) continue;
     rc = sync_engine(t, scene, touched);
@@ -378,8 +441,9 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   if (trace) {
     const auto t_end = clk::now();
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    fprintf(stderr, "[sa_tracker] assemble %.1f  associate %.1f  apply %.1f  bookkeeping %.1f us\n", us(t_entry, t_built),
-            us(t_built, t_assoc), us_apply, us(t_assoc, t_end) - us_apply);
+    fprintf(stderr, "[sa_tracker] assemble %.1f  associate %.1f (begin %.1f stage %.1f enqueue %.1f wait+fetch %.1f)  apply %.1f  bookkeeping %.1f us\n",
+            us(t_entry, t_built), us(t_built, t_assoc), us(t_built, t_begun), us(t_begun, t_added), us(t_added, t_run), us(t_run, t_assoc), us_apply,
+            us(t_assoc, t_end) - us_apply);
   }
   return SA_OK;
 }
@@ -490,8 +554,8 @@ int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out,
   uint32_t n = 0;
   auto it = t->by_scene.find(scene_id);
   if (it != t->by_scene.end())
-    for (uint64_t id : it->second) {
-      const Track& tr = t->store[id];
+    for (const Track* trp : it->second) {
+      const Track& tr = *trp;
       if (tr.epoch != current_epoch(t, scene_id)) {
         if (out && n < cap) out[n] = to_sort_track(t->o, tr);
         ++n;
