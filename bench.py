@@ -31,7 +31,6 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 VALU_F32_PEAK_TFLOPS = 157.3  # f32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 VALU_F64_PEAK_TFLOPS = 78.6  # f64 vector peak (MI355X_MICROARCH.md)
-MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md); the f16-split option issues 3 products per flop
 
 
 def workload(name: str, seed: int):
@@ -91,6 +90,19 @@ def workload(name: str, seed: int):
         sc = synth.sort_scene(rng, 100, 100, canvas=(1920.0, 1080.0))
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
         return cfg, [sc], "SORT IoU 100 x 100, dense variant (BASELINE C1)"
+    if name in ("c1ref", "c1ref100"):
+        # the reference's OWN bench layout (benches/simple_sort_iou_tracker.rs:29-61: object i at (1000 i, 1000 i), 50 x 50, drift 1 px,
+        # spatio-temporal constraint (1, 1.0), IoU(0.3)), 500 (or 100) objects: nearly every off-diagonal pair dies in the pre-filter, so
+        # "pairs/s" here is the NOMINAL objects^2 / time that sits beside assets/benchmarks/benchmarks.md:36-40 (13.4 M nominal pairs/s
+        # for the whole predict() at 500 objects on four laptop cores) — the association alone on this side
+        n = 100 if name.endswith("100") else 500
+        tb = synth.diagonal_boxes(n)
+        db = synth.jitter_boxes(rng, tb, pos_sigma=1.0, size_rel=0.001)
+        perm = rng.permutation(n)
+        sc = dict(track_ids=np.arange(1, n + 1, dtype=np.uint64), track_boxes=tb, track_epochs=np.zeros(n, np.uint64), det_boxes=db[perm],
+                  truth=(perm + 1).astype(np.uint64))
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=1, constraints=[(1, 1.0)])
+        return cfg, [sc], f"SORT IoU {n} x {n} in the reference bench layout (objects 1000 px apart, constraint (1, 1.0)): benches/simple_sort_iou_tracker.rs"
     if name == "sd":
         # not a BASELINE config: a crowd for plain SORT (the C2 frame without features) — the positional vote alone has to untangle
         # the overlaps, so its graph has large connected components
@@ -183,6 +195,64 @@ def pmc_traffic(workload: str, kernel: str):
         if d:
             best = (d["hbm_bytes"], f.name)
     return best
+
+
+def rocprof_stats(workload: str):
+    """Average kernel durations (us) of the rocprofv3 --kernel-trace --stats summary committed for this workload
+    (profiles/r*_<workload>_kernel_stats.csv, the newest round wins): {engine kernel name: avg us}."""
+    import csv
+
+    out = {}
+    files = sorted((ROOT / "profiles").glob(f"r*_{workload}_kernel_stats.csv"))
+    if not files:
+        return out
+    names = ("k_frame_visual", "k_frame", "k_visual_cost", "k_visual_cosine", "k_visual_euclid", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
+             "k_assign_label", "k_assign_solve", "k_assign_dense")
+    try:
+        for row in csv.DictReader(files[-1].open()):
+            nm = row.get("Name", "")
+            for k in names:
+                if nm.startswith("void " + k + "<") or nm.startswith("void " + k + "(") or nm.startswith(k + "<") or nm.startswith(k + "("):
+                    key = "k_visual_cost" if k in ("k_visual_cosine", "k_visual_euclid") else k
+                    avg = float(row.get("AverageNs", 0.0)) / 1e3
+                    out[key] = max(out.get(key, 0.0), avg)  # several specialisations: the one this workload runs dominates
+                    break
+    except Exception:
+        return {}
+    return out
+
+
+def cpu_solve_only(cfg, scenes, budget_s=8.0):
+    """What the assignment tail replaces, ALONE: the reference's pathfinding::kuhn_munkres (oracle: or_kuhn_munkres) on the very
+    N x (T + N) i64 matrix SortVoting::winners builds for this frame (sort/voting.rs:44-86: quantised weights, the new-track threshold
+    on the diagonal of the self columns) — one host thread, matrix already built.  So that a solve is compared with a solve."""
+    import ctypes as C
+
+    import oracle_lib as O
+
+    sc = scenes[0]
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+    det = abi.make_detections(sc["det_boxes"])
+    ref = O.associate(cfg, tracks, 1, det, shards=int(max(1, min(os.cpu_count() or 1, 64))))
+    q = ref["quantised"]
+    n, t = q.shape
+    thr_q = int(O.lib().or_quantise(cfg.positional_threshold)) if cfg.positional_kind == abi.SA_POS_IOU else 1000000
+    w = np.zeros((n, t + n), np.int64)
+    w[:, :t] = q
+    w[np.arange(n), t + np.arange(n)] = thr_q
+    w = np.ascontiguousarray(w)
+    total = C.c_int64()
+    assign = np.zeros(n, np.uint32)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 30):
+        t0 = time.perf_counter()
+        rc = O.lib().or_kuhn_munkres(n, t + n, w.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total), assign.ctypes.data_as(C.POINTER(C.c_uint32)))
+        times.append(time.perf_counter() - t0)
+        assert rc == 0
+    return {"ms": 1e3 * min(times), "runs": len(times), "cores": 1, "rows": int(n), "cols": int(t + n), "edges_above_threshold": int((q > thr_q).sum()),
+            "what": "or_kuhn_munkres (the oracle's restatement of pathfinding::kuhn_munkres) on the N x (T + N) matrix of SortVoting::winners, matrix already "
+                    "built, best run; compare with the assignment kernels' avg_us (k_assign_small, or k_assign_label + k_assign_solve + k_assign_dense)"}
 
 
 def cpu_baseline(cfg, scenes, budget_s=12.0):
@@ -445,7 +515,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU baselines (the oracle still checks the timed run's answer)")
     ap.add_argument("--no-oracle", action="store_true", help="skip match_vs_oracle as well")
     ap.add_argument("--profile-iters", type=int, default=50)
-    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own; 64 f16-split operands on the f16 matrix cores)")
+    ap.add_argument("--flags", type=int, default=-1, help="engine flags for the timed pass (default 0: eager launches, heterogeneous first phase where it applies; 8 hipGraph replay; 32 contraction as a kernel of its own)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive pass (value_h2d)")
     ap.add_argument("--cluster", type=int, default=0, help="single process: also time the workload's scenes through sa_cluster over this many shards (one engine per device; --cluster-devices to place several shards on one GPU)")
     ap.add_argument("--cluster-devices", default="", help="comma-separated HIP ordinals for --cluster (default 0..n-1)")
@@ -567,7 +637,7 @@ def main():
     else:
         eng.close()
         cfg_p = cfg
-        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME | abi.SA_FLAG_F16_SPLIT))  # same launches as the timed pass
+        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME))  # same launches as the timed pass
         engp = Engine(cfg_p)
         keep2 = stage(engp, cfg_p, scenes)
         for _ in range(5):
@@ -658,20 +728,16 @@ def main():
         cl.close()
 
     if rank == 0:
-        # Per-kernel durations come from an INSTRUMENTED pass: every launch carries two events stamped with the dispatch's begin / end,
-        # and a dispatch that signals completion also ends with a system-scope release, which the same kernel inside the plain
-        # pipeline does not pay (rocprofv3's kernel trace of the timed region: k_frame_visual 18.4 us against 20.0 us instrumented).
-        # avg_us = the instrumented durations rescaled so that one step's launches add up to the UN-instrumented per-step time (the
-        # slope between K-step and 4K-step regions: dependent launches back to back on one stream); avg_us_instrumented = raw.
+        # Per-kernel durations come from an INSTRUMENTED pass: every launch carries two events stamped with the dispatch's own begin /
+        # end (hipExtLaunchKernelGGL) — the clock rocprofv3's kernel trace reads.  avg_us = those durations AS MEASURED (a dispatch that
+        # signals completion also ends with a system-scope release the same kernel inside the plain pipeline does not pay: ~1.5 us on
+        # the fused first phase, so one step's launches may add up to slightly MORE than ms_per_step); avg_us_rocprof = the average
+        # rocprofv3 --kernel-trace --stats reported for the same command, from the summary committed under profiles/ (None when there is none).
         raw = {k: 1e3 * ms / max(n, 1) for k, (n, ms) in prof.items()}
-        step_instr = sum(raw[k] * prof[k][0] / float(args.profile_iters) for k in raw)
-        scale = min(1.0, (1e6 * step_s) / step_instr) if step_instr > 0 else 1.0  # both in microseconds per step
-        if "k_visual_raw" in raw:
-            scale = 1.0  # k_frame runs BESIDE the contraction (no barrier bit): the launches of a step do not add up to the step time
-        kern = {k: {"launches": int(prof[k][0]), "avg_us": raw[k] * scale, "avg_us_instrumented": raw[k]} for k in raw}
+        rp = rocprof_stats(args.workload)
+        kern = {k: {"launches": int(prof[k][0]), "avg_us": raw[k], "avg_us_rocprof": rp.get(k)} for k in raw}
         gpu_kernels = {k: v for k, v in kern.items() if k != "d2h_results"}
         visual = facade is None and cfg.visual_kind != abi.SA_VIS_NONE
-        f16 = facade is None and bool(cfg.flags & abi.SA_FLAG_F16_SPLIT)
         per_step = lambda k: prof[k][0] / float(args.profile_iters)  # launches of kernel k per step
         # ---- algorithmic work per launch, stated in DESIGN.md section 4 ----
         models = {}
@@ -706,11 +772,8 @@ def main():
                         "peak_note": "f32 vector peak (the same 157.3 TFLOP/s as the f32 matrix cores); sub + mul + add per element, 2 of 3 fuse"}
             elif bound == "mfma":
                 a = per_launch / dur_s / 1e12
-                mfma_peak = MFMA_F16_PEAK_TFLOPS / 3.0 if f16 else MFMA_F32_PEAK_TFLOPS
-                roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": a / mfma_peak, "traffic": None}
-                if f16:
-                    roof["peak_note"] = "f16 MFMA dense peak / 3: the f16-split contraction issues three f16 products per algorithmic product"
+                roof = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": a / MFMA_F32_PEAK_TFLOPS, "traffic": None}
             else:
                 a = per_launch / dur_s / 1e9
                 roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -733,7 +796,7 @@ def main():
             if k in kern and kern[k]["avg_us"] > 0:
                 per_launch = amount / per_step(k)
                 rate = per_launch / (kern[k]["avg_us"] * 1e-6)
-                mp = MFMA_F16_PEAK_TFLOPS / 3.0 if f16 else MFMA_F32_PEAK_TFLOPS
+                mp = MFMA_F32_PEAK_TFLOPS
                 kern[k]["roofline_frac"] = rate / 1e12 / mp if bound == "mfma" else rate / 1e12 / VALU_F32_PEAK_TFLOPS if bound == "valu" else rate / 1e9 / HBM_PEAK_GBS
         # the positional tiles' f64 vector work (they run inside k_frame, or inside k_frame_visual beside the contraction)
         pk = "k_frame" if "k_frame" in kern else ("k_frame_visual" if "k_frame_visual" in kern else None)
@@ -755,7 +818,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16-split operands (22 bit), f32 accumulate — NOT f32 arithmetic" if f16 else "f32",
+            "dtype": "f32",
             "data": "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
             "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "pairs_per_step_per_gpu": cells,
                        "parallelism": f"scene-sharded x{world}, no data-path collective"},
@@ -781,6 +844,11 @@ def main():
             ans = oracle_answers(cfg, scenes)
             same = np.concatenate([(g[0] == a[0]) & (g[1] == a[1]) for g, a in zip(got, ans)])
             out["match_vs_oracle"] = float(same.mean())
+        if world == 1 and facade is None and args.workload in ("giant", "bigpile", "bigcrowd", "sd"):
+            try:
+                out["cpu_solve_only"] = cpu_solve_only(cfg, scenes)
+            except Exception as ex:
+                out["cpu_solve_only"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1 and facade is None:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, scenes)
             try:

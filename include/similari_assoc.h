@@ -117,8 +117,6 @@ typedef struct sa_config {
  * feature length a multiple of 32) — one dependent launch less per frame — and otherwise runs them as two launches. */
 #define SA_FLAG_FUSED_FRAME 0x10u     /* ask for the heterogeneous launch explicitly (same as the default) */
 #define SA_FLAG_SEPARATE_FRAME 0x20u  /* always two launches: the contraction runs as a kernel of its own (per-kernel measurements) */
-#define SA_FLAG_F16_SPLIT 0x40u      /* cosine contraction with f16-split operands on the f16 matrix cores (22-bit operands, f32 accumulate:
-                                         |error| < 1e-6 on a cosine, several times the f32 rate; NOT f32 arithmetic — opt-in) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */
 #define SA_FLAG_TAP 0x80u           /* parity tests: the assignment tail copies out what the frame's OWN launches produced — the BestFit vote
                                        words of the first phase and the edge counts of the positional tiles — before it consumes them, for
@@ -305,6 +303,9 @@ int sa_tap_dims(sa_engine* e, uint32_t slot, uint32_t* n, uint32_t* t, uint32_t*
 int sa_tap_positional(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_visual(sa_engine* e, uint32_t slot, float* out);
 int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out);
+/* The polygons the IoU cells clip against: 4 f64 vertices (x, y) per row of the scene's track table, in sa_tracks_order order
+ * (Polygon::from(&Universal2DBox), bbox.rs:287-330).  *out_rows = rows of the table; written when cap_rows >= that. */
+int sa_tap_track_polygons(sa_engine* e, uint64_t scene_id, double* out, uint32_t cap_rows, uint32_t* out_rows);
 /* What the frame's own (timed) launches produced, as opposed to the matrices above, which the taps recompute on demand.  Engines created
  * with SA_FLAG_TAP only (SA_ERR_STATE otherwise).
  *   sa_tap_votes: the BestFit vote (track/voting/best.rs:52-128) as the first phase reduced it — per candidate its best track

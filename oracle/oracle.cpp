@@ -178,7 +178,11 @@ void or_vertices(const sa_box* b, double o[8]) {
   double angle = (double)opt_angle(b);
   double height = (double)b->height;
   double aspect = (double)b->aspect;
-  double c = std::cos(angle), s = std::sin(angle);
+  // angle.cos() and angle.sin() of ONE value: LLVM lowers the pair to a single sincos libcall on x86_64-unknown-linux-gnu (and gcc
+  // does the same merge here at -O2 and above); spelled out so that the restatement does not depend on an optimisation pass —
+  // glibc's sincos and its separate cos / sin differ in the last bit for about one angle in a thousand
+  double c, s;
+  ::sincos(angle, &s, &c);
   double half_width = height * aspect / 2.0;
   double half_height = height / 2.0;
   double r1x = -half_width * c - half_height * s;

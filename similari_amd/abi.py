@@ -36,7 +36,6 @@ SA_FLAG_PROFILE = 0x2
 SA_FLAG_GRAPH = 0x8
 SA_FLAG_FUSED_FRAME = 0x10
 SA_FLAG_SEPARATE_FRAME = 0x20
-SA_FLAG_F16_SPLIT = 0x40
 SA_FLAG_TAP = 0x80
 
 
@@ -385,6 +384,7 @@ PROTOTYPES = {
     "sa_tap_positional": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_visual": (C.c_int, [ENGINE, u32, P(C.c_float)]),
     "sa_tap_quantised": (C.c_int, [ENGINE, u32, P(C.c_int64)]),
+    "sa_tap_track_polygons": (C.c_int, [ENGINE, u64, f64p, u32, P(u32)]),
     "sa_tap_votes": (C.c_int, [ENGINE, u32, f64p, P(i32), f64p, P(i32), P(i32)]),
     "sa_tap_edges": (C.c_int, [ENGINE, u32, P(u32), u32, P(u32), P(C.c_int64), P(u32)]),
     "sa_profile_enable": (C.c_int, [ENGINE, C.c_int]),

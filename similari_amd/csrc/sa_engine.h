@@ -179,15 +179,6 @@ extern thread_local hipEvent_t sa_done_event;
       sa_done_event = nullptr;                                                                                 \
     } else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                      \
   } while (0)
-// The same with hipExtAnyOrderLaunch: documented as "the dispatch does not wait for the packets queued before it on the stream",
-// which would let two independent kernels of one frame run side by side without a second stream and its two cross-stream event
-// waits (those cost more than the overlap gains: SA_FLAG_FORK, +5.7 us).  Measured on this stack (ROCm 7.2, MI355X): the second
-// dispatch still starts when the first ends.  Kept for SA_FIRST_PHASE=any_order (measurement).
-#define SA_LAUNCH_ANY_ORDER(kern, grid, block, shmem, st, ...)                                                 \
-  do {                                                                                                         \
-    hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sa_prof_start, sa_prof_stop, hipExtAnyOrderLaunch, __VA_ARGS__); \
-  } while (0)
-
 // ---- launchers (sa_kernels.hip / sa_gemm.hip).  All enqueue on `st` and return the launch status. ----
 
 struct PrepTrackArgs {
@@ -225,16 +216,12 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
 // prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame), 2 = preparation blocks only (what a lean
 // frame left out, on demand: sa_tracks_apply, the visual tap)
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
-                           hipStream_t st, bool any_order = false, int prep = 1);
-// the contraction of a small VisualSORT frame on the RAW uploaded rows (needs nothing the preparation blocks produce), so that
-// sa_launch_frame(any_order) can run beside it; hipErrorNotSupported = not applicable (same conditions as sa_launch_frame_visual)
-hipError_t sa_launch_visual_raw(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                const SaParams& p, hipStream_t st, bool partials);
+                           hipStream_t st, int prep = 1);
 hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices, hipStream_t st);
 hipError_t sa_launch_positional_dense(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                       const SaParams& p, hipStream_t st);
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxTK,
-                            const SaParams& p, hipStream_t st, bool partials, bool f16_split);
+                            const SaParams& p, hipStream_t st, bool partials);
 // heterogeneous first phase of a VisualSORT frame (contraction tiles + positional tiles + preparation blocks in one launch);
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
@@ -288,6 +275,13 @@ struct BankArgs {
   float minimal_area, q_collect, own_collect;
 };
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st);
+// oriented boxes after sa_launch_apply: the host's libm cos / sin of a refreshed row's angle -> its polygon
+struct SaPolyFix {
+  uint32_t row, pad;
+  float xc, yc, aspect, height;
+  double c, s;
+};
+hipError_t sa_launch_apply_polygons(const SaPolyFix* fix, uint32_t n, double* verts, hipStream_t st);
 // NMS: mask[n][ceil(n/64)] words + keep[n] flags for rank-sorted boxes (at most SA_NMS_MAX)
 #define SA_NMS_MAX 16384u
 hipError_t sa_launch_nms(const BoxRaw* raw, uint32_t n, float thr, uint64_t* mask, uint8_t* keep, hipStream_t st);

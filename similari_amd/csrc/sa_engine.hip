@@ -21,11 +21,11 @@ thread_local std::string g_create_error;
 
 enum KernelId {
   KID_FRAME = 0, KID_FRAME_VISUAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
-  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_VISUAL_RAW, KID_ASSIGN_DENSE, KID_COUNT
+  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_ASSIGN_DENSE, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
     "k_frame", "k_frame_visual", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
-    "k_assign_label", "k_assign_solve", "d2h_results", "k_visual_raw", "k_assign_dense"};
+    "k_assign_label", "k_assign_solve", "d2h_results", "k_assign_dense"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -71,8 +71,8 @@ struct Slot {  // one scene of a request set
   DevBuf lab, cwin, big_rows, dq, big_bcol, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
-  HostBuf h_apply, h_pred;
-  void *d_pred = nullptr, *d_apply = nullptr;  // device views of the two
+  HostBuf h_apply, h_pred, h_fix;
+  void *d_pred = nullptr, *d_apply = nullptr, *d_fix = nullptr;  // device views of the three
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   bool ran = false;
@@ -126,18 +126,13 @@ struct sa_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t stream2 = nullptr;  // side stream: the positional cost kernel runs beside the feature contraction
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t copy_stream = nullptr;  // sa_pipe_*: H2D of the next request set beside the kernels of the current one
-  hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // SA_INGEST=sdma4: a large block split over four SDMA engines
-  hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
   Bank banks[SA_BANKS];
   Bank* B = &banks[0];               // the bank the synchronous entry points, the taps and sa_tracks_apply refer to
   uint64_t B_ticket = 0;             // != 0: B was bound by sa_pipe_wait(ticket); slot numbers mean THAT ticket's scenes for as long as its bank
                                      // has not been recycled by a later sa_pipe_stage (bound_bank_ok)
   uint64_t next_ticket = 1;
   uint32_t K = 1, D = 0, Dp = 0;
-  bool f16_split = false;               // SA_FLAG_F16_SPLIT: the contraction's operands as f16 pairs (separate launches only)
   bool bf_words_euclid = false;         // euclidean, bank depth 1: k_visual_euclid can reduce the vote into the vote words (frames up to 1024 x 1024)
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
@@ -221,40 +216,9 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
     if (_r != SA_OK) return _r;  \
   } while (0)
 
-// Waits for a stream.  hipStreamSynchronize parks the calling thread on an interrupt after a short spin, and the wake-up costs ~60 us on
-// this stack — three times the kernels of a SORT frame: a frame-latency API polls instead (hipStreamQuery, about a microsecond a
-// call) for as long as a frame can plausibly take, and only then parks.  SA_SYNC=block: always park (measurements).
-hipError_t stream_wait(hipStream_t st) {
-  static const bool park = getenv("SA_SYNC") && !strcmp(getenv("SA_SYNC"), "block");
-  if (!park) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0;; ++spins) {
-      const hipError_t q = hipStreamQuery(st);
-      if (q != hipErrorNotReady) return q;
-      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-    }
-  }
-  return hipStreamSynchronize(st);
-}
-
-hipError_t event_wait(hipEvent_t ev) {  // the same for an event (sa_pipe_wait)
-  static const bool park = getenv("SA_SYNC") && !strcmp(getenv("SA_SYNC"), "block");
-  if (!park) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0;; ++spins) {
-      const hipError_t q = hipEventQuery(ev);
-      if (q != hipErrorNotReady) return q;
-      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-    }
-  }
-  return hipEventSynchronize(ev);
-}
-
 int engine_sync(sa_engine* e) {
-  for (int k = 0; k < 3; ++k)
-    if (e->aux_stream[k]) HIPCHK(e, hipStreamSynchronize(e->aux_stream[k]));
-  if (e->copy_stream) HIPCHK(e, stream_wait(e->copy_stream));
-  HIPCHK(e, stream_wait(e->stream));
+  if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
   for (auto& g : e->garbage) hipFree(g.p);
   e->garbage.clear();
   e->synced = true;
@@ -275,7 +239,7 @@ int engine_sync(sa_engine* e) {
 // The compute stream alone (sa_tracks_apply: its kernels and the mapped results are all on it): the copy stream may be busy with the
 // ingest of the NEXT request set — that is the overlap the pipelined entry points exist for — and is left alone.
 int compute_sync(sa_engine* e) {
-  HIPCHK(e, stream_wait(e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
   return SA_OK;
 }
 
@@ -330,14 +294,18 @@ int check_box(sa_engine* e, const sa_box& b, const char* what, uint32_t i) {
   return SA_OK;
 }
 
-// libm cos/sin of (angle as f64) on the host: Rust's f64::cos/sin resolve to the same libm, and the
+// cos / sin of (angle as f64) from the host's libm, through ONE sincos() call: Polygon::from (bbox.rs:287-330) takes angle.cos() and
+// angle.sin() of the same value, which LLVM (rustc, x86_64-unknown-linux-gnu) lowers to a single sincos libcall (SelectionDAG merges an
+// FSIN / FCOS pair on one operand where the C library has sincos) — and glibc's sincos is NOT bit-identical to its separate cos and
+// sin (they differ in the last bit for about one angle in a thousand on this host: different fused-multiply-add variants).  gcc does
+// the same merge in the oracle; clang does not for plain libm calls (math-errno), so it is spelled out on both sides.  The
 // bit-exact IoU gate needs identical vertices.  Boxes without an angle use c = 1, s = 0.
 void fill_raw(BoxRaw* dst, const sa_box* src, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) {
     dst[i].box = src[i];
     double a = (double)(src[i].has_angle ? src[i].angle : 0.0f);
     if (a == 0.0) { dst[i].c = 1.0; dst[i].s = 0.0; }
-    else { dst[i].c = std::cos(a); dst[i].s = std::sin(a); }
+    else ::sincos(a, &dst[i].s, &dst[i].c);
   }
 }
 
@@ -553,36 +521,21 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   b->desc_off = desc_off;
   b->desc_last.swap(build);
   if (!b->uploaded) {
-    // SA_INGEST=sdma: hipMemcpyAsync per segment (one SDMA engine: 2 MB in 57 us); default: the ingest kernel (40 us), which needs
-    // the device mapping of every source and 16-byte alignment
-    static const bool sdma4 = getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4");
-    static const bool sdma = sdma4 || (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma"));
-    static const uint32_t blocks = getenv("SA_INGEST_BLOCKS") && atoi(getenv("SA_INGEST_BLOCKS")) > 0 ? (uint32_t)atoi(getenv("SA_INGEST_BLOCKS")) : 24u;
+    // the ingest kernel (the shader engines pull the pinned blocks through their device mapping: 2 MB in 40 us, against 57 for one
+    // hipMemcpyAsync on one SDMA engine) wherever source and destination allow 16-byte accesses, hipMemcpyAsync otherwise
     SaCopySegs segs;
     segs.n = 0;
     auto flush = [&](bool last = false) -> int {
       // the last launch of the upload carries the hand-over event as its own completion signal
-      static const bool own_event = getenv("SA_INGEST_EVENT") && !strcmp(getenv("SA_INGEST_EVENT"), "record");
-      const bool attach = last && done && !own_event && segs.n;
-      if (segs.n) HIPCHK(e, sa_launch_ingest(segs, blocks, st, attach ? done : nullptr));
+      const bool attach = last && done && segs.n;
+      if (segs.n) HIPCHK(e, sa_launch_ingest(segs, 24u, st, attach ? done : nullptr));
       if (attach && done_recorded) *done_recorded = true;
       segs.n = 0;
       return SA_OK;
     };
     auto move = [&](const void* src_host, const void* src_dev, void* dst, size_t bytes) -> int {
       if (!bytes) return SA_OK;
-      if (sdma4 && bytes >= (1u << 20) && e->aux_stream[0] && e->aux_stream[1] && e->aux_stream[2]) {
-        // four quarters on four streams (four SDMA engines: 2 MB in 39 us against 57 on one); `st` resumes when all have landed
-        const size_t q4 = (bytes / 4) & ~(size_t)255;
-        for (int k = 0; k < 3; ++k) {
-          HIPCHK(e, hipMemcpyAsync((char*)dst + (k + 1) * q4, (const char*)src_host + (k + 1) * q4, k == 2 ? bytes - 3 * q4 : q4, hipMemcpyHostToDevice, e->aux_stream[k]));
-          HIPCHK(e, hipEventRecord(e->aux_ev[k], e->aux_stream[k]));
-        }
-        HIPCHK(e, hipMemcpyAsync(dst, src_host, q4, hipMemcpyHostToDevice, st));
-        for (int k = 0; k < 3; ++k) HIPCHK(e, hipStreamWaitEvent(st, e->aux_ev[k], 0));
-        return SA_OK;
-      }
-      if (sdma || !src_dev || (((uintptr_t)src_dev | (uintptr_t)dst) & 15u)) {
+      if (!src_dev || (((uintptr_t)src_dev | (uintptr_t)dst) & 15u)) {
         HIPCHK(e, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, st));
         return SA_OK;
       }
@@ -619,7 +572,7 @@ int ensure_prepped(sa_engine* e, Bank* b) {
   }
   if (!need) return SA_OK;
   const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
-  HIPCHK(e, sa_launch_frame(ds, b->n_slots, maxN, maxT, e->visual ? 1 : 0, e->P, e->stream, false, 2));
+  HIPCHK(e, sa_launch_frame(ds, b->n_slots, maxN, maxT, e->visual ? 1 : 0, e->P, e->stream, 2));
   for (uint32_t i = 0; i < b->n_slots; ++i) b->slots[i]->prepped = true;
   e->synced = false;
   return SA_OK;
@@ -645,54 +598,38 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   SaParams Pt = P;                         // k_bestfit_tile: the words of deeper banks
   Pt.vote_words = b->words == 2 ? 1u : 0u;
   // First phase of a small VisualSORT frame (at most 1024 x 1024, feature length a multiple of 32): contraction tiles + positional
-  // tiles + frame-preparation blocks in ONE heterogeneous launch; otherwise positional tiles + preparation blocks, then the
-  // contraction.  SA_FIRST_PHASE=any_order (measurement): the contraction on the raw rows with two k-groups per tile as a kernel of
-  // its own and k_frame launched right behind it with hipExtAnyOrderLaunch — meant to run side by side on one stream; on this stack
-  // (ROCm 7.2) the second dispatch still starts when the first ends (rocprofv3 timeline), so it is not the default.
-  // SA_FIRST_PHASE=serial: k_frame, then the contraction (what SA_FLAG_SEPARATE_FRAME asks for per engine).
-  static const char* fp_env = getenv("SA_FIRST_PHASE");
-  const bool want_any_order = fp_env && !strcmp(fp_env, "any_order") && !((e->cfg.flags & SA_FLAG_GRAPH) && !e->profile);
-  const bool want_fused = !want_any_order;
-  const bool want_serial = fp_env && !strcmp(fp_env, "serial");
+  // tiles + frame-preparation blocks in ONE heterogeneous launch; otherwise (and with SA_FLAG_SEPARATE_FRAME) positional tiles +
+  // preparation blocks, then the contraction.
   // A LEAN frame leaves the preparation blocks out of its first phase (C2: 23.0 -> 20.8 us per frame).  They derive the candidates'
   // geometry / usability / padded features + norms and reset the state of the general tail and of the resolve kernel; the positional
   // tiles and the raw-row contraction derive what they need from the uploaded records themselves, the one-workgroup tail with vote
   // words keeps its state in LDS — so on such frames nothing reads them.  What does (sa_tracks_apply's feature-bank step, the
-  // visual tap) calls ensure_prepped first.
+  // visual tap) calls ensure_prepped first.  SA_LEAN=0 (tests): never lean.
   static const bool never_lean = getenv("SA_LEAN") && !strcmp(getenv("SA_LEAN"), "0");
   const bool lean_ok = small_tail && !never_lean && (!e->visual || words);
   bool with_prep = !lean_ok;
-  bool fused = false, side_by_side = false;
+  bool fused = false;
   bool all_feats = e->visual;
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
-  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->f16_split && all_feats && !want_serial) {
-    if (want_fused) {
-      ProfScope ps(e, KID_FRAME_VISUAL);
-      hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep);
-      if (fe == hipSuccess) fused = true;
-      else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
-      else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
-    } else {
-      ProfScope ps(e, KID_VISUAL_RAW);
-      hipError_t fe = sa_launch_visual_raw(ds, ns, maxN, maxT, e->K, e->D, P, st, partials);
-      if (fe == hipSuccess) side_by_side = true;
-      else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
-      else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
-    }
+  if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && all_feats) {
+    ProfScope ps(e, KID_FRAME_VISUAL);
+    hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep);
+    if (fe == hipSuccess) fused = true;
+    else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
+    else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
-  if (e->visual && !fused && !side_by_side) with_prep = true;  // the stand-alone contraction reads the padded features, norms and gates
-  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, side_by_side, with_prep ? 1 : 0)); }
+  if (e->visual && !fused) with_prep = true;  // the stand-alone contraction reads the padded features, norms and gates
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, with_prep ? 1 : 0)); }
   b->frame_with_prep = with_prep;
   b->frame_small_tail = small_tail;
   if (e->visual) {
-    if (!fused && !side_by_side) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials, e->f16_split)); }
+    if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials)); }
     if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
   // the frame's LAST launch carries the caller's completion event as its own completion signal (sa_pipe_launch), unless the frame is
   // being profiled (the launch then stamps the profile's events) or captured into a graph (the caller does not ask then)
-  static const bool done_by_marker = getenv("SA_DONE_EVENT") && !strcmp(getenv("SA_DONE_EVENT"), "record");
-  const bool attach = done && maxN && !e->profile && !done_by_marker;
+  const bool attach = done && maxN && !e->profile;
   hipError_t le;
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
@@ -907,7 +844,6 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   e->eu_rho = 5e-3f * std::sqrt((float)(e->Dp ? e->Dp : 32u));
   e->eu_mfma_ok = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->eu_rho < 0.3334f;
   e->profile = (cfg->flags & SA_FLAG_PROFILE) != 0;
-  e->f16_split = (cfg->flags & SA_FLAG_F16_SPLIT) != 0 && cfg->visual_kind == SA_VIS_COSINE;
   if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
   else {
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -945,25 +881,14 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   hipEventCreate(&e->ev_t1);
   {
     // the copy stream at the highest priority the device offers: its few ingest workgroups should be dispatched ahead of the
-    // compute stream's thousands, or the DMA of the next request set queues behind the current set's tiles (SA_COPY_PRIO=0: default priority)
+    // compute stream's thousands, or the DMA of the next request set queues behind the current set's tiles
     int lo = 0, hi = 0;
-    const bool prio = !(getenv("SA_COPY_PRIO") && atoi(getenv("SA_COPY_PRIO")) == 0);
-    if (!prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
     if (hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, hi) != hipSuccess) e->copy_stream = nullptr;
   }
-  if (getenv("SA_INGEST") && !strcmp(getenv("SA_INGEST"), "sdma4"))
-    for (int k = 0; k < 3; ++k) {
-      if (hipStreamCreateWithFlags(&e->aux_stream[k], hipStreamNonBlocking) != hipSuccess) e->aux_stream[k] = nullptr;
-      hipEventCreateWithFlags(&e->aux_ev[k], hipEventDisableTiming);
-    }
   for (Bank& bk : e->banks) {
     hipEventCreate(&bk.ev_staged);  // also handed to hipExtLaunchKernelGGL as the ingest dispatch's completion event
     hipEventCreate(&bk.ev_done);    // handed to hipExtLaunchKernelGGL as the completion event of a frame's last dispatch (enqueue_frame)
-  }
-  if (e->visual) {
-    if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) e->stream2 = nullptr;
-    hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   }
   *out = e;
   return SA_OK;
@@ -1001,6 +926,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->dq, &s->big_bcol, &s->dense})
         free_dev(*b);
       free_host(s->h_apply);
+      free_host(s->h_fix);
       free_host(s->h_pred);
       free_host(s->h_out);
       delete s;
@@ -1020,14 +946,7 @@ void sa_engine_destroy(sa_engine* e) {
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
   if (e->ev_t0) hipEventDestroy(e->ev_t0);
   if (e->ev_t1) hipEventDestroy(e->ev_t1);
-  if (e->ev_fork) hipEventDestroy(e->ev_fork);
-  if (e->ev_join) hipEventDestroy(e->ev_join);
-  if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
-  for (int k = 0; k < 3; ++k) {
-    if (e->aux_stream[k]) { hipStreamSynchronize(e->aux_stream[k]); hipStreamDestroy(e->aux_stream[k]); }
-    if (e->aux_ev[k]) hipEventDestroy(e->aux_ev[k]);
-  }
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1342,9 +1261,8 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   s->o_q = align_up(s->o_raw + (size_t)N * sizeof(BoxRaw), 256);
   s->o_own = align_up(s->o_q + (size_t)N * 4, 256);
   s->o_fp = align_up(s->o_own + (size_t)N * 4, 256);
-  // features on a boundary of their own (SA_FEAT_ALIGN, default 4 KB): the contraction streams them as 16-byte loads of Dp-float rows
-  static const size_t feat_align = getenv("SA_FEAT_ALIGN") ? (size_t)atol(getenv("SA_FEAT_ALIGN")) : 4096;
-  s->o_feat = align_up(s->o_fp + N, feat_align >= 256 ? feat_align : 256);
+  // features on a 4 KB boundary of their own: the contraction streams them as 16-byte loads of Dp-float rows
+  s->o_feat = align_up(s->o_fp + N, 4096);
   const size_t end = s->o_feat + ((s->has_feats && !s->feats_inplace && !s->feats_device) ? fbytes : 0);
   TRY(arena_reserve(e, b, end + 256));
   uint8_t* h = (uint8_t*)b->h_arena.p;
@@ -1486,12 +1404,10 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
   TRY(bank_prepare(e, b, &maxN, &maxT, false));  // sa_pipe_launch prepares again (the tables may change in between) and counts the frame
   // A request set without bulk (plain SORT, or features that are in device memory already: tens of KB) goes up on the COMPUTE stream, in
   // order in front of its kernels: the copy stream buys nothing there and its hand-over costs a barrier packet per frame
-  // (SA_SMALL_INGEST=copy_stream | inline: measurements).
-  static const char* small_env = getenv("SA_SMALL_INGEST");
   size_t moved = b->used;  // the arena, plus the feature rows the upload reads in place from a pinned block
   for (uint32_t i = 0; i < b->n_slots; ++i)
     if (b->slots[i]->feats_inplace) moved += (size_t)b->slots[i]->N * e->D * 4;
-  const bool small_inline = small_env ? small_env[0] == 'i' : moved <= (128u << 10);
+  const bool small_inline = moved <= (128u << 10);
   b->staged_inline = !e->copy_stream || small_inline;
   hipStream_t cs = b->staged_inline ? e->stream : e->copy_stream;
   if (b->staged_inline) {
@@ -1535,8 +1451,8 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
     return fail(e, SA_ERR_STATE, "ticket %llu has not been launched (or is unknown)", (unsigned long long)ticket);
   if (b->n_slots && !res) return fail(e, SA_ERR_BAD_ARG, "sa_pipe_wait: null result array");
   if (b->state == 2) {
-    hipError_t s = event_wait(b->ev_done);
-    if (s != hipSuccess) return fail(e, SA_ERR_HIP, "waiting for the ticket's completion event failed: %s", hipGetErrorString(s));
+    hipError_t s = hipEventSynchronize(b->ev_done);
+    if (s != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(s));
   }
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     const Slot* s = b->slots[i];
@@ -1652,6 +1568,33 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   if (e->B_ticket) TRY(compute_sync(e));  // pipelined: leave the copy stream (the next set's ingest) alone
   else TRY(engine_sync(e));
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
+  {
+    // Oriented boxes: the polygon of a refreshed row needs cos / sin of the predicted angle from THIS side's libm (fill_raw does the
+    // same for every box that is uploaded; the device's sincos is not bit-identical to it).  The predicted boxes are here already;
+    // (row, box, cos, sin) go back through mapped memory to a kernel queued behind the step — no wait: whatever reads the table
+    // next is ordered behind it on the stream.
+    const sa_box* pb = (const sa_box*)s->h_pred.p;
+    uint32_t nfix = 0;
+    for (uint32_t i = 0; i < n; ++i) nfix += (pb[i].has_angle && pb[i].angle != 0.0f) ? 1u : 0u;
+    if (nfix) {
+      void* before = s->h_fix.p;
+      TRY(host_ensure(e, s->h_fix, (size_t)nfix * sizeof(SaPolyFix)));
+      if (s->h_fix.p != before || !s->d_fix) HIPCHK(e, hipHostGetDevicePointer(&s->d_fix, s->h_fix.p, 0));
+      SaPolyFix* fx = (SaPolyFix*)s->h_fix.p;
+      uint32_t k = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (!(pb[i].has_angle && pb[i].angle != 0.0f)) continue;
+        const double ang = (double)pb[i].angle;
+        fx[k].row = winners[i] == 0 ? h_row[i] : (uint32_t)wcol[i];
+        fx[k].pad = 0;
+        fx[k].xc = pb[i].xc; fx[k].yc = pb[i].yc; fx[k].aspect = pb[i].aspect; fx[k].height = pb[i].height;
+        ::sincos(ang, &fx[k].s, &fx[k].c);  // as fill_raw
+        ++k;
+      }
+      HIPCHK(e, sa_launch_apply_polygons((const SaPolyFix*)s->d_fix, nfix, (double*)sc->verts.p, st));
+      e->synced = false;
+    }
+  }
   // host side of the table: the new rows
   for (uint32_t i = 0; i < n; ++i)
     if (winners[i] == 0) {
@@ -1867,7 +1810,7 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
     SaParams P = e->P;
     P.eu_mfma = e->B->eu_mfma ? 1u : 0u;  // the kernel the slot's descriptor (tile grid) was laid out for
     P.eu_rho = e->eu_rho;
-    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, P, e->stream, false, e->f16_split));
+    HIPCHK(e, sa_launch_visual((const SceneDev*)tmp.p, 1, s->N, s->T * e->K, P, e->stream, false));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     hipFree(tmp.p);
   }
@@ -1892,6 +1835,18 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipMemcpy(out, s->quant.p, cells * 8, hipMemcpyDeviceToHost));
   hipFree(tmp.p);
+  return SA_OK;
+}
+
+// The polygons of a scene's track table (f64 vertices, 8 per row in table order): what the IoU cells clip against.
+int sa_tap_track_polygons(sa_engine* e, uint64_t scene_id, double* out, uint32_t cap_rows, uint32_t* out_rows) {
+  if (!e || !out_rows) return fail(e, SA_ERR_BAD_ARG, "sa_tap_track_polygons: null argument");
+  SceneTable* sc = get_scene(e, scene_id, false);
+  *out_rows = sc ? sc->T : 0;
+  if (!sc || !sc->T || !out || cap_rows < sc->T) return SA_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(engine_sync(e));
+  HIPCHK(e, hipMemcpy(out, sc->verts.p, (size_t)sc->T * 64, hipMemcpyDeviceToHost));
   return SA_OK;
 }
 

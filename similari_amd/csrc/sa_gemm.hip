@@ -246,136 +246,6 @@ __device__ __forceinline__ void gemm_mainloop(gfloat_p A, gfloat_p B, uint32_t M
   SA_STAMP(tr, 2);
 }
 
-// ---- f16-split operands (SA_FLAG_F16_SPLIT) ---------------------------------------------------------------------
-// Every feature element is split, x * s = hi + lo / 2048 with hi, lo in f16 (22 bits of x; s = a power of two that brings the
-// row's norm to ~1, so that neither half leaves the f16 range), and the contraction runs as three products on the f16 matrix
-// cores — hi.hi into one f32 accumulator, hi.lo + lo.hi into a second that is scaled by 1/2048 at the end — at sixteen times the
-// rate of v_mfma_f32_32x32x2_f32.  Products of two 11-bit significands are exact in f32; what is lost against f32 operands is
-// the 2 bits below the split and the lo.lo term: < 1e-6 on a cosine (measured 4e-7 at K = 512, 9e-7 at K = 4096) against the
-// 1e-5 gate.  It is NOT f32 arithmetic, hence an option with its own dtype in the bench line.
-// The accumulators come back scaled by s_row * s_col; the caller feeds the equally scaled norms to the epilogue.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float sa_pow2_scale(float nrm) {  // power of two ~ 1 / sqrt(nrm); 1 for 0 / inf / NaN
-  if (!(nrm > 0.0f) || !(nrm < 3.0e38f)) return 1.0f;
-  int e;
-  frexpf(nrm, &e);
-  return ldexpf(1.0f, -(e >> 1));
-}
-// byte offset of 16-byte slot q (8 halves of k) of row r in a [rows][32 halves] tile.  A 64-byte row covers a quarter of the 64
-// banks and rows r, r + 4, r + 8, r + 12 share that quarter: the XOR with (r >> 2) & 3 gives those four rows four different
-// slots, so that the 16 rows a fragment read touches at a time cover all 64 banks (with (r >> 1) & 3 — the f32 tile's pattern,
-// whose rows are 128 bytes — rows r and r + 8 collided: SQ_LDS_BANK_CONFLICT a third of the LDS cycles)
-__device__ __forceinline__ uint32_t h2_slot(uint32_t r, uint32_t q) { return r * 64u + ((q ^ ((r >> 2) & 3u)) << 4); }
-template <int BM, int BN>
-__device__ __forceinline__ void gemm_mainloop_h2(gfloat_p A, gfloat_p B, const float SA_G* an, const float SA_G* bn, uint32_t M,
-                                                 uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0, float* lds_f,
-                                                 f32x16 (&acc)[BM / 64][BN / 64]) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256, L_CH = A_CH + B_CH;
-  constexpr uint32_t STAGE = (BM + BN) * 128u;  // bytes: A_hi | A_lo | B_hi | B_lo, 64 B per row each — the f32 stage's size
-  unsigned char* lds = (unsigned char*)lds_f;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = tid >> 6, wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
-  const uint32_t nchunks = Dp / BK;
-  uint32_t goff[L_CH], soff[L_CH];
-  float scl[L_CH];
-#pragma unroll
-  for (int r = 0; r < L_CH; ++r) {
-    const bool isA = r < A_CH;
-    const uint32_t c = tid + 256u * (isA ? r : r - A_CH), row = c >> 3, kc = c & 7u;
-    uint32_t gr = (isA ? m0 : n0) + row;
-    const uint32_t lim = isA ? M : Ncols;
-    gr = gr < lim ? gr : lim - 1;
-    goff[r] = gr * Dp + kc * 4u;
-    soff[r] = (isA ? 0u : (uint32_t)BM * 128u) + h2_slot(row, kc >> 1) + (kc & 1u) * 8u;  // hi part; lo part at + rows * 64
-    scl[r] = sa_pow2_scale(isA ? an[gr] : bn[gr]);
-  }
-  f32x4 rg[L_CH];
-  auto gload = [&](uint32_t k0) {
-#pragma unroll
-    for (int r = 0; r < L_CH; ++r) rg[r] = *(gf32x4_p)((r < A_CH ? A : B) + (size_t)(goff[r] + k0));
-  };
-  auto split_store = [&](uint32_t st) {
-    unsigned char* base = lds + st * STAGE;
-#pragma unroll
-    for (int r = 0; r < L_CH; ++r) {
-      // two elements per instruction where the ISA has it: packed f32 multiply / subtract, packed f32 -> f16 conversion.  (The
-      // split is the VALU cost of this kernel: with scalar conversions the main loop was VALU-bound, not matrix-core-bound.)
-      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-      f16x4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const f32x2 x = f32x2{rg[r][e], rg[r][e + 1]} * scl[r];
-        const f16x2 h = __builtin_convertvector(x, f16x2);
-        const f32x2 back = __builtin_convertvector(h, f32x2);
-        const f16x2 l = __builtin_convertvector((x - back) * 2048.0f, f16x2);
-        hi[e] = h[0]; hi[e + 1] = h[1];
-        lo[e] = l[0]; lo[e + 1] = l[1];
-      }
-      *(f16x4*)(base + soff[r]) = hi;
-      *(f16x4*)(base + soff[r] + (r < A_CH ? (uint32_t)BM : (uint32_t)BN) * 64u) = lo;
-    }
-  };
-  f32x16 accx[TM][TN];
-#pragma unroll
-  for (int m = 0; m < TM; ++m)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.f; accx[m][n][e] = 0.f; }
-  // One barrier per 32-deep chunk, between its two 16-deep k-steps (the f32 loop's arrangement, §3 item 7): the first k-step
-  // runs on fragments fetched during the previous iteration while this one splits and stores chunk c+1 and fetches the second
-  // k-step's fragments; after the barrier the second k-step runs while the first fragments of chunk c+1 and the global rows of
-  // chunk c+2 are fetched.
-  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-  auto frags = [&](int set, uint32_t st, uint32_t ks) {
-    const unsigned char* sA = lds + st * STAGE;
-    const unsigned char* sB = sA + (uint32_t)BM * 128u;
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const uint32_t o = h2_slot(wm * (BM / 2) + m * 32 + lr, 2 * ks + lh);
-      ah[set][m] = *(const f16x8*)(sA + o);
-      al[set][m] = *(const f16x8*)(sA + (uint32_t)BM * 64u + o);
-    }
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const uint32_t o = h2_slot(wn * (BN / 2) + n * 32 + lr, 2 * ks + lh);
-      bh[set][n] = *(const f16x8*)(sB + o);
-      bl[set][n] = *(const f16x8*)(sB + (uint32_t)BN * 64u + o);
-    }
-  };
-  auto mfmas = [&](int set) {
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bh[set][n], acc[m][n], 0, 0, 0);
-        accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bl[set][n], accx[m][n], 0, 0, 0);
-        accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][m], bh[set][n], accx[m][n], 0, 0, 0);
-      }
-  };
-  if (nchunks > 0) { gload(0); split_store(0); }
-  if (nchunks > 1) gload(BK);
-  __syncthreads();
-  if (nchunks > 0) frags(0, 0, 0);
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const uint32_t st = c & 1u;
-    if (c + 1 < nchunks) split_store(st ^ 1u);   // chunk c+1 (in registers) -> the other stage
-    frags(1, st, 1);
-    mfmas(0);
-    __syncthreads();
-    if (c + 2 < nchunks) gload((c + 2) * BK);    // chunk c+2 -> registers
-    if (c + 1 < nchunks) frags(0, st ^ 1u, 0);
-    mfmas(1);
-  }
-#pragma unroll
-  for (int m = 0; m < TM; ++m)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] += accx[m][n][e] * (1.0f / 2048.0f);
-}
-
 // Ring variant (KG == 0 in the kernel templates): ONE wave per SIMD, a 3-stage LDS ring, nothing left for a partner wave
 // to cover.  Used where a frame yields about one workgroup per CU (C2: 16 x 16 tiles of 64x64 on 256 CUs), so that the
 // k-group trick above would put the two waves of a SIMD behind the SAME barrier — they then stall together (measured:
@@ -650,9 +520,8 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
-template <int BM, int BN, int KGT, bool RAW, bool PART, bool H2 = false, bool EU = false>
+template <int BM, int BN, int KGT, bool RAW, bool PART, bool EU = false>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
-  static_assert(!(H2 && EU), "the f16-split operands are a cosine option");
   constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
@@ -663,7 +532,6 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   static_assert(!RAW || (TM == 1 && TN == 1 && KGT != 0), "raw mode: 64x64 tiles with k-groups");
-  static_assert(!H2 || (KGT == 1 && !RAW), "f16-split operands: one k-group, padded features with their norms");
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
@@ -692,7 +560,6 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       pre_us = usable ? 1.f : 0.f;
     } else {
       pre_na = S.c_fnorm[gi];
-      if constexpr (H2) { const float sc = sa_pow2_scale(pre_na); pre_na *= sc * sc; }  // the accumulators come back scaled alike
       pre_us = S.c_usable[gi] ? 1.f : 0.f;
       pre_g = sa_ldg(S.c_geo + gi);
     }
@@ -714,7 +581,6 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       const uint64_t te = S.t_epoch[t];
       col[n].g = sa_ldg(S.t_geo + t);
       col[n].nb = nb;
-      if constexpr (H2) { const float sc = sa_pow2_scale(nb); col[n].nb = nb * (sc * sc); }
       const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
       col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
       for (uint32_t i = 0; i < p.cons.n; ++i)
@@ -724,8 +590,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 
   f32x16 acc[TM][TN];
   float nsq = 0.f;
-  if constexpr (H2) gemm_mainloop_h2<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, S.c_fnorm, S.t_fnorm, N, TK, S.Dp, m0, n0, lds, acc);
-  else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
   else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
 
@@ -994,63 +859,14 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   SA_STAMP(tr, 5);
 }
 
-// Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin in launch order (block b -> XCD b % 8, observed;
-// MI355X_MICROARCH.md), every XCD has its own 4 MB L2, and the operands of a big frame (C5: 32 MB of candidates, 82 MB of bank)
-// are re-read by every tile that shares a row or a column panel.  With tiles numbered row by row, the ~100 tiles an XCD holds at
-// any time touch a dozen candidate panels and every bank panel: the L2s thrash and the contraction pulls ~9.7 TB/s through the
-// fabric (f16-split operands at C5: bound by exactly that).  Here each XCD gets a CONTIGUOUS stretch of a band order instead —
-// bands of `band` tile rows, walked column by column — so its tiles share one small set of candidate panels that stays in its L2
-// while the bank streams through once per band.
-__device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t band, uint32_t* bx, uint32_t* by) {
-  const uint32_t n = gx * gy, L = blockIdx.x + gx * blockIdx.y;
-  const uint32_t x = L & 7u, j = L >> 3;
-  const uint32_t i = x * (n >> 3) + (x < (n & 7u) ? x : (n & 7u)) + j;  // XCD x owns [start_x, start_x + count_x) of the band order
-  const uint32_t per_band = band * gx;
-  const uint32_t b = i / per_band, i2 = i - b * per_band;
-  const uint32_t rows = (b + 1) * band <= gy ? band : gy - b * band;       // the last band may be shorter
-  *bx = i2 / rows;
-  *by = b * band + i2 % rows;
-}
-// f16-split operands: the matrix instructions are short (32 cycles) and there is more load / store work between them than in the
-// f32 loop, so two waves per SIMD leave the matrix pipe idle 70 % of the time; the register cap buys a third.
-template <int BM, int BN, bool PART>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_visual_cosine_h2(const SceneDev* __restrict__ scenes, SaParams p,
-                                                                                                      uint32_t band) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
-  const SceneDev S = scenes[blockIdx.z];
-  uint32_t bx = blockIdx.x, by = blockIdx.y;
-  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
-  visual_cosine_tile<BM, BN, 1, false, PART, true>(S, p, bx, by, lds);
-}
-// the 128 x 128 tile holds two 64-register accumulator sets: no register cap to ask for (one wave per SIMD either way)
-template <bool PART>
-__global__ __launch_bounds__(256) void k_visual_cosine_h2_128(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (128 + 128) * BK];
-  const SceneDev S = scenes[blockIdx.z];
-  uint32_t bx = blockIdx.x, by = blockIdx.y;
-  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
-  visual_cosine_tile<128, 128, 1, false, PART, true>(S, p, bx, by, lds);
-}
-template <int BM, int BN, int KGT, bool PART = false, bool H2 = false, bool EU = false>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t band) {
+// (Tile order: row by row.  An XCD-aware band order — each XCD's L2 keeping one set of candidate panels — was measured at C5 with bands
+// of 1, 2 and 4 tile rows: no difference, the 114 MB working set sits in the 256 MB Infinity Cache and the fabric keeps up.)
+template <int BM, int BN, int KGT, bool PART = false, bool EU = false>
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  uint32_t bx = blockIdx.x, by = blockIdx.y;
-  if (band) xcd_tile(gridDim.x, gridDim.y, band, &bx, &by);
-  visual_cosine_tile<BM, BN, KGT, false, PART, H2, EU>(S, p, bx, by, lds);
-}
-
-// The contraction of a small frame on the RAW uploaded rows with two k-groups per 64 x 64 tile (512 threads, 64 KB: two waves per
-// SIMD), as a kernel of its own that needs nothing the preparation blocks produce: k_frame is then launched right behind it WITHOUT
-// the barrier bit (hipExtAnyOrderLaunch) and the two run side by side — the contraction keeps its two-k-group main loop (what the
-// heterogeneous launch below had to give up: every block of ONE launch shares one LDS size), the positional tiles and the
-// preparation blocks fill what it leaves, and there is still no second stream.
-template <int KG, bool PART, bool EU>
-__global__ __launch_bounds__(256 * KG) void k_visual_cosine_raw(const SceneDev* __restrict__ scenes, SaParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  visual_cosine_tile<64, 64, KG, true, PART, false, EU>(S, p, blockIdx.x, blockIdx.y, lds);
+  visual_cosine_tile<BM, BN, KGT, false, PART, EU>(S, p, blockIdx.x, blockIdx.y, lds);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1074,7 +890,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // frame with several rounds of contraction tiles do not queue behind them): C2 16.8 -> 17.5 us, three observations per track 40.9 -> 48.1.
   uint32_t b = blockIdx.x;
   if (b < gx * gy) {
-    visual_cosine_tile<64, 64, KG, true, PART, false, EU>(S, p, b % gx, b / gx, lds);
+    visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, b % gx, b / gx, lds);
     return;
   }
   b -= gx * gy;
@@ -1508,52 +1324,25 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
   // per launch, not per block — so only two blocks fit a CU, and even with two positional / preparation units side by side in
   // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
-  // against 22.7 (raising the contraction's wave priority changes nothing).  SA_FRAME_KG=2 selects that form for comparison.
-  static const bool one_group = !(getenv("SA_FRAME_KG") && atoi(getenv("SA_FRAME_KG")) == 2);
-  if (one_group) {
-    const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
-    if (eu) {
-      if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-      else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-    } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-    else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-  } else {
-    if (eu) return hipErrorNotSupported;  // the two-k-group form of the launch is a cosine measurement variant
-    const dim3 grid(gx * gy + cdiv(px * py + prep_blocks, 2), 1, ns);
-    if (partials) SA_LAUNCH((k_frame_visual<2, true>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-    else SA_LAUNCH((k_frame_visual<2, false>), grid, dim3(512), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-  }
-  return hipGetLastError();
-}
-
-hipError_t sa_launch_visual_raw(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                const SaParams& p, hipStream_t st, bool partials) {
-  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-  const uint32_t maxTK = maxT * K;
-  const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
-  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
-  const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
-  if (plan != 2 && plan != 4) return hipErrorNotSupported;
-  sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
-  const dim3 grid(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
+  // against 22.7 (raising the contraction's wave priority changes nothing).
+  const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
   if (eu) {
-    if (partials) SA_LAUNCH((k_visual_cosine_raw<2, true, true>), grid, dim3(512), 0, st, scenes, p);
-    else SA_LAUNCH((k_visual_cosine_raw<2, false, true>), grid, dim3(512), 0, st, scenes, p);
-  } else if (partials) SA_LAUNCH((k_visual_cosine_raw<2, true, false>), grid, dim3(512), 0, st, scenes, p);
-  else SA_LAUNCH((k_visual_cosine_raw<2, false, false>), grid, dim3(512), 0, st, scenes, p);
+    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
   return hipGetLastError();
 }
 
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
-                            hipStream_t st, bool partials, bool f16_split) {
+                            hipStream_t st, bool partials) {
   if (!maxN || !maxTK) return hipSuccess;
   sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
   if (p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma) {
     // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
     int plan = tile_plan(maxN, maxTK, ns, p.Dp);
     plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6) ? plan : 1;
-    const uint32_t band = 0;
-#define SA_EU_LAUNCH(BM_, BN_, PART_) SA_LAUNCH((k_visual_cosine<BM_, BN_, 1, PART_, false, true>), dim3(cdiv(maxTK, BN_), cdiv(maxN, BM_), ns), dim3(256), 0, st, scenes, p, band)
+#define SA_EU_LAUNCH(BM_, BN_, PART_) SA_LAUNCH((k_visual_cosine<BM_, BN_, 1, PART_, true>), dim3(cdiv(maxTK, BN_), cdiv(maxN, BM_), ns), dim3(256), 0, st, scenes, p)
     switch (plan) {
       case 0: if (partials) SA_EU_LAUNCH(128, 128, true); else SA_EU_LAUNCH(128, 128, false); break;
       case 5: if (partials) SA_EU_LAUNCH(64, 128, true); else SA_EU_LAUNCH(64, 128, false); break;
@@ -1566,51 +1355,26 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
     int plan = tile_plan(maxN, maxTK, ns, Dp);
-    // band height of the XCD-aware tile order (xcd_tile); 0 = tiles in row order.  Measured at C5 with bands of 1, 2 and 4 tile rows:
-    // no difference for either contraction (the working set sits in the Infinity Cache), so row order stays the default.
-    uint32_t band = 0;
-    {
-      static const char* env = getenv("SA_GEMM_BAND");
-      if (env) band = (uint32_t)atoi(env);
-    }
-    if (f16_split) {  // one k-group per tile; the k-group and ring plans run as the plain plan of their tile size
-      const dim3 g128x128(cdiv(maxTK, 128), cdiv(maxN, 128), ns), g64x128(cdiv(maxTK, 128), cdiv(maxN, 64), ns),
-          g128x64(cdiv(maxTK, 64), cdiv(maxN, 128), ns), g64x64(cdiv(maxTK, 64), cdiv(maxN, 64), ns);
-      if (plan == 0 || plan == 8) {
-        if (partials) SA_LAUNCH((k_visual_cosine_h2_128<true>), g128x128, dim3(256), 0, st, scenes, p, band);
-        else SA_LAUNCH((k_visual_cosine_h2_128<false>), g128x128, dim3(256), 0, st, scenes, p, band);
-      } else if (plan == 5) {
-        if (partials) SA_LAUNCH((k_visual_cosine_h2<64, 128, true>), g64x128, dim3(256), 0, st, scenes, p, band);
-        else SA_LAUNCH((k_visual_cosine_h2<64, 128, false>), g64x128, dim3(256), 0, st, scenes, p, band);
-      } else if (plan == 6) {
-        if (partials) SA_LAUNCH((k_visual_cosine_h2<128, 64, true>), g128x64, dim3(256), 0, st, scenes, p, band);
-        else SA_LAUNCH((k_visual_cosine_h2<128, 64, false>), g128x64, dim3(256), 0, st, scenes, p, band);
-      } else {
-        if (partials) SA_LAUNCH((k_visual_cosine_h2<64, 64, true>), g64x64, dim3(256), 0, st, scenes, p, band);
-        else SA_LAUNCH((k_visual_cosine_h2<64, 64, false>), g64x64, dim3(256), 0, st, scenes, p, band);
-      }
-      return hipGetLastError();
-    }
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {
-        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
-        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
-        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
-        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p, band); break;
-        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
+        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
+        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
       }
       return hipGetLastError();
     }
     switch (plan) {
-      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
-      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
-      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
-      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
-      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p, band); break;
-      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p, band); break;
-      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p, band); break;
-      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p, band); break;
+      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
+      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
+      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
+      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
     }
   } else {
     SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, EU_BN), cdiv(maxN, EU_BM), ns), dim3(EU_THREADS), 0, st, scenes, p);

@@ -1174,10 +1174,10 @@ hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uin
 }
 // First launch of a frame: positional tiles + frame-preparation blocks (see k_frame).
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
-                           hipStream_t st, bool any_order, int prep) {
+                           hipStream_t st, int prep) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-  static const char* wide_env = getenv("SA_POS_WIDE");  // measurements: 0 / 1 force the narrow / wide positional tiles
-  const bool wide = wide_env ? wide_env[0] == '1' : (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
+  // wide (16 x 256) positional tiles when the frame still gives at least one block per CU that way
+  const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
   const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
@@ -1186,10 +1186,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   if (prep == 0) prep_blocks = 0;
   if (!pos_rows && !prep_blocks) return hipSuccess;
   const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
-  if (any_order) {  // beside the contraction launched just before (enqueue_frame): small frames, one-workgroup tail
-    if (wide) SA_LAUNCH_ANY_ORDER((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
-    else SA_LAUNCH_ANY_ORDER((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
-  } else if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
+  if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
   else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
   else if (uni) SA_LAUNCH((k_frame<1, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
   else SA_LAUNCH((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
@@ -1264,13 +1261,9 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     }
     default:
       sa_tail_trace_hook(st, ns);
-      {
-        // SA_COOP_G=16: quarter-wave groups (four components per wavefront side by side) instead of whole wavefronts — measurements
-        static const bool g16 = getenv("SA_COOP_G") && atoi(getenv("SA_COOP_G")) == 16;
-        if (stage == 8) { if (g16) SA_LAUNCH((k_assign_small<true, true, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
-        else if (p.visual_kind != SA_VIS_NONE) { if (g16) SA_LAUNCH((k_assign_small<true, false, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
-        else { if (g16) SA_LAUNCH((k_assign_small<false, false, 16>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes); }
-      }
+      if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
       break;
   }
   return hipGetLastError();

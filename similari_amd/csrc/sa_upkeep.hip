@@ -8,8 +8,10 @@
 // With host upkeep (sa_tracks_upsert) that state crosses PCIe twice per frame; here it never leaves HBM: the winners are
 // already on the device (SceneDev::win_col), the candidates' boxes and padded features too.  Two small kernels, O(N).
 // The arithmetic is the shared header sa_kalman.h — the same source the host facade compiles — so the Kalman state is
-// bit-identical to the host path; the one exception is the polygon of an ORIENTED box, whose cos/sin come from the device's
-// math library instead of the host's libm (<= 1 ulp apart; axis-aligned boxes are unaffected).
+// bit-identical to the host path.  The polygon of an ORIENTED box needs cos / sin of its angle from the HOST's libm (the reference's
+// f64::cos / sin resolve to it, and the device's math library differs from it in the last bit for about one angle in a thousand,
+// which the bit-exact IoU gate would see): k_apply_kalman writes the polygon of boxes without an angle, and sa_tracks_apply — which
+// has the predicted boxes on the host anyway — sends (row, cos, sin) of the others to k_apply_polygons, queued behind it.
 #include "sa_engine.h"
 #include "sa_kalman.h"
 
@@ -39,10 +41,9 @@ __global__ __launch_bounds__(64) void k_apply_kalman(ApplyArgs a, SaParams p) {
   g.r = sa_radius(pred.aspect, pred.height);
   g.hha = pred.height * pred.height * pred.aspect;
   a.geo[row] = g;
-  double c = 1.0, sn = 0.0;
-  const double ang = (double)(pred.has_angle ? pred.angle : 0.0f);
-  if (ang != 0.0) sincos(ang, &sn, &c);
-  sa_vertices(pred.xc, pred.yc, pred.aspect, pred.height, c, sn, a.verts + (size_t)row * 8);
+  // (a box with an angle: its polygon follows from the host's cos / sin, k_apply_polygons; until then — nothing reads the table in
+  // between — the row holds the axis-aligned one)
+  sa_vertices(pred.xc, pred.yc, pred.aspect, pred.height, 1.0, 0.0, a.verts + (size_t)row * 8);
   a.t_epoch[row] = a.epoch;
   if (!merged) a.t_ids[row] = a.new_ids[i];
   float mean5[5], cov25[25];
@@ -52,6 +53,20 @@ __global__ __launch_bounds__(64) void k_apply_kalman(ApplyArgs a, SaParams p) {
   }
   sa_maha_prepare(p.kf_position_weight, mean5, cov25, a.maha + (size_t)row * 20);
   a.out_pred[i] = pred;
+}
+
+// Polygons of the oriented boxes among the rows k_apply_kalman refreshed: cos / sin from the host's libm (sa_tracks_apply), geometry
+// from the row itself (height and aspect recovered would not be exact: the host sends the box).
+__global__ void k_apply_polygons(const SaPolyFix* __restrict__ fix, uint32_t n, double* __restrict__ verts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SaPolyFix f = fix[i];
+  sa_vertices(f.xc, f.yc, f.aspect, f.height, f.c, f.s, verts + (size_t)f.row * 8);
+}
+hipError_t sa_launch_apply_polygons(const SaPolyFix* fix, uint32_t n, double* verts, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_apply_polygons, dim3(cdiv(n, 256)), dim3(256), 0, st, fix, n, verts);
+  return hipGetLastError();
 }
 
 // One workgroup per candidate: the destination track's feature bank after optimize_observations.

@@ -226,6 +226,14 @@ class Engine:
         self._chk(self.lib.sa_tap_quantised(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 
+    def tap_track_polygons(self, scene: int) -> np.ndarray:
+        """The f64 polygons of the scene's track table, [T, 4, 2] in table order."""
+        t = self.count(scene)
+        out = np.zeros((max(t, 1), 4, 2), np.float64)
+        rows = C.c_uint32()
+        self._chk(self.lib.sa_tap_track_polygons(self.h, scene, out.ctypes.data_as(C.POINTER(C.c_double)), t, C.byref(rows)))
+        return out[:t]
+
     def tap_votes(self, slot: int = 0):
         """The BestFit vote as the frame's own first phase reduced it (engines created with SA_FLAG_TAP): (row_w, row_idx, col_w,
         col_idx, kind); kind 1 = lightest visual weight per row / column, 2 = heaviest group weight W."""

@@ -18,7 +18,8 @@ void prep(const sa_box& b, sa_geo* g, double* verts) {
   g->r = sa_radius(b.aspect, b.height);
   g->hha = b.height * b.height * b.aspect;
   double a = (double)(b.has_angle ? b.angle : 0.0f);
-  double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+  double c = 1.0, s = 0.0;
+  if (a != 0.0) ::sincos(a, &s, &c);  // as the engine's fill_raw and the oracle's or_vertices
   sa_vertices(b.xc, b.yc, b.aspect, b.height, c, s, verts);
 }
 sa_constraints make_cons(const sa_config* cfg) {
@@ -361,7 +362,8 @@ int emu_clip_is_empty(const sa_box* cand, const sa_box* track) {
   double* vs[2] = {cv, tv};
   for (int k = 0; k < 2; ++k) {
     double a = (double)(bs[k]->has_angle ? bs[k]->angle : 0.0f);
-    double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+    double c = 1.0, s = 0.0;
+    if (a != 0.0) ::sincos(a, &s, &c);
     sa_vertices(bs[k]->xc, bs[k]->yc, bs[k]->aspect, bs[k]->height, c, s, vs[k]);
   }
   return sa_clip_is_empty(cv, tv) ? 1 : 0;
@@ -375,7 +377,8 @@ int emu_own_areas(uint32_t n, const sa_box* boxes, float* out_share, uint32_t ma
   for (uint32_t i = 0; i < n; ++i) {
     const sa_box& b = boxes[i];
     double a = (double)(b.has_angle ? b.angle : 0.0f);
-    double c = a == 0.0 ? 1.0 : std::cos(a), s = a == 0.0 ? 0.0 : std::sin(a);
+    double c = 1.0, s = 0.0;
+    if (a != 0.0) ::sincos(a, &s, &c);
     sa_vertices(b.xc, b.yc, b.aspect, b.height, c, s, &verts[(size_t)i * 8]);
     geo[i].xc = b.xc; geo[i].yc = b.yc; geo[i].r = sa_radius(b.aspect, b.height); geo[i].hha = 0.f;
   }

@@ -236,23 +236,6 @@ def test_detection_features_read_in_place_from_device_memory():
     assert r.returncode == 0 and "DEVICE-FEATURES-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("env", [{"SA_DONE_EVENT": "record"}, {"SA_SMALL_INGEST": "copy_stream"}, {"SA_SMALL_INGEST": "inline"},
-                                 {"SA_INGEST": "sdma"}])
-def test_pipeline_variants_match_the_oracle_too(env):
-    """The measured alternatives of the ticket path: SA_DONE_EVENT=record (a marker packet behind the frame's last kernel instead of the
-    completion event riding on that dispatch), SA_SMALL_INGEST=copy_stream | inline (request sets without bulk always / never on the
-    copy stream; the default rule sends up to 128 KB inline), SA_INGEST=sdma (hipMemcpyAsync instead of the ingest kernel).  The same
-    pipelined tests, the same oracle."""
-    import os
-    import subprocess
-    import sys
-
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_pipelined_tickets or test_pipelined_tracker_loop or test_associate_batch_matches"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, str(env) + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_a_recycled_ticket_is_refused_not_misread():
     """sa_pipe_wait binds the slot numbers of sa_tracks_apply / sa_batch_fetch / the taps to the waited ticket's scenes.  Staging more
     request sets afterwards may recycle that ticket's bank: the engine then refuses those calls (SA_ERR_STATE) instead of applying the

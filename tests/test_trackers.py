@@ -249,9 +249,54 @@ UPKEEP = pytest.mark.parametrize("backend", ["gpu", "gpu_dev"], ids=["host_upkee
 @UPKEEP
 @pytest.mark.parametrize("oriented", [False, True])
 def test_sort_iou_sequence_matches_oracle(oriented, backend):
-    # device upkeep + oriented boxes: the polygon's cos/sin come from the device's libm (<= 1 ulp from the host's); the f32
-    # IoU cells and every box still have to match the oracle exactly on this seeded sequence
+    # (device upkeep + oriented boxes: the polygons take cos / sin from the host's libm, test_device_upkeep_keeps_oriented_polygons_bit_exact)
     run_sort_sequence(IoU(0.3), oriented, seed=11 + oriented, backend=backend)
+
+
+@pytest.mark.gpu
+def test_device_upkeep_keeps_oriented_polygons_bit_exact():
+    """Oriented boxes under device-side upkeep, 220 frames: the polygon of every refreshed track row — what the next frame's IoU cells
+    clip against — must be Polygon::from(&predicted box) with the HOST libm's cos / sin (bbox.rs:287-330; the reference's f64::cos /
+    sin resolve to the same libm), bit for bit: the oracle's or_vertices of the predicted box the facade reports.  (Round 2 took the
+    device's sincos there: one angle in a thousand differs in the last bit, and the bit-exact IoU / quantised gates inherit it.)
+    The same frames through a host-upkeep facade (polygons from uploaded boxes) must give the same tracks, and its table the same
+    polygons."""
+    import ctypes as C
+
+    rng = np.random.default_rng(123)
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
+    g, h = make("gpu_dev", "sort", **kw), make("gpu", "sort", **kw)
+    L = O.lib()
+    try:
+        from similari_amd.engine import Engine
+        eg = Engine.borrowed(g.lib, g.lib.sa_tracker_engine(g.h))
+        eh = Engine.borrowed(h.lib, h.lib.sa_tracker_engine(h.h))
+        world = synth.dense_boxes(rng, 70, (1000.0, 800.0), True)
+        checked = 0
+        for f in range(220):
+            world = synth.jitter_boxes(rng, world, 2.0, angle_sigma=0.03)
+            if f % 40 == 39:
+                world["angle"] = rng.uniform(-3.1, 3.1, len(world)).astype(np.float32)   # every quadrant, large arguments too
+            det = world[rng.uniform(size=len(world)) > 0.1]
+            items = [(bx, None) for bx in boxes_to_u2d(det)]
+            rg, rh = g.predict(items), h.predict(items)
+            assert_tracks_equal(rg, rh)
+            order = {int(t): r for r, t in enumerate(eg.order(0))}
+            polys = eg.tap_track_polygons(0)
+            np.testing.assert_array_equal(eg.order(0), eh.order(0))
+            np.testing.assert_array_equal(polys, eh.tap_track_polygons(0))
+            for x in rg:
+                b = np.zeros(1, abi.BOX_DTYPE)
+                pb = x.predicted_bbox
+                b[0] = (pb.xc, pb.yc, pb.angle or 0.0, pb.aspect, pb.height, pb.confidence, 0 if pb.angle is None else 1, 0)
+                ref = np.zeros(8, np.float64)
+                L.or_vertices(O.box_ptr(b), ref.ctypes.data_as(C.POINTER(C.c_double)))
+                np.testing.assert_array_equal(polys[order[x.id]].ravel(), ref, err_msg=f"frame {f} track {x.id}")
+                checked += 1
+        assert checked > 10000
+    finally:
+        g.close()
+        h.close()
 
 
 @pytest.mark.gpu
