@@ -526,10 +526,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SA_BENCH_FORCE_DIST=1: join a process group even at world size 1 (the RCCL branch — communicator, scatter / gather of the
+    # dispatch pass — exercised on a one-GPU box: tests/test_gpu_cluster.py)
+    if world > 1 or os.environ.get("SA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("SA_BENCH_ONE_DEVICE"):
             # rehearsal of the multi-rank control flow on a one-GPU box: every rank drives device 0, collectives over gloo
             local_rank = 0

@@ -30,7 +30,8 @@ struct Shard {
   int device = 0;
   std::thread th;
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv;        // the worker sleeps here between tasks
+  std::condition_variable done_cv;   // callers sleep here while a task runs
   // mailbox (one task at a time per shard)
   std::atomic<int> pending{0};   // 1 = a task is waiting / running
   int kind = 0;                  // 1 associate_batch, 2 upsert, 3 remove, 9 quit
@@ -47,6 +48,7 @@ struct Shard {
 }  // namespace
 
 struct sa_cluster {
+  std::mutex api;  // one cluster call at a time: the shards' mailboxes (req / res / kind) are shared state
   std::vector<Shard*> shards;
   std::string err;
   std::vector<double> last_ms;
@@ -87,9 +89,14 @@ void worker(Shard* s) {
       std::unique_lock<std::mutex> lk(s->mu);
       s->cv.wait(lk, [&] { return s->pending.load(std::memory_order_acquire) != 0; });
     }
-    if (s->kind == 9) { s->pending.store(0, std::memory_order_release); return; }
-    run_task(s);
-    s->pending.store(0, std::memory_order_release);
+    const bool quit = s->kind == 9;
+    if (!quit) run_task(s);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);  // (under the lock: a caller that is about to sleep on the condition cannot miss this)
+      s->pending.store(0, std::memory_order_release);
+    }
+    s->done_cv.notify_all();
+    if (quit) return;
   }
 }
 
@@ -101,10 +108,13 @@ void post(Shard* s, int kind) {
   }
   s->cv.notify_one();
 }
+// The caller's side: a short spin (a shard's share of a batch is tens of microseconds), then sleep on the shard's condition — a host
+// core per cluster call is not burnt for the duration of every shard's GPU work, and the workers staging data keep theirs.
 void wait_done(Shard* s) {
-  int spins = 0;
-  while (s->pending.load(std::memory_order_acquire) != 0)
-    if (++spins > 2000) { std::this_thread::yield(); }
+  for (int spins = 0; spins < 4000; ++spins)
+    if (s->pending.load(std::memory_order_acquire) == 0) return;
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->done_cv.wait(lk, [&] { return s->pending.load(std::memory_order_acquire) == 0; });
 }
 
 // the share of every shard, in request order; map[i] = (shard, position inside its share)
@@ -184,6 +194,7 @@ sa_engine* sa_cluster_engine(sa_cluster* c, uint32_t shard) { return c && shard 
 
 int sa_cluster_tracks_upsert(sa_cluster* c, uint64_t scene_id, const sa_tracks* t) {
   if (!c || !t) return cfail(c, SA_ERR_BAD_ARG, "sa_cluster_tracks_upsert: null argument");
+  std::lock_guard<std::mutex> guard(c->api);
   Shard* s = c->shards[scene_id % c->shards.size()];
   wait_done(s);
   s->scene_id = scene_id;
@@ -195,6 +206,7 @@ int sa_cluster_tracks_upsert(sa_cluster* c, uint64_t scene_id, const sa_tracks* 
 
 int sa_cluster_tracks_remove(sa_cluster* c, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
   if (!c || (n && !ids)) return cfail(c, SA_ERR_BAD_ARG, "sa_cluster_tracks_remove: null argument");
+  std::lock_guard<std::mutex> guard(c->api);
   Shard* s = c->shards[scene_id % c->shards.size()];
   wait_done(s);
   s->scene_id = scene_id;
@@ -207,6 +219,7 @@ int sa_cluster_tracks_remove(sa_cluster* c, uint64_t scene_id, uint32_t n, const
 
 int sa_cluster_associate_batch(sa_cluster* c, uint32_t n_scenes, const sa_scene_request* req, const sa_scene_result* res) {
   if (!c || (n_scenes && (!req || !res))) return cfail(c, SA_ERR_BAD_ARG, "sa_cluster_associate_batch: null argument");
+  std::lock_guard<std::mutex> guard(c->api);
   Split sp;
   for (Shard* s : c->shards) wait_done(s);
   split(c, n_scenes, req, res, &sp);

@@ -258,14 +258,27 @@ class ShardedBatchTracker:
 # The tracker-level wrapper above moves Python objects; this one moves the arrays the C ABI takes.  One request set =
 # [(scene_id, epoch, boxes[N] (abi.BOX_DTYPE), feats[N, D] | None, quality[N] | None)]; the root packs every rank's share into one
 # byte buffer with numpy concatenations, ONE scatter delivers them, every rank hands its share to its engine as one
-# sa_associate_batch (one DMA + one set of launches), ONE gather returns ids[N] + votes[N] per scene.  Buffers have a fixed
-# capacity agreed at construction (collectives want equal shapes), so there is no size exchange per call.
-ASSOC_HEAD = 4  # int64 words: n_scenes, D, total N, flags (1 = shutdown)
+# sa_associate_batch (one set of launches), ONE gather returns ids[N] + votes[N] per scene.  Buffers have a fixed capacity agreed at
+# construction (collectives want equal shapes), so there is no size exchange per call.
+#
+# A share = a small PREFIX (head, scene table, boxes, qualities: kilobytes) and the BULK (the detections' feature rows), which starts
+# at a fixed offset.  On GPUs (RCCL) the share lands in device memory and the bulk STAYS there: the rank registers its receive buffer
+# with the engine once (sa_device_block_register) and hands the feature rows over as device pointers into it — only the prefix is
+# copied to the host (one small D2H), instead of the whole share going GPU -> host -> GPU.
+ASSOC_HEAD = 4  # int64 words: n_scenes, D, total N, flags (1 = shutdown, 4 = the root refused the request set: every rank raises)
+FLAG_SHUTDOWN, FLAG_ABORT = 1, 4
 
 
-def pack_share(items, D: int) -> np.ndarray:
+def prefix_bytes(max_scenes: int, capacity_rows: int) -> int:
+    """Where the feature rows of a share start: after head, table, boxes and qualities at full capacity, on a 256-byte boundary."""
+    from . import abi
+
+    return (32 + 32 * int(max_scenes) + int(capacity_rows) * (abi.BOX_DTYPE.itemsize + 4) + 255) // 256 * 256
+
+
+def pack_share(items, D: int, feat_base: int = 0, flags: int = 0) -> np.ndarray:
     """[(scene, epoch, boxes, feats, quality)] -> uint8 buffer: int64 head[4] | int64 table[n][4] (scene, epoch, N, has_feats |
-    has_quality << 1) | boxes | quality | feats."""
+    has_quality << 1) | boxes | quality | (zero padding up to feat_base) | feats."""
     from . import abi
 
     n = len(items)
@@ -273,16 +286,21 @@ def pack_share(items, D: int) -> np.ndarray:
     for i, (scene, epoch, boxes, feats, quality) in enumerate(items):
         table[i] = (scene, epoch, len(boxes), (1 if feats is not None else 0) | (2 if quality is not None else 0))
     total = int(table[:, 2].sum()) if n else 0
-    head = np.array([n, D, total, 0], np.int64)
+    head = np.array([n, D, total, flags], np.int64)
     parts = [head.view(np.uint8), table.reshape(-1).view(np.uint8)]
     parts += [np.ascontiguousarray(it[2], abi.BOX_DTYPE).view(np.uint8).reshape(-1) for it in items]
     parts += [np.ascontiguousarray(it[4], np.float32).view(np.uint8).reshape(-1) for it in items if it[4] is not None]
+    pre = sum(len(x) for x in parts)
+    if feat_base:
+        assert pre <= feat_base, f"prefix of {pre} B exceeds the agreed {feat_base} B (more scenes or rows than the capacity)"
+        parts.append(np.zeros(feat_base - pre, np.uint8))
     parts += [np.ascontiguousarray(it[3], np.float32).view(np.uint8).reshape(-1) for it in items if it[3] is not None]
     return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
 
 
-def unpack_share(buf: np.ndarray):
-    """Inverse of pack_share: views into `buf` (no copies)."""
+def unpack_share(buf: np.ndarray, feat_base: int = 0, bulk=None):
+    """Inverse of pack_share: views into `buf` (no copies).  bulk = None: the feature rows are views of buf as well; bulk = an
+    integer ADDRESS: buf holds the prefix only and the rows are returned as addresses bulk + offset (device memory)."""
     from . import abi
 
     n, D, total, flags = (int(x) for x in buf[:32].view(np.int64))
@@ -302,10 +320,12 @@ def unpack_share(buf: np.ndarray):
             o += 4 * c
         else:
             quality.append(None)
+    if feat_base:
+        o = feat_base
     for i, c in enumerate(counts):
         ft = None
         if table[i, 3] & 1:
-            ft = buf[o:o + 4 * c * D].view(np.float32).reshape(c, D)
+            ft = buf[o:o + 4 * c * D].view(np.float32).reshape(c, D) if bulk is None else int(bulk) + o
             o += 4 * c * D
         items.append((int(table[i, 0]), int(table[i, 1]), boxes[i], ft, quality[i]))
     return items, flags
@@ -313,10 +333,12 @@ def unpack_share(buf: np.ndarray):
 
 class ShardedAssociator:
     """SPMD wrapper around one Engine per rank.  Root: associate(request set) -> [(ids, votes)] in request order; other ranks:
-    serve_forever() (or associate(None) in lockstep).  `capacity_bytes` bounds one rank's share of a request set, `capacity_rows` its
-    detections.  Tracks are upserted per scene on the owning rank (upsert is a collective too: the root passes the arrays)."""
+    serve_forever() (or associate(None) in lockstep).  `capacity_bytes` bounds the FEATURE bytes of one rank's share of a request
+    set, `capacity_rows` its detections, `max_scenes` its scenes.  Tracks are upserted per scene on the owning rank (upsert is a
+    collective too: the root passes the arrays).  A request set that exceeds a capacity is refused on EVERY rank (the root validates
+    before any collective and sends the verdict with the shares): no rank is left waiting in a collective."""
 
-    def __init__(self, engine, capacity_bytes: int, capacity_rows: int, group=None, root: int = 0, device=None):
+    def __init__(self, engine, capacity_bytes: int, capacity_rows: int, group=None, root: int = 0, device=None, max_scenes: int = 64):
         import torch
         import torch.distributed as dist
 
@@ -326,37 +348,54 @@ class ShardedAssociator:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         self.device = device
-        self.cap_b = int(capacity_bytes) + 64
+        self.max_scenes = int(max_scenes)
         self.cap_r = int(capacity_rows)
+        self.feat_base = prefix_bytes(self.max_scenes, self.cap_r)
+        self.cap_b = self.feat_base + (int(capacity_bytes) + 255) // 256 * 256
         pin = device.type == "cuda"
-        self.h_req = torch.zeros(self.cap_b, dtype=torch.uint8, pin_memory=pin)       # this rank's share, host side
+        self.h_req = torch.zeros(self.feat_base if pin else self.cap_b, dtype=torch.uint8, pin_memory=pin)  # GPUs: the prefix only
         self.h_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, pin_memory=pin)   # ids[rows] (u64) then votes[rows]
         self.d_req = torch.zeros(self.cap_b, dtype=torch.uint8, device=device)
         self.d_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device)
+        # the bulk of a share is read where the collective put it: the receive buffer is a registered device block of the engine
+        self.in_place = pin and hasattr(engine, "register_device_block")
+        if self.in_place:
+            engine.register_device_block(self.d_req.data_ptr(), self.cap_b, device.index if device.index is not None else torch.cuda.current_device())
         if self.rank == root:
             self.h_all = torch.zeros((self.world, self.cap_b), dtype=torch.uint8, pin_memory=pin)
-            self.d_all = [torch.zeros(self.cap_b, dtype=torch.uint8, device=device) for _ in range(self.world)]
+            self.d_all = [torch.zeros(self.cap_b, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.world > 1 else None
             self.d_gather = [torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device) for _ in range(self.world)]
         self.last_local_ms = 0.0
 
-    def _run_share(self, buf: np.ndarray):
-        """This rank's share -> its engine (one sa_associate_batch) -> ids | votes packed into h_res."""
+    def close(self):
+        if self.in_place:
+            self.eng.unregister_device_block(self.d_req.data_ptr())
+            self.in_place = False
+
+    def _run_share(self, buf: np.ndarray, bulk=None):
+        """This rank's share -> its engine (one sa_associate_batch) -> ids | votes packed into h_res.  Returns False on shutdown."""
         import time
 
         from . import abi
         from .engine import Engine
 
-        items, flags = unpack_share(buf)
-        if flags & 1:
+        items, flags = unpack_share(buf, self.feat_base, bulk)
+        if flags & FLAG_SHUTDOWN:
             return False
+        if flags & FLAG_ABORT:
+            raise RuntimeError("the root refused this request set (a rank's share exceeds the capacities agreed at construction)")
         t0 = time.perf_counter()
-        dets = [abi.make_detections(b, feats=f, feat_quality=q) for (_, _, b, f, q) in items]
+        dets = []
+        for (_, _, b, f, q) in items:
+            if isinstance(f, int):   # device address inside the registered receive buffer
+                dets.append(abi.make_detections(b, feats_device_ptr=f, feat_quality=q))
+            else:
+                dets.append(abi.make_detections(b, feats=f, feat_quality=q))
         req, res, outs = Engine.make_requests([(it[0], it[1], d) for it, d in zip(items, dets)])
         if items:
             self.eng.associate_batch(req, res)
         self.last_local_ms = 1e3 * (time.perf_counter() - t0)
         total = sum(len(o[0]) for o in outs)
-        assert total <= self.cap_r, f"{total} detections exceed capacity_rows {self.cap_r}"
         out = self.h_res.numpy()
         if total:
             out[: 8 * total] = np.concatenate([o[0] for o in outs]).view(np.uint8)
@@ -366,6 +405,7 @@ class ShardedAssociator:
     def associate(self, items=None, shutdown: bool = False):
         torch, dist = self.torch, self.dist
         is_root = self.rank == self.root
+        refused = None
         if is_root:
             shares = [[] for _ in range(self.world)]
             where = []
@@ -375,23 +415,38 @@ class ShardedAssociator:
                     where.append((r, len(shares[r])))
                     shares[r].append(it)
             D = self.eng.cfg.feature_len if self.eng.cfg is not None else 0
+            # every capacity is checked HERE, before the first collective: a refusal travels with the shares
+            for r in range(self.world):
+                rows = sum(len(it[2]) for it in shares[r])
+                fbytes = sum(4 * D * len(it[2]) for it in shares[r] if it[3] is not None)
+                if rows > self.cap_r:
+                    refused = f"rank {r}'s share holds {rows} detections, capacity_rows is {self.cap_r}"
+                elif len(shares[r]) > self.max_scenes:
+                    refused = f"rank {r}'s share holds {len(shares[r])} scenes, max_scenes is {self.max_scenes}"
+                elif self.feat_base + fbytes > self.cap_b:
+                    refused = f"rank {r}'s share holds {fbytes} B of features, capacity_bytes is {self.cap_b - self.feat_base}"
             ha = self.h_all.numpy()
             for r in range(self.world):
-                b = pack_share(shares[r], D)
-                if shutdown:
-                    b[24:32].view(np.int64)[0] = 1
-                assert len(b) <= self.cap_b, f"rank {r}'s share ({len(b)} B) exceeds capacity_bytes {self.cap_b}"
+                flags = FLAG_SHUTDOWN if shutdown else (FLAG_ABORT if refused else 0)
+                b = pack_share([] if (shutdown or refused) else shares[r], D, self.feat_base, flags)
                 ha[r, : len(b)] = b
         if self.world > 1:
             if is_root:
                 for r in range(self.world):
                     self.d_all[r].copy_(self.h_all[r], non_blocking=True)
             dist.scatter(self.d_req, self.d_all if is_root else None, src=self.root, group=self.group)
+        elif self.in_place:
+            self.d_req.copy_(self.h_all[0], non_blocking=True)   # one rank: the share still goes where the engine will read it
+        if is_root and refused:   # (the other ranks learn it from their share's flags and skip the set)
+            raise RuntimeError("request set refused: " + refused)
+        if self.in_place:
+            self.h_req.copy_(self.d_req[: self.feat_base])        # the prefix only; the feature rows stay in device memory
+            alive = self._run_share(self.h_req.numpy(), bulk=self.d_req.data_ptr())
+        elif self.world > 1:
             self.h_req.copy_(self.d_req)
-            mine = self.h_req.numpy()
+            alive = self._run_share(self.h_req.numpy())
         else:
-            mine = self.h_all.numpy()[0]
-        alive = self._run_share(mine)
+            alive = self._run_share(self.h_all.numpy()[0])
         if not alive:
             return None
         if self.world > 1:
@@ -422,10 +477,16 @@ class ShardedAssociator:
             self.eng.upsert(scene_id, abi.make_tracks(**obj[0]))
 
     def serve_forever(self):
+        """Worker loop.  A refused request set raises on the root only; the workers skip it and keep serving."""
         assert self.rank != self.root
-        while self.associate(None) is not None:
-            pass
+        while True:
+            try:
+                if self.associate(None) is None:
+                    return
+            except RuntimeError:
+                continue
 
     def shutdown(self):
         assert self.rank == self.root
         self.associate(None, shutdown=True)
+        self.close()

@@ -142,3 +142,32 @@ def test_sharded_batch_tracker_over_the_hip_batch_sort():
     finally:
         hip.close()
         ora.close()
+
+
+@pytest.mark.parametrize("workload", ["c3", "c2"])
+def test_bench_under_torchrun_takes_the_rccl_branch(workload):
+    """bench.py the way the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), here with ONE rank
+    and SA_BENCH_FORCE_DIST=1 so that the process group is RCCL ("nccl") on this one-GPU box: communicator set-up, the barrier /
+    all-reduce of the timed region, and the dispatch pass — ShardedAssociator's scatter -> one sa_associate_batch per rank (feature rows
+    read in place from the registered receive buffer) -> gather — must run and give the resident run's answers."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload, "--steps", "5", "--warmup", "2", "--profile-iters", "3",
+           "--no-cpu-baseline", "--no-oracle", "--no-h2d"]
+    r = subprocess.run(cmd, env=dict(os.environ, SA_BENCH_FORCE_DIST="1"), capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    disp = d["dispatch"]
+    assert disp["backend"] == "nccl" and disp["ranks"] == 1
+    assert disp["rank0_answers_match_resident_run"] is True

@@ -225,6 +225,15 @@ def assoc_worker(rank: int, port: int, outfile: str):
         for f in range(3):  # the same scenes in another request order every time, one scene absent from one batch
             order = [s for s in (list(scenes) if f != 1 else list(scenes)[::-1]) if not (f == 2 and s == 8)]
             items = [(s, 1, scenes[s]["det_boxes"], scenes[s]["det_feats"], scenes[s]["det_quality"]) for s in order]
+            if f == 1:
+                # a request set beyond the agreed capacity is refused on EVERY rank (the root checks before the first collective and the
+                # verdict travels with the shares): the root gets the error, the workers skip the set and keep serving — nobody hangs
+                big = [(s, 1, np.concatenate([scenes[s]["det_boxes"]] * 12), None, None) for s in order]
+                try:
+                    sh.associate(big)
+                    raise AssertionError("an oversized request set went through")
+                except RuntimeError as ex:
+                    assert "refused" in str(ex) and "capacity_rows" in str(ex)
             res = sh.associate(items)
             assert len(res) == len(items)
             for s, (ids, votes) in zip(order, res):
