@@ -1,0 +1,51 @@
+#!/bin/bash
+# Round profile collection on the GPU box: rocprofv3 kernel stats of the default bench command (and of the other headline workloads),
+# bench lines of every workload, HBM-traffic PMC passes (separate --pmc runs with --kernel-trace only), MFMA utilisation counters.
+#   scripts/profile_round.sh <tag>        outputs under gpurun_out/<tag>/ — copy what is to be judged into profiles/
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+TAG=${1:-r03_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
+(rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
+# 1. kernel stats: the DEFAULT command first (the driver's line), then the other workloads
+for w in c2 c5 c4 c3 c2k3 c2d giant; do
+  extra="--workload $w --no-cpu-baseline --no-oracle --no-h2d"; [ "$w" = "c2" ] && extra="--no-cpu-baseline --no-oracle --no-h2d"
+  steps="--steps 50 --warmup 5"; [ "$w" = "c5" ] && steps="--steps 10 --warmup 2 --profile-iters 5"; [ "$w" = "giant" ] && steps="--steps 5 --warmup 1 --profile-iters 3"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o bench -- python $OLDPWD/bench.py $steps $extra > $O/prof_$w.log 2>&1)
+  f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_kernel_stats.csv && echo "== $w" && head -6 $O/${w}_kernel_stats.csv | cut -c1-200
+  rm -rf $O/prof_$w
+done
+# 2. bench lines (the default one with its CPU baselines)
+timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 exit $?"
+for w in c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd giant bigpile bigcrowd; do
+  st=""; [ "$w" = "c5" ] && st="--steps 20 --warmup 3 --profile-iters 10"
+  timeout 600 python bench.py --workload $w --no-cpu-baseline $st > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w exit $?"
+done
+timeout 300 python bench.py --flags 32 --no-cpu-baseline > $O/bench_c2_separate.json 2> $O/bench_c2_separate.err
+# 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes)
+for w in c2 c5 c4; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
+# 4. MFMA utilisation of the contraction (C2 default line and C5)
+for w in c2 c5; do
+  extra="--workload $w"; st="--steps 30 --warmup 5"; [ "$w" = "c5" ] && st="--steps 8 --warmup 2 --profile-iters 4"
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$w -o p -- \
+     python $OLDPWD/bench.py $extra $st --no-cpu-baseline --no-oracle --no-h2d > $O/pmc_mfma_$w.log 2>&1)
+  python - "$O/pmc_mfma_$w" "$O/mfma_util_$w.json" <<'PY'
+import csv, glob, json, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, d in agg.items():
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    if m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        m["launches"] = len(next(iter(d.values())))
+        if m.get("SQ_BUSY_CYCLES"): m["mfma_busy_over_sq_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"]
+        out[k] = m
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print({k: round(v.get("mfma_busy_over_sq_busy", 0), 3) for k, v in out.items()})
+PY
+  rm -rf $O/pmc_mfma_$w
+done
+# 5. the tracker loop
+timeout 300 python scripts/bench_tracker.py 1000 512 30 > $O/tracker_loop.jsonl 2> $O/tracker_loop.err; cat $O/tracker_loop.jsonl
+echo DONE

@@ -31,6 +31,19 @@ struct sa_geo {
   float xc, yc, r, hha;
 };
 
+// Half extents of a box for the axis-aligned quick reject (sa_aa_quick_reject): hw = aspect * height / 2, hh = height / 2; hw < 0 marks
+// a box with a non-zero angle (its polygon is not its bounding rectangle: no quick reject).
+struct sa_ext {
+  float hw, hh;
+};
+SA_HD sa_ext sa_box_ext(float aspect, float height, bool oriented) {
+  sa_ext e;
+  e.hw = aspect * height / 2.0f;
+  e.hh = height / 2.0f;
+  if (oriented) e.hw = -e.hw;
+  return e;
+}
+
 struct sa_constraints {
   uint32_t n;
   uint32_t pad;
@@ -87,6 +100,33 @@ SA_HD bool sa_compatible(const sa_geo& c, uint64_t ce, const sa_geo& t, uint64_t
   for (uint32_t i = 0; i < cons.n; ++i)
     if (cons.delta[i] >= delta) return sa_dist_in_2r(c, t) <= cons.max_dist[i];
   return true;
+}
+
+// Two boxes WITHOUT an angle are axis-aligned rectangles; the cell the reference computes for them — Sutherland–Hodgman, shoelace,
+// IoU, x confidence, threshold (bbox.rs:512-535, sort/metric.rs:65-77) — is absent whenever
+//   * the rectangles do not overlap (intersection exactly 0.0: every subject vertex lies outside one clip edge, the clipper emits
+//     nothing), or
+//   * an UPPER bound of intersection / union x confidence stays below the threshold.
+// Both are decided here in f32 from centres and half extents, with margins (1e-4 of the extents on the overlap, 1e-4 relative on the
+// bound) that are orders of magnitude above the f32 rounding of these few operations and of the f64 clip itself: a pair rejected
+// here is absent in the reference too; a pair within the margins is NOT rejected and goes through the exact clip.  Bounding-circle
+// neighbours that do not overlap, or overlap too little, are the bulk of the surviving pairs of a crowded frame (C2: 19 in 20).
+// IoU engines only (the Mahalanobis cell has no such bound).  Returns true = the cell is absent.
+SA_HD bool sa_aa_quick_reject(const sa_geo& c, const sa_ext& ce, const sa_geo& t, const sa_ext& te, float conf, float threshold) {
+  if (ce.hw < 0.0f || te.hw < 0.0f) return false;  // an oriented box: no shortcut
+  const float dx = fabsf(c.xc - t.xc), dy = fabsf(c.yc - t.yc);
+  const float sx = ce.hw + te.hw, sy = ce.hh + te.hh;
+  const float m = 1e-4f * (sx + sy);
+  const float ox = sx - dx, oy = sy - dy;
+  if (ox < -m || oy < -m) return true;  // disjoint, with room to spare
+  const float wx = 2.0f * (ce.hw < te.hw ? ce.hw : te.hw), wy = 2.0f * (ce.hh < te.hh ? ce.hh : te.hh);
+  float ix = (ox > 0.0f ? ox : 0.0f) + m, iy = (oy > 0.0f ? oy : 0.0f) + m;
+  ix = ix < wx ? ix : wx;
+  iy = iy < wy ? iy : wy;
+  const float inter_ub = ix * iy;
+  const float uni_lb = (c.hha + t.hha) - inter_ub;
+  if (!(uni_lb > 0.0f)) return false;
+  return inter_ub / uni_lb * conf * 1.0001f < threshold;
 }
 
 // ---- Sutherland–Hodgman + shoelace (clipping.rs:12-91, geo Area) ------------------------------------------

@@ -56,6 +56,7 @@ struct SceneDev {
   uint64_t epoch;
   // stored tracks (persist across frames)
   const sa_geo SA_G* t_geo;
+  const sa_ext SA_G* t_ext;   // half extents (negative hw = oriented): the axis-aligned quick reject of the positional tiles
   const double SA_G* t_verts;
   const uint64_t SA_G* t_epoch;
   const float SA_G* t_maha;
@@ -190,6 +191,7 @@ struct PrepTrackArgs {
   const float* kf_cov;      // [n][25] or nullptr
   uint32_t n;
   sa_geo* geo;
+  sa_ext* ext;
   double* verts;
   uint64_t* t_epoch;
   uint64_t* t_ids;
@@ -250,6 +252,7 @@ struct ApplyArgs {
   uint64_t epoch;
   float* kf;                 // [T][110] Kalman mean(10) + covariance(100)
   sa_geo* geo;
+  sa_ext* ext;
   double* verts;
   uint64_t* t_epoch;
   uint64_t* t_ids;

@@ -42,7 +42,7 @@ struct SceneTable {
   uint32_t T = 0, cap = 0;
   std::vector<uint64_t> ids;                       // slot -> id
   std::unordered_map<uint64_t, uint32_t> slot_of;  // id -> slot
-  DevBuf geo, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
+  DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
   DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
   std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
 };
@@ -325,6 +325,7 @@ int scene_reserve(sa_engine* e, SceneTable* s, uint32_t need) {
   while (ncap < need) ncap *= 2;
   const size_t KDp = (size_t)e->K * e->Dp;
   TRY(dev_ensure(e, s->geo, (size_t)ncap * sizeof(sa_geo), true));
+  TRY(dev_ensure(e, s->ext, (size_t)ncap * sizeof(sa_ext), true));
   TRY(dev_ensure(e, s->verts, (size_t)ncap * 8 * sizeof(double), true));
   TRY(dev_ensure(e, s->epoch, (size_t)ncap * 8, true));
   TRY(dev_ensure(e, s->maha, (size_t)ncap * 20 * sizeof(float), true));
@@ -454,7 +455,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   if (bk->partials) { d->CT = (s->T + bk->tile_bn - 1) / bk->tile_bn; d->RT = (s->N + bk->tile_bm - 1) / bk->tile_bm; }  // the contraction's own tile grid
   d->nkeys = e->visual ? ((s->N + bk->tile_bm - 1) / bk->tile_bm) * ((s->T * e->K + bk->tile_bn - 1) / bk->tile_bn) : 0;
   d->epoch = s->epoch;
-  d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
+  d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_ext = (decltype(d->t_ext))(sc->ext.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
   d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
   d->t_fpresent = (decltype(d->t_fpresent))(sc->fpresent.p); d->t_fcount = (decltype(d->t_fcount))(sc->fcount.p); d->t_ids = (decltype(d->t_ids))(sc->tids.p);
   d->c_raw = (decltype(d->c_raw))(s->p_raw); d->c_quality = (decltype(d->c_quality))(s->p_quality); d->c_own = (decltype(d->c_own))(s->p_own);
@@ -913,7 +914,7 @@ void sa_engine_destroy(sa_engine* e) {
   for (auto& g : e->garbage) hipFree(g.p);
   for (auto& kv : e->scenes) {
     SceneTable* s = kv.second;
-    for (DevBuf* b : {&s->geo, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
+    for (DevBuf* b : {&s->geo, &s->ext, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
     delete s;
   }
   for (Bank& bk : e->banks) {
@@ -1036,7 +1037,7 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
   a.ids = (const uint64_t*)e->up_ids.p;
   a.kf_mean = kf ? (const float*)e->up_mean.p : nullptr; a.kf_cov = kf ? (const float*)e->up_cov.p : nullptr;
   a.n = n;
-  a.geo = (sa_geo*)sc->geo.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p; a.t_ids = (uint64_t*)sc->tids.p;
+  a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p; a.t_ids = (uint64_t*)sc->tids.p;
   a.maha = (float*)sc->maha.p;
   HIPCHK(e, sa_launch_prep_tracks(a, e->P, st));
   if (feats) {
@@ -1077,7 +1078,7 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
     HIPCHK(e, hipMemcpy(e->up_index.p, keep.data(), (size_t)nT * 4, hipMemcpyHostToDevice));
     struct Arr { DevBuf* b; uint32_t row; };
     const uint32_t K = e->K;
-    std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u},
+    std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->ext, (uint32_t)sizeof(sa_ext)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u},
                              {&sc->kf, 440u}};
     if (e->visual) {
       arrs.push_back({&sc->feat, K * e->Dp * 4u});
@@ -1548,7 +1549,7 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   ApplyArgs a{};
   a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = (const uint32_t*)s->d_apply;
   a.new_ids = (const uint64_t*)((const uint8_t*)s->d_apply + ids_off); a.n = n; a.epoch = s->epoch;
-  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
+  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
   a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
   BankArgs b{};
   if (e->visual) {

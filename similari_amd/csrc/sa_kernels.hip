@@ -58,6 +58,7 @@ __global__ void k_prep_tracks(PrepTrackArgs a, SaParams p) {
   uint32_t s = a.slots[i];
   BoxRaw r = a.raw[i];
   prep_box_common(r, &a.geo[s], &a.verts[(size_t)s * 8]);
+  a.ext[s] = sa_box_ext(r.box.aspect, r.box.height, r.box.has_angle && r.box.angle != 0.0f);
   a.t_epoch[s] = a.epochs[i];
   a.t_ids[s] = a.ids[i];
   if (a.kf_mean && a.kf_cov) sa_maha_prepare(p.kf_position_weight, a.kf_mean + (size_t)i * 5, a.kf_cov + (size_t)i * 25, a.maha + (size_t)s * 20);
@@ -113,7 +114,7 @@ template <int NSUB, bool UNION>
 __global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
-  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, false, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
   else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.

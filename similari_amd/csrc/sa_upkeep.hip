@@ -41,6 +41,7 @@ __global__ __launch_bounds__(64) void k_apply_kalman(ApplyArgs a, SaParams p) {
   g.r = sa_radius(pred.aspect, pred.height);
   g.hha = pred.height * pred.height * pred.aspect;
   a.geo[row] = g;
+  a.ext[row] = sa_box_ext(pred.aspect, pred.height, pred.has_angle && pred.angle != 0.0f);
   // (a box with an angle: its polygon follows from the host's cos / sin, k_apply_polygons; until then — nothing reads the table in
   // between — the row holds the axis-aligned one)
   sa_vertices(pred.xc, pred.yc, pred.aspect, pred.height, 1.0, 0.0, a.verts + (size_t)row * 8);

@@ -63,6 +63,12 @@ int emu_positional_cell(const sa_config* cfg, const sa_box* cand, uint64_t cand_
   if (compatible) *compatible = comp;
   if (!comp || sa_too_far(cg, tg)) return 0;
   float conf = cand->confidence < cfg->positional_min_confidence ? cfg->positional_min_confidence : cand->confidence;
+  if (cfg->positional_kind != SA_POS_MAHALANOBIS) {
+    // the positional tiles' axis-aligned quick reject (sa_frame.h, phase 1): conservative — whatever it rejects the exact path rejects too
+    const sa_ext ce = sa_box_ext(cand->aspect, cand->height, cand->has_angle && cand->angle != 0.0f);
+    const sa_ext te = sa_box_ext(track->aspect, track->height, track->has_angle && track->angle != 0.0f);
+    if (sa_aa_quick_reject(cg, ce, tg, te, conf, cfg->positional_threshold)) return 0;
+  }
   if (cfg->positional_kind == SA_POS_MAHALANOBIS) {
     float m20[20];
     sa_maha_prepare(cfg->kf_position_weight, mean5, cov25, m20);

@@ -89,6 +89,44 @@ def test_iou_cells_bit_identical(oriented):
     assert present > 100
 
 
+@pytest.mark.parametrize("thr", [0.05, 0.3, 0.7])
+def test_axis_aligned_quick_reject_is_conservative(thr):
+    """The positional tiles decide most axis-aligned pairs without the f64 clip (sa_aa_quick_reject: the rectangles miss each other, or
+    an upper bound of IoU x confidence stays below the threshold).  Whatever it rejects must be absent in the oracle too: 60 000
+    pairs aimed at the decision boundaries — rectangles that just touch, overlaps of a hair, IoU x confidence a hair either side of
+    the threshold, nested boxes, huge coordinates."""
+    rng = np.random.default_rng(int(thr * 100))
+    cfg = abi.make_config(positional="iou", positional_threshold=thr, positional_min_confidence=0.05, max_idle_epochs=3)
+    n = 20000
+    present = rejected_nearly = 0
+    for variant in range(3):
+        a = random_boxes(rng, n, canvas=400.0 if variant < 2 else 30000.0)
+        b = a.copy()
+        w, h = a["aspect"] * a["height"], a["height"]
+        if variant == 0:   # sliding along x until the rectangles (almost) stop touching
+            b["aspect"] = rng.uniform(0.3, 1.5, n).astype(np.float32)
+            b["height"] = rng.uniform(20, 120, n).astype(np.float32)
+            gap = rng.choice([-1e-3, -1e-5, 0.0, 1e-5, 1e-3, 0.5], n).astype(np.float32)
+            b["xc"] = a["xc"] + (w + b["aspect"] * b["height"]) / 2 + gap
+            b["yc"] = a["yc"] + rng.uniform(-10, 10, n).astype(np.float32)
+        else:              # a shift chosen so that IoU x confidence lands close to the threshold
+            conf = a["confidence"].clip(0.05, 1.0)
+            target = np.clip(thr / conf * rng.choice([0.98, 0.999, 0.99999, 1.0, 1.00001, 1.001, 1.02], n), 0.0, 0.999)
+            # same-size boxes shifted by d along x: IoU = (w - d) / (w + d)  ->  d = w (1 - t) / (1 + t)
+            b["xc"] = a["xc"] + (w * (1 - target) / (1 + target)).astype(np.float32)
+        b["confidence"] = rng.uniform(0, 1, n).astype(np.float32)
+        for i in range(n):
+            ov, ev = C.c_float(), C.c_float()
+            comp = C.c_int()
+            r_o = OL.or_positional_metric(C.byref(cfg), O.box_ptr(a, i), O.box_ptr(b, i), None, None, C.byref(ov))
+            r_e = E.emu_positional_cell(C.byref(cfg), O.box_ptr(a, i), 5, O.box_ptr(b, i), 5, None, None, C.byref(ev), C.byref(comp))
+            assert r_o == r_e, (variant, i, a[i], b[i])
+            if r_o:
+                present += 1
+                assert np.float32(ov.value).tobytes() == np.float32(ev.value).tobytes()
+    assert present > 2000
+
+
 def test_maha_cells_bit_identical():
     rng = np.random.default_rng(5)
     n = 300
