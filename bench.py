@@ -789,6 +789,14 @@ def main():
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "note": "latency-bound helper kernel; no algorithmic-byte model"}
+        if roof is not None and dom in models and kern[dom].get("avg_us_rocprof"):
+            # the same figure from the committed rocprofv3 average of this kernel (no per-dispatch completion signal in that run:
+            # the instrumented duration above carries ~1.5 us of it on the fused first phase)
+            per_launch = models[dom][1] / per_step(dom)
+            rate = per_launch / (kern[dom]["avg_us_rocprof"] * 1e-6)
+            roof["achieved_rocprof"] = rate / (1e9 if roof["unit"] == "GB/s" else 1e12)
+            roof["frac_rocprof"] = roof["achieved_rocprof"] / roof["peak"]
+            roof["rocprof_source"] = "profiles/r*_%s_kernel_stats.csv (newest round)" % args.workload
         if roof is not None:
             tr = pmc_traffic(args.workload, dom)
             if tr:
