@@ -13,8 +13,8 @@
 //   * a column's search state (distance, labelled / scanned flags, its dual v) lives in the REGISTERS of the thread that owns it;
 //   * "nearest labelled, unscanned column" is a workgroup minimum of packed (distance << 16 | column) keys: 32-bit DPP
 //     reductions inside a wave, one LDS slot per wave, one barrier per search step;
-//   * per-row state (dual u, match) and the per-column match / predecessor live in LDS (k_assign_small) or in HBM behind the
-//     workgroup's own L1 (k_assign_dense on frames beyond the LDS budget).
+//   * per-row state (dual u, match) and the per-column match / predecessor live in LDS (k_assign_small; k_assign_solve when
+//     12 N + 8 T bytes fit) or in HBM behind the workgroup's own L1 (k_assign_solve on frames beyond that).
 // One search step = one barrier + one L2 round trip (~1.5 k cycles) whatever the density; 640 rows / 140 k edges: ~6 k steps.
 //
 // Written once for both worlds like the cooperative solver: on the device a "thread loop" runs its body once, for this thread;

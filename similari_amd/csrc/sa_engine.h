@@ -115,7 +115,6 @@ struct SceneDev {
   uint32_t SA_G* lab;        // [N] general tail: component root of the row (SA_NONE: takes no part)
   uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column (SA_NONE between frames)
   uint32_t SA_G* big_rows;   // [N] rows, then search roots, of the big components: one ascending segment each
-  uint32_t SA_G* dq;         // [N] general tail: roots of the components queued for the dense solver (stats[3] of them)
   uint32_t SA_G* big_bcol;   // [N] the column a row bids for
   int64_t SA_G* dense;       // [N][T] gains of the components the dense solver (sa_dense.h) is working on; all zero between frames
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)

@@ -21,11 +21,11 @@ thread_local std::string g_create_error;
 
 enum KernelId {
   KID_FRAME = 0, KID_FRAME_VISUAL, KID_VISUAL, KID_BESTFIT_TILE, KID_BESTFIT_RESOLVE, KID_ASSIGN_SMALL,
-  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_ASSIGN_DENSE, KID_COUNT
+  KID_ASSIGN_LABEL, KID_ASSIGN_SOLVE, KID_D2H, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {
     "k_frame", "k_frame_visual", "k_visual_cost", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
-    "k_assign_label", "k_assign_solve", "d2h_results", "k_assign_dense"};
+    "k_assign_label", "k_assign_solve", "d2h_results"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -68,7 +68,7 @@ struct Slot {  // one scene of a request set
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
-  DevBuf lab, cwin, big_rows, dq, big_bcol, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
+  DevBuf lab, cwin, big_rows, big_bcol, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
   HostBuf h_apply, h_pred, h_fix;
@@ -420,7 +420,6 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->lab, n * 4));
     TRY(dev_ensure(e, s->cwin, t * 4));
     TRY(dev_ensure(e, s->big_rows, n * 4));
-    TRY(dev_ensure(e, s->dq, n * 4));
     TRY(dev_ensure(e, s->big_bcol, n * 4));
   }
   {  // the dense solver's matrix: zero between frames (the solver wipes what it wrote), established after (re)allocation
@@ -478,7 +477,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->quant = (decltype(d->quant))(s->quant.p);
   d->win_col = (decltype(d->win_col))(s->win_col.p);
   d->lab = (decltype(d->lab))(s->lab.p); d->cwin = (decltype(d->cwin))(s->cwin.p); d->big_rows = (decltype(d->big_rows))(s->big_rows.p);
-  d->dq = (decltype(d->dq))(s->dq.p); d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dense = (decltype(d->dense))(s->dense.p);
+  d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dense = (decltype(d->dense))(s->dense.p);
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
   d->out_win = (decltype(d->out_win))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16);
@@ -638,10 +637,9 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
   } else {
     { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
-    { ProfScope ps(e, KID_ASSIGN_SOLVE); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 3)); }
-    ProfScope ps(e, KID_ASSIGN_DENSE);
+    ProfScope ps(e, KID_ASSIGN_SOLVE);
     if (attach) sa_done_event = done;
-    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, 4);
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, 3);
   }
   if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
   sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
@@ -924,7 +922,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                         &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
-                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->dq, &s->big_bcol, &s->dense})
+                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dense})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_fix);

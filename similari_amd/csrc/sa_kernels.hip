@@ -373,9 +373,9 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // strictly needed — harmless, it is still solved exactly.
 //   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
 //            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
-//   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a component of
-//            at most 8 rows: one lane in a private block of LDS; larger: the whole wavefront, greedy start + cooperative
-//            augmenting paths on state in HBM).
+//   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a one-row
+//            component: its heaviest edge; up to 8 rows: one lane in a private block of LDS; larger: the whole workgroup with the
+//            dense solver of sa_dense.h).
 // =====================================================================================================
 // In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
 // thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
@@ -868,7 +868,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (q == 0) { S.stats[1] = 0u; S.stats[3] = 0u; S.stats[4] = 0u; }  // the dense solver's: top of its row lists | queue length | next queue entry
+  if (q == 0) S.stats[1] = 0u;  // top of the dense solver's row lists
   if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
@@ -909,232 +909,309 @@ __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q,
   S.win_col[q] = win;
   S.out_win[q] = win;
 }
-template <bool VISUAL>
-__global__ __launch_bounds__(64) void k_assign_solve(const SceneDev* __restrict__ scenes) {
+// One big component by the dense solver of sa_dense.h, all NT threads of the workgroup on it.  rows ascending (ballot compaction of
+// the scene's row labels) -> greedy start: every row bids for the column of its heaviest usable edge (global atomic minimum on cwin,
+// SA_NONE between frames), its gains go into the dense matrix, u = -(heaviest gain) -> rows that lost their bid are the search roots
+// (ascending, compacted in place) -> sa_assign_component_dense -> results, matrix and bids wiped.
+template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
+__device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_t root, int64_t* u, int32_t* rmatch, int32_t* cmatch, int32_t* pred,
+                                                      unsigned long long* s_part, uint32_t* s_word) {
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t q = threadIdx.x, lane = q & 63u;
+  const uint8_t SA_G* excl = VISUAL ? S.col_excluded : nullptr;
+  const uint32_t R = (uint32_t)S.rnext[root];  // rows of the component (k_assign_label)
+  if (q == 0) { s_word[0] = atomicAdd((uint32_t*)(S.stats + 1), R); s_word[2] = 0; }  // its segment of the row lists | heaviest gain
+  __syncthreads();
+  uint32_t* rows = (uint32_t*)S.big_rows + s_word[0];   // the component's rows, then (in place of the matched ones) its search roots
+  if (q < 64) {  // eight label loads in flight per lane: the scan is a chain of L2 round trips otherwise
+    uint32_t cnt = 0;
+    for (uint32_t r0 = 0; r0 < N; r0 += 512) {
+      uint32_t lb8[8];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+        lb8[k2] = row < N ? S.lab[row] : SA_NONE;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+        const bool f = row < N && lb8[k2] == root;
+        const unsigned long long m = __ballot(f);
+        if (f) rows[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
+        cnt += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  // greedy start: bids, duals, gains into the dense matrix
+  for (uint32_t i = q; i < R; i += NT) {
+    const uint32_t row = rows[i];
+    const uint32_t ne = S.e_use[row];
+    const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+    int64_t SA_G* drow = S.dense + (size_t)row * T;
+    int64_t maxg = 0;
+    uint32_t bcol = SA_NONE;
+    for (uint32_t e0 = 0; e0 < ne; e0 += 4) {  // four records (and their exclusion flags) per round trip
+      SaEdge ed[4];
+      bool use[4];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(excl && excl[ed[k2].col]);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        if (!use[k2]) continue;
+        drow[ed[k2].col] = ed[k2].gain;
+        if (ed[k2].gain > maxg || (ed[k2].gain == maxg && ed[k2].col < bcol)) { maxg = ed[k2].gain; bcol = ed[k2].col; }
+      }
+    }
+    u[row] = -maxg;
+    S.big_bcol[row] = bcol;
+    if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
+    if (maxg > 0) atomicMax(&s_word[2], maxg > 0x7fffffffll ? 0x7fffffffu : (uint32_t)maxg);
+  }
+  __syncthreads();
+  if (q < 64) {  // matched rows keep their bid; the others become the search roots, ascending, compacted in place
+    uint32_t nroots = 0;
+    for (uint32_t i0 = 0; i0 < R; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      bool pend = false;
+      uint32_t row = 0;
+      if (i < R) {
+        row = rows[i];
+        const uint32_t bc = S.big_bcol[row];
+        if (bc != SA_NONE) {
+          if (__hip_atomic_load((uint32_t*)(S.cwin + bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == row) { rmatch[row] = (int32_t)bc; cmatch[bc] = (int32_t)row; }
+          else pend = true;
+        }
+      }
+      const unsigned long long m = __ballot(pend);
+      // (position nroots + rank <= i: a root never overwrites an entry that has not been read yet; all lanes of this step have read theirs)
+      if (pend) rows[nroots + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
+      nroots += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) s_word[1] = nroots;
+  }
+  __syncthreads();
+  {
+    sa_dense_ws w;
+    w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
+    w.u = u; w.rmatch = rmatch; w.cmatch = cmatch; w.pred = pred; w.part = s_part;
+    bool k32 = false;
+    if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) k32 = s_word[2] <= (uint32_t)SA_DENSE_K32_MAXGAIN;
+    if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) {
+      if (k32) sa_assign_component_dense<NT, CPT, true>(w, rows, s_word[1]);
+    }
+    if (!k32) sa_assign_component_dense<NT, CPT, false>(w, rows, s_word[1]);
+  }
+  // results; matrix, bids and (LDS) matches wiped for the next component / frame.  The rows list was overwritten by the roots:
+  // walk the scene's labels again.
+  for (uint32_t row = q; row < N; row += NT) {
+    if (S.lab[row] != root) continue;
+    const int32_t c = rmatch[row];
+    finalize_row_with<VISUAL>(S, row, c);
+    const uint32_t ne = S.e_use[row];
+    const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+    int64_t SA_G* drow = S.dense + (size_t)row * T;
+    for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+      uint32_t cj[4];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) cj[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2).col : 0u;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2)
+        if (e0 + k2 < ne) drow[cj[k2]] = 0;
+    }
+    const uint32_t bc = S.big_bcol[row];
+    if (bc != SA_NONE) S.cwin[bc] = SA_NONE;
+    if (LDS_STATE) {
+      if (c >= 0) cmatch[c] = -1;
+      rmatch[row] = -1;
+    }
+  }
+  __syncthreads();
+}
+
+// General tail, kernel 2 of 2.  NT threads per workgroup, thread = row.  The thread of a component's root (= its lowest row) owns it:
+//   * ONE row (most components of a tracking frame): its heaviest usable edge straight from the HBM list (lowest column on ties) —
+//     what the shortest-path search does for the first row of a component, without any search state;
+//   * up to 8 rows, 12 columns, 24 usable edges: gathered into a private block of LDS (from a pool of SL_POOL blocks per
+//     workgroup), solved there by the serial sa_assign_component, scattered back;
+//   * anything larger, or a small one that found the pool empty: onto the workgroup's own list, and after a barrier ALL its threads
+//     solve those one after the other with the dense solver (dense_solve_component) — no third launch.
+// Per-row duals / matches and per-column matches / predecessors of the dense solver: dynamic LDS when 12 N + 8 T bytes fit
+// (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
+#define SL_POOL 40
+template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
+__global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ SolveLocal s_local[64];
+  const uint32_t q = blockIdx.x * NT + threadIdx.x;
+  __shared__ SolveLocal s_local[SL_POOL];
+  __shared__ unsigned long long s_part[2 * (NT / 64)];
+  __shared__ uint32_t s_big[NT], s_nbig, s_pool_top, s_word[4];
+  extern __shared__ unsigned char s_dyn[];
+  if (threadIdx.x == 0) { s_nbig = 0; s_pool_top = 0; }
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
-  for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * blockDim.x) S.parent[i] = i;
+  for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * NT) S.parent[i] = i;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
   }
+  __syncthreads();
   bool big = false;
   if (q < S.N) {
+    // Everything a one-row component needs, requested TOGETHER: what the previous kernels wrote lies in other XCDs' L2s, so each
+    // dependent load of this thread is a trip to memory (~1.5 us); the row's first four edge records are fetched before their count
+    // is known (what lies beyond the count is stale but addressable) and the track ids / exclusion flags they point at right after.
     const uint32_t head = S.label[q];
-    if (!S.e_use[q] || (VISUAL && S.row_has[q])) finalize_row_with<VISUAL>(S, q, -1);
+    const uint32_t my_edges = S.e_use[q];
+    const uint32_t Rq = (uint32_t)S.rnext[q];
+    const uint8_t has_q = VISUAL ? S.row_has[q] : (uint8_t)0;
+    const int32_t vw_q = VISUAL ? S.vis_winner[q] : -1;
+    SaEdge pe[4];
+    {
+      const SaEdge SA_G* ep = S.e_edge + (size_t)q * S.estride;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) pe[k2] = sa_ldg(ep + ((uint32_t)k2 < S.estride ? (uint32_t)k2 : S.estride - 1u));
+    }
+    uint64_t pid[4];
+    bool pex[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const uint32_t c = pe[k2].col < S.T ? pe[k2].col : 0u;  // (a stale record may name a column of a larger, earlier table)
+      pid[k2] = S.T ? S.t_ids[c] : 0ull;  // (an empty table has no id array)
+      pex[k2] = VISUAL && S.col_excluded[c] != 0;
+    }
+    if (!my_edges || has_q) {
+      // no edge, or decided by the visual vote: this row's result is known (finalize_row_with, with the values already here)
+      const bool vis = vw_q >= 0;
+      S.out_track_id[q] = vis ? S.t_ids[vw_q] : 0ull;
+      S.out_vote[q] = vis ? SA_VOTE_VISUAL : SA_VOTE_NONE;
+      S.win_col[q] = vis ? vw_q : -1;
+      S.out_win[q] = vis ? vw_q : -1;
+    }
     if (head != SA_NONE) {
-      SolveLocal& L = s_local[threadIdx.x];
-      const uint32_t R = (uint32_t)S.rnext[q];  // rows in the component rooted here (k_assign_label)
-      bool fits = R <= SL_R;
-      uint32_t E = 0, C = 0;
-      if (fits) {
-        // rows of the component, ascending
-        uint32_t n = 0;
-        for (uint32_t cur = head; cur != SA_NONE && n < SL_R; cur = S.next_row[cur]) {
-          uint32_t k = n;
-          while (k > 0 && L.rows[k - 1] > cur) { L.rows[k] = L.rows[k - 1]; --k; }
-          L.rows[k] = cur;
-          ++n;
-        }
-        for (uint32_t r = 0; r < R && fits; ++r) {
-          const uint32_t row = L.rows[r];
-          const uint32_t cnt = S.e_use[row];
-          const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-          L.e_off[r] = E;
-          uint32_t n2 = 0;
-          int64_t maxg = 0;
-          for (uint32_t e = 0; e < cnt; ++e) {
-            const SaEdge ed = sa_ldg(ep + e);
-            if (VISUAL && S.col_excluded[ed.col]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71)
-            uint32_t c = 0;
-            while (c < C && L.colmap[c] != ed.col) ++c;
-            if (E >= SL_E || (c == C && C >= SL_C)) { fits = false; break; }
-            if (c == C) L.colmap[C++] = ed.col;
-            L.e_col[E] = c;
-            L.e_gain[E] = ed.gain;
-            ++E; ++n2;
-            maxg = ed.gain > maxg ? ed.gain : maxg;
+      const uint32_t R = Rq;  // rows in the component rooted here (k_assign_label)
+      if (R == 1 && head == q && my_edges <= 4u) {
+        // the usual component of a tracking frame: this row alone with a handful of edges, all of them in registers already
+        int64_t bg = 0;
+        int32_t bj = -1;
+        uint64_t bid = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+          if ((uint32_t)k2 < my_edges && !pex[k2] && (bj < 0 || pe[k2].gain > bg || (pe[k2].gain == bg && (int32_t)pe[k2].col < bj))) {
+            bg = pe[k2].gain; bj = (int32_t)pe[k2].col; bid = pid[k2];
           }
-          L.e_cnt[r] = n2;
-          L.u[r] = -maxg;
-          L.rmatch[r] = -1;
-          L.next_row[r] = r + 1 < R ? r + 1 : SA_NONE;
+        // (a row in a list has no visual verdict: k_assign_label leaves those out)
+        S.out_track_id[q] = bj >= 0 ? bid : 0ull;
+        S.out_vote[q] = bj >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+        S.win_col[q] = bj;
+        S.out_win[q] = bj;
+      } else
+      if (R == 1) {
+        // ONE row takes part (the list's only entry — not necessarily this thread's own row: the forest also holds the rows the
+        // visual vote decided, and one of those may be the root): its heaviest usable edge wins (lowest column on ties), or none
+        const uint32_t row = head;
+        const uint32_t ne = S.e_use[row];
+        const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+        int64_t bg = 0;
+        int32_t bj = -1;
+        for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+          SaEdge ed[4];
+          bool use[4];
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2)
+            if (use[k2] && (bj < 0 || ed[k2].gain > bg || (ed[k2].gain == bg && (int32_t)ed[k2].col < bj))) { bg = ed[k2].gain; bj = (int32_t)ed[k2].col; }
         }
+        finalize_row_with<VISUAL>(S, row, bj);
+      } else {
+        bool fits = R <= SL_R;
+        uint32_t blk = SA_NONE;
+        if (fits) {
+          blk = atomicAdd(&s_pool_top, 1u);
+          fits = blk < SL_POOL;
+        }
+        uint32_t E = 0, C = 0;
+        if (fits) {
+          SolveLocal& L = s_local[blk];
+          // rows of the component, ascending
+          uint32_t n = 0;
+          for (uint32_t cur = head; cur != SA_NONE && n < SL_R; cur = S.next_row[cur]) {
+            uint32_t k = n;
+            while (k > 0 && L.rows[k - 1] > cur) { L.rows[k] = L.rows[k - 1]; --k; }
+            L.rows[k] = cur;
+            ++n;
+          }
+          for (uint32_t r = 0; r < R && fits; ++r) {
+            const uint32_t row = L.rows[r];
+            const uint32_t cnt = S.e_use[row];
+            const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+            L.e_off[r] = E;
+            uint32_t n2 = 0;
+            int64_t maxg = 0;
+            for (uint32_t e = 0; e < cnt; ++e) {
+              const SaEdge ed = sa_ldg(ep + e);
+              if (VISUAL && S.col_excluded[ed.col]) continue;  // excluded_tracks (visual_sort/voting.rs:62-71)
+              uint32_t c = 0;
+              while (c < C && L.colmap[c] != ed.col) ++c;
+              if (E >= SL_E || (c == C && C >= SL_C)) { fits = false; break; }
+              if (c == C) L.colmap[C++] = ed.col;
+              L.e_col[E] = c;
+              L.e_gain[E] = ed.gain;
+              ++E; ++n2;
+              maxg = ed.gain > maxg ? ed.gain : maxg;
+            }
+            L.e_cnt[r] = n2;
+            L.u[r] = -maxg;
+            L.rmatch[r] = -1;
+            L.next_row[r] = r + 1 < R ? r + 1 : SA_NONE;
+          }
+        }
+        if (fits) {
+          SolveLocal& L = s_local[blk];
+          // columns in ascending order of their track index: rank, permute, renumber the edges
+          for (uint32_t c = 0; c < C; ++c) {
+            uint32_t rank = 0;
+            for (uint32_t d = 0; d < C; ++d) rank += L.colmap[d] < L.colmap[c];
+            L.cnext[c] = (int32_t)rank;
+          }
+          for (uint32_t c = 0; c < C; ++c) L.pred[L.cnext[c]] = (int32_t)L.colmap[c];
+          for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
+          for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
+          sa_assign_ws w;
+          w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = L.e_off;
+          w.excluded = nullptr;
+          w.next_row = L.next_row;
+          w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;
+          w.cstamp = L.cstamp; w.cscan = L.cscan; w.cnext = L.cnext; w.rdist = L.rdist; w.rnext = L.rnext;
+          sa_assign_component(w, 0);
+          for (uint32_t r = 0; r < R; ++r) {
+            const int32_t c = L.rmatch[r];
+            finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
+          }
+        } else big = true;
       }
-      if (fits) {
-        // columns in ascending order of their track index: rank, permute, renumber the edges
-        for (uint32_t c = 0; c < C; ++c) {
-          uint32_t rank = 0;
-          for (uint32_t d = 0; d < C; ++d) rank += L.colmap[d] < L.colmap[c];
-          L.cnext[c] = (int32_t)rank;
-        }
-        for (uint32_t c = 0; c < C; ++c) L.pred[L.cnext[c]] = (int32_t)L.colmap[c];
-        for (uint32_t e = 0; e < E; ++e) L.e_col[e] = (uint32_t)L.cnext[L.e_col[e]];
-        for (uint32_t c = 0; c < C; ++c) { L.colmap[c] = (uint32_t)L.pred[c]; L.v[c] = 0; L.cmatch[c] = -1; L.cstamp[c] = 0; L.cscan[c] = 0; }
-        sa_assign_ws w;
-        w.e_cnt = L.e_cnt; w.e_col = L.e_col; w.e_gain = L.e_gain; w.ecs = 1; w.egs = 1; w.rcs = 1; w.rgs = 1; w.estride = 0; w.e_off = L.e_off;
-        w.excluded = nullptr;
-        w.next_row = L.next_row;
-        w.u = L.u; w.v = L.v; w.rmatch = L.rmatch; w.cmatch = L.cmatch; w.dist = L.dist; w.pred = L.pred;
-        w.cstamp = L.cstamp; w.cscan = L.cscan; w.cnext = L.cnext; w.rdist = L.rdist; w.rnext = L.rnext;
-        sa_assign_component(w, 0);
-        for (uint32_t r = 0; r < R; ++r) {
-          const int32_t c = L.rmatch[r];
-          finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
-        }
-      } else big = true;
     }
   }
-  // components that did not fit a lane's private block go onto the dense solver's queue (k_assign_dense, the next launch)
-  if (big) S.dq[atomicAdd((uint32_t*)(S.stats + 3), 1u)] = q;
-}
-
-// General tail, kernel 3 of 3: the components k_assign_solve queued (more than 8 rows, 12 columns or 24 usable edges), one workgroup
-// per component at a time, by the dense solver of sa_dense.h.  NT threads, CPT columns per thread (T <= NT * CPT).  Per component:
-//   rows ascending (ballot compaction of the scene's row labels) -> greedy start: every row bids for the column of its heaviest
-//   usable edge (global atomic minimum on cwin, SA_NONE between frames), its gains go into the dense matrix, u = -(heaviest gain)
-//   -> rows that lost their bid are the search roots (ascending) -> sa_assign_component_dense -> results, matrix and bids wiped.
-// Per-row duals / matches and per-column matches / predecessors: LDS when 12 N + 8 T bytes fit (LDS_STATE), else the scene's
-// arrays in HBM — the workgroup's own L1 keeps them coherent between its waves, __syncthreads orders them.
-template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
-__global__ __launch_bounds__(NT) void k_assign_dense(const SceneDev* __restrict__ scenes) {
-  const SceneDev S = scenes[blockIdx.z];
+  if (big) s_big[atomicAdd(&s_nbig, 1u)] = q;
+  __syncthreads();
+  const uint32_t nbig = s_nbig;
+  if (nbig == 0) return;
+  // this workgroup's big components, one after the other, all its threads on each
   const uint32_t N = S.N, T = S.T;
-  const uint32_t nq = S.stats[3];
-  if (nq == 0) return;
-  extern __shared__ unsigned char s_dyn[];
-  __shared__ unsigned long long s_part[2 * (NT / 64)];
-  __shared__ uint32_t s_take, s_base[2], s_cnt[2];
-  const uint32_t q = threadIdx.x, lane = q & 63u;
   int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
   int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
   int32_t* cmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12) : (int32_t*)S.cmatch;
   int32_t* pred = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12 + (size_t)T * 4) : (int32_t*)S.pred;
   if (LDS_STATE) {  // (the HBM arrays were reset by the frame's preparation blocks)
-    for (uint32_t i = q; i < N; i += NT) rmatch[i] = -1;
-    for (uint32_t i = q; i < T; i += NT) cmatch[i] = -1;
+    for (uint32_t i = threadIdx.x; i < N; i += NT) rmatch[i] = -1;
+    for (uint32_t i = threadIdx.x; i < T; i += NT) cmatch[i] = -1;
+    __syncthreads();
   }
-  const uint8_t SA_G* excl = VISUAL ? S.col_excluded : nullptr;
-  for (;;) {
-    __syncthreads();
-    if (q == 0) s_take = atomicAdd((uint32_t*)(S.stats + 4), 1u);
-    __syncthreads();
-    const uint32_t k = s_take;
-    if (k >= nq) break;
-    const uint32_t root = S.dq[k];
-    const uint32_t R = (uint32_t)S.rnext[root];  // rows of the component (k_assign_label)
-    if (q == 0) s_base[0] = atomicAdd((uint32_t*)(S.stats + 1), R);
-    __syncthreads();
-    uint32_t* rows = (uint32_t*)S.big_rows + s_base[0];   // the component's rows, then (in place of the matched ones) its search roots
-    if (q < 64) {  // eight label loads in flight per lane: the scan is a chain of L2 round trips otherwise
-      uint32_t cnt = 0;
-      for (uint32_t r0 = 0; r0 < N; r0 += 512) {
-        uint32_t lb8[8];
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-          const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
-          lb8[k2] = row < N ? S.lab[row] : SA_NONE;
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-          const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
-          const bool f = row < N && lb8[k2] == root;
-          const unsigned long long m = __ballot(f);
-          if (f) rows[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
-          cnt += (uint32_t)__popcll(m);
-        }
-      }
-    }
-    if (q == 0) s_cnt[1] = 0;  // the component's heaviest gain
-    __syncthreads();
-    // greedy start: bids, duals, gains into the dense matrix
-    for (uint32_t i = q; i < R; i += NT) {
-      const uint32_t row = rows[i];
-      const uint32_t ne = S.e_use[row];
-      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-      int64_t SA_G* drow = S.dense + (size_t)row * T;
-      int64_t maxg = 0;
-      uint32_t bcol = SA_NONE;
-      for (uint32_t e0 = 0; e0 < ne; e0 += 4) {  // four records (and their exclusion flags) per round trip
-        SaEdge ed[4];
-        bool use[4];
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(excl && excl[ed[k2].col]);
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-          if (!use[k2]) continue;
-          drow[ed[k2].col] = ed[k2].gain;
-          if (ed[k2].gain > maxg || (ed[k2].gain == maxg && ed[k2].col < bcol)) { maxg = ed[k2].gain; bcol = ed[k2].col; }
-        }
-      }
-      u[row] = -maxg;
-      S.big_bcol[row] = bcol;
-      if (bcol != SA_NONE) atomicMin((uint32_t*)(S.cwin + bcol), row);
-      if (maxg > 0) atomicMax(&s_cnt[1], maxg > 0x7fffffffll ? 0x7fffffffu : (uint32_t)maxg);
-    }
-    __syncthreads();
-    if (q < 64) {  // matched rows keep their bid; the others become the search roots, ascending, compacted in place
-      uint32_t nroots = 0;
-      for (uint32_t i0 = 0; i0 < R; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        bool pend = false;
-        uint32_t row = 0;
-        if (i < R) {
-          row = rows[i];
-          const uint32_t bc = S.big_bcol[row];
-          if (bc != SA_NONE) {
-            if (__hip_atomic_load((uint32_t*)(S.cwin + bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == row) { rmatch[row] = (int32_t)bc; cmatch[bc] = (int32_t)row; }
-            else pend = true;
-          }
-        }
-        const unsigned long long m = __ballot(pend);
-        // (position nroots + rank <= i: a root never overwrites an entry that has not been read yet; all lanes of this step have read theirs)
-        if (pend) rows[nroots + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = row;
-        nroots += (uint32_t)__popcll(m);
-      }
-      if (lane == 0) s_cnt[0] = nroots;
-    }
-    __syncthreads();
-    {
-      sa_dense_ws w;
-      w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
-      w.u = u; w.rmatch = rmatch; w.cmatch = cmatch; w.pred = pred; w.part = s_part;
-      bool k32 = false;
-      if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) k32 = s_cnt[1] <= (uint32_t)SA_DENSE_K32_MAXGAIN;
-      if constexpr ((uint32_t)NT * CPT <= SA_DENSE_K32_MAXT) {
-        if (k32) sa_assign_component_dense<NT, CPT, true>(w, rows, s_cnt[0]);
-      }
-      if (!k32) sa_assign_component_dense<NT, CPT, false>(w, rows, s_cnt[0]);
-    }
-    // results; matrix, bids and (LDS) matches wiped for the next component / frame.  The rows list was overwritten by the roots:
-    // walk the scene's labels again.
-    for (uint32_t row = q; row < N; row += NT) {
-      if (S.lab[row] != root) continue;
-      const int32_t c = rmatch[row];
-      finalize_row_with<VISUAL>(S, row, c);
-      const uint32_t ne = S.e_use[row];
-      const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-      int64_t SA_G* drow = S.dense + (size_t)row * T;
-      for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
-        uint32_t cj[4];
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) cj[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2).col : 0u;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2)
-          if (e0 + k2 < ne) drow[cj[k2]] = 0;
-      }
-      const uint32_t bc = S.big_bcol[row];
-      if (bc != SA_NONE) S.cwin[bc] = SA_NONE;
-      if (LDS_STATE) {
-        if (c >= 0) cmatch[c] = -1;
-        rmatch[row] = -1;
-      }
-    }
-  }
+  for (uint32_t k = 0; k < nbig; ++k) dense_solve_component<VISUAL, NT, CPT, LDS_STATE>(S, s_big[k], u, rmatch, cmatch, pred, s_part, s_word);
 }
 
 // =====================================================================================================
@@ -1215,48 +1292,42 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
   else SA_LAUNCH(k_bestfit_resolve<false>, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
-// one instantiation of the dense kernel: the dynamic LDS limit is raised once per size class (above 64 KB it has to be asked for)
+// one instantiation of the general tail's solver: the dynamic LDS limit is raised once per size class (above 64 KB it has to be asked for)
 template <bool VIS, int NT, int CPT, bool LDS_STATE>
-static void launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static void launch_solve_one(dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
   if (LDS_STATE) {
     static size_t allowed = 0;
     if (lds > allowed) {
-      hipFuncSetAttribute((const void*)k_assign_dense<VIS, NT, CPT, LDS_STATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)k_assign_solve<VIS, NT, CPT, LDS_STATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       allowed = lds;
     }
   }
-  SA_LAUNCH((k_assign_dense<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes);
+  SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes);
 }
 template <int NT, int CPT>
-static void launch_dense(bool vis, bool in_lds, dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
-  if (vis && in_lds) launch_dense_one<true, NT, CPT, true>(grid, lds, st, scenes);
-  else if (vis) launch_dense_one<true, NT, CPT, false>(grid, lds, st, scenes);
-  else if (in_lds) launch_dense_one<false, NT, CPT, true>(grid, lds, st, scenes);
-  else launch_dense_one<false, NT, CPT, false>(grid, lds, st, scenes);
+static void launch_solve(bool vis, bool in_lds, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+  const dim3 grid(cdiv(maxN, NT), 1, ns);
+  if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, lds, st, scenes);
+  else if (vis) launch_solve_one<true, NT, CPT, false>(grid, lds, st, scenes);
+  else if (in_lds) launch_solve_one<false, NT, CPT, true>(grid, lds, st, scenes);
+  else launch_solve_one<false, NT, CPT, false>(grid, lds, st, scenes);
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                             hipStream_t st, int stage) {
   if (!maxN) return hipSuccess;
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    case 3:
-      if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH(k_assign_solve<true>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
-      else SA_LAUNCH(k_assign_solve<false>, dim3(cdiv(maxN, 64), 1, ns), dim3(64), 0, st, scenes);
-      break;
-    case 4: {
-      // the dense solver for the components k_assign_solve queued: a few workgroups per scene take them off the queue (a frame
-      // without any: every workgroup reads one word and leaves).  Columns per thread by the widest scene; the per-row / per-column
-      // state in LDS when it fits, else in the scene's HBM arrays.
-      if (!maxT) return hipSuccess;
+    case 3: {
+      // columns per thread of the dense solver by the widest scene; its per-row / per-column state in dynamic LDS when it fits beside
+      // the pool of private blocks, else in the scene's HBM arrays
       const bool vis = p.visual_kind != SA_VIS_NONE;
       const size_t lds = (size_t)maxN * 12 + (size_t)maxT * 8;
-      const bool in_lds = lds <= 144u * 1024u;
-      const dim3 grid(ns >= 16 ? 8u : ns >= 4 ? 16u : 64u, 1, ns);
-      if (maxT <= 256u * 4u) launch_dense<256, 4>(vis, in_lds, grid, lds, st, scenes);
-      else if (maxT <= 256u * 8u) launch_dense<256, 8>(vis, in_lds, grid, lds, st, scenes);
-      else if (maxT <= 256u * 16u) launch_dense<256, 16>(vis, in_lds, grid, lds, st, scenes);
-      else if (maxT <= 256u * 32u) launch_dense<256, 32>(vis, in_lds, grid, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) launch_dense<1024, 32>(vis, in_lds, grid, lds, st, scenes);
+      const bool in_lds = lds <= 96u * 1024u;
+      if (maxT <= 256u * 4u) launch_solve<256, 4>(vis, in_lds, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) launch_solve<256, 8>(vis, in_lds, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) launch_solve<256, 16>(vis, in_lds, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) launch_solve<256, 32>(vis, in_lds, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) launch_solve<1024, 32>(vis, in_lds, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
       break;
     }
