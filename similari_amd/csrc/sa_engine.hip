@@ -424,6 +424,9 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   }
   {  // the dense solver's matrix: zero between frames (the solver wipes what it wrote), established after (re)allocation
     void* before = s->dense.p;
+    // (a tracker's table grows by a few rows per frame: doubling instead of the usual quarter of slack — every regrowth of this
+    // one is a hipMalloc of megabytes plus a memset)
+    if (n * t * 8 > s->dense.cap && s->dense.cap) TRY(dev_ensure(e, s->dense, std::max(n * t * 8, 2 * s->dense.cap)));
     TRY(dev_ensure(e, s->dense, n * t * 8));
     if (s->dense.p != before) s->needs_init = true;
   }

@@ -1117,6 +1117,28 @@ def test_crowds_against_the_oracle(n, t, canvas, sigma):
     assert (ids != 0).sum() > 0.4 * min(n, t)
 
 
+@pytest.mark.parametrize("n,t", [(700, 700), (1300, 1200)])
+def test_mahalanobis_crowd_takes_the_64_bit_dense_solver(n, t):
+    """Mahalanobis gains are 1e8-scale (cost <= 100 / confidence, x 1e6): beyond the 32-bit variant of the dense solver.  A crowd with
+    genuine Kalman states on a small canvas — every detection inside the chi-square gate of dozens of tracks: components of hundreds
+    of rows — goes through the 64-bit keys and arithmetic (two-pass wave minima) of sa_assign_component_dense, in the one-workgroup
+    tail (700 x 700) and in the general one (1300 x 1200).  Cells and edges bit for bit, equal total gain (cells beyond the gate tie
+    at cost 0, so ids are not unique)."""
+    rng = np.random.default_rng(n + 3 * t)
+    sc = synth.sort_scene(rng, t, n, canvas=(700.0, 500.0))
+    kf = kf_states(rng, sc["track_boxes"])
+    m = min(n, t)
+    dets = synth.jitter_boxes(rng, kf[0][:m], 6.0)[rng.permutation(m)]
+    if n > m:
+        dets = np.concatenate([dets, synth.dense_boxes(rng, n - m, (700.0, 500.0))])
+    sc["det_boxes"] = dets
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.05, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc, kf=kf, require_ids=False)
+    assert (ids != 0).sum() > 0.5 * m
+    present = ~np.isnan(ref["positional"])
+    assert present.sum() > 20 * n, "the frame lost its density"
+
+
 @pytest.mark.parametrize("visual", ["cosine", "euclidean"])
 def test_dense_positional_stage_behind_a_visual_vote(visual):
     """VisualSORT on a pile: 35 % of the detections are new or below the quality gate, so the positional stage inherits hundreds of
