@@ -116,6 +116,7 @@ struct SceneDev {
   uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column (SA_NONE between frames)
   uint32_t SA_G* big_rows;   // [N] rows, then search roots, of the big components: one ascending segment each
   uint32_t SA_G* big_bcol;   // [N] the column a row bids for
+  uint32_t SA_G* dq;         // [N] roots of the big components of this frame (stats[3] of them), taken by ticket (stats[4])
   int64_t SA_G* dense;       // [N][T] gains of the components the dense solver (sa_dense.h) is working on; all zero between frames
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t SA_G* out_track_id;
@@ -123,7 +124,7 @@ struct SceneDev {
   int32_t SA_G* win_col;     // [N] winning track as a column of the table, -1 = none: what the device-side upkeep consumes
   int32_t SA_G* out_win;     // [N] the same, next to the results in mapped host memory (sa_batch_fetch_cols: a host that keeps its tracks in
                              // table order finds the winner without a hash lookup per candidate)
-  uint32_t SA_G* stats;      // [4] device words the first phase raises: [0] = 1 when the frame was ill-conditioned for the euclidean expansion
+  uint32_t SA_G* stats;      // [8] device words: [1] [3] [4] [5] the general tail's list top / queue length / ticket / row workgroups done; [0] = 1 when the frame was ill-conditioned for the euclidean expansion
   uint32_t SA_G* out_stats;  // [4] the same, moved next to the results (mapped host memory) and re-armed by the assignment tail
   int64_t SA_G* quant;  // optional N x T tap
   // SA_FLAG_TAP (parity tests): what the timed launches themselves produced, copied out by the assignment tail before it re-arms /

@@ -68,7 +68,7 @@ struct Slot {  // one scene of a request set
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
-  DevBuf lab, cwin, big_rows, big_bcol, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
+  DevBuf lab, cwin, big_rows, big_bcol, dq, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
   HostBuf h_apply, h_pred, h_fix;
@@ -421,6 +421,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->cwin, t * 4));
     TRY(dev_ensure(e, s->big_rows, n * 4));
     TRY(dev_ensure(e, s->big_bcol, n * 4));
+    TRY(dev_ensure(e, s->dq, n * 4));
   }
   {  // the dense solver's matrix: zero between frames (the solver wipes what it wrote), established after (re)allocation
     void* before = s->dense.p;
@@ -480,7 +481,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->quant = (decltype(d->quant))(s->quant.p);
   d->win_col = (decltype(d->win_col))(s->win_col.p);
   d->lab = (decltype(d->lab))(s->lab.p); d->cwin = (decltype(d->cwin))(s->cwin.p); d->big_rows = (decltype(d->big_rows))(s->big_rows.p);
-  d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dense = (decltype(d->dense))(s->dense.p);
+  d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dq = (decltype(d->dq))(s->dq.p); d->dense = (decltype(d->dense))(s->dense.p);
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
   d->out_win = (decltype(d->out_win))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16);
@@ -925,7 +926,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                         &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
-                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dense})
+                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dq, &s->dense})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_fix);

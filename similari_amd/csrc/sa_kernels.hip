@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 //   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
 //            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
 //   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a one-row
-//            component: its heaviest edge; up to 8 rows: one lane in a private block of LDS; larger: the whole workgroup with the
-//            dense solver of sa_dense.h).
+//            component: its heaviest edge; up to 8 rows: one lane in a private block of LDS; larger: onto the scene's queue, from
+//            which the launch's workgroups take them one each, with the dense solver of sa_dense.h).
 // =====================================================================================================
 // In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
 // thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
@@ -868,7 +868,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (q == 0) S.stats[1] = 0u;  // top of the dense solver's row lists
+  if (q == 0) { S.stats[1] = 0u; S.stats[3] = 0u; S.stats[4] = 0u; S.stats[5] = 0u; }  // the dense solver's: top of its row lists | queue length | next ticket | row workgroups done
   if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
@@ -1036,22 +1036,27 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 //     what the shortest-path search does for the first row of a component, without any search state;
 //   * up to 8 rows, 12 columns, 24 usable edges: gathered into a private block of LDS (from a pool of SL_POOL blocks per
 //     workgroup), solved there by the serial sa_assign_component, scattered back;
-//   * anything larger, or a small one that found the pool empty: onto the workgroup's own list, and after a barrier ALL its threads
-//     solve those one after the other with the dense solver (dense_solve_component) — no third launch.
+//   * anything larger, or a small one that found the pool empty: onto the SCENE's queue (S.dq).  When every row workgroup of the
+//     scene has said it is through with its rows, all workgroups of the scene — the row workgroups and the helper workgroups launched
+//     behind them, which do nothing else — take components off the queue by ticket, all threads of a workgroup on one component
+//     (dense_solve_component).  No third launch, and a crowd's dozens of mid-sized components are solved side by side (one
+//     workgroup per 256 rows solving its own one after the other: 263 us instead of 40 in the tracker loop's SORT frames).
 // Per-row duals / matches and per-column matches / predecessors of the dense solver: dynamic LDS when 12 N + 8 T bytes fit
 // (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
 #define SL_POOL 40
 template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
-__global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes) {
+__global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  const uint32_t q = blockIdx.x * NT + threadIdx.x;
+  const bool row_wg = blockIdx.x < row_wgs;  // (the workgroups behind them only take big components off the queue)
+  const uint32_t q = row_wg ? blockIdx.x * NT + threadIdx.x : 0xffffffffu;
   __shared__ SolveLocal s_local[SL_POOL];
   __shared__ unsigned long long s_part[2 * (NT / 64)];
-  __shared__ uint32_t s_big[NT], s_nbig, s_pool_top, s_word[4];
+  __shared__ uint32_t s_pool_top, s_word[4];
   extern __shared__ unsigned char s_dyn[];
-  if (threadIdx.x == 0) { s_nbig = 0; s_pool_top = 0; }
+  if (threadIdx.x == 0) s_pool_top = 0;
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
-  for (uint32_t i = q; i < S.N + S.T; i += gridDim.x * NT) S.parent[i] = i;
+  if (row_wg)
+    for (uint32_t i = q; i < S.N + S.T; i += row_wgs * NT) S.parent[i] = i;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
@@ -1196,22 +1201,44 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
       }
     }
   }
-  if (big) s_big[atomicAdd(&s_nbig, 1u)] = q;
+  // Big components go onto the scene's queue; a workgroup that is through with its rows says so, and once all of them have, every
+  // workgroup of the scene (the row workgroups and the helpers behind them) takes components off the queue, all its threads on one
+  // component at a time.  (The wait is for workgroups dispatched EARLIER in the same grid, which never wait themselves.)
+  if (row_wg) {
+    if (big) __hip_atomic_store((uint32_t*)S.dq + atomicAdd((uint32_t*)(S.stats + 3), 1u), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (queue entries and counters are agent-scope atomics: no cache maintenance — an agent-scope fence by every thread here costs
+    // 10 us at C4; everything else the takers read was written by earlier launches)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + 5), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load((uint32_t*)(S.stats + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs) __builtin_amdgcn_s_sleep(4);
+    s_word[3] = __hip_atomic_load((uint32_t*)(S.stats + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
-  const uint32_t nbig = s_nbig;
+  const uint32_t nbig = s_word[3];
   if (nbig == 0) return;
-  // this workgroup's big components, one after the other, all its threads on each
   const uint32_t N = S.N, T = S.T;
   int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
   int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
   int32_t* cmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12) : (int32_t*)S.cmatch;
   int32_t* pred = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12 + (size_t)T * 4) : (int32_t*)S.pred;
-  if (LDS_STATE) {  // (the HBM arrays were reset by the frame's preparation blocks)
-    for (uint32_t i = threadIdx.x; i < N; i += NT) rmatch[i] = -1;
-    for (uint32_t i = threadIdx.x; i < T; i += NT) cmatch[i] = -1;
+  bool fresh = true;
+  for (;;) {
     __syncthreads();
+    if (threadIdx.x == 0) s_word[3] = atomicAdd((uint32_t*)(S.stats + 4), 1u);
+    __syncthreads();
+    const uint32_t k = s_word[3];
+    if (k >= nbig) break;
+    if (LDS_STATE && fresh) {  // (the HBM arrays were reset by the frame's preparation blocks)
+      for (uint32_t i = threadIdx.x; i < N; i += NT) rmatch[i] = -1;
+      for (uint32_t i = threadIdx.x; i < T; i += NT) cmatch[i] = -1;
+      fresh = false;
+      __syncthreads();
+    }
+    const uint32_t root = __hip_atomic_load((uint32_t*)S.dq + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dense_solve_component<VISUAL, NT, CPT, LDS_STATE>(S, root, u, rmatch, cmatch, pred, s_part, s_word);
   }
-  for (uint32_t k = 0; k < nbig; ++k) dense_solve_component<VISUAL, NT, CPT, LDS_STATE>(S, s_big[k], u, rmatch, cmatch, pred, s_part, s_word);
 }
 
 // =====================================================================================================
@@ -1294,7 +1321,7 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
 }
 // one instantiation of the general tail's solver: the dynamic LDS limit is raised once per size class (above 64 KB it has to be asked for)
 template <bool VIS, int NT, int CPT, bool LDS_STATE>
-static void launch_solve_one(dim3 grid, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static void launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipStream_t st, const SceneDev* scenes) {
   if (LDS_STATE) {
     static size_t allowed = 0;
     if (lds > allowed) {
@@ -1302,15 +1329,19 @@ static void launch_solve_one(dim3 grid, size_t lds, hipStream_t st, const SceneD
       allowed = lds;
     }
   }
-  SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes);
+  SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes, row_wgs);
 }
 template <int NT, int CPT>
 static void launch_solve(bool vis, bool in_lds, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
-  const dim3 grid(cdiv(maxN, NT), 1, ns);
-  if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, lds, st, scenes);
-  else if (vis) launch_solve_one<true, NT, CPT, false>(grid, lds, st, scenes);
-  else if (in_lds) launch_solve_one<false, NT, CPT, true>(grid, lds, st, scenes);
-  else launch_solve_one<false, NT, CPT, false>(grid, lds, st, scenes);
+  // the row workgroups, and behind them helpers that only take big components off the scene's queue (a crowd has dozens; one
+  // workgroup per scene would solve them one after the other) — up to 64 workgroups per scene, fewer in a wide batch
+  const uint32_t rw = cdiv(maxN, NT);
+  const uint32_t want = ns >= 16 ? 8u : ns >= 4 ? 16u : 64u;
+  const dim3 grid(rw > want ? rw : want, 1, ns);
+  if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
+  else if (vis) launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
+  else if (in_lds) launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
+  else launch_solve_one<false, NT, CPT, false>(grid, rw, lds, st, scenes);
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                             hipStream_t st, int stage) {
