@@ -109,6 +109,12 @@ def workload(name: str, seed: int):
         sc = synth.sort_scene(rng, 1000, 1000, canvas=(1920.0, 1080.0))
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
         return cfg, [sc], "SORT IoU 1000 x 1000 on the C2 canvas (crowd: large components in the positional vote)"
+    if name == "sdt":
+        # not a BASELINE config: the frame a SORT tracker loop hands over in a crowd — 1000 detections against a table of 2500 tracks
+        # (live and idle ones): beyond the one-workgroup tail, dozens of components of 9..32 rows (the general tail's middle tier)
+        sc = synth.sort_scene(rng, 2500, 1000, canvas=(1920.0, 1080.0))
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+        return cfg, [sc], "SORT IoU 1000 detections x 2500 tracks on the C2 canvas (a tracker loop's crowd frame: general tail, mid-sized components)"
     if name == "c2n":
         # C2 with 15 % new objects and 10 % of the detections below the quality gate: the positional (Hungarian) stage has real
         # work after the visual vote inside the timed region
@@ -857,7 +863,7 @@ def main():
             ans = oracle_answers(cfg, scenes)
             same = np.concatenate([(g[0] == a[0]) & (g[1] == a[1]) for g, a in zip(got, ans)])
             out["match_vs_oracle"] = float(same.mean())
-        if world == 1 and facade is None and args.workload in ("giant", "bigpile", "bigcrowd", "sd"):
+        if world == 1 and facade is None and args.workload in ("giant", "bigpile", "bigcrowd", "sd", "sdt"):
             try:
                 out["cpu_solve_only"] = cpu_solve_only(cfg, scenes)
             except Exception as ex:

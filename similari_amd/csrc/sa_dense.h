@@ -27,7 +27,7 @@
 #define SA_WG_FN __device__ __forceinline__
 #define SA_WG_SLOTS(NT) 1
 #define SA_WG_SLOT(t) 0
-#define SA_WG_FOR(NT, t) for (uint32_t t [[maybe_unused]] = threadIdx.x, _sa_wg_once = 1; _sa_wg_once; _sa_wg_once = 0)
+#define SA_WG_FOR(NT, t) for (uint32_t t [[maybe_unused]] = threadIdx.x & (uint32_t)((NT) - 1), _sa_wg_once = 1; _sa_wg_once; _sa_wg_once = 0)
 #else
 #define SA_WG_FN inline
 #define SA_WG_SLOTS(NT) (NT)
@@ -114,8 +114,16 @@ __device__ __forceinline__ uint32_t sa_wg_min_u32(const uint32_t* key, unsigned 
   }
   return m;
 }
+// (NT == 64: ONE wavefront of a larger workgroup runs the solver on its own — its LDS accesses execute in program order, only the
+// compiler has to be kept from moving them across)
 template <int NT>
-__device__ __forceinline__ void sa_wg_sync() { __syncthreads(); }
+__device__ __forceinline__ void sa_wg_sync() {
+  if constexpr (NT == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else __syncthreads();
+}
 #else
 template <int NT>
 inline unsigned long long sa_wg_min_u64(const unsigned long long* key, unsigned long long*, uint32_t) {
@@ -150,7 +158,8 @@ struct sa_dense_ws {
 
 // Solves one component: `roots` = its rows the greedy start left unmatched (ascending), n_roots of them.  NT threads, thread t owns
 // the columns t, t + NT, ... (CPT of them: T <= NT * CPT).  Every thread must call it; control flow is uniform.  K32: the 32-bit
-// variant (the caller has checked SA_DENSE_K32_MAXGAIN and SA_DENSE_K32_MAXT).
+// variant (the caller has checked SA_DENSE_K32_MAXGAIN and SA_DENSE_K32_MAXT).  GAIN32 (with K32): w.gain points at int32_t cells
+// (the one-wavefront solver of the general tail keeps a component's matrix in LDS: NT = 64, CPT = 1, columns renumbered 0..63).
 // wave-uniform values the compiler cannot prove uniform (they come out of LDS): into a scalar register, so that the row's address and the
 // comparisons against it are scalar arithmetic
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -159,7 +168,7 @@ struct sa_dense_ws {
 #define SA_WG_UNIFORM(x) (x)
 #endif
 
-template <int NT, int CPT, bool K32>
+template <int NT, int CPT, bool K32, bool GAIN32 = false>
 SA_WG_FN void sa_assign_component_dense(const sa_dense_ws& w, const uint32_t* roots, uint32_t n_roots) {
   using D = typename std::conditional<K32, int32_t, int64_t>::type;              // duals, distances
   using KEY = typename std::conditional<K32, uint32_t, unsigned long long>::type;
@@ -214,7 +223,8 @@ SA_WG_FN void sa_assign_component_dense(const sa_dense_ws& w, const uint32_t* ro
         for (int c = 0; c < CPT; ++c) {
           const uint32_t j = t + (uint32_t)c * NT;
           const size_t at = (size_t)row * w.ld + (j < w.T ? j : 0u);
-          const D gv = K32 ? (D)((const int32_t*)w.gain)[2 * at] : (D)w.gain[at];   // (little endian: the low word of the i64 cell)
+          // (K32, little endian: the low word of the i64 cell; GAIN32: the matrix itself holds 32-bit cells)
+          const D gv = GAIN32 ? (D)((const int32_t*)w.gain)[at] : K32 ? (D)((const int32_t*)w.gain)[2 * at] : (D)w.gain[at];
           g[c] = j < w.T ? gv : (D)0;
         }
         KEY k = NONE;

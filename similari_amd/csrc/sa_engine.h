@@ -116,7 +116,7 @@ struct SceneDev {
   uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column (SA_NONE between frames)
   uint32_t SA_G* big_rows;   // [N] rows, then search roots, of the big components: one ascending segment each
   uint32_t SA_G* big_bcol;   // [N] the column a row bids for
-  uint32_t SA_G* dq;         // [N] roots of the big components of this frame (stats[3] of them), taken by ticket (stats[4])
+  uint32_t SA_G* dq;         // [2 N] the general tail's queues of this frame: roots of the big components, from N on those of the mid-sized ones
   int64_t SA_G* dense;       // [N][T] gains of the components the dense solver (sa_dense.h) is working on; all zero between frames
   // results: out_track_id[N] followed by out_vote[N] in one allocation (one D2H copy)
   uint64_t SA_G* out_track_id;

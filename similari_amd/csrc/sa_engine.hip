@@ -421,7 +421,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->cwin, t * 4));
     TRY(dev_ensure(e, s->big_rows, n * 4));
     TRY(dev_ensure(e, s->big_bcol, n * 4));
-    TRY(dev_ensure(e, s->dq, n * 4));
+    TRY(dev_ensure(e, s->dq, 2 * n * 4));
   }
   {  // the dense solver's matrix: zero between frames (the solver wipes what it wrote), established after (re)allocation
     void* before = s->dense.p;

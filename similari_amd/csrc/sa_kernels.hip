@@ -857,6 +857,16 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 // General tail, kernel 1 of 2: every participating row finds its component (root = minimum vertex, always a row) and
 // pushes itself onto that root's list — S.label[root] is the list head, S.next_row the links.  No O(N^2) scan for "the
 // next row of my component"; the push order is arbitrary and is put right by the solver thread.
+// The general tail's queue words live on their own 128-byte line of the scene's stats block: they are touched ONLY by agent-scope
+// atomics while k_assign_solve runs (workgroups on different XCDs), and stats[0] next door is read and written with plain
+// accesses by that kernel's first thread — a line held in one XCD's L2 by plain accesses and updated by other XCDs' atomics is
+// not something to rely on.
+#define SA_QW_TOP 32     // top of the dense solver's row lists
+#define SA_QW_LEN 33     // queue length
+#define SA_QW_TICKET 34  // next ticket
+#define SA_QW_DONE 35    // row workgroups through with their rows
+#define SA_QW_MLEN 36    // the same two for the queue of mid-sized components
+#define SA_QW_MTICKET 37
 __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -868,7 +878,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (q == 0) { S.stats[1] = 0u; S.stats[3] = 0u; S.stats[4] = 0u; S.stats[5] = 0u; }  // the dense solver's: top of its row lists | queue length | next ticket | row workgroups done
+  if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the dense solver's: top of its row lists | queue length | next ticket | row workgroups done
   if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
@@ -909,6 +919,188 @@ __device__ __forceinline__ void finalize_row_with(const SceneDev& S, uint32_t q,
   S.win_col[q] = win;
   S.out_win[q] = win;
 }
+
+// The general tail's MIDDLE tier: a component of up to ML_R rows (a knot of a crowd) is solved by ONE wavefront on a private block
+// of LDS.  The dense solver of the big tier reads a row of T gains from HBM and crosses a workgroup barrier per search step (~0.9 us
+// at 2000 tracks) however few columns the component has; here the component's distinct columns are renumbered in ascending track
+// order (a hash table in LDS finds them, a rank pass orders them — every index comparison of the solver keeps its outcome), its
+// gains become a [rows][128] (or, for at most 32 rows, [rows][256]) matrix of 32-bit cells in LDS and sa_assign_component_dense runs
+// with NT = 64 and 2 (4) columns per lane: a search step is an LDS read, a handful of VALU operations and a wave minimum.
+// Refused (-> the workgroup finishes it with the big tier's solver): more distinct usable columns than that, or a gain beyond the
+// 32-bit variant's bound.
+#define ML_R 64
+#define ML_WAVES 1u
+#define ML_C 256
+#define ML_CELLS 8192
+#define ML_H 512
+struct MidLocal {
+  int32_t gain[ML_CELLS];
+  int64_t u[ML_R];
+  int32_t rmatch[ML_R], cmatch[ML_C], pred[ML_C];  // (pred doubles as the bid words of the greedy start)
+  uint32_t rows[ML_R], cols[ML_C], hkey[ML_H], hval[ML_H], roots[ML_R];
+  uint32_t ckey[ML_C], cslot[ML_C];  // the occupied slots of the hash table, compacted: key | slot
+  uint32_t ncols, fail;
+};
+static_assert(sizeof(MidLocal) * ML_WAVES <= sizeof(SolveLocal) * 40, "the wavefronts' blocks lie over the pool of the small tier");
+__device__ __forceinline__ void sa_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// A big component's root onto the scene's queue.  The entry must have LANDED before this workgroup reports its rows done: a plain
+// (even atomic) store may still be in flight when the workgroup's barrier lets thread 0 signal — a returning exchange has been
+// performed at the coherence point when its result arrives, and using the result makes the wave wait for it.
+__device__ __forceinline__ void sa_queue_push(const SceneDev& S, uint32_t root, bool mid) {
+  const uint32_t at = atomicAdd((uint32_t*)(S.stats + (mid ? SA_QW_MLEN : SA_QW_LEN)), 1u) + (mid ? S.N : 0u);  // (dq: [N] big | [N] mid-sized)
+  const uint32_t old = __hip_atomic_exchange((uint32_t*)S.dq + at, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::"v"(old));
+}
+template <bool VISUAL>
+__device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t root, uint32_t R, MidLocal& M) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t N = S.N;
+  // rows, ascending: the labels from the root on (it is the component's lowest row), eight loads in flight per lane
+  {
+    uint32_t cnt = 0;
+    for (uint32_t r0 = root; r0 < N && cnt < R; r0 += 512) {
+      uint32_t lb8[8];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+        lb8[k2] = row < N ? S.lab[row] : SA_NONE;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
+        const bool f = row < N && lb8[k2] == root;
+        const unsigned long long m = __ballot(f);
+        const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (f && at < ML_R) M.rows[at] = row;
+        cnt += (uint32_t)__popcll(m);
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < ML_H / 64; ++h) M.hkey[lane + 64u * (uint32_t)h] = SA_NONE;
+#pragma unroll
+  for (int h = 0; h < ML_C / 64; ++h) { M.cmatch[lane + 64u * (uint32_t)h] = -1; M.pred[lane + 64u * (uint32_t)h] = (int32_t)0x7fffffff; }
+  if (lane == 0) { M.ncols = 0; M.fail = 0; }
+  sa_wave_sync();
+  // pass 1 over the edges (lane = row): the distinct usable columns into the hash table
+  const uint32_t row = lane < R ? M.rows[lane] : 0u;
+  const uint32_t ne = lane < R ? S.e_use[row] : 0u;
+  const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
+  for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+    SaEdge ed[4];
+    bool use[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      if (!use[k2]) continue;
+      if (ed[k2].gain > (int64_t)SA_DENSE_K32_MAXGAIN) { M.fail = 1; continue; }
+      const uint32_t col = ed[k2].col;
+      uint32_t slot = (col * 2654435761u) >> 23;
+      bool placed = false;
+      for (uint32_t probe = 0; probe < ML_H; ++probe) {
+        const uint32_t old = atomicCAS(&M.hkey[slot], SA_NONE, col);
+        if (old == SA_NONE) { if (atomicAdd(&M.ncols, 1u) >= ML_C) M.fail = 1; placed = true; break; }
+        if (old == col) { placed = true; break; }
+        slot = (slot + 1u) & (ML_H - 1u);
+      }
+      if (!placed) M.fail = 1;
+    }
+    if (*(volatile uint32_t*)&M.fail) break;
+  }
+  sa_wave_sync();
+  if (__builtin_amdgcn_readfirstlane((int)M.fail)) return false;  // (one word, every lane reads the same: uniform for the compiler too)
+  const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.ncols);
+  const uint32_t ldc = C <= 128u ? 128u : 256u;   // the matrix: [R][128], or [R][256] when the rows allow it
+  if (R * ldc > ML_CELLS) return false;
+  // the columns in ascending order of their track index: the occupied slots compacted, every key ranked among them
+  {
+    uint32_t base = 0;
+#pragma unroll
+    for (int h = 0; h < ML_H / 64; ++h) {
+      const uint32_t sl = lane + 64u * (uint32_t)h;
+      const uint32_t key = M.hkey[sl];
+      const unsigned long long m = __ballot(key != SA_NONE);
+      if (key != SA_NONE) {
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        M.ckey[at] = key;
+        M.cslot[at] = sl;
+      }
+      base += (uint32_t)__popcll(m);
+    }
+  }
+  for (uint32_t i = lane; i < R * (ldc / 4); i += 64) ((uint4*)M.gain)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t i = lane; i < ML_C; i += 64)
+    if (i >= C) M.ckey[i] = SA_NONE;   // (padding of the rank loop's vector reads: the largest word, never below a key)
+  sa_wave_sync();
+  for (uint32_t i = lane; i < C; i += 64) {
+    const uint32_t key = M.ckey[i];
+    uint32_t rank = 0;
+    for (uint32_t x = 0; x < C; x += 4) {
+      const uint4 o = *(const uint4*)&M.ckey[x];
+      rank += (o.x < key) + (o.y < key) + (o.z < key) + (o.w < key);
+    }
+    M.hval[M.cslot[i]] = rank;
+    M.cols[rank] = key;
+  }
+  sa_wave_sync();
+  // pass 2: gains into the matrix, the row's dual and its bid (heaviest usable edge, lowest column on ties)
+  int32_t maxg = 0, bj = -1;
+  for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+    SaEdge ed[4];
+    bool use[4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      if (!use[k2]) continue;
+      const uint32_t col = ed[k2].col;
+      uint32_t slot = (col * 2654435761u) >> 23;
+      while (M.hkey[slot] != col) slot = (slot + 1u) & (ML_H - 1u);  // (present: pass 1 placed it)
+      const int32_t j = (int32_t)M.hval[slot];
+      const int32_t g = (int32_t)ed[k2].gain;
+      M.gain[lane * ldc + (uint32_t)j] = g;
+      if (g > maxg || (g == maxg && j < bj)) { maxg = g; bj = j; }
+    }
+  }
+  if (lane < R) {
+    M.u[lane] = -(int64_t)maxg;
+    M.rmatch[lane] = -1;
+    if (bj >= 0) atomicMin((uint32_t*)&M.pred[bj], lane);
+  }
+  sa_wave_sync();
+  // greedy start: the lowest row bidding for a column has it; the others are the search roots, ascending
+  bool pend = false;
+  if (lane < R && bj >= 0) {
+    if ((uint32_t)M.pred[bj] == lane) { M.rmatch[lane] = bj; M.cmatch[bj] = (int32_t)lane; }
+    else pend = true;
+  }
+  const unsigned long long pm = __ballot(pend);
+  if (pend) M.roots[__popcll(pm & ((1ull << lane) - 1ull))] = lane;
+  const uint32_t n_roots = (uint32_t)__popcll(pm);
+  sa_wave_sync();
+  if (n_roots) {
+    sa_dense_ws w;
+    w.gain = (const int64_t*)M.gain; w.ld = ldc; w.T = ldc;
+    w.u = M.u; w.rmatch = M.rmatch; w.cmatch = M.cmatch; w.pred = M.pred; w.part = nullptr;
+    if (ldc == 128u) sa_assign_component_dense<64, 2, true, true>(w, M.roots, n_roots);
+    else sa_assign_component_dense<64, 4, true, true>(w, M.roots, n_roots);
+  }
+  if (lane < R) {
+    const int32_t c = M.rmatch[lane];
+    finalize_row_with<VISUAL>(S, row, c >= 0 ? (int32_t)M.cols[c] : -1);
+  }
+  sa_wave_sync();
+  return true;
+}
 // One big component by the dense solver of sa_dense.h, all NT threads of the workgroup on it.  rows ascending (ballot compaction of
 // the scene's row labels) -> greedy start: every row bids for the column of its heaviest usable edge (global atomic minimum on cwin,
 // SA_NONE between frames), its gains go into the dense matrix, u = -(heaviest gain) -> rows that lost their bid are the search roots
@@ -920,7 +1112,7 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
   const uint32_t q = threadIdx.x, lane = q & 63u;
   const uint8_t SA_G* excl = VISUAL ? S.col_excluded : nullptr;
   const uint32_t R = (uint32_t)S.rnext[root];  // rows of the component (k_assign_label)
-  if (q == 0) { s_word[0] = atomicAdd((uint32_t*)(S.stats + 1), R); s_word[2] = 0; }  // its segment of the row lists | heaviest gain
+  if (q == 0) { s_word[0] = atomicAdd((uint32_t*)(S.stats + SA_QW_TOP), R); s_word[2] = 0; }  // its segment of the row lists | heaviest gain
   __syncthreads();
   uint32_t* rows = (uint32_t*)S.big_rows + s_word[0];   // the component's rows, then (in place of the matched ones) its search roots
   if (q < 64) {  // eight label loads in flight per lane: the scan is a chain of L2 round trips otherwise
@@ -1045,15 +1237,24 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 // (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
 #define SL_POOL 40
 template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
-__global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs) {
+__global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs_) {
+  const uint32_t row_wgs = row_wgs_ & 0x7fffffffu;
+  const bool no_mid = row_wgs_ >> 31;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
+  // One lane gathering a component is a chain of dependent trips to L2 / memory — the list walk, then every row's count and
+  // records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker loop's crowd
+  // frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool keeps components of two rows
+  // (C4 has hundreds: a wavefront each would cost more); without it (Mahalanobis) everything that fits.
+  const uint32_t pool_r = no_mid ? SL_R : 2u;
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const bool row_wg = blockIdx.x < row_wgs;  // (the workgroups behind them only take big components off the queue)
   const uint32_t q = row_wg ? blockIdx.x * NT + threadIdx.x : 0xffffffffu;
-  __shared__ SolveLocal s_local[SL_POOL];
+  __shared__ union { SolveLocal pool[SL_POOL]; MidLocal mid[ML_WAVES]; } s_sh;  // (the middle tier runs after the small one, over its pool)
+  SolveLocal* const s_local = s_sh.pool;
   __shared__ unsigned long long s_part[2 * (NT / 64)];
-  __shared__ uint32_t s_pool_top, s_word[4];
+  __shared__ uint32_t s_pool_top, s_word[6], s_fail[NT], s_nfail[ML_WAVES];
   extern __shared__ unsigned char s_dyn[];
   if (threadIdx.x == 0) s_pool_top = 0;
+  if (threadIdx.x < ML_WAVES) s_nfail[threadIdx.x] = 0;
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
   if (row_wg)
     for (uint32_t i = q; i < S.N + S.T; i += row_wgs * NT) S.parent[i] = i;
@@ -1062,7 +1263,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     S.stats[0] = 0u;
   }
   __syncthreads();
-  bool big = false;
+  bool big = false, mid = false;
   if (q < S.N) {
     // Everything a one-row component needs, requested TOGETHER: what the previous kernels wrote lies in other XCDs' L2s, so each
     // dependent load of this thread is a trip to memory (~1.5 us); the row's first four edge records are fetched before their count
@@ -1133,7 +1334,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
         }
         finalize_row_with<VISUAL>(S, row, bj);
       } else {
-        bool fits = R <= SL_R;
+        bool fits = R <= pool_r;
         uint32_t blk = SA_NONE;
         if (fits) {
           blk = atomicAdd(&s_pool_top, 1u);
@@ -1197,47 +1398,83 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
             const int32_t c = L.rmatch[r];
             finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
           }
-        } else big = true;
+        } else if (R <= ML_R && !no_mid) mid = true;
+        else big = true;
       }
     }
   }
-  // Big components go onto the scene's queue; a workgroup that is through with its rows says so, and once all of them have, every
-  // workgroup of the scene (the row workgroups and the helpers behind them) takes components off the queue, all its threads on one
-  // component at a time.  (The wait is for workgroups dispatched EARLIER in the same grid, which never wait themselves.)
+  // Components beyond the pool go onto one of the scene's two queues: mid-sized ones (up to ML_R rows) for single wavefronts, the rest
+  // for whole workgroups.  A workgroup that is through with its rows says so, and once all of them have, EVERY workgroup of the
+  // scene — the row workgroups and the helpers launched behind them — takes big components by ticket (all its threads on one
+  // component), then its first two wavefronts take mid-sized ones by ticket, and at the end the workgroup finishes what its own
+  // wavefronts had to refuse.  (The wait is for workgroups dispatched EARLIER in the same grid, which never wait themselves.)
   if (row_wg) {
-    if (big) __hip_atomic_store((uint32_t*)S.dq + atomicAdd((uint32_t*)(S.stats + 3), 1u), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (big) sa_queue_push(S, q, false);
+    if (mid) sa_queue_push(S, q, true);
     // (queue entries and counters are agent-scope atomics: no cache maintenance — an agent-scope fence by every thread here costs
     // 10 us at C4; everything else the takers read was written by earlier launches)
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + 5), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_DONE), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load((uint32_t*)(S.stats + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs) __builtin_amdgcn_s_sleep(4);
-    s_word[3] = __hip_atomic_load((uint32_t*)(S.stats + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs) __builtin_amdgcn_s_sleep(4);
+    s_word[3] = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_word[4] = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const uint32_t nbig = s_word[3];
-  if (nbig == 0) return;
+  const uint32_t nbig = s_word[3], nmid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_word[4]);
+  if (nbig == 0 && nmid == 0) return;
   const uint32_t N = S.N, T = S.T;
   int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
   int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
   int32_t* cmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12) : (int32_t*)S.cmatch;
   int32_t* pred = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12 + (size_t)T * 4) : (int32_t*)S.pred;
   bool fresh = true;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_word[3] = atomicAdd((uint32_t*)(S.stats + 4), 1u);
-    __syncthreads();
-    const uint32_t k = s_word[3];
-    if (k >= nbig) break;
+  auto dense_one = [&](uint32_t root) {  // (every thread of the workgroup, uniformly)
     if (LDS_STATE && fresh) {  // (the HBM arrays were reset by the frame's preparation blocks)
       for (uint32_t i = threadIdx.x; i < N; i += NT) rmatch[i] = -1;
       for (uint32_t i = threadIdx.x; i < T; i += NT) cmatch[i] = -1;
       fresh = false;
       __syncthreads();
     }
-    const uint32_t root = __hip_atomic_load((uint32_t*)S.dq + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     dense_solve_component<VISUAL, NT, CPT, LDS_STATE>(S, root, u, rmatch, cmatch, pred, s_part, s_word);
+  };
+  if (nbig)
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_word[3] = atomicAdd((uint32_t*)(S.stats + SA_QW_TICKET), 1u);
+      __syncthreads();
+      const uint32_t k = s_word[3];
+      if (k >= nbig) break;
+      dense_one(__hip_atomic_load((uint32_t*)S.dq + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  if (nmid == 0) return;
+  // Middle tier.  Everything in this loop is wave-uniform BY CONSTRUCTION — the ticket is taken without a branch (lane 0 adds one, the
+  // others zero), indices go through readfirstlane, a refusal is recorded by every lane writing the same word: a lane-divergent
+  // branch before the back edge lets the compiler keep the two groups of lanes apart across iterations, and the group without lane
+  // 0 then never sees a new ticket (seen: a refusal pushed by `if (lane == 0)` inside such a loop hung the workgroup).
+  __syncthreads();  // (the pool of the small tier is free: the wavefronts' blocks lie over it)
+  {
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t nref = 0;
+    if (wv < ML_WAVES) {
+      for (;;) {
+        const uint32_t tk = atomicAdd((uint32_t*)(S.stats + SA_QW_MTICKET), (threadIdx.x & 63u) == 0 ? 1u : 0u);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        if (k >= nmid) break;
+        const uint32_t root = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.rnext[root]);
+        const bool ok = mid_solve_component<VISUAL>(S, root, R, s_sh.mid[wv]);
+        s_fail[wv * (NT / ML_WAVES) + nref] = root;
+        nref += ok ? 0u : 1u;
+      }
+      if ((threadIdx.x & 63u) == 0) s_nfail[wv] = nref;
+    }
+  }
+  __syncthreads();
+  for (uint32_t w2 = 0; w2 < ML_WAVES; ++w2) {
+    const uint32_t nf = s_nfail[w2];
+    for (uint32_t i = 0; i < nf; ++i) dense_one(s_fail[w2 * (NT / ML_WAVES) + i]);
   }
 }
 
@@ -1332,12 +1569,13 @@ static void launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipStream_
   SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes, row_wgs);
 }
 template <int NT, int CPT>
-static void launch_solve(bool vis, bool in_lds, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static void launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
   // the row workgroups, and behind them helpers that only take big components off the scene's queue (a crowd has dozens; one
   // workgroup per scene would solve them one after the other) — up to 64 workgroups per scene, fewer in a wide batch
-  const uint32_t rw = cdiv(maxN, NT);
+  const uint32_t rows = cdiv(maxN, NT);
   const uint32_t want = ns >= 16 ? 8u : ns >= 4 ? 16u : 64u;
-  const dim3 grid(rw > want ? rw : want, 1, ns);
+  const dim3 grid(rows > want ? rows : want, 1, ns);
+  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u);  // (bit 31: no middle tier)
   if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
   else if (vis) launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
   else if (in_lds) launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
@@ -1354,11 +1592,12 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const bool vis = p.visual_kind != SA_VIS_NONE;
       const size_t lds = (size_t)maxN * 12 + (size_t)maxT * 8;
       const bool in_lds = lds <= 96u * 1024u;
-      if (maxT <= 256u * 4u) launch_solve<256, 4>(vis, in_lds, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 8u) launch_solve<256, 8>(vis, in_lds, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 16u) launch_solve<256, 16>(vis, in_lds, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 32u) launch_solve<256, 32>(vis, in_lds, maxN, ns, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) launch_solve<1024, 32>(vis, in_lds, maxN, ns, lds, st, scenes);
+      const bool no_mid = p.positional_kind == SA_POS_MAHALANOBIS;  // gains of 1e8: beyond the middle tier's 32-bit cells
+      if (maxT <= 256u * 4u) launch_solve<256, 4>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) launch_solve<256, 8>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) launch_solve<256, 16>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) launch_solve<256, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) launch_solve<1024, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
       break;
     }

@@ -280,7 +280,7 @@ int emu_assign_coop(uint32_t N, uint32_t T, const float* pos, int64_t threshold_
 // usable edges, union-find, duals u = -(heaviest usable gain), greedy start, and then — for EVERY component with search roots
 // (min_roots = 1) or only those with at least min_roots of them (the others go to the wavefront-cooperative solver, as on the
 // device) — the component's gains scattered into a dense N x T matrix (excluded columns never written), its roots ascending,
-// sa_assign_component_dense<NT, CPT, K32>, and the matrix wiped again.  nt_cpt: 1 = 256 threads x 4 columns, 2 = 16 x 8, 3 = 256 x 8;
+// sa_assign_component_dense<NT, CPT, K32>, and the matrix wiped again.  nt_cpt: 1 = 256 threads x 4 columns, 2 = 16 x 8, 3 = 256 x 8, 4 = 64 x 2 / 5 = 64 x 4 on 32-bit cells (T <= 128 / 256: the one-wavefront form);
 // + 16 = the 64-bit variant even where the 32-bit one applies.
 int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold_q, const uint8_t* row_skip, const uint8_t* col_skip,
                      int nt_cpt, uint32_t min_roots, int32_t* rmatch_out, int64_t* total_gain) {
@@ -335,6 +335,23 @@ int emu_assign_dense(uint32_t N, uint32_t T, const float* pos, int64_t threshold
     case 1: if (T > 256 * 4) return -21; dense_solve_all<256, 4>(w, cw, comps, min_roots, k32); break;
     case 2: if (T > 16 * 8) return -21; dense_solve_all<16, 8>(w, cw, comps, min_roots, k32); break;
     case 3: if (T > 256 * 8) return -21; dense_solve_all<256, 8>(w, cw, comps, min_roots, k32); break;
+    case 4: case 5: {  // the one-wavefront form of the general tail's middle tier: 128 (256) columns, 32-bit cells
+      const uint32_t ldc = (nt_cpt & 15) == 4 ? 128u : 256u;
+      if (T > ldc || !k32) return -21;
+      std::vector<int32_t> g32((size_t)N * ldc, 0), cm(ldc, -1), pr(ldc, 0);
+      for (uint32_t q = 0; q < N; ++q)
+        for (uint32_t t = 0; t < T; ++t) g32[(size_t)q * ldc + t] = (int32_t)dense[(size_t)q * T + t];
+      for (uint32_t t = 0; t < T; ++t) cm[t] = cmatch[t];
+      sa_dense_ws w2 = w;
+      w2.gain = (const int64_t*)g32.data(); w2.ld = ldc; w2.T = ldc; w2.cmatch = cm.data(); w2.pred = pr.data();
+      for (const auto& roots : comps) {
+        if (roots.empty()) continue;
+        if (ldc == 128u) sa_assign_component_dense<64, 2, true, true>(w2, roots.data(), (uint32_t)roots.size());
+        else sa_assign_component_dense<64, 4, true, true>(w2, roots.data(), (uint32_t)roots.size());
+      }
+      for (uint32_t t = 0; t < T; ++t) cmatch[t] = cm[t];
+      break;
+    }
     default: return -20;
   }
   int64_t tot = 0;

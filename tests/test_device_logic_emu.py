@@ -432,6 +432,30 @@ def test_dense_assignment_reaches_dense_optimum(density, shape):
         np.testing.assert_array_equal(rm_mix, ref)
 
 
+@pytest.mark.parametrize("shape", [4, 5])
+@pytest.mark.parametrize("density", [0.05, 0.3, 1.0])
+def test_dense_assignment_one_wavefront_form(density, shape):
+    """The general tail's middle tier: sa_assign_component_dense<64, 2 | 4> on a [rows][128 | 256] matrix of 32-bit cells (one
+    wavefront, the component's columns renumbered).  Same matchings as the dense kuhn_munkres and as the 256-thread form; ties
+    break alike."""
+    rng = np.random.default_rng(int(density * 100) + 4000 + shape)
+    thr_q = 300000
+    for trial in range(30):
+        N, T = int(rng.integers(1, 64 if shape == 4 else 33)), int(rng.integers(1, 129 if shape == 4 else 257))
+        pos = rng.uniform(0.05, 1.0, (N, T)).astype(np.float32)
+        pos[rng.uniform(size=(N, T)) > density] = np.nan
+        rm, gain = run_emu_assign_dense(pos, thr_q, shape)
+        total, ref, _ = dense_reference(pos, thr_q)
+        assert gain + N * thr_q == total
+        np.testing.assert_array_equal(rm, ref)
+        pt = (rng.integers(1, 6, (N, T)) / 5.0).astype(np.float32)
+        pt[rng.uniform(size=(N, T)) > max(density, 0.3)] = np.nan
+        rm_t, gain_t = run_emu_assign_dense(pt, thr_q, shape)
+        rm_w, gain_w = run_emu_assign_dense(pt, thr_q, 1)
+        assert gain_t == gain_w
+        np.testing.assert_array_equal(rm_t, rm_w)
+
+
 @pytest.mark.parametrize("shape,n,t", [(1, 300, 320), (3, 640, 700), (19, 640, 700), (1, 1024, 1024)])
 def test_dense_assignment_one_giant_component(shape, n, t):
     """All boxes on one pile under a low threshold: one component of hundreds of rows, half of all cells usable, most greedy bids

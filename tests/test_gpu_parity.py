@@ -1117,6 +1117,59 @@ def test_crowds_against_the_oracle(n, t, canvas, sigma):
     assert (ids != 0).sum() > 0.4 * min(n, t)
 
 
+@pytest.mark.parametrize("oriented", [False, True])
+@pytest.mark.parametrize("n,t,canvas,sigma", [(1000, 2500, (1920.0, 1080.0), 2.0), (1500, 1300, (1920.0, 1080.0), 8.0), (1100, 1100, (1300.0, 900.0), 5.0)])
+def test_general_tail_mid_sized_components_against_the_oracle(n, t, canvas, sigma, oriented):
+    """A tracker loop's crowd frames beyond the one-workgroup tail: hundreds of components, dozens of them with 9..32 rows — the
+    general tail's middle tier (one wavefront per component on a [rows][64] matrix in LDS, columns renumbered through a hash
+    table), next to one-row components, pooled small ones and, on the denser frames, components that overflow 32 rows or 64
+    columns and go to the scene's queue."""
+    sc = synth.sort_scene(np.random.default_rng(n + 7 * t + int(oriented)), t, n, canvas=canvas, oriented=oriented, pos_sigma=sigma)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3 if canvas[0] > 1500 else 0.15, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc)
+    assert (ids != 0).sum() > 0.4 * min(n, t)
+
+
+def test_middle_tier_refusals_go_to_the_queue():
+    """Components the middle tier has to refuse: 40 large detections over a carpet of ~250 small tracks (IoU ~0.09 against a
+    threshold of 0.05) — more than 32 rows AND more than 128 distinct columns: no [rows][columns] matrix of 8192 cells holds it.
+    The wavefront that took such a component records the refusal and its workgroup finishes it with the workgroup-cooperative dense
+    solver; 1100 isolated pairs around them keep the frame in the general tail.  (A refusal used to be pushed by lane 0 inside the
+    wave's loop: the compiler kept the other 63 lanes apart from then on and they re-solved the first entry for ever.)"""
+    rng = np.random.default_rng(77)
+    singles = 1100
+    tb = synth.dense_boxes(rng, singles, (1.0, 1.0))
+    tb["xc"] = 40000.0 + 300.0 * (np.arange(singles) % 40)
+    tb["yc"] = 40000.0 + 300.0 * (np.arange(singles) // 40)
+    db = synth.jitter_boxes(rng, tb, 1.0)
+    tracks, dets = [tb], [db]
+    for c in range(6):
+        ox, oy = 3000.0 * c, 800.0 * c
+        gx, gy = np.meshgrid(np.arange(19), np.arange(13))
+        small = synth.dense_boxes(rng, gx.size, (1.0, 1.0))
+        small["xc"] = ox + 15.0 + 30.0 * gx.ravel() + rng.uniform(-0.5, 0.5, gx.size)
+        small["yc"] = oy + 15.0 + 30.0 * gy.ravel() + rng.uniform(-0.5, 0.5, gx.size)
+        small["height"] = rng.uniform(24.0, 29.0, gx.size)
+        small["aspect"] = rng.uniform(0.9, 1.1, gx.size)
+        dx, dy = np.meshgrid(np.arange(8), np.arange(5))
+        large = synth.dense_boxes(rng, dx.size, (1.0, 1.0))
+        large["xc"] = ox + 45.0 + 60.0 * dx.ravel() + rng.uniform(-1.0, 1.0, dx.size)
+        large["yc"] = oy + 45.0 + 60.0 * dy.ravel() + rng.uniform(-1.0, 1.0, dx.size)
+        large["height"] = 90.0
+        large["aspect"] = 1.0
+        tracks.append(small)
+        dets.append(large)
+    tb, db = np.concatenate(tracks), np.concatenate(dets)
+    db["confidence"] = 1.0
+    perm = rng.permutation(len(db))
+    sc = dict(track_ids=np.arange(1, len(tb) + 1, dtype=np.uint64), track_boxes=tb, track_epochs=np.zeros(len(tb), np.uint64), det_boxes=db[perm])
+    cfg = abi.make_config(positional="iou", positional_threshold=0.05, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc, require_ids=False)  # (a carpet of near-equal overlaps: equal totals, ids not unique)
+    present = ~np.isnan(ref["positional"])
+    big_rows = present.sum(1) >= 6
+    assert big_rows.sum() == 240 and (ids[big_rows] != 0).all()
+
+
 @pytest.mark.parametrize("n,t", [(700, 700), (1300, 1200)])
 def test_mahalanobis_crowd_takes_the_64_bit_dense_solver(n, t):
     """Mahalanobis gains are 1e8-scale (cost <= 100 / confidence, x 1e6): beyond the 32-bit variant of the dense solver.  A crowd with
