@@ -1271,6 +1271,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     const uint32_t head = S.label[q];
     const uint32_t my_edges = S.e_use[q];
     const uint32_t Rq = (uint32_t)S.rnext[q];
+    const uint32_t nx_q = S.next_row[q];  // (the other row of a two-row component when this one heads the list; stale otherwise)
     const uint8_t has_q = VISUAL ? S.row_has[q] : (uint8_t)0;
     const int32_t vw_q = VISUAL ? S.vis_winner[q] : -1;
     SaEdge pe[4];
@@ -1334,7 +1335,68 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
         }
         finalize_row_with<VISUAL>(S, row, bj);
       } else {
-        bool fits = R <= pool_r;
+        // TWO rows, this one (the root = the lowest row, in its own list unless the visual vote decided it) and one other, four usable
+        // records each at most: three round trips instead of the pool's ten — the other row is known from what is here already (the
+        // list's head, or this row's link), its count and first four records come together, their ids / flags right after.  The
+        // answer is the greedy start's when the two bids differ (each row its heaviest usable edge, lowest column on ties); when they
+        // collide, the better of (this row keeps the column, the other takes its runner-up) and the converse — the root keeps it on
+        // a tie, as it does in the solvers' greedy start.
+        bool pair_done = false;
+        if (R == 2 && !has_q && my_edges - 1u < 4u) {
+          const uint32_t other = head != q ? head : nx_q;
+          const uint32_t ne_o = other < S.N ? S.e_use[other] : 5u;
+          SaEdge po[4];
+          {
+            const SaEdge SA_G* epo = S.e_edge + (size_t)(other < S.N ? other : 0u) * S.estride;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) po[k2] = sa_ldg(epo + ((uint32_t)k2 < S.estride ? (uint32_t)k2 : S.estride - 1u));
+          }
+          if (ne_o - 1u < 4u) {
+            uint64_t oid[4];
+            bool oex[4];
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+              const uint32_t c = po[k2].col < S.T ? po[k2].col : 0u;
+              oid[k2] = S.t_ids[c];
+              oex[k2] = VISUAL && S.col_excluded[c] != 0;
+            }
+            // per row: the best usable record and the best one on another column than the rival's bid
+            auto best_of = [](const SaEdge* e, const bool* ex, uint32_t n, int32_t not_col, int& at) {
+              int64_t bg = 0;
+              at = -1;
+#pragma unroll
+              for (int k2 = 0; k2 < 4; ++k2)
+                if ((uint32_t)k2 < n && !ex[k2] && (int32_t)e[k2].col != not_col &&
+                    (at < 0 || e[k2].gain > bg || (e[k2].gain == bg && e[k2].col < e[at < 0 ? 0 : at].col))) { bg = e[k2].gain; at = k2; }
+              return at < 0 ? (int64_t)0 : bg;
+            };
+            int ia, ib;
+            const int64_t ga = best_of(pe, pex, my_edges, -1, ia), gb = best_of(po, oex, ne_o, -1, ib);
+            if (ia >= 0 && ib >= 0 && pe[ia].col == po[ib].col) {
+              int ia2, ib2;
+              const int64_t ga2 = best_of(pe, pex, my_edges, (int32_t)pe[ia].col, ia2), gb2 = best_of(po, oex, ne_o, (int32_t)po[ib].col, ib2);
+              if (ga + gb2 >= ga2 + gb) ib = ib2;
+              else ia = ia2;
+            }
+            int32_t ca = -1, cb = -1;
+            uint64_t ida = 0, idb = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+              if (k2 == ia) { ca = (int32_t)pe[k2].col; ida = pid[k2]; }
+              if (k2 == ib) { cb = (int32_t)po[k2].col; idb = oid[k2]; }
+            }
+            S.out_track_id[q] = ida;
+            S.out_vote[q] = ca >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+            S.win_col[q] = ca;
+            S.out_win[q] = ca;
+            S.out_track_id[other] = idb;
+            S.out_vote[other] = cb >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+            S.win_col[other] = cb;
+            S.out_win[other] = cb;
+            pair_done = true;
+          }
+        }
+        bool fits = !pair_done && R <= pool_r;
         uint32_t blk = SA_NONE;
         if (fits) {
           blk = atomicAdd(&s_pool_top, 1u);
@@ -1398,6 +1460,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
             const int32_t c = L.rmatch[r];
             finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
           }
+        } else if (pair_done) {
         } else if (R <= ML_R && !no_mid) mid = true;
         else big = true;
       }
