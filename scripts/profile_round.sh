@@ -7,7 +7,7 @@ TAG=${1:-r03_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 # 1. kernel stats: the DEFAULT command first (the driver's line), then the other workloads
-for w in c2 c5 c4 c3 c2k3 c2d giant; do
+for w in c2 c5 c4 c3 c2k3 c2d giant sdt; do
   extra="--workload $w --no-cpu-baseline --no-oracle --no-h2d"; [ "$w" = "c2" ] && extra="--no-cpu-baseline --no-oracle --no-h2d"
   steps="--steps 50 --warmup 5"; [ "$w" = "c5" ] && steps="--steps 10 --warmup 2 --profile-iters 5"; [ "$w" = "giant" ] && steps="--steps 5 --warmup 1 --profile-iters 3"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o bench -- python $OLDPWD/bench.py $steps $extra > $O/prof_$w.log 2>&1)
@@ -16,7 +16,7 @@ for w in c2 c5 c4 c3 c2k3 c2d giant; do
 done
 # 2. bench lines (the default one with its CPU baselines)
 timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 exit $?"
-for w in c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd giant bigpile bigcrowd; do
+for w in c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd sdt giant bigpile bigcrowd; do
   st=""; [ "$w" = "c5" ] && st="--steps 20 --warmup 3 --profile-iters 10"
   timeout 600 python bench.py --workload $w --no-cpu-baseline $st > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w exit $?"
 done
