@@ -213,7 +213,7 @@ def rocprof_stats(workload: str):
     if not files:
         return out
     names = ("k_frame_visual", "k_frame", "k_visual_cost", "k_visual_cosine", "k_visual_euclid", "k_bestfit_tile", "k_bestfit_resolve", "k_assign_small",
-             "k_assign_label", "k_assign_solve", "k_assign_dense")
+             "k_assign_label", "k_assign_solve")
     try:
         for row in csv.DictReader(files[-1].open()):
             nm = row.get("Name", "")
@@ -258,7 +258,7 @@ def cpu_solve_only(cfg, scenes, budget_s=8.0):
         assert rc == 0
     return {"ms": 1e3 * min(times), "runs": len(times), "cores": 1, "rows": int(n), "cols": int(t + n), "edges_above_threshold": int((q > thr_q).sum()),
             "what": "or_kuhn_munkres (the oracle's restatement of pathfinding::kuhn_munkres) on the N x (T + N) matrix of SortVoting::winners, matrix already "
-                    "built, best run; compare with the assignment kernels' avg_us (k_assign_small, or k_assign_label + k_assign_solve + k_assign_dense)"}
+                    "built, best run; compare with the assignment kernels' avg_us (k_assign_small, or k_assign_label + k_assign_solve)"}
 
 
 def cpu_baseline(cfg, scenes, budget_s=12.0):
