@@ -214,6 +214,13 @@ int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols);
  * and unused in the scene where candidate i has no winner (ignored elsewhere).  Tracks must have been created by this call
  * (or given a full state with sa_tracks_set_state): a track upserted with the 5 x 5 projection only cannot be stepped. */
 int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted);
+/* The same in two halves, for a caller with host work of its own between them (the tracker facade does its per-track bookkeeping
+ * there — what the reference does around Track::merge): _begin validates, appends the new rows and QUEUES the device-side step;
+ * _end waits for it and hands out the predicted boxes.  The candidates' feature rows must stay untouched until _end has returned.
+ * Several slots may be between the two halves at once; an entry point that needs the finished table first (the next request set, an
+ * upsert / remove / set_state, a table tap) finishes what is pending — _end then only copies the boxes. */
+int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids);
+int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted);
 /* Full per-track state for the device-side upkeep (debug / parity / seeding): Kalman mean[10] + cov[100] row-major, and per
  * bank slot the feature quality[K].  Any of the output pointers may be NULL. */
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality,

@@ -372,6 +372,8 @@ PROTOTYPES = {
     "sa_cluster_associate_batch": (C.c_int, [C.c_void_p, u32, P(sa_scene_request), P(sa_scene_result)]),
     "sa_cluster_last_ms": (C.c_double, [C.c_void_p, u32]),
     "sa_tracks_apply": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
+    "sa_tracks_apply_begin": (C.c_int, [ENGINE, u32, P(u64)]),
+    "sa_tracks_apply_end": (C.c_int, [ENGINE, u32, P(sa_box)]),
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_nms": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float), C.c_float, C.c_float, P(u32), P(u32)]),

@@ -76,6 +76,7 @@ struct Slot {  // one scene of a request set
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   bool ran = false;
+  bool apply_pending = false;  // sa_tracks_apply_begin has queued the upkeep of this slot; sa_tracks_apply_end (or the next entry point that needs the table) finishes it
   bool prepped = true;     // the frame-preparation blocks ran with the frame (false: a lean frame left them out; ensure_prepped runs them on demand)
   bool needs_init = true;  // e_cnt / u / parent were (re)allocated, or a run may have died half-way: k_slot_init before the next frame
 };
@@ -148,6 +149,7 @@ struct sa_engine {
   // number that was next when the buffer was replaced)
   struct Garbage { void* p; uint64_t tag; };
   std::vector<Garbage> garbage;
+  std::vector<Slot*> applying;  // slots between sa_tracks_apply_begin and _end
   // upload scratch for upserts
   DevBuf nms_mask, nms_keep;
   DevBuf up_raw, up_slots, up_epochs, up_ids, up_mean, up_cov, up_feats, up_present, up_index;
@@ -161,6 +163,9 @@ struct sa_engine {
   uint64_t prof_n[KID_COUNT] = {0};
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 };
+
+// (sa_tracks_apply_begin without its _end yet: whatever needs the finished table calls this first; defined next to sa_tracks_apply)
+static int finish_applies(sa_engine* e);
 
 namespace {
 
@@ -957,6 +962,7 @@ void sa_engine_destroy(sa_engine* e) {
 // ---- track state -------------------------------------------------------------------------------------
 int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
   if (!e || !t) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_upsert: null argument");
+  TRY(finish_applies(e));
   const uint32_t n = t->n;
   if (!n) { get_scene(e, scene_id, true); return SA_OK; }
   if (!t->ids || !t->boxes || !t->epochs) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_upsert: ids/boxes/epochs are required");
@@ -1059,6 +1065,7 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
 
 int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
   if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove: null argument");
+  TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
   if (!n) return SA_OK;
@@ -1149,6 +1156,7 @@ static void bank_clear(Bank* b) {
 
 int sa_batch_begin(sa_engine* e) {
   if (!e) return SA_ERR_BAD_ARG;
+  TRY(finish_applies(e));
   HIPCHK(e, hipSetDevice(e->device));
   for (Bank& bk : e->banks)
     if (bk.state == 1 || bk.state == 2)
@@ -1378,6 +1386,7 @@ static Bank* bank_of_ticket(sa_engine* e, uint64_t ticket) {
 
 int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, uint64_t* out_ticket) {
   if (!e || !out_ticket || (n_scenes && !req)) return fail(e, SA_ERR_BAD_ARG, "sa_pipe_stage: null argument");
+  TRY(finish_applies(e));
   *out_ticket = 0;
   for (uint32_t i = 0; i < n_scenes; ++i) {
     const sa_detections* d = &req[i].detections;
@@ -1483,7 +1492,15 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
 }
 
 // ---- device-side track upkeep ---------------------------------------------------------------------------
-int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted) {
+// sa_tracks_apply in two halves: _begin validates, stages and QUEUES the upkeep kernels; _end waits for them, hands out the predicted
+// boxes and queues the polygon fix-up of oriented boxes.  Between the two the host is free (the tracker facade does its own
+// bookkeeping there); whatever needs the finished table first — the next request set, an upsert, a tap — finishes a pending one.
+static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted);
+static int finish_applies(sa_engine* e) {
+  while (!e->applying.empty()) TRY(apply_finish(e, e->applying.back(), nullptr));
+  return SA_OK;
+}
+int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_tracks_apply"));
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
@@ -1568,8 +1585,32 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
   }
   HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
   e->synced = false;
+  // host side of the table: the new rows
+  for (uint32_t i = 0; i < n; ++i)
+    if (winners[i] == 0) {
+      sc->slot_of[new_ids[i]] = (uint32_t)sc->ids.size();
+      sc->ids.push_back(new_ids[i]);
+    }
+  sc->T = T0 + n_new;
+  sc->full.resize(sc->T, 1);  // (the winners' rows held a full state already: checked above)
+  s->ran = false;  // the table the slot ran against is gone
+  s->apply_pending = true;
+  e->applying.push_back(s);
+  return SA_OK;
+}
+static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
+  HIPCHK(e, hipSetDevice(e->device));
+  for (size_t k = 0; k < e->applying.size(); ++k)
+    if (e->applying[k] == s) { e->applying.erase(e->applying.begin() + (long)k); break; }
+  s->apply_pending = false;
   if (e->B_ticket) TRY(compute_sync(e));  // pipelined: leave the copy stream (the next set's ingest) alone
   else TRY(engine_sync(e));
+  SceneTable* sc = s->scene;
+  const uint32_t n = s->N;
+  hipStream_t st = e->stream;
+  const uint64_t* winners = (const uint64_t*)s->h_out.p;
+  const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
+  const uint32_t* h_row = (const uint32_t*)s->h_apply.p;
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
   {
     // Oriented boxes: the polygon of a refreshed row needs cos / sin of the predicted angle from THIS side's libm (fill_raw does the
@@ -1598,21 +1639,32 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
       e->synced = false;
     }
   }
-  // host side of the table: the new rows
-  for (uint32_t i = 0; i < n; ++i)
-    if (winners[i] == 0) {
-      sc->slot_of[new_ids[i]] = (uint32_t)sc->ids.size();
-      sc->ids.push_back(new_ids[i]);
-    }
-  sc->T = T0 + n_new;
-  sc->full.resize(sc->T, 1);  // (the winners' rows held a full state already: checked above)
-  s->ran = false;  // the table the slot ran against is gone
   return SA_OK;
+}
+
+int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_tracks_apply_end"));
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!s->apply_pending) {
+    // (an empty frame queues nothing; anything else: finished already by an entry point that needed the table — the boxes are still there)
+    if (!s->N) return SA_OK;
+    if (s->ran || !s->h_pred.p) return fail(e, SA_ERR_STATE, "sa_tracks_apply_end without sa_tracks_apply_begin");
+    if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)s->N * sizeof(sa_box));
+    return SA_OK;
+  }
+  return apply_finish(e, s, out_predicted);
+}
+int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted) {
+  TRY(sa_tracks_apply_begin(e, slot, new_ids));
+  return sa_tracks_apply_end(e, slot, out_predicted);
 }
 
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality, uint8_t* present,
                         float* feats) {
   if (!e) return SA_ERR_BAD_ARG;
+  TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
   auto it = sc->slot_of.find(id);
@@ -1634,6 +1686,7 @@ int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mea
 
 int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const float* mean10, const float* cov100, const float* quality) {
   if (!e || !mean10 || !cov100) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_set_state: null argument");
+  TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
   auto it = sc->slot_of.find(id);
@@ -1844,6 +1897,7 @@ int sa_tap_quantised(sa_engine* e, uint32_t slot, int64_t* out) {
 // The polygons of a scene's track table (f64 vertices, 8 per row in table order): what the IoU cells clip against.
 int sa_tap_track_polygons(sa_engine* e, uint64_t scene_id, double* out, uint32_t cap_rows, uint32_t* out_rows) {
   if (!e || !out_rows) return fail(e, SA_ERR_BAD_ARG, "sa_tap_track_polygons: null argument");
+  TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   *out_rows = sc ? sc->T : 0;
   if (!sc || !sc->T || !out || cap_rows < sc->T) return SA_OK;
@@ -1988,6 +2042,7 @@ int sa_profile_read(sa_engine* e, sa_kernel_stat* out, uint32_t cap, uint32_t* o
 }
 int sa_batch_time(sa_engine* e, uint32_t iters, double* out_ms_total) {
   if (!e || !out_ms_total) return SA_ERR_BAD_ARG;
+  TRY(finish_applies(e));
   HIPCHK(e, hipSetDevice(e->device));
   TRY(engine_sync(e));
   HIPCHK(e, hipEventRecord(e->ev_t0, e->stream));

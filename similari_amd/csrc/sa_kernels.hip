@@ -960,8 +960,8 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t N = S.N;
   // rows, ascending: the labels from the root on (it is the component's lowest row), eight loads in flight per lane
+  uint32_t cnt = 0;
   {
-    uint32_t cnt = 0;
     for (uint32_t r0 = root; r0 < N && cnt < R; r0 += 512) {
       uint32_t lb8[8];
 #pragma unroll
@@ -980,6 +980,7 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
       }
     }
   }
+  if (cnt != R || R > ML_R) return false;  // (labels and count disagree: not this tier's to sort out — wave-uniform, both from ballots / SGPRs)
 #pragma unroll
   for (int h = 0; h < ML_H / 64; ++h) M.hkey[lane + 64u * (uint32_t)h] = SA_NONE;
 #pragma unroll

@@ -352,30 +352,36 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   if (rc != SA_OK) return tfail(t, rc, "association: %s", sa_last_error(t->eng));
   const auto t_assoc = clk::now();
 
-  std::vector<uint64_t> touched, tids, new_ids;
-  std::vector<sa_box> dev_pred;
+  // ids first, scene by scene in the order the reference draws them; with device upkeep the Kalman step, table refresh and
+  // feature-bank policy of every scene are QUEUED right away (sa_tracks_apply_begin) — they run while this thread does the
+  // per-track bookkeeping that does not need their result; the predicted boxes are collected afterwards (sa_tracks_apply_end)
+  std::vector<uint64_t> touched;
+  std::vector<std::vector<uint64_t>> tids(n_scenes), new_ids(n_scenes);
+  std::vector<std::vector<sa_box>> dev_pred(n_scenes);
+  std::vector<std::vector<Track*>> trps(n_scenes);
   for (uint32_t s = 0; s < n_scenes; ++s) {
-    const uint64_t scene = scene_ids[s];
     const uint32_t n = counts[s];
-    touched.clear();
-    // ids first (same order the reference draws them in), so that the device-side upkeep can create the new tracks
-    tids.assign(n, 0);
-    new_ids.assign(n, 0);
+    tids[s].assign(n, 0);
+    new_ids[s].assign(n, 0);
     for (uint32_t i = 0; i < n; ++i) {
       const uint64_t dest = winners[s][i];
       uint64_t drawn = 0;
       if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
-      if (dest == 0) { tids[i] = o.batch_ids ? drawn : ++t->track_id; new_ids[i] = tids[i]; }
-      else tids[i] = dest;
+      if (dest == 0) { tids[s][i] = o.batch_ids ? drawn : ++t->track_id; new_ids[s][i] = tids[s][i]; }
+      else tids[s][i] = dest;
     }
     if (o.device_upkeep) {
-      // Kalman step, table refresh and feature-bank policy on the GPU: nothing but the predicted boxes comes back
-      dev_pred.resize(n);
       const auto ta = clk::now();
-      rc = sa_tracks_apply(t->eng, s, new_ids.data(), dev_pred.data());
+      rc = sa_tracks_apply_begin(t->eng, s, new_ids[s].data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
     }
+  }
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    const uint64_t scene = scene_ids[s];
+    const uint32_t n = counts[s];
+    touched.clear();
+    trps[s].assign(n, nullptr);
     std::vector<Track*>& rows = t->by_scene[scene];
     const size_t rows_before = rows.size();  // the table the engine voted against: columns refer to these rows
     for (uint32_t i = 0; i < n; ++i) {
@@ -384,9 +390,9 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        Track& tr = t->store[tids[i]];
+        Track& tr = t->store[tids[s][i]];
         trp = &tr;
-        tr.id = tids[i]; tr.scene = scene; tr.epoch = epoch[s];
+        tr.id = tids[s][i]; tr.scene = scene; tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
         tr.has_state = true;
         if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, c.raw); }  // with device upkeep the state is born on the GPU
@@ -415,9 +421,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         tr.epoch = epoch[s];
         tr.has_custom = c.has_custom; tr.custom = c.custom;
         if (o.visual) tr.voting = votes[s][i];
-        // optimize(is_merge = true): Kalman predict + update with the candidate's box, history
-        sa_box predicted = o.device_upkeep ? dev_pred[i] : make_prediction(pw, vw, tr.has_state, tr.kf, c.box);
-        update_history(o, tr, c.box, predicted);
+        // optimize(is_merge = true): Kalman predict + update with the candidate's box, history (device upkeep: once the boxes are back)
+        if (!o.device_upkeep) update_history(o, tr, c.box, make_prediction(pw, vw, tr.has_state, tr.kf, c.box));
         if (o.visual) {
           Obs nw;
           nw.quality = c.quality; nw.has_own = c.has_own; nw.own = c.own; nw.has_feat = c.has_feat;
@@ -431,13 +436,30 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
           for (auto& ob : tr.obs) tr.feat_count += ob.has_feat ? 1u : 0u;
         }
       }
-      if (!o.device_upkeep) touched.push_back(tids[i]);
-      out[s][i] = to_sort_track(o, *trp);
+      trps[s][i] = trp;
+      if (!o.device_upkeep) {
+        touched.push_back(tids[s][i]);
+        out[s][i] = to_sort_track(o, *trp);
+      }
     }
     if (o.device_upkeep) continue;
     rc = sync_engine(t, scene, touched);
     if (rc != SA_OK) return rc;
   }
+  if (o.device_upkeep)
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+      const uint32_t n = counts[s];
+      dev_pred[s].resize(n);
+      const auto ta = clk::now();
+      rc = sa_tracks_apply_end(t->eng, s, dev_pred[s].data());
+      if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
+      us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
+      for (uint32_t i = 0; i < n; ++i) {
+        Track& tr = *trps[s][i];
+        if (winners[s][i] != 0) update_history(o, tr, cands[s][i].box, dev_pred[s][i]);
+        out[s][i] = to_sort_track(o, tr);
+      }
+    }
   if (trace) {
     const auto t_end = clk::now();
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
