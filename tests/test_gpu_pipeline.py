@@ -135,6 +135,56 @@ def test_pipelined_tickets_match_the_synchronous_path(pinned):
         eng.close()
 
 
+def test_apply_in_two_halves_matches_the_single_call():
+    """sa_tracks_apply_begin / _end (the tracker facade's form: its own bookkeeping runs between the two) on oriented boxes against
+    sa_tracks_apply on a second engine, six frames: same predicted boxes, same tables and polygons.  On odd frames the second half is
+    left out until AFTER an entry point that needs the finished table (the polygon tap): it finishes what is pending, and _end
+    afterwards only hands out the boxes.  _end without a _begin is refused."""
+    rng = np.random.default_rng(75)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    world = synth.dense_boxes(rng, 50, (900.0, 700.0), True)
+    frames = []
+    for f in range(6):
+        world = synth.jitter_boxes(rng, world, 1.5, angle_sigma=0.02)
+        frames.append(np.concatenate([world, synth.dense_boxes(rng, 3, (900.0, 700.0), True)]))
+        world = frames[-1]
+    a, b = Engine(cfg), Engine(cfg)
+    u64p, bp = C.POINTER(C.c_uint64), C.POINTER(abi.sa_box)
+    try:
+        pred0 = np.zeros(1, abi.BOX_DTYPE)
+        nxt = 1
+        for f, boxes in enumerate(frames):
+            det = abi.make_detections(boxes)
+            got = []
+            for eng in (a, b):
+                eng.batch_begin()
+                eng.batch_add(0, f + 1, det)
+                eng.batch_run()
+                eng.batch_sync()
+                got.append(eng.batch_fetch(0, det.n)[0])
+            np.testing.assert_array_equal(got[0], got[1], err_msg=f"frame {f}")
+            nid = np.zeros(det.n, np.uint64)
+            for i, w in enumerate(got[0]):
+                if w == 0:
+                    nid[i] = nxt
+                    nxt += 1
+            if f == 0:
+                assert b.lib.sa_tracks_apply_end(b.h, 0, C.cast(pred0.ctypes.data, bp)) == abi.SA_ERR_STATE
+            pa, pb = np.zeros(det.n, abi.BOX_DTYPE), np.zeros(det.n, abi.BOX_DTYPE)
+            a._chk(a.lib.sa_tracks_apply(a.h, 0, nid.ctypes.data_as(u64p), C.cast(pa.ctypes.data, bp)))
+            b._chk(b.lib.sa_tracks_apply_begin(b.h, 0, nid.ctypes.data_as(u64p)))
+            if f % 2:
+                np.testing.assert_array_equal(b.tap_track_polygons(0), a.tap_track_polygons(0))  # finishes the pending half
+            b._chk(b.lib.sa_tracks_apply_end(b.h, 0, C.cast(pb.ctypes.data, bp)))
+            np.testing.assert_array_equal(pa.view(np.uint8), pb.view(np.uint8), err_msg=f"frame {f}")
+            np.testing.assert_array_equal(a.order(0), b.order(0))
+            np.testing.assert_array_equal(b.tap_track_polygons(0), a.tap_track_polygons(0))
+        assert a.count(0) == b.count(0) > 50
+    finally:
+        a.close()
+        b.close()
+
+
 def test_pipelined_tracker_loop_with_device_upkeep():
     """stage(n+1); wait(n); apply(n); launch(n+1): the H2D of the next frame overlaps the current frame's kernels, and the track
     table the next frame meets is the one sa_tracks_apply left (new tracks appended, Kalman steps taken).  Same ids, frame by
