@@ -1241,11 +1241,12 @@ template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
 __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs_) {
   const uint32_t row_wgs = row_wgs_ & 0x7fffffffu;
   const bool no_mid = row_wgs_ >> 31;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
-  // One lane gathering a component is a chain of dependent trips to L2 / memory — the list walk, then every row's count and
-  // records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker loop's crowd
-  // frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool keeps components of two rows
-  // (C4 has hundreds: a wavefront each would cost more); without it (Mahalanobis) everything that fits.
-  const uint32_t pool_r = no_mid ? SL_R : 2u;
+  // One lane gathering a component into its pool block is a chain of dependent trips to L2 / memory — the list walk, then every
+  // row's count and records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker
+  // loop's crowd frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool is not used at
+  // all (pairs come from registers, everything else goes to a wavefront: 1000 x 2500 crowd frame 37 -> 31 us against a pool of
+  // pairs); without it (Mahalanobis) it takes everything that fits.
+  const uint32_t pool_r = no_mid ? SL_R : 0u;
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const bool row_wg = blockIdx.x < row_wgs;  // (the workgroups behind them only take big components off the queue)
   const uint32_t q = row_wg ? blockIdx.x * NT + threadIdx.x : 0xffffffffu;
@@ -1634,10 +1635,11 @@ static void launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipStream_
 }
 template <int NT, int CPT>
 static void launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
-  // the row workgroups, and behind them helpers that only take big components off the scene's queue (a crowd has dozens; one
-  // workgroup per scene would solve them one after the other) — up to 64 workgroups per scene, fewer in a wide batch
+  // the row workgroups, and behind them helpers that only take components off the scene's queues (a crowd has dozens of knots, one
+  // wavefront of a workgroup each: 64 workgroups per scene left the 1000 x 2500 crowd frame two rounds of them, 30 us; 128: 24 us) —
+  // fewer per scene in a wide batch
   const uint32_t rows = cdiv(maxN, NT);
-  const uint32_t want = ns >= 16 ? 8u : ns >= 4 ? 16u : 64u;
+  const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
   const dim3 grid(rows > want ? rows : want, 1, ns);
   const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u);  // (bit 31: no middle tier)
   if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);

@@ -1237,6 +1237,23 @@ def test_big_visual_frame_with_a_dense_positional_stage():
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 100 and (votes == abi.SA_VOTE_VISUAL).sum() > 500
 
 
+@pytest.mark.parametrize("visual,k", [("cosine", 1), ("euclidean", 2)])
+def test_visual_frame_whose_positional_stage_is_pairs_and_knots(visual, k):
+    """1200 detections x 1500 tracks VisualSORT on the C2 canvas, 40 % of the detections new or below the quality gate: the
+    positional stage inherits several hundred rows in components of one, two (the register path of the general tail) and a dozen rows
+    (its one-wavefront middle tier), whose records also name columns the visual vote has taken (excluded_tracks: skipped when the
+    bids are formed, when the hash table is filled and when the pair's runner-ups are chosen)."""
+    rng = np.random.default_rng(91 + k)
+    n, t, d = 1200, 1500, 48
+    sc = synth.visual_scene(rng, t, n, d, k, canvas=(1920.0, 1080.0), new_fraction=0.25)
+    sc["det_quality"][rng.uniform(size=n) < 0.2] = 0.05
+    cfg = abi.make_config(positional="iou", positional_threshold=0.15, visual=visual, visual_threshold=0.2 if visual == "cosine" else 0.5,
+                          feature_len=d, max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.3,
+                          positional_min_confidence=0.1, max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc, tol_abs=1e-5 if visual == "cosine" else 0.0, tol_rel=0.0 if visual == "cosine" else 1e-5)
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 100 and (votes == abi.SA_VOTE_VISUAL).sum() > 400
+
+
 # ---- the headline configurations at FULL size against the oracle -------------------------------------------------------
 # The oracle's distance stage runs on host threads partitioned like the reference's TrackStore (or_associate_sharded: track id %
 # shards, one vote after the shards) — cell for cell the single-thread oracle, in a fraction of its time.
