@@ -202,7 +202,8 @@ def test_general_assignment_tail_matches_oracle_too():
     env = dict(os.environ, SA_TAIL="general")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
                         "test_sort_iou_parity or test_sort_maha_parity or test_visual_cosine_parity or test_batched_scenes or "
-                        "test_state_kept_clean or test_crowds_against or test_one_giant_component or test_dense_positional_stage"],
+                        "test_state_kept_clean or test_crowds_against or test_one_giant_component or test_dense_positional_stage or "
+                        "test_random_configurations or test_sort_iou_constraints"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
