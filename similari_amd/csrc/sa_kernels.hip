@@ -373,9 +373,10 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // strictly needed — harmless, it is still solved exactly.
 //   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
 //            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
-//   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a one-row
-//            component: its heaviest edge; up to 8 rows: one lane in a private block of LDS; larger: onto the scene's queue, from
-//            which the launch's workgroups take them one each, with the dense solver of sa_dense.h).
+//   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a component
+//            of one or two rows: from the root thread's registers; up to 64 rows and 256 columns: one wavefront on a renumbered
+//            matrix in LDS; larger: a whole workgroup with the dense solver of sa_dense.h — the last two handed out through
+//            per-scene queues that every workgroup of the launch serves).
 // =====================================================================================================
 // In-kernel timeline of the one-workgroup tail (build with -DSA_TAIL_TRACE, run with SA_TAIL_TRACE=<launch #>): s_memtime of
 // thread 0 at  0 entry | 1 counts scanned | 2 edges packed + components united | 3 labels | 4 sorted | 5 linked | 6 solved | 7 exit.
@@ -1225,15 +1226,18 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 }
 
 // General tail, kernel 2 of 2.  NT threads per workgroup, thread = row.  The thread of a component's root (= its lowest row) owns it:
-//   * ONE row (most components of a tracking frame): its heaviest usable edge straight from the HBM list (lowest column on ties) —
-//     what the shortest-path search does for the first row of a component, without any search state;
-//   * up to 8 rows, 12 columns, 24 usable edges: gathered into a private block of LDS (from a pool of SL_POOL blocks per
-//     workgroup), solved there by the serial sa_assign_component, scattered back;
-//   * anything larger, or a small one that found the pool empty: onto the SCENE's queue (S.dq).  When every row workgroup of the
-//     scene has said it is through with its rows, all workgroups of the scene — the row workgroups and the helper workgroups launched
-//     behind them, which do nothing else — take components off the queue by ticket, all threads of a workgroup on one component
-//     (dense_solve_component).  No third launch, and a crowd's dozens of mid-sized components are solved side by side (one
-//     workgroup per 256 rows solving its own one after the other: 263 us instead of 40 in the tracker loop's SORT frames).
+//   * ONE row (most components of a tracking frame): its heaviest usable edge (lowest column on ties) — what the shortest-path
+//     search does for the first row of a component, without any search state — from records requested at the top of the kernel;
+//   * TWO rows with at most four records each: from registers too, three round trips (see the pair path below);
+//   * up to ML_R rows and ML_C distinct columns: onto the scene's queue of mid-sized components, one WAVEFRONT each
+//     (mid_solve_component);
+//   * anything larger: onto the scene's queue of big components, one WORKGROUP each (dense_solve_component).
+//   (Mahalanobis engines, whose gains do not fit the middle tier's 32-bit cells: components of up to 8 rows, 12 columns and 24
+//   usable edges are gathered by the root's lane into a private block of LDS — a pool of SL_POOL per workgroup —, solved there by
+//   the serial sa_assign_component and scattered back; the rest goes to the big queue.)
+//   When every row workgroup of the scene has said it is through with its rows, all workgroups of the scene — the row workgroups
+//   and the helper workgroups launched behind them, which do nothing else — serve the queues by ticket.  No third launch, and a
+//   crowd's dozens of knots are solved side by side.
 // Per-row duals / matches and per-column matches / predecessors of the dense solver: dynamic LDS when 12 N + 8 T bytes fit
 // (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
 #define SL_POOL 40
