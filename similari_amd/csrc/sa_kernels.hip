@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t nref = 0;
     if (wv < ML_WAVES) {
-      for (;;) {
+      while (nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront takes no more tickets — the other workgroups' do)
         const uint32_t tk = atomicAdd((uint32_t*)(S.stats + SA_QW_MTICKET), (threadIdx.x & 63u) == 0 ? 1u : 0u);
         const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
         if (k >= nmid) break;
