@@ -90,6 +90,12 @@ struct SceneDev {
   uint32_t SA_G* col_part_q; // [RT][T] lowest row attaining it
   unsigned long long SA_G* row_best;  // [SA_SMALL_N] vote words (SaParams::vote_words): min over the row of (weight key << 32 | column); all ones = none
   unsigned long long SA_G* col_best;  // [SA_SMALL_N] min over the column of (weight key << 32 | row)
+  // Deeper banks without the weight matrix (SCN_WORDSK, the contraction's whole-track tiles): one word per candidate (track) and COUNT CLASS —
+  // groups with c present observations, c = 1 .. K at [q * K + c - 1] — holding min over the row (column) of (key of the f32 sum of
+  // the group's weights << 32 | column (row)): inside a class the heaviest BestFit group is the one with the smallest sum; the
+  // tail, which knows the frame's max_dist, compares the classes' winners by W = c max_dist - sum.
+  unsigned long long SA_G* row_cls;   // [SA_SMALL_N * SA_CLS_MAXK]
+  unsigned long long SA_G* col_cls;   // [SA_SMALL_N * SA_CLS_MAXK]
   uint8_t SA_G* row_has;
   int32_t SA_G* vis_winner;
   uint8_t SA_G* col_excluded;
@@ -138,6 +144,8 @@ struct SceneDev {
 #define SCN_HAS_QUALITY 2u
 #define SCN_HAS_OWN 4u
 #define SCN_HAS_FPRESENT 8u
+#define SCN_WORDSK 32u    // the vote words of this frame are per count class (row_cls / col_cls), the contraction's whole-track tiles'
+#define SA_CLS_MAXK 8u    // deepest bank the class words serve
 #define SCN_WORDS10 16u   // the vote words of this frame carry a 10-bit index below a 54-bit weight key (k_bestfit_tile, deeper banks)
 
 // Engine-wide constants, passed to kernels by value.
@@ -227,7 +235,8 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 // heterogeneous first phase of a VisualSORT frame (contraction tiles + positional tiles + preparation blocks in one launch);
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep = true);
+                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep = true, bool kpass = false);
+bool sa_frame_visual_ok(uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p);
 void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);

@@ -394,7 +394,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   }
   {
     void* before = s->vote_best.p;
-    TRY(dev_ensure(e, s->vote_best, 2 * SA_SMALL_N * 8));
+    TRY(dev_ensure(e, s->vote_best, (size_t)(2 + 2 * SA_CLS_MAXK) * SA_SMALL_N * 8));  // row / column words | row / column CLASS words
     if (s->vote_best.p != before) s->needs_init = true;
   }
   TRY(dev_ensure(e, s->row_has, n));
@@ -441,7 +441,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->stats, 256));
     if (s->stats.p != before) s->needs_init = true;
   }
-  if (e->cfg.flags & SA_FLAG_TAP) TRY(dev_ensure(e, s->tap, n * 8 + t * 8 + n * 4));
+  if (e->cfg.flags & SA_FLAG_TAP) TRY(dev_ensure(e, s->tap, (n * 8 + t * 8) * (e->K > 1 && e->K <= SA_CLS_MAXK ? e->K : 1) + n * 4));
   {
     void* before = s->h_out.p;
     TRY(host_ensure(e, s->h_out, n * 13 + 48));  // ids[n] | votes[n] | (8-byte aligned) stats[4] | winning columns[n]
@@ -458,10 +458,11 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->TK = s->T * e->K; d->estride = s->T ? s->T : 1;
   d->D = e->D;
   d->flags = (s->has_feats ? SCN_HAS_FEATS : 0u) | (s->has_quality ? SCN_HAS_QUALITY : 0u) | (s->has_own ? SCN_HAS_OWN : 0u) |
-             (s->has_fpresent ? SCN_HAS_FPRESENT : 0u) | (bk->words == 2 ? SCN_WORDS10 : 0u);
+             (s->has_fpresent ? SCN_HAS_FPRESENT : 0u) | (bk->words == 2 ? SCN_WORDS10 : 0u) | (bk->words == 3 ? SCN_WORDSK : 0u);
   d->CT = (s->T + 63) / 64; d->RT = (s->N + 63) / 64;
   if (bk->partials) { d->CT = (s->T + bk->tile_bn - 1) / bk->tile_bn; d->RT = (s->N + bk->tile_bm - 1) / bk->tile_bm; }  // the contraction's own tile grid
   d->nkeys = e->visual ? ((s->N + bk->tile_bm - 1) / bk->tile_bm) * ((s->T * e->K + bk->tile_bn - 1) / bk->tile_bn) : 0;
+  if (bk->words == 3) d->nkeys = ((s->N + 63) / 64) * ((s->T + 64 / e->K - 1) / (64 / e->K));  // whole-track tiles: floor(64 / K) tracks each
   d->epoch = s->epoch;
   d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_ext = (decltype(d->t_ext))(sc->ext.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
   d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
@@ -476,6 +477,8 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->row_part_w = (decltype(d->row_part_w))(s->row_part_w.p); d->row_part_t = (decltype(d->row_part_t))(s->row_part_t.p);
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
   d->row_best = (decltype(d->row_best))(s->vote_best.p); d->col_best = (decltype(d->col_best))((unsigned long long*)s->vote_best.p + SA_SMALL_N);
+  d->row_cls = (decltype(d->row_cls))((unsigned long long*)s->vote_best.p + 2 * SA_SMALL_N);
+  d->col_cls = (decltype(d->col_cls))((unsigned long long*)s->vote_best.p + (size_t)(2 + SA_CLS_MAXK) * SA_SMALL_N);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
   d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
   d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_edge = (decltype(d->e_edge))(s->e_edge.p);
@@ -492,9 +495,10 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->out_win = (decltype(d->out_win))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16);
   if (s->tap.p) {  // SA_FLAG_TAP: [N] row words | [T] column words | [N] edge counts (sizes as slot_reserve laid them out)
     const size_t n = s->N ? s->N : 1, t = s->T ? s->T : 1;
+    const size_t wk = bk->words == 3 ? e->K : 1;  // class words: K per candidate / track
     d->tap_row_best = (decltype(d->tap_row_best))(s->tap.p);
-    d->tap_col_best = (decltype(d->tap_col_best))((unsigned long long*)s->tap.p + n);
-    d->tap_ecnt = (decltype(d->tap_ecnt))((unsigned long long*)s->tap.p + n + t);
+    d->tap_col_best = (decltype(d->tap_col_best))((unsigned long long*)s->tap.p + n * wk);
+    d->tap_ecnt = (decltype(d->tap_ecnt))((unsigned long long*)s->tap.p + (n + t) * wk);
   }
 }
 
@@ -622,8 +626,9 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
   if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && all_feats) {
     ProfScope ps(e, KID_FRAME_VISUAL);
-    hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep);
+    hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep, b->words == 3);
     if (fe == hipSuccess) fused = true;
+    else if (b->words == 3) HIPCHK(e, fe);  // (bank_prepare asked sa_frame_visual_ok: cannot happen)
     else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
     else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
@@ -633,7 +638,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   b->frame_small_tail = small_tail;
   if (e->visual) {
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials)); }
-    if (!partials && b->words != 1) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
+    if (!partials && b->words != 1 && b->words != 3) { ProfScope ps(e, KID_BESTFIT_TILE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, Pt, st, 0)); }
   }
   if (e->visual && !words) { ProfScope ps(e, KID_BESTFIT_RESOLVE); HIPCHK(e, sa_launch_bestfit(ds, ns, maxN, maxT, P, st, partials ? 2 : 1)); }
   // the frame's LAST launch carries the caller's completion event as its own completion signal (sa_pipe_launch), unless the frame is
@@ -688,6 +693,15 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
     static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
     const bool small = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general && !separate_resolve;
     b->words = !(e->visual && small) ? 0 : (b->partials || e->bf_words_euclid) ? 1 : 2;
+    // deeper banks: the whole-track tiles of the fused first phase reduce into CLASS words (no weight matrix, no k_bestfit_tile) wherever
+    // that launch applies (every scene with features, rows of a multiple of 32 floats, cosine or the euclidean expansion)
+    if (b->words == 2 && e->K >= 2 && e->K <= SA_CLS_MAXK && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME)) {
+      bool all_feats = true;
+      for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
+      SaParams P = e->P;
+      P.eu_mfma = b->eu_mfma ? 1u : 0u;
+      if (all_feats && sa_frame_visual_ok(ns, maxN, maxT, e->K, e->D, P)) b->words = 3;
+    }
   }
   *maxN_out = maxN;
   *maxT_out = maxT;
@@ -705,7 +719,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t 
     if (!s->needs_init) continue;
     HIPCHK(e, sa_launch_slot_init((uint32_t*)s->e_cnt.p, (int64_t*)s->u.p, (uint32_t)(s->e_cnt.cap / 4 < s->u.cap / 8 ? s->e_cnt.cap / 4 : s->u.cap / 8),
                                   (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
-    HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, 2 * SA_SMALL_N * 8, st));  // vote words: all ones = no group
+    HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, (size_t)(2 + 2 * SA_CLS_MAXK) * SA_SMALL_N * 8, st));  // vote words: all ones = no group
     HIPCHK(e, hipMemsetAsync(s->stats.p, 0, 256, st));
     HIPCHK(e, hipMemsetAsync(s->dense.p, 0, s->dense.cap, st));  // (a frame that died half-way may have left gains behind)
     s->needs_init = false;
@@ -1856,8 +1870,8 @@ int sa_tap_visual(sa_engine* e, uint32_t slot, float* out) {
   size_t bytes = (size_t)s->N * s->T * e->K * 4;
   if (!bytes) return SA_OK;
   TRY(ensure_prepped(e, e->B));
-  if (e->B->partials || e->bf_words_euclid) {
-    // the product path never wrote the weight matrix (euclidean: not on frames that used the vote words — re-running is harmless otherwise): run the contraction once more, in matrix mode, on the slot's resident inputs
+  if (e->B->partials || e->bf_words_euclid || e->B->words == 3) {
+    // the product path never wrote the weight matrix (class words of deeper banks: neither) (euclidean: not on frames that used the vote words — re-running is harmless otherwise): run the contraction once more, in matrix mode, on the slot's resident inputs
     SceneDev h;
     fill_scene_dev(e, e->B, s, &h);
     DevBuf tmp;
@@ -1918,6 +1932,31 @@ int sa_tap_votes(sa_engine* e, uint32_t slot, double* row_w, int32_t* row_idx, d
   const uint32_t N = s->N, T = s->T;
   *kind = (b->partials || b->words == 1) ? 1 : 2;
   if (!N || !T) return SA_OK;
+  if (b->words == 3) {
+    // class words (the whole-track tiles of the contraction): [N K] then [T K], (key of the f32 sum of a group's weights << 32 | index) per count class;
+    // the group weight the tail compares is W = c max_dist - sum with the frame's max_dist folded from the first phase's slots
+    const uint32_t K = e->K;
+    std::vector<unsigned long long> w(((size_t)N + T) * K);
+    HIPCHK(e, hipMemcpy(w.data(), s->tap.p, w.size() * 8, hipMemcpyDeviceToHost));
+    const uint32_t nkeys = ((N + 63) / 64) * ((T + 64 / K - 1) / (64 / K));
+    std::vector<uint32_t> keys(nkeys);
+    HIPCHK(e, hipMemcpy(keys.data(), s->vis_max_key.p, (size_t)nkeys * 4, hipMemcpyDeviceToHost));
+    uint32_t mk = 0;
+    for (uint32_t v : keys) mk = v > mk ? v : mk;
+    const double max_dist = mk ? (double)sa_key_f32(mk) : -1.0;
+    auto best = [&](const unsigned long long* cls, double* wt, int32_t* idx) {
+      *wt = NAN; *idx = -1;
+      for (uint32_t c = 0; c < K; ++c) {
+        if (cls[c] == ~0ull) continue;
+        const double W = (double)(c + 1) * max_dist - (double)sa_key_f32((uint32_t)(cls[c] >> 32));
+        const int32_t i = (int32_t)(uint32_t)cls[c];
+        if (*idx < 0 || W > *wt || (W == *wt && i < *idx)) { *wt = W; *idx = i; }
+      }
+    };
+    for (uint32_t i = 0; i < N; ++i) best(w.data() + (size_t)i * K, &row_w[i], &row_idx[i]);
+    for (uint32_t j = 0; j < T; ++j) best(w.data() + ((size_t)N + j) * K, &col_w[j], &col_idx[j]);
+    return SA_OK;
+  }
   if (b->words) {
     std::vector<unsigned long long> w((size_t)N + T);
     HIPCHK(e, hipMemcpy(w.data(), s->tap.p, (size_t)N * 8, hipMemcpyDeviceToHost));
@@ -1985,7 +2024,7 @@ int sa_tap_edges(sa_engine* e, uint32_t slot, uint32_t* counts, uint32_t cap, ui
   const uint32_t N = s->N, T = s->T;
   *out_total = 0;
   if (!N) return SA_OK;
-  HIPCHK(e, hipMemcpy(counts, (unsigned long long*)s->tap.p + (size_t)(N ? N : 1) + (T ? T : 1), (size_t)N * 4, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(counts, (unsigned long long*)s->tap.p + ((size_t)(N ? N : 1) + (T ? T : 1)) * (e->B->words == 3 ? e->K : 1), (size_t)N * 4, hipMemcpyDeviceToHost));
   uint64_t total = 0;
   uint32_t maxc = 0;
   for (uint32_t i = 0; i < N; ++i) { total += counts[i]; maxc = counts[i] > maxc ? counts[i] : maxc; }

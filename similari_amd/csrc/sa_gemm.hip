@@ -859,6 +859,193 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   SA_STAMP(tr, 5);
 }
 
+// Deeper banks (K = 2 .. SA_CLS_MAXK observations per track) WITHOUT the N x T x K weight matrix and without k_bestfit_tile: the
+// whole-track tile of the fused frame launch.  A 64-column tile of the contraction holds the observations of floor(64 / K) WHOLE
+// tracks (its first column is bank row bx floor(64 / K) K: the B operand stays one contiguous run of rows; the 64 mod K columns left
+// over are computed and ignored — 1 of 64 at K = 3, 4 at K = 5), so every BestFit group (candidate, track) of the tile is complete
+// inside it: the cells' weights go to an LDS tile instead of memory, and one thread per group adds the present ones up (f64, k
+// ascending like the reference's sum) and counts them.  BestFit ranks a group by W = sum_k f64(max_dist - w_k) and max_dist is known
+// only when every tile is done — but among groups with the SAME count c the heaviest is the one with the smallest sum.  So the tile
+// reduces its groups per count class: 64-bit LDS minima of (order-preserving key of the f32 sum << 32 | index: lowest index on ties,
+// as the reference orders exact ties) per row and per track, folded into the class words S.row_cls / S.col_cls with 64-bit atomic
+// minima; the one-workgroup tail, which folds max_dist anyway, compares a row's (track's) class winners by W = c max_dist - sum.
+// (W differs from the reference's sum of f32 differences by <= c/2 ulp of max_dist, 2e-7: the distances themselves are good to 1e-5.)
+// The tiles stay as many and as independent as before (three per CU in flight at C2's size — a version that kept one 64 x 64 tile of
+// (candidate, track) pairs per workgroup and ran the main loop K times lost exactly that: 44.7 us against 38.6 for the first phase).
+// RAW rows only (the fused launch); EU: the flagged cells are recomputed directly as in euclid_fixup, into the LDS tile.
+template <bool EU>
+__device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
+  constexpr int BM = 64, BN = 64, R = 16, G = 4;
+  const uint32_t N = S.N, T = S.T, K = S.K, TK = S.TK;
+  const uint32_t TPT = 64u / K, used = TPT * K;       // whole tracks per tile, columns they occupy
+  const uint32_t m0 = by * BM, t0 = bx * TPT, n0 = t0 * K;
+  if (m0 >= N || t0 >= T) return;
+  const uint32_t key_slot = by * ((T + TPT - 1) / TPT) + bx;  // < S.nkeys (tiles of this scene in this mode)
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  float pre_us = 0.f;
+  sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  if (tid < (uint32_t)BM && m0 + tid < N) {
+    const uint32_t gi = m0 + tid;
+    const BoxRaw r = sa_ldg(S.c_raw + gi);
+    const sa_box& b = r.box;
+    pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
+    bool usable = false;
+    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
+      const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
+      bool perc_ok = true;
+      if (S.flags & SCN_HAS_OWN) {
+        const float oa = S.c_own[gi];
+        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+      }
+      usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
+    }
+    pre_us = usable ? 1.f : 0.f;
+  }
+  const uint32_t lc = wn * 32 + lr, gj = n0 + lc;
+  GemmCols col;
+  col.ok = false; col.nb = 0.f; col.cmax = -1.0f; col.g = sa_geo{0.f, 0.f, 0.f, 0.f};
+  if (lc < used && gj < TK) {
+    const uint32_t t = gj / K;
+    const float nb = S.t_fnorm[gj];
+    const uint8_t pres = S.t_fpresent[gj];
+    const uint32_t cnt = S.t_fcount[t];
+    const uint64_t te = S.t_epoch[t];
+    col.g = sa_ldg(S.t_geo + t);
+    col.nb = nb;
+    const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
+    col.ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
+    for (uint32_t i = 0; i < p.cons.n; ++i)
+      if (p.cons.delta[i] >= delta) { col.cmax = p.cons.max_dist[i]; break; }
+  }
+  f32x16 acc[1][1];
+  float nsq = 0.f;
+  gemm_mainloop<BM, BN, 1, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, nullptr, &nsq);
+  float* s_na = lds;                      // [BM]
+  sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
+  float* s_np = lds + 6 * BM;             // [BM] squared norms of the candidates' rows (raw mode)
+  constexpr uint32_t KS = BN + 4;
+  uint32_t* s_w = (uint32_t*)(lds + 7 * BM);                       // [64][KS] the cells' weights (f32 bits, NaN = absent)
+  constexpr uint32_t FW = BN / 32;
+  uint32_t* s_flag = (uint32_t*)(lds + 7 * BM + 64 * KS);
+  constexpr uint32_t FL_CAP = 255;
+  uint32_t* s_flist = s_flag + 64 * FW;
+  unsigned long long* s_rc = (unsigned long long*)(s_flist + FL_CAP + 1);  // [64][K] row class words of the tile
+  unsigned long long* s_cc = s_rc + 64 * SA_CLS_MAXK;                      // [TPT][K] track class words of the tile
+  static_assert((7 * BM + 64 * (BN + 4) + 64 * (BN / 32) + 256 + 2 * 64 * SA_CLS_MAXK + 2 * 64) <= 2 * (BM + BN) * BK, "the epilogue's tables must fit the stages");
+  if constexpr (EU) {
+    for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
+    if (tid == 0) s_flist[FL_CAP] = 0u;
+  }
+  for (uint32_t i = tid; i < 64u * K; i += blockDim.x) s_rc[i] = ~0ull;
+  if (tid < used) s_cc[tid] = ~0ull;
+  if (tid < (uint32_t)BM) s_g[tid] = pre_g;
+  nsq += __shfl_xor(nsq, 32);
+  if (wn == 0 && lh == 0) s_np[wm * 32 + lr] = nsq;
+  __syncthreads();
+  if (tid < (uint32_t)BM) s_na[tid] = pre_us != 0.f ? s_np[tid] : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
+  __syncthreads();
+  uint32_t rbase[G];
+  f32x4 nav[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    rbase[g] = wm * 32 + 8u * g + 4u * lh;
+    nav[g] = *(const f32x4*)(s_na + rbase[g]);
+  }
+  uint32_t kmax = 0;
+  const uint32_t cfail = constraint_mask<R>(col, [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const uint32_t li = rbase[i >> 2] + (i & 3);
+    const uint32_t gi = m0 + li;
+    bool flagged;
+    float w = visual_cell<EU>(p, acc[0][0][i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col, &kmax, &flagged);
+    if (gi >= N) w = __builtin_nanf("");  // (columns past the tile's tracks: col.ok = false)
+    if constexpr (EU) {
+      if (flagged && gi < N) {
+        atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));
+        const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
+        if (pos < FL_CAP) s_flist[pos] = (li << 8) | lc;
+      }
+    }
+    s_w[li * KS + lc] = __float_as_uint(w);
+  }
+  if constexpr (EU) {
+    __syncthreads();  // flag words / list and the weight tile complete
+    const uint32_t wave = tid >> 6, nw = blockDim.x >> 6;
+    auto recompute = [&](uint32_t li, uint32_t lc2) {
+      const uint32_t gi = m0 + li;
+      const float SA_G* a = S.c_feat_raw + (size_t)gi * S.Dp;
+      const float SA_G* b = S.t_feat + (size_t)(n0 + lc2) * S.Dp;
+      float acc2 = 0.f;
+      for (uint32_t kk = lane * 4u; kk < S.Dp; kk += 256u) {
+        const f32x4 x = *(const f32x4 SA_G*)(a + kk), y = *(const f32x4 SA_G*)(b + kk);
+        const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+        acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o);
+      if (lane == 0) {
+        const float d = __fsqrt_rn(acc2);
+        const bool ok = d <= p.visual_threshold;
+        const uint32_t key = ok ? sa_f32_key(d) : 0u;
+        s_w[li * KS + lc2] = __float_as_uint(ok ? d : __builtin_nanf(""));
+        kmax = key > kmax ? key : kmax;
+      }
+    };
+    const uint32_t nf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flist[FL_CAP]);
+    if (nf <= FL_CAP) {
+      for (uint32_t i = wave; i < nf; i += nw) {
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flist[i]);
+        recompute(ent >> 8, ent & 255u);
+      }
+    } else {
+      for (uint32_t lrow = wave; lrow < 64u; lrow += nw)
+        for (uint32_t wd = 0; wd < FW; ++wd) {
+          uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flag[lrow * FW + wd]);
+          while (bits) {
+            const uint32_t c2 = wd * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            recompute(lrow, c2);
+          }
+        }
+    }
+    if (nf > 64u && tid == 0) S.stats[0] = 1u;  // ill-conditioned for the expansion (see euclid_fixup)
+  }
+  __syncthreads();  // the weight tile (and the reset class words) complete
+  // one thread per group (row-major over the tile's tracks: a wave's LDS reads fall K words apart, conflict-free)
+  const uint32_t mv = p.min_votes > 1u ? p.min_votes : 1u;
+  for (uint32_t g2 = tid; g2 < 64u * TPT; g2 += blockDim.x) {
+    const uint32_t row = g2 / TPT, tr = g2 % TPT;
+    const uint32_t gi = m0 + row, gt = t0 + tr;
+    if (gi >= N || gt >= T) continue;
+    const uint32_t* wp = s_w + row * KS + tr * K;
+    double sum = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+      const float w = __uint_as_float(wp[k]);
+      if (w == w) { sum += (double)w; ++cnt; }
+    }
+    if (cnt >= mv) {
+      const unsigned long long key = (unsigned long long)sa_f32_key((float)sum) << 32;
+      atomicMin(&s_rc[row * K + cnt - 1u], key | gt);
+      atomicMin(&s_cc[tr * K + cnt - 1u], key | gi);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < 64u * K; i += blockDim.x) {
+    const unsigned long long v = s_rc[i];
+    const uint32_t gi = m0 + i / K;
+    if (v != ~0ull && gi < N) __hip_atomic_fetch_min(S.row_cls + (size_t)gi * K + i % K, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < used) {
+    const unsigned long long v = s_cc[tid];
+    const uint32_t gt = t0 + tid / K;
+    if (v != ~0ull && gt < T) __hip_atomic_fetch_min(S.col_cls + (size_t)gt * K + tid % K, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  block_max_key(S.vis_max_key, key_slot, kmax);
+}
+
 // (Tile order: row by row.  An XCD-aware band order — each XCD's L2 keeping one set of candidate panels — was measured at C5 with bands
 // of 1, 2 and 4 tile rows: no difference, the 114 MB working set sits in the 256 MB Infinity Cache and the fabric keeps up.)
 template <int BM, int BN, int KGT, bool PART = false, bool EU = false>
@@ -877,7 +1064,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
-template <int KG, bool PART, bool EU = false>
+template <int KG, bool PART, bool EU = false, bool KP = false>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py, uint32_t nprep) {
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
@@ -890,7 +1077,8 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // frame with several rounds of contraction tiles do not queue behind them): C2 16.8 -> 17.5 us, three observations per track 40.9 -> 48.1.
   uint32_t b = blockIdx.x;
   if (b < gx * gy) {
-    visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, b % gx, b / gx, lds);
+    if constexpr (KP) visual_ktile<EU>(S, p, b % gx, b / gx, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
+    else visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, b % gx, b / gx, lds);
     return;
   }
   b -= gx * gy;
@@ -1305,17 +1493,23 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 // frames, where the other two kinds of work are a sizeable part of the frame — the feature length needs no padding, and the
 // one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
 // it does not apply: the caller falls back to k_frame + k_visual_cost.
-hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep) {
+// the fused first phase applies (and with it, for banks of 2 .. SA_CLS_MAXK observations, the whole-track tiles and their class words)
+bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
-  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return hipErrorNotSupported;
+  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return false;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
-  if (plan != 1 && plan != 2 && plan != 4 && plan != 7) return hipErrorNotSupported;
-  const uint32_t gx = cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
+  return plan == 1 || plan == 2 || plan == 4 || plan == 7;
+}
+hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
+                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep, bool kpass) {
+  const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
+  if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p)) return hipErrorNotSupported;
+  const uint32_t maxTK = maxT * K;
+  const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
   if (!with_prep) prep_blocks = 0;  // lean frame: nothing on its path reads what the preparation blocks write (enqueue_frame)
@@ -1326,6 +1520,11 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
   // against 22.7 (raising the contraction's wave priority changes nothing).
   const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
+  if (kpass) {
+    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    return hipGetLastError();
+  }
   if (eu) {
     if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
     else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);

@@ -496,7 +496,49 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   bool has_verdict;
   int32_t vw0 = -1;
   uint32_t bt = SA_NONE;
+  // SCN_WORDSK (deeper banks through the whole-track tiles of the contraction, sa_gemm.hip): K words per candidate and per track, one per count class —
+  // (key of the f32 sum of the group's weights << 32 | index).  Whether a candidate has ANY group is known at once (it decides
+  // whether the row takes part in the positional vote); WHICH group wins needs the frame's max_dist: W = c max_dist - sum, heaviest
+  // wins, lowest index among equals — folded from the first phase's per-tile slots by this workgroup (one slot per thread, the
+  // wave maxima through LDS at the barrier that is there anyway), then one more barrier for the two tables.
+  __shared__ uint32_t s_wmk[WORDS ? SA_SMALL_N / WAVE : 1];
+  unsigned long long rcls[WORDS ? SA_CLS_MAXK : 1], ccls[WORDS ? SA_CLS_MAXK : 1];
+  bool clsmode = false;
+  if constexpr (WORDS) clsmode = (S.flags & SCN_WORDSK) != 0;
+  if constexpr (WORDS) if (clsmode) {
+    const uint32_t K = S.K;
+    bool any = false;
+#pragma unroll
+    for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+      rcls[c] = (c < K && q < N) ? S.row_cls[(size_t)q * K + c] : ~0ull;
+      ccls[c] = (c < K && q < T) ? S.col_cls[(size_t)q * K + c] : ~0ull;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+      if (rcls[c] != ~0ull) S.row_cls[(size_t)q * K + c] = ~0ull;  // re-armed (most classes of a row are empty: nothing to store)
+      if (ccls[c] != ~0ull) S.col_cls[(size_t)q * K + c] = ~0ull;
+      if (S.tap_row_best && c < K) {  // SA_FLAG_TAP: the class words as the first phase left them ([N K] then [T K])
+        if (q < N) S.tap_row_best[(size_t)q * K + c] = rcls[c];
+        if (q < T) S.tap_col_best[(size_t)q * K + c] = ccls[c];
+      }
+      any = any || rcls[c] != ~0ull;
+    }
+    uint32_t mk = 0;
+    for (uint32_t i = q; i < S.nkeys; i += SA_SMALL_N) {
+      const uint32_t v = S.vis_max_key[i];
+      mk = v > mk ? v : mk;
+    }
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+      const uint32_t ok = __shfl_xor(mk, o);
+      mk = ok > mk ? ok : mk;
+    }
+    if (q % WAVE == 0) s_wmk[q / WAVE] = mk;
+    has_verdict = any;  // feature_winners.contains_key(q)
+    s_bt[q] = SA_NONE;  // (rows / columns beyond N / T)
+    s_cq[q] = SA_NONE;
+  }
   if constexpr (WORDS) {
+   if (!clsmode) {
     // (weight key << 32 | index), all ones = no group at all; lowest weight wins, lowest index on ties — k_bestfit_resolve's order
     const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
     const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
@@ -512,6 +554,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     has_verdict = bt != SA_NONE;  // feature_winners.contains_key(q)
     s_bt[q] = bt;
     s_cq[q] = cq;
+   }
   } else {
     has_verdict = VISUAL && q < N && S.row_has[q];
     vw0 = (VISUAL && q < N) ? S.vis_winner[q] : -1;  // with the first round trip, not after the scan
@@ -564,6 +607,28 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     if (lane == WAVE - 1) s_wsum[q / WAVE] = incl;
   }
   sa_lds_barrier();
+  if constexpr (WORDS) if (clsmode) {
+    uint32_t mk = 0;
+#pragma unroll
+    for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) mk = s_wmk[w2] > mk ? s_wmk[w2] : mk;
+    const double max_dist = mk ? (double)sa_key_f32(mk) : -1.0;
+    auto best_of = [&](const unsigned long long* cls) -> uint32_t {
+      double bw = 0.0;
+      uint32_t bi = SA_NONE;
+#pragma unroll
+      for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+        if (cls[c] == ~0ull) continue;
+        const double w = (double)(c + 1u) * max_dist - (double)sa_key_f32((uint32_t)(cls[c] >> 32));
+        const uint32_t i = (uint32_t)cls[c];
+        if (bi == SA_NONE || w > bw || (w == bw && i < bi)) { bw = w; bi = i; }
+      }
+      return bi;
+    };
+    bt = best_of(rcls);
+    s_bt[q] = bt;
+    s_cq[q] = best_of(ccls);
+    sa_lds_barrier();
+  }
   if constexpr (WORDS) {
     if (has_verdict && s_cq[bt] == q) vw0 = (int32_t)bt;  // the candidate that is best in its own best column wins it
     s_cexcl[q] = q < T && excluded(q);
