@@ -510,8 +510,12 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     bool any = false;
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
-      rcls[c] = (c < K && q < N) ? S.row_cls[(size_t)q * K + c] : ~0ull;
-      ccls[c] = (c < K && q < T) ? S.col_cls[(size_t)q * K + c] : ~0ull;
+      // (no branch around the loads: with `c < K ? load : ~0` every class became a basic block of its own and the 2 K round trips ran
+      // one after the other, ~1 us per class; the clamped index re-reads a word that is needed anyway)
+      const unsigned long long rv = S.row_cls[(size_t)(q < N ? q : 0u) * K + (c < K ? c : 0u)];
+      const unsigned long long cv = S.col_cls[(size_t)(q < T ? q : 0u) * K + (c < K ? c : 0u)];
+      rcls[c] = (c < K && q < N) ? rv : ~0ull;
+      ccls[c] = (c < K && q < T) ? cv : ~0ull;
     }
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
