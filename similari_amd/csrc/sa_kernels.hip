@@ -510,12 +510,17 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     bool any = false;
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
-      // (no branch around the loads: with `c < K ? load : ~0` every class became a basic block of its own and the 2 K round trips ran
-      // one after the other, ~1 us per class; the clamped index re-reads a word that is needed anyway)
-      const unsigned long long rv = S.row_cls[(size_t)(q < N ? q : 0u) * K + (c < K ? c : 0u)];
-      const unsigned long long cv = S.col_cls[(size_t)(q < T ? q : 0u) * K + (c < K ? c : 0u)];
-      rcls[c] = (c < K && q < N) ? rv : ~0ull;
-      ccls[c] = (c < K && q < T) ? cv : ~0ull;
+      // all 2 x SA_CLS_MAXK loads issued together, whatever K is (the clamped index re-reads a word that is needed anyway): with the
+      // load inside `c < K ? ... : ~0` every class became a scalar branch with its own load + s_waitcnt vmcnt(0) — K round trips
+      // to memory one after the other, ~1 us per class
+      rcls[c] = S.row_cls[(size_t)(q < N ? q : 0u) * K + (c < K ? c : K - 1u)];
+      ccls[c] = S.col_cls[(size_t)(q < T ? q : 0u) * K + (c < K ? c : K - 1u)];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+      rcls[c] = (c < K && q < N) ? rcls[c] : ~0ull;
+      ccls[c] = (c < K && q < T) ? ccls[c] : ~0ull;
     }
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
