@@ -135,6 +135,7 @@ struct sa_engine {
   uint64_t next_ticket = 1;
   uint32_t K = 1, D = 0, Dp = 0;
   bool bf_words_euclid = false;         // euclidean, bank depth 1: k_visual_euclid can reduce the vote into the vote words (frames up to 1024 x 1024)
+  bool bf_tile_forced = false;          // SA_BESTFIT=tile (tests): the weight matrix + k_bestfit_tile also where the contraction could vote itself
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
@@ -695,7 +696,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
     b->words = !(e->visual && small) ? 0 : (b->partials || e->bf_words_euclid) ? 1 : 2;
     // deeper banks: the whole-track tiles of the fused first phase reduce into CLASS words (no weight matrix, no k_bestfit_tile) wherever
     // that launch applies (every scene with features, rows of a multiple of 32 floats, cosine or the euclidean expansion)
-    if (b->words == 2 && e->K >= 2 && e->K <= SA_CLS_MAXK && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME)) {
+    if (b->words == 2 && e->K >= 2 && e->K <= SA_CLS_MAXK && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->bf_tile_forced) {
       bool all_feats = true;
       for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
       SaParams P = e->P;
@@ -858,6 +859,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
     const char* bf = getenv("SA_BESTFIT");
     e->bf_partials = cfg->visual_kind == SA_VIS_COSINE && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
     e->bf_words_euclid = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
+    e->bf_tile_forced = bf && !strcmp(bf, "tile");
   }
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
