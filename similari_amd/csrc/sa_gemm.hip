@@ -1502,7 +1502,10 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
-  return plan == 1 || plan == 2 || plan == 4 || plan == 7;
+  if (plan == 1 || plan == 2 || plan == 4 || plan == 7) return true;
+  // deeper banks: the whole-track tiles (64 x 64, class words) replace THREE launches of the other family's path (positional tiles,
+  // the contraction on wider tiles, k_bestfit_tile) — C2's frame with two observations per track: 42.9 us there
+  return K >= 2 && K <= SA_CLS_MAXK;
 }
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p, hipStream_t st, bool partials, bool with_prep, bool kpass) {
