@@ -236,7 +236,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p, hipStream_t st, bool partials, bool with_prep = true, bool kpass = false);
-bool sa_frame_visual_ok(uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p);
+bool sa_frame_visual_ok(uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words);
 void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);

@@ -701,7 +701,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
       for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
       SaParams P = e->P;
       P.eu_mfma = b->eu_mfma ? 1u : 0u;
-      if (all_feats && sa_frame_visual_ok(ns, maxN, maxT, e->K, e->D, P)) b->words = 3;
+      if (all_feats && sa_frame_visual_ok(ns, maxN, maxT, e->K, e->D, P, true)) b->words = 3;
     }
   }
   *maxN_out = maxN;

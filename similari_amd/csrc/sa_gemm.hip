@@ -1494,7 +1494,7 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 // one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
 // it does not apply: the caller falls back to k_frame + k_visual_cost.
 // the fused first phase applies (and with it, for banks of 2 .. SA_CLS_MAXK observations, the whole-track tiles and their class words)
-bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p) {
+bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words) {
   static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
   const uint32_t maxTK = maxT * K;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
@@ -1503,14 +1503,15 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
   if (plan == 1 || plan == 2 || plan == 4 || plan == 7) return true;
-  // deeper banks: the whole-track tiles (64 x 64, class words) replace THREE launches of the other family's path (positional tiles,
-  // the contraction on wider tiles, k_bestfit_tile) — C2's frame with two observations per track: 42.9 us there
-  return K >= 2 && K <= SA_CLS_MAXK;
+  // deeper banks with class words: the whole-track tiles (64 x 64) replace THREE launches of the other family's path (positional
+  // tiles, the contraction on wider tiles, k_bestfit_tile) — C2's frame with two observations per track: 42.9 us there.  (Only
+  // with class words: the matrix mode's per-tile slots are laid out by the engine for the plan's own tile grid.)
+  return class_words && K >= 2 && K <= SA_CLS_MAXK;
 }
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p, hipStream_t st, bool partials, bool with_prep, bool kpass) {
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
-  if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p)) return hipErrorNotSupported;
+  if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;
   const uint32_t maxTK = maxT * K;
   const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
