@@ -44,6 +44,24 @@ def workload(name: str, seed: int):
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
         return cfg, [sc], "VisualSORT 1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K=1 (BASELINE C2)"
+    if name in ("c2b", "c2bk3"):
+        # BatchVisualSORT (visual_sort/batch_api.rs:213-317): S scenes of the C2 frame in ONE request set (grid.z = scene)
+        n = t = 1000
+        d, k = 512, (3 if name.endswith("k3") else 1)
+        scs = [synth.visual_scene(rng, t, n, d, k) for _ in range(8)]
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                              max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
+                              positional_min_confidence=0.1, max_idle_epochs=5)
+        return cfg, scs, f"BatchVisualSORT 8 scenes x (1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K={k}) per GPU in one request set"
+    if name == "c2t":
+        # the frame a VisualSORT tracker loop hands over once idle tracks linger (max_idle_epochs): more table rows than detections
+        n, t = 1000, 1500
+        d, k = 512, 1
+        sc = synth.visual_scene(rng, t, n, d, k)
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                              max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
+                              positional_min_confidence=0.1, max_idle_epochs=5)
+        return cfg, [sc], "VisualSORT 1000 dets x 1500 tracks (a tracker loop's table with idle tracks), 512-d cosine + IoU(0.3), K=1"
     if name in ("c2k3", "c2k2"):
         n = t = 1000
         d, k = 512, int(name[-1])

@@ -109,6 +109,12 @@ typedef struct sa_config {
   /* device-side track upkeep (sa_tracks_apply): the COLLECT gates of VisualMetric::optimize, visual_sort/metric.rs:337-349 */
   float visual_minimal_quality_collect;
   float visual_minimal_own_area_percentage_collect;
+
+  /* tuning / test knobs (0 = the engine's own choice).  Per ENGINE: two engines of one process may differ. */
+  int32_t gemm_plan;               /* n + 1 pins tile plan n of the contraction (sa_gemm.hip: 0 = 128x128, 5 = 64x128, 6 = 128x64, 1/2/4 = 64x64
+                                      with 1/2/4 k-groups, 7/8 = the ring variants) */
+  uint32_t euclid_backoff_frames;  /* euclidean engines: after a frame that reported itself ill-conditioned for the matrix-core expansion, that
+                                      SCENE's next frames run on the vector-pipe kernel, this many of them (0 = 256), before another try */
 } sa_config;
 
 #define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */
@@ -121,6 +127,15 @@ typedef struct sa_config {
 #define SA_FLAG_TAP 0x80u           /* parity tests: the assignment tail copies out what the frame's OWN launches produced — the BestFit vote
                                        words of the first phase and the edge counts of the positional tiles — before it consumes them, for
                                        sa_tap_votes / sa_tap_edges.  Same kernels, same launches; three more stores per candidate. */
+
+/* Path switches (parity tests, measurements): each pins ONE decision the engine otherwise takes by frame size / metric.  They live in
+ * the config, not in the environment: two engines of one process may run different paths. */
+#define SA_FLAG_GENERAL_TAIL 0x100u     /* the many-workgroup assignment tail (k_assign_label + k_assign_solve) also on frames the one-workgroup tail would take */
+#define SA_FLAG_NEVER_LEAN 0x200u       /* the frame-preparation blocks ride in every first phase (by default frames whose path does not read them leave them out) */
+#define SA_FLAG_SEPARATE_RESOLVE 0x400u /* no vote words: per-tile partials + k_bestfit_resolve as a launch of its own */
+#define SA_FLAG_EUCLID_VALU 0x800u      /* euclidean engines: always the vector-pipe kernel (direct sums of squares) */
+#define SA_FLAG_EUCLID_MFMA 0x1000u     /* euclidean engines: always the matrix-core expansion + flagged recompute, also after an ill-conditioned frame */
+#define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,
  * one observation per track, max_idle_epochs 5, Kalman weights 1/20 and 1/160 (kalman_2d_box.rs:26), device -1. */

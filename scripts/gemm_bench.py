@@ -16,9 +16,7 @@ for name in which:
     a = rng.standard_normal((n, d)).astype(np.float32)
     b = rng.standard_normal((t, d)).astype(np.float32)
     for plan in plans:
-        if plan == "auto": os.environ.pop("SA_GEMM_PLAN", None)
-        else: os.environ["SA_GEMM_PLAN"] = plan
-        eng = Engine(abi.make_config())
+        eng = Engine(abi.make_config(gemm_plan=None if plan == "auto" else int(plan)))
         iters = 50 if name.startswith("c2") else 10
         _, ms = eng.distance_matrix(kind, a, b, iters=iters, want_out=False)
         eng.close()

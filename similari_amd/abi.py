@@ -37,6 +37,16 @@ SA_FLAG_GRAPH = 0x8
 SA_FLAG_FUSED_FRAME = 0x10
 SA_FLAG_SEPARATE_FRAME = 0x20
 SA_FLAG_TAP = 0x80
+SA_FLAG_GENERAL_TAIL = 0x100
+SA_FLAG_NEVER_LEAN = 0x200
+SA_FLAG_SEPARATE_RESOLVE = 0x400
+SA_FLAG_EUCLID_VALU = 0x800
+SA_FLAG_EUCLID_MFMA = 0x1000
+SA_FLAG_BESTFIT_TILE = 0x2000
+
+# Path switches OR-ed into every config make_config builds (tests: the `sa_path` fixture of tests/conftest.py sends whole parity tests
+# through the engine's other paths in the same process) and a tile-plan override for the same purpose.
+EXTRA_FLAGS = 0
 
 
 class sa_box(C.Structure):
@@ -93,6 +103,8 @@ class sa_config(C.Structure):
         ("flags", C.c_uint32),
         ("visual_minimal_quality_collect", C.c_float),
         ("visual_minimal_own_area_percentage_collect", C.c_float),
+        ("gemm_plan", C.c_int32),
+        ("euclid_backoff_frames", C.c_uint32),
     ]
 
 
@@ -257,6 +269,8 @@ def make_config(
     flags=0,
     visual_minimal_quality_collect=0.0,
     visual_minimal_own_area_percentage_collect=0.0,
+    gemm_plan=None,
+    euclid_backoff_frames=0,
 ):
     """sa_config with the reference's defaults; returns (cfg, keepalive)."""
     keep = Keep()
@@ -290,7 +304,9 @@ def make_config(
     cfg.constraint_max_dist = _ptr(dists, C.c_float)
     cfg.kf_position_weight = kf_position_weight
     cfg.kf_velocity_weight = kf_velocity_weight
-    cfg.flags = flags
+    cfg.flags = flags | EXTRA_FLAGS
+    cfg.gemm_plan = 0 if gemm_plan is None else int(gemm_plan) + 1
+    cfg.euclid_backoff_frames = euclid_backoff_frames
     cfg.visual_minimal_quality_collect = visual_minimal_quality_collect
     cfg.visual_minimal_own_area_percentage_collect = visual_minimal_own_area_percentage_collect
     cfg._keep = keep

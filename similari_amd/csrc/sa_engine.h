@@ -170,6 +170,8 @@ struct SaParams {
                                 // instead of writing per-tile partials; the one-workgroup tail reads and re-arms them
   uint32_t eu_mfma;             // per launch: euclidean distances through the matrix-core contraction (expansion + flagged direct recompute)
   float eu_rho;                 // a cell with d^2 < eu_rho (|a|^2 + |b|^2) is recomputed directly
+  uint32_t force_general;       // SA_FLAG_GENERAL_TAIL: the many-workgroup assignment tail (and the launches that feed it) whatever the frame size
+  int32_t gemm_plan;            // sa_config.gemm_plan - 1: the contraction's tile plan pinned (tuning / tests), -1 = tile_plan()'s own choice
 };
 
 // Profile mode (SA_FLAG_PROFILE): while sa_prof_start is set, the per-frame launches go through hipExtLaunchKernelGGL,
@@ -237,7 +239,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p, hipStream_t st, bool partials, bool with_prep = true, bool kpass = false);
 bool sa_frame_visual_ok(uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words);
-void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn);
+void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, int32_t plan_override, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
 // stage 1 label + push, 3 solve + results; stage 5 = the whole tail in ONE workgroup per
@@ -249,7 +251,7 @@ hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32
                                hipStream_t st);
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
-                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st);
+                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st, int32_t plan_override = -1);
 
 // ---- device-side track upkeep (sa_upkeep.hip) ----
 struct ApplyArgs {

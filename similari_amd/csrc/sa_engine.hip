@@ -45,6 +45,8 @@ struct SceneTable {
   DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
   DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
   std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
+  uint32_t eu_valu_left = 0;       // euclidean engines: frames of THIS scene still to run on the vector-pipe kernel after one of its frames
+                                   // reported itself ill-conditioned for the matrix-core expansion (sa_config.euclid_backoff_frames)
 };
 
 struct Slot {  // one scene of a request set
@@ -135,13 +137,12 @@ struct sa_engine {
   uint64_t next_ticket = 1;
   uint32_t K = 1, D = 0, Dp = 0;
   bool bf_words_euclid = false;         // euclidean, bank depth 1: k_visual_euclid can reduce the vote into the vote words (frames up to 1024 x 1024)
-  bool bf_tile_forced = false;          // SA_BESTFIT=tile (tests): the weight matrix + k_bestfit_tile also where the contraction could vote itself
+  bool bf_tile_forced = false;          // SA_FLAG_BESTFIT_TILE: the weight matrix + k_bestfit_tile also where the contraction could vote itself
   bool bf_partials = false;             // the contraction emits the BestFit partials itself (cosine, bank depth 1): no weight matrix,
                                         // no k_bestfit_tile; the parity taps re-run it in matrix mode
   bool visual = false;
   bool eu_mfma_ok = false;              // euclidean engines: the expansion is usable at this feature length (eu_rho < 1/3)
   float eu_rho = 0.f;
-  uint32_t eu_valu_left = 0;            // frames still to run on the vector-pipe kernel after an ill-conditioned frame was reported
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
@@ -596,9 +597,9 @@ int ensure_prepped(sa_engine* e, Bank* b) {
 // the side stream between two events).  Also the body of the captured graph.
 int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32_t maxN, uint32_t maxT, hipEvent_t done = nullptr, bool* done_attached = nullptr) {
   hipStream_t st = e->stream;
-  // SA_TAIL=general forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
-  // SA_RESOLVE=separate keeps the vote's resolve step a launch of its own (no vote words)
-  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  // SA_FLAG_GENERAL_TAIL forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
+  // SA_FLAG_SEPARATE_RESOLVE keeps the vote's resolve step a launch of its own (no vote words)
+  const bool force_general = (e->cfg.flags & SA_FLAG_GENERAL_TAIL) != 0;
   const bool small_tail = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general;
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
@@ -618,8 +619,8 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // geometry / usability / padded features + norms and reset the state of the general tail and of the resolve kernel; the positional
   // tiles and the raw-row contraction derive what they need from the uploaded records themselves, the one-workgroup tail with vote
   // words keeps its state in LDS — so on such frames nothing reads them.  What does (sa_tracks_apply's feature-bank step, the
-  // visual tap) calls ensure_prepped first.  SA_LEAN=0 (tests): never lean.
-  static const bool never_lean = getenv("SA_LEAN") && !strcmp(getenv("SA_LEAN"), "0");
+  // visual tap) calls ensure_prepped first.  SA_FLAG_NEVER_LEAN (tests): never lean.
+  const bool never_lean = (e->cfg.flags & SA_FLAG_NEVER_LEAN) != 0;
   const bool lean_ok = small_tail && !never_lean && (!e->visual || words);
   bool with_prep = !lean_ok;
   bool fused = false;
@@ -678,20 +679,27 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
   for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, b->slots[i], b->slots[i]->N, b->slots[i]->T));
   // Euclidean engines: the matrix-core path unless a recent frame reported itself ill-conditioned for the expansion (most of its
   // cells needed the direct recompute: features far from the origin compared with their spread) — then the vector-pipe kernel for
-  // the next 256 frames, and another try.
+  // that SCENE's next sa_config.euclid_backoff_frames frames (256 by default), and another try.  A request set runs ONE kernel
+  // family: the vector-pipe one while any of its scenes is backing off.
   const bool euclid = e->cfg.visual_kind == SA_VIS_EUCLIDEAN;
-  static const bool eu_off = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "valu");   // measurements / tests: always the vector-pipe kernel
-  static const bool eu_force = getenv("SA_EUCLID") && !strcmp(getenv("SA_EUCLID"), "mfma");  // ... always the contraction
-  b->eu_mfma = euclid && e->eu_mfma_ok && !eu_off && (e->eu_valu_left == 0 || eu_force);
-  if (euclid && e->eu_valu_left && count_frame) --e->eu_valu_left;
+  const bool eu_off = (e->cfg.flags & SA_FLAG_EUCLID_VALU) != 0;    // measurements / tests: always the vector-pipe kernel
+  const bool eu_force = (e->cfg.flags & SA_FLAG_EUCLID_MFMA) != 0;  // ... always the contraction
+  bool backing_off = false;
+  if (euclid)
+    for (uint32_t i = 0; i < ns; ++i) {
+      SceneTable* sc = b->slots[i]->scene;
+      backing_off = backing_off || sc->eu_valu_left != 0;
+      if (sc->eu_valu_left && count_frame) --sc->eu_valu_left;
+    }
+  b->eu_mfma = euclid && e->eu_mfma_ok && !eu_off && (!backing_off || eu_force);
   b->partials = e->bf_partials || (b->eu_mfma && e->bf_words_euclid);
-  if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, &b->tile_bm, &b->tile_bn);
+  if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, e->P.gemm_plan, &b->tile_bm, &b->tile_bn);
   {
     // vote words (frames of at most 1024 x 1024 on the one-workgroup tail): the first phase reduces the BestFit vote into one 64-bit
     // word per candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip) and the tail reads its
     // two words per thread — no resolve launch.  One observation per track: the cost kernel itself; deeper banks: k_bestfit_tile.
-    static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
-    static const bool separate_resolve = getenv("SA_RESOLVE") && !strcmp(getenv("SA_RESOLVE"), "separate");
+    const bool force_general = (e->cfg.flags & SA_FLAG_GENERAL_TAIL) != 0;
+    const bool separate_resolve = (e->cfg.flags & SA_FLAG_SEPARATE_RESOLVE) != 0;
     const bool small = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general && !separate_resolve;
     b->words = !(e->visual && small) ? 0 : (b->partials || e->bf_words_euclid) ? 1 : 2;
     // deeper banks: the whole-track tiles of the fused first phase reduce into CLASS words (no weight matrix, no k_bestfit_tile) wherever
@@ -855,11 +863,11 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   e->visual = cfg->visual_kind != SA_VIS_NONE;
   e->K = e->visual ? cfg->max_observations : 1;
   {
-    // SA_BESTFIT=tile keeps the two-kernel BestFit (weight matrix + k_bestfit_tile) for A/B runs and for the tests of that path
-    const char* bf = getenv("SA_BESTFIT");
-    e->bf_partials = cfg->visual_kind == SA_VIS_COSINE && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
-    e->bf_words_euclid = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->K == 1 && cfg->visual_min_votes <= 1 && !(bf && !strcmp(bf, "tile"));
-    e->bf_tile_forced = bf && !strcmp(bf, "tile");
+    // SA_FLAG_BESTFIT_TILE keeps the two-kernel BestFit (weight matrix + k_bestfit_tile) for A/B runs and for the tests of that path
+    const bool bf = (cfg->flags & SA_FLAG_BESTFIT_TILE) != 0;
+    e->bf_partials = cfg->visual_kind == SA_VIS_COSINE && e->K == 1 && cfg->visual_min_votes <= 1 && !bf;
+    e->bf_words_euclid = cfg->visual_kind == SA_VIS_EUCLIDEAN && e->K == 1 && cfg->visual_min_votes <= 1 && !bf;
+    e->bf_tile_forced = bf;
   }
   e->D = e->visual ? cfg->feature_len : 0;
   e->Dp = e->visual ? (e->D + 31u) / 32u * 32u : 0;
@@ -895,6 +903,8 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.kf_velocity_weight = cfg->kf_velocity_weight;
   P.max_idle = cfg->max_idle_epochs;
   P.vote_words = 0;  // set per frame by enqueue_frame
+  P.force_general = (cfg->flags & SA_FLAG_GENERAL_TAIL) ? 1u : 0u;
+  P.gemm_plan = cfg->gemm_plan > 0 ? cfg->gemm_plan - 1 : -1;
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
   for (uint32_t i = 0; i < cfg->n_constraints; ++i) {
@@ -1260,7 +1270,7 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   if (s->ran && s->h_out.p && e->cfg.visual_kind == SA_VIS_EUCLIDEAN) {
     // what the slot's previous frame reported (the bank is idle: that frame has retired)
     const uint32_t* st4 = (const uint32_t*)((const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
-    if (st4[0]) e->eu_valu_left = 256;
+    if (st4[0] && s->scene) s->scene->eu_valu_left = e->cfg.euclid_backoff_frames ? e->cfg.euclid_backoff_frames : 256u;  // (the scene that frame belonged to)
   }
   s->scene = sc;
   s->epoch = epoch;
@@ -1331,6 +1341,7 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
 int sa_batch_run(sa_engine* e) {
   if (!e) return SA_ERR_BAD_ARG;
   HIPCHK(e, hipSetDevice(e->device));
+  TRY(finish_applies(e));  // (the launches read the track tables: see sa_pipe_launch)
   return run_pipeline(e);
 }
 
@@ -1456,6 +1467,9 @@ int sa_pipe_launch(sa_engine* e, uint64_t ticket) {
   Bank* b = bank_of_ticket(e, ticket);
   if (!b || b->state != 1) return fail(e, SA_ERR_STATE, "ticket %llu is not staged (unknown, launched already, or waited)", (unsigned long long)ticket);
   HIPCHK(e, hipSetDevice(e->device));
+  // the kernels queued here read the track tables: an upkeep step that is still between sa_tracks_apply_begin and _end has written the
+  // AXIS-ALIGNED polygon for refreshed oriented rows and queues the right one only when it is finished (apply_finish) — finish it first
+  TRY(finish_applies(e));
   uint32_t maxN = 0, maxT = 0;
   TRY(bank_prepare(e, b, &maxN, &maxT));  // the track tables as they are NOW (an upsert / sa_tracks_apply may have come in between)
   if (!b->staged_inline) HIPCHK(e, hipStreamWaitEvent(e->stream, b->ev_staged, 0));
@@ -1478,6 +1492,7 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
   if (!b || (b->state != 2 && b->state != 3))
     return fail(e, SA_ERR_STATE, "ticket %llu has not been launched (or is unknown)", (unsigned long long)ticket);
   if (b->n_slots && !res) return fail(e, SA_ERR_BAD_ARG, "sa_pipe_wait: null result array");
+  TRY(finish_applies(e));  // (slot numbers are about to mean THIS ticket's scenes: a pending sa_tracks_apply_end could no longer name its slot)
   if (b->state == 2) {
     hipError_t s = hipEventSynchronize(b->ev_done);
     if (s != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(s));
@@ -2119,10 +2134,10 @@ int sa_feature_distance_matrix(sa_engine* e, int32_t kind, uint32_t n, uint32_t 
     if (sa_launch_pad_features((const float*)ra.p, n, d, d8, 1, nullptr, nullptr, (float*)pa.p, (float*)na.p, nullptr, nullptr, st) != hipSuccess ||
         sa_launch_pad_features((const float*)rb.p, t, d, d8, 1, nullptr, nullptr, (float*)pb.p, (float*)nb.p, nullptr, nullptr, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "pad launch failed"); break; }
     // one warm-up launch, then `iters` timed launches of the contraction kernel alone
-    if (sa_launch_distance_matrix(kind, (const float*)pa.p, (const float*)na.p, (const float*)pb.p, (const float*)nb.p, n, t, d8, (float*)o.p, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "kernel launch failed"); break; }
+    if (sa_launch_distance_matrix(kind, (const float*)pa.p, (const float*)na.p, (const float*)pb.p, (const float*)nb.p, n, t, d8, (float*)o.p, st, e->P.gemm_plan) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "kernel launch failed"); break; }
     hipEventRecord(e->ev_t0, st);
     for (uint32_t i = 0; i < iters; ++i)
-      sa_launch_distance_matrix(kind, (const float*)pa.p, (const float*)na.p, (const float*)pb.p, (const float*)nb.p, n, t, d8, (float*)o.p, st);
+      sa_launch_distance_matrix(kind, (const float*)pa.p, (const float*)na.p, (const float*)pb.p, (const float*)nb.p, n, t, d8, (float*)o.p, st, e->P.gemm_plan);
     hipEventRecord(e->ev_t1, st);
     if (hipStreamSynchronize(st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "stream sync failed: %s", hipGetErrorString(hipGetLastError())); break; }
     float ms = 0.f;

@@ -1453,8 +1453,8 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // (3 rounds of 16384 cells), 64x128 gives 1280 = 5 per CU (5 rounds of 8192 cells) — 17 % less work on the critical CU.
 // Frames that fit in one round of 64x64 tiles split k over 2 or 4 wave groups inside each workgroup so that every SIMD
 // still holds 2-4 waves.
-static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp) {
-  if (const char* f = getenv("SA_GEMM_PLAN")) return atoi(f);  // tuning override
+static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp, int32_t plan_override = -1) {
+  if (plan_override >= 0) return plan_override;  // sa_config.gemm_plan: tuning / tests
   struct Cand { int plan, bm, bn; };
   const Cand cands[4] = {{0, 128, 128}, {5, 64, 128}, {6, 128, 64}, {1, 64, 64}};
   int best = 1;
@@ -1477,11 +1477,11 @@ static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp
 
 // Tile extents the visual cost kernel will use for a batch with these maxima (the host needs them for the per-scene number of
 // max-key slots, SceneDev::nkeys).
-void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, uint32_t* bm, uint32_t* bn) {
+void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, int32_t plan_override, uint32_t* bm, uint32_t* bn) {
   *bm = 64; *bn = 64;
   if (visual_kind == SA_VIS_EUCLIDEAN && !eu_mfma) { *bm = EU_BM; *bn = EU_BN; return; }  // k_visual_euclid's block tile (vis_max_key slots)
   if ((visual_kind != SA_VIS_COSINE && visual_kind != SA_VIS_EUCLIDEAN) || !maxN || !maxTK) return;
-  switch (tile_plan(maxN, maxTK, ns, Dp)) {
+  switch (tile_plan(maxN, maxTK, ns, Dp, plan_override)) {
     case 0: case 8: *bm = 128; *bn = 128; break;
     case 5: *bm = 64; *bn = 128; break;
     case 6: *bm = 128; *bn = 64; break;
@@ -1495,11 +1495,11 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 // it does not apply: the caller falls back to k_frame + k_visual_cost.
 // the fused first phase applies (and with it, for banks of 2 .. SA_CLS_MAXK observations, the whole-track tiles and their class words)
 bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words) {
-  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const bool force_general = p.force_general != 0;
   const uint32_t maxTK = maxT * K;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return false;
-  const int plan = tile_plan(maxN, maxTK, ns, p.Dp);
+  const int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
   if (plan == 1 || plan == 2 || plan == 4 || plan == 7) return true;
@@ -1543,7 +1543,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   sa_trace_hook(st, cdiv(maxTK, 64) * cdiv(maxN, 64));
   if (p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma) {
     // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
-    int plan = tile_plan(maxN, maxTK, ns, p.Dp);
+    int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
     plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6) ? plan : 1;
 #define SA_EU_LAUNCH(BM_, BN_, PART_) SA_LAUNCH((k_visual_cosine<BM_, BN_, 1, PART_, true>), dim3(cdiv(maxTK, BN_), cdiv(maxN, BM_), ns), dim3(256), 0, st, scenes, p)
     switch (plan) {
@@ -1557,7 +1557,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   }
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
-    int plan = tile_plan(maxN, maxTK, ns, Dp);
+    int plan = tile_plan(maxN, maxTK, ns, Dp, p.gemm_plan);
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {
@@ -1586,11 +1586,11 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
 }
 
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
-                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st) {
+                                     uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st, int32_t plan_override) {
   if (!n || !t) return hipSuccess;
   sa_trace_hook(st, cdiv(t, 64) * cdiv(n, 64));
   if (kind == SA_VIS_COSINE) {
-    switch (tile_plan(n, t, 1, dp)) {
+    switch (tile_plan(n, t, 1, dp, plan_override)) {
       case 0: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 1>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 5: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 1>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 7: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 0>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;

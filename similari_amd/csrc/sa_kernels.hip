@@ -1660,7 +1660,7 @@ hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uin
 // First launch of a frame: positional tiles + frame-preparation blocks (see k_frame).
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
                            hipStream_t st, int prep) {
-  static const bool force_general = getenv("SA_TAIL") && !strcmp(getenv("SA_TAIL"), "general");
+  const bool force_general = p.force_general != 0;
   // wide (16 x 256) positional tiles when the frame still gives at least one block per CU that way
   const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
   const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
@@ -1699,20 +1699,32 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t ns, uint32_t maxN,
   else SA_LAUNCH(k_bestfit_resolve<false>, dim3(cdiv(maxN, 4), 1, ns), dim3(256), 0, st, scenes);
   return hipGetLastError();
 }
-// one instantiation of the general tail's solver: the dynamic LDS limit is raised once per size class (above 64 KB it has to be asked for)
+// one instantiation of the general tail's solver.  Above 64 KB the dynamic LDS limit has to be asked for, and the attribute belongs to
+// the (function, DEVICE) pair: one engine thread per GPU (sa_cluster) launches the same instantiation on different devices, so the
+// size already granted is remembered per device (an atomic per ordinal: the threads do not share a lock on the launch path).
+#include <atomic>
+#define SA_MAX_DEVICES 64
 template <bool VIS, int NT, int CPT, bool LDS_STATE>
-static void launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipStream_t st, const SceneDev* scenes) {
-  if (LDS_STATE) {
-    static size_t allowed = 0;
-    if (lds > allowed) {
-      hipFuncSetAttribute((const void*)k_assign_solve<VIS, NT, CPT, LDS_STATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      allowed = lds;
+static hipError_t launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipStream_t st, const SceneDev* scenes) {
+  if (LDS_STATE && lds > 64u * 1024u) {
+    static std::atomic<size_t> allowed[SA_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    const bool cached = dev >= 0 && dev < SA_MAX_DEVICES;
+    if (!cached || lds > allowed[dev].load(std::memory_order_relaxed)) {
+      const hipError_t ae = hipFuncSetAttribute((const void*)k_assign_solve<VIS, NT, CPT, LDS_STATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ae != hipSuccess) return ae;
+      if (cached) {
+        size_t cur = allowed[dev].load(std::memory_order_relaxed);
+        while (cur < lds && !allowed[dev].compare_exchange_weak(cur, lds, std::memory_order_relaxed)) {}
+      }
     }
   }
   SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes, row_wgs);
+  return hipSuccess;
 }
 template <int NT, int CPT>
-static void launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
   // the row workgroups, and behind them helpers that only take components off the scene's queues (a crowd has dozens of knots, one
   // wavefront of a workgroup each: 64 workgroups per scene left the 1000 x 2500 crowd frame two rounds of them, 30 us; 128: 24 us) —
   // fewer per scene in a wide batch
@@ -1720,10 +1732,10 @@ static void launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint
   const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
   const dim3 grid(rows > want ? rows : want, 1, ns);
   const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u);  // (bit 31: no middle tier)
-  if (vis && in_lds) launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
-  else if (vis) launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
-  else if (in_lds) launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
-  else launch_solve_one<false, NT, CPT, false>(grid, rw, lds, st, scenes);
+  if (vis && in_lds) return launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
+  if (vis) return launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
+  if (in_lds) return launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
+  return launch_solve_one<false, NT, CPT, false>(grid, rw, lds, st, scenes);
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
                             hipStream_t st, int stage) {
@@ -1737,12 +1749,14 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const size_t lds = (size_t)maxN * 12 + (size_t)maxT * 8;
       const bool in_lds = lds <= 96u * 1024u;
       const bool no_mid = p.positional_kind == SA_POS_MAHALANOBIS;  // gains of 1e8: beyond the middle tier's 32-bit cells
-      if (maxT <= 256u * 4u) launch_solve<256, 4>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 8u) launch_solve<256, 8>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 16u) launch_solve<256, 16>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 32u) launch_solve<256, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) launch_solve<1024, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      hipError_t se;
+      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
+      if (se != hipSuccess) return se;
       break;
     }
     default:

@@ -269,6 +269,16 @@ ASSOC_HEAD = 4  # int64 words: n_scenes, D, total N, flags (1 = shutdown, 4 = th
 FLAG_SHUTDOWN, FLAG_ABORT = 1, 4
 
 
+class RequestRefused(RuntimeError):
+    """The root refused a request set BEFORE the first collective (a share exceeds the capacities agreed at construction): every rank
+    learns it from its share's flags and skips the set consistently — the only exception a worker loop may swallow."""
+
+
+class ShardFailed(RuntimeError):
+    """A rank's engine call failed between the scatter and the gather: the rank still takes part in the gather (with an error marker
+    in its result block), the root raises this, and the failing rank re-raises its own exception afterwards."""
+
+
 def prefix_bytes(max_scenes: int, capacity_rows: int) -> int:
     """Where the feature rows of a share start: after head, table, boxes and qualities at full capacity, on a 256-byte boundary."""
     from . import abi
@@ -354,9 +364,9 @@ class ShardedAssociator:
         self.cap_b = self.feat_base + (int(capacity_bytes) + 255) // 256 * 256
         pin = device.type == "cuda"
         self.h_req = torch.zeros(self.feat_base if pin else self.cap_b, dtype=torch.uint8, pin_memory=pin)  # GPUs: the prefix only
-        self.h_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, pin_memory=pin)   # ids[rows] (u64) then votes[rows]
+        self.h_res = torch.zeros(self.cap_r * 9 + 8, dtype=torch.uint8, pin_memory=pin)   # ids[rows] (u64), votes[rows], then one status byte (1 = this rank failed)
         self.d_req = torch.zeros(self.cap_b, dtype=torch.uint8, device=device)
-        self.d_res = torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device)
+        self.d_res = torch.zeros(self.cap_r * 9 + 8, dtype=torch.uint8, device=device)
         # the bulk of a share is read where the collective put it: the receive buffer is a registered device block of the engine
         self.in_place = pin and hasattr(engine, "register_device_block")
         if self.in_place:
@@ -364,7 +374,7 @@ class ShardedAssociator:
         if self.rank == root:
             self.h_all = torch.zeros((self.world, self.cap_b), dtype=torch.uint8, pin_memory=pin)
             self.d_all = [torch.zeros(self.cap_b, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.world > 1 else None
-            self.d_gather = [torch.zeros(self.cap_r * 9, dtype=torch.uint8, device=device) for _ in range(self.world)]
+            self.d_gather = [torch.zeros(self.cap_r * 9 + 8, dtype=torch.uint8, device=device) for _ in range(self.world)]
         self.last_local_ms = 0.0
 
     def close(self):
@@ -383,7 +393,7 @@ class ShardedAssociator:
         if flags & FLAG_SHUTDOWN:
             return False
         if flags & FLAG_ABORT:
-            raise RuntimeError("the root refused this request set (a rank's share exceeds the capacities agreed at construction)")
+            raise RequestRefused("the root refused this request set (a rank's share exceeds the capacities agreed at construction)")
         t0 = time.perf_counter()
         dets = []
         for (_, _, b, f, q) in items:
@@ -438,24 +448,41 @@ class ShardedAssociator:
         elif self.in_place:
             self.d_req.copy_(self.h_all[0], non_blocking=True)   # one rank: the share still goes where the engine will read it
         if is_root and refused:   # (the other ranks learn it from their share's flags and skip the set)
-            raise RuntimeError("request set refused: " + refused)
-        if self.in_place:
-            self.h_req.copy_(self.d_req[: self.feat_base])        # the prefix only; the feature rows stay in device memory
-            alive = self._run_share(self.h_req.numpy(), bulk=self.d_req.data_ptr())
-        elif self.world > 1:
-            self.h_req.copy_(self.d_req)
-            alive = self._run_share(self.h_req.numpy())
-        else:
-            alive = self._run_share(self.h_all.numpy()[0])
+            raise RequestRefused("request set refused: " + refused)
+        # Between the scatter and the gather every rank MUST reach the gather, whatever its engine does: a rank that raised here and
+        # went back to its scatter would leave the root blocked in the gather (or the collectives out of step).  A failure is carried
+        # to the root as the status byte of the rank's result block and re-raised on the failing rank after the gather.
+        failure = None
+        alive = True
+        self.h_res.numpy()[9 * self.cap_r] = 0
+        try:
+            if self.in_place:
+                self.h_req.copy_(self.d_req[: self.feat_base])        # the prefix only; the feature rows stay in device memory
+                alive = self._run_share(self.h_req.numpy(), bulk=self.d_req.data_ptr())
+            elif self.world > 1:
+                self.h_req.copy_(self.d_req)
+                alive = self._run_share(self.h_req.numpy())
+            else:
+                alive = self._run_share(self.h_all.numpy()[0])
+        except RequestRefused:
+            raise   # (every rank sees the same flag: nobody enters the gather)
+        except Exception as ex:  # noqa: BLE001 - anything the engine / the unpacking raised
+            failure = ex
+            self.h_res.numpy()[9 * self.cap_r] = 1
         if not alive:
             return None
         if self.world > 1:
             self.d_res.copy_(self.h_res, non_blocking=True)
             dist.gather(self.d_res, self.d_gather if is_root else None, dst=self.root, group=self.group)
+        if failure is not None:
+            raise failure
         if not is_root:
             return ()
         out = []
         per_rank = [self.d_gather[r].cpu().numpy() if self.world > 1 else self.h_res.numpy() for r in range(self.world)]
+        bad = [r for r in range(self.world) if per_rank[r][9 * self.cap_r]]
+        if bad:
+            raise ShardFailed(f"rank(s) {bad} failed inside their share of the request set (their own exception is raised there)")
         offs = [[0] for _ in range(self.world)]
         for r in range(self.world):
             for it in shares[r]:
@@ -477,13 +504,15 @@ class ShardedAssociator:
             self.eng.upsert(scene_id, abi.make_tracks(**obj[0]))
 
     def serve_forever(self):
-        """Worker loop.  A refused request set raises on the root only; the workers skip it and keep serving."""
+        """Worker loop.  A REFUSED request set (RequestRefused: decided by the root before the first collective, seen by every rank)
+        is skipped; anything else — an engine error inside this rank's share (reported to the root through the gather first), a dead
+        process group — ends the loop by raising."""
         assert self.rank != self.root
         while True:
             try:
                 if self.associate(None) is None:
                     return
-            except RuntimeError:
+            except RequestRefused:
                 continue
 
     def shutdown(self):

@@ -174,6 +174,7 @@ def check_sort(cfg, sc, epoch=1, kf=None, require_ids=True):
     return ids, ref
 
 
+@pytest.mark.paths("general", "never_lean")
 @pytest.mark.parametrize("oriented", [False, True])
 @pytest.mark.parametrize("n,t", [(257, 300), (64, 64), (1, 1), (130, 65)])
 def test_sort_iou_parity(oriented, n, t):
@@ -188,54 +189,16 @@ def test_sort_iou_parity(oriented, n, t):
 
 def test_general_assignment_tail_matches_oracle_too():
     """Frames with more than 1024 candidates leave the one-workgroup tail for the two-kernel one (component lists + one solver
-    thread per component).  It is exercised here twice: at a size that needs it, and — in a child process, because the switch
-    is read once per process — forced onto the small frames of the other parity tests."""
+    thread per component).  Here at a size that needs it; forced onto the small frames of the other parity tests by the `general`
+    path of their `paths` marker (SA_FLAG_GENERAL_TAIL, tests/conftest.py)."""
     rng = np.random.default_rng(5)
     sc = synth.sort_scene(rng, 1500, 1300, canvas=(6000.0, 4000.0), oriented=True)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
     ids, ref = check_sort(cfg, sc)
     assert (ids != 0).sum() > 900
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, SA_TAIL="general")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_sort_iou_parity or test_sort_maha_parity or test_visual_cosine_parity or test_batched_scenes or "
-                        "test_state_kept_clean or test_crowds_against or test_one_giant_component or test_dense_positional_stage or "
-                        "test_random_configurations or test_sort_iou_constraints"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_frames_with_preparation_blocks_match_oracle_too():
-    """SA_LEAN=0: the preparation blocks ride in every frame's first phase (by default frames whose path does not read what they
-    write leave them out).  Same tests, same oracle, in a child process (the switch is read once per process)."""
-    import os
-    import subprocess
-    import sys
-
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_batched_visual or "
-                        "test_sort_iou_parity or test_sort_maha_parity or test_batched_scenes or test_full_size_sort_oriented"],
-                       env=dict(os.environ, SA_LEAN="0"), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_two_kernel_bestfit_matches_oracle_too():
-    """With one observation per track the contraction emits the BestFit partials itself (no weight matrix, no k_bestfit_tile).
-    SA_BESTFIT=tile keeps the matrix + k_bestfit_tile path for those frames as well: same tests, same oracle."""
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, SA_BESTFIT="tile")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_zero_feature"],
-                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
+@pytest.mark.paths("general")
 def test_state_kept_clean_across_frames_of_changing_size():
     """Edge counters, row duals and the union-find forest are not reset at the start of a frame: the assignment tail leaves
     them clean (k_slot_init only after a reallocation).  One engine, one slot, frames whose N and T grow, shrink and cross
@@ -268,6 +231,7 @@ def test_state_kept_clean_across_frames_of_changing_size():
         eng.close()
 
 
+@pytest.mark.paths("separate_resolve", "euclid_valu", "euclid_mfma")
 @pytest.mark.parametrize("visual,thr", [("cosine", 0.2), ("euclidean", 0.5)])
 def test_vote_words_rearmed_across_frames(visual, thr):
     """One observation per track, at most 1024 candidates and tracks: the contraction reduces the BestFit vote into one 64-bit word
@@ -303,20 +267,35 @@ def test_vote_words_rearmed_across_frames(visual, thr):
         eng.close()
 
 
-def test_resolve_as_its_own_launch_matches_oracle_too():
-    """SA_RESOLVE=separate keeps k_bestfit_resolve a launch of its own on small frames (per-tile partials, no vote words).  Same
-    tests, same oracle."""
-    import os
-    import subprocess
-    import sys
-
-    for mode in ("separate",):
-        env = dict(os.environ, SA_RESOLVE=mode)
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                            "test_visual_cosine_parity or test_every_tile_plan or test_full_size_properties_c2 or test_zero_feature or "
-                            "test_vote_words_rearmed or test_batched_visual"],
-                           env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0, mode + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+def test_two_engines_of_one_process_run_different_paths():
+    """The path switches are bits of sa_config.flags, not process-wide environment: a default engine (one-workgroup tail, lean frames,
+    vote words) and one pinned to the general tail + preparation blocks + a separate resolve launch live side by side, take turns
+    frame by frame, show different launches in their profiles and give the oracle's answers both."""
+    rng = np.random.default_rng(808)
+    mk = lambda flags: abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,  # noqa: E731
+                                       max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                                       max_idle_epochs=5, flags=flags | abi.SA_FLAG_PROFILE)
+    cfg_a = mk(0)
+    cfg_b = mk(abi.SA_FLAG_GENERAL_TAIL | abi.SA_FLAG_NEVER_LEAN | abi.SA_FLAG_SEPARATE_RESOLVE)
+    ea, eb = Engine(cfg_a), Engine(cfg_b)
+    try:
+        for f in range(3):
+            sc = synth.visual_scene(rng, 230 + 10 * f, 200, 64, 1, canvas=(1600.0, 900.0), new_fraction=0.15)
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+            det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+            ref = O.associate(cfg_a, tracks, 1, det)
+            for eng in (ea, eb):
+                eng.upsert(0, tracks)
+                ids, votes = eng.associate(0, 1, det)
+                np.testing.assert_array_equal(ids, ref["track_id"])
+                np.testing.assert_array_equal(votes, ref["voting_type"])
+        pa, pb = ea.profile_read(), eb.profile_read()
+        if abi.EXTRA_FLAGS == 0:
+            assert "k_assign_small" in pa and "k_assign_solve" not in pa and "k_bestfit_resolve" not in pa
+        assert "k_assign_solve" in pb and "k_assign_label" in pb and "k_assign_small" not in pb and "k_bestfit_resolve" in pb
+    finally:
+        ea.close()
+        eb.close()
 
 
 def test_features_from_a_pinned_block_give_the_same_answers():
@@ -467,6 +446,7 @@ def test_device_upkeep_refuses_tracks_without_state():
         eng.close()
 
 
+@pytest.mark.paths("general")
 def test_sort_iou_constraints_and_idle_epochs():
     rng = np.random.default_rng(7)
     sc = synth.sort_scene(rng, 200, 220, canvas=(1200.0, 800.0))
@@ -475,6 +455,7 @@ def test_sort_iou_constraints_and_idle_epochs():
     check_sort(cfg, sc, epoch=8)
 
 
+@pytest.mark.paths("general", "never_lean")
 def test_sort_maha_parity():
     rng = np.random.default_rng(21)
     sc = synth.sort_scene(rng, 180, 200, canvas=(1500.0, 900.0))
@@ -568,6 +549,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
+@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve")
 @pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "default"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
@@ -600,6 +582,7 @@ def test_visual_cosine_more_than_1024_detections():
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50
 
 
+@pytest.mark.paths("euclid_valu", "euclid_mfma")
 def test_visual_euclid_parity():
     rng = np.random.default_rng(77)
     sc = synth.visual_scene(rng, 120, 140, 256, 3, canvas=(1500.0, 900.0), new_fraction=0.1)
@@ -608,6 +591,7 @@ def test_visual_euclid_parity():
     check_visual(cfg, sc, tol_abs=1e-6, tol_rel=1e-5)
 
 
+@pytest.mark.paths("euclid_valu", "euclid_mfma")
 def test_visual_euclid_reference_bench_distribution():
     # features = 10*idx +- 0.01 (benches/simple_visual_sort_tracker.rs:135-141): the case a GEMM expansion cannot hold
     rng = np.random.default_rng(78)
@@ -680,6 +664,33 @@ def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_cond
         assert "k_visual_cost" in kernels[-1] and "k_frame_visual" not in kernels[-1], kernels  # after the report: the vector-pipe kernel
     finally:
         eng.close()
+    # The back-off is per SCENE and bounded by sa_config.euclid_backoff_frames: with 2, the ill-conditioned scene runs matrix cores /
+    # vector pipe / vector pipe / matrix cores ... while an ordinary scene of the same engine never leaves the matrix cores.
+    if not (abi.EXTRA_FLAGS & (abi.SA_FLAG_EUCLID_VALU | abi.SA_FLAG_EUCLID_MFMA)):
+        cfg3 = abi.make_config(positional="iou", visual="euclidean", visual_threshold=3.4e38, feature_len=d, max_observations=1,
+                               visual_min_votes=1, positional_min_confidence=0.1, max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE, euclid_backoff_frames=2)
+        sc1 = synth.visual_scene(rng, t, n, d, 1, canvas=(3000.0, 3000.0))
+        tr1 = abi.make_tracks(sc1["track_ids"], sc1["track_boxes"], sc1["track_epochs"], feats=sc1["track_feats"], feat_present=sc1["track_present"])
+        det1 = abi.make_detections(sc1["det_boxes"], feats=sc1["det_feats"], feat_quality=sc1["det_quality"])
+        ref1 = O.associate(cfg3, tr1, 1, det1)
+        eng = Engine(cfg3)
+        try:
+            eng.upsert(0, tracks)
+            eng.upsert(1, tr1)
+            seq0, seq1 = [], []
+            for f in range(7):
+                eng.profile_reset()
+                ids, _ = eng.associate(0, 1, det)
+                seq0.append("M" if "k_frame_visual" in eng.profile_read() else "V")
+                np.testing.assert_array_equal(ids, sc["truth"])
+                eng.profile_reset()
+                ids1, _ = eng.associate(1, 1, det1)
+                seq1.append("M" if "k_frame_visual" in eng.profile_read() else "V")
+                np.testing.assert_array_equal(ids1, ref1["track_id"])
+            assert "".join(seq0) == "MVVMVVM", seq0
+            assert "".join(seq1) == "MMMMMMM", seq1
+        finally:
+            eng.close()
     sc2 = synth.visual_scene(rng, t, n, d, 1, canvas=(3000.0, 3000.0))
     cfg2 = abi.make_config(positional="iou", visual="euclidean", visual_threshold=0.6, feature_len=d, max_observations=1,
                            visual_min_votes=1, positional_min_confidence=0.1, max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
@@ -695,21 +706,6 @@ def test_euclidean_engine_leaves_the_matrix_cores_when_the_expansion_is_ill_cond
         eng.close()
 
 
-@pytest.mark.parametrize("mode", ["valu", "mfma"])
-def test_both_euclidean_kernels_match_oracle(mode):
-    """SA_EUCLID=valu: always the vector-pipe kernel (direct sums); SA_EUCLID=mfma: always the contraction + flagged recompute, also on
-    frames that report themselves ill-conditioned.  The euclidean tests of this module under each."""
-    import os
-    import subprocess
-    import sys
-
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                        "test_visual_euclid_parity or test_visual_euclid_reference_bench or test_full_size_c2_euclidean_against or "
-                        "test_dense_positional_stage or test_vote_words_rearmed or test_random_configurations"],
-                       env=dict(os.environ, SA_EUCLID=mode), capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_visual_maha_with_constraints_and_own_area():
     rng = np.random.default_rng(79)
     sc = synth.visual_scene(rng, 100, 110, 64, 2, canvas=(1200.0, 800.0), new_fraction=0.1)
@@ -723,6 +719,7 @@ def test_visual_maha_with_constraints_and_own_area():
     check_visual(cfg, sc, kf=kf, own_area=own, det_present=dpres)
 
 
+@pytest.mark.paths("bestfit_tile", "separate_resolve")
 def test_zero_feature_vectors_are_absent():
     rng = np.random.default_rng(80)
     sc = synth.visual_scene(rng, 20, 20, 32, 1, canvas=(800.0, 600.0))
@@ -822,6 +819,7 @@ def test_upsert_replace_remove_keep_order():
         eng.close()
 
 
+@pytest.mark.paths("general", "never_lean")
 def test_batched_scenes_match_single_scene_runs():
     rng = np.random.default_rng(83)
     cfg = abi.make_config(positional="iou", max_idle_epochs=5)
@@ -853,6 +851,7 @@ def test_batched_scenes_match_single_scene_runs():
 
 @pytest.mark.parametrize("k,d,flags", [(1, 64, 0), (1, 64, abi.SA_FLAG_SEPARATE_FRAME), (1, 40, 0), (3, 64, 0)],
                          ids=["partials_fused", "partials_separate", "partials_padded", "bank3"])
+@pytest.mark.paths("never_lean", "separate_resolve")
 def test_batched_visual_scenes_match_single_scene_runs(k, d, flags):
     """Scenes of different sizes in ONE set of launches (grid.z = scene): every scene has its own tile grid of BestFit partials,
     tiles past a small scene's edge do nothing, and the answers are those of the oracle scene by scene."""
@@ -908,16 +907,16 @@ def test_distance_matrix_vs_numpy_f64(kind, n, t, d):
     assert out.shape == (n, t)
 
 
+@pytest.mark.paths("never_lean", "bestfit_tile", "separate_resolve")
 @pytest.mark.parametrize("plan", [0, 1, 2, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("n,t,d", [(300, 333, 512), (129, 70, 96)])
-def test_every_tile_plan_of_the_contraction(plan, n, t, d, monkeypatch):
+def test_every_tile_plan_of_the_contraction(plan, n, t, d):
     """All six tile plans (128x128, 64x128, 128x64, 64x64 with 1/2/4 k-groups) produce the same cosine matrix, both in the
     standalone entry point and in the fused VisualSORT kernel (tap), including ragged edge tiles."""
-    monkeypatch.setenv("SA_GEMM_PLAN", str(plan))
     rng = np.random.default_rng(plan + n)
     a = rng.standard_normal((n, d)).astype(np.float32)
     b = rng.standard_normal((t, d)).astype(np.float32)
-    eng = Engine(abi.make_config())
+    eng = Engine(abi.make_config(gemm_plan=plan))
     try:
         out, _ = eng.distance_matrix("cosine", a, b)
     finally:
@@ -928,10 +927,11 @@ def test_every_tile_plan_of_the_contraction(plan, n, t, d, monkeypatch):
     sc = synth.visual_scene(np.random.default_rng(3 + plan), t, n, d, 2, canvas=(1500.0, 900.0), new_fraction=0.1)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
                           max_observations=2, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
-                          max_idle_epochs=5)
+                          max_idle_epochs=5, gemm_plan=plan)
     check_visual(cfg, sc)
 
 
+@pytest.mark.paths("never_lean", "bestfit_tile", "separate_resolve")
 def test_full_size_properties_c2():
     """BASELINE config C2 (1000 x 1000 x 512 cosine): size-independent properties instead of the slow oracle."""
     rng = np.random.default_rng(2)
@@ -969,6 +969,7 @@ def test_full_size_properties_c2():
         eng.close()
 
 
+@pytest.mark.paths("never_lean")
 def test_full_size_sort_oriented_c4_properties():
     """C4-sized oriented SORT (2000 x 2000): every shuffled, jittered detection returns to its track."""
     rng = np.random.default_rng(4)
@@ -1063,6 +1064,7 @@ def test_full_size_properties_c5():
         eng.close()
 
 
+@pytest.mark.paths("never_lean", "bestfit_tile", "separate_resolve")
 def test_full_size_properties_c2_euclidean():
     """The C2 frame with the euclidean metric (vector-pipe kernel, vote words): identities re-found, idempotence, permutation
     equivariance, distances against f64 numpy within 1e-5 relative."""
@@ -1095,6 +1097,7 @@ def test_full_size_properties_c2_euclidean():
 
 
 # ---- the positional vote on graphs that do NOT fall apart into tiny components ---------------------------------------------
+@pytest.mark.paths("general")
 def test_one_giant_component_against_the_oracle():
     """640 boxes piled on each other under IoU(0.05): ONE connected component, ~100 k usable edges (they stay in the HBM lists: the
     LDS pool holds 3072), most greedy bids colliding.  kuhn_munkres does not care about density (sort/voting.rs:86); the
@@ -1107,6 +1110,7 @@ def test_one_giant_component_against_the_oracle():
         assert (~np.isnan(ref["positional"])).sum() > 50_000
 
 
+@pytest.mark.paths("general")
 @pytest.mark.parametrize("sigma", [2.0, 12.0])
 @pytest.mark.parametrize("n,t,canvas", [(1000, 1000, (1920.0, 1080.0)), (1024, 1024, (700.0, 500.0)), (300, 900, (500.0, 400.0))])
 def test_crowds_against_the_oracle(n, t, canvas, sigma):
@@ -1193,6 +1197,7 @@ def test_mahalanobis_crowd_takes_the_64_bit_dense_solver(n, t):
     assert present.sum() > 20 * n, "the frame lost its density"
 
 
+@pytest.mark.paths("general", "euclid_valu", "euclid_mfma")
 @pytest.mark.parametrize("visual", ["cosine", "euclidean"])
 def test_dense_positional_stage_behind_a_visual_vote(visual):
     """VisualSORT on a pile: 35 % of the detections are new or below the quality gate, so the positional stage inherits hundreds of
@@ -1317,6 +1322,7 @@ def test_full_size_c2_three_observations_against_the_oracle():
     compare_visual(cfg, ids, votes, pos, vis, ref)
 
 
+@pytest.mark.paths("euclid_valu", "euclid_mfma")
 def test_full_size_c2_euclidean_against_the_oracle():
     """The C2 frame under the reference's DEFAULT visual metric: every euclidean distance within 1e-5 relative."""
     sc = synth.visual_scene(np.random.default_rng(6), 1000, 1000, 512, 1)
@@ -1461,6 +1467,7 @@ def _fuzz_case(seed):
     return rng, cfg, sc, epoch, positional, visual
 
 
+@pytest.mark.paths("general", "euclid_valu", "euclid_mfma")
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SA_FUZZ_N", "40"))))
 def test_random_configurations(seed):
     rng, cfg, sc, epoch, positional, visual = _fuzz_case(seed)

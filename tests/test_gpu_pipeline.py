@@ -249,6 +249,69 @@ def test_pipelined_tracker_loop_with_device_upkeep():
         b.close()
 
 
+def test_oriented_boxes_between_apply_begin_and_end_meet_the_next_launch_with_their_polygons():
+    """stage(n+1); wait(n); apply_begin(n); launch(n+1); apply_end(n) with ORIENTED boxes: the upkeep kernel writes the axis-aligned
+    polygon for refreshed oriented rows and the right one is queued only when the step is finished — sa_pipe_launch finishes a pending
+    step before it queues kernels that read the table, so every frame's ids and the table's f64 polygons equal the synchronous loop's."""
+    rng = np.random.default_rng(91)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    n = 70
+    world = synth.dense_boxes(rng, n, (700.0, 500.0), oriented=True)
+    world["angle"] = rng.uniform(-3.0, 3.0, n).astype(np.float32)
+    frames = []
+    for f in range(6):
+        world = synth.jitter_boxes(rng, world, 1.5, angle_sigma=0.02)
+        frames.append(world.copy())
+    a, b = Engine(cfg), Engine(cfg)
+    u64p, boxp = C.POINTER(C.c_uint64), C.POINTER(abi.sa_box)
+    try:
+        next_id = [1, 1]
+
+        def new_ids(k, ids):
+            out = np.zeros(len(ids), np.uint64)
+            for i, w in enumerate(ids):
+                if w == 0:
+                    out[i] = next_id[k]
+                    next_id[k] += 1
+            return out
+
+        sync_ids, sync_poly = [], []
+        for f, boxes in enumerate(frames):
+            det = abi.make_detections(boxes)
+            a.batch_begin()
+            a.batch_add(0, f + 1, det)
+            a.batch_run()
+            a.batch_sync()
+            ids, _ = a.batch_fetch(0, det.n)
+            sync_ids.append(ids)
+            nid = new_ids(0, ids)
+            pred = np.zeros(len(ids), abi.BOX_DTYPE)
+            a._chk(a.lib.sa_tracks_apply(a.h, 0, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp)))
+            sync_poly.append(a.tap_track_polygons(0))
+        sets = [Engine.make_requests([(0, f + 1, abi.make_detections(boxes))]) for f, boxes in enumerate(frames)]
+        tk = b.pipe_stage(sets[0][0])
+        b.pipe_launch(tk)
+        for f in range(len(frames)):
+            nxt = b.pipe_stage(sets[f + 1][0]) if f + 1 < len(frames) else None
+            b.pipe_wait(tk, sets[f][1])
+            ids = sets[f][2][0][0]
+            np.testing.assert_array_equal(ids, sync_ids[f], err_msg=f"frame {f}")
+            nid = new_ids(1, ids)
+            b._chk(b.lib.sa_tracks_apply_begin(b.h, 0, nid.ctypes.data_as(u64p)))
+            if nxt is not None:
+                b.pipe_launch(nxt)   # reads the table: must see the oriented polygons of the step queued above
+            pred = np.zeros(len(ids), abi.BOX_DTYPE)
+            b._chk(b.lib.sa_tracks_apply_end(b.h, 0, C.cast(pred.ctypes.data, boxp)))
+            if nxt is not None:
+                tk = nxt
+            else:
+                np.testing.assert_array_equal(b.tap_track_polygons(0).view(np.uint64), sync_poly[f].view(np.uint64))
+        assert (sync_ids[-1] != 0).sum() >= n - 2
+    finally:
+        a.close()
+        b.close()
+
+
 def test_graph_replay_survives_a_changing_epoch():
     """SA_FLAG_GRAPH under a tracker: the epoch (and the detections) change every frame, the launch geometry does not — the
     captured graph is replayed, and every frame's answer is the oracle's for THAT epoch (idle tracks drop out as it advances)."""

@@ -266,6 +266,71 @@ def test_two_rank_gloo_array_sharding_matches_the_oracle_per_scene(tmp_path):
             np.testing.assert_array_equal(got[f"f{f}_s{s}_votes"], ref["voting_type"])
 
 
+class FailingEngine(OracleEngine):
+    """Raises inside the share that holds scene 9 (what an engine error — a HIP failure, a refused box — looks like to the layer)."""
+
+    def associate_batch(self, req, res, n=None):
+        for i in range(len(req) if n is None else n):
+            if req[i].scene_id == 9:
+                raise RuntimeError("engine failure inside the share")
+        return super().associate_batch(req, res, n)
+
+
+def fail_worker(rank: int, port: int, outfile: str):
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import torch.distributed as dist
+
+    from similari_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        cfg, scenes = assoc_scenes(9)
+        sh = sharding.ShardedAssociator(FailingEngine(cfg), capacity_bytes=1 << 16, capacity_rows=256)
+        for s, sc in scenes.items():
+            sh.upsert_arrays(s, **(dict(ids=sc["track_ids"], boxes=sc["track_boxes"], epochs=sc["track_epochs"], feats=sc["track_feats"],
+                                        feat_present=sc["track_present"]) if rank == 0 else {}))
+        if rank != 0:
+            # scene 9 lives on rank 1 (9 % 2): the first set goes through, the second one fails HERE — after the scatter.  The worker
+            # must still reach the gather (the root is waiting in it) and only then raise its own exception out of the loop.
+            try:
+                sh.serve_forever()
+                verdict = "returned"
+            except sharding.RequestRefused:
+                verdict = "refused"
+            except RuntimeError as ex:
+                verdict = "raised: " + str(ex)
+            np.savez(outfile + ".worker.npz", verdict=np.array(verdict))
+            return
+        ok_items = [(s, 1, scenes[s]["det_boxes"], scenes[s]["det_feats"], scenes[s]["det_quality"]) for s in (2, 8, 5)]
+        res = sh.associate(ok_items)
+        assert len(res) == 3
+        bad_items = [(s, 1, scenes[s]["det_boxes"], scenes[s]["det_feats"], scenes[s]["det_quality"]) for s in (2, 9)]
+        try:
+            sh.associate(bad_items)
+            verdict = "went through"
+        except sharding.ShardFailed as ex:
+            verdict = "ShardFailed: " + str(ex)
+        np.savez(outfile, verdict=np.array(verdict))
+        sh.close()  # (no shutdown broadcast: the failed worker has left its loop)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_fails_inside_its_share_still_reaches_the_gather(tmp_path):
+    """a worker whose engine call fails between the scatter and the gather used to swallow the error and loop back
+    into the next scatter — the root then hung in the gather.  Now the rank takes part in the gather with an error marker, the root
+    raises ShardFailed, and the worker's own exception ends its loop (only RequestRefused is skipped)."""
+    import torch.multiprocessing as mp
+
+    outfile = str(tmp_path / "fail.npz")
+    mp.spawn(fail_worker, args=(free_port(), outfile), nprocs=WORLD, join=True)
+    root = str(np.load(outfile)["verdict"])
+    worker = str(np.load(outfile + ".worker.npz")["verdict"])
+    assert root.startswith("ShardFailed") and "[1]" in root, root
+    assert worker == "raised: engine failure inside the share", worker
+
+
 def test_share_pack_roundtrip():
     sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
     from similari_amd import sharding
