@@ -88,14 +88,14 @@ struct SceneDev {
   int32_t SA_G* row_part_t;  // [CT][N]
   double SA_G* col_part_w;   // [RT][T] best weight of the column inside row tile rt
   uint32_t SA_G* col_part_q; // [RT][T] lowest row attaining it
-  unsigned long long SA_G* row_best;  // [SA_SMALL_N] vote words (SaParams::vote_words): min over the row of (weight key << 32 | column); all ones = none
-  unsigned long long SA_G* col_best;  // [SA_SMALL_N] min over the column of (weight key << 32 | row)
+  unsigned long long SA_G* row_best;  // [N] vote words (SaParams::vote_words): min over the row of (weight key << 32 | column); all ones = none
+  unsigned long long SA_G* col_best;  // [T] min over the column of (weight key << 32 | row)
   // Deeper banks without the weight matrix (SCN_WORDSK, the contraction's whole-track tiles): one word per candidate (track) and COUNT CLASS —
   // groups with c present observations, c = 1 .. K at [q * K + c - 1] — holding min over the row (column) of (key of the f32 sum of
   // the group's weights << 32 | column (row)): inside a class the heaviest BestFit group is the one with the smallest sum; the
   // tail, which knows the frame's max_dist, compares the classes' winners by W = c max_dist - sum.
-  unsigned long long SA_G* row_cls;   // [SA_SMALL_N * SA_CLS_MAXK]
-  unsigned long long SA_G* col_cls;   // [SA_SMALL_N * SA_CLS_MAXK]
+  unsigned long long SA_G* row_cls;   // [N][K]
+  unsigned long long SA_G* col_cls;   // [T][K]
   uint8_t SA_G* row_has;
   int32_t SA_G* vis_winner;
   uint8_t SA_G* col_excluded;
@@ -225,8 +225,9 @@ hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* ind
                                  hipStream_t st);
 
 // first launch of a frame: positional tiles + frame-preparation blocks
-// prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame), 2 = preparation blocks only (what a lean
-// frame left out, on demand: sa_tracks_apply, the visual tap)
+// prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame on the one-workgroup tail), 2 = preparation
+// blocks only (what a lean frame left out, on demand: sa_tracks_apply, the visual tap), 3 = positional tiles + the preparation blocks'
+// RESET half only (a lean frame on the many-workgroup tail, whose per-row / per-column state lives in HBM)
 hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, int visual, const SaParams& p,
                            hipStream_t st, int prep = 1);
 hipError_t sa_launch_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices, hipStream_t st);
@@ -237,13 +238,14 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
 // heterogeneous first phase of a VisualSORT frame (contraction tiles + positional tiles + preparation blocks in one launch);
 // hipErrorNotSupported = not applicable, use sa_launch_frame + sa_launch_visual
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep = true, bool kpass = false);
+                                  const SaParams& p, hipStream_t st, bool partials, int prep = 1, bool kpass = false, bool general_tail = false);
 bool sa_frame_visual_ok(uint32_t n_scenes, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words);
 void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK, uint32_t ns, uint32_t Dp, int32_t plan_override, uint32_t* bm, uint32_t* bn);
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
-// stage 1 label + push, 3 solve + results; stage 5 = the whole tail in ONE workgroup per
-// scene (requires maxN <= SA_SMALL_N)
+// stage 1 label + push, 3 solve + results (2 / 4: the same with the visual vote read from the vote words — the label kernel turns
+// them into verdicts, the solver re-arms them); stage 5 = the whole tail in ONE workgroup per scene (requires maxN, maxT <= SA_SMALL_N;
+// 8: with vote words)
 #define SA_SMALL_N 1024
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                             const SaParams& p, hipStream_t st, int stage);

@@ -77,6 +77,7 @@ struct Slot {  // one scene of a request set
   void *d_pred = nullptr, *d_apply = nullptr, *d_fix = nullptr;  // device views of the three
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
+  uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
   bool apply_pending = false;  // sa_tracks_apply_begin has queued the upkeep of this slot; sa_tracks_apply_end (or the next entry point that needs the table) finishes it
   bool prepped = true;     // the frame-preparation blocks ran with the frame (false: a lean frame left them out; ensure_prepped runs them on demand)
@@ -394,10 +395,14 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
     TRY(dev_ensure(e, s->col_part_w, RT * t * 8));
     TRY(dev_ensure(e, s->col_part_q, RT * t * 4));
   }
-  {
-    void* before = s->vote_best.p;
-    TRY(dev_ensure(e, s->vote_best, (size_t)(2 + 2 * SA_CLS_MAXK) * SA_SMALL_N * 8));  // row / column words | row / column CLASS words
-    if (s->vote_best.p != before) s->needs_init = true;
+  if (e->visual && (n > s->vb_n || t > s->vb_t || !s->vote_best.p)) {
+    // vote words: one per candidate and per track (and per count class for banks of 2 .. SA_CLS_MAXK observations) — sized by the frame,
+    // with room to grow (a tracker's table gains a few rows per frame); all ones between frames (bank_launch establishes that once)
+    const size_t cn = std::max<size_t>(n + n / 4, SA_SMALL_N), ct = std::max<size_t>(t + t / 4, SA_SMALL_N);
+    const size_t kc = (K >= 2 && K <= SA_CLS_MAXK) ? K : 0;
+    TRY(dev_ensure(e, s->vote_best, (cn + ct) * (1 + kc) * 8, false));
+    s->vb_n = (uint32_t)cn; s->vb_t = (uint32_t)ct;
+    s->needs_init = true;
   }
   TRY(dev_ensure(e, s->row_has, n));
   TRY(dev_ensure(e, s->vis_winner, n * 4));
@@ -478,9 +483,9 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->vis_max_key = (decltype(d->vis_max_key))(s->vis_max_key.p);
   d->row_part_w = (decltype(d->row_part_w))(s->row_part_w.p); d->row_part_t = (decltype(d->row_part_t))(s->row_part_t.p);
   d->col_part_w = (decltype(d->col_part_w))(s->col_part_w.p); d->col_part_q = (decltype(d->col_part_q))(s->col_part_q.p);
-  d->row_best = (decltype(d->row_best))(s->vote_best.p); d->col_best = (decltype(d->col_best))((unsigned long long*)s->vote_best.p + SA_SMALL_N);
-  d->row_cls = (decltype(d->row_cls))((unsigned long long*)s->vote_best.p + 2 * SA_SMALL_N);
-  d->col_cls = (decltype(d->col_cls))((unsigned long long*)s->vote_best.p + (size_t)(2 + SA_CLS_MAXK) * SA_SMALL_N);
+  d->row_best = (decltype(d->row_best))(s->vote_best.p); d->col_best = (decltype(d->col_best))((unsigned long long*)s->vote_best.p + s->vb_n);
+  d->row_cls = (decltype(d->row_cls))((unsigned long long*)s->vote_best.p + (size_t)s->vb_n + s->vb_t);
+  d->col_cls = (decltype(d->col_cls))((unsigned long long*)s->vote_best.p + (size_t)s->vb_n + s->vb_t + (size_t)s->vb_n * e->K);
   d->row_has = (decltype(d->row_has))(s->row_has.p); d->vis_winner = (decltype(d->vis_winner))(s->vis_winner.p); d->col_excluded = (decltype(d->col_excluded))(s->col_excluded.p);
   d->parent = (decltype(d->parent))(s->parent.p); d->label = (decltype(d->label))(s->label.p); d->next_row = (decltype(d->next_row))(s->next_row.p);
   d->e_cnt = (decltype(d->e_cnt))(s->e_cnt.p); d->e_use = (decltype(d->e_use))(s->e_use.p); d->e_edge = (decltype(d->e_edge))(s->e_edge.p);
@@ -612,31 +617,32 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   P.eu_rho = e->eu_rho;
   SaParams Pt = P;                         // k_bestfit_tile: the words of deeper banks
   Pt.vote_words = b->words == 2 ? 1u : 0u;
-  // First phase of a small VisualSORT frame (at most 1024 x 1024, feature length a multiple of 32): contraction tiles + positional
-  // tiles + frame-preparation blocks in ONE heterogeneous launch; otherwise (and with SA_FLAG_SEPARATE_FRAME) positional tiles +
-  // preparation blocks, then the contraction.
-  // A LEAN frame leaves the preparation blocks out of its first phase (C2: 23.0 -> 20.8 us per frame).  They derive the candidates'
-  // geometry / usability / padded features + norms and reset the state of the general tail and of the resolve kernel; the positional
-  // tiles and the raw-row contraction derive what they need from the uploaded records themselves, the one-workgroup tail with vote
-  // words keeps its state in LDS — so on such frames nothing reads them.  What does (sa_tracks_apply's feature-bank step, the
-  // visual tap) calls ensure_prepped first.  SA_FLAG_NEVER_LEAN (tests): never lean.
+  // First phase of a VisualSORT frame whose contraction runs as 64 x 64 tiles (feature length a multiple of 32): contraction tiles +
+  // positional tiles + frame-preparation blocks in ONE heterogeneous launch; otherwise (and with SA_FLAG_SEPARATE_FRAME) positional
+  // tiles + preparation blocks, then the contraction.
+  // A LEAN frame leaves the preparation blocks' candidate half out of its first phase (C2: 23.0 -> 20.8 us per frame).  It derives the
+  // candidates' geometry / usability / padded features + norms; the positional tiles and the raw-row contraction derive what they
+  // need from the uploaded records themselves and, with vote words, nothing of the resolve kernel's state is touched — so on such
+  // frames nothing reads it.  What does (sa_tracks_apply's feature-bank step, the visual tap) calls ensure_prepped first.  The other
+  // half — the reset of the many-workgroup tail's per-row / per-column state — the one-workgroup tail does not need either (its state
+  // lives in LDS): prep 0; the many-workgroup tail keeps it: prep 3 (a dozen blocks instead of N / 4).  SA_FLAG_NEVER_LEAN: never lean.
   const bool never_lean = (e->cfg.flags & SA_FLAG_NEVER_LEAN) != 0;
-  const bool lean_ok = small_tail && !never_lean && (!e->visual || words);
-  bool with_prep = !lean_ok;
+  const bool lean_ok = !never_lean && (!e->visual || words);
+  int prep = lean_ok ? (small_tail ? 0 : 3) : 1;
   bool fused = false;
   bool all_feats = e->visual;
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
   if (e->visual && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && all_feats) {
     ProfScope ps(e, KID_FRAME_VISUAL);
-    hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, with_prep, b->words == 3);
+    hipError_t fe = sa_launch_frame_visual(ds, ns, maxN, maxT, e->K, e->D, P, st, partials, prep, b->words == 3, !small_tail);
     if (fe == hipSuccess) fused = true;
     else if (b->words == 3) HIPCHK(e, fe);  // (bank_prepare asked sa_frame_visual_ok: cannot happen)
     else if (fe != hipErrorNotSupported) HIPCHK(e, fe);
     else { sa_prof_start = sa_prof_stop = nullptr; ps.cancel(); }
   }
-  if (e->visual && !fused) with_prep = true;  // the stand-alone contraction reads the padded features, norms and gates
-  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, with_prep ? 1 : 0)); }
-  b->frame_with_prep = with_prep;
+  if (e->visual && !fused) prep = 1;  // the stand-alone contraction reads the padded features, norms and gates
+  if (!fused) { ProfScope ps(e, KID_FRAME); HIPCHK(e, sa_launch_frame(ds, ns, maxN, maxT, e->visual ? 1 : 0, P, st, prep)); }
+  b->frame_with_prep = prep == 1;
   b->frame_small_tail = small_tail;
   if (e->visual) {
     if (!fused) { ProfScope ps(e, KID_VISUAL); HIPCHK(e, sa_launch_visual(ds, ns, maxN, maxT * e->K, P, st, partials)); }
@@ -652,10 +658,11 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     if (attach) sa_done_event = done;
     le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
   } else {
-    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, 1)); }
+    // (with vote words the label kernel also turns them into the verdicts the solver honours, and the solver re-arms them)
+    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 2 : 1)); }
     ProfScope ps(e, KID_ASSIGN_SOLVE);
     if (attach) sa_done_event = done;
-    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, 3);
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 4 : 3);
   }
   if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
   sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
@@ -695,21 +702,28 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
   b->partials = e->bf_partials || (b->eu_mfma && e->bf_words_euclid);
   if (e->visual) sa_visual_tile(e->cfg.visual_kind, b->eu_mfma, maxN, maxT * e->K, ns, e->Dp, e->P.gemm_plan, &b->tile_bm, &b->tile_bn);
   {
-    // vote words (frames of at most 1024 x 1024 on the one-workgroup tail): the first phase reduces the BestFit vote into one 64-bit
-    // word per candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip) and the tail reads its
-    // two words per thread — no resolve launch.  One observation per track: the cost kernel itself; deeper banks: k_bestfit_tile.
+    // Vote words: the first phase reduces the BestFit vote into one 64-bit word per candidate and per track (atomic minima, free at tile
+    // retirement: scripts/micro/atomic_min.hip) and the assignment tail reads them — the one-workgroup tail its two words per thread,
+    // the many-workgroup tail in its label kernel (k_assign_label<WORDS>) — no resolve launch, whatever the frame size.
+    //   1  one observation per track: the cost kernel itself, (key32 << 32 | index)
+    //   2  deeper banks through the weight matrix: k_bestfit_tile, (key54 << 10 | index) — a 10-bit index: frames up to 1024 x 1024
+    //   3  deeper banks (2 .. SA_CLS_MAXK observations) through the whole-track tiles of the fused first phase: CLASS words (no weight
+    //      matrix, no k_bestfit_tile) wherever that launch applies (every scene with features, rows of a multiple of 32 floats, cosine
+    //      or the euclidean expansion)
     const bool force_general = (e->cfg.flags & SA_FLAG_GENERAL_TAIL) != 0;
     const bool separate_resolve = (e->cfg.flags & SA_FLAG_SEPARATE_RESOLVE) != 0;
-    const bool small = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general && !separate_resolve;
-    b->words = !(e->visual && small) ? 0 : (b->partials || e->bf_words_euclid) ? 1 : 2;
-    // deeper banks: the whole-track tiles of the fused first phase reduce into CLASS words (no weight matrix, no k_bestfit_tile) wherever
-    // that launch applies (every scene with features, rows of a multiple of 32 floats, cosine or the euclidean expansion)
-    if (b->words == 2 && e->K >= 2 && e->K <= SA_CLS_MAXK && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->bf_tile_forced) {
-      bool all_feats = true;
-      for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
-      SaParams P = e->P;
-      P.eu_mfma = b->eu_mfma ? 1u : 0u;
-      if (all_feats && sa_frame_visual_ok(ns, maxN, maxT, e->K, e->D, P, true)) b->words = 3;
+    const bool small = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general;
+    b->words = 0;
+    if (e->visual && !separate_resolve) {
+      if (b->partials || e->bf_words_euclid) b->words = 1;
+      else if (small) b->words = 2;
+      if (b->words != 1 && e->K >= 2 && e->K <= SA_CLS_MAXK && !(e->cfg.flags & SA_FLAG_SEPARATE_FRAME) && !e->bf_tile_forced) {
+        bool all_feats = true;
+        for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
+        SaParams P = e->P;
+        P.eu_mfma = b->eu_mfma ? 1u : 0u;
+        if (all_feats && sa_frame_visual_ok(ns, maxN, maxT, e->K, e->D, P, true)) b->words = 3;
+      }
     }
   }
   *maxN_out = maxN;
@@ -728,7 +742,7 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t 
     if (!s->needs_init) continue;
     HIPCHK(e, sa_launch_slot_init((uint32_t*)s->e_cnt.p, (int64_t*)s->u.p, (uint32_t)(s->e_cnt.cap / 4 < s->u.cap / 8 ? s->e_cnt.cap / 4 : s->u.cap / 8),
                                   (uint32_t*)s->parent.p, (uint32_t)(s->parent.cap / 4), st));
-    HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, (size_t)(2 + 2 * SA_CLS_MAXK) * SA_SMALL_N * 8, st));  // vote words: all ones = no group
+    if (s->vote_best.p) HIPCHK(e, hipMemsetAsync(s->vote_best.p, 0xFF, s->vote_best.cap, st));  // vote words: all ones = no group
     HIPCHK(e, hipMemsetAsync(s->stats.p, 0, 256, st));
     HIPCHK(e, hipMemsetAsync(s->dense.p, 0, s->dense.cap, st));  // (a frame that died half-way may have left gains behind)
     s->needs_init = false;

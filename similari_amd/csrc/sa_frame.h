@@ -57,7 +57,8 @@ __device__ __forceinline__ void pad_feature_row(const float* s, float* d, uint32
 // reset beside them; the assignment tail leaves it clean for the next frame instead (k_slot_init establishes it once).
 // =====================================================================================================
 // (tid = thread index inside the 256-thread unit: a 512-thread block of the fused launch runs two units side by side)
-__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk, uint32_t tid) {
+// light: the RESET half only (a lean frame on the many-workgroup tail: nothing reads the candidates' derived arrays)
+__device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk, uint32_t tid, bool light = false) {
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blk * 256 + tid;
   if (i < T) {
@@ -75,6 +76,9 @@ __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaPara
     S.label[i] = SA_NONE;
     S.next_row[i] = SA_NONE;
     S.rnext[i] = 0;        // rows per component, counted by k_assign_label
+  }
+  if (light) return;
+  if (i < N) {
     BoxRaw r = sa_ldg(S.c_raw + i);
     prep_box_common(r, (sa_geo*)(S.c_geo + i), (double*)(S.c_verts + (size_t)i * 8));
     const sa_box& b = r.box;

@@ -1066,7 +1066,11 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
 template <int KG, bool PART, bool EU = false, bool KP = false>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
-                                                           uint32_t px, uint32_t py, uint32_t nprep) {
+                                                           uint32_t px, uint32_t py, uint32_t nprep_) {
+  // nprep_: preparation blocks of the launch; bit 31: they run their RESET half only, bit 30: the positional tiles also feed the
+  // many-workgroup tail (row-major edge lists, row duals, union-find: UNION) — frames beyond the one-workgroup tail's 1024 x 1024
+  const uint32_t nprep = nprep_ & 0x3fffffffu;
+  const bool prep_light = (nprep_ >> 31) != 0, uni = ((nprep_ >> 30) & 1u) != 0;
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
   using FusedPos = PosSmem<2, 64>;  // the wide, proof-filtered positional tile of this launch (sa_frame.h)
   static_assert(sizeof(FusedPos) <= sizeof(float) * 2 * 128 * BK, "the positional tile must fit one k-group's stages");
@@ -1094,8 +1098,11 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
 #endif
   // preparation blocks (short) before the positional tiles (long): the tiles alone fill every slot the contraction leaves, and
   // preparation blocks queued behind them started only when the first tiles retired — the last thing to finish in the launch
-  if (unit < nprep) frame_prep_block(S, p, unit, tid);
-  else if (unit - nprep < px * py) positional_tile<false, true, 2, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+  if (unit < nprep) frame_prep_block(S, p, unit, tid, prep_light);
+  else if (unit - nprep < px * py) {
+    if (uni) positional_tile<false, true, 2, true, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+    else positional_tile<false, true, 2, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+  }
 #ifdef SA_GEMM_TRACE
   if (tr2 && threadIdx.x == 0) tr2[5] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1489,16 +1496,16 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
   }
 }
 
-// The fused first phase (k_frame_visual) applies when the contraction would run as 64x64 tiles with 2 or 4 k-groups — small
-// frames, where the other two kinds of work are a sizeable part of the frame — the feature length needs no padding, and the
-// one-workgroup assignment tail is in use (the positional tiles then need no union-find).  Returns hipErrorNotSupported when
-// it does not apply: the caller falls back to k_frame + k_visual_cost.
-// the fused first phase applies (and with it, for banks of 2 .. SA_CLS_MAXK observations, the whole-track tiles and their class words)
+// The fused first phase (k_frame_visual) applies when the contraction runs as 64 x 64 tiles — frames of up to two tiles per compute
+// unit, where the other two kinds of work are a sizeable part of the frame and a dependent launch (~4 us) is a sizeable part of
+// either — and the feature length needs no padding; any N, T: with more than 1024 detections or tracks the positional tiles of the
+// launch feed the many-workgroup tail (UNION) instead of the one-workgroup one.  Returns hipErrorNotSupported when it does not
+// apply: the caller falls back to k_frame + k_visual_cost.
+// (and with it, for banks of 2 .. SA_CLS_MAXK observations, the whole-track tiles and their class words)
 bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D, const SaParams& p, bool class_words) {
-  const bool force_general = p.force_general != 0;
   const uint32_t maxTK = maxT * K;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
-  if (force_general || (p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || maxN > SA_SMALL_N || maxT > SA_SMALL_N || D != p.Dp) return false;
+  if ((p.visual_kind != SA_VIS_COSINE && !eu) || !maxN || !maxTK || D != p.Dp) return false;
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
@@ -1506,17 +1513,23 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
   // deeper banks with class words: the whole-track tiles (64 x 64) replace THREE launches of the other family's path (positional
   // tiles, the contraction on wider tiles, k_bestfit_tile) — C2's frame with two observations per track: 42.9 us there.  (Only
   // with class words: the matrix mode's per-tile slots are laid out by the engine for the plan's own tile grid.)
-  return class_words && K >= 2 && K <= SA_CLS_MAXK;
+  if (class_words && K >= 2 && K <= SA_CLS_MAXK) return true;
+  // a frame of at most two 64 x 64 tiles per compute unit that the plan would give wider tiles (1000 detections x 1500 tracks: 64 x 128):
+  // one launch less and the positional tiles beside the contraction weigh more than the wider tile's shorter main loop.  Vote-word
+  // frames only (p.vote_words: the matrix mode's per-tile slots follow the plan's own grid).
+  return p.gemm_plan < 0 && p.vote_words && K == 1 && (size_t)cdiv(maxN, 64) * cdiv(maxTK, 64) * ns <= 512;
 }
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials, bool with_prep, bool kpass) {
+                                  const SaParams& p, hipStream_t st, bool partials, int prep, bool kpass, bool general_tail) {
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;
   const uint32_t maxTK = maxT * K;
   const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
+  // preparation blocks: 1 = all of them (one wave per feature row: N / 4), 3 = the reset half only (one thread per row / column),
+  // 0 = none (a lean frame on the one-workgroup tail: nothing on its path reads what they write, enqueue_frame)
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
-  if (cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
-  if (!with_prep) prep_blocks = 0;  // lean frame: nothing on its path reads what the preparation blocks write (enqueue_frame)
+  if (prep == 1 && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  if (prep == 0) prep_blocks = 0;
   sa_trace_hook(st, gx * gy + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
@@ -1524,16 +1537,17 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
   // against 22.7 (raising the contraction's wave priority changes nothing).
   const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
+  const uint32_t np = prep_blocks | (prep == 3 ? 0x80000000u : 0u) | (general_tail ? 0x40000000u : 0u);
   if (kpass) {
-    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
     return hipGetLastError();
   }
   if (eu) {
-    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
-  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, prep_blocks);
+    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
   return hipGetLastError();
 }
 

@@ -111,11 +111,12 @@ __global__ void k_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32
 
 // The first launch of a frame: blockIdx.y < pos_rows -> a positional tile; the rows above carry the frame-preparation blocks.
 template <int NSUB, bool UNION>
-__global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows) {
+__global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows_) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
+  const uint32_t pos_rows = pos_rows_ & 0x7fffffffu;  // (bit 31: the preparation blocks run their reset half only)
   if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
-  else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x);
+  else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x, (pos_rows_ >> 31) != 0);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.
 __global__ __launch_bounds__(256) void k_positional_dense(const SceneDev* __restrict__ scenes, SaParams p) {
@@ -942,9 +943,88 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 #define SA_QW_DONE 35    // row workgroups through with their rows
 #define SA_QW_MLEN 36    // the same two for the queue of mid-sized components
 #define SA_QW_MTICKET 37
-__global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
+// WORDS: the visual vote arrives as vote words (one per candidate and per track, or one per count class of each: SCN_WORDSK) instead of
+// k_bestfit_resolve's verdict arrays; this kernel — the first of the tail, one thread per row AND per column — turns them into those
+// arrays for the solver (row_has / vis_winner for every candidate, col_excluded for every track: all of them written, none needs a
+// reset) exactly the way k_assign_small<.., WORDS> decides: candidate q wins its best column iff that column's word names q; column j
+// is excluded iff the best column of the candidate its word names is j.  One dependent load each.  The words are re-armed by the
+// solver (every reader is in THIS launch).
+template <bool WORDS>
+__global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict__ scenes) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  bool has_verdict = false;
+  if constexpr (WORDS) {
+    const uint32_t N = S.N, T = S.T, K = S.K;
+    if (S.flags & SCN_WORDSK) {
+      // class words: W = c max_dist - sum decides between a row's (column's) class winners; max_dist from the first phase's per-tile slots
+      __shared__ uint32_t s_mk[4];
+      uint32_t mk = 0;
+      for (uint32_t i = threadIdx.x; i < S.nkeys; i += 256) {
+        const uint32_t v = S.vis_max_key[i];
+        mk = v > mk ? v : mk;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ok = __shfl_xor(mk, o);
+        mk = ok > mk ? ok : mk;
+      }
+      if ((threadIdx.x & 63u) == 0) s_mk[threadIdx.x >> 6] = mk;
+      __syncthreads();
+      mk = s_mk[0] > s_mk[1] ? s_mk[0] : s_mk[1];
+      mk = s_mk[2] > mk ? s_mk[2] : mk;
+      mk = s_mk[3] > mk ? s_mk[3] : mk;
+      const double max_dist = mk ? (double)sa_key_f32(mk) : -1.0;
+      auto best_of = [&](const unsigned long long SA_G* cls, bool in, bool* any) -> uint32_t {
+        unsigned long long w[SA_CLS_MAXK];
+#pragma unroll
+        for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) w[c] = cls[c < K ? c : K - 1u];  // all loads together (see k_assign_small)
+        double bw = 0.0;
+        uint32_t bi = SA_NONE;
+#pragma unroll
+        for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+          if (!in || c >= K || w[c] == ~0ull) continue;
+          const double wt = (double)(c + 1u) * max_dist - (double)sa_key_f32((uint32_t)(w[c] >> 32));
+          const uint32_t i = (uint32_t)w[c];
+          if (bi == SA_NONE || wt > bw || (wt == bw && i < bi)) { bw = wt; bi = i; }
+        }
+        if (any) *any = bi != SA_NONE;
+        return bi;
+      };
+      if (S.tap_row_best) {  // SA_FLAG_TAP: the class words as the first phase left them ([N K] then [T K])
+        for (uint32_t c = 0; c < K; ++c) {
+          if (q < N) S.tap_row_best[(size_t)q * K + c] = S.row_cls[(size_t)q * K + c];
+          if (q < T) S.tap_col_best[(size_t)q * K + c] = S.col_cls[(size_t)q * K + c];
+        }
+      }
+      const uint32_t bt = best_of(S.row_cls + (size_t)(q < N ? q : 0u) * K, q < N, &has_verdict);
+      const uint32_t cq = best_of(S.col_cls + (size_t)(q < T ? q : 0u) * K, q < T, nullptr);
+      // (second round trip: the column my row prefers, the row my column prefers)
+      const uint32_t bt_cq = best_of(S.col_cls + (size_t)(bt != SA_NONE ? bt : 0u) * K, bt != SA_NONE, nullptr);
+      const uint32_t cq_bt = best_of(S.row_cls + (size_t)(cq != SA_NONE ? cq : 0u) * K, cq != SA_NONE, nullptr);
+      if (q < N) {
+        S.row_has[q] = has_verdict ? 1 : 0;
+        S.vis_winner[q] = (has_verdict && bt_cq == q) ? (int32_t)bt : -1;
+      }
+      if (q < T) S.col_excluded[q] = (cq != SA_NONE && cq_bt == q) ? 1 : 0;
+    } else {
+      const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
+      const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
+      if (S.tap_row_best) {  // SA_FLAG_TAP: the words as the first phase left them
+        if (q < N) S.tap_row_best[q] = rb;
+        if (q < T) S.tap_col_best[q] = cb;
+      }
+      const uint32_t bt = rb != ~0ull ? (uint32_t)rb : SA_NONE;
+      const uint32_t cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
+      has_verdict = bt != SA_NONE;
+      const unsigned long long cb_bt = bt != SA_NONE ? S.col_best[bt] : ~0ull;  // (bt < T, cq < N: written by this frame's tiles)
+      const unsigned long long rb_cq = cq != SA_NONE ? S.row_best[cq] : ~0ull;
+      if (q < N) {
+        S.row_has[q] = has_verdict ? 1 : 0;
+        S.vis_winner[q] = (has_verdict && cb_bt != ~0ull && (uint32_t)cb_bt == q) ? (int32_t)bt : -1;
+      }
+      if (q < T) S.col_excluded[q] = (cq != SA_NONE && rb_cq != ~0ull && (uint32_t)rb_cq == q) ? 1 : 0;
+    }
+  }
   if (q >= S.N) return;
   // move this row's edge count and dual to the solver's copies and leave the accumulators clean for the next frame
   const uint32_t cnt = S.e_cnt[q];
@@ -954,7 +1034,7 @@ __global__ void k_assign_label(const SceneDev* __restrict__ scenes) {
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
   if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the dense solver's: top of its row lists | queue length | next ticket | row workgroups done
-  if (!cnt || S.row_has[q]) { S.lab[q] = SA_NONE; return; }
+  if (!cnt || (WORDS ? has_verdict : S.row_has[q] != 0)) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
   atomicAdd((uint32_t*)(S.rnext + root), 1u);  // rows in the component (rnext is zeroed by the preparation blocks)
@@ -1317,8 +1397,9 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 #define SL_POOL 40
 template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
 __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs_) {
-  const uint32_t row_wgs = row_wgs_ & 0x7fffffffu;
-  const bool no_mid = row_wgs_ >> 31;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
+  const uint32_t row_wgs = row_wgs_ & 0x3fffffffu;
+  const bool no_mid = (row_wgs_ >> 31) != 0;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
+  const bool rearm_words = ((row_wgs_ >> 30) & 1u) != 0;  // the frame's visual vote came as vote words: re-armed here
   // One lane gathering a component into its pool block is a chain of dependent trips to L2 / memory — the list walk, then every
   // row's count and records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker
   // loop's crowd frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool is not used at
@@ -1341,6 +1422,17 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
+  }
+  if (VISUAL && rearm_words) {
+    // the vote words have been read (k_assign_label<WORDS>, the launch before this one): all ones again for the next frame's tiles
+    const uint32_t g = blockIdx.x * NT + threadIdx.x, stride = gridDim.x * NT;
+    if (S.flags & SCN_WORDSK) {
+      for (uint32_t i = g; i < S.N * S.K; i += stride) S.row_cls[i] = ~0ull;
+      for (uint32_t i = g; i < S.T * S.K; i += stride) S.col_cls[i] = ~0ull;
+    } else {
+      for (uint32_t i = g; i < S.N; i += stride) S.row_best[i] = ~0ull;
+      for (uint32_t i = g; i < S.T; i += stride) S.col_best[i] = ~0ull;
+    }
   }
   __syncthreads();
   bool big = false, mid = false;
@@ -1667,14 +1759,15 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
-  if (visual && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
+  if (visual && prep != 3 && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
   if (prep == 0) prep_blocks = 0;
   if (!pos_rows && !prep_blocks) return hipSuccess;
   const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
-  if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
-  else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
-  else if (uni) SA_LAUNCH((k_frame<1, true>), grid, dim3(256), 0, st, scenes, p, pos_rows);
-  else SA_LAUNCH((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pos_rows);
+  const uint32_t pr = pos_rows | (prep == 3 ? 0x80000000u : 0u);
+  if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pr);
+  else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pr);
+  else if (uni) SA_LAUNCH((k_frame<1, true>), grid, dim3(256), 0, st, scenes, p, pr);
+  else SA_LAUNCH((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pr);
   return hipGetLastError();
 }
 // parity taps: the dense f32 cost matrix of the staged scenes, no side effects on the assignment state
@@ -1724,14 +1817,14 @@ static hipError_t launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipS
   return hipSuccess;
 }
 template <int NT, int CPT>
-static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
   // the row workgroups, and behind them helpers that only take components off the scene's queues (a crowd has dozens of knots, one
   // wavefront of a workgroup each: 64 workgroups per scene left the 1000 x 2500 crowd frame two rounds of them, 30 us; 128: 24 us) —
   // fewer per scene in a wide batch
   const uint32_t rows = cdiv(maxN, NT);
   const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
   const dim3 grid(rows > want ? rows : want, 1, ns);
-  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u);  // (bit 31: no middle tier)
+  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u);  // (bit 31: no middle tier; bit 30: re-arm the vote words)
   if (vis && in_lds) return launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
   if (vis) return launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
   if (in_lds) return launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
@@ -1741,8 +1834,9 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
                             hipStream_t st, int stage) {
   if (!maxN) return hipSuccess;
   switch (stage) {
-    case 1: SA_LAUNCH(k_assign_label, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
-    case 3: {
+    case 1: SA_LAUNCH(k_assign_label<false>, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
+    case 2: SA_LAUNCH(k_assign_label<true>, dim3(cdiv(maxN > maxT ? maxN : maxT, 256), 1, ns), dim3(256), 0, st, scenes); break;  // (one thread per row AND per column)
+    case 3: case 4: {
       // columns per thread of the dense solver by the widest scene; its per-row / per-column state in dynamic LDS when it fits beside
       // the pool of private blocks, else in the scene's HBM arrays
       const bool vis = p.visual_kind != SA_VIS_NONE;
@@ -1750,11 +1844,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const bool in_lds = lds <= 96u * 1024u;
       const bool no_mid = p.positional_kind == SA_POS_MAHALANOBIS;  // gains of 1e8: beyond the middle tier's 32-bit cells
       hipError_t se;
-      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, maxN, ns, lds, st, scenes);
+      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
       if (se != hipSuccess) return se;
       break;
