@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """bench.py — assoc-pairs/sec of the association hot path on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (pair pre-filter + cost matrices + quantise + assignment) over one scene-frame
-whose inputs are already resident in HBM.  At N GPUs every rank owns its own scene (scenes are independent:
-compatible() is false across scene ids, sort.rs:251), so there is no data-path collective and scaling is weak.
+A step = one pass of the hot path (pair pre-filter + cost matrices + quantise + assignment) over one request set.
+  N = 1 (default): BASELINE C2, one scene-frame whose inputs are already resident in HBM (value = value_resident; value_h2d = the
+      same frame ingested from host buffers every step).
+  N > 1: scenes are independent (compatible() is false across scene ids, sort.rs:251), so the path shards by scene.  The default
+      workload becomes its batched form: a FIXED set of 64 scenes of the C2 frame split scene_id % N (strong scaling); a step = rank 0
+      scatters the request set (RCCL), every rank runs its share, one gather — `value` = total cells / that wall time.  The per-rank
+      replay with resident inputs stays beside it as value_resident.  Workloads that are one frame (c4, c5, ...) are replicated per
+      rank instead ("weak", no data-path collective) and carry the scatter / gather pass as the side object `dispatch`.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2b|c2t|c3|c4|c5|...] [--scenes S]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -33,9 +38,24 @@ VALU_F32_PEAK_TFLOPS = 157.3  # f32 vector peak (256 CUs x 128 lanes x 2 flop x 
 VALU_F64_PEAK_TFLOPS = 78.6  # f64 vector peak (MI355X_MICROARCH.md)
 
 
-def workload(name: str, seed: int):
-    """Returns (config, scene dict, description).  C2 is the configuration the metric is quoted on."""
+# Workloads that are a SET of independent scenes (BatchSort / BatchVisualSort request sets): under --gpus N > 1 the set is FIXED
+# (--scenes, default 64: BASELINE C3's count) and split scene_id % N over the ranks — strong scaling — and the default workload c2
+# becomes its batched form c2b (64 scenes of the C2 frame).  Scene s is generated from seed 1000 * seed + s on whichever rank owns it.
+SCENE_SETS = {"c2b": 8, "c2bk3": 8, "c3": 8}   # scenes per request set at one GPU
+
+
+def scene_ids_of_rank(total: int, world: int, rank: int):
+    """The scenes of a fixed set that rank `rank` of `world` owns: scene_id % world (similari_amd.sharding.owner, sa_cluster_shard_of)."""
+    return [s for s in range(int(total)) if s % int(world) == int(rank)]
+
+
+def workload(name: str, seed: int, scene_ids=None):
+    """Returns (config, scene dicts, description).  C2 is the configuration the metric is quoted on.  scene_ids (scene-set workloads):
+    generate exactly these scenes of the set."""
     rng = np.random.default_rng(seed)
+    if name in SCENE_SETS and scene_ids is None:
+        scene_ids = list(range(SCENE_SETS[name]))
+    srng = lambda sid: np.random.default_rng(1000 * seed + sid)   # noqa: E731
     if name == "c2":
         n = t = 1000
         d, k = 512, 1
@@ -48,11 +68,11 @@ def workload(name: str, seed: int):
         # BatchVisualSORT (visual_sort/batch_api.rs:213-317): S scenes of the C2 frame in ONE request set (grid.z = scene)
         n = t = 1000
         d, k = 512, (3 if name.endswith("k3") else 1)
-        scs = [synth.visual_scene(rng, t, n, d, k) for _ in range(8)]
+        scs = [synth.visual_scene(srng(sid), t, n, d, k) for sid in scene_ids]
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
                               max_observations=k, visual_min_votes=1, visual_minimal_track_length=1,
                               positional_min_confidence=0.1, max_idle_epochs=5)
-        return cfg, scs, f"BatchVisualSORT 8 scenes x (1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K={k}) per GPU in one request set"
+        return cfg, scs, f"BatchVisualSORT scenes of (1000 tracks x 1000 dets, 512-d cosine + IoU(0.3), K={k}) in one request set per GPU (BASELINE C2, batched: visual_sort/batch_api.rs)"
     if name == "c2t":
         # the frame a VisualSORT tracker loop hands over once idle tracks linger (max_idle_epochs): more table rows than detections
         n, t = 1000, 1500
@@ -101,9 +121,9 @@ def workload(name: str, seed: int):
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
         return cfg, [sc], "Oriented SORT 2000 x 2000, rotated IoU clipping (BASELINE C4)"
     if name == "c3":
-        scs = [synth.sort_scene(rng, 500, 500, canvas=(4096.0, 4096.0)) for _ in range(8)]
+        scs = [synth.sort_scene(srng(sid), 500, 500, canvas=(4096.0, 4096.0)) for sid in scene_ids]
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
-        return cfg, scs, "BatchSORT IoU, 8 scenes x 500 x 500 per GPU (BASELINE C3: 64 scenes over 8 GPUs)"
+        return cfg, scs, "BatchSORT IoU, scenes of 500 x 500 in one request set per GPU (BASELINE C3: 64 scenes over 8 GPUs)"
     if name == "c1":
         sc = synth.sort_scene(rng, 100, 100, canvas=(1920.0, 1080.0))
         cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
@@ -188,17 +208,19 @@ def maha_engine(local_rank, seed, n_scenes=8, n=500):
     return trk, eng, n_scenes * n * n, cont / float(n_scenes * n)
 
 
-def stage(eng, cfg, scenes):
+def stage(eng, cfg, scenes, keys=None):
+    """Upserts every scene's tracks and stages its detections as one request set; keys = the scenes' ids (default 0, 1, ...)."""
     visual = cfg.visual_kind != abi.SA_VIS_NONE
     keep = []
-    for s, sc in enumerate(scenes):
+    keys = list(range(len(scenes))) if keys is None else list(keys)
+    for s, sc in zip(keys, scenes):
         kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
         tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw)
         eng.upsert(s, tr)
         keep.append(tr)
     eng.batch_begin()
     dets = []
-    for s, sc in enumerate(scenes):
+    for s, sc in zip(keys, scenes):
         kw = dict(feats=sc["det_feats"], feat_quality=sc["det_quality"]) if visual else {}
         d = abi.make_detections(sc["det_boxes"], **kw)
         eng.batch_add(s, 1, d)
@@ -434,14 +456,14 @@ def kernel_bytes_model(cfg, scenes, matched_edges):
     return b
 
 
-def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False):
+def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
     """The reference's predict() ingests host buffers every frame (visual_sort/simple_api.rs:130-170): the same frame through
     sa_pipe_submit / sa_pipe_wait, two request sets in flight, features in a block from sa_host_alloc (DMA'd in place), results
     copied out — H2D and D2H inside the timed region.  feats_on_device: the feature rows lie in device memory already (a ReID model on
     the same GPU: sa_device_block_register) and are read in place; boxes and qualities still arrive from the host every frame."""
     visual = cfg.visual_kind != abi.SA_VIS_NONE
     blocks, items, dev_blocks = [], [], []
-    for s, sc in enumerate(scenes):
+    for s, sc in zip(list(range(len(scenes))) if keys is None else keys, scenes):
         kw = {}
         if visual and feats_on_device:
             import torch
@@ -543,6 +565,7 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive pass (value_h2d)")
     ap.add_argument("--cluster", type=int, default=0, help="single process: also time the workload's scenes through sa_cluster over this many shards (one engine per device; --cluster-devices to place several shards on one GPU)")
     ap.add_argument("--cluster-devices", default="", help="comma-separated HIP ordinals for --cluster (default 0..n-1)")
+    ap.add_argument("--scenes", type=int, default=0, help="scene-set workloads (c2b, c2bk3, c3): scenes of the set — in all, split scene_id %% N under --gpus N (default 64 there, 8 at one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -575,7 +598,16 @@ def main():
 
     from similari_amd.engine import Engine
 
-    cfg, scenes, desc = workload(args.workload, seed=1234 + rank)
+    # --gpus N > 1 on a scene-set workload (and on the default one, whose batched form is c2b): a FIXED set of scenes, split scene_id % N
+    wname = "c2b" if (args.workload == "c2" and world > 1) else args.workload
+    fixed_set = world > 1 and wname in SCENE_SETS
+    total_scenes = (args.scenes or 64) if fixed_set else (args.scenes or SCENE_SETS.get(wname, 0))
+    if fixed_set:
+        scene_keys = scene_ids_of_rank(total_scenes, world, rank)
+        cfg, scenes, desc = workload(wname, seed=1234, scene_ids=scene_keys)
+    else:
+        cfg, scenes, desc = workload(wname, seed=1234 + rank, scene_ids=(list(range(total_scenes)) if wname in SCENE_SETS else None))
+        scene_keys = list(range(len(scenes))) if scenes else []
     facade = None
     if cfg is None:  # c3m: tracks with Kalman states built by the product itself
         facade, eng, cells, acc0 = maha_engine(local_rank, 1234 + rank)
@@ -583,7 +615,7 @@ def main():
         cfg.device = local_rank
         cfg.flags = DEFAULT_FLAGS if args.flags < 0 else args.flags
         eng = Engine(cfg)
-        keep = stage(eng, cfg, scenes)
+        keep = stage(eng, cfg, scenes, scene_keys)
         cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
 
     def barrier():
@@ -635,7 +667,7 @@ def main():
     # PCIe-inclusive: the same frame from host buffers every step, pipelined (detections H2D and assignments D2H included)
     h2d, h2d_ids = None, None
     if not args.no_h2d and facade is None:
-        h2d, h2d_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50))
+        h2d, h2d_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50), keys=scene_keys)
         if dist is not None:
             th = torch.tensor([h2d["ms_per_step"]], dtype=torch.float64, device=cdev)
             dist.all_reduce(th, op=dist.ReduceOp.MAX)
@@ -645,7 +677,7 @@ def main():
     # the same with the feature rows already in HBM (the detector's ReID head ran on this GPU): only boxes + qualities cross PCIe
     devf = None
     if not args.no_h2d and facade is None and cfg.visual_kind != abi.SA_VIS_NONE and dist is None:
-        devf, devf_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50), feats_on_device=True)
+        devf, devf_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50), feats_on_device=True, keys=scene_keys)
         devf["matches_resident_run"] = bool(all(np.array_equal(a, g[0]) for a, g in zip(devf_ids, got)))
 
     # per-kernel durations: hipEvents stamped with each dispatch's own begin / end on the engine's stream (hipExtLaunchKernelGGL),
@@ -668,7 +700,7 @@ def main():
         cfg_p = cfg
         cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME))  # same launches as the timed pass
         engp = Engine(cfg_p)
-        keep2 = stage(engp, cfg_p, scenes)
+        keep2 = stage(engp, cfg_p, scenes, scene_keys)
         for _ in range(5):
             engp.batch_run()
         engp.batch_sync()
@@ -681,8 +713,11 @@ def main():
 
     # N > 1: the request set of ALL ranks from ONE ingest point (rank 0) through the scene scatter / result gather north_star names
     # (similari_amd.sharding.ShardedAssociator: one scatter of packed shares, one sa_associate_batch per rank, one gather), inside
-    # the timed region.  `value` above stays the resident replay (same definition at every N, so the driver's efficiency is
-    # meaningful); this object is the cost of getting a batch to the GPUs and its answers back.
+    # the timed region: W untimed request sets, then EXACTLY K of them between two barriers on rank 0's clock (every step ends with
+    # the gather, so rank 0's clock is the maximum over the ranks).  On a FIXED scene set (scene-set workloads: the 64 scenes split
+    # scene_id % N) this is `value` — total cells / wall time of scatter + per-rank batch + gather, strong scaling — and the per-rank
+    # resident replay above becomes value_resident; on the other workloads (every rank replays its own frame: weak scaling) it stays
+    # the side object `dispatch`.
     dispatch = None
     if dist is not None and facade is None:
         from similari_amd import sharding
@@ -691,31 +726,38 @@ def main():
         visual = cfg.visual_kind != abi.SA_VIS_NONE
         cfg.flags = 0
         deng = _E(cfg)
-        per_rank = [workload(args.workload, seed=1234 + r)[1] for r in range(world)] if rank == 0 else None
-        mine = scenes
-        rows = sum(len(sc["det_boxes"]) for sc in mine)
-        bytes_ = sum(len(sc["det_boxes"]) * (32 + 4 + (4 * cfg.feature_len if visual else 0)) + 64 for sc in mine) + 4096
-        sh = sharding.ShardedAssociator(deng, capacity_bytes=bytes_, capacity_rows=rows + 16)
-        for s_, sc in enumerate(mine):  # every rank seeds its own scenes' tables (global scene id = rank + world * local index -> owner = rank)
+        if fixed_set:
+            gids = scene_keys                                            # this rank's scenes of the fixed set (owner = id % world)
+            everyone = [(sid, sc) for sid, sc in zip(range(total_scenes), workload(wname, seed=1234, scene_ids=list(range(total_scenes)))[1])] if rank == 0 else None
+        else:
+            gids = [rank + world * s_ for s_ in range(len(scenes))]      # replicas: global scene id = rank + world * local index -> owner = rank
+            everyone = [(r + world * s_, sc) for r in range(world) for s_, sc in enumerate(workload(wname, seed=1234 + r)[1])] if rank == 0 else None
+        # capacities: the largest share any rank receives (the set is split evenly up to one scene)
+        per_scene_rows = max(len(sc["det_boxes"]) for sc in scenes) if scenes else 1
+        n_mine = (total_scenes + world - 1) // world if fixed_set else len(scenes)
+        rows = n_mine * per_scene_rows
+        bytes_ = rows * (4 * cfg.feature_len if visual else 0) + 4096
+        sh = sharding.ShardedAssociator(deng, capacity_bytes=bytes_, capacity_rows=rows + 16, max_scenes=max(64, n_mine))
+        for gid, sc in zip(gids, scenes):  # every rank seeds its own scenes' tables
             kw = dict(feats=sc["track_feats"], feat_present=sc["track_present"]) if visual else {}
-            deng.upsert(rank + world * s_, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw))
+            deng.upsert(gid, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], **kw))
         barrier()
         if rank == 0:
-            items = []
-            for r in range(world):
-                for s_, sc in enumerate(per_rank[r]):
-                    items.append((r + world * s_, 1, sc["det_boxes"], sc["det_feats"] if visual else None, sc["det_quality"] if visual else None))
-            for _ in range(5):
+            items = [(gid, 1, sc["det_boxes"], sc["det_feats"] if visual else None, sc["det_quality"] if visual else None) for gid, sc in everyone]
+            for _ in range(max(1, min(args.warmup, 5))):
                 res = sh.associate(items)
+            iters = args.steps if fixed_set else min(args.steps, 30)
             t0 = time.perf_counter()
-            iters = 30
             for _ in range(iters):
                 res = sh.associate(items)
             dtd = (time.perf_counter() - t0) / iters
-            ok = all(np.array_equal(res[i][0], g[0]) for i, g in enumerate(got))  # rank 0's own scenes come first in `items`
+            mine_at = [i for i, (gid, _) in enumerate(everyone) if gid % world == 0]  # rank 0's own scenes, in its staging order
+            ok = all(np.array_equal(res[i][0], g[0]) for i, g in zip(mine_at, got))
+            truth_ok = float(np.mean(np.concatenate([res[i][0] == sc["truth"] for i, (_, sc) in enumerate(everyone)])))
             sh.shutdown()
-            dispatch = {"pairs_per_s": total_cells / dtd, "ms_per_batch": 1e3 * dtd, "scenes": len(items), "ranks": world,
+            dispatch = {"pairs_per_s": total_cells / dtd, "ms_per_batch": 1e3 * dtd, "steps": iters, "scenes": len(items), "ranks": world,
                         "backend": dist.get_backend(), "rank0_local_ms": sh.last_local_ms, "rank0_answers_match_resident_run": bool(ok),
+                        "match_accuracy_all_scenes": truth_ok,
                         "note": "rank 0 packs every rank's share (numpy concatenation), ONE scatter, every rank runs one sa_associate_batch on its GPU "
                                 "(H2D + kernels + results), ONE gather; host buffers in, host buffers out on rank 0"}
         else:
@@ -846,22 +888,27 @@ def main():
                         "note": "pairs that pass too_far() x the f64 operations Sutherland-Hodgman + shoelace spend on them (counted on a sample by a host restatement)"}
         out = {
             "metric": "assoc-pairs/sec (NxM cost+assign) VisualSORT 512-d",
-            "value": total_cells * args.steps / dt,
+            "value": (dispatch["pairs_per_s"] if (fixed_set and dispatch) else total_cells * args.steps / dt),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step": (dispatch["ms_per_batch"] if (fixed_set and dispatch) else 1e3 * dt / args.steps),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if fixed_set else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
-            "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "pairs_per_step_per_gpu": cells,
-                       "parallelism": f"scene-sharded x{world}, no data-path collective"},
+            "data": ("synthetic (seeded, SURVEY §8d); a FIXED set of %d scenes split scene_id %% %d: every step rank 0 scatters the request set (RCCL), every rank "
+                     "runs its share (H2D + kernels), one gather — value = total cells / that wall time; value_resident = the per-rank replay with inputs resident in HBM"
+                     % (total_scenes, world)) if fixed_set else "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
+            "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "scenes_total": (total_scenes if fixed_set else world * (len(scenes) if scenes else 8)),
+                       "pairs_per_step_per_gpu": cells,
+                       "parallelism": (f"fixed scene set sharded scene_id % {world}: one scatter + one gather per step (RCCL), no collective inside a rank's share"
+                                       if fixed_set else f"scene-sharded x{world}, no data-path collective")},
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
                               "max_ms_per_step": 1e3 * max(regions) / args.steps, "ms_per_step_slope": 1e3 * step_s},
             "value_resident": total_cells * args.steps / dt,
+            "ms_per_step_resident": 1e3 * dt / args.steps,
             "value_h2d": h2d["pairs_per_s"] if h2d else None,
             "match_accuracy": acc,
             "roofline": roof,

@@ -245,12 +245,24 @@ struct PosSmem {
 // for 60, so proofs alone make it worse (24.6 us).  There the tiles are 16 x 128 (~120 surviving pairs): the threads of two
 // waves prove what they can and the ~25 pairs that are left take ONE clip round where two 16 x 64 tiles took two: 21.2 us.
 // (16 x 192 and 16 x 256 tiles: 25 us — the tile itself then outlasts the contraction.)
+// In-kernel timeline of a tile (build with -DSA_POS_TRACE, run with SA_POS_TRACE=<launch #>: scripts/pos_trace.sh): s_memtime of thread 0 at
+//   0 entry | 1 candidate boxes in LDS, this thread's track loads landed | 2 every cell screened (too_far + compatible), survivors listed |
+//   3 disjointness proofs done (= 2 when the stage is skipped) | 4 clip rounds done, edges appended | [6] survivors, [7] pairs clipped
+#ifdef SA_POS_TRACE
+#define POS_STAMP(tr, i) do { if ((tr) && tid == 0) (tr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define POS_NOTE(tr, i, v) do { if ((tr) && tid == 0) (tr)[i] = (uint64_t)(v); } while (0)
+#else
+#define POS_STAMP(tr, i) do { } while (0)
+#define POS_NOTE(tr, i, v) do { } while (0)
+#endif
 template <bool DENSE, bool EDGES, int NSUB, bool UNION, bool PROOF = false, int WORKERS = 64, bool COOP = false>
-__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem, uint32_t tid) {
+__device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, void* smem, uint32_t tid,
+                                                uint64_t* tr = nullptr) {
   constexpr uint32_t POS_TJ = 64u * NSUB, POS_WORKERS = (uint32_t)WORKERS;
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
+  POS_STAMP(tr, 0);
   // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
   // static LDS with the contraction's stages instead of adding to it
   PosSmem<NSUB, WORKERS>& sm = *reinterpret_cast<PosSmem<NSUB, WORKERS>*>(smem);
@@ -283,6 +295,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     if (wave == 0) s_thha[s * 64 + lane] = tg[s].hha;
   }
   __syncthreads();
+  POS_STAMP(tr, 1);
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
 #pragma unroll
@@ -305,6 +318,8 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   }
   __syncthreads();
   uint32_t cnt = s_cnt;
+  POS_STAMP(tr, 2);
+  POS_NOTE(tr, 6, cnt);
   // (only where it saves a clip round: up to 64 surviving pairs are one round of the four-lane clipper whatever their number)
   if (PROOF && p.positional_kind != SA_POS_MAHALANOBIS && cnt > 64u) {
     // one thread per surviving pair proves, where it can, that the polygons do not overlap; the rest are compacted in place
@@ -344,6 +359,8 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     __syncthreads();
     cnt = sm.cnt2;
   }
+  POS_STAMP(tr, 3);
+  POS_NOTE(tr, 7, cnt);
   // one surviving cell -> (optionally) the dense matrix, and its edge
   auto emit = [&](uint32_t i, uint32_t j, float w, bool present) {
     if (DENSE) S.pos[(size_t)i * T + j] = present ? w : nanv;
@@ -421,5 +438,6 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
       emit(i, j, out, present);
     }
   }
+  POS_STAMP(tr, 4);
 }
 

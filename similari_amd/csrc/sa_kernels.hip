@@ -109,13 +109,46 @@ __global__ void k_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32
   if (i < n_vertices) parent[i] = i;
 }
 
+#ifdef SA_POS_TRACE
+// per-tile timeline of the positional launch (positional_tile, sa_frame.h): 8 words per block, dumped by sa_pos_trace_hook
+__device__ uint64_t* g_pos_trace;
+static void sa_pos_trace_hook(hipStream_t st, uint32_t nb) {
+  static uint64_t* buf = nullptr;
+  static int calls = 0;
+  const char* env = getenv("SA_POS_TRACE");
+  if (!env) return;
+  if (!buf) {
+    hipMalloc(&buf, 64 * 262144);
+    hipMemset(buf, 0, 64 * 262144);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_pos_trace), &buf, sizeof(void*));
+  }
+  if (++calls != atoi(env)) return;   // dumps what the PREVIOUS launches left
+  hipStreamSynchronize(st);
+  if (nb > 262144) nb = 262144;
+  uint64_t* h = (uint64_t*)malloc((size_t)nb * 64);
+  hipMemcpy(h, buf, (size_t)nb * 64, hipMemcpyDeviceToHost);
+  if (FILE* f = fopen("gpurun_out/pos_trace.txt", "w")) {
+    for (uint32_t i = 0; i < nb; ++i)
+      if (h[i * 8])
+        fprintf(f, "%u %llu %llu %llu %llu %llu %llu %llu %llu\n", i, (unsigned long long)h[i * 8], (unsigned long long)h[i * 8 + 1],
+                (unsigned long long)h[i * 8 + 2], (unsigned long long)h[i * 8 + 3], (unsigned long long)h[i * 8 + 4],
+                (unsigned long long)h[i * 8 + 5], (unsigned long long)h[i * 8 + 6], (unsigned long long)h[i * 8 + 7]);
+    fclose(f);
+  }
+  free(h);
+}
+#define SA_POS_TRACE_PTR() (g_pos_trace && (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) < 262144u ? g_pos_trace + 8 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr)
+#else
+static inline void sa_pos_trace_hook(hipStream_t, uint32_t) {}
+#define SA_POS_TRACE_PTR() nullptr
+#endif
 // The first launch of a frame: blockIdx.y < pos_rows -> a positional tile; the rows above carry the frame-preparation blocks.
 template <int NSUB, bool UNION>
 __global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows_) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
   const uint32_t pos_rows = pos_rows_ & 0x7fffffffu;  // (bit 31: the preparation blocks run their reset half only)
-  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x);
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x, SA_POS_TRACE_PTR());
   else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x, (pos_rows_ >> 31) != 0);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.
@@ -1763,6 +1796,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   if (prep == 0) prep_blocks = 0;
   if (!pos_rows && !prep_blocks) return hipSuccess;
   const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
+  sa_pos_trace_hook(st, grid.x * grid.y * grid.z);
   const uint32_t pr = pos_rows | (prep == 3 ? 0x80000000u : 0u);
   if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pr);
   else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pr);

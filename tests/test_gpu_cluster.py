@@ -171,3 +171,34 @@ def test_bench_under_torchrun_takes_the_rccl_branch(workload):
     disp = d["dispatch"]
     assert disp["backend"] == "nccl" and disp["ranks"] == 1
     assert disp["rank0_answers_match_resident_run"] is True
+
+
+@pytest.mark.parametrize("workload,scenes", [("c3", 6), ("c2", 4)])
+def test_bench_fixed_scene_set_over_two_ranks_on_one_device(workload, scenes):
+    """bench.py --gpus 2 as the driver launches it, rehearsed on this one-GPU box (SA_BENCH_ONE_DEVICE=1: both ranks drive device 0,
+    collectives over gloo): a FIXED set of scenes split scene_id % 2 (the default workload in its batched form c2b), `value` = total
+    cells / wall time of rank 0's scatter + per-rank batch + gather ("scaling": "strong"), the per-rank replay as value_resident; every
+    scene's answer matches the synthetic truth and rank 0's own scenes match its resident run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--scenes", str(scenes), "--steps", "4", "--warmup", "2",
+           "--profile-iters", "2", "--no-cpu-baseline", "--no-oracle", "--no-h2d"]
+    r = subprocess.run(cmd, env=dict(os.environ, SA_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4
+    assert d["config"]["scenes_total"] == scenes and d["config"]["scenes_per_gpu"] == scenes // 2
+    disp = d["dispatch"]
+    assert disp["ranks"] == 2 and disp["scenes"] == scenes and disp["steps"] == 4
+    assert disp["rank0_answers_match_resident_run"] is True
+    assert disp["match_accuracy_all_scenes"] > 0.9
+    assert abs(d["value"] - disp["pairs_per_s"]) <= 1e-6 * d["value"] and d["value_resident"] > d["value"] > 0

@@ -1322,6 +1322,92 @@ def test_full_size_c2_three_observations_against_the_oracle():
     compare_visual(cfg, ids, votes, pos, vis, ref)
 
 
+@pytest.mark.paths("separate_resolve", "never_lean")
+@pytest.mark.parametrize("k", [1, 3])
+def test_full_size_more_tracks_than_the_small_tail_holds_against_the_oracle(k):
+    """1000 detections x 1500 tracks x 512-d (a tracker loop's table once idle tracks linger: T > 1024 is its NORMAL state): the fused
+    first phase with vote words (class words at K = 3) feeding the many-workgroup tail — k_assign_label<WORDS> turns the words into
+    verdicts, the solver re-arms them — three launches.  Same gates as C2: IoU cells and the quantised matrix bit for bit, every
+    cosine weight within 1e-5, the timed launches' own edges and votes, ids and vote types identical."""
+    rng = np.random.default_rng(1500 + k)
+    sc = synth.visual_scene(rng, 1500, 1000, 512, k, new_fraction=0.1)
+    sc["det_quality"][rng.uniform(size=1000) < 0.05] = 0.05
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=512,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          visual_minimal_quality_use=0.3, max_idle_epochs=5)
+    ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+    compare_visual(cfg, ids, votes, pos, vis, ref)
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 10 and (votes == abi.SA_VOTE_VISUAL).sum() > 700
+
+
+def test_frames_beyond_1024_tracks_take_three_launches():
+    """The launches of a 1000 x 1500 VisualSORT frame: first phase, label, solve — no stand-alone contraction, no resolve kernel."""
+    rng = np.random.default_rng(1503)
+    sc = synth.visual_scene(rng, 1500, 1000, 128, 1)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=128,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
+    if abi.EXTRA_FLAGS:
+        pytest.skip("default path only")
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+    det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        eng.associate(0, 1, det)
+        eng.profile_reset()
+        ids, votes = eng.associate(0, 1, det)
+        prof = eng.profile_read()
+    finally:
+        eng.close()
+    launched = {k for k, (n, _) in prof.items() if n and k != "d2h_results"}
+    assert launched == {"k_frame_visual", "k_assign_label", "k_assign_solve"}, prof
+    np.testing.assert_array_equal(ids, sc["truth"])
+
+
+@pytest.mark.paths("never_lean")
+@pytest.mark.parametrize("k", [1, 3])
+def test_full_size_batched_c2_against_the_oracle(k):
+    """BatchVisualSORT at configuration scale (visual_sort/batch_api.rs:213-317): 8 scenes x (1000 x 1000 x 512-d cosine + IoU) in ONE
+    request set — grid.z = scene through the first phase and the tail — with SA_FLAG_TAP: every scene's edge records bit for bit, its
+    vote words (class words at K = 3) within the distance tolerance, its ids and vote types against the oracle's (distance stage
+    sharded over the host's cores)."""
+    S = 8
+    rng = np.random.default_rng(800 + k)
+    scs = [synth.visual_scene(rng, 1000, 1000, 512, k, new_fraction=0.05 * (s % 3)) for s in range(S)]
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=512,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_idle_epochs=5, flags=abi.SA_FLAG_TAP)
+    trs = [abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"]) for sc in scs]
+    dets = [abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"]) for sc in scs]
+    eng = Engine(cfg)
+    try:
+        for s in range(S):
+            eng.upsert(100 + s, trs[s])
+        eng.batch_begin()
+        slots = [eng.batch_add(100 + s, 1, dets[s]) for s in range(S)]
+        eng.batch_run()
+        eng.batch_sync()
+        first = {}
+        for s in range(S):
+            ref = O.associate(cfg, trs[s], 1, dets[s], shards=32)
+            ids, votes = eng.batch_fetch(slots[s], 1000)
+            first[s] = ids
+            assert check_edges(eng, ref["quantised"], thr_q_of(cfg), slot=slots[s]) > 0
+            check_votes(cfg, eng, ref["visual"], tol_abs=1e-5, slot=slots[s])
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"scene {s}")
+            np.testing.assert_array_equal(votes, ref["voting_type"], err_msg=f"scene {s}")
+            assert (ids == scs[s]["truth"]).mean() > 0.99
+        # the same request set again (the replay the bench times): state left clean by the first run
+        eng.batch_run()
+        eng.batch_sync()
+        for s in (0, S - 1):
+            ids2, _ = eng.batch_fetch(slots[s], 1000)
+            np.testing.assert_array_equal(ids2, first[s])
+    finally:
+        eng.close()
+
+
 @pytest.mark.paths("euclid_valu", "euclid_mfma")
 def test_full_size_c2_euclidean_against_the_oracle():
     """The C2 frame under the reference's DEFAULT visual metric: every euclidean distance within 1e-5 relative."""

@@ -331,6 +331,79 @@ def test_a_rank_that_fails_inside_its_share_still_reaches_the_gather(tmp_path):
     assert worker == "raised: engine failure inside the share", worker
 
 
+def fixed_set_worker(rank: int, port: int, outfile: str):
+    """bench.py's --gpus N form on a scene-set workload: a FIXED set of scenes, scene s owned by rank s % N (bench.scene_ids_of_rank),
+    every rank generating and seeding exactly its own scenes, rank 0 scattering the whole set and gathering every scene's answer."""
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import torch.distributed as dist
+
+    import bench
+    from similari_amd import abi, sharding, synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        total, d = 7, 16
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.3, feature_len=d, max_observations=1,
+                              visual_min_votes=1, visual_minimal_track_length=1, max_idle_epochs=5)
+        gen = lambda sid: synth.visual_scene(np.random.default_rng(1000 * 77 + sid), 30 + sid, 25 + 2 * sid, d, 1, canvas=(600.0, 400.0), new_fraction=0.1)  # noqa: E731
+        mine = bench.scene_ids_of_rank(total, WORLD, rank)
+        assert all(sharding.owner(s, WORLD) == rank for s in mine)
+        eng = OracleEngine(cfg)
+        n_mine = (total + WORLD - 1) // WORLD
+        sh = sharding.ShardedAssociator(eng, capacity_bytes=n_mine * 64 * 4 * d, capacity_rows=n_mine * 64, max_scenes=n_mine)
+        for sid in mine:   # every rank seeds ITS scenes itself (no collective): the set is sticky
+            sc = gen(sid)
+            eng.upsert(sid, abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"]))
+        dist.barrier()
+        if rank != 0:
+            sh.serve_forever()
+            return
+        everyone = [(sid, gen(sid)) for sid in range(total)]
+        items = [(sid, 1, sc["det_boxes"], sc["det_feats"], sc["det_quality"]) for sid, sc in everyone]
+        out = {}
+        for step in range(2):
+            res = sh.associate(items)
+            for (sid, _), (ids, votes) in zip(everyone, res):
+                out[f"t{step}_s{sid}_ids"], out[f"t{step}_s{sid}_votes"] = ids, votes
+        sh.shutdown()
+        np.savez(outfile, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fixed_scene_set_split_over_two_ranks_matches_the_oracle(tmp_path):
+    """The strong-scaling form of bench.py (--gpus N on c2b / c3): 7 scenes split scene_id % 2, two steps; every scene's ids and vote
+    types equal the oracle's whichever rank served it."""
+    import torch.multiprocessing as mp
+
+    import bench
+    import oracle_lib as O
+    from similari_amd import abi, synth
+
+    assert bench.scene_ids_of_rank(7, 2, 0) == [0, 2, 4, 6] and bench.scene_ids_of_rank(7, 2, 1) == [1, 3, 5]
+    assert sorted(bench.scene_ids_of_rank(64, 8, 3)) == list(range(3, 64, 8))
+    # a rank that generates only its own scenes gets the very scenes rank 0 generates for the whole set
+    c_all = bench.workload("c3", seed=5, scene_ids=[0, 1, 2, 3])[1]
+    c_mine = bench.workload("c3", seed=5, scene_ids=[1, 3])[1]
+    np.testing.assert_array_equal(c_all[1]["det_boxes"], c_mine[0]["det_boxes"])
+    np.testing.assert_array_equal(c_all[3]["track_boxes"], c_mine[1]["track_boxes"])
+    outfile = str(tmp_path / "fixed.npz")
+    mp.spawn(fixed_set_worker, args=(free_port(), outfile), nprocs=WORLD, join=True)
+    got = dict(np.load(outfile))
+    d = 16
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.3, feature_len=d, max_observations=1,
+                          visual_min_votes=1, visual_minimal_track_length=1, max_idle_epochs=5)
+    for sid in range(7):
+        sc = synth.visual_scene(np.random.default_rng(1000 * 77 + sid), 30 + sid, 25 + 2 * sid, d, 1, canvas=(600.0, 400.0), new_fraction=0.1)
+        tr = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"], feats=sc["track_feats"], feat_present=sc["track_present"])
+        det = abi.make_detections(sc["det_boxes"], feats=sc["det_feats"], feat_quality=sc["det_quality"])
+        ref = O.associate(cfg, tr, 1, det, want_matrices=False)
+        for step in range(2):
+            np.testing.assert_array_equal(got[f"t{step}_s{sid}_ids"], ref["track_id"], err_msg=f"scene {sid} step {step}")
+            np.testing.assert_array_equal(got[f"t{step}_s{sid}_votes"], ref["voting_type"])
+
+
 def test_share_pack_roundtrip():
     sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
     from similari_amd import sharding
