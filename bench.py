@@ -53,9 +53,12 @@ def workload(name: str, seed: int, scene_ids=None):
     """Returns (config, scene dicts, description).  C2 is the configuration the metric is quoted on.  scene_ids (scene-set workloads):
     generate exactly these scenes of the set."""
     rng = np.random.default_rng(seed)
-    if name in SCENE_SETS and scene_ids is None:
+    # (the default set of a one-GPU run keeps the scenes of earlier rounds: ONE generator streamed over the scenes; an explicit list of
+    # scene ids — the fixed set of a multi-GPU run — draws scene s from its own seed, so that any rank can generate exactly its scenes)
+    legacy = name in SCENE_SETS and scene_ids is None
+    if legacy:
         scene_ids = list(range(SCENE_SETS[name]))
-    srng = lambda sid: np.random.default_rng(1000 * seed + sid)   # noqa: E731
+    srng = (lambda sid: rng) if legacy else (lambda sid: np.random.default_rng(1000 * seed + sid))
     if name == "c2":
         n = t = 1000
         d, k = 512, 1

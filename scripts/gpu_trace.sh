@@ -5,8 +5,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 TAG=${1:-r04_t}; POSW=${2:-c4 c3}; GEMW=${3:-c2t}
 O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-[ -x scripts/micro/launch_floor.bin ] && scripts/micro/launch_floor.bin > $O/launch_floor.txt 2>&1 && cat $O/launch_floor.txt
-SA_EXTRA_FLAGS="-DSA_POS_TRACE -DSA_GEMM_TRACE" python -m similari_amd.build > $O/build.log 2>&1 || { echo BUILD FAILED; tail -20 $O/build.log; exit 1; }
+if [ -z "$SKIP_FLOOR" ] && [ -x scripts/micro/launch_floor.bin ]; then scripts/micro/launch_floor.bin > $O/launch_floor.txt 2>&1; cat $O/launch_floor.txt; fi
+SA_EXTRA_FLAGS="-DSA_POS_TRACE -DSA_GEMM_TRACE" python -m similari_amd.build --force > $O/build.log 2>&1 || { echo BUILD FAILED; tail -20 $O/build.log; exit 1; }
 WORKLOADS="$POSW" bash scripts/pos_trace.sh > $O/pos_trace.txt 2>&1; cat $O/pos_trace.txt
 for w in $GEMW; do
   echo "== gemm trace $w" | tee -a $O/gemm_trace.txt

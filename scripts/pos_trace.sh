@@ -9,23 +9,23 @@ for w in ${WORKLOADS:-c4 c3}; do
   python - "$w" <<'PY' | tee gpurun_out/pos_trace_$w.txt
 import sys, numpy as np
 w = sys.argv[1]
-a = np.loadtxt("gpurun_out/pos_trace.txt")
-a = a[a[:, 5] > 0]   # tiles that ran to the end
-blk, t = a[:, 0].astype(int), a[:, 1:6]
+a = np.loadtxt("gpurun_out/pos_trace.txt", dtype=np.uint64)
+a = a[a[:, 5] > 0]   # tiles that ran to the end (column 5 = stamp 4)
+blk, t = a[:, 0].astype(int), a[:, 1:6].astype(np.int64)
 d = np.diff(t, axis=1)
 pct = lambda v: " / ".join("%6.0f" % np.percentile(v, q) for q in (10, 50, 90, 99, 100))
 print(f"== {w}: {len(a)} positional tiles of one k_frame launch; cycles (s_memtime), percentiles 10 / 50 / 90 / 99 / max")
 for i, name in enumerate(("boxes -> LDS + track loads", "screen (too_far, compatible) + survivor list", "disjointness proofs", "clip rounds + edge append")):
     print(f"   {name:46s} {pct(d[:, i])}")
 print(f"   {'tile life (entry -> last edge out)':46s} {pct(t[:, 4] - t[:, 0])}")
-print(f"   survivors per tile {pct(a[:, 7])} | pairs clipped per tile {pct(a[:, 8])}")
-# occupancy timeline inside each XCD (s_memtime bases differ between XCDs; workgroups go round-robin over the 8 XCDs)
-xcd = blk % 8
-for x in range(8):
-    m = xcd == x
-    if not m.any(): continue
-    base = t[m, 0].min()
-    ent, ext = t[m, 0] - base, t[m, 4] - base
-    print(f"   XCD {x}: {m.sum():5d} tiles, entries {pct(ent)} | exits {pct(ext)}")
+print(f"   survivors per tile {pct(a[:, 7].astype(np.int64))} | pairs clipped per tile {pct(a[:, 8].astype(np.int64))}")
+# when the tiles ran, on the 100 MHz clock all XCDs share ([5] = entry << 32 | exit): microseconds from the first tile's entry
+rt = a[:, 6]
+ent, ext = (rt >> np.uint64(32)).astype(np.int64), (rt & np.uint64(0xffffffff)).astype(np.int64)
+ent = ent & 0xffffffff
+ext = np.where(ext < ent, ext + (1 << 32), ext)
+t0 = ent.min()
+print(f"   tile entry, us after the first tile's   {' / '.join('%6.2f' % (np.percentile(ent - t0, q) / 100.0) for q in (10, 50, 90, 99, 100))}")
+print(f"   tile exit,  us after the first tile's   {' / '.join('%6.2f' % (np.percentile(ext - t0, q) / 100.0) for q in (10, 50, 90, 99, 100))}")
 PY
 done

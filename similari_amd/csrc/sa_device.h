@@ -480,6 +480,29 @@ SA_HD void sa_uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
     if (sa_cas_u32(parent + a, a, b) == a) return;
   }
 }
+// The same with the two vertices' parents ALREADY LOADED by the caller (pa = parent[a], pb = parent[b]): a caller that has other
+// requests to make for the same edge issues those two loads beside them, and the usual case — both vertices still roots, or one hop from
+// one — costs one round trip (the loads) plus the compare-and-swap instead of three dependent ones.
+SA_HD uint32_t sa_uf_find_from(uint32_t* parent, uint32_t v, uint32_t p) {
+  while (p != v) {
+    uint32_t gp = sa_ld_u32(parent + p);
+    if (gp != p) sa_st_u32(parent + v, gp);
+    v = p;
+    p = gp;
+  }
+  return v;
+}
+SA_HD void sa_uf_union_from(uint32_t* parent, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb) {
+  a = sa_uf_find_from(parent, a, pa);
+  b = sa_uf_find_from(parent, b, pb);
+  for (;;) {
+    if (a == b) return;
+    if (a < b) { uint32_t t = a; a = b; b = t; }
+    if (sa_cas_u32(parent + a, a, b) == a) return;
+    a = sa_uf_find(parent, a);
+    b = sa_uf_find(parent, b);
+  }
+}
 
 // ---- exact sparse assignment of one connected component -----------------------------------------------------
 // SortVoting::winners (sort/voting.rs:30-100) maximises sum of quantised weights over an N x (N+T) matrix

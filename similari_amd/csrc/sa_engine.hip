@@ -658,11 +658,13 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     if (attach) sa_done_event = done;
     le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
   } else {
-    // (with vote words the label kernel also turns them into the verdicts the solver honours, and the solver re-arms them)
-    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 2 : 1)); }
+    // (with vote words the label step also turns them into the verdicts the solver honours, and the solver re-arms them).  Up to
+    // SA_MERGE_MAX_WGS x 256 candidates the label step is the first phase of the solver's launch (SA_FLAG_SEPARATE_LABEL: never)
+    const bool merged = sa_tail_merged_ok(maxN, maxT) && !(e->cfg.flags & SA_FLAG_SEPARATE_LABEL);
+    if (!merged) { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 2 : 1)); }
     ProfScope ps(e, KID_ASSIGN_SOLVE);
     if (attach) sa_done_event = done;
-    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 4 : 3);
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, merged ? (words ? 7 : 6) : (words ? 4 : 3));
   }
   if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
   sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
@@ -919,6 +921,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.vote_words = 0;  // set per frame by enqueue_frame
   P.force_general = (cfg->flags & SA_FLAG_GENERAL_TAIL) ? 1u : 0u;
   P.gemm_plan = cfg->gemm_plan > 0 ? cfg->gemm_plan - 1 : -1;
+  P.row_major_tiles = (cfg->flags & SA_FLAG_ROW_MAJOR_TILES) ? 1u : 0u;
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
   for (uint32_t i = 0; i < cfg->n_constraints; ++i) {

@@ -61,6 +61,7 @@ __device__ __forceinline__ void pad_feature_row(const float* s, float* d, uint32
 __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk, uint32_t tid, bool light = false) {
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blk * 256 + tid;
+  if (i >= SA_QW_TOP && i <= SA_QW_LABELLED) S.stats[i] = 0u;  // the general tail's queue words (block 0 always exists: N + T + 1 threads)
   if (i < T) {
     S.col_excluded[i] = 0;
     S.v[i] = 0;
@@ -247,11 +248,14 @@ struct PosSmem {
 // (16 x 192 and 16 x 256 tiles: 25 us — the tile itself then outlasts the contraction.)
 // In-kernel timeline of a tile (build with -DSA_POS_TRACE, run with SA_POS_TRACE=<launch #>: scripts/pos_trace.sh): s_memtime of thread 0 at
 //   0 entry | 1 candidate boxes in LDS, this thread's track loads landed | 2 every cell screened (too_far + compatible), survivors listed |
-//   3 disjointness proofs done (= 2 when the stage is skipped) | 4 clip rounds done, edges appended | [6] survivors, [7] pairs clipped
+//   3 disjointness proofs done (= 2 when the stage is skipped) | 4 clip rounds done, edges appended | [6] survivors, [7] pairs clipped |
+//   [5] = (s_memrealtime at entry << 32) | (s_memrealtime at exit & 0xffffffff): the 100 MHz clock every XCD shares (s_memtime's base differs per XCD)
 #ifdef SA_POS_TRACE
 #define POS_STAMP(tr, i) do { if ((tr) && tid == 0) (tr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define POS_NOTE(tr, i, v) do { if ((tr) && tid == 0) (tr)[i] = (uint64_t)(v); } while (0)
+#define POS_RT() __builtin_amdgcn_s_memrealtime()
 #else
+#define POS_RT() 0ull
 #define POS_STAMP(tr, i) do { } while (0)
 #define POS_NOTE(tr, i, v) do { } while (0)
 #endif
@@ -263,6 +267,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
   POS_STAMP(tr, 0);
+  const uint64_t pos_rt0 = POS_RT();
   // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
   // static LDS with the contraction's stages instead of adding to it
   PosSmem<NSUB, WORKERS>& sm = *reinterpret_cast<PosSmem<NSUB, WORKERS>*>(smem);
@@ -298,6 +303,10 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   POS_STAMP(tr, 1);
   const float nanv = __builtin_nanf("");
   const uint64_t epoch = S.epoch;
+  // The screen: 16 cells per thread (4 candidate rows of this wave x NSUB tracks of this lane).  It is VALU THROUGHPUT, not latency:
+  // every co-resident tile of a CU is in this phase at the same time (in-kernel timeline, scripts/pos_trace.sh: 4.0 k cycles of a C4
+  // tile's 18 k — 4 M cells x ~15 instructions over the chip's 1024 SIMDs — whatever the survivors' path costs: appending them per wave
+  // with one ballot and a scalar branch per step instead of this divergent branch was measured at 4.8 k).
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) {
     const uint32_t lj = s * 64 + lane, j = j0 + lj;
@@ -367,15 +376,21 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     if (EDGES && present) {
       const int64_t gain = sa_quantise(w) - p.threshold_q;  // (w * 1e6f) as i64 vs the diagonal of SortVoting's matrix
       if (gain > 0) {
+        // every request of the edge that does not depend on another one goes out together: the slot in the row's list, and (UNION)
+        // the two union-find parents — one round trip to L2 instead of three in a row at the tail of the tile (pos_trace: the edge
+        // append was ~6 k of a C4 tile's 18 k cycles)
         const uint32_t slot = atomicAdd((uint32_t*)(S.e_cnt + i), 1u);
+        uint32_t pa = 0, pb = 0;
+        if (UNION) {
+          pa = sa_ld_u32((const uint32_t*)S.parent + i);
+          pb = sa_ld_u32((const uint32_t*)S.parent + N + j);
+          __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
+        }
         // general tail (UNION): row-major lists, a short row is one cache line for the thread that gathers its component;
         // one-workgroup tail: SLOT-major — its 1024 threads fetch "edge k of my row" side by side, 64 lanes = one contiguous
         // kilobyte (row-major: 64 lines per wave-load through ONE compute unit's address path, 4 k cycles of the tail)
         sa_stg(S.e_edge + (UNION ? (size_t)i * S.estride + slot : (size_t)slot * N + i), SaEdge{gain, j, 0u});
-        if (UNION) {
-          __hip_atomic_fetch_min((int64_t*)(S.u + i), -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // row dual = -max gain
-          sa_uf_union((uint32_t*)S.parent, i, N + j);
-        }
+        if (UNION) sa_uf_union_from((uint32_t*)S.parent, i, pa, N + j, pb);
       }
     }
   };
@@ -439,5 +454,6 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     }
   }
   POS_STAMP(tr, 4);
+  POS_NOTE(tr, 5, (pos_rt0 << 32) | (POS_RT() & 0xffffffffull));
 }
 

@@ -50,6 +50,41 @@ __device__ uint64_t* g_trace_dev;
 #define SA_TRACE_PTR() nullptr
 #endif
 
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// XCD-aware tile order.  Workgroups of a launch go round-robin over the 8 XCDs (workgroup b -> XCD b % 8), each with an L2 of its own:
+// with tiles numbered row by row, every XCD's L2 ends up pulling the WHOLE candidate panel and its share of the track panel out of
+// HBM (C2: 19.9 MB measured for 4.1 MB of operands).  Instead XCD x takes the x-th CONTIGUOUS chunk of a tile numbering that walks
+// the grid in bands of W tile columns (row by row inside a band): its tiles form a compact block of about W x chunk / W tiles that
+// shares W column panels and chunk / W row panels (C2, 16 x 16 tiles, chunk 32, W 4: 8 x 4 tiles = 1.5 MB per XCD instead of 2.25).
+// b in [0, 8 chunk) -> tile number t = (b % 8) chunk + b / 8 (t >= tiles: an idle workgroup); t -> (row, column).
+struct XcdOrder { uint32_t chunk, W; };
+static inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool row_major = false) {
+  XcdOrder o;
+  const uint32_t tiles = gx * gy;
+  if (row_major) { o.chunk = tiles; o.W = 0; return o; }  // SA_FLAG_ROW_MAJOR_TILES (A/B measurements): W = 0 -> workgroup b is tile b, row by row
+  o.chunk = (tiles + 7u) / 8u;
+  uint32_t w = 1;
+  while ((w + 1) * (w + 1) <= o.chunk) ++w;   // ~ sqrt(chunk): square-ish blocks
+  o.W = w < gx ? w : gx;
+  if (o.W == 0) o.W = 1;
+  return o;
+}
+__device__ __forceinline__ bool xcd_tile(uint32_t b, uint32_t gx, uint32_t gy, uint32_t chunk, uint32_t W, uint32_t* bx, uint32_t* by) {
+  if (W == 0) {  // row-major numbering (chunk = tiles)
+    if (b >= gx * gy) return false;
+    *bx = b % gx; *by = b / gx;
+    return true;
+  }
+  const uint32_t t = (b & 7u) * chunk + (b >> 3);
+  if (t >= gx * gy || (b >> 3) >= chunk) return false;
+  const uint32_t band = t / (W * gy), t2 = t - band * W * gy;
+  const uint32_t wb = gx - band * W < W ? gx - band * W : W;
+  *by = t2 / wb;
+  *bx = band * W + t2 % wb;
+  return true;
+}
+
 // Physical float offset of logical 16-byte chunk `kc` (0..7) of row `row` in a [rows][32] f32 LDS tile.
 // XOR with (row>>1)&7: with a 128-B row stride, the 16 rows one ds_read_b128 lane group touches land on
 // 16 distinct 16-B slots of the 256-B bank row (conflict-free); see MI355X_MICROARCH.md §LDS.
@@ -1049,11 +1084,21 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
 // (Tile order: row by row.  An XCD-aware band order — each XCD's L2 keeping one set of candidate panels — was measured at C5 with bands
 // of 1, 2 and 4 tile rows: no difference, the 114 MB working set sits in the 256 MB Infinity Cache and the fabric keeps up.)
 template <int BM, int BN, int KGT, bool PART = false, bool EU = false>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p) {
+__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
+                                                                          uint32_t xo_) {
   constexpr int KG = KGT ? KGT : 1;
   __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  visual_cosine_tile<BM, BN, KGT, false, PART, EU>(S, p, blockIdx.x, blockIdx.y, lds);
+  uint32_t bx, by;  // XCD-aware tile order (xcd_order): a 1-D grid of 8 chunk workgroups per scene
+  if (!xcd_tile(blockIdx.x, gx, gy, xo_ >> 8, xo_ & 255u, &bx, &by)) return;
+  visual_cosine_tile<BM, BN, KGT, false, PART, EU>(S, p, bx, by, lds);
+}
+// (the tiles of the stand-alone contraction in XCD-aware order)
+template <int BM, int BN, int KGT, bool PART, bool EU>
+static void launch_cosine(uint32_t maxTK, uint32_t maxN, uint32_t ns, hipStream_t st, const SceneDev* scenes, const SaParams& p) {
+  const uint32_t gx = cdiv(maxTK, BN), gy = cdiv(maxN, BM);
+  const XcdOrder xo = xcd_order(gx, gy, p.row_major_tiles != 0);
+  SA_LAUNCH((k_visual_cosine<BM, BN, KGT, PART, EU>), dim3(xo.W ? 8u * xo.chunk : xo.chunk, 1, ns), dim3(256 * (KGT ? KGT : 1)), 0, st, scenes, p, gx, gy, (xo.chunk << 8) | xo.W);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1066,7 +1111,7 @@ __global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const S
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
 template <int KG, bool PART, bool EU = false, bool KP = false>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
-                                                           uint32_t px, uint32_t py, uint32_t nprep_) {
+                                                           uint32_t px, uint32_t py, uint32_t nprep_, uint32_t xo_) {
   // nprep_: preparation blocks of the launch; bit 31: they run their RESET half only, bit 30: the positional tiles also feed the
   // many-workgroup tail (row-major edge lists, row duals, union-find: UNION) — frames beyond the one-workgroup tail's 1024 x 1024
   const uint32_t nprep = nprep_ & 0x3fffffffu;
@@ -1079,13 +1124,17 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
   // kinds (one contraction tile every k blocks) was measured: 32-50 us instead of 22.6; the other kinds FIRST (so that the positional tiles of a
   // frame with several rounds of contraction tiles do not queue behind them): C2 16.8 -> 17.5 us, three observations per track 40.9 -> 48.1.
+  // xo_ = XcdOrder: chunk << 8 | W — the contraction's tiles in XCD-aware order (8 chunk workgroup slots, the last few possibly idle)
   uint32_t b = blockIdx.x;
-  if (b < gx * gy) {
-    if constexpr (KP) visual_ktile<EU>(S, p, b % gx, b / gx, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
-    else visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, b % gx, b / gx, lds);
+  const uint32_t xchunk = xo_ >> 8, xW = xo_ & 255u;
+  if (b < (xW ? 8u * xchunk : xchunk)) {
+    uint32_t tbx, tby;
+    if (!xcd_tile(b, gx, gy, xchunk, xW, &tbx, &tby)) return;
+    if constexpr (KP) visual_ktile<EU>(S, p, tbx, tby, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
+    else visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, tbx, tby, lds);
     return;
   }
-  b -= gx * gy;
+  b -= xW ? 8u * xchunk : xchunk;
   // the other two kinds are 256-thread units: a block of KG * 256 threads runs KG of them side by side, each in its own part of the
   // LDS buffer.  Their barriers are the block's; units pair up barrier for barrier (same kind: same count), and a unit that has
   // nothing to do, or none, simply ends — ended waves do not take part in s_barrier.
@@ -1451,7 +1500,6 @@ static void sa_trace_hook(hipStream_t st, uint32_t nb) {
 #else
 static inline void sa_trace_hook(hipStream_t, uint32_t) {}
 #endif
-static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // Tile plans: 0 = 128x128, 5 = 64x128, 6 = 128x64 (4 waves, one k-group), 1/2/4 = 64x64 with 1/2/4 k-groups.
 // The contraction is matrix-core bound once every SIMD holds >= 2 waves, so a CU's time is (tiles it receives) x (tile
@@ -1530,24 +1578,26 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
   if (prep == 1 && cdiv(maxN, 4) > prep_blocks) prep_blocks = cdiv(maxN, 4);
   if (prep == 0) prep_blocks = 0;
-  sa_trace_hook(st, gx * gy + px * py + prep_blocks);
+  const XcdOrder xo = xcd_order(gx, gy, p.row_major_tiles != 0);
+  const uint32_t xo_ = (xo.chunk << 8) | xo.W, n_gemm = xo.W ? 8u * xo.chunk : xo.chunk;
+  sa_trace_hook(st, n_gemm + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
   // per launch, not per block — so only two blocks fit a CU, and even with two positional / preparation units side by side in
   // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
   // against 22.7 (raising the contraction's wave priority changes nothing).
-  const dim3 grid(gx * gy + px * py + prep_blocks, 1, ns);
+  const dim3 grid(n_gemm + px * py + prep_blocks, 1, ns);
   const uint32_t np = prep_blocks | (prep == 3 ? 0x80000000u : 0u) | (general_tail ? 0x40000000u : 0u);
   if (kpass) {
-    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
-    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
     return hipGetLastError();
   }
   if (eu) {
-    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
-    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
-  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
-  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np);
+    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
   return hipGetLastError();
 }
 
@@ -1559,7 +1609,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
     int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
     plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6) ? plan : 1;
-#define SA_EU_LAUNCH(BM_, BN_, PART_) SA_LAUNCH((k_visual_cosine<BM_, BN_, 1, PART_, true>), dim3(cdiv(maxTK, BN_), cdiv(maxN, BM_), ns), dim3(256), 0, st, scenes, p)
+#define SA_EU_LAUNCH(BM_, BN_, PART_) launch_cosine<BM_, BN_, 1, PART_, true>(maxTK, maxN, ns, st, scenes, p)
     switch (plan) {
       case 0: if (partials) SA_EU_LAUNCH(128, 128, true); else SA_EU_LAUNCH(128, 128, false); break;
       case 5: if (partials) SA_EU_LAUNCH(64, 128, true); else SA_EU_LAUNCH(64, 128, false); break;
@@ -1575,23 +1625,23 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {
-        case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-        case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1, true>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-        case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-        case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
-        default: SA_LAUNCH((k_visual_cosine<64, 64, 1, true>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+        case 0: launch_cosine<128, 128, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 5: launch_cosine<64, 128, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 6: launch_cosine<128, 64, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 2: launch_cosine<64, 64, 2, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        default: launch_cosine<64, 64, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
       }
       return hipGetLastError();
     }
     switch (plan) {
-      case 0: SA_LAUNCH((k_visual_cosine<128, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 5: SA_LAUNCH((k_visual_cosine<64, 128, 1>), dim3(cdiv(maxTK, 128), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-      case 7: SA_LAUNCH((k_visual_cosine<64, 64, 0>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
-      case 8: SA_LAUNCH((k_visual_cosine<128, 128, 0>), dim3(cdiv(maxTK, 128), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 6: SA_LAUNCH((k_visual_cosine<128, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 128), ns), dim3(256), 0, st, scenes, p); break;
-      case 4: SA_LAUNCH((k_visual_cosine<64, 64, 4>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(1024), 0, st, scenes, p); break;
-      case 2: SA_LAUNCH((k_visual_cosine<64, 64, 2>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(512), 0, st, scenes, p); break;
-      default: SA_LAUNCH((k_visual_cosine<64, 64, 1>), dim3(cdiv(maxTK, 64), cdiv(maxN, 64), ns), dim3(256), 0, st, scenes, p); break;
+      case 0: launch_cosine<128, 128, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 5: launch_cosine<64, 128, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 7: launch_cosine<64, 64, 0, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 8: launch_cosine<128, 128, 0, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 6: launch_cosine<128, 64, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 4: launch_cosine<64, 64, 4, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 2: launch_cosine<64, 64, 2, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      default: launch_cosine<64, 64, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
     }
   } else {
     SA_LAUNCH(k_visual_euclid, dim3(cdiv(maxTK, EU_BN), cdiv(maxN, EU_BM), ns), dim3(EU_THREADS), 0, st, scenes, p);

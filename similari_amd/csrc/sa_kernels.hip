@@ -970,30 +970,22 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 // atomics while k_assign_solve runs (workgroups on different XCDs), and stats[0] next door is read and written with plain
 // accesses by that kernel's first thread — a line held in one XCD's L2 by plain accesses and updated by other XCDs' atomics is
 // not something to rely on.
-#define SA_QW_TOP 32     // top of the dense solver's row lists
-#define SA_QW_LEN 33     // queue length
-#define SA_QW_TICKET 34  // next ticket
-#define SA_QW_DONE 35    // row workgroups through with their rows
-#define SA_QW_MLEN 36    // the same two for the queue of mid-sized components
-#define SA_QW_MTICKET 37
-// WORDS: the visual vote arrives as vote words (one per candidate and per track, or one per count class of each: SCN_WORDSK) instead of
-// k_bestfit_resolve's verdict arrays; this kernel — the first of the tail, one thread per row AND per column — turns them into those
-// arrays for the solver (row_has / vis_winner for every candidate, col_excluded for every track: all of them written, none needs a
-// reset) exactly the way k_assign_small<.., WORDS> decides: candidate q wins its best column iff that column's word names q; column j
-// is excluded iff the best column of the candidate its word names is j.  One dependent load each.  The words are re-armed by the
-// solver (every reader is in THIS launch).
-template <bool WORDS>
-__global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict__ scenes) {
-  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+// The label step as a device function (k_assign_label: a launch of its own; k_assign_solve with SA_SOLVE_MERGED: its first phase).
+// Thread q handles ROW q (q < N) and the COLUMNS q, q + cstride, ... (< T).
+// words: the visual vote arrives as vote words (one per candidate and per track, or one per count class of each: SCN_WORDSK) instead of
+// k_bestfit_resolve's verdict arrays; they are turned into those arrays here for the solver (row_has / vis_winner for every candidate,
+// col_excluded for every track: all of them written, none needs a reset) exactly the way k_assign_small<.., WORDS> decides: candidate q
+// wins its best column iff that column's word names q; column j is excluded iff the best column of the candidate its word names is j.
+// One dependent load each.  The words are re-armed by the solver, after every reader.
+// s_mk: nthreads / 64 words of LDS (class words: the frame's max_dist is folded by the whole workgroup — every thread of it calls this).
+__device__ __forceinline__ void sa_label_phase(const SceneDev& S, bool words, uint32_t q, uint32_t cstride, uint32_t* s_mk, uint32_t nthreads) {
   bool has_verdict = false;
-  if constexpr (WORDS) {
-    const uint32_t N = S.N, T = S.T, K = S.K;
+  const uint32_t N = S.N, T = S.T, K = S.K;
+  if (words) {
     if (S.flags & SCN_WORDSK) {
       // class words: W = c max_dist - sum decides between a row's (column's) class winners; max_dist from the first phase's per-tile slots
-      __shared__ uint32_t s_mk[4];
       uint32_t mk = 0;
-      for (uint32_t i = threadIdx.x; i < S.nkeys; i += 256) {
+      for (uint32_t i = threadIdx.x; i < S.nkeys; i += nthreads) {
         const uint32_t v = S.vis_max_key[i];
         mk = v > mk ? v : mk;
       }
@@ -1003,9 +995,8 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
       }
       if ((threadIdx.x & 63u) == 0) s_mk[threadIdx.x >> 6] = mk;
       __syncthreads();
-      mk = s_mk[0] > s_mk[1] ? s_mk[0] : s_mk[1];
-      mk = s_mk[2] > mk ? s_mk[2] : mk;
-      mk = s_mk[3] > mk ? s_mk[3] : mk;
+      mk = 0;
+      for (uint32_t w2 = 0; w2 < nthreads / 64u; ++w2) mk = s_mk[w2] > mk ? s_mk[w2] : mk;
       const double max_dist = mk ? (double)sa_key_f32(mk) : -1.0;
       auto best_of = [&](const unsigned long long SA_G* cls, bool in, bool* any) -> uint32_t {
         unsigned long long w[SA_CLS_MAXK];
@@ -1026,39 +1017,42 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
       if (S.tap_row_best) {  // SA_FLAG_TAP: the class words as the first phase left them ([N K] then [T K])
         for (uint32_t c = 0; c < K; ++c) {
           if (q < N) S.tap_row_best[(size_t)q * K + c] = S.row_cls[(size_t)q * K + c];
-          if (q < T) S.tap_col_best[(size_t)q * K + c] = S.col_cls[(size_t)q * K + c];
+          for (uint32_t j = q; j < T; j += cstride) S.tap_col_best[(size_t)j * K + c] = S.col_cls[(size_t)j * K + c];
         }
       }
       const uint32_t bt = best_of(S.row_cls + (size_t)(q < N ? q : 0u) * K, q < N, &has_verdict);
-      const uint32_t cq = best_of(S.col_cls + (size_t)(q < T ? q : 0u) * K, q < T, nullptr);
-      // (second round trip: the column my row prefers, the row my column prefers)
+      // (second round trip: the column my row prefers; below, for my columns: the row each of them prefers)
       const uint32_t bt_cq = best_of(S.col_cls + (size_t)(bt != SA_NONE ? bt : 0u) * K, bt != SA_NONE, nullptr);
-      const uint32_t cq_bt = best_of(S.row_cls + (size_t)(cq != SA_NONE ? cq : 0u) * K, cq != SA_NONE, nullptr);
       if (q < N) {
         S.row_has[q] = has_verdict ? 1 : 0;
         S.vis_winner[q] = (has_verdict && bt_cq == q) ? (int32_t)bt : -1;
       }
-      if (q < T) S.col_excluded[q] = (cq != SA_NONE && cq_bt == q) ? 1 : 0;
+      for (uint32_t j = q; j < T; j += cstride) {
+        const uint32_t cq = best_of(S.col_cls + (size_t)j * K, true, nullptr);
+        const uint32_t cq_bt = best_of(S.row_cls + (size_t)(cq != SA_NONE ? cq : 0u) * K, cq != SA_NONE, nullptr);
+        S.col_excluded[j] = (cq != SA_NONE && cq_bt == j) ? 1 : 0;
+      }
     } else {
       const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
-      const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
-      if (S.tap_row_best) {  // SA_FLAG_TAP: the words as the first phase left them
-        if (q < N) S.tap_row_best[q] = rb;
-        if (q < T) S.tap_col_best[q] = cb;
-      }
+      const unsigned long long cb0 = q < T ? S.col_best[q] : ~0ull;   // (this thread's first column, requested beside the row word)
+      if (S.tap_row_best && q < N) S.tap_row_best[q] = rb;  // SA_FLAG_TAP: the words as the first phase left them
       const uint32_t bt = rb != ~0ull ? (uint32_t)rb : SA_NONE;
-      const uint32_t cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
       has_verdict = bt != SA_NONE;
       const unsigned long long cb_bt = bt != SA_NONE ? S.col_best[bt] : ~0ull;  // (bt < T, cq < N: written by this frame's tiles)
-      const unsigned long long rb_cq = cq != SA_NONE ? S.row_best[cq] : ~0ull;
       if (q < N) {
         S.row_has[q] = has_verdict ? 1 : 0;
         S.vis_winner[q] = (has_verdict && cb_bt != ~0ull && (uint32_t)cb_bt == q) ? (int32_t)bt : -1;
       }
-      if (q < T) S.col_excluded[q] = (cq != SA_NONE && rb_cq != ~0ull && (uint32_t)rb_cq == q) ? 1 : 0;
+      for (uint32_t j = q; j < T; j += cstride) {
+        const unsigned long long cb = j == q ? cb0 : S.col_best[j];
+        if (S.tap_row_best) S.tap_col_best[j] = cb;
+        const uint32_t cq = cb != ~0ull ? (uint32_t)cb : SA_NONE;
+        const unsigned long long rb_cq = cq != SA_NONE ? S.row_best[cq] : ~0ull;
+        S.col_excluded[j] = (cq != SA_NONE && rb_cq != ~0ull && (uint32_t)rb_cq == j) ? 1 : 0;
+      }
     }
   }
-  if (q >= S.N) return;
+  if (q >= N) return;
   // move this row's edge count and dual to the solver's copies and leave the accumulators clean for the next frame
   const uint32_t cnt = S.e_cnt[q];
   S.e_use[q] = cnt;
@@ -1066,12 +1060,19 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
   if (S.tap_ecnt) S.tap_ecnt[q] = cnt;  // SA_FLAG_TAP
   S.u_use[q] = S.u[q];
   S.u[q] = 0;
-  if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the dense solver's: top of its row lists | queue length | next ticket | row workgroups done
-  if (!cnt || (WORDS ? has_verdict : S.row_has[q] != 0)) { S.lab[q] = SA_NONE; return; }
+  if (!cnt || (words ? has_verdict : S.row_has[q] != 0)) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
   atomicAdd((uint32_t*)(S.rnext + root), 1u);  // rows in the component (rnext is zeroed by the preparation blocks)
   S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
+}
+template <bool WORDS>
+__global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict__ scenes) {
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  __shared__ uint32_t s_mk[4];
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  // (the general tail's queue words are zeroed by the frame's preparation blocks, frame_prep_block)
+  sa_label_phase(S, WORDS, q, gridDim.x * blockDim.x, s_mk, 256u);
 }
 
 // Kernel 2 of 2: thread `root` owns the component rooted at row `root`: orders its rows ascending (components are a handful of
@@ -1430,9 +1431,10 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 #define SL_POOL 40
 template <bool VISUAL, int NT, int CPT, bool LDS_STATE>
 __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict__ scenes, uint32_t row_wgs_) {
-  const uint32_t row_wgs = row_wgs_ & 0x3fffffffu;
+  const uint32_t row_wgs = row_wgs_ & 0x0fffffffu;
   const bool no_mid = (row_wgs_ >> 31) != 0;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
   const bool rearm_words = ((row_wgs_ >> 30) & 1u) != 0;  // the frame's visual vote came as vote words: re-armed here
+  const bool merged = ((row_wgs_ >> 29) & 1u) != 0;       // SA_SOLVE_MERGED: the label step is this launch's first phase
   // One lane gathering a component into its pool block is a chain of dependent trips to L2 / memory — the list walk, then every
   // row's count and records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker
   // loop's crowd frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool is not used at
@@ -1449,16 +1451,38 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   extern __shared__ unsigned char s_dyn[];
   if (threadIdx.x == 0) s_pool_top = 0;
   if (threadIdx.x < ML_WAVES) s_nfail[threadIdx.x] = 0;
-  // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
+  // MERGED: the label step (k_assign_label: every row onto its component's list, the vote words into verdicts) as the first phase of
+  // THIS launch, by the row workgroups, which then meet at a barrier of their own — a counter in the scene's queue words — before any
+  // of them reads what the others wrote: one dependent launch (~3 us of floor + the step's own trips to memory, 4.4 us at C4) becomes
+  // a barrier among cdiv(N, NT) workgroups (8 at C4).  What crosses XCDs between the two phases is published by ONE agent-scope release
+  // per workgroup (its L2's dirty lines: this phase's few kilobytes) and picked up behind one acquire (scripts/micro/grid_barrier.hip:
+  // a counter barrier costs 2.3 us at 64 workgroups, 10.7 at 256 — the launcher merges only up to SA_MERGE_MAX_WGS row workgroups, all
+  // of one scene resident together: they are dispatched first).  The helpers behind them wait for SA_QW_DONE as before.
+  if (merged && row_wg) {
+    __shared__ uint32_t s_mk[NT / 64];
+    sa_label_phase(S, VISUAL && rearm_words, q, row_wgs * NT, s_mk, (uint32_t)NT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_LABELLED), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (bounded: ~1 s — row workgroups that could not all be resident would otherwise spin for ever; the launcher rules that out)
+      for (uint32_t spin = 0; __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LABELLED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs && spin < (1u << 23); ++spin)
+        __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  // the forest has done its job (the label step): back to the identity for the next frame's unions
   if (row_wg)
     for (uint32_t i = q; i < S.N + S.T; i += row_wgs * NT) S.parent[i] = i;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
   }
-  if (VISUAL && rearm_words) {
-    // the vote words have been read (k_assign_label<WORDS>, the launch before this one): all ones again for the next frame's tiles
-    const uint32_t g = blockIdx.x * NT + threadIdx.x, stride = gridDim.x * NT;
+  if (VISUAL && rearm_words && (!merged || row_wg)) {
+    // the vote words have been read (the label step: the launch before this one, or — merged — the phase the row workgroups have just
+    // left through their barrier; the helpers, which never wait for it, keep out): all ones again for the next frame's tiles
+    const uint32_t g = blockIdx.x * NT + threadIdx.x, stride = (merged ? row_wgs : gridDim.x) * NT;
     if (S.flags & SCN_WORDSK) {
       for (uint32_t i = g; i < S.N * S.K; i += stride) S.row_cls[i] = ~0ull;
       for (uint32_t i = g; i < S.T * S.K; i += stride) S.col_cls[i] = ~0ull;
@@ -1851,14 +1875,14 @@ static hipError_t launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipS
   return hipSuccess;
 }
 template <int NT, int CPT>
-static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, bool merged, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
   // the row workgroups, and behind them helpers that only take components off the scene's queues (a crowd has dozens of knots, one
   // wavefront of a workgroup each: 64 workgroups per scene left the 1000 x 2500 crowd frame two rounds of them, 30 us; 128: 24 us) —
   // fewer per scene in a wide batch
   const uint32_t rows = cdiv(maxN, NT);
   const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
   const dim3 grid(rows > want ? rows : want, 1, ns);
-  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u);  // (bit 31: no middle tier; bit 30: re-arm the vote words)
+  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u) | (merged ? 0x20000000u : 0u);  // (bit 31: no middle tier; bit 30: vote words; bit 29: the label step rides here)
   if (vis && in_lds) return launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
   if (vis) return launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
   if (in_lds) return launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
@@ -1870,7 +1894,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label<false>, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     case 2: SA_LAUNCH(k_assign_label<true>, dim3(cdiv(maxN > maxT ? maxN : maxT, 256), 1, ns), dim3(256), 0, st, scenes); break;  // (one thread per row AND per column)
-    case 3: case 4: {
+    case 3: case 4: case 6: case 7: {  // (6 / 7 = 3 / 4 with the label step as the launch's first phase: sa_tail_merged_ok)
       // columns per thread of the dense solver by the widest scene; its per-row / per-column state in dynamic LDS when it fits beside
       // the pool of private blocks, else in the scene's HBM arrays
       const bool vis = p.visual_kind != SA_VIS_NONE;
@@ -1878,11 +1902,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const bool in_lds = lds <= 96u * 1024u;
       const bool no_mid = p.positional_kind == SA_POS_MAHALANOBIS;  // gains of 1e8: beyond the middle tier's 32-bit cells
       hipError_t se;
-      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
       if (se != hipSuccess) return se;
       break;
