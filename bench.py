@@ -609,7 +609,8 @@ def main():
         scene_keys = scene_ids_of_rank(total_scenes, world, rank)
         cfg, scenes, desc = workload(wname, seed=1234, scene_ids=scene_keys)
     else:
-        cfg, scenes, desc = workload(wname, seed=1234 + rank, scene_ids=(list(range(total_scenes)) if wname in SCENE_SETS else None))
+        replica_ids = list(range(args.scenes)) if (args.scenes and wname in SCENE_SETS) else None   # (None: the workload's default set)
+        cfg, scenes, desc = workload(wname, seed=1234 + rank, scene_ids=replica_ids)
         scene_keys = list(range(len(scenes))) if scenes else []
     facade = None
     if cfg is None:  # c3m: tracks with Kalman states built by the product itself
@@ -734,7 +735,7 @@ def main():
             everyone = [(sid, sc) for sid, sc in zip(range(total_scenes), workload(wname, seed=1234, scene_ids=list(range(total_scenes)))[1])] if rank == 0 else None
         else:
             gids = [rank + world * s_ for s_ in range(len(scenes))]      # replicas: global scene id = rank + world * local index -> owner = rank
-            everyone = [(r + world * s_, sc) for r in range(world) for s_, sc in enumerate(workload(wname, seed=1234 + r)[1])] if rank == 0 else None
+            everyone = [(r + world * s_, sc) for r in range(world) for s_, sc in enumerate(workload(wname, seed=1234 + r, scene_ids=replica_ids)[1])] if rank == 0 else None
         # capacities: the largest share any rank receives (the set is split evenly up to one scene)
         per_scene_rows = max(len(sc["det_boxes"]) for sc in scenes) if scenes else 1
         n_mine = (total_scenes + world - 1) // world if fixed_set else len(scenes)

@@ -135,7 +135,6 @@ typedef struct sa_config {
 #define SA_FLAG_SEPARATE_RESOLVE 0x400u /* no vote words: per-tile partials + k_bestfit_resolve as a launch of its own */
 #define SA_FLAG_EUCLID_VALU 0x800u      /* euclidean engines: always the vector-pipe kernel (direct sums of squares) */
 #define SA_FLAG_EUCLID_MFMA 0x1000u     /* euclidean engines: always the matrix-core expansion + flagged recompute, also after an ill-conditioned frame */
-#define SA_FLAG_SEPARATE_LABEL 0x8000u  /* the many-workgroup tail as TWO launches (k_assign_label, k_assign_solve) also where the label step could ride in the solver's launch */
 #define SA_FLAG_ROW_MAJOR_TILES 0x4000u /* the contraction's tiles numbered row by row instead of in XCD-aware order (A/B measurements of the HBM traffic) */
 #define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
@@ -238,6 +237,16 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
  * upsert / remove / set_state, a table tap) finishes what is pending — _end then only copies the boxes. */
 int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids);
 int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted);
+/* The same upkeep QUEUED BEHIND the association on the device, no host round trip in between (the tracker facade's path):
+ * sa_batch_run_apply = sa_batch_run of the staged scenes + for every one of them the step sa_tracks_apply would take, with the ids of
+ * the tracks that START drawn on the device the way the reference draws them — from a counter, in candidate order (sort/simple_api.rs:
+ * 165-187): candidate i without a winner gets id_base[slot] + 1 + r, r = its rank among the slot's new tracks (id_per_candidate != 0:
+ * id_base[slot] + 1 + i — Batch* trackers draw one id per candidate, batch_api.rs:102-106).  The caller waits ONCE (sa_batch_sync /
+ * sa_batch_fetch), then sa_tracks_apply_collect(slot) updates the host side of the table and hands out, per candidate, the id it
+ * started a track with (0 where it merged) and the destination track's predicted box.  Either output may be NULL.  A pending slot is
+ * collected by any entry point that needs the finished table.  Synchronous batches only. */
+int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base /* one per staged scene */, int id_per_candidate);
+int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted);
 /* Full per-track state for the device-side upkeep (debug / parity / seeding): Kalman mean[10] + cov[100] row-major, and per
  * bank slot the feature quality[K].  Any of the output pointers may be NULL. */
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality,

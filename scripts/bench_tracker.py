@@ -5,6 +5,9 @@ GPU idle for milliseconds between frames measures the wake-up of an idle queue (
 VisualSORT features three ways: one host array per observation (`rows`: the facade gathers them), one pinned N x D block per frame
 from sa_host_alloc (`pinned`: read in place over the link), one N x D block per frame in device memory registered with
 sa_device_block_register (`device`: the ReID model's output buffer on the same GPU, read where it lies).
+`churn` > 0: that fraction of the objects leaves and as many enter EVERY frame (max_idle_epochs 3): the departed tracks linger in the
+table until they are wasted, so the table holds more rows than the frame has detections — T > 1024 at 1000 objects, a tracker loop's
+normal state (the many-workgroup assignment tail, vote words beyond the one-workgroup tail's 1024 x 1024).
    python scripts/bench_tracker.py [n_objects] [feature_len] [frames]"""
 import ctypes as C
 import json
@@ -25,15 +28,16 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 rng = np.random.default_rng(0)
-ident = synth.reid_identities(rng, n, d)
-world0 = synth.dense_boxes(rng, n, (1920.0, 1080.0))
+pool = n + frames * max(1, n // 20) + 8          # identities: the n of frame 0 + everything a churned loop brings in
+ident = synth.reid_identities(rng, pool, d)
+world0 = synth.dense_boxes(rng, pool, (1920.0, 1080.0))
 
 
 def u2d(b):
     return TR.Universal2DBox(float(b["xc"]), float(b["yc"]), None, float(b["aspect"]), float(b["height"]), float(b["confidence"]))
 
 
-def run(kind, device_upkeep, feats_mode="rows"):
+def run(kind, device_upkeep, feats_mode="rows", churn=0.0):
     if kind == "visual":
         opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.2))
                 .positional_metric(TR.PositionalMetricType.iou(0.3)).visual_minimal_track_length(1).visual_max_observations(3))
@@ -43,6 +47,8 @@ def run(kind, device_upkeep, feats_mode="rows"):
     lib = trk.lib
     world = world0.copy()
     r = np.random.default_rng(1)
+    active = np.arange(n)      # which identity each of the n detections of a frame belongs to
+    fresh = n
     keep, arrs, blocks = [], [], []
     dev = None
     if kind == "visual" and feats_mode == "device":
@@ -50,7 +56,12 @@ def run(kind, device_upkeep, feats_mode="rows"):
         lib.sa_device_block_register(C.c_void_p(dev.data_ptr()), dev.numel() * 4, 0)
     for f in range(frames):
         world = synth.jitter_boxes(r, world, 2.0)
-        feats = synth.observe(r, ident, 0.01)
+        if churn > 0.0 and f > 0:
+            k_out = max(1, int(churn * n))
+            gone = r.choice(n, k_out, replace=False)
+            active[gone] = np.arange(fresh, fresh + k_out)
+            fresh += k_out
+        feats = synth.observe(r, ident[active], 0.01)
         if kind == "visual":
             if feats_mode == "pinned":
                 p = lib.sa_host_alloc(n * d * 4)
@@ -58,9 +69,9 @@ def run(kind, device_upkeep, feats_mode="rows"):
                 blk[...] = feats
                 blocks.append(p)
                 feats = blk
-            items = [TR.VisualSortObservation(feats[k], 0.9, u2d(world[k]), None) for k in range(n)]
+            items = [TR.VisualSortObservation(feats[k], 0.9, u2d(world[active[k]]), None) for k in range(n)]
         else:
-            items = [(u2d(world[k]), None) for k in range(n)]
+            items = [(u2d(world[active[k]]), None) for k in range(n)]
         arr = trk._obs_array(items, keep)
         if dev is not None:
             dev[f].copy_(torch.from_numpy(feats))
@@ -78,17 +89,20 @@ def run(kind, device_upkeep, feats_mode="rows"):
         times.append(time.perf_counter() - t0)
         assert rc == 0, lib.sa_tracker_last_error(trk.h)
     matched = sum(1 for i in range(n) if out[i].length > 1)
+    table_rows = C.c_uint32()
+    lib.sa_tracks_count(lib.sa_tracker_engine(trk.h), 0, C.byref(table_rows))
     trk.close()
     if dev is not None:
         lib.sa_device_block_unregister(C.c_void_p(dev.data_ptr()))
     for p in blocks:
         lib.sa_host_free(p)
-    return 1e3 * float(np.median(times[3:])), matched
+    return 1e3 * float(np.median(times[3:])), matched, int(table_rows.value)
 
 
-for kind, dev, mode in (("sort", False, "rows"), ("sort", True, "rows"), ("visual", False, "rows"), ("visual", True, "rows"),
-                        ("visual", True, "pinned"), ("visual", True, "device")):
-    ms, matched = run(kind, dev, mode)
+for kind, dev, mode, churn in (("sort", False, "rows", 0.0), ("sort", True, "rows", 0.0), ("visual", False, "rows", 0.0), ("visual", True, "rows", 0.0),
+                               ("visual", True, "pinned", 0.0), ("visual", True, "device", 0.0),
+                               ("sort", True, "rows", 0.05), ("visual", True, "pinned", 0.05), ("visual", True, "device", 0.05)):
+    ms, matched, rows = run(kind, dev, mode, churn)
     print(json.dumps({"tracker": kind, "objects": n, "feature_len": d if kind == "visual" else 0, "upkeep": "device" if dev else "host",
-                      "features": mode if kind == "visual" else None, "ms_per_frame_median": round(ms, 3),
-                      "tracks_continued_last_frame": matched}), flush=True)
+                      "features": mode if kind == "visual" else None, "churn_per_frame": churn, "ms_per_frame_median": round(ms, 3),
+                      "tracks_continued_last_frame": matched, "table_rows_last_frame": rows}), flush=True)

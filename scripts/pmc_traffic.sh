@@ -7,7 +7,7 @@ W=${1:-c2}; TAG=${2:-r01}
 OUT=$PWD/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o p -- \
-     python $OLDPWD/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-oracle --profile-iters 5 > $OUT/$C.log 2>&1)
+     python $OLDPWD/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-oracle --no-h2d --profile-iters 5 ${SA_BENCH_FLAGS:+--flags $SA_BENCH_FLAGS} > $OUT/$C.log 2>&1)
 done
 python - "$OUT" "$W" <<'PY'
 import csv, glob, json, sys, collections

@@ -44,7 +44,6 @@ SA_FLAG_EUCLID_VALU = 0x800
 SA_FLAG_EUCLID_MFMA = 0x1000
 SA_FLAG_BESTFIT_TILE = 0x2000
 SA_FLAG_ROW_MAJOR_TILES = 0x4000
-SA_FLAG_SEPARATE_LABEL = 0x8000
 
 # Path switches OR-ed into every config make_config builds (tests: the `sa_path` fixture of tests/conftest.py sends whole parity tests
 # through the engine's other paths in the same process) and a tile-plan override for the same purpose.
@@ -392,6 +391,8 @@ PROTOTYPES = {
     "sa_tracks_apply": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
     "sa_tracks_apply_begin": (C.c_int, [ENGINE, u32, P(u64)]),
     "sa_tracks_apply_end": (C.c_int, [ENGINE, u32, P(sa_box)]),
+    "sa_batch_run_apply": (C.c_int, [ENGINE, P(u64), C.c_int]),
+    "sa_tracks_apply_collect": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_nms": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float), C.c_float, C.c_float, P(u32), P(u32)]),

@@ -143,15 +143,13 @@ struct SceneDev {
 // The general tail's queue words live on their own 128-byte line of the scene's stats block: they are touched ONLY by agent-scope atomics
 // while k_assign_solve runs (workgroups on different XCDs), and stats[0] next door is read and written with plain accesses by that
 // kernel's first thread — a line held in one XCD's L2 by plain accesses and updated by other XCDs' atomics is not something to rely on.
-// All zero when the tail starts: the frame's preparation blocks (frame_prep_block) reset them.
+// Zeroed by k_assign_label's first thread.
 #define SA_QW_TOP 32       // top of the dense solver's row lists
 #define SA_QW_LEN 33       // queue length
 #define SA_QW_TICKET 34    // next ticket
 #define SA_QW_DONE 35      // row workgroups through with their rows
 #define SA_QW_MLEN 36      // the same two for the queue of mid-sized components
 #define SA_QW_MTICKET 37
-#define SA_QW_LABELLED 38  // merged tail: row workgroups through with the label phase (their barrier)
-#define SA_MERGE_MAX_WGS 64u  // the label step rides in k_assign_solve up to this many row workgroups of 256 rows (N <= 16384)
 #define SCN_HAS_FEATS 1u
 #define SCN_HAS_QUALITY 2u
 #define SCN_HAS_OWN 4u
@@ -257,13 +255,11 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
 // stage 1 label + push, 3 solve + results (2 / 4: the same with the visual vote read from the vote words — the label kernel turns
-// them into verdicts, the solver re-arms them); 6 / 7 = 3 / 4 with the label step as the first phase of the SAME launch (frames of at
-// most SA_MERGE_MAX_WGS x 256 candidates, sa_tail_merged_ok); stage 5 = the whole tail in ONE workgroup per scene (requires maxN, maxT <= SA_SMALL_N;
+// them into verdicts, the solver re-arms them); stage 5 = the whole tail in ONE workgroup per scene (requires maxN, maxT <= SA_SMALL_N;
 // 8: with vote words)
 #define SA_SMALL_N 1024
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                             const SaParams& p, hipStream_t st, int stage);
-inline bool sa_tail_merged_ok(uint32_t maxN, uint32_t maxT) { return maxN <= SA_MERGE_MAX_WGS * 256u && maxT <= 256u * 32u; }  // (NT = 256 variants)
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                hipStream_t st);
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).
@@ -306,6 +302,9 @@ struct BankArgs {
   float minimal_area, q_collect, own_collect;
 };
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st);
+// rows and ids of the tracks that start this frame, drawn on the device from the winners (k_apply_ids); *n_new_out = how many
+hipError_t sa_launch_apply_ids(const int32_t* win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate, uint32_t* new_row, uint64_t* new_ids,
+                               uint32_t* n_new_out, hipStream_t st);
 // oriented boxes after sa_launch_apply: the host's libm cos / sin of a refreshed row's angle -> its polygon
 struct SaPolyFix {
   uint32_t row, pad;

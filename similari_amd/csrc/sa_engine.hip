@@ -79,6 +79,10 @@ struct Slot {  // one scene of a request set
   void* d_out = nullptr;  // device view of h_out
   uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
+  bool fused_pending = false;  // sa_batch_run_apply has queued the upkeep of this slot behind its association; sa_tracks_apply_collect finishes the host side
+  uint64_t fused_id_base = 0;  // ... ids of the tracks that start: fused_id_base + 1 + (per candidate ? candidate index : rank among the new ones)
+  int fused_per_candidate = 0;
+  uint32_t fused_T0 = 0;       // rows of the scene's table when the upkeep was queued
   bool apply_pending = false;  // sa_tracks_apply_begin has queued the upkeep of this slot; sa_tracks_apply_end (or the next entry point that needs the table) finishes it
   bool prepped = true;     // the frame-preparation blocks ran with the frame (false: a lean frame left them out; ensure_prepped runs them on demand)
   bool needs_init = true;  // e_cnt / u / parent were (re)allocated, or a run may have died half-way: k_slot_init before the next frame
@@ -108,6 +112,7 @@ struct Bank {
   bool frame_with_prep = true;          // what enqueue_frame decided for this set's launches: the preparation blocks ride in the first phase
                                         // (a replayed graph runs no host code of enqueue_frame: bank_launch re-applies it to the slots)
   bool frame_small_tail = false;        // the set's last launches went through the one-workgroup tail (slot-major edge lists, vote words)
+  bool want_prep = false;               // the upkeep follows on the stream (sa_batch_run_apply): its feature-bank step reads what the preparation blocks write
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -268,7 +273,9 @@ hipEvent_t prof_event(sa_engine* e) {
     return ev;
   }
   hipEvent_t ev = nullptr;
-  hipEventCreate(&ev);
+  // device-scope release: a dispatch that carries a default event ends with a SYSTEM-scope release the same kernel inside the plain
+  // pipeline does not pay (~1.5 us on the fused first phase) — the instrumented duration should be the pipeline's, the one rocprofv3 reads
+  if (hipEventCreateWithFlags(&ev, hipEventReleaseToDevice) != hipSuccess) { (void)hipGetLastError(); hipEventCreate(&ev); }
   return ev;
 }
 struct ProfScope {
@@ -628,7 +635,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // lives in LDS): prep 0; the many-workgroup tail keeps it: prep 3 (a dozen blocks instead of N / 4).  SA_FLAG_NEVER_LEAN: never lean.
   const bool never_lean = (e->cfg.flags & SA_FLAG_NEVER_LEAN) != 0;
   const bool lean_ok = !never_lean && (!e->visual || words);
-  int prep = lean_ok ? (small_tail ? 0 : 3) : 1;
+  int prep = (lean_ok && !(b->want_prep && e->visual)) ? (small_tail ? 0 : 3) : 1;
   bool fused = false;
   bool all_feats = e->visual;
   for (uint32_t i = 0; i < ns; ++i) all_feats = all_feats && b->slots[i]->has_feats;
@@ -658,13 +665,14 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     if (attach) sa_done_event = done;
     le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
   } else {
-    // (with vote words the label step also turns them into the verdicts the solver honours, and the solver re-arms them).  Up to
-    // SA_MERGE_MAX_WGS x 256 candidates the label step is the first phase of the solver's launch (SA_FLAG_SEPARATE_LABEL: never)
-    const bool merged = sa_tail_merged_ok(maxN, maxT) && !(e->cfg.flags & SA_FLAG_SEPARATE_LABEL);
-    if (!merged) { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 2 : 1)); }
+    // (with vote words the label kernel also turns them into the verdicts the solver honours, and the solver re-arms them).
+    // Measured and dropped (round 4): the label step as the FIRST PHASE of the solver's launch, its row workgroups meeting at a counter
+    // barrier behind one agent-scope release / acquire each — one launch less, but the barrier and its cache maintenance cost what the
+    // launch did: C4 k_assign_solve 5.5 -> 8.75 us, frame 21.8 -> 22.0; 1000 x 1500 VisualSORT 36.2 -> 36.6; C5 solve 6.0 -> 12.8.
+    { ProfScope ps(e, KID_ASSIGN_LABEL); HIPCHK(e, sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 2 : 1)); }
     ProfScope ps(e, KID_ASSIGN_SOLVE);
     if (attach) sa_done_event = done;
-    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, merged ? (words ? 7 : 6) : (words ? 4 : 3));
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 4 : 3);
   }
   if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
   sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
@@ -1544,8 +1552,45 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
 // boxes and queues the polygon fix-up of oriented boxes.  Between the two the host is free (the tracker facade does its own
 // bookkeeping there); whatever needs the finished table first — the next request set, an upsert, a tap — finishes a pending one.
 static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted);
+static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted);
 static int finish_applies(sa_engine* e) {
   while (!e->applying.empty()) TRY(apply_finish(e, e->applying.back(), nullptr));
+  for (Bank& bk : e->banks)
+    for (uint32_t i = 0; i < bk.n_slots; ++i)
+      if (bk.slots[i]->fused_pending) TRY(fused_collect(e, bk.slots[i], nullptr, nullptr));
+  return SA_OK;
+}
+// Queues the upkeep kernels of slot `s` (Kalman step + table rows, feature-bank policy) on the compute stream.  new_row / new_ids: device-visible
+// arrays — table row and id of every candidate that starts a track (SA_NONE / 0 elsewhere).
+static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids) {
+  SceneTable* sc = s->scene;
+  const uint32_t n = s->N, K = e->K;
+  {
+    void* before = s->h_pred.p;
+    TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
+    if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
+  }
+  hipStream_t st = e->stream;
+  ApplyArgs a{};
+  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = new_row;
+  a.new_ids = new_ids; a.n = n; a.epoch = s->epoch;
+  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
+  a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
+  BankArgs b{};
+  if (e->visual) {
+    TRY(dev_ensure(e, s->bank_tmp, (size_t)n * K * e->Dp * 4));
+    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.n = n; b.K = K; b.Dp = e->Dp;
+    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
+    b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
+    b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
+    b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
+    b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
+    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p; b.tmp = (float*)s->bank_tmp.p;
+    b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
+    b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
+  }
+  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
+  e->synced = false;
   return SA_OK;
 }
 int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) {
@@ -1607,32 +1652,7 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
     h_row[i] = winners[i] == 0 ? next++ : SA_NONE;
     h_ids[i] = winners[i] == 0 ? new_ids[i] : 0;
   }
-  {
-    void* before = s->h_pred.p;
-    TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
-    if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
-  }
-  hipStream_t st = e->stream;
-  ApplyArgs a{};
-  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = (const uint32_t*)s->d_apply;
-  a.new_ids = (const uint64_t*)((const uint8_t*)s->d_apply + ids_off); a.n = n; a.epoch = s->epoch;
-  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
-  a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
-  BankArgs b{};
-  if (e->visual) {
-    TRY(dev_ensure(e, s->bank_tmp, (size_t)n * K * e->Dp * 4));
-    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.n = n; b.K = K; b.Dp = e->Dp;
-    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
-    b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
-    b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
-    b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
-    b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
-    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p; b.tmp = (float*)s->bank_tmp.p;
-    b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
-    b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
-  }
-  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
-  e->synced = false;
+  TRY(apply_launch(e, s, (const uint32_t*)s->d_apply, (const uint64_t*)((const uint8_t*)s->d_apply + ids_off)));
   // host side of the table: the new rows
   for (uint32_t i = 0; i < n; ++i)
     if (winners[i] == 0) {
@@ -1646,6 +1666,38 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
   e->applying.push_back(s);
   return SA_OK;
 }
+// Oriented boxes: the polygon of a refreshed row needs cos / sin of the predicted angle from THIS side's libm (fill_raw does the same for
+// every box that is uploaded; the device's sincos is not bit-identical to it).  The predicted boxes are on the host (h_pred), the rows of
+// the tracks that started in h_apply; (row, box, cos, sin) go back through mapped memory to a kernel queued behind the step — no wait:
+// whatever reads the table next is ordered behind it on the stream.
+static int polygon_fixups(sa_engine* e, Slot* s) {
+  SceneTable* sc = s->scene;
+  const uint32_t n = s->N;
+  const uint64_t* winners = (const uint64_t*)s->h_out.p;
+  const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
+  const uint32_t* h_row = (const uint32_t*)s->h_apply.p;
+  const sa_box* pb = (const sa_box*)s->h_pred.p;
+  uint32_t nfix = 0;
+  for (uint32_t i = 0; i < n; ++i) nfix += (pb[i].has_angle && pb[i].angle != 0.0f) ? 1u : 0u;
+  if (!nfix) return SA_OK;
+  void* before = s->h_fix.p;
+  TRY(host_ensure(e, s->h_fix, (size_t)nfix * sizeof(SaPolyFix)));
+  if (s->h_fix.p != before || !s->d_fix) HIPCHK(e, hipHostGetDevicePointer(&s->d_fix, s->h_fix.p, 0));
+  SaPolyFix* fx = (SaPolyFix*)s->h_fix.p;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!(pb[i].has_angle && pb[i].angle != 0.0f)) continue;
+    const double ang = (double)pb[i].angle;
+    fx[k].row = winners[i] == 0 ? h_row[i] : (uint32_t)wcol[i];
+    fx[k].pad = 0;
+    fx[k].xc = pb[i].xc; fx[k].yc = pb[i].yc; fx[k].aspect = pb[i].aspect; fx[k].height = pb[i].height;
+    ::sincos(ang, &fx[k].s, &fx[k].c);  // as fill_raw
+    ++k;
+  }
+  HIPCHK(e, sa_launch_apply_polygons((const SaPolyFix*)s->d_fix, nfix, (double*)sc->verts.p, e->stream));
+  e->synced = false;
+  return SA_OK;
+}
 static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
   HIPCHK(e, hipSetDevice(e->device));
   for (size_t k = 0; k < e->applying.size(); ++k)
@@ -1653,41 +1705,57 @@ static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
   s->apply_pending = false;
   if (e->B_ticket) TRY(compute_sync(e));  // pipelined: leave the copy stream (the next set's ingest) alone
   else TRY(engine_sync(e));
+  if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)s->N * sizeof(sa_box));
+  return polygon_fixups(e, s);
+}
+
+// ---- the upkeep QUEUED BEHIND the association (sa_batch_run_apply / sa_tracks_apply_collect) ----------------------------
+// sa_tracks_apply needs the winners on the host before it can queue the upkeep: wait for the frame, fetch, validate, draw ids, launch —
+// the GPU idles through a host round trip and the caller waits twice.  When the ids of the tracks that start are a function of the
+// winners alone — the reference draws them from a counter in candidate order (sort/simple_api.rs:165-187; Batch*: one per candidate,
+// batch_api.rs:102-106) — the device can draw them itself: k_apply_ids turns the winners into (row, id) of every new track and the
+// Kalman / feature-bank kernels run right behind the assignment tail on the same stream.  The host learns everything in ONE wait and
+// replays the (trivial) id arithmetic for its own copy of the table.
+static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
+  HIPCHK(e, hipSetDevice(e->device));
+  s->fused_pending = false;
+  TRY(engine_sync(e));
   SceneTable* sc = s->scene;
-  const uint32_t n = s->N;
-  hipStream_t st = e->stream;
+  const uint32_t n = s->N, T0 = s->fused_T0;
+  if (!n) return SA_OK;
   const uint64_t* winners = (const uint64_t*)s->h_out.p;
   const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
-  const uint32_t* h_row = (const uint32_t*)s->h_apply.p;
-  if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
-  {
-    // Oriented boxes: the polygon of a refreshed row needs cos / sin of the predicted angle from THIS side's libm (fill_raw does the
-    // same for every box that is uploaded; the device's sincos is not bit-identical to it).  The predicted boxes are here already;
-    // (row, box, cos, sin) go back through mapped memory to a kernel queued behind the step — no wait: whatever reads the table
-    // next is ordered behind it on the stream.
-    const sa_box* pb = (const sa_box*)s->h_pred.p;
-    uint32_t nfix = 0;
-    for (uint32_t i = 0; i < n; ++i) nfix += (pb[i].has_angle && pb[i].angle != 0.0f) ? 1u : 0u;
-    if (nfix) {
-      void* before = s->h_fix.p;
-      TRY(host_ensure(e, s->h_fix, (size_t)nfix * sizeof(SaPolyFix)));
-      if (s->h_fix.p != before || !s->d_fix) HIPCHK(e, hipHostGetDevicePointer(&s->d_fix, s->h_fix.p, 0));
-      SaPolyFix* fx = (SaPolyFix*)s->h_fix.p;
-      uint32_t k = 0;
-      for (uint32_t i = 0; i < n; ++i) {
-        if (!(pb[i].has_angle && pb[i].angle != 0.0f)) continue;
-        const double ang = (double)pb[i].angle;
-        fx[k].row = winners[i] == 0 ? h_row[i] : (uint32_t)wcol[i];
-        fx[k].pad = 0;
-        fx[k].xc = pb[i].xc; fx[k].yc = pb[i].yc; fx[k].aspect = pb[i].aspect; fx[k].height = pb[i].height;
-        ::sincos(ang, &fx[k].s, &fx[k].c);  // as fill_raw
-        ++k;
-      }
-      HIPCHK(e, sa_launch_apply_polygons((const SaPolyFix*)s->d_fix, nfix, (double*)sc->verts.p, st));
-      e->synced = false;
+  if (sc->T != T0) return fail(e, SA_ERR_STATE, "the scene's track table changed while its upkeep was queued");
+  TRY(host_ensure(e, s->h_apply, (size_t)n * 4));
+  uint32_t* h_row = (uint32_t*)s->h_apply.p;
+  sc->full.resize(T0, 0);
+  uint32_t r = 0;
+  int bad = SA_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (winners[i] == 0) {
+      const uint64_t id = s->fused_id_base + 1ull + (s->fused_per_candidate ? (uint64_t)i : (uint64_t)r);
+      h_row[i] = T0 + r;
+      ++r;
+      if (sc->slot_of.count(id)) bad = fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)id);
+      sc->slot_of[id] = (uint32_t)sc->ids.size();
+      sc->ids.push_back(id);
+      if (out_ids) out_ids[i] = id;
+    } else {
+      h_row[i] = SA_NONE;
+      const int32_t c = wcol[i];
+      if (c < 0 || (uint32_t)c >= T0 || sc->ids[c] != winners[i]) bad = fail(e, SA_ERR_STATE, "winner %llu is not in the table", (unsigned long long)winners[i]);
+      else if (!sc->full[c])
+        bad = fail(e, SA_ERR_STATE, "track %llu was upserted without a Kalman state: device-side upkeep needs tracks created by "
+                   "sa_tracks_apply or seeded with sa_tracks_set_state", (unsigned long long)winners[i]);
+      if (out_ids) out_ids[i] = 0;
     }
   }
-  return SA_OK;
+  sc->T = T0 + r;
+  sc->full.resize(sc->T, 1);
+  s->ran = false;  // the table the slot ran against is gone
+  if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
+  if (bad != SA_OK) return bad;
+  return polygon_fixups(e, s);
 }
 
 int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted) {
@@ -1707,6 +1775,52 @@ int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted) {
 int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box* out_predicted) {
   TRY(sa_tracks_apply_begin(e, slot, new_ids));
   return sa_tracks_apply_end(e, slot, out_predicted);
+}
+
+int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candidate) {
+  if (!e || !id_base) return fail(e, SA_ERR_BAD_ARG, "sa_batch_run_apply: null argument");
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(finish_applies(e));
+  if (e->B_ticket) return fail(e, SA_ERR_STATE, "sa_batch_run_apply works on a synchronous batch (sa_batch_begin / sa_batch_add), not on a waited ticket");
+  Bank* b = e->B;
+  // every scene's table with room for as many new tracks as it has candidates — BEFORE the descriptors are built (a table that grows moves)
+  for (uint32_t i = 0; i < b->n_slots; ++i) {
+    Slot* s = b->slots[i];
+    SceneTable* sc = s->scene;
+    sc->full.resize(sc->T, 0);
+    TRY(scene_reserve(e, sc, sc->T + s->N));
+  }
+  b->want_prep = true;   // the feature-bank step reads the candidates' padded rows and norms: the preparation blocks ride in this frame
+  int rc = run_pipeline(e);
+  b->want_prep = false;
+  if (rc != SA_OK) return rc;
+  for (uint32_t i = 0; i < b->n_slots; ++i) {
+    Slot* s = b->slots[i];
+    const uint32_t n = s->N;
+    if (!n) continue;
+    TRY(dev_ensure(e, s->new_row, (size_t)n * 4 + 16));   // rows[n] | the count of new tracks
+    TRY(dev_ensure(e, s->new_ids, (size_t)n * 8));
+    s->fused_T0 = s->scene->T;
+    s->fused_id_base = id_base[i];
+    s->fused_per_candidate = id_per_candidate ? 1 : 0;
+    HIPCHK(e, sa_launch_apply_ids((const int32_t*)s->win_col.p, n, s->fused_T0, s->fused_id_base, s->fused_per_candidate, (uint32_t*)s->new_row.p,
+                                  (uint64_t*)s->new_ids.p, (uint32_t*)s->new_row.p + n, e->stream));
+    TRY(apply_launch(e, s, (const uint32_t*)s->new_row.p, (const uint64_t*)s->new_ids.p));
+    s->fused_pending = true;
+  }
+  return SA_OK;
+}
+
+int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_tracks_apply_collect"));
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!s->fused_pending) {
+    if (!s->N) return SA_OK;
+    return fail(e, SA_ERR_STATE, "sa_tracks_apply_collect without sa_batch_run_apply (or collected already)");
+  }
+  return fused_collect(e, s, out_new_ids, out_predicted);
 }
 
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality, uint8_t* present,

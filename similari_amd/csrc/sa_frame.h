@@ -61,7 +61,6 @@ __device__ __forceinline__ void pad_feature_row(const float* s, float* d, uint32
 __device__ __forceinline__ void frame_prep_block(const SceneDev& S, const SaParams& p, uint32_t blk, uint32_t tid, bool light = false) {
   const uint32_t N = S.N, T = S.T;
   const uint32_t i = blk * 256 + tid;
-  if (i >= SA_QW_TOP && i <= SA_QW_LABELLED) S.stats[i] = 0u;  // the general tail's queue words (block 0 always exists: N + T + 1 threads)
   if (i < T) {
     S.col_excluded[i] = 0;
     S.v[i] = 0;

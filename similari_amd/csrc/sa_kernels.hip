@@ -970,7 +970,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
 // atomics while k_assign_solve runs (workgroups on different XCDs), and stats[0] next door is read and written with plain
 // accesses by that kernel's first thread — a line held in one XCD's L2 by plain accesses and updated by other XCDs' atomics is
 // not something to rely on.
-// The label step as a device function (k_assign_label: a launch of its own; k_assign_solve with SA_SOLVE_MERGED: its first phase).
+// The label step (k_assign_label's body).
 // Thread q handles ROW q (q < N) and the COLUMNS q, q + cstride, ... (< T).
 // words: the visual vote arrives as vote words (one per candidate and per track, or one per count class of each: SCN_WORDSK) instead of
 // k_bestfit_resolve's verdict arrays; they are turned into those arrays here for the solver (row_has / vis_winner for every candidate,
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ uint32_t s_mk[4];
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  // (the general tail's queue words are zeroed by the frame's preparation blocks, frame_prep_block)
+  if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the solver's queues: top of its row lists | queue length | next ticket | row workgroups done
   sa_label_phase(S, WORDS, q, gridDim.x * blockDim.x, s_mk, 256u);
 }
 
@@ -1434,7 +1434,6 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   const uint32_t row_wgs = row_wgs_ & 0x0fffffffu;
   const bool no_mid = (row_wgs_ >> 31) != 0;  // (Mahalanobis gains are beyond the middle tier's 32-bit cells)
   const bool rearm_words = ((row_wgs_ >> 30) & 1u) != 0;  // the frame's visual vote came as vote words: re-armed here
-  const bool merged = ((row_wgs_ >> 29) & 1u) != 0;       // SA_SOLVE_MERGED: the label step is this launch's first phase
   // One lane gathering a component into its pool block is a chain of dependent trips to L2 / memory — the list walk, then every
   // row's count and records: ~12 us for two rows, ~60 us for eight, and the launch lasts as long as its slowest lane (a tracker
   // loop's crowd frame: 65 us before the last row workgroup was through).  With the middle tier behind it the pool is not used at
@@ -1451,38 +1450,16 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   extern __shared__ unsigned char s_dyn[];
   if (threadIdx.x == 0) s_pool_top = 0;
   if (threadIdx.x < ML_WAVES) s_nfail[threadIdx.x] = 0;
-  // MERGED: the label step (k_assign_label: every row onto its component's list, the vote words into verdicts) as the first phase of
-  // THIS launch, by the row workgroups, which then meet at a barrier of their own — a counter in the scene's queue words — before any
-  // of them reads what the others wrote: one dependent launch (~3 us of floor + the step's own trips to memory, 4.4 us at C4) becomes
-  // a barrier among cdiv(N, NT) workgroups (8 at C4).  What crosses XCDs between the two phases is published by ONE agent-scope release
-  // per workgroup (its L2's dirty lines: this phase's few kilobytes) and picked up behind one acquire (scripts/micro/grid_barrier.hip:
-  // a counter barrier costs 2.3 us at 64 workgroups, 10.7 at 256 — the launcher merges only up to SA_MERGE_MAX_WGS row workgroups, all
-  // of one scene resident together: they are dispatched first).  The helpers behind them wait for SA_QW_DONE as before.
-  if (merged && row_wg) {
-    __shared__ uint32_t s_mk[NT / 64];
-    sa_label_phase(S, VISUAL && rearm_words, q, row_wgs * NT, s_mk, (uint32_t)NT);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_LABELLED), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // (bounded: ~1 s — row workgroups that could not all be resident would otherwise spin for ever; the launcher rules that out)
-      for (uint32_t spin = 0; __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LABELLED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs && spin < (1u << 23); ++spin)
-        __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-  }
-  // the forest has done its job (the label step): back to the identity for the next frame's unions
+  // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
   if (row_wg)
     for (uint32_t i = q; i < S.N + S.T; i += row_wgs * NT) S.parent[i] = i;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
     S.stats[0] = 0u;
   }
-  if (VISUAL && rearm_words && (!merged || row_wg)) {
-    // the vote words have been read (the label step: the launch before this one, or — merged — the phase the row workgroups have just
-    // left through their barrier; the helpers, which never wait for it, keep out): all ones again for the next frame's tiles
-    const uint32_t g = blockIdx.x * NT + threadIdx.x, stride = (merged ? row_wgs : gridDim.x) * NT;
+  if (VISUAL && rearm_words) {
+    // the vote words have been read (k_assign_label<WORDS>, the launch before this one): all ones again for the next frame's tiles
+    const uint32_t g = blockIdx.x * NT + threadIdx.x, stride = gridDim.x * NT;
     if (S.flags & SCN_WORDSK) {
       for (uint32_t i = g; i < S.N * S.K; i += stride) S.row_cls[i] = ~0ull;
       for (uint32_t i = g; i < S.T * S.K; i += stride) S.col_cls[i] = ~0ull;
@@ -1875,14 +1852,14 @@ static hipError_t launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipS
   return hipSuccess;
 }
 template <int NT, int CPT>
-static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, bool merged, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
+static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, uint32_t maxN, uint32_t ns, size_t lds, hipStream_t st, const SceneDev* scenes) {
   // the row workgroups, and behind them helpers that only take components off the scene's queues (a crowd has dozens of knots, one
   // wavefront of a workgroup each: 64 workgroups per scene left the 1000 x 2500 crowd frame two rounds of them, 30 us; 128: 24 us) —
   // fewer per scene in a wide batch
   const uint32_t rows = cdiv(maxN, NT);
   const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
   const dim3 grid(rows > want ? rows : want, 1, ns);
-  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u) | (merged ? 0x20000000u : 0u);  // (bit 31: no middle tier; bit 30: vote words; bit 29: the label step rides here)
+  const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u);  // (bit 31: no middle tier; bit 30: re-arm the vote words)
   if (vis && in_lds) return launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
   if (vis) return launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
   if (in_lds) return launch_solve_one<false, NT, CPT, true>(grid, rw, lds, st, scenes);
@@ -1894,7 +1871,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label<false>, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
     case 2: SA_LAUNCH(k_assign_label<true>, dim3(cdiv(maxN > maxT ? maxN : maxT, 256), 1, ns), dim3(256), 0, st, scenes); break;  // (one thread per row AND per column)
-    case 3: case 4: case 6: case 7: {  // (6 / 7 = 3 / 4 with the label step as the launch's first phase: sa_tail_merged_ok)
+    case 3: case 4: {
       // columns per thread of the dense solver by the widest scene; its per-row / per-column state in dynamic LDS when it fits beside
       // the pool of private blocks, else in the scene's HBM arrays
       const bool vis = p.visual_kind != SA_VIS_NONE;
@@ -1902,11 +1879,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       const bool in_lds = lds <= 96u * 1024u;
       const bool no_mid = p.positional_kind == SA_POS_MAHALANOBIS;  // gains of 1e8: beyond the middle tier's 32-bit cells
       hipError_t se;
-      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
-      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
-      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, stage == 4 || stage == 7, stage >= 6, maxN, ns, lds, st, scenes);
+      if (maxT <= 256u * 4u) se = launch_solve<256, 4>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 8u) se = launch_solve<256, 8>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 16u) se = launch_solve<256, 16>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 256u * 32u) se = launch_solve<256, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
+      else if (maxT <= 1024u * 32u) se = launch_solve<1024, 32>(vis, in_lds, no_mid, stage == 4, maxN, ns, lds, st, scenes);
       else return hipErrorInvalidValue;  // more than 32768 tracks in one scene (refused earlier, in bank_prepare)
       if (se != hipSuccess) return se;
       break;

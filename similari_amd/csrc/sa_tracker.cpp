@@ -342,6 +342,17 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     rc = contiguous[s] ? sa_batch_add(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, nullptr)
                        : sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? cfeat[s].data() : nullptr, nullptr);
   const auto t_added = clk::now();
+  // Device upkeep: the Kalman step, the table refresh and the feature-bank policy of every scene are queued right BEHIND the association
+  // on the device (sa_batch_run_apply) — the ids of the tracks that start are a function of the winners alone (a counter, in candidate
+  // order), so the device draws them itself and this thread waits once, for everything.  (Several scenes under Sort / VisualSort id
+  // rules — one id per NEW track across scenes — would make a scene's first id depend on the previous scenes' winners: two phases then.)
+  const bool fused = o.device_upkeep && (o.batch_ids || n_scenes == 1);
+  if (rc == SA_OK && fused) {
+    std::vector<uint64_t> id_base(n_scenes);
+    uint64_t next = t->track_id;
+    for (uint32_t s = 0; s < n_scenes; ++s) { id_base[s] = next; next += counts[s]; }   // (batch ids: one per candidate; a single scene: its own counter)
+    rc = sa_batch_run_apply(t->eng, id_base.data(), o.batch_ids ? 1 : 0);
+  } else
   if (rc == SA_OK) rc = sa_batch_run(t->eng);
   const auto t_run = clk::now();
   if (rc == SA_OK) rc = sa_batch_sync(t->eng);
@@ -370,7 +381,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       if (dest == 0) { tids[s][i] = o.batch_ids ? drawn : ++t->track_id; new_ids[s][i] = tids[s][i]; }
       else tids[s][i] = dest;
     }
-    if (o.device_upkeep) {
+    if (o.device_upkeep && !fused) {
       const auto ta = clk::now();
       rc = sa_tracks_apply_begin(t->eng, s, new_ids[s].data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
@@ -451,7 +462,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       const uint32_t n = counts[s];
       dev_pred[s].resize(n);
       const auto ta = clk::now();
-      rc = sa_tracks_apply_end(t->eng, s, dev_pred[s].data());
+      rc = fused ? sa_tracks_apply_collect(t->eng, s, nullptr, dev_pred[s].data()) : sa_tracks_apply_end(t->eng, s, dev_pred[s].data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
       for (uint32_t i = 0; i < n; ++i) {

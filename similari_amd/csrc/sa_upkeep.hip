@@ -149,6 +149,46 @@ __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
   if (tid == 0) a.t_fcount[row] = count;
 }
 
+// Where the tracks that START this frame go, decided on the device (sa_batch_run_apply: the upkeep queued right behind the assignment,
+// no host round trip for the winners): candidate i without a winner takes table row T0 + r and id id_base + 1 + (per_candidate ? i : r),
+// r = its rank among the scene's new tracks in candidate order — the order in which the reference draws ids (sort/simple_api.rs:
+// 165-187; Batch*: one id per candidate, batch_api.rs:102-106).  One workgroup, a running count over chunks of 1024 candidates.
+__global__ __launch_bounds__(1024) void k_apply_ids(const int32_t* __restrict__ win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate,
+                                                    uint32_t* __restrict__ new_row, uint64_t* __restrict__ new_ids, uint32_t* __restrict__ n_new_out) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < n; c0 += 1024u) {
+    const uint32_t i = c0 + tid;
+    const bool fresh = i < n && win_col[i] < 0;
+    const unsigned long long m = __ballot(fresh);
+    const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = s_base, tot = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+      if (w < wave) off += s_w[w];
+      tot += s_w[w];
+    }
+    if (i < n) {
+      const uint32_t r = off + below;
+      new_row[i] = fresh ? T0 + r : SA_NONE;
+      new_ids[i] = fresh ? id_base + 1ull + (per_candidate ? (uint64_t)i : (uint64_t)r) : 0ull;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *n_new_out = s_base;
+}
+hipError_t sa_launch_apply_ids(const int32_t* win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate, uint32_t* new_row, uint64_t* new_ids,
+                               uint32_t* n_new_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply_ids, dim3(1), dim3(1024), 0, st, win_col, n, T0, id_base, per_candidate, new_row, new_ids, n_new_out);
+  return hipGetLastError();
+}
+
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st) {
   if (!a.n) return hipSuccess;
   hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 64)), dim3(64), 0, st, a, p);

@@ -23,7 +23,7 @@ import pytest  # noqa: E402
 def _path_flags():
     from similari_amd import abi
 
-    return {"default": 0, "general": abi.SA_FLAG_GENERAL_TAIL, "general2": abi.SA_FLAG_GENERAL_TAIL | abi.SA_FLAG_SEPARATE_LABEL, "never_lean": abi.SA_FLAG_NEVER_LEAN, "bestfit_tile": abi.SA_FLAG_BESTFIT_TILE,
+    return {"default": 0, "general": abi.SA_FLAG_GENERAL_TAIL, "never_lean": abi.SA_FLAG_NEVER_LEAN, "bestfit_tile": abi.SA_FLAG_BESTFIT_TILE,
             "separate_resolve": abi.SA_FLAG_SEPARATE_RESOLVE, "euclid_valu": abi.SA_FLAG_EUCLID_VALU, "euclid_mfma": abi.SA_FLAG_EUCLID_MFMA}
 
 

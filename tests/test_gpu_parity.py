@@ -174,7 +174,7 @@ def check_sort(cfg, sc, epoch=1, kf=None, require_ids=True):
     return ids, ref
 
 
-@pytest.mark.paths("general", "general2", "never_lean")
+@pytest.mark.paths("general", "never_lean")
 @pytest.mark.parametrize("oriented", [False, True])
 @pytest.mark.parametrize("n,t", [(257, 300), (64, 64), (1, 1), (130, 65)])
 def test_sort_iou_parity(oriented, n, t):
@@ -198,7 +198,7 @@ def test_general_assignment_tail_matches_oracle_too():
     assert (ids != 0).sum() > 900
 
 
-@pytest.mark.paths("general", "general2")
+@pytest.mark.paths("general")
 def test_state_kept_clean_across_frames_of_changing_size():
     """Edge counters, row duals and the union-find forest are not reset at the start of a frame: the assignment tail leaves
     them clean (k_slot_init only after a reallocation).  One engine, one slot, frames whose N and T grow, shrink and cross
@@ -276,7 +276,7 @@ def test_two_engines_of_one_process_run_different_paths():
                                        max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
                                        max_idle_epochs=5, flags=flags | abi.SA_FLAG_PROFILE)
     cfg_a = mk(0)
-    cfg_b = mk(abi.SA_FLAG_GENERAL_TAIL | abi.SA_FLAG_NEVER_LEAN | abi.SA_FLAG_SEPARATE_RESOLVE | abi.SA_FLAG_SEPARATE_LABEL)
+    cfg_b = mk(abi.SA_FLAG_GENERAL_TAIL | abi.SA_FLAG_NEVER_LEAN | abi.SA_FLAG_SEPARATE_RESOLVE)
     ea, eb = Engine(cfg_a), Engine(cfg_b)
     try:
         for f in range(3):
@@ -446,7 +446,7 @@ def test_device_upkeep_refuses_tracks_without_state():
         eng.close()
 
 
-@pytest.mark.paths("general", "general2")
+@pytest.mark.paths("general")
 def test_sort_iou_constraints_and_idle_epochs():
     rng = np.random.default_rng(7)
     sc = synth.sort_scene(rng, 200, 220, canvas=(1200.0, 800.0))
@@ -455,7 +455,7 @@ def test_sort_iou_constraints_and_idle_epochs():
     check_sort(cfg, sc, epoch=8)
 
 
-@pytest.mark.paths("general", "general2", "never_lean")
+@pytest.mark.paths("general", "never_lean")
 def test_sort_maha_parity():
     rng = np.random.default_rng(21)
     sc = synth.sort_scene(rng, 180, 200, canvas=(1500.0, 900.0))
@@ -549,7 +549,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
-@pytest.mark.paths("general", "general2", "never_lean", "bestfit_tile", "separate_resolve")
+@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve")
 @pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "default"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
@@ -819,7 +819,7 @@ def test_upsert_replace_remove_keep_order():
         eng.close()
 
 
-@pytest.mark.paths("general", "general2", "never_lean")
+@pytest.mark.paths("general", "never_lean")
 def test_batched_scenes_match_single_scene_runs():
     rng = np.random.default_rng(83)
     cfg = abi.make_config(positional="iou", max_idle_epochs=5)
@@ -1097,7 +1097,7 @@ def test_full_size_properties_c2_euclidean():
 
 
 # ---- the positional vote on graphs that do NOT fall apart into tiny components ---------------------------------------------
-@pytest.mark.paths("general", "general2")
+@pytest.mark.paths("general")
 def test_one_giant_component_against_the_oracle():
     """640 boxes piled on each other under IoU(0.05): ONE connected component, ~100 k usable edges (they stay in the HBM lists: the
     LDS pool holds 3072), most greedy bids colliding.  kuhn_munkres does not care about density (sort/voting.rs:86); the
@@ -1110,7 +1110,7 @@ def test_one_giant_component_against_the_oracle():
         assert (~np.isnan(ref["positional"])).sum() > 50_000
 
 
-@pytest.mark.paths("general", "general2")
+@pytest.mark.paths("general")
 @pytest.mark.parametrize("sigma", [2.0, 12.0])
 @pytest.mark.parametrize("n,t,canvas", [(1000, 1000, (1920.0, 1080.0)), (1024, 1024, (700.0, 500.0)), (300, 900, (500.0, 400.0))])
 def test_crowds_against_the_oracle(n, t, canvas, sigma):
@@ -1197,7 +1197,7 @@ def test_mahalanobis_crowd_takes_the_64_bit_dense_solver(n, t):
     assert present.sum() > 20 * n, "the frame lost its density"
 
 
-@pytest.mark.paths("general", "general2", "euclid_valu", "euclid_mfma")
+@pytest.mark.paths("general", "euclid_valu", "euclid_mfma")
 @pytest.mark.parametrize("visual", ["cosine", "euclidean"])
 def test_dense_positional_stage_behind_a_visual_vote(visual):
     """VisualSORT on a pile: 35 % of the detections are new or below the quality gate, so the positional stage inherits hundreds of
@@ -1340,9 +1340,8 @@ def test_full_size_more_tracks_than_the_small_tail_holds_against_the_oracle(k):
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 10 and (votes == abi.SA_VOTE_VISUAL).sum() > 700
 
 
-def test_frames_beyond_1024_tracks_take_two_launches():
-    """The launches of a 1000 x 1500 VisualSORT frame: the fused first phase and the many-workgroup tail with the label step as its first
-    phase — no stand-alone contraction, no resolve kernel, no label launch (SA_FLAG_SEPARATE_LABEL brings that one back)."""
+def test_frames_beyond_1024_tracks_take_three_launches():
+    """The launches of a 1000 x 1500 VisualSORT frame: first phase, label, solve — no stand-alone contraction, no resolve kernel."""
     rng = np.random.default_rng(1503)
     sc = synth.visual_scene(rng, 1500, 1000, 128, 1)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=128,
@@ -1362,20 +1361,8 @@ def test_frames_beyond_1024_tracks_take_two_launches():
     finally:
         eng.close()
     launched = {k for k, (n, _) in prof.items() if n and k != "d2h_results"}
-    assert launched == {"k_frame_visual", "k_assign_solve"}, prof
+    assert launched == {"k_frame_visual", "k_assign_label", "k_assign_solve"}, prof
     np.testing.assert_array_equal(ids, sc["truth"])
-    cfg.flags |= abi.SA_FLAG_SEPARATE_LABEL
-    eng = Engine(cfg)
-    try:
-        eng.upsert(0, tracks)
-        eng.associate(0, 1, det)
-        eng.profile_reset()
-        ids2, _ = eng.associate(0, 1, det)
-        prof = eng.profile_read()
-    finally:
-        eng.close()
-    assert {k for k, (n, _) in prof.items() if n and k != "d2h_results"} == {"k_frame_visual", "k_assign_label", "k_assign_solve"}, prof
-    np.testing.assert_array_equal(ids2, sc["truth"])
 
 
 @pytest.mark.paths("never_lean")
@@ -1566,7 +1553,7 @@ def _fuzz_case(seed):
     return rng, cfg, sc, epoch, positional, visual
 
 
-@pytest.mark.paths("general", "general2", "euclid_valu", "euclid_mfma")
+@pytest.mark.paths("general", "euclid_valu", "euclid_mfma")
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SA_FUZZ_N", "40"))))
 def test_random_configurations(seed):
     rng, cfg, sc, epoch, positional, visual = _fuzz_case(seed)

@@ -312,6 +312,109 @@ def test_oriented_boxes_between_apply_begin_and_end_meet_the_next_launch_with_th
         b.close()
 
 
+@pytest.mark.parametrize("per_candidate", [0, 1])
+@pytest.mark.parametrize("visual", [False, True])
+def test_upkeep_queued_behind_the_association_equals_the_two_phase_upkeep(visual, per_candidate):
+    """sa_batch_run_apply / sa_tracks_apply_collect (the facade's path: the Kalman / feature-bank step queued right behind the assignment
+    tail, the ids of new tracks drawn ON THE DEVICE from a counter in candidate order) against sa_associate + sa_tracks_apply with the
+    ids drawn on the host: same winners, same new ids, same predicted boxes, same tables (f64 polygons of oriented boxes included),
+    frame after frame — new objects every frame, two scenes in one request set."""
+    rng = np.random.default_rng(97 + per_candidate + 2 * visual)
+    d = 64
+    cfg = (visual_cfg(d, k=2, visual_minimal_quality_collect=0.4) if visual else abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5))
+    u64p, boxp = C.POINTER(C.c_uint64), C.POINTER(abi.sa_box)
+    scenes = (4, 9)
+    world = {sc: synth.dense_boxes(rng, 40, (800.0, 600.0), oriented=(sc == 9)) for sc in scenes}
+    ident = {sc: synth.reid_identities(rng, 200, d) for sc in scenes}
+    a, b = Engine(cfg), Engine(cfg)
+    try:
+        counter = [0, 0]
+        for f in range(6):
+            items = []
+            for sc in scenes:
+                world[sc] = np.concatenate([synth.jitter_boxes(rng, world[sc], 1.5, angle_sigma=0.02 if sc == 9 else 0.0),
+                                            synth.dense_boxes(rng, 3, (800.0, 600.0), oriented=(sc == 9))])
+                n = len(world[sc])
+                kw = dict(feats=synth.observe(rng, ident[sc][:n]), feat_quality=rng.uniform(0.2, 1.0, n).astype(np.float32)) if visual else {}
+                items.append((sc, f + 1, abi.make_detections(world[sc], **kw)))
+            # two-phase reference on engine a: associate, draw ids on the host in the reference's order, sa_tracks_apply
+            a.batch_begin()
+            slots = [a.batch_add(sc, ep, det) for sc, ep, det in items]
+            a.batch_run()
+            a.batch_sync()
+            ref = []
+            base_a = []
+            for (sc, ep, det), sl in zip(items, slots):
+                base_a.append(counter[0])
+                ids, votes = a.batch_fetch(sl, det.n)
+                nid = np.zeros(det.n, np.uint64)
+                for i in range(det.n):
+                    if per_candidate:
+                        counter[0] += 1
+                    if ids[i] == 0:
+                        if not per_candidate:
+                            counter[0] += 1
+                        nid[i] = counter[0]
+                ref.append((ids, votes, nid))
+            preds_a = []
+            for sl, (ids, votes, nid) in zip(slots, ref):
+                pred = np.zeros(len(ids), abi.BOX_DTYPE)
+                a._chk(a.lib.sa_tracks_apply(a.h, sl, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp)))
+                preds_a.append(pred)
+            # fused on engine b
+            if not per_candidate:
+                # (a counter per NEW track across scenes would make a scene's first id depend on the earlier scenes' winners: one scene
+                # per request set under that rule — what Sort / VisualSort::predict are)
+                got = []
+                for k, (sc, ep, det) in enumerate(items):
+                    b.batch_begin()
+                    sl = b.batch_add(sc, ep, det)
+                    base = np.array([counter[1]], np.uint64)
+                    b._chk(b.lib.sa_batch_run_apply(b.h, base.ctypes.data_as(u64p), 0))
+                    b.batch_sync()
+                    ids, votes = b.batch_fetch(sl, det.n)
+                    nid = np.zeros(det.n, np.uint64)
+                    pred = np.zeros(det.n, abi.BOX_DTYPE)
+                    b._chk(b.lib.sa_tracks_apply_collect(b.h, sl, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp)))
+                    counter[1] += int((ids == 0).sum())
+                    got.append((ids, votes, nid, pred))
+            else:
+                b.batch_begin()
+                slots_b = [b.batch_add(sc, ep, det) for sc, ep, det in items]
+                bases, nxt = [], counter[1]
+                for sc, ep, det in items:
+                    bases.append(nxt)
+                    nxt += det.n
+                ba = np.array(bases, np.uint64)
+                b._chk(b.lib.sa_batch_run_apply(b.h, ba.ctypes.data_as(u64p), 1))
+                b.batch_sync()
+                got = []
+                for sl, (sc, ep, det) in zip(slots_b, items):
+                    ids, votes = b.batch_fetch(sl, det.n)
+                    nid = np.zeros(det.n, np.uint64)
+                    pred = np.zeros(det.n, abi.BOX_DTYPE)
+                    b._chk(b.lib.sa_tracks_apply_collect(b.h, sl, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp)))
+                    got.append((ids, votes, nid, pred))
+                counter[1] = nxt
+            for k, ((ids, votes, nid), pred_a, (ids_b, votes_b, nid_b, pred_b)) in enumerate(zip(ref, preds_a, got)):
+                np.testing.assert_array_equal(ids_b, ids, err_msg=f"frame {f} scene {k}")
+                np.testing.assert_array_equal(votes_b, votes)
+                np.testing.assert_array_equal(nid_b, nid, err_msg=f"frame {f} scene {k}: new ids")
+                np.testing.assert_array_equal(pred_b.view(np.uint8), pred_a.view(np.uint8))
+            for sc in scenes:
+                assert a.count(sc) == b.count(sc)
+                np.testing.assert_array_equal(b.tap_track_polygons(sc).view(np.uint64), a.tap_track_polygons(sc).view(np.uint64))
+            if f == 0:
+                assert (ref[0][0] == 0).all()   # first frame: every candidate starts a track
+        assert a.count(4) > 40 and (ref[0][0] != 0).sum() >= 40
+        # collecting twice is refused, not repeated
+        with pytest.raises(EngineError):
+            b._chk(b.lib.sa_tracks_apply_collect(b.h, 0, None, None))
+    finally:
+        a.close()
+        b.close()
+
+
 def test_graph_replay_survives_a_changing_epoch():
     """SA_FLAG_GRAPH under a tracker: the epoch (and the detections) change every frame, the launch geometry does not — the
     captured graph is replayed, and every frame's answer is the oracle's for THAT epoch (idle tracks drop out as it advances)."""
