@@ -135,7 +135,8 @@ typedef struct sa_config {
 #define SA_FLAG_SEPARATE_RESOLVE 0x400u /* no vote words: per-tile partials + k_bestfit_resolve as a launch of its own */
 #define SA_FLAG_EUCLID_VALU 0x800u      /* euclidean engines: always the vector-pipe kernel (direct sums of squares) */
 #define SA_FLAG_EUCLID_MFMA 0x1000u     /* euclidean engines: always the matrix-core expansion + flagged recompute, also after an ill-conditioned frame */
-#define SA_FLAG_ROW_MAJOR_TILES 0x4000u /* the contraction's tiles numbered row by row instead of in XCD-aware order (A/B measurements of the HBM traffic) */
+#define SA_FLAG_XCD_TILES 0x4000u       /* the contraction's tiles in XCD-aware order (each XCD's L2 takes a compact block of tiles: C2 19.1 -> 15.3 MB of HBM
+                                           traffic per launch) instead of row by row — measured: no faster at C2 / c2b, 4 % slower at C5; A/B measurements */
 #define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,

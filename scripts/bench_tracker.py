@@ -99,6 +99,14 @@ def run(kind, device_upkeep, feats_mode="rows", churn=0.0):
     return 1e3 * float(np.median(times[3:])), matched, int(table_rows.value)
 
 
+import os  # noqa: E402
+
+only = os.environ.get("SA_BENCH_TRACKER_ONLY")   # e.g. "visual,device,0.0" (tracker, features, churn): that one device-upkeep run only
+if only:
+    k_, m_, c_ = only.split(",")
+    ms, matched, rows = run(k_, True, m_, float(c_))
+    print(json.dumps({"tracker": k_, "features": m_, "churn_per_frame": float(c_), "ms_per_frame_median": round(ms, 3), "table_rows_last_frame": rows}), flush=True)
+    sys.exit(0)
 for kind, dev, mode, churn in (("sort", False, "rows", 0.0), ("sort", True, "rows", 0.0), ("visual", False, "rows", 0.0), ("visual", True, "rows", 0.0),
                                ("visual", True, "pinned", 0.0), ("visual", True, "device", 0.0),
                                ("sort", True, "rows", 0.05), ("visual", True, "pinned", 0.05), ("visual", True, "device", 0.05)):

@@ -181,7 +181,7 @@ struct SaParams {
   uint32_t eu_mfma;             // per launch: euclidean distances through the matrix-core contraction (expansion + flagged direct recompute)
   float eu_rho;                 // a cell with d^2 < eu_rho (|a|^2 + |b|^2) is recomputed directly
   uint32_t force_general;       // SA_FLAG_GENERAL_TAIL: the many-workgroup assignment tail (and the launches that feed it) whatever the frame size
-  uint32_t row_major_tiles;     // SA_FLAG_ROW_MAJOR_TILES: the contraction's tiles numbered row by row instead of in XCD-aware order (A/B measurements)
+  uint32_t row_major_tiles;     // the contraction's tiles numbered row by row (the default; 0 with SA_FLAG_XCD_TILES: XCD-aware order, sa_gemm.hip)
   int32_t gemm_plan;            // sa_config.gemm_plan - 1: the contraction's tile plan pinned (tuning / tests), -1 = tile_plan()'s own choice
 };
 

@@ -57,12 +57,16 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // HBM (C2: 19.9 MB measured for 4.1 MB of operands).  Instead XCD x takes the x-th CONTIGUOUS chunk of a tile numbering that walks
 // the grid in bands of W tile columns (row by row inside a band): its tiles form a compact block of about W x chunk / W tiles that
 // shares W column panels and chunk / W row panels (C2, 16 x 16 tiles, chunk 32, W 4: 8 x 4 tiles = 1.5 MB per XCD instead of 2.25).
+// MEASURED (round 4, SA_FLAG_XCD_TILES; profiles/r04_*): FETCH_SIZE of the C2 launch 19.1 -> 15.3 MB, the frame no faster (20.42 against
+// 20.48 us; the launch itself 17.6 against 16.5 us between its own timestamps), c2b's stand-alone contraction 92.3 -> 91.0 us, C5's
+// 634 -> 657 us (bands of 12 x 128 tracks x 16 KB overflow the 4 MB L2 that a row-by-row walk keeps one candidate panel in): the HBM
+// traffic is not what bounds these launches (1.1 TB/s at C5), so the order stays row by row and this one is an option.
 // b in [0, 8 chunk) -> tile number t = (b % 8) chunk + b / 8 (t >= tiles: an idle workgroup); t -> (row, column).
 struct XcdOrder { uint32_t chunk, W; };
 static inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool row_major = false) {
   XcdOrder o;
   const uint32_t tiles = gx * gy;
-  if (row_major) { o.chunk = tiles; o.W = 0; return o; }  // SA_FLAG_ROW_MAJOR_TILES (A/B measurements): W = 0 -> workgroup b is tile b, row by row
+  if (row_major) { o.chunk = tiles; o.W = 0; return o; }  // the default: W = 0 -> workgroup b is tile b, row by row
   o.chunk = (tiles + 7u) / 8u;
   uint32_t w = 1;
   while ((w + 1) * (w + 1) <= o.chunk) ++w;   // ~ sqrt(chunk): square-ish blocks
