@@ -13,6 +13,8 @@ for ln in open("gpurun_out/tt.err"):
 a = np.array(rows[5:])
 names = ["assemble", "associate", "begin", "stage", "enqueue", "wait+fetch", "apply", "bookkeeping"]
 print(sys.argv[1], open("gpurun_out/tt.out").read().strip())
+col = np.array([[float(x) for x in re.findall(r"(-?[0-9]+[.][0-9]+)", ln)] for ln in open("gpurun_out/tt.err") if ln.startswith("[sa_collect]")][5:])
+if len(col): print("   collect:", {n: round(float(np.median(col[:, i])), 1) for i, n in enumerate(("sync", "table", "polygons"))})
 print("   median us per predict():", {n: round(float(np.median(a[:, i])), 1) for i, n in enumerate(names)}, "sum", round(float(np.median(a[:, 0] + a[:, 1] + a[:, 6] + a[:, 7])), 1))
 PY
 done

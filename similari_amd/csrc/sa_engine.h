@@ -270,9 +270,12 @@ hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, 
 struct ApplyArgs {
   const BoxRaw* c_raw;       // [n] candidates of the slot
   const int32_t* win_col;    // [n] winning column or -1
-  const uint32_t* new_row;   // [n] table row for a candidate that starts a track
-  const uint64_t* new_ids;   // [n] its id
-  uint32_t n;
+  const uint32_t* new_row;   // [n] table row for a candidate that starts a track; nullptr: drawn on the device — T0 + its rank among the
+  const uint64_t* new_ids;   // [n] its id                                                  candidates without a winner, in candidate order,
+  uint32_t n;                //                                                              id = id_base + 1 + (id_per_candidate ? index : rank)
+  uint32_t T0;
+  uint64_t id_base;
+  int32_t id_per_candidate;
   uint64_t epoch;
   float* kf;                 // [T][110] Kalman mean(10) + covariance(100)
   sa_geo* geo;
@@ -286,7 +289,8 @@ struct ApplyArgs {
 struct BankArgs {
   const BoxRaw* c_raw;
   const int32_t* win_col;
-  const uint32_t* new_row;
+  const uint32_t* new_row;   // (nullptr: T0 + rank, as in ApplyArgs)
+  uint32_t T0;
   uint32_t n, K, Dp;
   const float* c_feat;       // [n][Dp] padded candidate features (nullptr: the frame carried none)
   const float* c_fnorm;
@@ -298,13 +302,9 @@ struct BankArgs {
   uint8_t* t_fpresent;
   float* t_fquality;
   uint32_t* t_fcount;
-  float* tmp;                // [n][K][Dp]
   float minimal_area, q_collect, own_collect;
 };
-hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st);
-// rows and ids of the tracks that start this frame, drawn on the device from the winners (k_apply_ids); *n_new_out = how many
-hipError_t sa_launch_apply_ids(const int32_t* win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate, uint32_t* new_row, uint64_t* new_ids,
-                               uint32_t* n_new_out, hipStream_t st);
+hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done = nullptr);
 // oriented boxes after sa_launch_apply: the host's libm cos / sin of a refreshed row's angle -> its polygon
 struct SaPolyFix {
   uint32_t row, pad;

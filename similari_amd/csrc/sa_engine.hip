@@ -69,7 +69,7 @@ struct Slot {  // one scene of a request set
   DevBuf pos, vis, quant;
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
-  DevBuf win_col, new_row, new_ids, bank_tmp;  // device-side upkeep
+  DevBuf win_col;                              // device-side upkeep: the winners as table columns
   DevBuf lab, cwin, big_rows, big_bcol, dq, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
@@ -112,6 +112,9 @@ struct Bank {
   bool frame_with_prep = true;          // what enqueue_frame decided for this set's launches: the preparation blocks ride in the first phase
                                         // (a replayed graph runs no host code of enqueue_frame: bank_launch re-applies it to the slots)
   bool frame_small_tail = false;        // the set's last launches went through the one-workgroup tail (slot-major edge lists, vote words)
+  bool assoc_event = false;             // sa_batch_run_apply: ev_done marks the end of the ASSOCIATION (the frame's last dispatch carries it); the
+                                        // upkeep kernels run behind it — sa_batch_fetch waits for the event only, so that the caller's own
+                                        // bookkeeping overlaps them
   bool want_prep = false;               // the upkeep follows on the stream (sa_batch_run_apply): its feature-bank step reads what the preparation blocks write
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
@@ -119,6 +122,9 @@ struct Bank {
   uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};  // launch geometry + kernel selection of the captured frame (run_pipeline)
   // pipelined tickets
   hipEvent_t ev_staged = nullptr, ev_done = nullptr;
+  hipEvent_t ev_apply = nullptr;   // sa_batch_run_apply: carried by the last upkeep dispatch of the set (sa_tracks_apply_collect waits for it)
+  bool apply_event = false;
+  uint64_t apply_seq = 0;          // sa_engine::busy_seq right after that dispatch: unchanged at the wait = the engine is drained
   bool staged_inline = false;  // the request set was uploaded on the compute stream itself (no hand-over event to wait for)
   uint64_t ticket = 0;       // 0 = none
   int state = 0;             // 0 idle, 1 staged (H2D queued), 2 launched (pipeline queued), 3 done and waited
@@ -152,6 +158,7 @@ struct sa_engine {
   std::string err;
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
+  uint64_t busy_seq = 0;             // counts the enqueues since the engine was created (SA_BUSY): "nothing was queued since event X" is a comparison
   // device buffers that were replaced while work that may still read them was queued: freed at the next full sync, or — pipelined
   // loops never reach one — by sa_pipe_wait once every ticket issued before the replacement has been waited for (tag = the ticket
   // number that was next when the buffer was replaced)
@@ -172,6 +179,7 @@ struct sa_engine {
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 };
 
+#define SA_BUSY(e) do { (e)->synced = false; ++(e)->busy_seq; } while (0)
 // (sa_tracks_apply_begin without its _end yet: whatever needs the finished table calls this first; defined next to sa_tracks_apply)
 static int finish_applies(sa_engine* e);
 
@@ -229,9 +237,14 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
     if (_r != SA_OK) return _r;  \
   } while (0)
 
+// what a drained engine owes: replaced buffers freed, open profile records resolved
+int engine_idle(sa_engine* e);
 int engine_sync(sa_engine* e) {
   if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return engine_idle(e);
+}
+int engine_idle(sa_engine* e) {
   for (auto& g : e->garbage) hipFree(g.p);
   e->garbage.clear();
   e->synced = true;
@@ -583,7 +596,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   } else {
     HIPCHK(e, hipMemcpyAsync(dbase + desc_off, h + desc_off, dbytes, hipMemcpyHostToDevice, st));
   }
-  e->synced = false;
+  SA_BUSY(e);
   return SA_OK;
 }
 
@@ -601,7 +614,7 @@ int ensure_prepped(sa_engine* e, Bank* b) {
   const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
   HIPCHK(e, sa_launch_frame(ds, b->n_slots, maxN, maxT, e->visual ? 1 : 0, e->P, e->stream, 2));
   for (uint32_t i = 0; i < b->n_slots; ++i) b->slots[i]->prepped = true;
-  e->synced = false;
+  SA_BUSY(e);
   return SA_OK;
 }
 
@@ -743,7 +756,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
 
 int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t done = nullptr, bool* done_attached = nullptr) {
   const uint32_t ns = b->n_slots;
-  e->synced = false;
+  SA_BUSY(e);
   const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
   hipStream_t st = e->stream;
   // assignment state that the tail kernels keep clean from frame to frame: establish it after (re)allocation
@@ -948,6 +961,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   for (Bank& bk : e->banks) {
     hipEventCreate(&bk.ev_staged);  // also handed to hipExtLaunchKernelGGL as the ingest dispatch's completion event
     hipEventCreate(&bk.ev_done);    // handed to hipExtLaunchKernelGGL as the completion event of a frame's last dispatch (enqueue_frame)
+    hipEventCreate(&bk.ev_apply);
   }
   *out = e;
   return SA_OK;
@@ -981,8 +995,8 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->usable, &s->feat, &s->fnorm, &s->pos, &s->vis, &s->quant, &s->vis_max_key, &s->row_part_w,
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
-                        &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col, &s->new_row, &s->new_ids,
-                        &s->bank_tmp, &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dq, &s->dense})
+                        &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col,
+                        &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dq, &s->dense})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_fix);
@@ -996,6 +1010,7 @@ void sa_engine_destroy(sa_engine* e) {
     if (bk.graph) hipGraphDestroy(bk.graph);
     if (bk.ev_staged) hipEventDestroy(bk.ev_staged);
     if (bk.ev_done) hipEventDestroy(bk.ev_done);
+    if (bk.ev_apply) hipEventDestroy(bk.ev_apply);
   }
   for (DevBuf* b : {&e->nms_mask, &e->nms_keep, &e->up_raw, &e->up_slots, &e->up_epochs, &e->up_ids, &e->up_mean, &e->up_cov, &e->up_feats,
                     &e->up_present, &e->up_index})
@@ -1110,7 +1125,7 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
                                      (const uint32_t*)e->up_slots.p, (const uint8_t*)e->up_present.p, (float*)sc->feat.p,
                                      (float*)sc->fnorm.p, (uint8_t*)sc->fpresent.p, (uint32_t*)sc->fcount.p, st));
   }
-  e->synced = false;
+  SA_BUSY(e);
   return engine_sync(e);
 }
 
@@ -1175,7 +1190,7 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
   sc->ids = nids;
   sc->slot_of.clear();
   for (uint32_t s = 0; s < nT; ++s) sc->slot_of[nids[s]] = s;
-  e->synced = false;
+  SA_BUSY(e);
   return engine_sync(e);
 }
 
@@ -1198,6 +1213,8 @@ int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t
 
 // ---- batches ------------------------------------------------------------------------------------------
 static void bank_clear(Bank* b) {
+  b->assoc_event = false;
+  b->apply_event = false;
   b->n_slots = 0;
   b->used = 0;
   b->uploaded = false;
@@ -1212,7 +1229,10 @@ int sa_batch_begin(sa_engine* e) {
   for (Bank& bk : e->banks)
     if (bk.state == 1 || bk.state == 2)
       return fail(e, SA_ERR_STATE, "ticket %llu is still outstanding: sa_pipe_wait it before a synchronous batch", (unsigned long long)bk.ticket);
-  TRY(engine_sync(e));  // "busy monitor": the previous batch must have drained (sort/batch_api.rs:233-241)
+  // "busy monitor": the previous batch must have drained (sort/batch_api.rs:233-241).  (Known drained already — the last thing queued was
+  // waited for through its own completion event, fused_collect —: no stream synchronisation, which would cost a marker packet's round
+  // trip through the command processor, ~10 us, even on an idle queue.)
+  if (!e->synced) TRY(engine_sync(e));
   e->B_ticket = 0;      // the synchronous entry points own e->B from here on
   bank_clear(e->B);
   return SA_OK;
@@ -1381,7 +1401,10 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch before sa_batch_run");
-  if (!e->synced) TRY(engine_sync(e));
+  if (e->B->assoc_event) {  // (the upkeep queued behind the association is still running: the winners are in)
+    hipError_t we = hipEventSynchronize(e->B->ev_done);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+  } else if (!e->synced) TRY(engine_sync(e));
   const uint8_t* h = (const uint8_t*)s->h_out.p;
   if (out_track_id) std::memcpy(out_track_id, h, (size_t)s->N * 8);
   if (out_voting_type) std::memcpy(out_voting_type, h + (size_t)s->N * 8, s->N);
@@ -1397,7 +1420,10 @@ int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
   if (!out_cols && s->N) return fail(e, SA_ERR_BAD_ARG, "sa_batch_fetch_cols: null argument");
   if (!s->N) return SA_OK;
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch_cols before sa_batch_run");
-  if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
+  if (e->B->assoc_event) {
+    hipError_t we = hipEventSynchronize(e->B->ev_done);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+  } else if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
   std::memcpy(out_cols, (const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16, (size_t)s->N * 4);
   return SA_OK;
 }
@@ -1562,9 +1588,9 @@ static int finish_applies(sa_engine* e) {
 }
 // Queues the upkeep kernels of slot `s` (Kalman step + table rows, feature-bank policy) on the compute stream.  new_row / new_ids: device-visible
 // arrays — table row and id of every candidate that starts a track (SA_NONE / 0 elsewhere).
-static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids) {
+static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids, hipEvent_t done = nullptr) {  // (both nullptr: drawn on the device from s->fused_*)
   SceneTable* sc = s->scene;
-  const uint32_t n = s->N, K = e->K;
+  const uint32_t n = s->N;
   {
     void* before = s->h_pred.p;
     TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
@@ -1574,23 +1600,23 @@ static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const ui
   ApplyArgs a{};
   a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = new_row;
   a.new_ids = new_ids; a.n = n; a.epoch = s->epoch;
+  a.T0 = s->fused_T0; a.id_base = s->fused_id_base; a.id_per_candidate = s->fused_per_candidate;
   a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
   a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
   BankArgs b{};
   if (e->visual) {
-    TRY(dev_ensure(e, s->bank_tmp, (size_t)n * K * e->Dp * 4));
-    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.n = n; b.K = K; b.Dp = e->Dp;
+    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.T0 = a.T0; b.n = n; b.K = e->K; b.Dp = e->Dp;
     b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
     b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
     b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
     b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
     b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
-    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p; b.tmp = (float*)s->bank_tmp.p;
+    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p;
     b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
     b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
   }
-  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st));
-  e->synced = false;
+  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st, done));
+  SA_BUSY(e);
   return SA_OK;
 }
 int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) {
@@ -1604,7 +1630,7 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
   // Never the copy stream: it may be carrying the NEXT request set's ingest, which is exactly what this call is meant to overlap.
   if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
   SceneTable* sc = s->scene;
-  const uint32_t n = s->N, K = e->K;
+  const uint32_t n = s->N;
   if (!n) return SA_OK;
   if (s->T != sc->T) return fail(e, SA_ERR_STATE, "the scene's track table changed since the slot ran");
   if (e->visual) TRY(ensure_prepped(e, e->B));  // the feature-bank step reads the candidates' padded rows and norms
@@ -1695,7 +1721,7 @@ static int polygon_fixups(sa_engine* e, Slot* s) {
     ++k;
   }
   HIPCHK(e, sa_launch_apply_polygons((const SaPolyFix*)s->d_fix, nfix, (double*)sc->verts.p, e->stream));
-  e->synced = false;
+  SA_BUSY(e);
   return SA_OK;
 }
 static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
@@ -1717,9 +1743,22 @@ static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
 // Kalman / feature-bank kernels run right behind the assignment tail on the same stream.  The host learns everything in ONE wait and
 // replays the (trivial) id arithmetic for its own copy of the table.
 static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
+  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;  // (trace hook: where the collect spends its time)
+  const auto tc0 = std::chrono::steady_clock::now();
   HIPCHK(e, hipSetDevice(e->device));
   s->fused_pending = false;
-  TRY(engine_sync(e));
+  {
+    Bank* ob = nullptr;   // the bank the slot belongs to: its last upkeep dispatch carries ev_apply
+    for (Bank& bk : e->banks)
+      for (uint32_t i = 0; i < bk.n_slots; ++i)
+        if (bk.slots[i] == s) ob = &bk;
+    if (ob && ob->apply_event) {
+      hipError_t we = hipEventSynchronize(ob->ev_apply);
+      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+      if (e->busy_seq == ob->apply_seq) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
+    } else TRY(engine_sync(e));
+  }
+  const auto tc1 = std::chrono::steady_clock::now();
   SceneTable* sc = s->scene;
   const uint32_t n = s->N, T0 = s->fused_T0;
   if (!n) return SA_OK;
@@ -1755,7 +1794,13 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
   s->ran = false;  // the table the slot ran against is gone
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
   if (bad != SA_OK) return bad;
-  return polygon_fixups(e, s);
+  const auto tc2 = std::chrono::steady_clock::now();
+  const int prc = polygon_fixups(e, s);
+  if (trace) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[sa_collect] sync %.1f  table %.1f  polygons %.1f us\n", us(tc0, tc1), us(tc1, tc2), us(tc2, std::chrono::steady_clock::now()));
+  }
+  return prc;
 }
 
 int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted) {
@@ -1791,21 +1836,32 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
     TRY(scene_reserve(e, sc, sc->T + s->N));
   }
   b->want_prep = true;   // the feature-bank step reads the candidates' padded rows and norms: the preparation blocks ride in this frame
-  int rc = run_pipeline(e);
+  int rc = SA_OK;
+  if (b->n_slots) {
+    // (run_pipeline, with the end of the ASSOCIATION marked on the stream: the frame's last dispatch carries ev_done as its completion
+    // signal, so that sa_batch_fetch can hand out the winners while the upkeep kernels queued below are still running)
+    uint32_t maxN = 0, maxT = 0;
+    bool rides = false;
+    rc = bank_prepare(e, b, &maxN, &maxT);
+    if (rc == SA_OK) rc = bank_upload(e, b, e->stream, true);
+    if (rc == SA_OK) rc = bank_launch(e, b, maxN, maxT, b->ev_done, &rides);
+    if (rc == SA_OK && !rides) { if (hipEventRecord(b->ev_done, e->stream) != hipSuccess) rc = fail(e, SA_ERR_HIP, "hipEventRecord failed"); }
+    b->assoc_event = rc == SA_OK;
+  }
   b->want_prep = false;
   if (rc != SA_OK) return rc;
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     Slot* s = b->slots[i];
     const uint32_t n = s->N;
     if (!n) continue;
-    TRY(dev_ensure(e, s->new_row, (size_t)n * 4 + 16));   // rows[n] | the count of new tracks
-    TRY(dev_ensure(e, s->new_ids, (size_t)n * 8));
     s->fused_T0 = s->scene->T;
     s->fused_id_base = id_base[i];
     s->fused_per_candidate = id_per_candidate ? 1 : 0;
-    HIPCHK(e, sa_launch_apply_ids((const int32_t*)s->win_col.p, n, s->fused_T0, s->fused_id_base, s->fused_per_candidate, (uint32_t*)s->new_row.p,
-                                  (uint64_t*)s->new_ids.p, (uint32_t*)s->new_row.p + n, e->stream));
-    TRY(apply_launch(e, s, (const uint32_t*)s->new_row.p, (const uint64_t*)s->new_ids.p));
+    // rows and ids of the tracks that start: drawn inside the kernels, from the winners; the set's LAST upkeep dispatch signals ev_apply
+    bool last = true;
+    for (uint32_t j = i + 1; j < b->n_slots; ++j) last = last && b->slots[j]->N == 0;
+    TRY(apply_launch(e, s, nullptr, nullptr, last ? b->ev_apply : nullptr));
+    if (last) { b->apply_event = true; b->apply_seq = e->busy_seq; }
     s->fused_pending = true;
   }
   return SA_OK;
@@ -1900,7 +1956,7 @@ int sa_nms(sa_engine* e, uint32_t n, const sa_box* boxes, const float* scores, f
   HIPCHK(e, sa_launch_nms((const BoxRaw*)e->up_raw.p, m, nms_threshold, (uint64_t*)e->nms_mask.p, (uint8_t*)e->nms_keep.p, st));
   uint8_t* hkeep = (uint8_t*)e->up_host.p + (size_t)m * sizeof(BoxRaw);
   HIPCHK(e, hipMemcpyAsync(hkeep, e->nms_keep.p, m, hipMemcpyDeviceToHost, st));
-  e->synced = false;
+  SA_BUSY(e);
   TRY(engine_sync(e));
   uint32_t k = 0;
   for (uint32_t i = 0; i < m; ++i)
@@ -1929,7 +1985,7 @@ int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share
   HIPCHK(e, sa_launch_own_areas((const BoxRaw*)e->up_raw.p, n, dshare, dstatus, st));
   uint8_t* hout = (uint8_t*)e->up_host.p + raw_bytes;
   HIPCHK(e, hipMemcpyAsync(hout, dshare, out_bytes, hipMemcpyDeviceToHost, st));
-  e->synced = false;
+  SA_BUSY(e);
   TRY(engine_sync(e));
   uint32_t status;
   memcpy(&status, hout + (size_t)n * 4, 4);
@@ -1952,7 +2008,7 @@ int sa_own_areas(sa_engine* e, uint32_t n, const sa_box* boxes, float* out_share
         rc = fail(e, SA_ERR_HIP, "sa_own_areas: spill launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     if (rc == SA_OK && hipMemcpyAsync(hout, dshare, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(e, SA_ERR_HIP, "sa_own_areas: result copy failed");
-    e->synced = false;
+    SA_BUSY(e);
     const int rs = engine_sync(e);
     if (scratch.p) hipFree(scratch.p);
     if (dlist.p) hipFree(dlist.p);

@@ -355,7 +355,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   } else
   if (rc == SA_OK) rc = sa_batch_run(t->eng);
   const auto t_run = clk::now();
-  if (rc == SA_OK) rc = sa_batch_sync(t->eng);
+  if (rc == SA_OK && !fused) rc = sa_batch_sync(t->eng);  // (fused: sa_batch_fetch waits for the END OF THE ASSOCIATION only — the upkeep kernels
+                                                          // queued behind it run while this thread does its bookkeeping below)
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) {
     rc = sa_batch_fetch(t->eng, s, winners[s].data(), votes[s].data());
     if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, s, wcols[s].data());

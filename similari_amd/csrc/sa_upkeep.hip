@@ -17,24 +17,150 @@
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-__global__ __launch_bounds__(64) void k_apply_kalman(ApplyArgs a, SaParams p) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// Rank of candidate i among the candidates WITHOUT a winner (those that start a track), in candidate order: the row / id it takes when
+// the engine draws them on the device (ApplyArgs::new_row == nullptr: sa_batch_run_apply).  One wave, a strided count over win_col[0, i).
+__device__ __forceinline__ uint32_t sa_rank_of_new(const int32_t* __restrict__ win_col, uint32_t i, uint32_t lane) {
+  uint32_t cnt = 0;
+  for (uint32_t j = lane; j < i; j += 64u) cnt += win_col[j] < 0 ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  return cnt;
+}
+#define SA_KF_SYNC()                                       \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+// One WAVEFRONT per candidate: the destination track's Kalman step (make_prediction: [initiate,] predict, update — sa_kalman.h) with the
+// state in LDS and every stage's elements spread over the lanes.  Each ELEMENT is still computed by one lane with exactly the
+// operations, and in exactly the order, of the serial code (sa_kf_predict / sa_kf_update: the loops below are those loops with the outer
+// index replaced by the lane), so the state stays bit-identical to the host facade's and the oracle's — but a step is a dozen short
+// stages instead of ~4 k dependent instructions of one thread on a 110-float state in scratch memory (1000 candidates: 16 wavefronts of
+// single threads took ~25 us — the longest link of the facade's predict() after the association; in-kernel ids: no k_apply_ids launch).
+struct KfLds {
+  float mean[10], sd[10], innov[5], nm[10];
+  float cov[100], mc[100], P[25], G[50], gtp[50];
+};
+__global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p) {
+  __shared__ KfLds s_kf[4];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint32_t i = blockIdx.x * 4u + w;   // wave-uniform
   if (i >= a.n) return;
+  KfLds& L = s_kf[w];
   const BoxRaw r = a.c_raw[i];
   const sa_box& cbox = r.box;
   const int32_t col = a.win_col[i];
   const bool merged = col >= 0;
-  const uint32_t row = merged ? (uint32_t)col : a.new_row[i];
-  sa_kf s;
-  float* st = a.kf + (size_t)row * 110;
-  if (merged) {
-    for (int k = 0; k < 10; ++k) s.mean[k] = st[k];
-    for (int k = 0; k < 100; ++k) s.cov[k] = st[10 + k];
+  uint32_t row;
+  uint64_t new_id = 0;
+  if (merged) row = (uint32_t)col;
+  else if (a.new_row) { row = a.new_row[i]; new_id = a.new_ids[i]; }
+  else {
+    const uint32_t rk = sa_rank_of_new(a.win_col, i, lane);
+    row = a.T0 + rk;
+    new_id = a.id_base + 1ull + (a.id_per_candidate ? (uint64_t)i : (uint64_t)rk);
   }
-  const sa_box pred = sa_kf_make_prediction(p.kf_position_weight, p.kf_velocity_weight, merged, s, cbox);
-  for (int k = 0; k < 10; ++k) st[k] = s.mean[k];
-  for (int k = 0; k < 100; ++k) st[10 + k] = s.cov[k];
-  // the track's row of the cost tables, exactly what k_prep_tracks derives from an upserted box
+  float* st = a.kf + (size_t)row * 110;
+  const float pw = p.kf_position_weight, vw = p.kf_velocity_weight;
+  // ---- state in: the stored one, or sa_kf_initiate
+  if (merged) {
+    for (uint32_t e = lane; e < 110u; e += 64u) {
+      const float v = st[e];
+      if (e < 10u) L.mean[e] = v; else L.cov[e - 10u] = v;
+    }
+  } else {
+    const float h = cbox.height;
+    const float vp = 2.0f * pw * h, vv = 10.0f * vw * h;   // sa_kf_std_diag: k * w * p
+    if (lane < 10u) {
+      const float m0[5] = {cbox.xc, cbox.yc, sa_kf_opt_angle(cbox), cbox.aspect, cbox.height};
+      L.mean[lane] = lane < 5u ? m0[lane] : 0.0f;
+    }
+    for (uint32_t e = lane; e < 100u; e += 64u) {
+      const uint32_t ii = e / 10u, jj = e % 10u;
+      const float sdv = ii < 5u ? (ii == 3u ? 1e-2f : vp) : (ii == 8u ? 1e-5f : vv);
+      L.cov[e] = ii == jj ? sdv * sdv : 0.0f;
+    }
+  }
+  SA_KF_SYNC();
+  // ---- sa_kf_predict
+  if (lane < 10u) {
+    const float m4 = L.mean[4];
+    const float vp = 1.0f * pw * m4, vv = 1.0f * vw * m4;
+    L.sd[lane] = lane < 5u ? (lane == 3u ? 1e-2f : vp) : (lane == 8u ? 1e-5f : vv);
+  }
+  SA_KF_SYNC();
+  if (lane < 5u) L.mean[lane] = L.mean[lane] + L.mean[lane + 5u];
+  for (uint32_t e = lane; e < 100u; e += 64u) {
+    const uint32_t ii = e / 10u;
+    L.mc[e] = ii < 5u ? L.cov[e] + L.cov[e + 50u] : L.cov[e];
+  }
+  SA_KF_SYNC();
+  for (uint32_t e = lane; e < 100u; e += 64u) {
+    const uint32_t ii = e / 10u, jj = e % 10u;
+    const float v = jj < 5u ? L.mc[e] + L.mc[e + 5u] : L.mc[e];
+    L.cov[e] = v + (ii == jj ? L.sd[ii] * L.sd[ii] : 0.0f);
+  }
+  SA_KF_SYNC();
+  // ---- sa_kf_update
+  if (lane < 5u) {
+    const float vp = 1.0f * pw * L.mean[4];
+    L.sd[lane] = lane == 3u ? 1e-1f : vp;
+  }
+  SA_KF_SYNC();
+  if (lane < 25u) {
+    const uint32_t ii = lane / 5u, jj = lane % 5u;
+    L.P[lane] = L.cov[ii * 10u + jj] + (ii == jj ? L.sd[ii] * L.sd[ii] : 0.0f);
+  }
+  if (lane < 50u) {
+    const uint32_t rr = lane / 10u, cc = lane % 10u;
+    L.G[lane] = L.cov[cc * 10u + rr];
+  }
+  if (lane < 5u) {
+    const float z[5] = {cbox.xc, cbox.yc, sa_kf_opt_angle(cbox), cbox.aspect, cbox.height};
+    L.innov[lane] = z[lane] - L.mean[lane];
+  }
+  SA_KF_SYNC();
+  if (lane < 10u) {  // solve_lower_triangular on the un-factorised covariance, one column per lane
+    const uint32_t c = lane;
+    for (int ii = 0; ii < 5; ++ii) {
+      const float coeff = L.G[ii * 10 + c] / L.P[ii * 5 + ii];
+      L.G[ii * 10 + c] = coeff;
+      const float nc = -coeff;
+      for (int rr = ii + 1; rr < 5; ++rr) L.G[rr * 10 + c] = nc * L.P[rr * 5 + ii] + L.G[rr * 10 + c];
+    }
+  }
+  SA_KF_SYNC();
+  if (lane < 10u) {
+    const uint32_t c = lane;
+    float acc = L.innov[0] * L.G[c];
+    for (int rr = 1; rr < 5; ++rr) acc = L.innov[rr] * L.G[rr * 10 + c] + acc;
+    L.nm[c] = L.mean[c] + acc;
+  }
+  if (lane < 50u) {
+    const uint32_t ii = lane / 5u, jj = lane % 5u;
+    float acc = L.G[ii] * L.P[jj];
+    for (int k = 1; k < 5; ++k) acc = L.G[k * 10 + ii] * L.P[k * 5 + jj] + acc;
+    L.gtp[lane] = acc;
+  }
+  SA_KF_SYNC();
+  for (uint32_t e = lane; e < 100u; e += 64u) {
+    const uint32_t ii = e / 10u, jj = e % 10u;
+    float acc = L.gtp[ii * 5u] * L.G[jj];
+    for (int k = 1; k < 5; ++k) acc = L.gtp[ii * 5u + k] * L.G[k * 10 + jj] + acc;
+    L.mc[e] = L.cov[e] - acc;   // (the new covariance)
+  }
+  SA_KF_SYNC();
+  // ---- state out
+  for (uint32_t e = lane; e < 110u; e += 64u) st[e] = e < 10u ? L.nm[e] : L.mc[e - 10u];
+  if (lane != 0) return;
+  // sa_kf_state_box + the observation's confidence; the track's row of the cost tables, exactly what k_prep_tracks derives from an upserted box
+  sa_box pred;
+  pred.xc = L.nm[0]; pred.yc = L.nm[1];
+  pred.has_angle = L.nm[2] == 0.0f ? 0 : 1;
+  pred.angle = L.nm[2];
+  pred.aspect = L.nm[3]; pred.height = L.nm[4];
+  pred.confidence = cbox.confidence;
+  pred.reserved = 0;
   sa_geo g;
   g.xc = pred.xc;
   g.yc = pred.yc;
@@ -46,11 +172,11 @@ __global__ __launch_bounds__(64) void k_apply_kalman(ApplyArgs a, SaParams p) {
   // between — the row holds the axis-aligned one)
   sa_vertices(pred.xc, pred.yc, pred.aspect, pred.height, 1.0, 0.0, a.verts + (size_t)row * 8);
   a.t_epoch[row] = a.epoch;
-  if (!merged) a.t_ids[row] = a.new_ids[i];
+  if (!merged) a.t_ids[row] = new_id;
   float mean5[5], cov25[25];
   for (int x = 0; x < 5; ++x) {
-    mean5[x] = s.mean[x];
-    for (int y = 0; y < 5; ++y) cov25[x * 5 + y] = s.cov[x * 10 + y];
+    mean5[x] = L.nm[x];
+    for (int y = 0; y < 5; ++y) cov25[x * 5 + y] = L.mc[x * 10 + y];
   }
   sa_maha_prepare(p.kf_position_weight, mean5, cov25, a.maha + (size_t)row * 20);
   a.out_pred[i] = pred;
@@ -70,7 +196,11 @@ hipError_t sa_launch_apply_polygons(const SaPolyFix* fix, uint32_t n, double* ve
   return hipGetLastError();
 }
 
-// One workgroup per candidate: the destination track's feature bank after optimize_observations.
+// One workgroup per candidate: the destination track's feature bank after optimize_observations.  The policy (which stored row ends up
+// in which slot) is a few dozen scalar operations of thread 0; the rows then move IN REGISTERS: thread x holds element x of all K stored
+// rows (K loads in flight together) and writes every slot's new content — one pass over the bank, no scratch copy and no second barrier
+// (the first version went row by row through a per-candidate scratch buffer: two dependent passes, ~20 us at 1000 candidates x 3 x 512).
+template <int KMAX>
 __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
   const uint32_t i = blockIdx.x;
   if (i >= a.n) return;
@@ -80,9 +210,13 @@ __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
   const uint32_t K = a.K, Dp = a.Dp, tid = threadIdx.x;
   const int32_t col = a.win_col[i];
   const bool merged = col >= 0;
-  const uint32_t row = merged ? (uint32_t)col : a.new_row[i];
+  uint32_t row;
+  if (merged) row = (uint32_t)col;
+  else if (a.new_row) row = a.new_row[i];
+  else {  // (rows drawn on the device: table rows T0 + rank among the candidates that start a track — every wave counts the same)
+    row = a.T0 + sa_rank_of_new(a.win_col, i, tid & 63u);
+  }
   float* bank = a.t_feat + (size_t)row * K * Dp;
-  float* tmp = a.tmp + (size_t)i * K * Dp;
   if (tid == 0) {
     const sa_box& b = a.c_raw[i].box;
     const bool has = a.c_feat && (!a.c_fpresent_in || a.c_fpresent_in[i]);
@@ -111,90 +245,63 @@ __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
     s_q[K] = q;  // quality of the new observation
   }
   __syncthreads();
-  // stored rows that move: through this candidate's scratch (the permutation is in place)
-  for (uint32_t k = 0; k < K; ++k) {
-    const uint32_t src = s_src[k];
-    if (src < SA_BANK_NEW && src != k)
-      for (uint32_t x = tid; x < Dp; x += 256) tmp[(size_t)k * Dp + x] = bank[(size_t)src * Dp + x];
-  }
-  __syncthreads();
-  uint32_t count = 0;
-  for (uint32_t k = 0; k < K; ++k) {
-    const uint32_t src = s_src[k];
-    float* dst = bank + (size_t)k * Dp;
-    bool pres = false;
-    float q = 0.0f, nrm = 0.0f;
-    if (src == SA_BANK_NEW) {
-      pres = s_newfeat != 0;
-      q = s_q[K];
-      nrm = pres ? a.c_fnorm[i] : 0.0f;
-      const float* cf = a.c_feat + (size_t)i * Dp;
-      for (uint32_t x = tid; x < Dp; x += 256) dst[x] = pres ? cf[x] : 0.0f;
-    } else if (src < SA_BANK_NEW) {
-      pres = true;
-      q = s_q[src];
-      nrm = s_nrm[src];
-      if (src != k)
-        for (uint32_t x = tid; x < Dp; x += 256) dst[x] = tmp[(size_t)k * Dp + x];
-    } else {
-      for (uint32_t x = tid; x < Dp; x += 256) dst[x] = 0.0f;
+  const bool new_pres = s_newfeat != 0;
+  const float* cf = a.c_feat ? a.c_feat + (size_t)i * Dp : nullptr;
+  uint32_t srcs[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) srcs[k] = (uint32_t)k < K ? s_src[k] : SA_BANK_NONE;
+  for (uint32_t x = tid; x < Dp; x += 256) {
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = (merged && (uint32_t)k < K) ? bank[(size_t)k * Dp + x] : 0.0f;   // (a new track's row: nothing stored yet)
+    const float nv = (new_pres && cf) ? cf[x] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if ((uint32_t)k >= K) continue;
+      const uint32_t src = srcs[k];
+      if (src == (uint32_t)k) continue;   // the row stays where it is
+      float out = 0.0f;                   // SA_BANK_NONE: an empty slot
+      if (src == SA_BANK_NEW) out = nv;
+      else {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) out = src == (uint32_t)j ? v[j] : out;
+      }
+      bank[(size_t)k * Dp + x] = out;
     }
-    if (tid == 0) {
+  }
+  if (tid == 0) {
+    uint32_t count = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+      const uint32_t src = s_src[k];
+      bool pres = false;
+      float q = 0.0f, nrm = 0.0f;
+      if (src == SA_BANK_NEW) { pres = new_pres; q = s_q[K]; nrm = pres ? a.c_fnorm[i] : 0.0f; }
+      else if (src < SA_BANK_NEW) { pres = true; q = s_q[src]; nrm = s_nrm[src]; }
       a.t_fpresent[(size_t)row * K + k] = pres ? 1 : 0;
       a.t_fquality[(size_t)row * K + k] = q;
       a.t_fnorm[(size_t)row * K + k] = nrm;
+      count += pres ? 1u : 0u;
     }
-    count += pres ? 1u : 0u;
+    a.t_fcount[row] = count;
   }
-  if (tid == 0) a.t_fcount[row] = count;
+}
+template <int KMAX>
+static void launch_bank(const BankArgs& b, hipStream_t st, hipEvent_t done) {
+  if (done) hipExtLaunchKernelGGL(k_apply_bank<KMAX>, dim3(b.n), dim3(256), 0, st, nullptr, done, 0, b);
+  else hipLaunchKernelGGL(k_apply_bank<KMAX>, dim3(b.n), dim3(256), 0, st, b);
 }
 
-// Where the tracks that START this frame go, decided on the device (sa_batch_run_apply: the upkeep queued right behind the assignment,
-// no host round trip for the winners): candidate i without a winner takes table row T0 + r and id id_base + 1 + (per_candidate ? i : r),
-// r = its rank among the scene's new tracks in candidate order — the order in which the reference draws ids (sort/simple_api.rs:
-// 165-187; Batch*: one id per candidate, batch_api.rs:102-106).  One workgroup, a running count over chunks of 1024 candidates.
-__global__ __launch_bounds__(1024) void k_apply_ids(const int32_t* __restrict__ win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate,
-                                                    uint32_t* __restrict__ new_row, uint64_t* __restrict__ new_ids, uint32_t* __restrict__ n_new_out) {
-  __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_base;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (uint32_t c0 = 0; c0 < n; c0 += 1024u) {
-    const uint32_t i = c0 + tid;
-    const bool fresh = i < n && win_col[i] < 0;
-    const unsigned long long m = __ballot(fresh);
-    const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t off = s_base, tot = 0;
-    for (uint32_t w = 0; w < 16; ++w) {
-      if (w < wave) off += s_w[w];
-      tot += s_w[w];
-    }
-    if (i < n) {
-      const uint32_t r = off + below;
-      new_row[i] = fresh ? T0 + r : SA_NONE;
-      new_ids[i] = fresh ? id_base + 1ull + (per_candidate ? (uint64_t)i : (uint64_t)r) : 0ull;
-    }
-    __syncthreads();
-    if (tid == 0) s_base += tot;
-    __syncthreads();
-  }
-  if (tid == 0) *n_new_out = s_base;
-}
-hipError_t sa_launch_apply_ids(const int32_t* win_col, uint32_t n, uint32_t T0, uint64_t id_base, int per_candidate, uint32_t* new_row, uint64_t* new_ids,
-                               uint32_t* n_new_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_ids, dim3(1), dim3(1024), 0, st, win_col, n, T0, id_base, per_candidate, new_row, new_ids, n_new_out);
-  return hipGetLastError();
-}
-
-hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st) {
+// done (optional): the step's LAST dispatch carries it as its own completion signal — a caller that waits for the step waits for the
+// event instead of synchronising the stream (a marker packet and its round trip through the command processor: ~10 us)
+hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done) {
   if (!a.n) return hipSuccess;
-  hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 64)), dim3(64), 0, st, a, p);
+  if (done && !b) hipExtLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, nullptr, done, 0, a, p);
+  else hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, a, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !b) return e;
-  hipLaunchKernelGGL(k_apply_bank, dim3(a.n), dim3(256), 0, st, *b);
+  if (b->K <= 4) launch_bank<4>(*b, st, done);
+  else if (b->K <= 8) launch_bank<8>(*b, st, done);
+  else launch_bank<SA_MAX_BANK>(*b, st, done);
   return hipGetLastError();
 }
 
