@@ -41,10 +41,9 @@ struct KfLds {
   float mean[10], sd[10], innov[5], nm[10];
   float cov[100], mc[100], P[25], G[50], gtp[50];
 };
-__global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p) {
-  __shared__ KfLds s_kf[4];
+__device__ __forceinline__ void kalman_block(const ApplyArgs& a, const SaParams& p, uint32_t blk, KfLds* s_kf) {
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  const uint32_t i = blockIdx.x * 4u + w;   // wave-uniform
+  const uint32_t i = blk * 4u + w;   // wave-uniform
   if (i >= a.n) return;
   KfLds& L = s_kf[w];
   const BoxRaw r = a.c_raw[i];
@@ -181,6 +180,10 @@ __global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p) {
   sa_maha_prepare(p.kf_position_weight, mean5, cov25, a.maha + (size_t)row * 20);
   a.out_pred[i] = pred;
 }
+__global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p) {
+  __shared__ KfLds s_kf[4];
+  kalman_block(a, p, blockIdx.x, s_kf);
+}
 
 // Polygons of the oriented boxes among the rows k_apply_kalman refreshed: cos / sin from the host's libm (sa_tracks_apply), geometry
 // from the row itself (height and aspect recovered would not be exact: the host sends the box).
@@ -200,13 +203,15 @@ hipError_t sa_launch_apply_polygons(const SaPolyFix* fix, uint32_t n, double* ve
 // in which slot) is a few dozen scalar operations of thread 0; the rows then move IN REGISTERS: thread x holds element x of all K stored
 // rows (K loads in flight together) and writes every slot's new content — one pass over the bank, no scratch copy and no second barrier
 // (the first version went row by row through a per-candidate scratch buffer: two dependent passes, ~20 us at 1000 candidates x 3 x 512).
+struct BankLds {
+  uint8_t src[SA_MAX_BANK];
+  float q[SA_MAX_BANK + 1], nrm[SA_MAX_BANK];  // q[K] = the new observation's quality (K may be SA_MAX_BANK)
+  uint32_t newfeat;
+};
 template <int KMAX>
-__global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
-  const uint32_t i = blockIdx.x;
+__device__ __forceinline__ void bank_block(const BankArgs& a, uint32_t i, BankLds& B) {
   if (i >= a.n) return;
-  __shared__ uint8_t s_src[SA_MAX_BANK];
-  __shared__ float s_q[SA_MAX_BANK + 1], s_nrm[SA_MAX_BANK];  // s_q[K] = the new observation's quality (K may be SA_MAX_BANK)
-  __shared__ uint32_t s_newfeat;
+  auto& s_src = B.src; auto& s_q = B.q; auto& s_nrm = B.nrm; uint32_t& s_newfeat = B.newfeat;
   const uint32_t K = a.K, Dp = a.Dp, tid = threadIdx.x;
   const int32_t col = a.win_col[i];
   const bool merged = col >= 0;
@@ -285,23 +290,36 @@ __global__ __launch_bounds__(256) void k_apply_bank(BankArgs a) {
     a.t_fcount[row] = count;
   }
 }
+// The whole upkeep of a VisualSORT frame in ONE launch: blocks [0, kf_blocks) take the Kalman steps (four candidates each, a wavefront
+// per candidate), the n blocks behind them the feature banks.  The two halves share nothing but the winners they read (the Kalman half
+// writes states, boxes, table rows; the bank half feature rows and their bookkeeping), so they run side by side — one dependent launch
+// (~4 us) and a serialisation less.  (Round 3 measured the merge with the one-thread-per-track Kalman step and dropped it: that code's
+// 110-float state in scratch made every block of the merged kernel slow; the wave-parallel step keeps its state in 1.4 KB of LDS.)
 template <int KMAX>
-static void launch_bank(const BankArgs& b, hipStream_t st, hipEvent_t done) {
-  if (done) hipExtLaunchKernelGGL(k_apply_bank<KMAX>, dim3(b.n), dim3(256), 0, st, nullptr, done, 0, b);
-  else hipLaunchKernelGGL(k_apply_bank<KMAX>, dim3(b.n), dim3(256), 0, st, b);
+__global__ __launch_bounds__(256) void k_apply_visual(ApplyArgs a, BankArgs b, SaParams p, uint32_t kf_blocks) {
+  __shared__ union { KfLds kf[4]; BankLds bank; } s_u;
+  if (blockIdx.x < kf_blocks) kalman_block(a, p, blockIdx.x, s_u.kf);
+  else bank_block<KMAX>(b, blockIdx.x - kf_blocks, s_u.bank);
+}
+template <int KMAX>
+static void launch_visual_apply(const ApplyArgs& a, const BankArgs& b, const SaParams& p, hipStream_t st, hipEvent_t done) {
+  const uint32_t kfb = cdiv(a.n, 4);
+  if (done) hipExtLaunchKernelGGL(k_apply_visual<KMAX>, dim3(kfb + b.n), dim3(256), 0, st, nullptr, done, 0, a, b, p, kfb);
+  else hipLaunchKernelGGL(k_apply_visual<KMAX>, dim3(kfb + b.n), dim3(256), 0, st, a, b, p, kfb);
 }
 
 // done (optional): the step's LAST dispatch carries it as its own completion signal — a caller that waits for the step waits for the
 // event instead of synchronising the stream (a marker packet and its round trip through the command processor: ~10 us)
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done) {
   if (!a.n) return hipSuccess;
-  if (done && !b) hipExtLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, nullptr, done, 0, a, p);
-  else hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, a, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !b) return e;
-  if (b->K <= 4) launch_bank<4>(*b, st, done);
-  else if (b->K <= 8) launch_bank<8>(*b, st, done);
-  else launch_bank<SA_MAX_BANK>(*b, st, done);
+  if (!b) {
+    if (done) hipExtLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, nullptr, done, 0, a, p);
+    else hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, a, p);
+    return hipGetLastError();
+  }
+  if (b->K <= 4) launch_visual_apply<4>(a, *b, p, st, done);
+  else if (b->K <= 8) launch_visual_apply<8>(a, *b, p, st, done);
+  else launch_visual_apply<SA_MAX_BANK>(a, *b, p, st, done);
   return hipGetLastError();
 }
 
