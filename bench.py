@@ -246,6 +246,21 @@ def pmc_traffic(workload: str, kernel: str):
     return best
 
 
+def launch_floor_us():
+    """What ONE dependent launch costs on this stack whatever it computes (scripts/micro/launch_floor.hip: an empty 1000-block kernel in a
+    chain of 200 launches on one stream), from the newest committed measurement profiles/r*_launch_floor.txt; None when there is none."""
+    import re
+
+    files = sorted((ROOT / "profiles").glob("r*_launch_floor.txt"))
+    if not files:
+        return None
+    for ln in files[-1].read_text().splitlines():
+        m = re.match(r"^empty\s+blocks\s+1000:\s+([0-9.]+) us per launch in a chain", ln)
+        if m:
+            return float(m.group(1)), files[-1].name
+    return None
+
+
 def rocprof_stats(workload: str):
     """Average kernel durations (us) of the rocprofv3 --kernel-trace --stats summary committed for this workload
     (profiles/r*_<workload>_kernel_stats.csv, the newest round wins): {engine kernel name: avg us}."""
@@ -568,6 +583,7 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive pass (value_h2d)")
     ap.add_argument("--cluster", type=int, default=0, help="single process: also time the workload's scenes through sa_cluster over this many shards (one engine per device; --cluster-devices to place several shards on one GPU)")
     ap.add_argument("--cluster-devices", default="", help="comma-separated HIP ordinals for --cluster (default 0..n-1)")
+    ap.add_argument("--gemm-plan", type=int, default=-1, help="pin the contraction's tile plan (sa_config.gemm_plan; tuning / A-B measurements)")
     ap.add_argument("--scenes", type=int, default=0, help="scene-set workloads (c2b, c2bk3, c3): scenes of the set — in all, split scene_id %% N under --gpus N (default 64 there, 8 at one GPU)")
     args = ap.parse_args()
 
@@ -618,6 +634,8 @@ def main():
     else:
         cfg.device = local_rank
         cfg.flags = DEFAULT_FLAGS if args.flags < 0 else args.flags
+        if args.gemm_plan >= 0:
+            cfg.gemm_plan = args.gemm_plan + 1
         eng = Engine(cfg)
         keep = stage(eng, cfg, scenes, scene_keys)
         cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
@@ -702,7 +720,7 @@ def main():
     else:
         eng.close()
         cfg_p = cfg
-        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & (abi.SA_FLAG_FUSED_FRAME | abi.SA_FLAG_SEPARATE_FRAME))  # same launches as the timed pass
+        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & ~(abi.SA_FLAG_GRAPH | abi.SA_FLAG_TAP))  # same launches as the timed pass
         engp = Engine(cfg_p)
         keep2 = stage(engp, cfg_p, scenes, scene_keys)
         for _ in range(5):
@@ -820,7 +838,7 @@ def main():
             euclid = cfg.visual_kind == abi.SA_VIS_EUCLIDEAN
             # euclidean engines run on the matrix cores too (expansion + flagged direct recompute) unless told otherwise or the
             # feature length rules it out (rho = 5e-3 sqrt(Dp) >= 1/3): then sub, mul, add per element on the vector pipe
-            eu_valu = euclid and (os.environ.get("SA_EUCLID") == "valu" or 5e-3 * ((cfg.feature_len + 31) // 32 * 32) ** 0.5 >= 1.0 / 3.0)
+            eu_valu = euclid and (bool(cfg.flags & abi.SA_FLAG_EUCLID_VALU) or 5e-3 * ((cfg.feature_len + 31) // 32 * 32) ** 0.5 >= 1.0 / 3.0)
             K = cfg.max_observations
             flops = sum((3.0 if eu_valu else 2.0) * len(s["det_boxes"]) * len(s["track_boxes"]) * K * cfg.feature_len for s in scenes)
             models["k_visual_cost"] = ("valu" if eu_valu else "mfma", flops)
@@ -920,6 +938,17 @@ def main():
         }
         if valu_f64:
             out["valu_f64"] = valu_f64
+        # Frames whose launches are chains of latencies, not streams (positional-only workloads: the dominant kernel has no matrix-core
+        # model and moves kilobytes): an HBM fraction of 0.005 says nothing — what such a frame costs is read against the floor of its
+        # dependent launches (an empty kernel in a chain: ~3 us each on this stack)
+        lf = launch_floor_us()
+        if lf is not None and roof is not None and roof.get("bound") == "hbm":
+            n_launch = sum(per_step(k) for k in gpu_kernels)
+            out["fixed_cost"] = {"frame_us": 1e3 * dt / args.steps, "launches_per_frame": n_launch, "launch_floor_us": lf[0],
+                                 "floor_of_the_frame_us": n_launch * lf[0], "above_the_floor_us": 1e3 * dt / args.steps - n_launch * lf[0],
+                                 "source": f"profiles/{lf[1]} (scripts/micro/launch_floor.hip: an empty 1000-block kernel, average of a chain of 200 dependent launches)",
+                                 "note": "positional launches and assignment tails are chains of dependent round trips (in-kernel timelines: profiles/r04_pos_trace_*.txt); "
+                                         "read the frame against its launch floor, not against HBM bandwidth"}
         if h2d is not None:
             out["h2d_inclusive"] = h2d
         if devf is not None:

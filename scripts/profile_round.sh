@@ -1,31 +1,35 @@
 #!/bin/bash
 # Round profile collection on the GPU box: rocprofv3 kernel stats of the default bench command (and of the other headline workloads),
-# bench lines of every workload, HBM-traffic PMC passes (separate --pmc runs with --kernel-trace only), MFMA utilisation counters.
+# bench lines of every workload, HBM-traffic PMC passes (separate --pmc runs with --kernel-trace only), MFMA utilisation counters, the
+# tracker loop, and — last, because they rebuild the library with the trace hooks — the in-kernel timelines.
 #   scripts/profile_round.sh <tag>        outputs under gpurun_out/<tag>/ — copy what is to be judged into profiles/
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-TAG=${1:-r03_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+TAG=${1:-r04_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 # 1. kernel stats: the DEFAULT command first (the driver's line), then the other workloads
-for w in c2 c5 c4 c3 c2k3 c2d giant sdt; do
+for w in c2 c2b c2t c5 c4 c3 c2k3 sdt; do
   extra="--workload $w --no-cpu-baseline --no-oracle --no-h2d"; [ "$w" = "c2" ] && extra="--no-cpu-baseline --no-oracle --no-h2d"
-  steps="--steps 50 --warmup 5"; [ "$w" = "c5" ] && steps="--steps 10 --warmup 2 --profile-iters 5"; [ "$w" = "giant" ] && steps="--steps 5 --warmup 1 --profile-iters 3"
+  steps="--steps 50 --warmup 5"; [ "$w" = "c5" ] && steps="--steps 10 --warmup 2 --profile-iters 5"; [ "$w" = "c2b" ] && steps="--steps 20 --warmup 3 --profile-iters 10"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o bench -- python $OLDPWD/bench.py $steps $extra > $O/prof_$w.log 2>&1)
-  f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_kernel_stats.csv && echo "== $w" && head -6 $O/${w}_kernel_stats.csv | cut -c1-200
+  f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_kernel_stats.csv && echo "== $w" && head -5 $O/${w}_kernel_stats.csv | cut -c1-160
   rm -rf $O/prof_$w
 done
 # 2. bench lines (the default one with its CPU baselines)
 timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 exit $?"
-for w in c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd sdt giant bigpile bigcrowd; do
-  st=""; [ "$w" = "c5" ] && st="--steps 20 --warmup 3 --profile-iters 10"
+for w in c2b c2bk3 c2t c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd sdt giant bigpile bigcrowd; do
+  st=""; [ "$w" = "c5" ] && st="--steps 20 --warmup 3 --profile-iters 10"; [ "$w" = "c2b" -o "$w" = "c2bk3" ] && st="--steps 50 --warmup 5 --profile-iters 10"
   timeout 600 python bench.py --workload $w --no-cpu-baseline $st > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w exit $?"
 done
 timeout 300 python bench.py --flags 32 --no-cpu-baseline > $O/bench_c2_separate.json 2> $O/bench_c2_separate.err
-# 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes)
-for w in c2 c5 c4; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
-# 4. MFMA utilisation of the contraction (C2 default line and C5)
-for w in c2 c5; do
-  extra="--workload $w"; st="--steps 30 --warmup 5"; [ "$w" = "c5" ] && st="--steps 8 --warmup 2 --profile-iters 4"
+timeout 300 python bench.py --flags 16384 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2_xcd_tiles.json 2> $O/bench_c2_xcd_tiles.err
+timeout 300 python bench.py --workload c2b --gemm-plan 1 --steps 50 --warmup 5 --profile-iters 10 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2b_fused64.json 2> $O/bench_c2b_fused64.err
+# 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes); C2 also with the XCD-aware tile order
+for w in c2 c2b c5 c4; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
+SA_BENCH_FLAGS=16384 bash scripts/pmc_traffic.sh c2 ${TAG}_c2xcd > $O/pmc_traffic_c2_xcd_tiles.log 2>&1; cp gpurun_out/pmc_${TAG}_c2xcd/summary.json $O/pmc_traffic_c2_xcd_tiles.json 2>/dev/null
+# 4. MFMA utilisation of the contraction (C2 default line, c2b and C5)
+for w in c2 c2b c5; do
+  extra="--workload $w"; st="--steps 30 --warmup 5"; [ "$w" = "c5" ] && st="--steps 8 --warmup 2 --profile-iters 4"; [ "$w" = "c2b" ] && st="--steps 10 --warmup 2 --profile-iters 4"
   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$w -o p -- \
      python $OLDPWD/bench.py $extra $st --no-cpu-baseline --no-oracle --no-h2d > $O/pmc_mfma_$w.log 2>&1)
   python - "$O/pmc_mfma_$w" "$O/mfma_util_$w.json" <<'PY'
@@ -46,6 +50,9 @@ print({k: round(v.get("mfma_busy_over_sq_busy", 0), 3) for k, v in out.items()})
 PY
   rm -rf $O/pmc_mfma_$w
 done
-# 5. the tracker loop
-timeout 300 python scripts/bench_tracker.py 1000 512 30 > $O/tracker_loop.jsonl 2> $O/tracker_loop.err; cat $O/tracker_loop.jsonl
+# 5. the tracker loop (plain and churned) and where a predict() spends its time
+timeout 600 python scripts/bench_tracker.py 1000 512 30 > $O/tracker_loop.jsonl 2> $O/tracker_loop.err; cat $O/tracker_loop.jsonl
+bash scripts/tracker_trace.sh "visual,device,0.0" "visual,pinned,0.0" "sort,rows,0.0" "visual,device,0.05" "sort,rows,0.05" > $O/tracker_breakdown.txt 2>&1; cat $O/tracker_breakdown.txt
+# 6. in-kernel timelines (rebuilds the library with -DSA_POS_TRACE -DSA_GEMM_TRACE) + the launch floor
+bash scripts/gpu_trace.sh ${TAG}_trace "c4 c3 c1" "c2 c2t" > $O/trace.log 2>&1; cp gpurun_out/${TAG}_trace/*.txt $O/ 2>/dev/null; tail -45 $O/trace.log
 echo DONE

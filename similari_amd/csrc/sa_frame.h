@@ -305,22 +305,39 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   // The screen: 16 cells per thread (4 candidate rows of this wave x NSUB tracks of this lane).  It is VALU THROUGHPUT, not latency:
   // every co-resident tile of a CU is in this phase at the same time (in-kernel timeline, scripts/pos_trace.sh: 4.0 k cycles of a C4
   // tile's 18 k — 4 M cells x ~15 instructions over the chip's 1024 SIMDs — whatever the survivors' path costs: appending them per wave
-  // with one ballot and a scalar branch per step instead of this divergent branch was measured at 4.8 k).
+  // with one ballot and a scalar branch per step instead of this divergent branch was measured at 4.8 k).  So the cells are made
+  // cheaper: too_far() (bbox.rs:452-462) of TWO candidate rows against the lane's track in packed f32 arithmetic (v_pk_add / v_pk_mul:
+  // two cells per instruction; every element is still subtract, multiply, multiply, add, compare in the reference's order — no fused
+  // multiply-add — so each cell's verdict is bit for bit the scalar one), and compatible()'s epoch test once per TRACK.
+  typedef float pf2 __attribute__((ext_vector_type(2)));
+  pf2 cgx[2], cgy[2], cgr[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const sa_geo g0 = s_cg[wave * 4 + 2 * h], g1 = s_cg[wave * 4 + 2 * h + 1];
+    cgx[h] = pf2{g0.xc, g1.xc}; cgy[h] = pf2{g0.yc, g1.yc}; cgr[h] = pf2{g0.r, g1.r};
+  }
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) {
     const uint32_t lj = s * 64 + lane, j = j0 + lj;
+    const pf2 tx = pf2{tg[s].xc, tg[s].xc}, ty = pf2{tg[s].yc, tg[s].yc}, tr = pf2{tg[s].r, tg[s].r};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t li = wave * 4 + r, i = i0 + li;
-      bool live = false;
-      if (i < N && j < T) {
-        const sa_geo cg = s_cg[li];
-        live = !sa_too_far(cg, tg[s]) && sa_compatible(cg, epoch, tg[s], te[s], p.max_idle, p.cons);
-        if (DENSE && !live) S.pos[(size_t)i * T + j] = nanv;
-      }
-      if (live) {
-        uint32_t slot = atomicAdd(&s_cnt, 1u);
-        s_list[slot] = (uint16_t)((li << 8) | lj);
+    for (int h = 0; h < 2; ++h) {
+      // sa_too_far: max_distance = l.r + r.r; x = l.xc - r.xc, y = l.yc - r.yc; x * x + y * y > max_distance * max_distance
+      const pf2 md = cgr[h] + tr, x = cgx[h] - tx, y = cgy[h] - ty;
+      const pf2 d2 = x * x + y * y, m2 = md * md;
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int r = 2 * h + q2;
+        const uint32_t li = wave * 4 + r, i = i0 + li;
+        bool live = false;
+        if (i < N && j < T) {
+          live = !(d2[q2] > m2[q2]) && sa_compatible(s_cg[li], epoch, tg[s], te[s], p.max_idle, p.cons);
+          if (DENSE && !live) S.pos[(size_t)i * T + j] = nanv;
+        }
+        if (live) {
+          uint32_t slot = atomicAdd(&s_cnt, 1u);
+          s_list[slot] = (uint16_t)((li << 8) | lj);
+        }
       }
     }
   }
