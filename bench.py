@@ -667,6 +667,23 @@ def main():
         step_s = max(0.0, (dt4 - dt) / (3.0 * args.steps)) or dt / args.steps
     else:
         step_s = dt / args.steps  # a region of 50 ms and more: the fixed cost is below a tenth of a percent
+    # per-kernel durations: hipEvents stamped with each dispatch's own begin / end on the engine's stream (hipExtLaunchKernelGGL; the
+    # events release to the DEVICE, like the plain pipeline's dispatches), on the SAME engine and staged inputs, right behind the timed
+    # regions — the GPU in the state the timed loop left it in (a second engine after seconds of CPU-side work read 1 us more per launch
+    # of the fused first phase: clocks and caches of an idle device) — and after them, so that the timed regions stay free of instrumentation
+    def profile_pass():
+        eng.profile_enable(True)
+        for _ in range(5):
+            eng.batch_run()
+        eng.batch_sync()
+        eng.profile_reset()
+        for _ in range(args.profile_iters):
+            eng.batch_run()
+        eng.batch_sync()
+        pr = eng.profile_read()
+        eng.profile_enable(False)
+        return pr
+    prof = profile_pass()
     if dist is not None:
         cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -702,36 +719,12 @@ def main():
         devf, devf_ids = h2d_pipelined(eng, cfg, scenes, max(args.steps, 50), feats_on_device=True, keys=scene_keys)
         devf["matches_resident_run"] = bool(all(np.array_equal(a, g[0]) for a, g in zip(devf_ids, got)))
 
-    # per-kernel durations: hipEvents stamped with each dispatch's own begin / end on the engine's stream (hipExtLaunchKernelGGL),
-    # same staged inputs, separate pass so that the timed region above stays free of instrumentation
+    # (the per-kernel durations were taken right after the timed regions, on the same engine: see profile_pass above)
     if facade is not None:
-        eng.profile_enable(True)
-        for _ in range(5):
-            eng.batch_run()
-        eng.batch_sync()
-        eng.profile_reset()
-        for _ in range(args.profile_iters):
-            eng.batch_run()
-        eng.batch_sync()
-        prof = eng.profile_read()
-        eng.profile_enable(False)
         eng.close()
         facade.close()
     else:
         eng.close()
-        cfg_p = cfg
-        cfg_p.flags = abi.SA_FLAG_PROFILE | (cfg.flags & ~(abi.SA_FLAG_GRAPH | abi.SA_FLAG_TAP))  # same launches as the timed pass
-        engp = Engine(cfg_p)
-        keep2 = stage(engp, cfg_p, scenes, scene_keys)
-        for _ in range(5):
-            engp.batch_run()
-        engp.batch_sync()
-        engp.profile_reset()
-        for _ in range(args.profile_iters):
-            engp.batch_run()
-        engp.batch_sync()
-        prof = engp.profile_read()
-        engp.close()
 
     # N > 1: the request set of ALL ranks from ONE ingest point (rank 0) through the scene scatter / result gather north_star names
     # (similari_amd.sharding.ShardedAssociator: one scatter of packed shares, one sa_associate_batch per rank, one gather), inside

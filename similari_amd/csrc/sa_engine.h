@@ -234,6 +234,16 @@ struct SaCopySegs {
 hipError_t sa_launch_ingest(const SaCopySegs& segs, uint32_t blocks, hipStream_t st, hipEvent_t done = nullptr);
 hipError_t sa_launch_gather_rows(const void* src, void* dst, const uint32_t* index, uint32_t rows, uint32_t row_bytes,
                                  hipStream_t st);
+// all arrays of a track table compacted in one launch (sa_tracks_remove): dst[a][r] = src[a][index[r]]
+#define SA_TABLE_ARRAYS 12
+struct SaGatherTable {
+  const void* src[SA_TABLE_ARRAYS];
+  void* dst[SA_TABLE_ARRAYS];
+  uint32_t row_bytes[SA_TABLE_ARRAYS];
+  uint32_t n_arrays, rows;
+  const uint32_t* index;   // [rows] device-visible (mapped pinned memory)
+};
+hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st);
 
 // first launch of a frame: positional tiles + frame-preparation blocks
 // prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame on the one-workgroup tail), 2 = preparation

@@ -41,7 +41,15 @@ struct SceneTable {
   uint64_t scene_id = 0;
   uint32_t T = 0, cap = 0;
   std::vector<uint64_t> ids;                       // slot -> id
-  std::unordered_map<uint64_t, uint32_t> slot_of;  // id -> slot
+  // id -> slot.  A caller that hands out increasing ids (gen_track_id: every tracker of the reference) keeps `ids` ascending, and the
+  // lookup is a binary search; the hash map exists only for tables whose ids arrived out of order (built on first use, kept in step
+  // afterwards) — so appending a row or compacting the table does not touch a hash map at all.
+  bool ascending = true;
+  bool map_built = false;
+  std::unordered_map<uint64_t, uint32_t> slot_of;
+  DevBuf spare[SA_TABLE_ARRAYS];                   // sa_tracks_remove compacts the table into these and swaps (no allocation per call)
+  HostBuf h_index;                                 // ... the kept rows' old indices (mapped pinned memory the gather kernel reads in place)
+  void* d_index = nullptr;
   DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
   DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
   std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
@@ -368,6 +376,31 @@ int scene_reserve(sa_engine* e, SceneTable* s, uint32_t need) {
   }
   s->cap = ncap;
   return SA_OK;
+}
+
+// id -> row of the scene's table (false: no such track)
+bool find_slot(SceneTable* sc, uint64_t id, uint32_t* out) {
+  if (sc->ascending) {
+    auto it = std::lower_bound(sc->ids.begin(), sc->ids.end(), id);
+    if (it == sc->ids.end() || *it != id) return false;
+    if (out) *out = (uint32_t)(it - sc->ids.begin());
+    return true;
+  }
+  if (!sc->map_built) {
+    sc->slot_of.clear();
+    for (uint32_t s = 0; s < (uint32_t)sc->ids.size(); ++s) sc->slot_of[sc->ids[s]] = s;
+    sc->map_built = true;
+  }
+  auto it = sc->slot_of.find(id);
+  if (it == sc->slot_of.end()) return false;
+  if (out) *out = it->second;
+  return true;
+}
+// a new row at the end of the table (the caller has checked that the id is new)
+void append_id(SceneTable* sc, uint64_t id) {
+  if (sc->ascending && !sc->ids.empty() && id < sc->ids.back()) sc->ascending = false;  // (find_slot builds the map when it is next needed)
+  if (!sc->ascending && sc->map_built) sc->slot_of[id] = (uint32_t)sc->ids.size();
+  sc->ids.push_back(id);
 }
 
 Slot* get_slot(Bank* b, uint32_t i) {
@@ -987,6 +1020,8 @@ void sa_engine_destroy(sa_engine* e) {
   for (auto& kv : e->scenes) {
     SceneTable* s = kv.second;
     for (DevBuf* b : {&s->geo, &s->ext, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
+    for (DevBuf& b : s->spare) free_dev(b);
+    free_host(s->h_index);
     delete s;
   }
   for (Bank& bk : e->banks) {
@@ -1050,12 +1085,11 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
   std::vector<uint32_t> slots(n);
   uint32_t T = sc->T;
   for (uint32_t i = 0; i < n; ++i) {
-    auto it = sc->slot_of.find(t->ids[i]);
-    if (it != sc->slot_of.end()) slots[i] = it->second;
+    uint32_t at;
+    if (find_slot(sc, t->ids[i], &at)) slots[i] = at;
     else {
       slots[i] = T;
-      sc->slot_of[t->ids[i]] = T;
-      sc->ids.push_back(t->ids[i]);
+      append_id(sc, t->ids[i]);
       ++T;
     }
   }
@@ -1129,6 +1163,11 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
   return engine_sync(e);
 }
 
+// Rows leave, the others close ranks IN ORDER (the column order is part of the solvers' tie-breaks).  Cheap enough to be called every
+// few frames by a tracker that evicts the tracks its frames can no longer match (sa_tracker.cpp): every array of the table is compacted
+// into a spare of the same capacity by ONE gather launch on the compute stream and swapped in — no allocation, no host copy of table
+// data, no synchronisation (whatever reads the table next is ordered behind the launch); the kept rows' old indices travel through a
+// mapped pinned buffer the kernel reads in place; ascending ids need no hash map (find_slot).
 int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
   if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove: null argument");
   TRY(finish_applies(e));
@@ -1138,60 +1177,53 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
   HIPCHK(e, hipSetDevice(e->device));
   std::vector<uint8_t> drop(sc->T, 0);
   for (uint32_t i = 0; i < n; ++i) {
-    auto it = sc->slot_of.find(ids[i]);
-    if (it == sc->slot_of.end()) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[i]);
-    drop[it->second] = 1;
+    uint32_t at;
+    if (!find_slot(sc, ids[i], &at)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[i]);
+    drop[at] = 1;
   }
-  std::vector<uint32_t> keep;
-  std::vector<uint64_t> nids;
-  for (uint32_t s = 0; s < sc->T; ++s)
-    if (!drop[s]) { keep.push_back(s); nids.push_back(sc->ids[s]); }
-  const uint32_t nT = (uint32_t)keep.size();
-  TRY(engine_sync(e));
-  if (nT) {
-    TRY(dev_ensure(e, e->up_index, (size_t)nT * 4));
-    HIPCHK(e, hipMemcpy(e->up_index.p, keep.data(), (size_t)nT * 4, hipMemcpyHostToDevice));
-    struct Arr { DevBuf* b; uint32_t row; };
-    const uint32_t K = e->K;
-    std::vector<Arr> arrs = {{&sc->geo, (uint32_t)sizeof(sa_geo)}, {&sc->ext, (uint32_t)sizeof(sa_ext)}, {&sc->verts, 64u}, {&sc->epoch, 8u}, {&sc->maha, 80u}, {&sc->tids, 8u},
-                             {&sc->kf, 440u}};
-    if (e->visual) {
-      arrs.push_back({&sc->feat, K * e->Dp * 4u});
-      arrs.push_back({&sc->fnorm, K * 4u});
-      arrs.push_back({&sc->fpresent, K});
-      arrs.push_back({&sc->fcount, 4u});
-      arrs.push_back({&sc->fquality, K * 4u});
-    }
-    // every new array is built before any is swapped in: a failure half-way leaves the table as it was
-    std::vector<DevBuf> fresh(arrs.size());
-    int rc = SA_OK;
-    for (size_t k = 0; k < arrs.size() && rc == SA_OK; ++k) {
-      rc = dev_ensure(e, fresh[k], arrs[k].b->cap);
-      if (rc == SA_OK && sa_launch_gather_rows(arrs[k].b->p, fresh[k].p, (const uint32_t*)e->up_index.p, nT, arrs[k].row, e->stream) != hipSuccess)
-        rc = fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
-    }
-    if (rc != SA_OK) {
-      hipStreamSynchronize(e->stream);
-      for (DevBuf& b : fresh) if (b.p) hipFree(b.p);
-      return rc;
-    }
-    for (size_t k = 0; k < arrs.size(); ++k) {
-      e->garbage.push_back({arrs[k].b->p, e->next_ticket});
-      *arrs[k].b = fresh[k];
-    }
-  }
+  // (the index buffer of the previous call must have been consumed: calls on one engine are serial and the gather is short — only a
+  // second removal queued right behind the first would find it in flight)
+  if (!e->synced) TRY(compute_sync(e));
   {
-    std::vector<uint8_t> nfull;
-    sc->full.resize(sc->T, 0);
-    for (uint32_t s2 : keep) nfull.push_back(sc->full[s2]);
-    sc->full = nfull;
+    void* before = sc->h_index.p;
+    TRY(host_ensure(e, sc->h_index, (size_t)(sc->T ? sc->T : 1) * 4));
+    if (sc->h_index.p != before || !sc->d_index) HIPCHK(e, hipHostGetDevicePointer(&sc->d_index, sc->h_index.p, 0));
+  }
+  uint32_t* keep = (uint32_t*)sc->h_index.p;
+  uint32_t nT = 0;
+  sc->full.resize(sc->T, 0);
+  for (uint32_t s = 0; s < sc->T; ++s)
+    if (!drop[s]) {
+      keep[nT] = s;
+      sc->ids[nT] = sc->ids[s];
+      sc->full[nT] = sc->full[s];
+      ++nT;
+    }
+  if (nT) {
+    const uint32_t K = e->K;
+    DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
+    const uint32_t rowb[SA_TABLE_ARRAYS] = {(uint32_t)sizeof(sa_geo), (uint32_t)sizeof(sa_ext), 64u, 8u, 80u, 8u, 440u, K * e->Dp * 4u, K * 4u, K, 4u, K * 4u};
+    const uint32_t na = e->visual ? SA_TABLE_ARRAYS : 7u;
+    SaGatherTable g{};
+    g.n_arrays = na; g.rows = nT; g.index = (const uint32_t*)sc->d_index;
+    for (uint32_t k = 0; k < na; ++k) {
+      if (sc->spare[k].cap < arrs[k]->cap || !sc->spare[k].p) {
+        if (sc->spare[k].p) e->garbage.push_back({sc->spare[k].p, e->next_ticket});
+        sc->spare[k] = DevBuf{};
+        TRY(dev_ensure(e, sc->spare[k], arrs[k]->cap));
+      }
+      g.src[k] = arrs[k]->p; g.dst[k] = sc->spare[k].p; g.row_bytes[k] = rowb[k];
+    }
+    if (sa_launch_gather_table(g, e->stream) != hipSuccess)
+      return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
+    for (uint32_t k = 0; k < na; ++k) std::swap(*arrs[k], sc->spare[k]);   // (the old arrays are next call's spares: nothing queued reads them after the gather)
   }
   sc->T = nT;
-  sc->ids = nids;
-  sc->slot_of.clear();
-  for (uint32_t s = 0; s < nT; ++s) sc->slot_of[nids[s]] = s;
+  sc->ids.resize(nT);
+  sc->full.resize(nT);
+  sc->map_built = false;   // (tables whose ids are not ascending rebuild their map on the next lookup)
   SA_BUSY(e);
-  return engine_sync(e);
+  return SA_OK;
 }
 
 int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n) {
@@ -1642,7 +1674,7 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
   for (uint32_t i = 0; i < n; ++i) {
     if (winners[i] == 0) {
       if (!new_ids || new_ids[i] == 0) return fail(e, SA_ERR_BAD_ARG, "candidate %u starts a track and needs new_ids[%u] > 0", i, i);
-      if (sc->slot_of.count(new_ids[i])) return fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)new_ids[i]);
+      if (find_slot(sc, new_ids[i], nullptr)) return fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)new_ids[i]);
       ++n_new;
     } else {
       const int32_t c = wcol[i];
@@ -1682,8 +1714,7 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
   // host side of the table: the new rows
   for (uint32_t i = 0; i < n; ++i)
     if (winners[i] == 0) {
-      sc->slot_of[new_ids[i]] = (uint32_t)sc->ids.size();
-      sc->ids.push_back(new_ids[i]);
+      append_id(sc, new_ids[i]);
     }
   sc->T = T0 + n_new;
   sc->full.resize(sc->T, 1);  // (the winners' rows held a full state already: checked above)
@@ -1775,9 +1806,8 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
       const uint64_t id = s->fused_id_base + 1ull + (s->fused_per_candidate ? (uint64_t)i : (uint64_t)r);
       h_row[i] = T0 + r;
       ++r;
-      if (sc->slot_of.count(id)) bad = fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)id);
-      sc->slot_of[id] = (uint32_t)sc->ids.size();
-      sc->ids.push_back(id);
+      if (find_slot(sc, id, nullptr)) bad = fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)id);
+      append_id(sc, id);
       if (out_ids) out_ids[i] = id;
     } else {
       h_row[i] = SA_NONE;
@@ -1885,11 +1915,11 @@ int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mea
   TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
-  auto it = sc->slot_of.find(id);
-  if (it == sc->slot_of.end()) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
+  uint32_t found_row = 0;
+  if (!find_slot(sc, id, &found_row)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
   HIPCHK(e, hipSetDevice(e->device));
   TRY(engine_sync(e));
-  const uint32_t r = it->second, K = e->K;
+  const uint32_t r = found_row, K = e->K;
   if (mean10) HIPCHK(e, hipMemcpy(mean10, (float*)sc->kf.p + (size_t)r * 110, 40, hipMemcpyDeviceToHost));
   if (cov100) HIPCHK(e, hipMemcpy(cov100, (float*)sc->kf.p + (size_t)r * 110 + 10, 400, hipMemcpyDeviceToHost));
   if (e->visual) {
@@ -1907,11 +1937,11 @@ int sa_tracks_set_state(sa_engine* e, uint64_t scene_id, uint64_t id, const floa
   TRY(finish_applies(e));
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
-  auto it = sc->slot_of.find(id);
-  if (it == sc->slot_of.end()) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
+  uint32_t found_row = 0;
+  if (!find_slot(sc, id, &found_row)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)id);
   HIPCHK(e, hipSetDevice(e->device));
   TRY(engine_sync(e));
-  const uint32_t r = it->second, K = e->K;
+  const uint32_t r = found_row, K = e->K;
   HIPCHK(e, hipMemcpy((float*)sc->kf.p + (size_t)r * 110, mean10, 40, hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy((float*)sc->kf.p + (size_t)r * 110 + 10, cov100, 400, hipMemcpyHostToDevice));
   if (e->visual && quality) HIPCHK(e, hipMemcpy((float*)sc->fquality.p + (size_t)r * K, quality, (size_t)K * 4, hipMemcpyHostToDevice));

@@ -102,6 +102,30 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restri
   }
 }
 
+// sa_tracks_remove: row r of every array of a scene's track table := its old row index[r], all arrays in ONE launch (one block per kept row)
+__global__ __launch_bounds__(256) void k_gather_table(SaGatherTable g) {
+  const uint32_t row = blockIdx.x;
+  if (row >= g.rows) return;
+  const uint32_t from = g.index[row];
+  for (uint32_t a = 0; a < g.n_arrays; ++a) {
+    const uint32_t rb = g.row_bytes[a];
+    const uint8_t* s = (const uint8_t*)g.src[a] + (size_t)from * rb;
+    uint8_t* d = (uint8_t*)g.dst[a] + (size_t)row * rb;
+    if ((rb & 15u) == 0) {
+      for (uint32_t k = threadIdx.x; k < rb / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k];
+    } else if ((rb & 3u) == 0) {
+      for (uint32_t k = threadIdx.x; k < rb / 4; k += 256) ((uint32_t*)d)[k] = ((const uint32_t*)s)[k];
+    } else {
+      for (uint32_t k = threadIdx.x; k < rb; k += 256) d[k] = s[k];
+    }
+  }
+}
+hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st) {
+  if (!g.rows || !g.n_arrays) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_table, dim3(g.rows), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+
 // Once per (re)allocation of a slot's assignment state: what the tail kernels afterwards leave behind every frame.
 __global__ void k_slot_init(uint32_t* e_cnt, int64_t* u, uint32_t n_rows, uint32_t* parent, uint32_t n_vertices) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

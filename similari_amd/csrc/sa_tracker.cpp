@@ -65,6 +65,7 @@ struct Track {
   int64_t custom = 0;
   int32_t voting = -1;  // VisualAttributes::voting_type: None
   bool has_state = false;
+  bool in_engine = true;   // false: evicted from the engine's table (it can never match again) but not wasted yet
   KF kf;
   Ring predicted, observed;
   std::vector<Obs> obs;
@@ -86,6 +87,13 @@ struct sa_tracker {
   // removals close the gaps on both sides, so the winner the engine reports as a COLUMN (sa_batch_fetch_cols) is rows[column] —
   // no lookup by id on the per-candidate path
   std::map<uint64_t, std::vector<Track*>> by_scene;
+  // Eviction.  A track whose last update lies more than max_idle_epochs behind its scene's epoch fails compatible() (sort.rs:250-270) for
+  // every later frame — epochs only grow — but the reference keeps it in the store until the next auto_waste (every 100th predict by
+  // default), and so would the engine's table: at 5 % churn a 1000-object VisualSORT loop associates against 6 700 rows instead of
+  // 1 200.  The facade therefore takes such tracks out of the ENGINE's table as soon as they are a sixteenth of it (sa_tracks_remove:
+  // one gather launch), and keeps them in its own store — idle_tracks / wasted see them as before.
+  std::map<uint64_t, std::vector<uint64_t>> row_epoch;   // scene -> last_updated_epoch of by_scene's rows, in the same order (the scan's input)
+  std::map<uint64_t, std::vector<Track*>> evicted;       // scene -> tracks out of the engine's table, still in `store`
   std::vector<Track> wasted_store;
   uint32_t waste_counter = 0;
 };
@@ -143,11 +151,20 @@ int auto_waste(sa_tracker* t) {
   }
   for (auto& kv : gone) {
     std::sort(kv.second.begin(), kv.second.end());
-    int rc = sa_tracks_remove(t->eng, kv.first, (uint32_t)kv.second.size(), kv.second.data());
+    std::vector<uint64_t> resident;   // those the engine's table still holds (the others were evicted from it earlier)
+    for (uint64_t id : kv.second)
+      if (t->store[id].in_engine) resident.push_back(id);
+    int rc = resident.empty() ? SA_OK : sa_tracks_remove(t->eng, kv.first, (uint32_t)resident.size(), resident.data());
     if (rc != SA_OK) return tfail(t, rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
     auto& rows = t->by_scene[kv.first];
-    rows.erase(std::remove_if(rows.begin(), rows.end(), [&](const Track* tr) { return std::binary_search(kv.second.begin(), kv.second.end(), tr->id); }),
-               rows.end());
+    auto& eps = t->row_epoch[kv.first];
+    size_t w = 0;
+    for (size_t r = 0; r < rows.size(); ++r)
+      if (!std::binary_search(kv.second.begin(), kv.second.end(), rows[r]->id)) { rows[w] = rows[r]; eps[w] = eps[r]; ++w; }
+    rows.resize(w);
+    eps.resize(w);
+    auto& ev = t->evicted[kv.first];
+    ev.erase(std::remove_if(ev.begin(), ev.end(), [&](const Track* tr) { return std::binary_search(kv.second.begin(), kv.second.end(), tr->id); }), ev.end());
     for (uint64_t id : kv.second) {
       t->wasted_store.push_back(std::move(t->store[id]));
       t->store.erase(id);
@@ -333,6 +350,27 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       }
     }
   }
+  // eviction (see sa_tracker::row_epoch): tracks of these scenes that no frame from now on can match leave the engine's table
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    auto& rows = t->by_scene[scene_ids[s]];
+    auto& eps = t->row_epoch[scene_ids[s]];
+    const uint64_t cur = epoch[s];
+    size_t expired = 0;
+    for (uint64_t ep : eps) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
+    if (expired < 16 || expired * 16 < rows.size()) continue;
+    std::vector<uint64_t> out_ids;
+    out_ids.reserve(expired);
+    auto& ev = t->evicted[scene_ids[s]];
+    size_t w = 0;
+    for (size_t r = 0; r < rows.size(); ++r) {
+      if (eps[r] + o.max_idle_epochs < cur) { out_ids.push_back(rows[r]->id); rows[r]->in_engine = false; ev.push_back(rows[r]); }
+      else { rows[w] = rows[r]; eps[w] = eps[r]; ++w; }
+    }
+    rows.resize(w);
+    eps.resize(w);
+    int rce = sa_tracks_remove(t->eng, scene_ids[s], (uint32_t)out_ids.size(), out_ids.data());
+    if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
+  }
   const auto t_built = clk::now();
   double us_apply = 0.0;
   // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
@@ -419,14 +457,18 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
           tr.feat_count = c.has_feat ? 1 : 0;
         }
         rows.push_back(trp);
+        t->row_epoch[scene].push_back(epoch[s]);
       } else {
         // the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
         const int32_t col = wcols[s][i];
-        if (col >= 0 && (size_t)col < rows_before && rows[col]->id == dest) trp = rows[col];
+        std::vector<uint64_t>& eps = t->row_epoch[scene];
+        if (col >= 0 && (size_t)col < rows_before && rows[col]->id == dest) { trp = rows[col]; eps[col] = epoch[s]; }
         else {
           auto it = t->store.find(dest);
           if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
           trp = &it->second;
+          for (size_t r = 0; r < rows.size(); ++r)
+            if (rows[r] == trp) { eps[r] = epoch[s]; break; }
         }
         Track& tr = *trp;
         // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215
@@ -586,8 +628,9 @@ int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out,
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_idle_tracks: null argument");
   // IdleLookup  sort.rs:213-228: same scene and last_updated_epoch != current epoch
   uint32_t n = 0;
-  auto it = t->by_scene.find(scene_id);
-  if (it != t->by_scene.end())
+  for (const auto* m : {&t->by_scene, &t->evicted}) {   // (evicted tracks are idle tracks like any other until they are wasted)
+    auto it = m->find(scene_id);
+    if (it == m->end()) continue;
     for (const Track* trp : it->second) {
       const Track& tr = *trp;
       if (tr.epoch != current_epoch(t, scene_id)) {
@@ -595,6 +638,7 @@ int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out,
         ++n;
       }
     }
+  }
   *out_n = n;
   return SA_OK;
 }
