@@ -3,6 +3,8 @@ visual_sort/simple_api.rs:328-666) are ported literally and run against
   * the oracle's tracker loops (CPU, always) — this pins the oracle's orchestration on the reference's expectations,
   * the product facade on the GPU (marked gpu) — same assertions, so the parity tests read like the reference's.
 Then the product is compared frame by frame with the oracle on seeded multi-frame sequences."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -447,3 +449,57 @@ def test_device_bank_equals_host_policy_bank():
     finally:
         h.close()
         g.close()
+
+
+@pytest.mark.gpu
+@UPKEEP
+@pytest.mark.parametrize("kind", ["sort", "visual"])
+def test_churned_loop_with_eviction_matches_oracle(kind, backend):
+    """Objects leave and enter every frame (max_idle_epochs 2, auto-waste only every 100th predict): the facade takes the tracks that
+    can no longer match out of the ENGINE's table as soon as they are a sixteenth of it (sa_tracks_remove: the table closes ranks in
+    order) while keeping them in its store — frame by frame the same tracks as the oracle's tracker, which keeps everything until
+    auto_waste as the reference does; idle_tracks and wasted still see the evicted ones; the engine's table stays near the live set."""
+    rng = np.random.default_rng(404 + (kind == "visual"))
+    n, d = 220, 32
+    if kind == "visual":
+        # (cosine 0.9: random non-negative 32-d features sit at ~0.64 of each other — a lower threshold lets new objects revive idle tracks)
+        opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.9))
+                .positional_metric(IoU(0.3)).visual_minimal_track_length(1).visual_max_observations(2).visual_min_votes(1))
+        g, o = make(backend, "visual", opts=opts, feature_len=d), make("oracle", "visual", opts=opts, feature_len=d)
+    else:
+        kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
+        g, o = make(backend, "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        pool = n + 14 * 30
+        world = synth.dense_boxes(rng, pool, (2600.0, 1800.0))
+        ident = synth.reid_identities(rng, pool, d)
+        active = np.arange(n)
+        fresh = n
+        rows_seen = []
+        for f in range(14):
+            world = synth.jitter_boxes(rng, world, 1.5)
+            if f:
+                gone = rng.choice(n, 24, replace=False)           # ~11 % of the objects leave, as many enter
+                active[gone] = np.arange(fresh, fresh + 24)
+                fresh += 24
+            boxes = boxes_to_u2d(world[active])
+            if kind == "visual":
+                feats = synth.observe(rng, ident[active], 0.01)
+                items = [TR.VisualSortObservation(feats[k], 0.9, boxes[k], None) for k in range(n)]
+            else:
+                items = [(boxes[k], None) for k in range(n)]
+            rg, ro = g.predict(items), o.predict(items)
+            assert_tracks_equal(rg, ro)
+            cnt = C.c_uint32()
+            g.lib.sa_tracks_count(g.lib.sa_tracker_engine(g.h), 0, C.byref(cnt))
+            rows_seen.append(int(cnt.value))
+            if f % 4 == 3:
+                assert_tracks_equal(sorted(g.idle_tracks_with_scene(0), key=lambda x: x.id), sorted(o.idle_tracks_with_scene(0), key=lambda x: x.id))
+        # eviction happened: the engine's table holds the live set + the recently idle tracks, not everything since frame 0
+        assert g.active_tracks() == o.active_tracks()   # (the store: evicted tracks included, until they are wasted)
+        assert rows_seen[-1] < n + 6 * 24, rows_seen
+        assert max(rows_seen) > n, rows_seen
+        assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+    finally:
+        g.close()
+        o.close()
