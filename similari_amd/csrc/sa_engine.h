@@ -243,7 +243,7 @@ struct SaGatherTable {
   uint32_t n_arrays, rows;
   const uint32_t* index;   // [rows] device-visible (mapped pinned memory)
 };
-hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st);
+hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st, hipEvent_t done = nullptr);
 
 // first launch of a frame: positional tiles + frame-preparation blocks
 // prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame on the one-workgroup tail), 2 = preparation

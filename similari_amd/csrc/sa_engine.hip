@@ -167,6 +167,16 @@ struct sa_engine {
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
   uint64_t busy_seq = 0;             // counts the enqueues since the engine was created (SA_BUSY): "nothing was queued since event X" is a comparison
+  // The LAST thing queued carried a completion event of its own (the upkeep's last dispatch, the gather of sa_tracks_remove): draining the
+  // engine is then one event wait — a stream synchronisation costs a marker packet's trip through the command processor (~10 us) even
+  // when the queue has long been idle.  Valid while busy_seq == tail_seq.
+  hipEvent_t tail_ev = nullptr;
+  uint64_t tail_seq = 0;
+  hipEvent_t ev_misc = nullptr;      // (the event sa_tracks_remove's gather carries)
+  uint64_t gather_seq = 0;           // busy_seq right after sa_tracks_remove's gather, when the engine was drained before it (0: n/a): while it
+                                     // equals busy_seq the ONLY thing in flight is that gather, which touches the scene's table and its own
+                                     // index buffer — staging the next request set need not wait for it (only_gather_in_flight)
+  bool copy_dirty = false;           // something was queued on the copy stream since the last full synchronisation: the tail event says nothing about it
   // device buffers that were replaced while work that may still read them was queued: freed at the next full sync, or — pipelined
   // loops never reach one — by sa_pipe_wait once every ticket issued before the replacement has been waited for (tag = the ticket
   // number that was next when the buffer was replaced)
@@ -245,11 +255,20 @@ int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
     if (_r != SA_OK) return _r;  \
   } while (0)
 
+// nothing but sa_tracks_remove's gather is in flight: entry points that only stage HOST buffers (the arena of the next request set) skip
+// the "busy monitor" wait — the launches they queue are ordered behind the gather on the compute stream anyway
+static inline bool only_gather_in_flight(const sa_engine* e) { return !e->synced && e->gather_seq != 0 && e->gather_seq == e->busy_seq && !e->copy_dirty; }
 // what a drained engine owes: replaced buffers freed, open profile records resolved
 int engine_idle(sa_engine* e);
 int engine_sync(sa_engine* e) {
+  if (e->tail_ev && e->tail_seq == e->busy_seq && !e->synced && !e->copy_dirty) {  // the last enqueue signals an event of its own: wait for that
+    hipError_t we = hipEventSynchronize(e->tail_ev);
+    if (we == hipSuccess) return engine_idle(e);
+    (void)hipGetLastError();
+  }
   if (e->copy_stream) HIPCHK(e, hipStreamSynchronize(e->copy_stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->copy_dirty = false;
   return engine_idle(e);
 }
 int engine_idle(sa_engine* e) {
@@ -588,7 +607,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   for (uint32_t i = 0; i < ns; ++i) fill_scene_dev(e, b, b->slots[i], &bd[i]);
   const bool same_descs = b->desc_off == desc_off && b->desc_last.size() == dbytes && dbytes && std::memcmp(b->desc_last.data(), build.data(), dbytes) == 0;
   if (b->uploaded && same_descs) return SA_OK;
-  if (may_be_busy && !e->synced) TRY(engine_sync(e));
+  if (may_be_busy && !e->synced && !only_gather_in_flight(e)) TRY(engine_sync(e));
   uint8_t* h = (uint8_t*)b->h_arena.p;
   std::memcpy(h + desc_off, build.data(), dbytes);
   b->desc_off = desc_off;
@@ -984,6 +1003,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   }
   hipEventCreate(&e->ev_t0);
   hipEventCreate(&e->ev_t1);
+  if (hipEventCreate(&e->ev_misc) != hipSuccess) { (void)hipGetLastError(); e->ev_misc = nullptr; }
   {
     // the copy stream at the highest priority the device offers: its few ingest workgroups should be dispatched ahead of the
     // compute stream's thousands, or the DMA of the next request set queues behind the current set's tiles
@@ -1053,6 +1073,7 @@ void sa_engine_destroy(sa_engine* e) {
   free_host(e->up_host);
   for (auto& r : e->prof_open) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
+  if (e->ev_misc) hipEventDestroy(e->ev_misc);
   if (e->ev_t0) hipEventDestroy(e->ev_t0);
   if (e->ev_t1) hipEventDestroy(e->ev_t1);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
@@ -1183,7 +1204,7 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
   }
   // (the index buffer of the previous call must have been consumed: calls on one engine are serial and the gather is short — only a
   // second removal queued right behind the first would find it in flight)
-  if (!e->synced) TRY(compute_sync(e));
+  if (!e->synced) TRY(engine_sync(e));
   {
     void* before = sc->h_index.p;
     TRY(host_ensure(e, sc->h_index, (size_t)(sc->T ? sc->T : 1) * 4));
@@ -1214,15 +1235,17 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
       }
       g.src[k] = arrs[k]->p; g.dst[k] = sc->spare[k].p; g.row_bytes[k] = rowb[k];
     }
-    if (sa_launch_gather_table(g, e->stream) != hipSuccess)
+    if (sa_launch_gather_table(g, e->stream, e->ev_misc) != hipSuccess)
       return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
     for (uint32_t k = 0; k < na; ++k) std::swap(*arrs[k], sc->spare[k]);   // (the old arrays are next call's spares: nothing queued reads them after the gather)
+    SA_BUSY(e);
+    if (e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
+    e->gather_seq = e->busy_seq;   // (the engine was drained right before this launch: nothing else is in flight)
   }
   sc->T = nT;
   sc->ids.resize(nT);
   sc->full.resize(nT);
   sc->map_built = false;   // (tables whose ids are not ascending rebuild their map on the next lookup)
-  SA_BUSY(e);
   return SA_OK;
 }
 
@@ -1264,7 +1287,7 @@ int sa_batch_begin(sa_engine* e) {
   // "busy monitor": the previous batch must have drained (sort/batch_api.rs:233-241).  (Known drained already — the last thing queued was
   // waited for through its own completion event, fused_collect —: no stream synchronisation, which would cost a marker packet's round
   // trip through the command processor, ~10 us, even on an idle queue.)
-  if (!e->synced) TRY(engine_sync(e));
+  if (!e->synced && !only_gather_in_flight(e)) TRY(engine_sync(e));
   e->B_ticket = 0;      // the synchronous entry points own e->B from here on
   bank_clear(e->B);
   return SA_OK;
@@ -1532,6 +1555,7 @@ int sa_pipe_stage(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req, 
   const bool small_inline = moved <= (128u << 10);
   b->staged_inline = !e->copy_stream || small_inline;
   hipStream_t cs = b->staged_inline ? e->stream : e->copy_stream;
+  if (!b->staged_inline) e->copy_dirty = true;
   if (b->staged_inline) {
     TRY(bank_upload(e, b, cs, false));
   } else {
@@ -1786,7 +1810,7 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
     if (ob && ob->apply_event) {
       hipError_t we = hipEventSynchronize(ob->ev_apply);
       if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
-      if (e->busy_seq == ob->apply_seq) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
+      if (e->busy_seq == ob->apply_seq && !e->copy_dirty) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
     } else TRY(engine_sync(e));
   }
   const auto tc1 = std::chrono::steady_clock::now();
@@ -1891,7 +1915,7 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
     bool last = true;
     for (uint32_t j = i + 1; j < b->n_slots; ++j) last = last && b->slots[j]->N == 0;
     TRY(apply_launch(e, s, nullptr, nullptr, last ? b->ev_apply : nullptr));
-    if (last) { b->apply_event = true; b->apply_seq = e->busy_seq; }
+    if (last) { b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq; }
     s->fused_pending = true;
   }
   return SA_OK;

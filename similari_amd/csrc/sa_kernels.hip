@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void k_gather_table(SaGatherTable g) {
     }
   }
 }
-hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st) {
+hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st, hipEvent_t done) {
   if (!g.rows || !g.n_arrays) return hipSuccess;
-  hipLaunchKernelGGL(k_gather_table, dim3(g.rows), dim3(256), 0, st, g);
+  if (done) hipExtLaunchKernelGGL(k_gather_table, dim3(g.rows), dim3(256), 0, st, nullptr, done, 0, g);   // (carries its own completion signal)
+  else hipLaunchKernelGGL(k_gather_table, dim3(g.rows), dim3(256), 0, st, g);
   return hipGetLastError();
 }
 
