@@ -303,7 +303,7 @@ struct BankArgs {
   uint32_t T0;
   uint32_t n, K, Dp;
   const float* c_feat;       // [n][Dp] padded candidate features (nullptr: the frame carried none)
-  const float* c_fnorm;
+  const float* c_fnorm;       // (nullptr: the frame ran lean — the step forms the new rows' norms itself; only with D == Dp)
   const uint8_t* c_fpresent_in;
   const float* c_quality;
   const float* c_own;

@@ -757,6 +757,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
     maxN = s->N > maxN ? s->N : maxN;
     maxT = s->T > maxT ? s->T : maxT;
   }
+  if (maxN >= (1u << 24)) return fail(e, SA_ERR_UNSUPPORTED, "a scene brings %u detections: fewer than 2^24 per scene (the assignment's queue entries)", maxN);
   if (maxT > 32768u) return fail(e, SA_ERR_UNSUPPORTED, "a scene holds %u tracks: at most 32768 per scene (the assignment's column keys)", maxT);
   for (uint32_t i = 0; i < ns; ++i) TRY(slot_reserve(e, b->slots[i], b->slots[i]->N, b->slots[i]->T));
   // Euclidean engines: the matrix-core path unless a recent frame reported itself ill-conditioned for the expansion (most of its
@@ -1662,7 +1663,7 @@ static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const ui
   BankArgs b{};
   if (e->visual) {
     b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.T0 = a.T0; b.n = n; b.K = e->K; b.Dp = e->Dp;
-    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = (const float*)s->fnorm.p;
+    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = s->prepped ? (const float*)s->fnorm.p : nullptr;   // (a lean frame: D == Dp, the step forms the norms of the rows it stores)
     b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
     b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
     b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
@@ -1689,7 +1690,7 @@ int sa_tracks_apply_begin(sa_engine* e, uint32_t slot, const uint64_t* new_ids) 
   const uint32_t n = s->N;
   if (!n) return SA_OK;
   if (s->T != sc->T) return fail(e, SA_ERR_STATE, "the scene's track table changed since the slot ran");
-  if (e->visual) TRY(ensure_prepped(e, e->B));  // the feature-bank step reads the candidates' padded rows and norms
+  if (e->visual && e->D != e->Dp) TRY(ensure_prepped(e, e->B));  // the feature-bank step reads the candidates' PADDED rows (rows that need no padding: it reads them where they were uploaded)
   const uint64_t* winners = (const uint64_t*)s->h_out.p;
   // the same winners as rows of the table (written next to the ids by the assignment tail): no lookup by id per candidate
   const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
@@ -1889,7 +1890,8 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
     sc->full.resize(sc->T, 0);
     TRY(scene_reserve(e, sc, sc->T + s->N));
   }
-  b->want_prep = true;   // the feature-bank step reads the candidates' padded rows and norms: the preparation blocks ride in this frame
+  b->want_prep = e->D != e->Dp;   // the feature-bank step reads the candidates' PADDED rows: the preparation blocks ride in this frame (rows that
+                                  // need no padding are read where they were uploaded, their norms formed by the step itself: the frame stays lean)
   int rc = SA_OK;
   if (b->n_slots) {
     // (run_pipeline, with the end of the ASSOCIATION marked on the stream: the frame's last dispatch carries ev_done as its completion

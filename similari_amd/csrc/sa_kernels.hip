@@ -471,9 +471,81 @@ static void sa_tail_trace_hook(hipStream_t st, uint32_t ns) {
     fclose(f);
   }
 }
+// ... and of the many-workgroup tail's second kernel (SA_SOLVE_TRACE=<launch #>): per workgroup of scene 0, the 100 MHz clock every XCD
+// shares at  0 entry | 1 own rows done | 2 mid-sized components served (own tickets) | 3 big components served | 5 exit ;
+// [6] = big << 32 | mid components of the scene ; [7] = big << 32 | mid components THIS workgroup took.
+__device__ unsigned long long* g_solve_buf;
+#define SOLVE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.z == 0 && g_solve_buf && blockIdx.x < 512) g_solve_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SOLVE_NOTE(k, v) do { if (threadIdx.x == 0 && blockIdx.z == 0 && g_solve_buf && blockIdx.x < 512) g_solve_buf[blockIdx.x * 8 + (k)] = (v); } while (0)
+// (the workgroup's FIRST mid-sized component, second half of the buffer: 0 taken | 1 rows listed | 2 columns hashed | 3 ranked | 4 matrix filled |
+//  5 searched | 6 results out | [7] = rows << 32 | columns)
+#define MID_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.z == 0 && g_solve_buf && blockIdx.x < 512 && g_solve_buf[4096 + blockIdx.x * 8 + (k)] == 0) g_solve_buf[4096 + blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MID_NOTE(k, v) do { if (threadIdx.x == 0 && blockIdx.z == 0 && g_solve_buf && blockIdx.x < 512 && g_solve_buf[4096 + blockIdx.x * 8 + (k)] == 0) g_solve_buf[4096 + blockIdx.x * 8 + (k)] = (v); } while (0)
+static unsigned long long* g_solve_host = nullptr;
+static int g_solve_calls = 0;
+static void sa_solve_trace_before(hipStream_t st) {
+  const char* env = getenv("SA_SOLVE_TRACE");
+  if (!env) return;
+  if (++g_solve_calls != atoi(env)) return;
+  hipStreamSynchronize(st);
+  hipMalloc(&g_solve_host, 64 * 1024);
+  hipMemset(g_solve_host, 0, 64 * 1024);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_solve_buf), &g_solve_host, sizeof g_solve_host);
+  hipDeviceSynchronize();
+}
+static void sa_solve_trace_after(hipStream_t st, uint32_t wgs) {
+  const char* env = getenv("SA_SOLVE_TRACE");
+  if (!env || g_solve_calls != atoi(env) || !g_solve_host) return;
+  hipStreamSynchronize(st);
+  unsigned long long* nul = nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_solve_buf), &nul, sizeof nul);
+  std::vector<unsigned long long> h(8 * 1024);
+  hipMemcpy(h.data(), g_solve_host, 64 * 1024, hipMemcpyDeviceToHost);
+  g_solve_host = nullptr;
+  if (wgs > 512) wgs = 512;
+  if (FILE* f = fopen("gpurun_out/solve_trace.txt", "a")) {
+    unsigned long long t0 = ~0ull;
+    for (uint32_t w = 0; w < wgs; ++w) if (h[w * 8] && h[w * 8] < t0) t0 = h[w * 8];
+    fprintf(f, "== k_assign_solve: %u workgroups, scene 0: %llu big + %llu mid-sized components; us after the first workgroup's entry (10 ns ticks), percentiles 10 / 50 / 90 / max\n",
+            wgs, h[6] >> 32, h[6] & 0xffffffffull);
+    const char* names[6] = {"entry", "own rows done", "mid-sized served (own tickets)", "big components served", "", "exit"};
+    for (int k = 0; k < 6; ++k) {
+      std::vector<double> v;
+      for (uint32_t w = 0; w < wgs; ++w) if (h[w * 8 + k]) v.push_back((double)(h[w * 8 + k] - t0) / 100.0);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      fprintf(f, "   %-28s %7.2f / %7.2f / %7.2f / %7.2f   (%zu workgroups)\n", names[k], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+    }
+    {
+      const char* mn[7] = {"taken", "rows listed", "columns hashed", "ranked", "matrix filled", "searched", "results out"};
+      fprintf(f, "   a workgroup's first mid-sized component, us since it was taken, percentiles 10 / 50 / 90 / max:\n");
+      for (int k = 1; k < 7; ++k) {
+        std::vector<double> v;
+        for (uint32_t w = 0; w < wgs; ++w) if (h[4096 + w * 8 + k] && h[4096 + w * 8]) v.push_back((double)(h[4096 + w * 8 + k] - h[4096 + w * 8]) / 100.0);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        fprintf(f, "      %-16s %7.2f / %7.2f / %7.2f / %7.2f   (%zu)\n", mn[k], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+      }
+      std::vector<double> rr, cc;
+      for (uint32_t w = 0; w < wgs; ++w) if (h[4096 + w * 8 + 7]) { rr.push_back((double)(h[4096 + w * 8 + 7] >> 32)); cc.push_back((double)(h[4096 + w * 8 + 7] & 0xffffffffull)); }
+      if (!rr.empty()) { std::sort(rr.begin(), rr.end()); std::sort(cc.begin(), cc.end());
+        fprintf(f, "      rows %g / %g / %g / %g   columns %g / %g / %g / %g\n", rr[rr.size() / 10], rr[rr.size() / 2], rr[rr.size() * 9 / 10], rr.back(), cc[cc.size() / 10], cc[cc.size() / 2], cc[cc.size() * 9 / 10], cc.back()); }
+    }
+    unsigned long long mx_mid = 0, mx_big = 0;
+    for (uint32_t w = 0; w < wgs; ++w) { mx_mid = std::max(mx_mid, h[w * 8 + 7] & 0xffffffffull); mx_big = std::max(mx_big, h[w * 8 + 7] >> 32); }
+    fprintf(f, "   most components one workgroup took: %llu big, %llu mid-sized\n", mx_big, mx_mid);
+    fclose(f);
+  }
+}
 #else
 #define TAIL_STAMP(k) do { } while (0)
+#define SOLVE_STAMP(k) do { } while (0)
+#define SOLVE_NOTE(k, v) do { } while (0)
+#define MID_STAMP(k) do { } while (0)
+#define MID_NOTE(k, v) do { } while (0)
 static inline void sa_tail_trace_hook(hipStream_t, uint32_t) {}
+static inline void sa_solve_trace_before(hipStream_t) {}
+static inline void sa_solve_trace_after(hipStream_t, uint32_t) {}
 #endif
 
 // One 1024-thread workgroup per scene: edge lists -> LDS, components, solve, results.  The solver's duals / matches / search
@@ -1097,6 +1169,7 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
   __shared__ uint32_t s_mk[4];
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the solver's queues: top of its row lists | queue length | next ticket | row workgroups done
+  if (q < S.N) ((uint32_t SA_G*)S.dq)[S.N + q] = SA_NONE;  // the queue of mid-sized components: an entry that is not SA_NONE has LANDED (k_assign_solve serves it at once)
   sa_label_phase(S, WORDS, q, gridDim.x * blockDim.x, s_mk, 256u);
 }
 
@@ -1164,36 +1237,42 @@ __device__ __forceinline__ void sa_wave_sync() {
 // A big component's root onto the scene's queue.  The entry must have LANDED before this workgroup reports its rows done: a plain
 // (even atomic) store may still be in flight when the workgroup's barrier lets thread 0 signal — a returning exchange has been
 // performed at the coherence point when its result arrives, and using the result makes the wave wait for it.
-__device__ __forceinline__ void sa_queue_push(const SceneDev& S, uint32_t root, bool mid) {
+// A mid-sized entry carries the component's row count with the root ((R << 24) | root, R <= ML_R): its taker needs no second trip for it.
+__device__ __forceinline__ void sa_queue_push(const SceneDev& S, uint32_t root, bool mid, uint32_t R) {
   const uint32_t at = atomicAdd((uint32_t*)(S.stats + (mid ? SA_QW_MLEN : SA_QW_LEN)), 1u) + (mid ? S.N : 0u);  // (dq: [N] big | [N] mid-sized)
-  const uint32_t old = __hip_atomic_exchange((uint32_t*)S.dq + at, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t old = __hip_atomic_exchange((uint32_t*)S.dq + at, mid ? ((R << 24) | root) : root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" ::"v"(old));
 }
 template <bool VISUAL>
 __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t root, uint32_t R, MidLocal& M) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t N = S.N;
-  // rows, ascending: the labels from the root on (it is the component's lowest row), eight loads in flight per lane
+  MID_STAMP(0);
+  // rows, ascending: the labels from the root on (it is the component's lowest row), sixteen loads in flight per lane (a frame of up to
+  // 1024 detections: one trip)
+  // ... and their usable-edge counts in the SAME trip (a second one otherwise: what the label kernel wrote lies in memory, ~1.5 us away)
   uint32_t cnt = 0;
   {
-    for (uint32_t r0 = root; r0 < N && cnt < R; r0 += 512) {
-      uint32_t lb8[8];
+    for (uint32_t r0 = root; r0 < N && cnt < R; r0 += 1024) {
+      uint32_t lb8[16], ne8[16];
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
+      for (int k2 = 0; k2 < 16; ++k2) {
         const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
         lb8[k2] = row < N ? S.lab[row] : SA_NONE;
+        ne8[k2] = row < N ? S.e_use[row] : 0u;
       }
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
+      for (int k2 = 0; k2 < 16; ++k2) {
         const uint32_t row = r0 + (uint32_t)k2 * 64u + lane;
         const bool f = row < N && lb8[k2] == root;
         const unsigned long long m = __ballot(f);
         const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (f && at < ML_R) M.rows[at] = row;
+        if (f && at < ML_R) { M.rows[at] = row; M.roots[at] = ne8[k2]; }   // (roots: free until the greedy start)
         cnt += (uint32_t)__popcll(m);
       }
     }
   }
+  MID_STAMP(1);
   if (cnt != R || R > ML_R) return false;  // (labels and count disagree: not this tier's to sort out — wave-uniform, both from ballots / SGPRs)
 #pragma unroll
   for (int h = 0; h < ML_H / 64; ++h) M.hkey[lane + 64u * (uint32_t)h] = SA_NONE;
@@ -1203,7 +1282,7 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   sa_wave_sync();
   // pass 1 over the edges (lane = row): the distinct usable columns into the hash table
   const uint32_t row = lane < R ? M.rows[lane] : 0u;
-  const uint32_t ne = lane < R ? S.e_use[row] : 0u;
+  const uint32_t ne = lane < R ? M.roots[lane] : 0u;
   const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
   for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
     SaEdge ed[4];
@@ -1232,6 +1311,8 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   sa_wave_sync();
   if (__builtin_amdgcn_readfirstlane((int)M.fail)) return false;  // (one word, every lane reads the same: uniform for the compiler too)
   const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.ncols);
+  MID_STAMP(2);
+  MID_NOTE(7, ((unsigned long long)R << 32) | C);
   const uint32_t ldc = C <= 128u ? 128u : 256u;   // the matrix: [R][128], or [R][256] when the rows allow it
   if (R * ldc > ML_CELLS) return false;
   // the columns in ascending order of their track index: the occupied slots compacted, every key ranked among them
@@ -1265,6 +1346,7 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
     M.cols[rank] = key;
   }
   sa_wave_sync();
+  MID_STAMP(3);
   // pass 2: gains into the matrix, the row's dual and its bid (heaviest usable edge, lowest column on ties)
   int32_t maxg = 0, bj = -1;
   for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
@@ -1301,6 +1383,14 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   const unsigned long long pm = __ballot(pend);
   if (pend) M.roots[__popcll(pm & ((1ull << lane) - 1ull))] = lane;
   const uint32_t n_roots = (uint32_t)__popcll(pm);
+  MID_STAMP(4);
+  // the ids of the component's columns, requested now: they arrive while the search runs
+  uint64_t cid_r[ML_C / 64];
+#pragma unroll
+  for (int h = 0; h < ML_C / 64; ++h) {
+    const uint32_t j = lane + 64u * (uint32_t)h;
+    cid_r[h] = j < C ? S.t_ids[M.cols[j]] : 0ull;
+  }
   sa_wave_sync();
   if (n_roots) {
     sa_dense_ws w;
@@ -1309,11 +1399,25 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
     if (ldc == 128u) sa_assign_component_dense<64, 2, true, true>(w, M.roots, n_roots);
     else sa_assign_component_dense<64, 4, true, true>(w, M.roots, n_roots);
   }
+  MID_STAMP(5);
+  // results: a row of a component carries no visual verdict (k_assign_label leaves those out of the lists), so its answer is its column
+  // — whose id was requested before the search (cid_r) and went through LDS, over the hash table that pass 2 was the last to read
+  uint64_t* const cid = (uint64_t*)M.hkey;   // [ML_C] ids over hkey | hval (2 x ML_H words)
+  static_assert(ML_C * 8 <= 2 * ML_H * 4, "the columns' ids lie over the hash table");
+#pragma unroll
+  for (int h = 0; h < ML_C / 64; ++h)
+    if (lane + 64u * (uint32_t)h < C) cid[lane + 64u * (uint32_t)h] = cid_r[h];
+  sa_wave_sync();
   if (lane < R) {
     const int32_t c = M.rmatch[lane];
-    finalize_row_with<VISUAL>(S, row, c >= 0 ? (int32_t)M.cols[c] : -1);
+    const int32_t win = c >= 0 ? (int32_t)M.cols[c] : -1;
+    S.out_track_id[row] = c >= 0 ? cid[c] : 0ull;
+    S.out_vote[row] = c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+    S.win_col[row] = win;
+    S.out_win[row] = win;
   }
   sa_wave_sync();
+  MID_STAMP(6);
   return true;
 }
 // One big component by the dense solver of sa_dense.h, all NT threads of the workgroup on it.  rows ascending (ballot compaction of
@@ -1473,6 +1577,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   __shared__ unsigned long long s_part[2 * (NT / 64)];
   __shared__ uint32_t s_pool_top, s_word[6], s_fail[NT], s_nfail[ML_WAVES];
   extern __shared__ unsigned char s_dyn[];
+  SOLVE_STAMP(0);
   if (threadIdx.x == 0) s_pool_top = 0;
   if (threadIdx.x < ML_WAVES) s_nfail[threadIdx.x] = 0;
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
@@ -1495,6 +1600,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   }
   __syncthreads();
   bool big = false, mid = false;
+  uint32_t mid_R = 0;
   if (q < S.N) {
     // Everything a one-row component needs, requested TOGETHER: what the previous kernels wrote lies in other XCDs' L2s, so each
     // dependent load of this thread is a trip to memory (~1.5 us); the row's first four edge records are fetched before their count
@@ -1692,7 +1798,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
             finalize_row_with<VISUAL>(S, L.rows[r], c >= 0 ? (int32_t)L.colmap[c] : -1);
           }
         } else if (pair_done) {
-        } else if (R <= ML_R && !no_mid) mid = true;
+        } else if (R <= ML_R && !no_mid) { mid = true; mid_R = R; }
         else big = true;
       }
     }
@@ -1702,23 +1808,96 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   // scene — the row workgroups and the helpers launched behind them — takes big components by ticket (all its threads on one
   // component), then its first two wavefronts take mid-sized ones by ticket, and at the end the workgroup finishes what its own
   // wavefronts had to refuse.  (The wait is for workgroups dispatched EARLIER in the same grid, which never wait themselves.)
+  SOLVE_STAMP(1);
   if (row_wg) {
-    if (big) sa_queue_push(S, q, false);
-    if (mid) sa_queue_push(S, q, true);
+    if (big) sa_queue_push(S, q, false, 0u);
+    if (mid) sa_queue_push(S, q, true, mid_R);
     // (queue entries and counters are agent-scope atomics: no cache maintenance — an agent-scope fence by every thread here costs
     // 10 us at C4; everything else the takers read was written by earlier launches)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_DONE), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (threadIdx.x == 0) {
-    while (__hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs) __builtin_amdgcn_s_sleep(4);
-    s_word[3] = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_word[4] = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const uint32_t nbig = s_word[3], nmid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_word[4]);
-  if (nbig == 0 && nmid == 0) return;
+  // Middle tier first, AS THE ENTRIES ARRIVE: the first wavefront(s) of every workgroup take tickets of the mid-sized queue and serve
+  // entry k the moment it has landed (k_assign_label left SA_NONE in every slot) — a crowd's knots are being solved while the slowest
+  // row workgroup is still on its pairs (in-kernel timeline of a tracker loop's crowd frame: the last row workgroup was through 11 us
+  // after the first one entered, and the wait for it was time no knot was worked on).  A ticket beyond the queue's end is known as such
+  // once every row workgroup has reported (SA_QW_DONE) and the slot still holds SA_NONE: the pushes of a workgroup are performed
+  // (returning exchanges) before its report.
+  // Everything in this loop is wave-uniform BY CONSTRUCTION — the ticket is taken without a branch (lane 0 adds one, the others zero),
+  // indices go through readfirstlane, a refusal is recorded by every lane writing the same word: a lane-divergent branch before the
+  // back edge lets the compiler keep the two groups of lanes apart across iterations, and the group without lane 0 then never sees a
+  // new ticket (seen: a refusal pushed by `if (lane == 0)` inside such a loop hung the workgroup).
   const uint32_t N = S.N, T = S.T;
+  [[maybe_unused]] uint32_t took_big = 0, took_mid = 0;
+  uint32_t nbig_seen = SA_NONE;  // wave 0: the length of the big queue, read once every row workgroup had reported (SA_NONE: not seen yet)
+  if (!no_mid) {
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t nref = 0;
+    if (wv < ML_WAVES) {
+      // Before the first ticket: is there a mid-sized component at all?  (A frame without one — most tracking frames — leaves here at the
+      // price of the old wait: the report count and the two queue lengths, no ticket, no slot.)
+      bool any = false;
+      for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+        const uint32_t ml = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t d = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        any = __builtin_amdgcn_readfirstlane((int)ml) != 0;
+        if (any) break;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d) >= row_wgs) {  // every push has been performed: the lengths are final
+          const uint32_t ml2 = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t l2 = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same trip)
+          any = __builtin_amdgcn_readfirstlane((int)ml2) != 0;
+          nbig_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)l2);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      while (any && nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront takes no more tickets — the other workgroups' do)
+        const uint32_t tk = atomicAdd((uint32_t*)(S.stats + SA_QW_MTICKET), (threadIdx.x & 63u) == 0 ? 1u : 0u);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        if (k >= N) break;  // (at most one mid-sized component per row)
+        uint32_t ent = SA_NONE;
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {  // (bounded: ~1 s; a slot that never fills and a report that never comes is a bug, not a hang)
+          const uint32_t v = __hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t d = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+          if (ent != SA_NONE) break;
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d) >= row_wgs) {  // every push has been performed: what the slot holds now is final
+            const uint32_t v2 = __hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t l2 = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same trip)
+            ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)v2);
+            nbig_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)l2);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (ent == SA_NONE) break;
+        ++took_mid;
+        const uint32_t root = ent & 0xffffffu, R = ent >> 24;
+        const bool ok = mid_solve_component<VISUAL>(S, root, R, s_sh.mid[wv]);
+        s_fail[wv * (NT / ML_WAVES) + nref] = root;
+        nref += ok ? 0u : 1u;
+      }
+      if ((threadIdx.x & 63u) == 0) s_nfail[wv] = nref;
+    }
+  }
+  SOLVE_STAMP(2);
+  // Then the big components, one WORKGROUP each, by ticket — their queue is complete once every row workgroup has reported (the
+  // wavefront above left its loop on that condition unless its refusal list filled first; the wait is for workgroups dispatched EARLIER
+  // in the same grid, which never wait themselves).
+  if (threadIdx.x == 0) {
+    if (nbig_seen == SA_NONE) {
+      for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs; ++spin)
+        __builtin_amdgcn_s_sleep(4);
+      nbig_seen = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_word[3] = nbig_seen;
+  }
+  __syncthreads();  // (also: the middle tier's blocks — they lie over the pool of the small tier — are free)
+  const uint32_t nbig = s_word[3];
+  SOLVE_NOTE(6, ((unsigned long long)nbig << 32) | __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  uint32_t nrefused = 0;
+  for (uint32_t w2 = 0; w2 < ML_WAVES; ++w2) nrefused += s_nfail[w2];
+  if (nbig == 0 && nrefused == 0) { SOLVE_STAMP(5); return; }
   int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
   int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
   int32_t* cmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 12) : (int32_t*)S.cmatch;
@@ -1740,36 +1919,17 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
       __syncthreads();
       const uint32_t k = s_word[3];
       if (k >= nbig) break;
+      ++took_big;
       dense_one(__hip_atomic_load((uint32_t*)S.dq + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
-  if (nmid == 0) return;
-  // Middle tier.  Everything in this loop is wave-uniform BY CONSTRUCTION — the ticket is taken without a branch (lane 0 adds one, the
-  // others zero), indices go through readfirstlane, a refusal is recorded by every lane writing the same word: a lane-divergent
-  // branch before the back edge lets the compiler keep the two groups of lanes apart across iterations, and the group without lane
-  // 0 then never sees a new ticket (seen: a refusal pushed by `if (lane == 0)` inside such a loop hung the workgroup).
-  __syncthreads();  // (the pool of the small tier is free: the wavefronts' blocks lie over it)
-  {
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t nref = 0;
-    if (wv < ML_WAVES) {
-      while (nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront takes no more tickets — the other workgroups' do)
-        const uint32_t tk = atomicAdd((uint32_t*)(S.stats + SA_QW_MTICKET), (threadIdx.x & 63u) == 0 ? 1u : 0u);
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-        if (k >= nmid) break;
-        const uint32_t root = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.rnext[root]);
-        const bool ok = mid_solve_component<VISUAL>(S, root, R, s_sh.mid[wv]);
-        s_fail[wv * (NT / ML_WAVES) + nref] = root;
-        nref += ok ? 0u : 1u;
-      }
-      if ((threadIdx.x & 63u) == 0) s_nfail[wv] = nref;
-    }
-  }
-  __syncthreads();
+  SOLVE_STAMP(3);
+  SOLVE_NOTE(7, ((unsigned long long)took_big << 32) | took_mid);
+  // ... and what the workgroup's own wavefronts had to refuse (more distinct columns than the middle tier's matrix holds)
   for (uint32_t w2 = 0; w2 < ML_WAVES; ++w2) {
     const uint32_t nf = s_nfail[w2];
     for (uint32_t i = 0; i < nf; ++i) dense_one(s_fail[w2 * (NT / ML_WAVES) + i]);
   }
+  SOLVE_STAMP(5);
 }
 
 // =====================================================================================================
@@ -1873,7 +2033,9 @@ static hipError_t launch_solve_one(dim3 grid, uint32_t row_wgs, size_t lds, hipS
       }
     }
   }
+  sa_solve_trace_before(st);
   SA_LAUNCH((k_assign_solve<VIS, NT, CPT, LDS_STATE>), grid, dim3(NT), LDS_STATE ? lds : 0, st, scenes, row_wgs);
+  sa_solve_trace_after(st, grid.x);
   return hipSuccess;
 }
 template <int NT, int CPT>

@@ -45,31 +45,36 @@ struct Obs {  // one stored observation of a VisualSORT track; index 0 carries t
   std::vector<float> feat;   // host upkeep only: with device upkeep the vectors live in the device bank
 };
 
-// The last `cap` boxes of a track (SortAttributes::observed_boxes / predicted_boxes are VecDeques trimmed to the history length,
-// sort.rs:160-176): a fixed ring — no allocation per frame.
+// The last `cap` (observed, predicted) boxes of a track (SortAttributes::observed_boxes / predicted_boxes are VecDeques trimmed to the
+// history length, sort.rs:160-176; the two are always pushed together): ONE fixed ring of pairs — no allocation per frame, one heap
+// block per track.
+struct BoxPair { sa_box observed, predicted; };
 struct Ring {
-  std::vector<sa_box> v;
+  std::vector<BoxPair> v;
   uint32_t head = 0, count = 0;
-  void push(const sa_box& b, uint32_t cap) {
+  void push(const sa_box& observed, const sa_box& predicted, uint32_t cap) {
     if (v.size() != cap) { v.resize(cap); head = 0; count = 0; }
-    if (count < cap) v[(head + count++) % cap] = b;
-    else { v[head] = b; head = (head + 1) % cap; }
+    uint32_t at;
+    if (count < cap) { at = head + count++; at = at >= cap ? at - cap : at; }
+    else { at = head; head = head + 1 == cap ? 0 : head + 1; }
+    v[at].observed = observed;
+    v[at].predicted = predicted;
   }
-  const sa_box& back() const { return v[(head + count - 1) % (uint32_t)v.size()]; }
+  const BoxPair& back() const { const uint32_t at = head + count - 1, cap = (uint32_t)v.size(); return v[at >= cap ? at - cap : at]; }
   uint32_t size() const { return count; }
 };
 
-struct Track {
+struct Track {  // (what a frame's bookkeeping touches first; the filter state — 440 bytes the device owns under device upkeep — last)
   uint64_t id = 0, scene = 0, epoch = 0, length = 0;
   bool has_custom = false;
   int64_t custom = 0;
   int32_t voting = -1;  // VisualAttributes::voting_type: None
   bool has_state = false;
   bool in_engine = true;   // false: evicted from the engine's table (it can never match again) but not wasted yet
-  KF kf;
-  Ring predicted, observed;
-  std::vector<Obs> obs;
   uint32_t feat_count = 0;
+  Ring boxes;
+  std::vector<Obs> obs;
+  KF kf;
 };
 
 }  // namespace
@@ -96,6 +101,20 @@ struct sa_tracker {
   std::map<uint64_t, std::vector<Track*>> evicted;       // scene -> tracks out of the engine's table, still in `store`
   std::vector<Track> wasted_store;
   uint32_t waste_counter = 0;
+  // predict()'s per-scene work arrays, kept between calls: a frame allocates nothing once the arrays have grown to its size
+  struct SceneScratch {
+    std::vector<sa_box> cboxes, dev_pred;      // the candidates' boxes after their own Kalman no-op step ; the device's predicted boxes
+    std::vector<float> cq, cown, shares;
+    std::vector<const float*> cfeat;           // one pointer per detection: the engine gathers the rows itself ...
+    std::vector<uint8_t> cpres, votes;
+    std::vector<uint64_t> winners, tids, new_ids;
+    std::vector<int32_t> wcols;
+    std::vector<Track*> trps;
+    uint8_t contiguous = 0;                    // ... unless they already ARE one N x D block (then: no gather at all)
+  };
+  std::vector<SceneScratch> scratch;
+  std::vector<uint64_t> sc_epoch, sc_id_base, sc_touched;
+  std::vector<sa_scene_request> sc_req;
 };
 
 namespace {
@@ -117,8 +136,7 @@ bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, 
 
 void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
   tr.length += 1;                                     // sort.rs:160-176, track_attributes.rs:60-78
-  tr.observed.push(observed, o.history_length);
-  tr.predicted.push(predicted, o.history_length);
+  tr.boxes.push(observed, predicted, o.history_length);
 }
 
 sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
@@ -126,8 +144,9 @@ sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
   std::memset(&s, 0, sizeof s);
   s.id = tr.id;
   s.epoch = tr.epoch;
-  s.predicted_bbox = tr.predicted.back();
-  s.observed_bbox = tr.observed.back();
+  const BoxPair& last = tr.boxes.back();
+  s.predicted_bbox = last.predicted;
+  s.observed_bbox = last.observed;
   s.scene_id = tr.scene;
   s.length = tr.length;
   // Sort: always Positional (sort/simple_api.rs:260) ; VisualSort: attrs.voting_type.unwrap_or(Positional)
@@ -184,7 +203,7 @@ int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids)
   if (t->o.visual) { feats.assign((size_t)n * K * D, 0.0f); present.assign((size_t)n * K, 0); }
   for (uint32_t i = 0; i < n; ++i) {
     const Track& tr = t->store[ids[i]];
-    boxes[i] = tr.predicted.back();
+    boxes[i] = tr.boxes.back().predicted;
     epochs[i] = tr.epoch;
     for (int a = 0; a < 5; ++a) {
       mean[i * 5 + a] = tr.kf.mean[a];
@@ -206,15 +225,6 @@ int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids)
   if (rc != SA_OK) return tfail(t, rc, "sa_tracks_upsert: %s", sa_last_error(t->eng));
   return SA_OK;
 }
-
-struct Cand {  // the throw-away candidate track of one detection (simple_api.rs:125-145); the feature stays the caller's until a track stores it
-  sa_box raw;      // detection as passed
-  sa_box box;      // after its own Kalman no-op step: angle 0.0 -> None, confidence kept
-  float quality, own;
-  bool has_own, has_feat, has_custom;
-  const float* fptr;
-  int64_t custom;
-};
 
 // optimize_observations  visual_sort/metric.rs:129-154 on a track's stored observations: keep those with a feature, stable sort by
 // quality (descending), drop the worst when the bank is full, push the new one and bring it to the front.  At most SA_MAX_BANK + 1
@@ -253,23 +263,18 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     t->waste_counter = o.auto_waste_periodicity;
   } else t->waste_counter -= 1;
 
-  std::vector<std::vector<Cand>> cands(n_scenes);
-  std::vector<uint64_t> epoch(n_scenes);
-  std::vector<sa_scene_request> req(n_scenes);
-  std::vector<std::vector<sa_box>> cboxes(n_scenes);
-  std::vector<std::vector<float>> cq(n_scenes), cown(n_scenes);
-  std::vector<std::vector<const float*>> cfeat(n_scenes);   // one pointer per detection: the engine gathers the rows itself ...
-  std::vector<uint8_t> contiguous(n_scenes, 0);             // ... unless they already ARE one N x D block (then: no gather at all)
-  std::vector<std::vector<uint8_t>> cpres(n_scenes), votes(n_scenes);
-  std::vector<std::vector<uint64_t>> winners(n_scenes);
-  std::vector<std::vector<int32_t>> wcols(n_scenes);
+  if (t->scratch.size() < n_scenes) t->scratch.resize(n_scenes);
+  t->sc_epoch.resize(n_scenes);
+  t->sc_req.resize(n_scenes);
+  std::vector<sa_tracker::SceneScratch>& ss = t->scratch;
+  std::vector<uint64_t>& epoch = t->sc_epoch;
+  std::vector<sa_scene_request>& req = t->sc_req;
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint32_t n = counts[s];
+    sa_tracker::SceneScratch& W = ss[s];
     epoch[s] = ++t->epochs[scene_ids[s]];  // next_epoch  epoch_db.rs:35-49
-    auto& cs = cands[s];
-    cs.resize(n);
-    cboxes[s].resize(n);
-    if (o.visual) { cfeat[s].assign(n, nullptr); cq[s].resize(n); cown[s].resize(n); cpres[s].resize(n); }
+    W.cboxes.resize(n);
+    if (o.visual) { W.cfeat.resize(n); W.cq.resize(n); W.cown.resize(n); W.cpres.resize(n); }
     for (uint32_t i = 0; i < n; ++i) {
       const sa_box& bb = obs[s][i].bbox;
       if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f))
@@ -277,7 +282,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     }
     // exclusively_owned_areas_normalized_shares over the frame's observed boxes, when either own-area gate is armed
     // (visual_sort/simple_api.rs:111-127) — on the GPU (sa_own_areas).  A share the caller supplies takes precedence.
-    std::vector<float> shares;
+    std::vector<float>& shares = W.shares;
+    shares.clear();
     if (o.visual && n && o.visual_minimal_own_area_percentage_collect + o.visual_minimal_own_area_percentage_use > 0.0f) {
       bool any_missing = false;
       for (uint32_t i = 0; i < n; ++i) any_missing = any_missing || obs[s][i].own_area != obs[s][i].own_area;
@@ -289,64 +295,60 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
       }
     }
+    // The throw-away candidate track of a detection (simple_api.rs:125-145) is never materialised: its box goes into the request, the
+    // rest of it (custom id, feature pointer) is read from the caller's observation when a track takes it over.
+    // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from, kalman_prediction.rs:13-32)
+    // is the identity on the box: zero velocity, zero innovation, so the new mean is the observation plus (+-0) * gain.  All that
+    // changes is TryFrom<KalmanState>: an angle of exactly 0.0 reads back as None (kalman.rs:82-86).  The 10 x 10 filter arithmetic
+    // (about 1 us per detection on the host) is therefore only run for the candidates that become tracks and need the state
+    // (below); the tests compare every box with the oracle, which does run the filter.
     const float* block = nullptr;  // where row 0 of an N x D block would lie, if the features form one
-    bool one_block = o.visual && n > 0;
+    bool one_block = o.visual && n > 0, all_present = true;
+    sa_box* cb = W.cboxes.data();
     for (uint32_t i = 0; i < n; ++i) {
       const sa_observation& ob = obs[s][i];
-      Cand& c = cs[i];
-      c.raw = ob.bbox;
-      // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from,
-      // kalman_prediction.rs:13-32) is the identity on the box: zero velocity, zero innovation, so the new mean is the
-      // observation plus (+-0) * gain.  All that changes is TryFrom<KalmanState>: an angle of exactly 0.0 reads back as None
-      // (kalman.rs:82-86).  The 10 x 10 filter arithmetic (about 1 us per detection on the host) is therefore only run for
-      // the candidates that become tracks and need the state (below); the tests compare every box with the oracle, which
-      // does run the filter.
-      c.box = ob.bbox;
-      c.box.angle = ob.bbox.has_angle ? ob.bbox.angle : 0.0f;
-      c.box.has_angle = (ob.bbox.has_angle && ob.bbox.angle != 0.0f) ? 1 : 0;
-      c.box.reserved = 0;
-      c.has_custom = ob.has_custom_object_id != 0;
-      c.custom = ob.custom_object_id;
-      c.quality = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
-      c.has_own = ob.own_area == ob.own_area || !shares.empty();
-      c.own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
-      c.has_feat = o.visual && ob.feature != nullptr;
-      c.fptr = c.has_feat ? ob.feature : nullptr;
-      cboxes[s][i] = c.box;
+      sa_box& c = cb[i];
+      c = ob.bbox;
+      c.angle = ob.bbox.has_angle ? ob.bbox.angle : 0.0f;
+      c.has_angle = (ob.bbox.has_angle && ob.bbox.angle != 0.0f) ? 1 : 0;
+      c.reserved = 0;
       if (o.visual) {
-        cq[s][i] = c.quality;
-        cown[s][i] = c.has_own ? c.own : NAN;
-        cpres[s][i] = c.has_feat ? 1 : 0;
-        if (c.has_feat) {
-          cfeat[s][i] = ob.feature;
+        const bool has_own = ob.own_area == ob.own_area || !shares.empty();
+        const float own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
+        const bool has_feat = ob.feature != nullptr;
+        W.cq[i] = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
+        W.cown[i] = has_own ? own : NAN;
+        W.cpres[i] = has_feat ? 1 : 0;
+        W.cfeat[i] = ob.feature;
+        all_present = all_present && has_feat;
+        if (has_feat) {
           if (!block) block = ob.feature - (size_t)i * D;
           one_block = one_block && ob.feature == block + (size_t)i * D;
         }
       }
     }
-    winners[s].assign(n, 0);
-    votes[s].assign(n, 0);
-    wcols[s].assign(n, -1);
+    W.winners.resize(n);
+    W.votes.resize(n);
+    W.wcols.resize(n);
     sa_scene_request& r = req[s];
     std::memset(&r, 0, sizeof r);
     r.scene_id = scene_ids[s];
     r.epoch = epoch[s];
     r.detections.n = n;
-    r.detections.boxes = cboxes[s].data();
+    r.detections.boxes = W.cboxes.data();
+    W.contiguous = 0;
     if (o.visual) {
-      r.detections.feat_present = cpres[s].data();
-      r.detections.feat_quality = cq[s].data();
-      r.detections.own_area = cown[s].data();
+      r.detections.feat_present = W.cpres.data();
+      r.detections.feat_quality = W.cq.data();
+      r.detections.own_area = W.cown.data();
       // The observations' features as ONE block (a producer that writes its N x D output contiguously — a ReID head's output buffer,
       // host or device): handed over as such — read in place when the block is pinned (sa_host_alloc) or registered device memory
       // (sa_device_block_register), one memcpy otherwise — instead of one gather per row.  Rows of detections without a feature are
       // never dereferenced by the host (flagged absent).  Only when every row lies inside a block the engine knows: rows of
       // absent detections may otherwise be unmapped memory.
-      if (one_block && block) {
-        bool all_present = true;
-        for (uint32_t i = 0; i < n; ++i) all_present = all_present && cs[i].has_feat;
-        contiguous[s] = all_present ? 1 : 0;
-        if (all_present) r.detections.feats = block;
+      if (one_block && block && all_present) {
+        W.contiguous = 1;
+        r.detections.feats = block;
       }
     }
   }
@@ -377,8 +379,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   int rc = sa_batch_begin(t->eng);
   const auto t_begun = clk::now();
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
-    rc = contiguous[s] ? sa_batch_add(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, nullptr)
-                       : sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? cfeat[s].data() : nullptr, nullptr);
+    rc = ss[s].contiguous ? sa_batch_add(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, nullptr)
+                          : sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? ss[s].cfeat.data() : nullptr, nullptr);
   const auto t_added = clk::now();
   // Device upkeep: the Kalman step, the table refresh and the feature-bank policy of every scene are queued right BEHIND the association
   // on the device (sa_batch_run_apply) — the ids of the tracks that start are a function of the winners alone (a counter, in candidate
@@ -386,7 +388,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   // rules — one id per NEW track across scenes — would make a scene's first id depend on the previous scenes' winners: two phases then.)
   const bool fused = o.device_upkeep && (o.batch_ids || n_scenes == 1);
   if (rc == SA_OK && fused) {
-    std::vector<uint64_t> id_base(n_scenes);
+    std::vector<uint64_t>& id_base = t->sc_id_base;
+    id_base.resize(n_scenes);
     uint64_t next = t->track_id;
     for (uint32_t s = 0; s < n_scenes; ++s) { id_base[s] = next; next += counts[s]; }   // (batch ids: one per candidate; a single scene: its own counter)
     rc = sa_batch_run_apply(t->eng, id_base.data(), o.batch_ids ? 1 : 0);
@@ -396,8 +399,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   if (rc == SA_OK && !fused) rc = sa_batch_sync(t->eng);  // (fused: sa_batch_fetch waits for the END OF THE ASSOCIATION only — the upkeep kernels
                                                           // queued behind it run while this thread does its bookkeeping below)
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) {
-    rc = sa_batch_fetch(t->eng, s, winners[s].data(), votes[s].data());
-    if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, s, wcols[s].data());
+    rc = sa_batch_fetch(t->eng, s, ss[s].winners.data(), ss[s].votes.data());
+    if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, s, ss[s].wcols.data());
   }
   if (rc != SA_OK) return tfail(t, rc, "association: %s", sa_last_error(t->eng));
   const auto t_assoc = clk::now();
@@ -405,24 +408,23 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   // ids first, scene by scene in the order the reference draws them; with device upkeep the Kalman step, table refresh and
   // feature-bank policy of every scene are QUEUED right away (sa_tracks_apply_begin) — they run while this thread does the
   // per-track bookkeeping that does not need their result; the predicted boxes are collected afterwards (sa_tracks_apply_end)
-  std::vector<uint64_t> touched;
-  std::vector<std::vector<uint64_t>> tids(n_scenes), new_ids(n_scenes);
-  std::vector<std::vector<sa_box>> dev_pred(n_scenes);
-  std::vector<std::vector<Track*>> trps(n_scenes);
+  std::vector<uint64_t>& touched = t->sc_touched;
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint32_t n = counts[s];
-    tids[s].assign(n, 0);
-    new_ids[s].assign(n, 0);
+    sa_tracker::SceneScratch& W = ss[s];
+    W.tids.resize(n);
+    W.new_ids.resize(n);
+    const uint64_t* win = W.winners.data();
     for (uint32_t i = 0; i < n; ++i) {
-      const uint64_t dest = winners[s][i];
+      const uint64_t dest = win[i];
       uint64_t drawn = 0;
       if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
-      if (dest == 0) { tids[s][i] = o.batch_ids ? drawn : ++t->track_id; new_ids[s][i] = tids[s][i]; }
-      else tids[s][i] = dest;
+      if (dest == 0) { W.tids[i] = o.batch_ids ? drawn : ++t->track_id; W.new_ids[i] = W.tids[i]; }
+      else { W.tids[i] = dest; W.new_ids[i] = 0; }
     }
     if (o.device_upkeep && !fused) {
       const auto ta = clk::now();
-      rc = sa_tracks_apply_begin(t->eng, s, new_ids[s].data());
+      rc = sa_tracks_apply_begin(t->eng, s, W.new_ids.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
     }
@@ -430,38 +432,44 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint64_t scene = scene_ids[s];
     const uint32_t n = counts[s];
+    sa_tracker::SceneScratch& W = ss[s];
     touched.clear();
-    trps[s].assign(n, nullptr);
+    W.trps.resize(n);
     std::vector<Track*>& rows = t->by_scene[scene];
+    std::vector<uint64_t>& eps = t->row_epoch[scene];
     const size_t rows_before = rows.size();  // the table the engine voted against: columns refer to these rows
     for (uint32_t i = 0; i < n; ++i) {
-      const Cand& c = cands[s][i];
-      const uint64_t dest = winners[s][i];
+      const sa_observation& ob = obs[s][i];
+      const sa_box& cbox = W.cboxes[i];
+      const uint64_t dest = W.winners[i];
+      const bool c_has_feat = o.visual && W.cpres[i] != 0;
+      const float c_quality = o.visual ? W.cq[i] : 1.0f;
+      const bool c_has_own = o.visual && W.cown[i] == W.cown[i];
+      const float c_own = c_has_own ? W.cown[i] : 0.0f;
       Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        Track& tr = t->store[tids[s][i]];
+        Track& tr = t->store[W.tids[i]];
         trp = &tr;
-        tr.id = tids[s][i]; tr.scene = scene; tr.epoch = epoch[s];
-        tr.has_custom = c.has_custom; tr.custom = c.custom;
+        tr.id = W.tids[i]; tr.scene = scene; tr.epoch = epoch[s];
+        tr.has_custom = ob.has_custom_object_id != 0; tr.custom = ob.custom_object_id;
         tr.has_state = true;
-        if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, c.raw); }  // with device upkeep the state is born on the GPU
+        if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, ob.bbox); }  // with device upkeep the state is born on the GPU
         tr.length = 0;
-        update_history(o, tr, c.raw, c.box);
+        update_history(o, tr, ob.bbox, cbox);
         if (o.visual) {
           tr.obs.reserve(o.visual_max_observations + 1);
           tr.obs.emplace_back();                         // is_merge = false: the feature is kept as is
-          Obs& ob = tr.obs.back();
-          ob.quality = c.quality; ob.has_own = c.has_own; ob.own = c.own; ob.has_feat = c.has_feat;
-          if (!o.device_upkeep && c.fptr) ob.feat.assign(c.fptr, c.fptr + D);  // device upkeep: the vectors live in the device bank only
-          tr.feat_count = c.has_feat ? 1 : 0;
+          Obs& nb = tr.obs.back();
+          nb.quality = c_quality; nb.has_own = c_has_own; nb.own = c_own; nb.has_feat = c_has_feat;
+          if (!o.device_upkeep && c_has_feat) nb.feat.assign(ob.feature, ob.feature + D);  // device upkeep: the vectors live in the device bank only
+          tr.feat_count = c_has_feat ? 1 : 0;
         }
         rows.push_back(trp);
-        t->row_epoch[scene].push_back(epoch[s]);
+        eps.push_back(epoch[s]);
       } else {
         // the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
-        const int32_t col = wcols[s][i];
-        std::vector<uint64_t>& eps = t->row_epoch[scene];
+        const int32_t col = W.wcols[i];
         if (col >= 0 && (size_t)col < rows_before && rows[col]->id == dest) { trp = rows[col]; eps[col] = epoch[s]; }
         else {
           auto it = t->store.find(dest);
@@ -473,26 +481,26 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         Track& tr = *trp;
         // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215
         tr.epoch = epoch[s];
-        tr.has_custom = c.has_custom; tr.custom = c.custom;
-        if (o.visual) tr.voting = votes[s][i];
+        tr.has_custom = ob.has_custom_object_id != 0; tr.custom = ob.custom_object_id;
+        if (o.visual) tr.voting = W.votes[i];
         // optimize(is_merge = true): Kalman predict + update with the candidate's box, history (device upkeep: once the boxes are back)
-        if (!o.device_upkeep) update_history(o, tr, c.box, make_prediction(pw, vw, tr.has_state, tr.kf, c.box));
+        if (!o.device_upkeep) update_history(o, tr, cbox, make_prediction(pw, vw, tr.has_state, tr.kf, cbox));
         if (o.visual) {
           Obs nw;
-          nw.quality = c.quality; nw.has_own = c.has_own; nw.own = c.own; nw.has_feat = c.has_feat;
-          if (!feature_can_be_used(o, c.box, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
+          nw.quality = c_quality; nw.has_own = c_has_own; nw.own = c_own; nw.has_feat = c_has_feat;
+          if (!feature_can_be_used(o, cbox, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
                                    o.visual_minimal_own_area_percentage_collect))
             nw.has_feat = false;
-          if (!o.device_upkeep && nw.has_feat) nw.feat.assign(c.fptr, c.fptr + D);
+          if (!o.device_upkeep && nw.has_feat) nw.feat.assign(ob.feature, ob.feature + D);
           // (with device upkeep: the bookkeeping only — the same policy moves the feature rows inside the device bank, sa_upkeep.hip)
           optimize_observations(tr.obs, std::move(nw), o.visual_max_observations);
           tr.feat_count = 0;
-          for (auto& ob : tr.obs) tr.feat_count += ob.has_feat ? 1u : 0u;
+          for (auto& so : tr.obs) tr.feat_count += so.has_feat ? 1u : 0u;
         }
       }
-      trps[s][i] = trp;
+      W.trps[i] = trp;
       if (!o.device_upkeep) {
-        touched.push_back(tids[s][i]);
+        touched.push_back(W.tids[i]);
         out[s][i] = to_sort_track(o, *trp);
       }
     }
@@ -503,14 +511,15 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   if (o.device_upkeep)
     for (uint32_t s = 0; s < n_scenes; ++s) {
       const uint32_t n = counts[s];
-      dev_pred[s].resize(n);
+      sa_tracker::SceneScratch& W = ss[s];
+      W.dev_pred.resize(n);
       const auto ta = clk::now();
-      rc = fused ? sa_tracks_apply_collect(t->eng, s, nullptr, dev_pred[s].data()) : sa_tracks_apply_end(t->eng, s, dev_pred[s].data());
+      rc = fused ? sa_tracks_apply_collect(t->eng, s, nullptr, W.dev_pred.data()) : sa_tracks_apply_end(t->eng, s, W.dev_pred.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
       for (uint32_t i = 0; i < n; ++i) {
-        Track& tr = *trps[s][i];
-        if (winners[s][i] != 0) update_history(o, tr, cands[s][i].box, dev_pred[s][i]);
+        Track& tr = *W.trps[i];
+        if (W.winners[i] != 0) update_history(o, tr, W.cboxes[i], W.dev_pred[i]);
         out[s][i] = to_sort_track(o, tr);
       }
     }
@@ -699,7 +708,7 @@ int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]) {
   const Track& tr = it->second;
   out4[0] = tr.feat_count;
   out4[1] = t->o.visual ? tr.obs.size() : 1;
-  out4[2] = tr.observed.size();
+  out4[2] = tr.boxes.size();
   out4[3] = tr.length;
   return SA_OK;
 }

@@ -13,6 +13,7 @@
 // which the bit-exact IoU gate would see): k_apply_kalman writes the polygon of boxes without an angle, and sa_tracks_apply — which
 // has the predicted boxes on the host anyway — sends (row, cos, sin) of the others to k_apply_polygons, queued behind it.
 #include "sa_engine.h"
+#include "sa_frame.h"
 #include "sa_kalman.h"
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -252,6 +253,12 @@ __device__ __forceinline__ void bank_block(const BankArgs& a, uint32_t i, BankLd
   __syncthreads();
   const bool new_pres = s_newfeat != 0;
   const float* cf = a.c_feat ? a.c_feat + (size_t)i * Dp : nullptr;
+  // The squared norm of the new row.  A frame that carried its preparation blocks left it in c_fnorm; a LEAN frame did not (its rows
+  // are the uploaded ones, D == Dp, and nothing else of the candidates' half is read here): the block's first wave forms it the way the
+  // preparation block would have — pad_feature_row, same lanes, same order: bit for bit the value the next frame's cells are scaled by.
+  float nrm_new = 0.0f;
+  if (a.c_fnorm) nrm_new = new_pres ? a.c_fnorm[i] : 0.0f;
+  else if (new_pres && cf && tid < WAVE) pad_feature_row(cf, const_cast<float*>(cf), Dp, Dp, true, tid, &nrm_new);
   uint32_t srcs[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) srcs[k] = (uint32_t)k < K ? s_src[k] : SA_BANK_NONE;
@@ -280,7 +287,7 @@ __device__ __forceinline__ void bank_block(const BankArgs& a, uint32_t i, BankLd
       const uint32_t src = s_src[k];
       bool pres = false;
       float q = 0.0f, nrm = 0.0f;
-      if (src == SA_BANK_NEW) { pres = new_pres; q = s_q[K]; nrm = pres ? a.c_fnorm[i] : 0.0f; }
+      if (src == SA_BANK_NEW) { pres = new_pres; q = s_q[K]; nrm = pres ? nrm_new : 0.0f; }
       else if (src < SA_BANK_NEW) { pres = true; q = s_q[src]; nrm = s_nrm[src]; }
       a.t_fpresent[(size_t)row * K + k] = pres ? 1 : 0;
       a.t_fquality[(size_t)row * K + k] = q;
