@@ -937,10 +937,10 @@ def main():
         lf = launch_floor_us()
         if lf is not None and roof is not None and roof.get("bound") == "hbm":
             n_launch = sum(per_step(k) for k in gpu_kernels)
-            out["fixed_cost"] = {"frame_us": 1e3 * dt / args.steps, "launches_per_frame": n_launch, "launch_floor_us": lf[0],
-                                 "floor_of_the_frame_us": n_launch * lf[0], "above_the_floor_us": 1e3 * dt / args.steps - n_launch * lf[0],
+            out["fixed_cost"] = {"frame_us": 1e6 * dt / args.steps, "launches_per_frame": n_launch, "launch_floor_us": lf[0],
+                                 "floor_of_the_frame_us": n_launch * lf[0], "above_the_floor_us": 1e6 * dt / args.steps - n_launch * lf[0],
                                  "source": f"profiles/{lf[1]} (scripts/micro/launch_floor.hip: an empty 1000-block kernel, average of a chain of 200 dependent launches)",
-                                 "note": "positional launches and assignment tails are chains of dependent round trips (in-kernel timelines: profiles/r04_pos_trace_*.txt); "
+                                 "note": "positional launches and assignment tails are chains of dependent round trips (in-kernel timelines: profiles/r04_z_pos_trace.txt); "
                                          "read the frame against its launch floor, not against HBM bandwidth"}
         if h2d is not None:
             out["h2d_inclusive"] = h2d

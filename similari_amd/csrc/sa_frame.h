@@ -2,6 +2,7 @@
 // preparation blocks) and sa_gemm.hip (k_frame_visual: the same two block kinds riding beside the contraction's tiles).
 #pragma once
 #include "sa_engine.h"
+#include <type_traits>
 
 #ifndef WAVE
 #define WAVE 64
@@ -424,28 +425,35 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
       emit(i, j, sa_maha_cell(m20, z5, s_cconf[li]), true);
     }
   } else if (COOP) {
-    // four lanes per pair (clip_area_lanes): 64 pairs at a time over the four waves; the vertex lists are the same 24 KB
-    const uint32_t grp = tid >> 2, gl = tid & 3u, gshift = lane & 60u;
-    double* ws = s_poly + grp * (4 * SA_POLY_CAP);
-    for (uint32_t sidx = grp; sidx < cnt; sidx += 64) {
-      const uint32_t c = s_list[sidx];
-      const uint32_t li = c >> 8, lj = c & 255u;
-      const uint32_t i = i0 + li, j = j0 + lj;
-      double tv[8];
-      const double SA_G* tp = S.t_verts + (size_t)j * 8;
+    // L lanes per pair (clip_area_lanes): four — 64 pairs at a time over the four waves, the vertex lists are the same 24 KB — or, when
+    // the tile's survivors fit 32 groups (cnt is uniform over the block), EIGHT: a pass over a list of up to eight vertices is then ONE step
+    // of the dependent chain instead of two (a quad clipped by a quad: 4 -> at most 8 vertices), and a tile's clip phase is that chain
+    auto clip_pairs = [&](auto LTAG) {
+      constexpr uint32_t L = decltype(LTAG)::value, GROUPS = 256u / L;
+      const uint32_t grp = tid / L, gl = tid & (L - 1u), gshift = lane & (64u - L);
+      double* ws = s_poly + grp * (4 * SA_POLY_CAP);
+      for (uint32_t sidx = grp; sidx < cnt; sidx += GROUPS) {
+        const uint32_t c = s_list[sidx];
+        const uint32_t li = c >> 8, lj = c & 255u;
+        const uint32_t i = i0 + li, j = j0 + lj;
+        double tv[8];
+        const double SA_G* tp = S.t_verts + (size_t)j * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) tv[k] = tp[k];
-      const double inter = clip_area_lanes<4>(s_cv[li], tv, ws, gl, gshift);
-      if (gl == 0) {
-        float iou, out = nanv;
-        bool present = false;
-        if (sa_iou_from_area(inter, s_cg[li].hha, s_thha[lj], &iou)) {
-          const float e = iou * s_cconf[li];
-          if (e >= p.positional_threshold) { out = e; present = true; }
+        for (int k = 0; k < 8; ++k) tv[k] = tp[k];
+        const double inter = clip_area_lanes<(int)L>(s_cv[li], tv, ws, gl, gshift);
+        if (gl == 0) {
+          float iou, out = nanv;
+          bool present = false;
+          if (sa_iou_from_area(inter, s_cg[li].hha, s_thha[lj], &iou)) {
+            const float e = iou * s_cconf[li];
+            if (e >= p.positional_threshold) { out = e; present = true; }
+          }
+          emit(i, j, out, present);
         }
-        emit(i, j, out, present);
       }
-    }
+    };
+    if (cnt <= 32u) clip_pairs(std::integral_constant<uint32_t, 8u>{});
+    else clip_pairs(std::integral_constant<uint32_t, 4u>{});
   } else if (tid < POS_WORKERS) {
     // Sutherland–Hodgman vertex lists: 4 lists x 12 vertices per worker lane, [list][vertex][lane] in LDS
     double* ws = s_poly + tid;
