@@ -408,15 +408,17 @@ def test_oracle_own_area_gates_change_the_outcome():
 
 
 @pytest.mark.gpu
-def test_device_bank_equals_host_policy_bank():
+@pytest.mark.parametrize("d", [48, 64], ids=["padded_rows", "lean_frames"])
+def test_device_bank_equals_host_policy_bank(d):
     """The feature bank the device keeps (rows, presence flags, qualities, order) is what the host policy
     (optimize_observations, visual_sort/metric.rs:129-154) builds from the same observations: two facades, one with host
     upkeep (its bank is uploaded every frame), one with device upkeep, are fed the same frames and their engines' banks are
-    read back and compared slot for slot."""
+    read back and compared slot for slot.  d = 48: the rows are padded to 64 floats, the frame carries its preparation blocks for the
+    bank step; d = 64: the frame runs lean and the bank step reads the uploaded rows and forms their norms itself."""
     import ctypes as C
 
     rng = np.random.default_rng(31)
-    d, n = 48, 30
+    n = 30
     opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
             .positional_metric(IoU(0.3)).visual_minimal_track_length(1).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.3).visual_minimal_quality_collect(0.5).visual_max_observations(3).visual_min_votes(1))
@@ -500,6 +502,42 @@ def test_churned_loop_with_eviction_matches_oracle(kind, backend):
         assert rows_seen[-1] < n + 6 * 24, rows_seen
         assert max(rows_seen) > n, rows_seen
         assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+@UPKEEP
+@pytest.mark.parametrize("kind", ["sort", "visual"])
+def test_frame_sizes_from_empty_to_hundreds_match_oracle(kind, backend):
+    """predict() keeps its work arrays between calls: frames that shrink, grow and vanish (0, 9, 0, 260, 3, ...) must leave nothing of the
+    previous frame behind — every frame's tracks against the oracle tracker's."""
+    rng = np.random.default_rng(77)
+    d, pool = 64, 260
+    if kind == "visual":
+        opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(2).visual_metric(TR.VisualSortMetricType.cosine(0.5))
+                .positional_metric(IoU(0.3)).visual_minimal_track_length(1).visual_max_observations(2).visual_min_votes(1))
+        g, o = make(backend, "visual", opts=opts, feature_len=d), make("oracle", "visual", opts=opts, feature_len=d)
+    else:
+        kw = dict(bbox_history=2, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
+        g, o = make(backend, "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        ident = synth.reid_identities(rng, pool, d)
+        world = synth.dense_boxes(rng, pool, (1400.0, 1000.0))
+        for size in (0, 9, 0, 260, 3, 260, 0, 40, 41, 1):
+            world = synth.jitter_boxes(rng, world, 2.0)
+            pick = rng.permutation(pool)[:size]
+            boxes = boxes_to_u2d(world[pick])
+            if kind == "visual":
+                feats = synth.observe(rng, ident[pick], 0.01) if size else np.zeros((0, d), np.float32)
+                items = [TR.VisualSortObservation(ft, 0.9, bx, int(k) if k % 4 == 0 else None) for k, (bx, ft) in enumerate(zip(boxes, feats))]
+            else:
+                items = [(bx, int(k) if k % 4 == 0 else None) for k, bx in enumerate(boxes)]
+            rg, ro = g.predict(items), o.predict(items)
+            assert len(rg) == size
+            assert_tracks_equal(rg, ro)
+        assert g.active_tracks() == o.active_tracks()
     finally:
         g.close()
         o.close()
