@@ -553,10 +553,13 @@ def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
                      "sa_host_alloc block, results copied out; synchronous_ms_per_step = sa_associate_batch on the same buffers")}, ids
 
 
-def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400):
+def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400, max_over_ranks=None):
     """EXACTLY K steps per timed region, bracketed by barrier + synchronize on both sides; the region is repeated until at least
     min_total_s has been measured (a 20-step region of a 25 us step is 0.5 ms of signal: one region is a noisy sample) and the
-    MEDIAN region is reported."""
+    MEDIAN region is reported.  Under several ranks a region's time is the MAX over ranks (max_over_ranks: an all-reduce OUTSIDE the
+    timed region) — the contract's definition, and what makes every rank take the same "one more region?" decision: with each rank
+    summing its own clock, two ranks a microsecond apart at the threshold would leave the loop in different rounds and the next
+    collective would never match."""
     times = []
     total = 0.0
     while len(times) < min_rounds or (total < min_total_s and len(times) < max_rounds):
@@ -565,6 +568,8 @@ def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400):
         run_k()
         barrier()
         dt = time.perf_counter() - t0
+        if max_over_ranks is not None:
+            dt = max_over_ranks(dt)
         times.append(dt)
         total += dt
     return float(np.median(times)), times
@@ -646,6 +651,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def run_k():
         for _ in range(args.steps):
             eng.batch_run()
@@ -654,7 +666,7 @@ def main():
     for _ in range(args.warmup):
         eng.batch_run()
     eng.batch_sync()
-    dt, regions = timed_rounds(run_k, barrier)
+    dt, regions = timed_rounds(run_k, barrier, max_over_ranks=max_over_ranks)
     # the pure per-step time: a region carries a fixed cost (the first launch's latency, the final synchronisation: ~20 us, 5 % of a
     # 20-step region) — regions of 4 K steps give the slope; `value` stays the K-step region, the slope only rescales the
     # instrumented per-kernel durations below
@@ -663,7 +675,7 @@ def main():
             eng.batch_run()
         eng.batch_sync()
     if dt < 0.05:
-        dt4, _r4 = timed_rounds(run_4k, barrier, min_total_s=0.2, min_rounds=3, max_rounds=60)
+        dt4, _r4 = timed_rounds(run_4k, barrier, min_total_s=0.2, min_rounds=3, max_rounds=60, max_over_ranks=max_over_ranks)
         step_s = max(0.0, (dt4 - dt) / (3.0 * args.steps)) or dt / args.steps
     else:
         step_s = dt / args.steps  # a region of 50 ms and more: the fixed cost is below a tenth of a percent
