@@ -314,7 +314,7 @@ struct BankArgs {
   uint32_t* t_fcount;
   float minimal_area, q_collect, own_collect;
 };
-hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done = nullptr);
+hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done = nullptr, int part = 0);
 // oriented boxes after sa_launch_apply: the host's libm cos / sin of a refreshed row's angle -> its polygon
 struct SaPolyFix {
   uint32_t row, pad;

@@ -132,6 +132,8 @@ struct Bank {
   hipEvent_t ev_staged = nullptr, ev_done = nullptr;
   hipEvent_t ev_apply = nullptr;   // sa_batch_run_apply: carried by the last upkeep dispatch of the set (sa_tracks_apply_collect waits for it)
   bool apply_event = false;
+  hipEvent_t ev_kf = nullptr;      // VisualSORT: the set's last KALMAN dispatch (the predicted boxes are out; the feature-bank dispatches run on)
+  bool kf_event = false;
   uint64_t apply_seq = 0;          // sa_engine::busy_seq right after that dispatch: unchanged at the wait = the engine is drained
   bool staged_inline = false;  // the request set was uploaded on the compute stream itself (no hand-over event to wait for)
   uint64_t ticket = 0;       // 0 = none
@@ -1016,6 +1018,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
     hipEventCreate(&bk.ev_staged);  // also handed to hipExtLaunchKernelGGL as the ingest dispatch's completion event
     hipEventCreate(&bk.ev_done);    // handed to hipExtLaunchKernelGGL as the completion event of a frame's last dispatch (enqueue_frame)
     hipEventCreate(&bk.ev_apply);
+    hipEventCreate(&bk.ev_kf);
   }
   *out = e;
   return SA_OK;
@@ -1067,6 +1070,7 @@ void sa_engine_destroy(sa_engine* e) {
     if (bk.ev_staged) hipEventDestroy(bk.ev_staged);
     if (bk.ev_done) hipEventDestroy(bk.ev_done);
     if (bk.ev_apply) hipEventDestroy(bk.ev_apply);
+    if (bk.ev_kf) hipEventDestroy(bk.ev_kf);
   }
   for (DevBuf* b : {&e->nms_mask, &e->nms_keep, &e->up_raw, &e->up_slots, &e->up_epochs, &e->up_ids, &e->up_mean, &e->up_cov, &e->up_feats,
                     &e->up_present, &e->up_index})
@@ -1271,6 +1275,7 @@ int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t
 static void bank_clear(Bank* b) {
   b->assoc_event = false;
   b->apply_event = false;
+  b->kf_event = false;
   b->n_slots = 0;
   b->used = 0;
   b->uploaded = false;
@@ -1645,7 +1650,7 @@ static int finish_applies(sa_engine* e) {
 }
 // Queues the upkeep kernels of slot `s` (Kalman step + table rows, feature-bank policy) on the compute stream.  new_row / new_ids: device-visible
 // arrays — table row and id of every candidate that starts a track (SA_NONE / 0 elsewhere).
-static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids, hipEvent_t done = nullptr) {  // (both nullptr: drawn on the device from s->fused_*)
+static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids, hipEvent_t done = nullptr, int part = 0) {  // (both nullptr: drawn on the device from s->fused_*; part: sa_launch_apply)
   SceneTable* sc = s->scene;
   const uint32_t n = s->N;
   {
@@ -1672,7 +1677,7 @@ static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const ui
     b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
     b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
   }
-  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st, done));
+  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st, done, part));
   SA_BUSY(e);
   return SA_OK;
 }
@@ -1808,7 +1813,10 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
     for (Bank& bk : e->banks)
       for (uint32_t i = 0; i < bk.n_slots; ++i)
         if (bk.slots[i] == s) ob = &bk;
-    if (ob && ob->apply_event) {
+    if (ob && ob->kf_event) {   // (the predicted boxes and the table's rows are out; the feature banks may still be moving: the engine stays busy)
+      hipError_t we = hipEventSynchronize(ob->ev_kf);
+      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    } else if (ob && ob->apply_event) {
       hipError_t we = hipEventSynchronize(ob->ev_apply);
       if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
       if (e->busy_seq == ob->apply_seq && !e->copy_dirty) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
@@ -1906,20 +1914,31 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
   }
   b->want_prep = false;
   if (rc != SA_OK) return rc;
-  for (uint32_t i = 0; i < b->n_slots; ++i) {
-    Slot* s = b->slots[i];
-    const uint32_t n = s->N;
-    if (!n) continue;
-    s->fused_T0 = s->scene->T;
-    s->fused_id_base = id_base[i];
-    s->fused_per_candidate = id_per_candidate ? 1 : 0;
-    // rows and ids of the tracks that start: drawn inside the kernels, from the winners; the set's LAST upkeep dispatch signals ev_apply
-    bool last = true;
-    for (uint32_t j = i + 1; j < b->n_slots; ++j) last = last && b->slots[j]->N == 0;
-    TRY(apply_launch(e, s, nullptr, nullptr, last ? b->ev_apply : nullptr));
-    if (last) { b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq; }
-    s->fused_pending = true;
-  }
+  // VisualSORT: every scene's Kalman dispatch first, then the feature-bank dispatches — the predicted boxes (all a caller of
+  // sa_tracks_apply_collect needs from the device) are out when the LAST Kalman dispatch retires (ev_kf), the banks (10+ us of row
+  // moves at 1000 x 3 x 512 floats) run on behind them; whatever touches the engine next is ordered behind them on the stream, or
+  // waits for ev_apply.  SORT: one dispatch per scene.
+  const int parts = e->visual ? 2 : 1;
+  for (int part = 1; part <= parts; ++part)
+    for (uint32_t i = 0; i < b->n_slots; ++i) {
+      Slot* s = b->slots[i];
+      const uint32_t n = s->N;
+      if (!n) continue;
+      if (part == 1) {
+        s->fused_T0 = s->scene->T;
+        s->fused_id_base = id_base[i];
+        s->fused_per_candidate = id_per_candidate ? 1 : 0;
+      }
+      // rows and ids of the tracks that start: drawn inside the kernels, from the winners; the set's LAST upkeep dispatch signals ev_apply
+      bool last = true;
+      for (uint32_t j = i + 1; j < b->n_slots; ++j) last = last && b->slots[j]->N == 0;
+      const bool final_part = part == parts;
+      hipEvent_t ev = !last ? nullptr : (final_part ? b->ev_apply : b->ev_kf);
+      TRY(apply_launch(e, s, nullptr, nullptr, ev, e->visual ? part : 0));
+      if (last && final_part) { b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq; }
+      if (last && !final_part) b->kf_event = true;
+      s->fused_pending = true;
+    }
   return SA_OK;
 }
 

@@ -112,9 +112,20 @@ struct sa_tracker {
     std::vector<Track*> trps;
     uint8_t contiguous = 0;                    // ... unless they already ARE one N x D block (then: no gather at all)
   };
-  std::vector<SceneScratch> scratch;
+  std::vector<SceneScratch> scratch[2];     // two sets, used in turn: the set of the previous predict() may still hold deferred work
+  int cur_set = 0;
   std::vector<uint64_t> sc_epoch, sc_id_base, sc_touched;
   std::vector<sa_scene_request> sc_req;
+  // Deferred bookkeeping (device upkeep queued behind the association: the fused path).  What a predict() RETURNS needs, per continued
+  // track, one cache line of its record (id, length, epoch, custom id, vote); the rest of the reference's merge — the history deques
+  // (sort.rs:160-176) and the observation policy (visual_sort/metric.rs:129-154) — only has to be in place before anything READS it:
+  // the next predict()'s own merges, idle_tracks, wasted, track_info.  It is therefore run by the NEXT call on the tracker, and a
+  // predict() runs it while its own association is on the device (the host would wait there anyway); every other entry point runs
+  // it first.  All it reads lies in the scratch set of the frame that left it behind.
+  bool pending = false;
+  int pending_set = 0;
+  uint32_t pending_scenes = 0;
+  std::vector<uint32_t> pending_counts;
 };
 
 namespace {
@@ -137,6 +148,22 @@ bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, 
 void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
   tr.length += 1;                                     // sort.rs:160-176, track_attributes.rs:60-78
   tr.boxes.push(observed, predicted, o.history_length);
+}
+
+// What to_sort_track would read from a track whose history had just taken (observed, predicted) — without the history
+sa_sort_track to_sort_track_with(const sa_tracker_options& o, const Track& tr, const sa_box& observed, const sa_box& predicted) {
+  sa_sort_track s;
+  std::memset(&s, 0, sizeof s);
+  s.id = tr.id;
+  s.epoch = tr.epoch;
+  s.predicted_bbox = predicted;
+  s.observed_bbox = observed;
+  s.scene_id = tr.scene;
+  s.length = tr.length;
+  s.voting_type = (o.visual && tr.voting >= 0) ? tr.voting : SA_VOTE_POSITIONAL;
+  s.has_custom_object_id = tr.has_custom ? 1 : 0;
+  s.custom_object_id = tr.custom;
+  return s;
 }
 
 sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
@@ -244,6 +271,38 @@ void optimize_observations(std::vector<Obs>& obs, Obs&& nw, uint32_t max_observa
   std::swap(obs.front(), obs.back());
 }
 
+// The heavy half of a continued track's merge under device upkeep: history (the boxes are the candidate's and the device's prediction)
+// and, for VisualSort, the observation policy on the bookkeeping records (the feature rows move inside the device bank, sa_upkeep.hip).
+inline void merge_heavy(const sa_tracker_options& o, Track& tr, const sa_tracker::SceneScratch& W, uint32_t i) {
+  tr.boxes.push(W.cboxes[i], W.dev_pred[i], o.history_length);
+  if (o.visual) {
+    Obs nw;
+    nw.quality = W.cq[i];
+    nw.has_own = W.cown[i] == W.cown[i];
+    nw.own = nw.has_own ? W.cown[i] : 0.0f;
+    nw.has_feat = W.cpres[i] != 0;
+    if (!feature_can_be_used(o, W.cboxes[i], nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own, o.visual_minimal_own_area_percentage_collect))
+      nw.has_feat = false;
+    optimize_observations(tr.obs, std::move(nw), o.visual_max_observations);
+    tr.feat_count = 0;
+    for (auto& so : tr.obs) tr.feat_count += so.has_feat ? 1u : 0u;
+  }
+}
+
+// Runs what the previous predict() deferred (sa_tracker::pending).  Idempotent; every entry point that reads a track's history or
+// observations calls it first.
+void flush_pending(sa_tracker* t) {
+  if (!t->pending) return;
+  t->pending = false;
+  const std::vector<sa_tracker::SceneScratch>& ss = t->scratch[t->pending_set];
+  for (uint32_t s = 0; s < t->pending_scenes; ++s) {
+    const sa_tracker::SceneScratch& W = ss[s];
+    const uint32_t n = t->pending_counts[s];
+    for (uint32_t i = 0; i < n; ++i)
+      if (W.winners[i] != 0) merge_heavy(t->o, *W.trps[i], W, i);
+  }
+}
+
 int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
                    const sa_observation* const* obs, sa_sort_track* const* out) {
   const sa_tracker_options& o = t->o;
@@ -258,15 +317,19 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   const auto t_entry = clk::now();
   // auto waste (simple_api.rs:115-120)
   if (t->waste_counter == 0) {
+    flush_pending(t);   // (wasted tracks are read out with their histories)
     int rc = auto_waste(t);
     if (rc != SA_OK) return rc;
     t->waste_counter = o.auto_waste_periodicity;
   } else t->waste_counter -= 1;
 
-  if (t->scratch.size() < n_scenes) t->scratch.resize(n_scenes);
+  // (the other scratch set may hold the previous frame's deferred bookkeeping: it is run below, while this frame's association is on the device)
+  const int set = t->pending ? (t->pending_set ^ 1) : t->cur_set;
+  t->cur_set = set;
+  if (t->scratch[set].size() < n_scenes) t->scratch[set].resize(n_scenes);
   t->sc_epoch.resize(n_scenes);
   t->sc_req.resize(n_scenes);
-  std::vector<sa_tracker::SceneScratch>& ss = t->scratch;
+  std::vector<sa_tracker::SceneScratch>& ss = t->scratch[set];
   std::vector<uint64_t>& epoch = t->sc_epoch;
   std::vector<sa_scene_request>& req = t->sc_req;
   for (uint32_t s = 0; s < n_scenes; ++s) {
@@ -396,6 +459,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   } else
   if (rc == SA_OK) rc = sa_batch_run(t->eng);
   const auto t_run = clk::now();
+  flush_pending(t);   // the previous frame's deferred bookkeeping: while this frame's kernels run (or, on an error path, before the return)
   if (rc == SA_OK && !fused) rc = sa_batch_sync(t->eng);  // (fused: sa_batch_fetch waits for the END OF THE ASSOCIATION only — the upkeep kernels
                                                           // queued behind it run while this thread does its bookkeeping below)
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) {
@@ -485,7 +549,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         if (o.visual) tr.voting = W.votes[i];
         // optimize(is_merge = true): Kalman predict + update with the candidate's box, history (device upkeep: once the boxes are back)
         if (!o.device_upkeep) update_history(o, tr, cbox, make_prediction(pw, vw, tr.has_state, tr.kf, cbox));
-        if (o.visual) {
+        if (fused) tr.length += 1;   // (the rest of the merge — history, observation policy — is deferred: merge_heavy / flush_pending)
+        else if (o.visual) {
           Obs nw;
           nw.quality = c_quality; nw.has_own = c_has_own; nw.own = c_own; nw.has_feat = c_has_feat;
           if (!feature_can_be_used(o, cbox, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
@@ -517,12 +582,23 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       rc = fused ? sa_tracks_apply_collect(t->eng, s, nullptr, W.dev_pred.data()) : sa_tracks_apply_end(t->eng, s, W.dev_pred.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
       us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
+      if (fused) {
+        for (uint32_t i = 0; i < n; ++i)
+          out[s][i] = W.winners[i] != 0 ? to_sort_track_with(o, *W.trps[i], W.cboxes[i], W.dev_pred[i]) : to_sort_track(o, *W.trps[i]);
+        continue;
+      }
       for (uint32_t i = 0; i < n; ++i) {
         Track& tr = *W.trps[i];
         if (W.winners[i] != 0) update_history(o, tr, W.cboxes[i], W.dev_pred[i]);
         out[s][i] = to_sort_track(o, tr);
       }
     }
+  if (fused) {
+    t->pending = true;
+    t->pending_set = set;
+    t->pending_scenes = n_scenes;
+    t->pending_counts.assign(counts, counts + n_scenes);
+  }
   if (trace) {
     const auto t_end = clk::now();
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -635,6 +711,7 @@ int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* s
 
 int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_idle_tracks: null argument");
+  flush_pending(t);
   // IdleLookup  sort.rs:213-228: same scene and last_updated_epoch != current epoch
   uint32_t n = 0;
   for (const auto* m : {&t->by_scene, &t->evicted}) {   // (evicted tracks are idle tracks like any other until they are wasted)
@@ -654,6 +731,7 @@ int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out,
 
 int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n) {
   if (!t) return SA_ERR_BAD_ARG;
+  flush_pending(t);
   t->epochs[scene_id] += n;  // skip_epochs_for_scene  epoch_db.rs:11-20
   return auto_waste(t);      // tracker_api.rs:48-51
 }
@@ -666,6 +744,7 @@ int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out) {
 
 int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_wasted: null argument");
+  flush_pending(t);
   int rc = auto_waste(t);
   if (rc != SA_OK) return rc;
   std::sort(t->wasted_store.begin(), t->wasted_store.end(), [](const Track& a, const Track& b) { return a.id < b.id; });
@@ -703,6 +782,7 @@ int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, floa
 
 int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]) {
   if (!t || !out4) return SA_ERR_BAD_ARG;
+  flush_pending(t);
   auto it = t->store.find(track_id);
   if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
   const Track& tr = it->second;

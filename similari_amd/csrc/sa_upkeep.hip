@@ -317,9 +317,19 @@ static void launch_visual_apply(const ApplyArgs& a, const BankArgs& b, const SaP
 
 // done (optional): the step's LAST dispatch carries it as its own completion signal — a caller that waits for the step waits for the
 // event instead of synchronising the stream (a marker packet and its round trip through the command processor: ~10 us)
-hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done) {
+// part: 0 = the whole step (VisualSORT: Kalman and bank blocks in ONE launch); 1 = the Kalman half alone, 2 = the bank half alone — a
+// caller that hands the predicted boxes out as soon as they exist (the tracker facade) waits for the first and lets the second run on
+hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done, int part) {
   if (!a.n) return hipSuccess;
-  if (!b) {
+  if (part == 2) {
+    if (!b) return hipSuccess;
+    ApplyArgs none = a;
+    if (b->K <= 4) { if (done) hipExtLaunchKernelGGL(k_apply_visual<4>, dim3(b->n), dim3(256), 0, st, nullptr, done, 0, none, *b, p, 0u); else hipLaunchKernelGGL(k_apply_visual<4>, dim3(b->n), dim3(256), 0, st, none, *b, p, 0u); }
+    else if (b->K <= 8) { if (done) hipExtLaunchKernelGGL(k_apply_visual<8>, dim3(b->n), dim3(256), 0, st, nullptr, done, 0, none, *b, p, 0u); else hipLaunchKernelGGL(k_apply_visual<8>, dim3(b->n), dim3(256), 0, st, none, *b, p, 0u); }
+    else { if (done) hipExtLaunchKernelGGL(k_apply_visual<SA_MAX_BANK>, dim3(b->n), dim3(256), 0, st, nullptr, done, 0, none, *b, p, 0u); else hipLaunchKernelGGL(k_apply_visual<SA_MAX_BANK>, dim3(b->n), dim3(256), 0, st, none, *b, p, 0u); }
+    return hipGetLastError();
+  }
+  if (!b || part == 1) {
     if (done) hipExtLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, nullptr, done, 0, a, p);
     else hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, a, p);
     return hipGetLastError();
