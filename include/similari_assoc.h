@@ -245,7 +245,10 @@ int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted);
  * id_base[slot] + 1 + i — Batch* trackers draw one id per candidate, batch_api.rs:102-106).  The caller waits ONCE (sa_batch_sync /
  * sa_batch_fetch), then sa_tracks_apply_collect(slot) updates the host side of the table and hands out, per candidate, the id it
  * started a track with (0 where it merged) and the destination track's predicted box.  Either output may be NULL.  A pending slot is
- * collected by any entry point that needs the finished table.  Synchronous batches only. */
+ * collected by any entry point that needs the finished table.  Synchronous batches only.
+ * sa_tracks_apply_collect returns as soon as the boxes and the table's rows are out: a VisualSORT engine may still be moving feature
+ * rows inside its bank (kernels queued behind the Kalman step) — every later call on the engine is ordered behind them; the candidates'
+ * feature rows (device blocks, pinned blocks) must stay untouched until the next call on the engine has returned. */
 int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base /* one per staged scene */, int id_per_candidate);
 int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted);
 /* Full per-track state for the device-side upkeep (debug / parity / seeding): Kalman mean[10] + cov[100] row-major, and per

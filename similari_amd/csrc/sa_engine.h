@@ -295,6 +295,12 @@ struct ApplyArgs {
   uint64_t* t_ids;
   float* maha;
   sa_box* out_pred;          // [n] device view of pinned host memory
+  // The Kalman dispatch of a VisualSORT upkeep queued behind the association also takes the candidates' feature rows OUT OF THE CALLER'S
+  // MEMORY (a registered device block read in place) into the slot's own buffer — n more blocks, one row each — so that the bank
+  // dispatch behind it reads engine memory only: when this dispatch has retired, nothing of the engine reads caller memory any more.
+  const float* copy_src;     // nullptr: nothing to copy
+  float* copy_dst;
+  uint32_t copy_row_floats;
 };
 struct BankArgs {
   const BoxRaw* c_raw;

@@ -1665,10 +1665,17 @@ static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const ui
   a.T0 = s->fused_T0; a.id_base = s->fused_id_base; a.id_per_candidate = s->fused_per_candidate;
   a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
   a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
+  // queued behind the association, Kalman dispatch first: the rows a registered device block is read in place for leave the caller's
+  // memory with that dispatch (ApplyArgs::copy_src); the bank dispatch reads the slot's copy
+  const bool in_place = e->visual && s->has_feats && e->D == e->Dp && s->feats_device && s->p_feat_raw == (void*)s->feats_device;
+  if (part == 1 && in_place) {
+    TRY(dev_ensure(e, s->feat_raw, (size_t)n * e->D * 4));
+    a.copy_src = (const float*)s->feats_device; a.copy_dst = (float*)s->feat_raw.p; a.copy_row_floats = e->D;
+  }
   BankArgs b{};
   if (e->visual) {
     b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.T0 = a.T0; b.n = n; b.K = e->K; b.Dp = e->Dp;
-    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? s->p_feat_raw : s->feat.p) : nullptr; b.c_fnorm = s->prepped ? (const float*)s->fnorm.p : nullptr;   // (a lean frame: D == Dp, the step forms the norms of the rows it stores)
+    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? ((part == 2 && in_place) ? s->feat_raw.p : s->p_feat_raw) : s->feat.p) : nullptr; b.c_fnorm = s->prepped ? (const float*)s->fnorm.p : nullptr;   // (a lean frame: D == Dp, the step forms the norms of the rows it stores)
     b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
     b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
     b.c_own = s->has_own ? (const float*)s->p_own : nullptr;

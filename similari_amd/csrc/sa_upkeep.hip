@@ -181,9 +181,14 @@ __device__ __forceinline__ void kalman_block(const ApplyArgs& a, const SaParams&
   sa_maha_prepare(p.kf_position_weight, mean5, cov25, a.maha + (size_t)row * 20);
   a.out_pred[i] = pred;
 }
-__global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p) {
+__global__ __launch_bounds__(256) void k_apply_kalman(ApplyArgs a, SaParams p, uint32_t kf_blocks) {
   __shared__ KfLds s_kf[4];
-  kalman_block(a, p, blockIdx.x, s_kf);
+  if (blockIdx.x < kf_blocks) { kalman_block(a, p, blockIdx.x, s_kf); return; }
+  // (ApplyArgs::copy_src: one candidate's feature row out of the caller's block; rows are 16-byte aligned multiples of 32 floats)
+  const uint32_t i = blockIdx.x - kf_blocks;
+  const float4* src = (const float4*)(a.copy_src + (size_t)i * a.copy_row_floats);
+  float4* dst = (float4*)(a.copy_dst + (size_t)i * a.copy_row_floats);
+  for (uint32_t x = threadIdx.x; x < a.copy_row_floats / 4u; x += 256u) dst[x] = src[x];
 }
 
 // Polygons of the oriented boxes among the rows k_apply_kalman refreshed: cos / sin from the host's libm (sa_tracks_apply), geometry
@@ -330,8 +335,9 @@ hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams
     return hipGetLastError();
   }
   if (!b || part == 1) {
-    if (done) hipExtLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, nullptr, done, 0, a, p);
-    else hipLaunchKernelGGL(k_apply_kalman, dim3(cdiv(a.n, 4)), dim3(256), 0, st, a, p);
+    const uint32_t kfb = cdiv(a.n, 4), grid = kfb + (a.copy_src ? a.n : 0u);
+    if (done) hipExtLaunchKernelGGL(k_apply_kalman, dim3(grid), dim3(256), 0, st, nullptr, done, 0, a, p, kfb);
+    else hipLaunchKernelGGL(k_apply_kalman, dim3(grid), dim3(256), 0, st, a, p, kfb);
     return hipGetLastError();
   }
   if (b->K <= 4) launch_visual_apply<4>(a, *b, p, st, done);

@@ -541,3 +541,20 @@ def test_frame_sizes_from_empty_to_hundreds_match_oracle(kind, backend):
     finally:
         g.close()
         o.close()
+
+
+@pytest.mark.gpu
+def test_caller_may_overwrite_its_device_feature_block_once_predict_has_returned():
+    """The reference's predict() takes the observations' features by value.  Here a registered device block is READ IN PLACE, and the
+    VisualSORT upkeep's bank dispatches are still running when predict() returns — they must not read the caller's block any more
+    (the Kalman dispatch takes the rows into engine memory first).  Runs tests/devblock_overwrite_child.py (the device buffers are torch
+    tensors, and torch's HIP context wants to be the first one of its process): two device-upkeep trackers see the same frames, one
+    from a fresh region of device memory per frame, the other from ONE buffer that is overwritten — garbage, then the next frame —
+    right after every predict() has returned; their tracks and their feature banks must be the same."""
+    import os
+    import subprocess
+    import sys
+
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "devblock_overwrite_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OVERWRITE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
