@@ -119,6 +119,8 @@ struct SceneDev {
   int64_t SA_G* rdist;
   int32_t SA_G* rnext;       // [N] general tail: rows in the component rooted at this row
   uint32_t SA_G* lab;        // [N] general tail: component root of the row (SA_NONE: takes no part)
+  uint2 SA_G* crow;          // [N][SA_CROW] general tail: the first SA_CROW rows of the component rooted at a row, (row, usable-edge count), in the
+                             // order they arrived (k_assign_label) — a mid-sized component of up to SA_CROW rows is gathered from ONE load
   uint32_t SA_G* cwin;       // [T] general tail, big components: lowest row bidding for the column (SA_NONE between frames)
   uint32_t SA_G* big_rows;   // [N] rows, then search roots, of the big components: one ascending segment each
   uint32_t SA_G* big_bcol;   // [N] the column a row bids for
@@ -144,6 +146,7 @@ struct SceneDev {
 // while k_assign_solve runs (workgroups on different XCDs), and stats[0] next door is read and written with plain accesses by that
 // kernel's first thread — a line held in one XCD's L2 by plain accesses and updated by other XCDs' atomics is not something to rely on.
 // Zeroed by k_assign_label's first thread.
+#define SA_CROW 32u
 #define SA_QW_TOP 32       // top of the dense solver's row lists
 #define SA_QW_LEN 33       // queue length
 #define SA_QW_TICKET 34    // next ticket

@@ -78,7 +78,7 @@ struct Slot {  // one scene of a request set
   DevBuf vis_max_key, row_part_w, row_part_t, col_part_w, col_part_q, row_has, vis_winner, col_excluded, vote_best;
   DevBuf parent, label, next_row, e_cnt, e_use, e_edge, u, u_use, v, rmatch, cmatch, dist, pred, cstamp, cscan, cnext, rdist, rnext;
   DevBuf win_col;                              // device-side upkeep: the winners as table columns
-  DevBuf lab, cwin, big_rows, big_bcol, dq, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
+  DevBuf lab, crow, cwin, big_rows, big_bcol, dq, dense;  // general tail: component labels, the dense solver's queue and lists; both tails: its matrix
   DevBuf stats;                                // [4] words raised by the first phase, moved to h_out and re-armed by the tail
   DevBuf tap;                                  // SA_FLAG_TAP: row words [n] | column words [t] | edge counts [n], written by the assignment tail
   HostBuf h_apply, h_pred, h_fix;
@@ -504,6 +504,7 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   TRY(dev_ensure(e, s->win_col, n * 4));
   {  // the general tail's component labels and the lists of its cooperative solver (a batch takes that tail when ANY scene needs it)
     TRY(dev_ensure(e, s->lab, n * 4));
+    TRY(dev_ensure(e, s->crow, n * SA_CROW * 8));
     TRY(dev_ensure(e, s->cwin, t * 4));
     TRY(dev_ensure(e, s->big_rows, n * 4));
     TRY(dev_ensure(e, s->big_bcol, n * 4));
@@ -569,7 +570,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->out_track_id = (decltype(d->out_track_id))(s->d_out); d->out_vote = (decltype(d->out_vote))((uint8_t*)s->d_out + (size_t)(s->N ? s->N : 1) * 8);
   d->quant = (decltype(d->quant))(s->quant.p);
   d->win_col = (decltype(d->win_col))(s->win_col.p);
-  d->lab = (decltype(d->lab))(s->lab.p); d->cwin = (decltype(d->cwin))(s->cwin.p); d->big_rows = (decltype(d->big_rows))(s->big_rows.p);
+  d->lab = (decltype(d->lab))(s->lab.p); d->crow = (decltype(d->crow))(s->crow.p); d->cwin = (decltype(d->cwin))(s->cwin.p); d->big_rows = (decltype(d->big_rows))(s->big_rows.p);
   d->big_bcol = (decltype(d->big_bcol))(s->big_bcol.p); d->dq = (decltype(d->dq))(s->dq.p); d->dense = (decltype(d->dense))(s->dense.p);
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
@@ -1055,7 +1056,7 @@ void sa_engine_destroy(sa_engine* e) {
                         &s->row_part_t, &s->col_part_w, &s->col_part_q, &s->row_has, &s->vis_winner, &s->col_excluded, &s->vote_best,
                         &s->parent, &s->label, &s->next_row, &s->e_cnt, &s->e_use, &s->e_edge, &s->u, &s->u_use, &s->v, &s->rmatch,
                         &s->cmatch, &s->dist, &s->pred, &s->cstamp, &s->cscan, &s->cnext, &s->rdist, &s->rnext, &s->win_col,
-                        &s->stats, &s->tap, &s->lab, &s->cwin, &s->big_rows, &s->big_bcol, &s->dq, &s->dense})
+                        &s->stats, &s->tap, &s->lab, &s->crow, &s->cwin, &s->big_rows, &s->big_bcol, &s->dq, &s->dense})
         free_dev(*b);
       free_host(s->h_apply);
       free_host(s->h_fix);

@@ -1160,7 +1160,8 @@ __device__ __forceinline__ void sa_label_phase(const SceneDev& S, bool words, ui
   if (!cnt || (words ? has_verdict : S.row_has[q] != 0)) { S.lab[q] = SA_NONE; return; }
   const uint32_t root = sa_uf_find((uint32_t*)S.parent, q);
   S.lab[q] = root;
-  atomicAdd((uint32_t*)(S.rnext + root), 1u);  // rows in the component (rnext is zeroed by the preparation blocks)
+  const uint32_t pos = atomicAdd((uint32_t*)(S.rnext + root), 1u);  // rows in the component (rnext is zeroed by the preparation blocks)
+  if (pos < SA_CROW) S.crow[(size_t)root * SA_CROW + pos] = make_uint2(q, cnt);   // (k_assign_solve's middle tier: the component from one load)
   S.next_row[q] = atomicExch((uint32_t*)(S.label + root), q);
 }
 template <bool WORDS>
@@ -1250,9 +1251,18 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   MID_STAMP(0);
   // rows, ascending: the labels from the root on (it is the component's lowest row), sixteen loads in flight per lane (a frame of up to
   // 1024 detections: one trip)
-  // ... and their usable-edge counts in the SAME trip (a second one otherwise: what the label kernel wrote lies in memory, ~1.5 us away)
+  // ... and their usable-edge counts in the SAME trip (a second one otherwise: what the label kernel wrote lies in memory, ~1.5 us away).
+  // A component of at most SA_CROW rows: from the list the label kernel left at its root — one load per lane instead of 32; the rows
+  // arrive in any order, a rank by counting puts them in ascending order.
   uint32_t cnt = 0;
-  {
+  const bool listed = R <= SA_CROW;   // (wave-uniform: R comes with the queue entry)
+  if (listed) {
+    const uint2 rc = lane < R ? S.crow[(size_t)root * SA_CROW + lane] : make_uint2(SA_NONE, 0u);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < R; ++j) rank += (uint32_t)__shfl((int)rc.x, (int)j) < rc.x ? 1u : 0u;
+    if (lane < R) { M.rows[rank] = rc.x; M.roots[rank] = rc.y; }
+    cnt = R;
+  } else {
     for (uint32_t r0 = root; r0 < N && cnt < R; r0 += 1024) {
       uint32_t lb8[16], ne8[16];
 #pragma unroll
@@ -1280,92 +1290,152 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
   for (int h = 0; h < ML_C / 64; ++h) { M.cmatch[lane + 64u * (uint32_t)h] = -1; M.pred[lane + 64u * (uint32_t)h] = (int32_t)0x7fffffff; }
   if (lane == 0) { M.ncols = 0; M.fail = 0; }
   sa_wave_sync();
-  // pass 1 over the edges (lane = row): the distinct usable columns into the hash table
   const uint32_t row = lane < R ? M.rows[lane] : 0u;
   const uint32_t ne = lane < R ? M.roots[lane] : 0u;
   const SaEdge SA_G* ep = S.e_edge + (size_t)row * S.estride;
-  for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
-    SaEdge ed[4];
-    bool use[4];
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-      if (!use[k2]) continue;
-      if (ed[k2].gain > (int64_t)SA_DENSE_K32_MAXGAIN) { M.fail = 1; continue; }
-      const uint32_t col = ed[k2].col;
-      uint32_t slot = (col * 2654435761u) >> 23;
-      bool placed = false;
-      for (uint32_t probe = 0; probe < ML_H; ++probe) {
-        const uint32_t old = atomicCAS(&M.hkey[slot], SA_NONE, col);
-        if (old == SA_NONE) { if (atomicAdd(&M.ncols, 1u) >= ML_C) M.fail = 1; placed = true; break; }
-        if (old == col) { placed = true; break; }
-        slot = (slot + 1u) & (ML_H - 1u);
-      }
-      if (!placed) M.fail = 1;
-    }
-    if (*(volatile uint32_t*)&M.fail) break;
+  // every edge of the component: offsets by a wave scan of the rows' counts
+  uint32_t incl = ne;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += up;
   }
-  sa_wave_sync();
-  if (__builtin_amdgcn_readfirstlane((int)M.fail)) return false;  // (one word, every lane reads the same: uniform for the compiler too)
-  const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.ncols);
-  MID_STAMP(2);
-  MID_NOTE(7, ((unsigned long long)R << 32) | C);
-  const uint32_t ldc = C <= 128u ? 128u : 256u;   // the matrix: [R][128], or [R][256] when the rows allow it
-  if (R * ldc > ML_CELLS) return false;
-  // the columns in ascending order of their track index: the occupied slots compacted, every key ranked among them
-  {
-    uint32_t base = 0;
-#pragma unroll
-    for (int h = 0; h < ML_H / 64; ++h) {
-      const uint32_t sl = lane + 64u * (uint32_t)h;
-      const uint32_t key = M.hkey[sl];
-      const unsigned long long m = __ballot(key != SA_NONE);
-      if (key != SA_NONE) {
-        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        M.ckey[at] = key;
-        M.cslot[at] = sl;
-      }
-      base += (uint32_t)__popcll(m);
+  const uint32_t eoff = incl - ne, total = (uint32_t)__shfl((int)incl, 63);
+  const bool fast = listed && total <= 64u;   // (wave-uniform)
+  uint32_t C = 0, ldc = 128u;
+  int32_t maxg = 0, bj = -1;
+  if (fast) {
+    // A knot of a crowd — a handful of rows, a few dozen edges, what the tracker loop's crowd frames consist of: ONE EDGE PER LANE.  The
+    // records come in one trip (not a serial walk per row, and not twice), the distinct columns are ranked by two passes over the
+    // (at most 64) column words in LDS instead of a hash table + compaction + rank + second walk, the matrix is [R][64].  (In-kernel
+    // timeline of the hash path on such knots: columns hashed 2.1 us, ranked 1.4, matrix 1.1 — for a 0.5 us search.)
+    uint32_t* const erow = M.ckey; uint32_t* const ek = M.cslot;
+    uint32_t* const ecol = M.hkey; uint32_t* const ecid = M.hkey + 64; uint32_t* const efirst = M.hkey + 128;
+    int32_t* const egain = (int32_t*)M.hval;
+    for (uint32_t k = 0; k < ne; ++k) { erow[eoff + k] = lane; ek[eoff + k] = k; }
+    sa_wave_sync();
+    const bool valid = lane < total;
+    const uint32_t er = valid ? erow[lane] : 0u;
+    const SaEdge ed = valid ? sa_ldg(S.e_edge + (size_t)M.rows[er] * S.estride + ek[lane]) : SaEdge{0, 0u, 0u};
+    const bool use = valid && !(VISUAL && S.col_excluded[ed.col]);
+    if (__ballot(use && ed.gain > (int64_t)SA_DENSE_K32_MAXGAIN)) return false;
+    const uint32_t key = use ? ed.col : SA_NONE;
+    ecol[lane] = key;
+    sa_wave_sync();
+    // (four column words per LDS read; a lane beyond the last edge holds SA_NONE, which equals no key and lies below none)
+    const uint32_t quads = (total + 3u) / 4u;
+    bool first = use;
+    for (uint32_t x = 0; x < quads; ++x) {
+      const uint4 o = ((const uint4*)ecol)[x];
+      const uint32_t j = 4u * x;
+      first = first && !((j < lane && o.x == key) || (j + 1u < lane && o.y == key) || (j + 2u < lane && o.z == key) || (j + 3u < lane && o.w == key));
     }
-  }
-  for (uint32_t i = lane; i < R * (ldc / 4); i += 64) ((uint4*)M.gain)[i] = make_uint4(0u, 0u, 0u, 0u);
-  for (uint32_t i = lane; i < ML_C; i += 64)
-    if (i >= C) M.ckey[i] = SA_NONE;   // (padding of the rank loop's vector reads: the largest word, never below a key)
-  sa_wave_sync();
-  for (uint32_t i = lane; i < C; i += 64) {
-    const uint32_t key = M.ckey[i];
+    efirst[lane] = first ? key : SA_NONE;   // the DISTINCT columns: a repeated one leaves SA_NONE
+    sa_wave_sync();
     uint32_t rank = 0;
-    for (uint32_t x = 0; x < C; x += 4) {
-      const uint4 o = *(const uint4*)&M.ckey[x];
+    for (uint32_t x = 0; x < quads; ++x) {
+      const uint4 o = ((const uint4*)efirst)[x];
       rank += (o.x < key) + (o.y < key) + (o.z < key) + (o.w < key);
     }
-    M.hval[M.cslot[i]] = rank;
-    M.cols[rank] = key;
-  }
-  sa_wave_sync();
-  MID_STAMP(3);
-  // pass 2: gains into the matrix, the row's dual and its bid (heaviest usable edge, lowest column on ties)
-  int32_t maxg = 0, bj = -1;
-  for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
-    SaEdge ed[4];
-    bool use[4];
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-      if (!use[k2]) continue;
-      const uint32_t col = ed[k2].col;
-      uint32_t slot = (col * 2654435761u) >> 23;
-      while (M.hkey[slot] != col) slot = (slot + 1u) & (ML_H - 1u);  // (present: pass 1 placed it)
-      const int32_t j = (int32_t)M.hval[slot];
-      const int32_t g = (int32_t)ed[k2].gain;
-      M.gain[lane * ldc + (uint32_t)j] = g;
-      if (g > maxg || (g == maxg && j < bj)) { maxg = g; bj = j; }
+    C = (uint32_t)__popcll(__ballot(first));
+    MID_STAMP(2);
+    MID_NOTE(7, ((unsigned long long)R << 32) | C);
+    ldc = 64u;
+    if (first) M.cols[rank] = key;
+    for (uint32_t i = lane; i < R * 16u; i += 64) ((uint4*)M.gain)[i] = make_uint4(0u, 0u, 0u, 0u);
+    egain[lane] = use ? (int32_t)ed.gain : 0;
+    ecid[lane] = rank;
+    sa_wave_sync();
+    MID_STAMP(3);
+    if (use) M.gain[er * 64u + rank] = (int32_t)ed.gain;
+    for (uint32_t k = 0; k < ne; ++k) {
+      const int32_t g = egain[eoff + k], j = (int32_t)ecid[eoff + k];
+      if (g > 0 && (g > maxg || (g == maxg && j < bj))) { maxg = g; bj = j; }
+    }
+    sa_wave_sync();
+  } else {
+    // pass 1 over the edges (lane = row): the distinct usable columns into the hash table
+    for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+      SaEdge ed[4];
+      bool use[4];
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        if (!use[k2]) continue;
+        if (ed[k2].gain > (int64_t)SA_DENSE_K32_MAXGAIN) { M.fail = 1; continue; }
+        const uint32_t col = ed[k2].col;
+        uint32_t slot = (col * 2654435761u) >> 23;
+        bool placed = false;
+        for (uint32_t probe = 0; probe < ML_H; ++probe) {
+          const uint32_t old = atomicCAS(&M.hkey[slot], SA_NONE, col);
+          if (old == SA_NONE) { if (atomicAdd(&M.ncols, 1u) >= ML_C) M.fail = 1; placed = true; break; }
+          if (old == col) { placed = true; break; }
+          slot = (slot + 1u) & (ML_H - 1u);
+        }
+        if (!placed) M.fail = 1;
+      }
+      if (*(volatile uint32_t*)&M.fail) break;
+    }
+    sa_wave_sync();
+    if (__builtin_amdgcn_readfirstlane((int)M.fail)) return false;  // (one word, every lane reads the same: uniform for the compiler too)
+    C = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.ncols);
+    MID_STAMP(2);
+    MID_NOTE(7, ((unsigned long long)R << 32) | C);
+    ldc = C <= 128u ? 128u : 256u;   // the matrix: [R][128], or [R][256] when the rows allow it
+    if (R * ldc > ML_CELLS) return false;
+    // the columns in ascending order of their track index: the occupied slots compacted, every key ranked among them
+    {
+      uint32_t base = 0;
+  #pragma unroll
+      for (int h = 0; h < ML_H / 64; ++h) {
+        const uint32_t sl = lane + 64u * (uint32_t)h;
+        const uint32_t key = M.hkey[sl];
+        const unsigned long long m = __ballot(key != SA_NONE);
+        if (key != SA_NONE) {
+          const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          M.ckey[at] = key;
+          M.cslot[at] = sl;
+        }
+        base += (uint32_t)__popcll(m);
+      }
+    }
+    for (uint32_t i = lane; i < R * (ldc / 4); i += 64) ((uint4*)M.gain)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = lane; i < ML_C; i += 64)
+      if (i >= C) M.ckey[i] = SA_NONE;   // (padding of the rank loop's vector reads: the largest word, never below a key)
+    sa_wave_sync();
+    for (uint32_t i = lane; i < C; i += 64) {
+      const uint32_t key = M.ckey[i];
+      uint32_t rank = 0;
+      for (uint32_t x = 0; x < C; x += 4) {
+        const uint4 o = *(const uint4*)&M.ckey[x];
+        rank += (o.x < key) + (o.y < key) + (o.z < key) + (o.w < key);
+      }
+      M.hval[M.cslot[i]] = rank;
+      M.cols[rank] = key;
+    }
+    sa_wave_sync();
+    MID_STAMP(3);
+    // pass 2: gains into the matrix, the row's dual and its bid (heaviest usable edge, lowest column on ties)
+    for (uint32_t e0 = 0; e0 < ne; e0 += 4) {
+      SaEdge ed[4];
+      bool use[4];
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < ne ? sa_ldg(ep + e0 + k2) : SaEdge{0, 0u, 0u};
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) use[k2] = e0 + k2 < ne && !(VISUAL && S.col_excluded[ed[k2].col]);
+  #pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        if (!use[k2]) continue;
+        const uint32_t col = ed[k2].col;
+        uint32_t slot = (col * 2654435761u) >> 23;
+        while (M.hkey[slot] != col) slot = (slot + 1u) & (ML_H - 1u);  // (present: pass 1 placed it)
+        const int32_t j = (int32_t)M.hval[slot];
+        const int32_t g = (int32_t)ed[k2].gain;
+        M.gain[lane * ldc + (uint32_t)j] = g;
+        if (g > maxg || (g == maxg && j < bj)) { maxg = g; bj = j; }
+      }
     }
   }
   if (lane < R) {
@@ -1396,7 +1466,8 @@ __device__ __forceinline__ bool mid_solve_component(const SceneDev& S, uint32_t 
     sa_dense_ws w;
     w.gain = (const int64_t*)M.gain; w.ld = ldc; w.T = ldc;
     w.u = M.u; w.rmatch = M.rmatch; w.cmatch = M.cmatch; w.pred = M.pred; w.part = nullptr;
-    if (ldc == 128u) sa_assign_component_dense<64, 2, true, true>(w, M.roots, n_roots);
+    if (ldc == 64u) sa_assign_component_dense<64, 1, true, true>(w, M.roots, n_roots);
+    else if (ldc == 128u) sa_assign_component_dense<64, 2, true, true>(w, M.roots, n_roots);
     else sa_assign_component_dense<64, 4, true, true>(w, M.roots, n_roots);
   }
   MID_STAMP(5);
@@ -1575,10 +1646,10 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   __shared__ union { SolveLocal pool[SL_POOL]; MidLocal mid[ML_WAVES]; } s_sh;  // (the middle tier runs after the small one, over its pool)
   SolveLocal* const s_local = s_sh.pool;
   __shared__ unsigned long long s_part[2 * (NT / 64)];
-  __shared__ uint32_t s_pool_top, s_word[6], s_fail[NT], s_nfail[ML_WAVES];
+  __shared__ uint32_t s_pool_top, s_word[6], s_fail[NT], s_nfail[ML_WAVES], s_resume;
   extern __shared__ unsigned char s_dyn[];
   SOLVE_STAMP(0);
-  if (threadIdx.x == 0) s_pool_top = 0;
+  if (threadIdx.x == 0) { s_pool_top = 0; s_resume = 0xffffffffu; }
   if (threadIdx.x < ML_WAVES) s_nfail[threadIdx.x] = 0;
   // the forest has done its job (k_assign_label): back to the identity for the next frame's unions
   if (row_wg)
@@ -1834,26 +1905,12 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t nref = 0;
     if (wv < ML_WAVES) {
-      // Before the first ticket: is there a mid-sized component at all?  (A frame without one — most tracking frames — leaves here at the
-      // price of the old wait: the report count and the two queue lengths, no ticket, no slot.)
-      bool any = false;
-      for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-        const uint32_t ml = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t d = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        any = __builtin_amdgcn_readfirstlane((int)ml) != 0;
-        if (any) break;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d) >= row_wgs) {  // every push has been performed: the lengths are final
-          const uint32_t ml2 = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t l2 = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same trip)
-          any = __builtin_amdgcn_readfirstlane((int)ml2) != 0;
-          nbig_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)l2);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      while (any && nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront takes no more tickets — the other workgroups' do)
-        const uint32_t tk = atomicAdd((uint32_t*)(S.stats + SA_QW_MTICKET), (threadIdx.x & 63u) == 0 ? 1u : 0u);
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+      // No tickets: workgroup b serves the entries b, b + (workgroups), ... of the queue — entries are numbered in the order they were
+      // pushed, workgroups in the order they were dispatched, so the first knots go to the workgroups that are through first, and a
+      // frame WITHOUT a mid-sized component (most tracking frames) leaves here at the price of the old wait: one poll of its slot and of
+      // the report count, then the slot again + the big queue's length once every row workgroup has reported.
+      uint32_t k = blockIdx.x;
+      while (nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront serves no more — its later entries would be lost, so it is sized for every row it could get)
         if (k >= N) break;  // (at most one mid-sized component per row)
         uint32_t ent = SA_NONE;
         for (uint32_t spin = 0; spin < (1u << 22); ++spin) {  // (bounded: ~1 s; a slot that never fills and a report that never comes is a bug, not a hang)
@@ -1870,6 +1927,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
           }
           __builtin_amdgcn_s_sleep(2);
         }
+        k += gridDim.x;
         if (ent == SA_NONE) break;
         ++took_mid;
         const uint32_t root = ent & 0xffffffu, R = ent >> 24;
@@ -1877,7 +1935,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
         s_fail[wv * (NT / ML_WAVES) + nref] = root;
         nref += ok ? 0u : 1u;
       }
-      if ((threadIdx.x & 63u) == 0) s_nfail[wv] = nref;
+      if ((threadIdx.x & 63u) == 0) { s_nfail[wv] = nref; s_resume = k; }   // (k: the first of this workgroup's entries the wavefront did not look at)
     }
   }
   SOLVE_STAMP(2);
@@ -1897,6 +1955,8 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   SOLVE_NOTE(6, ((unsigned long long)nbig << 32) | __hip_atomic_load((uint32_t*)(S.stats + SA_QW_MLEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   uint32_t nrefused = 0;
   for (uint32_t w2 = 0; w2 < ML_WAVES; ++w2) nrefused += s_nfail[w2];
+  // (a wavefront whose refusal list filled up left entries of this workgroup unserved: the workgroup takes them below, one by one)
+  const bool leftover = nrefused >= NT / ML_WAVES && s_resume < N;
   if (nbig == 0 && nrefused == 0) { SOLVE_STAMP(5); return; }
   int64_t* u = LDS_STATE ? (int64_t*)s_dyn : (int64_t*)S.u_use;
   int32_t* rmatch = LDS_STATE ? (int32_t*)(s_dyn + (size_t)N * 8) : (int32_t*)S.rmatch;
@@ -1929,6 +1989,12 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     const uint32_t nf = s_nfail[w2];
     for (uint32_t i = 0; i < nf; ++i) dense_one(s_fail[w2 * (NT / ML_WAVES) + i]);
   }
+  if (leftover)
+    for (uint32_t k = s_resume; k < N; k += gridDim.x) {   // (every row workgroup has reported: the slots are final)
+      const uint32_t ent = __hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ent == SA_NONE) break;
+      dense_one(ent & 0xffffffu);
+    }
   SOLVE_STAMP(5);
 }
 
