@@ -1468,6 +1468,12 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
     if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
   } else if (!e->synced) TRY(engine_sync(e));
   const uint8_t* h = (const uint8_t*)s->h_out.p;
+  {
+    // (k_assign_solve's waits for the scene's row workgroups are bounded: a wait that ran out — the launch's workgroups were not all
+    // resident, e.g. a partitioned or heavily shared device — leaves a mark instead of a hung queue)
+    const uint32_t* st4 = (const uint32_t*)(h + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
+    if (s->N && st4[1]) return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the frame's results are not valid");
+  }
   if (out_track_id) std::memcpy(out_track_id, h, (size_t)s->N * 8);
   if (out_voting_type) std::memcpy(out_voting_type, h + (size_t)s->N * 8, s->N);
   return SA_OK;
@@ -1614,6 +1620,8 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     const Slot* s = b->slots[i];
     const uint8_t* h = (const uint8_t*)s->h_out.p;
+    if (s->N && ((const uint32_t*)(h + (((size_t)s->N * 9 + 7) & ~(size_t)7)))[1])   // (see sa_batch_fetch)
+      return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the results of ticket %llu are not valid", (unsigned long long)ticket);
     if (res[i].out_track_id) std::memcpy(res[i].out_track_id, h, (size_t)s->N * 8);
     if (res[i].out_voting_type) std::memcpy(res[i].out_voting_type, h + (size_t)s->N * 8, s->N);
   }

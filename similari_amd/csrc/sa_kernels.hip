@@ -619,6 +619,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
+    S.out_stats[1] = 0u;   // (k_assign_solve: a bounded wait ran out — the host refuses the frame's results)
     S.stats[0] = 0u;
   }
   __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
@@ -1656,6 +1657,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     for (uint32_t i = q; i < S.N + S.T; i += row_wgs * NT) S.parent[i] = i;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
     S.out_stats[0] = S.stats[0];
+    S.out_stats[1] = 0u;   // (k_assign_solve: a bounded wait ran out — the host refuses the frame's results)
     S.stats[0] = 0u;
   }
   if (VISUAL && rearm_words) {
@@ -1926,6 +1928,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
             break;
           }
           __builtin_amdgcn_s_sleep(2);
+          if (spin + 1u == (1u << 22)) S.out_stats[1] = 1u;   // gave up: a row workgroup that never reported (a partitioned or shared device?)
         }
         k += gridDim.x;
         if (ent == SA_NONE) break;
@@ -1944,8 +1947,10 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
   // in the same grid, which never wait themselves).
   if (threadIdx.x == 0) {
     if (nbig_seen == SA_NONE) {
-      for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs; ++spin)
+      for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load((uint32_t*)(S.stats + SA_QW_DONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < row_wgs; ++spin) {
         __builtin_amdgcn_s_sleep(4);
+        if (spin + 1u == (1u << 22)) S.out_stats[1] = 1u;
+      }
       nbig_seen = __hip_atomic_load((uint32_t*)(S.stats + SA_QW_LEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     s_word[3] = nbig_seen;
