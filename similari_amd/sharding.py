@@ -308,6 +308,42 @@ def pack_share(items, D: int, feat_base: int = 0, flags: int = 0) -> np.ndarray:
     return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
 
 
+def pack_share_into(dst: np.ndarray, items, D: int, feat_base: int = 0, flags: int = 0) -> int:
+    """pack_share written straight into `dst` (a uint8 view of the pinned staging row of the rank): ONE copy of every array instead of
+    a concatenation and a second copy into the staging buffer — at 64 scenes x 1000 x 512-d that is 131 MB per request set.  Returns the
+    bytes written; the layout is pack_share's."""
+    from . import abi
+
+    n = len(items)
+    table = np.zeros((n, 4), np.int64)
+    for i, (scene, epoch, boxes, feats, quality) in enumerate(items):
+        table[i] = (scene, epoch, len(boxes), (1 if feats is not None else 0) | (2 if quality is not None else 0))
+    total = int(table[:, 2].sum()) if n else 0
+    o = 0
+
+    def put(a: np.ndarray):
+        nonlocal o
+        v = a.reshape(-1).view(np.uint8)
+        dst[o:o + len(v)] = v
+        o += len(v)
+
+    put(np.array([n, D, total, flags], np.int64))
+    put(table)
+    for it in items:
+        put(np.ascontiguousarray(it[2], abi.BOX_DTYPE))
+    for it in items:
+        if it[4] is not None:
+            put(np.ascontiguousarray(it[4], np.float32))
+    if feat_base:
+        assert o <= feat_base, f"prefix of {o} B exceeds the agreed {feat_base} B (more scenes or rows than the capacity)"
+        dst[o:feat_base] = 0
+        o = feat_base
+    for it in items:
+        if it[3] is not None:
+            put(np.ascontiguousarray(it[3], np.float32))
+    return o
+
+
 def unpack_share(buf: np.ndarray, feat_base: int = 0, bulk=None):
     """Inverse of pack_share: views into `buf` (no copies).  bulk = None: the feature rows are views of buf as well; bulk = an
     integer ADDRESS: buf holds the prefix only and the rows are returned as addresses bulk + offset (device memory)."""
@@ -438,8 +474,7 @@ class ShardedAssociator:
             ha = self.h_all.numpy()
             for r in range(self.world):
                 flags = FLAG_SHUTDOWN if shutdown else (FLAG_ABORT if refused else 0)
-                b = pack_share([] if (shutdown or refused) else shares[r], D, self.feat_base, flags)
-                ha[r, : len(b)] = b
+                pack_share_into(ha[r], [] if (shutdown or refused) else shares[r], D, self.feat_base, flags)
         if self.world > 1:
             if is_root:
                 for r in range(self.world):

@@ -420,3 +420,10 @@ def test_share_pack_roundtrip():
             if x is not None:
                 np.testing.assert_array_equal(x, y)
     assert sharding.unpack_share(sharding.pack_share([], 0)) == ([], 0)
+    # the in-place form (ShardedAssociator writes a share straight into its pinned staging row): the same bytes
+    for base in (0, sharding.prefix_bytes(8, sum(len(it[2]) for it in items))):
+        ref = sharding.pack_share(items, 24, base, 0)
+        dst = np.full(len(ref) + 64, 0xAB, np.uint8)
+        assert sharding.pack_share_into(dst, items, 24, base, 0) == len(ref)
+        np.testing.assert_array_equal(dst[: len(ref)], ref)
+        assert (dst[len(ref):] == 0xAB).all()
