@@ -308,10 +308,11 @@ def pack_share(items, D: int, feat_base: int = 0, flags: int = 0) -> np.ndarray:
     return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
 
 
-def pack_share_into(dst: np.ndarray, items, D: int, feat_base: int = 0, flags: int = 0) -> int:
+def pack_share_into(dst: np.ndarray, items, D: int, feat_base: int = 0, flags: int = 0, bulk=None) -> int:
     """pack_share written straight into `dst` (a uint8 view of the pinned staging row of the rank): ONE copy of every array instead of
     a concatenation and a second copy into the staging buffer — at 64 scenes x 1000 x 512-d that is 131 MB per request set.  Returns the
-    bytes written; the layout is pack_share's."""
+    bytes written; the layout is pack_share's.  bulk: a list — the copies of the FEATURE rows are not made but appended to it as
+    (destination view, source view) pairs, for the caller to run on several threads (numpy releases the GIL in them)."""
     from . import abi
 
     n = len(items)
@@ -340,7 +341,12 @@ def pack_share_into(dst: np.ndarray, items, D: int, feat_base: int = 0, flags: i
         o = feat_base
     for it in items:
         if it[3] is not None:
-            put(np.ascontiguousarray(it[3], np.float32))
+            src = np.ascontiguousarray(it[3], np.float32).reshape(-1).view(np.uint8)
+            if bulk is None:
+                dst[o:o + len(src)] = src
+            else:
+                bulk.append((dst[o:o + len(src)], src))
+            o += len(src)
     return o
 
 
@@ -412,8 +418,12 @@ class ShardedAssociator:
             self.d_all = [torch.zeros(self.cap_b, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.world > 1 else None
             self.d_gather = [torch.zeros(self.cap_r * 9 + 8, dtype=torch.uint8, device=device) for _ in range(self.world)]
         self.last_local_ms = 0.0
+        self._pool = None
 
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         if self.in_place:
             self.eng.unregister_device_block(self.d_req.data_ptr())
             self.in_place = False
@@ -472,9 +482,20 @@ class ShardedAssociator:
                 elif self.feat_base + fbytes > self.cap_b:
                     refused = f"rank {r}'s share holds {fbytes} B of features, capacity_bytes is {self.cap_b - self.feat_base}"
             ha = self.h_all.numpy()
+            bulk = []
             for r in range(self.world):
                 flags = FLAG_SHUTDOWN if shutdown else (FLAG_ABORT if refused else 0)
-                pack_share_into(ha[r], [] if (shutdown or refused) else shares[r], D, self.feat_base, flags)
+                pack_share_into(ha[r], [] if (shutdown or refused) else shares[r], D, self.feat_base, flags, bulk)
+            # the feature rows (megabytes per scene) on a few threads: one host core copies ~10 GB/s, the ingest point has more
+            if len(bulk) > 1 and sum(len(d) for d, _ in bulk) > (8 << 20):
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+
+                    self._pool = ThreadPoolExecutor(max_workers=8)
+                list(self._pool.map(lambda p: np.copyto(p[0], p[1]), bulk))
+            else:
+                for d_, s_ in bulk:
+                    np.copyto(d_, s_)
         if self.world > 1:
             if is_root:
                 for r in range(self.world):
