@@ -267,7 +267,7 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
   POS_STAMP(tr, 0);
-  const uint64_t pos_rt0 = POS_RT();
+  [[maybe_unused]] const uint64_t pos_rt0 = POS_RT();
   // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
   // static LDS with the contraction's stages instead of adding to it
   PosSmem<NSUB, WORKERS>& sm = *reinterpret_cast<PosSmem<NSUB, WORKERS>*>(smem);
