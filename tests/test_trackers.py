@@ -544,6 +544,65 @@ def test_frame_sizes_from_empty_to_hundreds_match_oracle(kind, backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sort", "visual"])
+def test_queries_between_frames_see_the_finished_bookkeeping(kind):
+    """With device upkeep the facade defers the heavy half of a frame's merges (history deques, observation policy) to the next call on
+    the tracker.  Whatever that next call is — another predict(), idle_tracks, wasted, track_info, skip_epochs, active_tracks — it must
+    see the finished state: a random interleaving of all of them, 120 frames of varying size, against the oracle tracker."""
+    rng = np.random.default_rng(123)
+    d, pool = 32, 90
+    if kind == "visual":
+        opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
+                .positional_metric(IoU(0.3)).visual_minimal_track_length(2).visual_max_observations(3).visual_min_votes(1)
+                .visual_minimal_quality_use(0.3).visual_minimal_quality_collect(0.5))
+        g, o = make("gpu_dev", "visual", opts=opts, feature_len=d), make("oracle", "visual", opts=opts, feature_len=d)
+    else:
+        kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
+        g, o = make("gpu_dev", "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        ident = synth.reid_identities(rng, pool, d)
+        world = synth.dense_boxes(rng, pool, (900.0, 700.0))
+        seen = []
+        for f in range(120):
+            world = synth.jitter_boxes(rng, world, 2.0)
+            size = int(rng.integers(0, pool + 1)) if f % 7 else 0
+            pick = rng.permutation(pool)[:size]
+            boxes = boxes_to_u2d(world[pick])
+            if kind == "visual":
+                feats = synth.observe(rng, ident[pick], 0.01) if size else np.zeros((0, d), np.float32)
+                items = [TR.VisualSortObservation(None if k % 9 == 4 else ft, float(rng.uniform(0.2, 1.0)), bx, int(k) if k % 3 == 0 else None)
+                         for k, (bx, ft) in enumerate(zip(boxes, feats))]
+            else:
+                items = [(bx, int(k) if k % 3 == 0 else None) for k, bx in enumerate(boxes)]
+            rg, ro = g.predict(items), o.predict(items)
+            assert_tracks_equal(rg, ro)
+            seen = [x.id for x in rg] or seen
+            # one or two queries, chosen at random, right behind the frame
+            for _ in range(int(rng.integers(0, 3))):
+                what = int(rng.integers(0, 6))
+                if what == 0:
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(0), key=lambda x: x.id), sorted(o.idle_tracks_with_scene(0), key=lambda x: x.id))
+                elif what == 1:
+                    assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+                elif what == 2 and seen:
+                    tid = seen[int(rng.integers(0, len(seen)))]
+                    assert g.track_info(tid) == o.track_info(tid)
+                elif what == 3:
+                    n = int(rng.integers(1, 3))
+                    g.skip_epochs_for_scene(0, n)
+                    o.skip_epochs_for_scene(0, n)
+                elif what == 4:
+                    assert g.active_tracks() == o.active_tracks()
+                else:
+                    assert g.current_epoch_with_scene(0) == o.current_epoch_with_scene(0)
+        assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+        assert g.active_tracks() == o.active_tracks()
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
 def test_caller_may_overwrite_its_device_feature_block_once_predict_has_returned():
     """The reference's predict() takes the observations' features by value.  Here a registered device block is READ IN PLACE, and the
     VisualSORT upkeep's bank dispatches are still running when predict() returns — they must not read the caller's block any more
