@@ -472,7 +472,7 @@ static void sa_tail_trace_hook(hipStream_t st, uint32_t ns) {
   }
 }
 // ... and of the many-workgroup tail's second kernel (SA_SOLVE_TRACE=<launch #>): per workgroup of scene 0, the 100 MHz clock every XCD
-// shares at  0 entry | 1 own rows done | 2 mid-sized components served (own tickets) | 3 big components served | 5 exit ;
+// shares at  0 entry | 1 own rows done | 2 mid-sized components served (own entries) | 3 big components served | 5 exit ;
 // [6] = big << 32 | mid components of the scene ; [7] = big << 32 | mid components THIS workgroup took.
 __device__ unsigned long long* g_solve_buf;
 #define SOLVE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.z == 0 && g_solve_buf && blockIdx.x < 512) g_solve_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -508,7 +508,7 @@ static void sa_solve_trace_after(hipStream_t st, uint32_t wgs) {
     for (uint32_t w = 0; w < wgs; ++w) if (h[w * 8] && h[w * 8] < t0) t0 = h[w * 8];
     fprintf(f, "== k_assign_solve: %u workgroups, scene 0: %llu big + %llu mid-sized components; us after the first workgroup's entry (10 ns ticks), percentiles 10 / 50 / 90 / max\n",
             wgs, h[6] >> 32, h[6] & 0xffffffffull);
-    const char* names[6] = {"entry", "own rows done", "mid-sized served (own tickets)", "big components served", "", "exit"};
+    const char* names[6] = {"entry", "own rows done", "mid-sized served (own entries)", "big components served", "", "exit"};
     for (int k = 0; k < 6; ++k) {
       std::vector<double> v;
       for (uint32_t w = 0; w < wgs; ++w) if (h[w * 8 + k]) v.push_back((double)(h[w * 8 + k] - t0) / 100.0);
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_assign_label(const SceneDev* __restrict
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   __shared__ uint32_t s_mk[4];
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the solver's queues: top of its row lists | queue length | next ticket | row workgroups done
+  if (q == 0) { S.stats[SA_QW_TOP] = 0u; S.stats[SA_QW_LEN] = 0u; S.stats[SA_QW_TICKET] = 0u; S.stats[SA_QW_DONE] = 0u; S.stats[SA_QW_MLEN] = 0u; S.stats[SA_QW_MTICKET] = 0u; }  // the solver's queues: top of its row lists | big queue: length, next ticket | row workgroups done | mid-sized queue: length (SA_QW_MTICKET: unused since the entries are shared out statically)
   if (q < S.N) ((uint32_t SA_G*)S.dq)[S.N + q] = SA_NONE;  // the queue of mid-sized components: an entry that is not SA_NONE has LANDED (k_assign_solve serves it at once)
   sa_label_phase(S, WORDS, q, gridDim.x * blockDim.x, s_mk, 256u);
 }
@@ -1624,9 +1624,9 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 //   (Mahalanobis engines, whose gains do not fit the middle tier's 32-bit cells: components of up to 8 rows, 12 columns and 24
 //   usable edges are gathered by the root's lane into a private block of LDS — a pool of SL_POOL per workgroup —, solved there by
 //   the serial sa_assign_component and scattered back; the rest goes to the big queue.)
-//   When every row workgroup of the scene has said it is through with its rows, all workgroups of the scene — the row workgroups
-//   and the helper workgroups launched behind them, which do nothing else — serve the queues by ticket.  No third launch, and a
-//   crowd's dozens of knots are solved side by side.
+//   All workgroups of the scene — the row workgroups and the helper workgroups launched behind them, which do nothing else — serve
+//   the queues: workgroup b the mid-sized entries b, b + G, ... as they land, then, once every row workgroup has said it is through
+//   with its rows, the big ones by ticket.  No third launch, and a crowd's dozens of knots are solved side by side.
 // Per-row duals / matches and per-column matches / predecessors of the dense solver: dynamic LDS when 12 N + 8 T bytes fit
 // (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
 #define SL_POOL 40
@@ -1877,10 +1877,10 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     }
   }
   // Components beyond the pool go onto one of the scene's two queues: mid-sized ones (up to ML_R rows) for single wavefronts, the rest
-  // for whole workgroups.  A workgroup that is through with its rows says so, and once all of them have, EVERY workgroup of the
-  // scene — the row workgroups and the helpers launched behind them — takes big components by ticket (all its threads on one
-  // component), then its first two wavefronts take mid-sized ones by ticket, and at the end the workgroup finishes what its own
-  // wavefronts had to refuse.  (The wait is for workgroups dispatched EARLIER in the same grid, which never wait themselves.)
+  // for whole workgroups.  A workgroup that is through with its rows says so; its first wavefront serves its share of the mid-sized
+  // queue (below), and once every row workgroup has reported EVERY workgroup of the scene takes big components by ticket (all its
+  // threads on one component) and finally finishes what its own wavefront had to refuse.  (The waits are for workgroups dispatched
+  // EARLIER in the same grid and are bounded.)
   SOLVE_STAMP(1);
   if (row_wg) {
     if (big) sa_queue_push(S, q, false, 0u);
@@ -1890,16 +1890,15 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_DONE), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // Middle tier first, AS THE ENTRIES ARRIVE: the first wavefront(s) of every workgroup take tickets of the mid-sized queue and serve
-  // entry k the moment it has landed (k_assign_label left SA_NONE in every slot) — a crowd's knots are being solved while the slowest
-  // row workgroup is still on its pairs (in-kernel timeline of a tracker loop's crowd frame: the last row workgroup was through 11 us
-  // after the first one entered, and the wait for it was time no knot was worked on).  A ticket beyond the queue's end is known as such
-  // once every row workgroup has reported (SA_QW_DONE) and the slot still holds SA_NONE: the pushes of a workgroup are performed
-  // (returning exchanges) before its report.
-  // Everything in this loop is wave-uniform BY CONSTRUCTION — the ticket is taken without a branch (lane 0 adds one, the others zero),
-  // indices go through readfirstlane, a refusal is recorded by every lane writing the same word: a lane-divergent branch before the
-  // back edge lets the compiler keep the two groups of lanes apart across iterations, and the group without lane 0 then never sees a
-  // new ticket (seen: a refusal pushed by `if (lane == 0)` inside such a loop hung the workgroup).
+  // Middle tier first, AS THE ENTRIES ARRIVE: the first wavefront of every workgroup serves its entries of the mid-sized queue the
+  // moment they have landed (k_assign_label left SA_NONE in every slot) — a crowd's knots are being solved while the slowest row
+  // workgroup is still on its pairs (in-kernel timeline of a tracker loop's crowd frame: the last row workgroup was through 11 us after
+  // the first one entered, and the wait for it was time no knot was worked on).  An entry beyond the queue's end is known as such once
+  // every row workgroup has reported (SA_QW_DONE) and the slot still holds SA_NONE: the pushes of a workgroup are performed (returning
+  // exchanges) before its report.
+  // Everything in this loop is wave-uniform BY CONSTRUCTION — indices go through readfirstlane, a refusal is recorded by every lane
+  // writing the same word: a lane-divergent branch before the back edge lets the compiler keep the two groups of lanes apart across
+  // iterations (seen with a ticket taken by lane 0 only: a refusal pushed by `if (lane == 0)` inside such a loop hung the workgroup).
   const uint32_t N = S.N, T = S.T;
   [[maybe_unused]] uint32_t took_big = 0, took_mid = 0;
   uint32_t nbig_seen = SA_NONE;  // wave 0: the length of the big queue, read once every row workgroup had reported (SA_NONE: not seen yet)
