@@ -437,7 +437,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
   }
   const auto t_built = clk::now();
-  double us_apply = 0.0;
+  double us_apply = 0.0, us_new = 0.0;
+  uint32_t n_new_tracks = 0;
   // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
   int rc = sa_batch_begin(t->eng);
   const auto t_begun = clk::now();
@@ -513,6 +514,8 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
       Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
+        const auto tn0 = trace ? clk::now() : clk::time_point();
+        ++n_new_tracks;
         Track& tr = t->store[W.tids[i]];
         trp = &tr;
         tr.id = W.tids[i]; tr.scene = scene; tr.epoch = epoch[s];
@@ -531,6 +534,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         }
         rows.push_back(trp);
         eps.push_back(epoch[s]);
+        if (trace) us_new += std::chrono::duration<double, std::micro>(clk::now() - tn0).count();
       } else {
         // the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
         const int32_t col = W.wcols[i];
@@ -605,6 +609,7 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     fprintf(stderr, "[sa_tracker] assemble %.1f  associate %.1f (begin %.1f stage %.1f enqueue %.1f wait+fetch %.1f)  apply %.1f  bookkeeping %.1f us\n",
             us(t_entry, t_built), us(t_built, t_assoc), us(t_built, t_begun), us(t_begun, t_added), us(t_added, t_run), us(t_run, t_assoc), us_apply,
             us(t_assoc, t_end) - us_apply);
+    fprintf(stderr, "[sa_newtracks] %u tracks started in %.1f us (with the trace's own clock reads)\n", n_new_tracks, us_new);
   }
   return SA_OK;
 }
