@@ -640,6 +640,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   if constexpr (WORDS) if (clsmode) {
     const uint32_t K = S.K;
     bool any = false;
+    // (the first phase's max-key slots are requested FIRST, so that they travel with the class words: behind the words' processing the
+    // loop below was a second trip to memory — one of the ~3 us the class-word tail took over the single-word one)
+    uint32_t mk = 0, mk0 = q < S.nkeys ? S.vis_max_key[q] : 0u;
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
       // all 2 x SA_CLS_MAXK loads issued together, whatever K is (the clamped index re-reads a word that is needed anyway): with the
@@ -664,8 +667,8 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       }
       any = any || rcls[c] != ~0ull;
     }
-    uint32_t mk = 0;
-    for (uint32_t i = q; i < S.nkeys; i += SA_SMALL_N) {
+    mk = mk0;
+    for (uint32_t i = q + SA_SMALL_N; i < S.nkeys; i += SA_SMALL_N) {   // (more than 1024 tiles: frames beyond this tail's reach today)
       const uint32_t v = S.vis_max_key[i];
       mk = v > mk ? v : mk;
     }
