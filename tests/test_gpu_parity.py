@@ -198,6 +198,35 @@ def test_general_assignment_tail_matches_oracle_too():
     assert (ids != 0).sum() > 900
 
 
+def test_random_crowd_frames_beyond_1024_tracks_match_the_oracle():
+    """The many-workgroup tail's MIDDLE tier on what it is for: crowds beyond 1024 tracks under thresholds from 0.1 to 0.3, i.e. dozens
+    to a hundred components of 3 to 60 rows per frame — gathered from the per-root row lists, built one edge per lane (up to 64
+    edges) or through the hash table (more), served as their queue entries land.  Random sizes, canvases and jitter; every frame's ids
+    against the oracle, and two reruns of the staged frame (the state a frame leaves behind must be as clean as it found it)."""
+    rng = np.random.default_rng(2024)
+    for it in range(12):
+        n, t = int(rng.integers(300, 1500)), int(rng.integers(1030, 2600))
+        canvas = (float(rng.uniform(700, 2600)), float(rng.uniform(600, 1600)))
+        thr = float(rng.choice([0.1, 0.15, 0.2, 0.3]))
+        sc = synth.sort_scene(rng, t, n, canvas=canvas, pos_sigma=float(rng.uniform(4.0, 14.0)))
+        cfg = abi.make_config(positional="iou", positional_threshold=thr, max_idle_epochs=5)
+        eng = Engine(cfg)
+        try:
+            tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+            eng.upsert(0, tracks)
+            det = abi.make_detections(sc["det_boxes"])
+            ids, votes = eng.associate(0, 1, det)
+            ref = O.associate(cfg, tracks, 1, det, want_matrices=False)
+            np.testing.assert_array_equal(ids, ref["track_id"], err_msg=f"frame {it}: {n} x {t}, threshold {thr}")
+            np.testing.assert_array_equal(votes, ref["voting_type"])
+            for _ in range(2):
+                eng.batch_run()
+                eng.batch_sync()
+                np.testing.assert_array_equal(eng.batch_fetch(0, n)[0], ids, err_msg=f"frame {it} rerun")
+        finally:
+            eng.close()
+
+
 @pytest.mark.paths("general")
 def test_state_kept_clean_across_frames_of_changing_size():
     """Edge counters, row duals and the union-find forest are not reset at the start of a frame: the assignment tail leaves
