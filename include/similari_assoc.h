@@ -135,8 +135,10 @@ typedef struct sa_config {
 #define SA_FLAG_SEPARATE_RESOLVE 0x400u /* no vote words: per-tile partials + k_bestfit_resolve as a launch of its own */
 #define SA_FLAG_EUCLID_VALU 0x800u      /* euclidean engines: always the vector-pipe kernel (direct sums of squares) */
 #define SA_FLAG_EUCLID_MFMA 0x1000u     /* euclidean engines: always the matrix-core expansion + flagged recompute, also after an ill-conditioned frame */
-#define SA_FLAG_XCD_TILES 0x4000u       /* the contraction's tiles in XCD-aware order (each XCD's L2 takes a compact block of tiles: C2 19.1 -> 15.3 MB of HBM
-                                           traffic per launch) instead of row by row — measured: no faster at C2 / c2b, 4 % slower at C5; A/B measurements */
+#define SA_FLAG_XCD_TILES 0x4000u       /* the contraction's tiles in XCD-aware order (each XCD's L2 takes a compact block of tiles) ALSO where the contraction is
+                                           a launch of its own — measured: c2b no faster, C5 4 % slower (the fused first phase uses that order by default:
+                                           C2 20.0 -> 16.1 MB of L2 fills per launch at the same speed); A/B measurements */
+#define SA_FLAG_ROW_TILES 0x8000u       /* the contraction's tiles row by row everywhere, the fused first phase included; A/B measurements */
 #define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,

@@ -22,11 +22,11 @@ for w in c2b c2bk3 c2t c2n c2e c2k3 c2d c3 c3m c4 c5 c1 c1ref sd sdt giant bigpi
   timeout 600 python bench.py --workload $w --no-cpu-baseline $st > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w exit $?"
 done
 timeout 300 python bench.py --flags 32 --no-cpu-baseline > $O/bench_c2_separate.json 2> $O/bench_c2_separate.err
-timeout 300 python bench.py --flags 16384 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2_xcd_tiles.json 2> $O/bench_c2_xcd_tiles.err
+timeout 300 python bench.py --flags 32768 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2_row_tiles.json 2> $O/bench_c2_row_tiles.err
 timeout 300 python bench.py --workload c2b --gemm-plan 1 --steps 50 --warmup 5 --profile-iters 10 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2b_fused64.json 2> $O/bench_c2b_fused64.err
-# 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes); C2 also with the XCD-aware tile order
+# 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes); C2 also with its tiles row by row (SA_FLAG_ROW_TILES)
 for w in c2 c2b c5 c4; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
-SA_BENCH_FLAGS=16384 bash scripts/pmc_traffic.sh c2 ${TAG}_c2xcd > $O/pmc_traffic_c2_xcd_tiles.log 2>&1; cp gpurun_out/pmc_${TAG}_c2xcd/summary.json $O/pmc_traffic_c2_xcd_tiles.json 2>/dev/null
+SA_BENCH_FLAGS=32768 bash scripts/pmc_traffic.sh c2 ${TAG}_c2row > $O/pmc_traffic_c2_row_tiles.log 2>&1; cp gpurun_out/pmc_${TAG}_c2row/summary.json $O/pmc_traffic_c2_row_tiles.json 2>/dev/null
 # 4. MFMA utilisation of the contraction (C2 default line, c2b and C5)
 for w in c2 c2b c5; do
   extra="--workload $w"; st="--steps 30 --warmup 5"; [ "$w" = "c5" ] && st="--steps 8 --warmup 2 --profile-iters 4"; [ "$w" = "c2b" ] && st="--steps 10 --warmup 2 --profile-iters 4"

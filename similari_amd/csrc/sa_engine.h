@@ -184,7 +184,8 @@ struct SaParams {
   uint32_t eu_mfma;             // per launch: euclidean distances through the matrix-core contraction (expansion + flagged direct recompute)
   float eu_rho;                 // a cell with d^2 < eu_rho (|a|^2 + |b|^2) is recomputed directly
   uint32_t force_general;       // SA_FLAG_GENERAL_TAIL: the many-workgroup assignment tail (and the launches that feed it) whatever the frame size
-  uint32_t row_major_tiles;     // the contraction's tiles numbered row by row (the default; 0 with SA_FLAG_XCD_TILES: XCD-aware order, sa_gemm.hip)
+  uint32_t row_major_tiles;     // order of the contraction's tiles: 1 = the default (stand-alone contraction row by row, fused first phase XCD-aware),
+                                // 0 = XCD-aware everywhere (SA_FLAG_XCD_TILES), 2 = row by row everywhere (SA_FLAG_ROW_TILES); sa_gemm.hip
   int32_t gemm_plan;            // sa_config.gemm_plan - 1: the contraction's tile plan pinned (tuning / tests), -1 = tile_plan()'s own choice
 };
 

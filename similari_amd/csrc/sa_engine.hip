@@ -998,7 +998,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.vote_words = 0;  // set per frame by enqueue_frame
   P.force_general = (cfg->flags & SA_FLAG_GENERAL_TAIL) ? 1u : 0u;
   P.gemm_plan = cfg->gemm_plan > 0 ? cfg->gemm_plan - 1 : -1;
-  P.row_major_tiles = (cfg->flags & SA_FLAG_XCD_TILES) ? 0u : 1u;
+  P.row_major_tiles = (cfg->flags & SA_FLAG_XCD_TILES) ? 0u : ((cfg->flags & SA_FLAG_ROW_TILES) ? 2u : 1u);
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
   for (uint32_t i = 0; i < cfg->n_constraints; ++i) {

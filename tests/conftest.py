@@ -24,7 +24,8 @@ def _path_flags():
     from similari_amd import abi
 
     return {"default": 0, "general": abi.SA_FLAG_GENERAL_TAIL, "never_lean": abi.SA_FLAG_NEVER_LEAN, "bestfit_tile": abi.SA_FLAG_BESTFIT_TILE,
-            "separate_resolve": abi.SA_FLAG_SEPARATE_RESOLVE, "euclid_valu": abi.SA_FLAG_EUCLID_VALU, "euclid_mfma": abi.SA_FLAG_EUCLID_MFMA}
+            "separate_resolve": abi.SA_FLAG_SEPARATE_RESOLVE, "euclid_valu": abi.SA_FLAG_EUCLID_VALU, "euclid_mfma": abi.SA_FLAG_EUCLID_MFMA,
+            "row_tiles": abi.SA_FLAG_ROW_TILES, "xcd_tiles": abi.SA_FLAG_XCD_TILES}
 
 
 def pytest_generate_tests(metafunc):

@@ -578,7 +578,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
-@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve")
+@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve", "row_tiles", "xcd_tiles")
 @pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "default"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
@@ -1315,6 +1315,7 @@ def _full_size_visual(cfg, sc, shards=32):
     return ids, votes, pos, vis, ref
 
 
+@pytest.mark.paths("row_tiles")
 def test_full_size_c2_against_the_oracle():
     """BASELINE C2 (1000 x 1000 x 512-d cosine + IoU): IoU cells and the quantised matrix bit for bit, every cosine weight within
     1e-5, ids and vote types identical."""
