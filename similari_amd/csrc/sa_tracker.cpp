@@ -95,7 +95,7 @@ struct sa_tracker {
   // Eviction.  A track whose last update lies more than max_idle_epochs behind its scene's epoch fails compatible() (sort.rs:250-270) for
   // every later frame — epochs only grow — but the reference keeps it in the store until the next auto_waste (every 100th predict by
   // default), and so would the engine's table: at 5 % churn a 1000-object VisualSORT loop associates against 6 700 rows instead of
-  // 1 200.  The facade therefore takes such tracks out of the ENGINE's table as soon as they are a sixteenth of it (sa_tracks_remove:
+  // 1 200.  The facade therefore takes such tracks out of the ENGINE's table as soon as they are 64 and a sixteenth of it (sa_tracks_remove:
   // one gather launch), and keeps them in its own store — idle_tracks / wasted see them as before.
   std::map<uint64_t, std::vector<uint64_t>> row_epoch;   // scene -> last_updated_epoch of by_scene's rows, in the same order (the scan's input)
   std::map<uint64_t, std::vector<Track*>> evicted;       // scene -> tracks out of the engine's table, still in `store`
@@ -422,7 +422,9 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
     const uint64_t cur = epoch[s];
     size_t expired = 0;
     for (uint64_t ep : eps) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
-    if (expired < 16 || expired * 16 < rows.size()) continue;
+    // (a removal is a drain + one gather launch, ~20 us; a row left in the table costs the frames until auto_waste ~1/64 us each: it pays
+    // from about 64 rows on — with 16 a batch tracker of 8 x 500 objects spent 78 us per predict() removing a few rows from four scenes)
+    if (expired < 64 || expired * 16 < rows.size()) continue;
     std::vector<uint64_t> out_ids;
     out_ids.reserve(expired);
     auto& ev = t->evicted[scene_ids[s]];

@@ -458,7 +458,7 @@ def test_device_bank_equals_host_policy_bank(d):
 @pytest.mark.parametrize("kind", ["sort", "visual"])
 def test_churned_loop_with_eviction_matches_oracle(kind, backend):
     """Objects leave and enter every frame (max_idle_epochs 2, auto-waste only every 100th predict): the facade takes the tracks that
-    can no longer match out of the ENGINE's table as soon as they are a sixteenth of it (sa_tracks_remove: the table closes ranks in
+    can no longer match out of the ENGINE's table as soon as they are 64 and a sixteenth of it (sa_tracks_remove: the table closes ranks in
     order) while keeping them in its store — frame by frame the same tracks as the oracle's tracker, which keeps everything until
     auto_waste as the reference does; idle_tracks and wasted still see the evicted ones; the engine's table stays near the live set."""
     rng = np.random.default_rng(404 + (kind == "visual"))
@@ -472,7 +472,7 @@ def test_churned_loop_with_eviction_matches_oracle(kind, backend):
         kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
         g, o = make(backend, "sort", **kw), make("oracle", "sort", **kw)
     try:
-        pool = n + 14 * 30
+        pool = n + 14 * 40
         world = synth.dense_boxes(rng, pool, (2600.0, 1800.0))
         ident = synth.reid_identities(rng, pool, d)
         active = np.arange(n)
@@ -481,9 +481,9 @@ def test_churned_loop_with_eviction_matches_oracle(kind, backend):
         for f in range(14):
             world = synth.jitter_boxes(rng, world, 1.5)
             if f:
-                gone = rng.choice(n, 24, replace=False)           # ~11 % of the objects leave, as many enter
-                active[gone] = np.arange(fresh, fresh + 24)
-                fresh += 24
+                gone = rng.choice(n, 40, replace=False)           # ~18 % of the objects leave, as many enter
+                active[gone] = np.arange(fresh, fresh + 40)
+                fresh += 40
             boxes = boxes_to_u2d(world[active])
             if kind == "visual":
                 feats = synth.observe(rng, ident[active], 0.01)
@@ -499,7 +499,7 @@ def test_churned_loop_with_eviction_matches_oracle(kind, backend):
                 assert_tracks_equal(sorted(g.idle_tracks_with_scene(0), key=lambda x: x.id), sorted(o.idle_tracks_with_scene(0), key=lambda x: x.id))
         # eviction happened: the engine's table holds the live set + the recently idle tracks, not everything since frame 0
         assert g.active_tracks() == o.active_tracks()   # (the store: evicted tracks included, until they are wasted)
-        assert rows_seen[-1] < n + 6 * 24, rows_seen
+        assert rows_seen[-1] < n + 6 * 40, rows_seen
         assert max(rows_seen) > n, rows_seen
         assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
     finally:
