@@ -213,12 +213,22 @@ int sa_batch_add(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detec
  * (visual_sort/simple_api.rs:130-170): the rows go straight into the pinned staging block, no N x D assembly on the caller's side. */
 int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
                       uint32_t* out_slot);
+/* Staging a request set of many scenes on several threads (Batch*::predict): sa_batch_add_deferred lays the scene out in the arena and
+ * remembers the caller's arrays (which must stay valid until the fill); sa_batch_fill(slot) validates the boxes and copies them in.
+ * Fills of DIFFERENT slots may run on different threads at once (never beside an add); every slot must be filled before sa_batch_run*. */
+int sa_batch_add_deferred(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
+                          uint32_t* out_slot);
+int sa_batch_fill(sa_engine* e, uint32_t slot);
 int sa_batch_run(sa_engine* e);
 int sa_batch_sync(sa_engine* e);
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type);
 /* The same winners as COLUMNS of the scene's track table (the order of sa_tracks_order), -1 = none: a host that keeps its tracks in
  * table order — rows are appended in upsert / apply order, sa_tracks_remove closes the gaps — finds the winner without a lookup by id. */
 int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols);
+/* sa_batch_fetch + sa_batch_fetch_cols without the copies: pointers to the slot's results where the assignment tail wrote them (pinned
+ * host memory), valid until the next sa_batch_begin.  Any output may be NULL.  Waits like sa_batch_fetch; after sa_batch_run_apply it may
+ * be called for different slots from different threads at once. */
+int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id, const uint8_t** out_voting_type, const int32_t** out_cols);
 
 /* ---- device-side track upkeep: the step either side of the association ------------
  * Applies the result of the last run of batch slot `slot` to that scene's device-resident track table, the way
@@ -253,6 +263,13 @@ int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted);
  * feature rows (device blocks, pinned blocks) must stay untouched until the next call on the engine has returned. */
 int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base /* one per staged scene */, int id_per_candidate);
 int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted);
+/* The same for a whole request set in three steps, so that the per-scene host work can be spread over threads (Batch*::predict over
+ * dozens of scenes): _begin waits ONCE for the set's upkeep (one Kalman dispatch for every scene of the set); _slot does one scene's host
+ * side and may run for DIFFERENT slots on different threads at once; _end, on the calling thread again, queues what is left (the
+ * polygons of refreshed oriented rows). */
+int sa_tracks_apply_collect_begin(sa_engine* e);
+int sa_tracks_apply_collect_slot(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted);
+int sa_tracks_apply_collect_end(sa_engine* e);
 /* Full per-track state for the device-side upkeep (debug / parity / seeding): Kalman mean[10] + cov[100] row-major, and per
  * bank slot the feature quality[K].  Any of the output pointers may be NULL. */
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality,

@@ -87,7 +87,8 @@ typedef struct sa_tracker_options {
   float visual_minimal_own_area_percentage_collect;
   int32_t device_upkeep;                /* 1 = Kalman step, table refresh and feature-bank policy run on the GPU (sa_tracks_apply):
                                            no per-frame upload of boxes / Kalman state / features; 0 = host upkeep + sa_tracks_upsert */
-  int32_t reserved;
+  int32_t workers;                      /* threads working on the scenes of one request set (Batch*: the reference's voting_shards,
+                                           sort/batch_api.rs:197-207), the calling thread included; 0 = the facade's choice, 1 = none */
 } sa_tracker_options;
 
 typedef struct sa_tracker sa_tracker;
@@ -105,6 +106,26 @@ int sa_tracker_predict(sa_tracker* t, uint64_t scene_id, uint32_t n, const sa_ob
 /* Batch*::predict: scenes are processed in request order; every scene goes through ONE set of kernel launches. */
 int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
                              const sa_observation* const* obs, sa_sort_track* const* out);
+
+/* Batch*::predict as the reference shapes it (sort/batch_api.rs:222-290, visual_sort/batch_api.rs:213-317): the call returns once the
+ * request set is on the device, with a handle that delivers the scenes' tracks as they become final — PredictionBatchResult,
+ * trackers/batch.rs:19-38:
+ *   sa_batch_result_size   batch_size(): scenes in the request set
+ *   sa_batch_result_ready  ready(): 1 when sa_batch_result_get would not block
+ *   sa_batch_result_get    get(): the next finished scene — its id, its tracks in candidate order (cap < *out_n: SA_ERR_BAD_ARG, nothing is
+ *                          taken, *out_n says how many there are); blocks until one is there; SA_ERR_STATE once every scene was taken
+ * The request is taken by value like the reference's: the observation arrays (and feature rows in host memory) may be reused as soon as
+ * _begin has returned; feature rows in a registered DEVICE block must stay untouched until the last scene has been delivered.  One
+ * request set is in flight at a time: every other call on the tracker first waits for it (the reference's busy monitor,
+ * sort/batch_api.rs:233-241).  Trackers without device upkeep do all the work inside _begin (every scene is ready when it returns).
+ * The handle is the caller's: sa_batch_result_free (at any time). */
+typedef struct sa_batch_result sa_batch_result;
+int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                                   const sa_observation* const* obs, sa_batch_result** out_result);
+uint32_t sa_batch_result_size(const sa_batch_result* r);
+int sa_batch_result_ready(sa_batch_result* r);
+int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
+void sa_batch_result_free(sa_batch_result* r);
 
 int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
 int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n);

@@ -201,7 +201,7 @@ class sa_tracker_options(C.Structure):
         ("visual_minimal_own_area_percentage_use", C.c_float),
         ("visual_minimal_own_area_percentage_collect", C.c_float),
         ("device_upkeep", C.c_int32),
-        ("reserved", C.c_int32),
+        ("workers", C.c_int32),
     ]
 
 
@@ -370,10 +370,13 @@ PROTOTYPES = {
     "sa_batch_begin": (C.c_int, [ENGINE]),
     "sa_batch_add": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u32)]),
     "sa_batch_add_rows": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(P(C.c_float)), P(u32)]),
+    "sa_batch_add_deferred": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(P(C.c_float)), P(u32)]),
+    "sa_batch_fill": (C.c_int, [ENGINE, u32]),
     "sa_batch_run": (C.c_int, [ENGINE]),
     "sa_batch_sync": (C.c_int, [ENGINE]),
     "sa_batch_fetch": (C.c_int, [ENGINE, u32, P(u64), P(C.c_uint8)]),
     "sa_batch_fetch_cols": (C.c_int, [ENGINE, u32, P(i32)]),
+    "sa_batch_results": (C.c_int, [ENGINE, u32, P(P(u64)), P(P(C.c_uint8)), P(P(i32))]),
     "sa_associate_batch": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(sa_scene_result)]),
     "sa_pipe_stage": (C.c_int, [ENGINE, u32, P(sa_scene_request), P(u64)]),
     "sa_pipe_launch": (C.c_int, [ENGINE, u64]),
@@ -394,6 +397,9 @@ PROTOTYPES = {
     "sa_tracks_apply_end": (C.c_int, [ENGINE, u32, P(sa_box)]),
     "sa_batch_run_apply": (C.c_int, [ENGINE, P(u64), C.c_int]),
     "sa_tracks_apply_collect": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
+    "sa_tracks_apply_collect_begin": (C.c_int, [ENGINE]),
+    "sa_tracks_apply_collect_slot": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
+    "sa_tracks_apply_collect_end": (C.c_int, [ENGINE]),
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),
     "sa_nms": (C.c_int, [ENGINE, u32, P(sa_box), P(C.c_float), C.c_float, C.c_float, P(u32), P(u32)]),
@@ -424,6 +430,11 @@ PROTOTYPES = {
     "sa_tracker_last_error": (C.c_char_p, [C.c_void_p]),
     "sa_tracker_predict": (C.c_int, [C.c_void_p, u64, u32, P(sa_observation), P(sa_sort_track)]),
     "sa_tracker_predict_batch": (C.c_int, [C.c_void_p, u32, P(u64), P(u32), P(P(sa_observation)), P(P(sa_sort_track))]),
+    "sa_tracker_predict_batch_begin": (C.c_int, [C.c_void_p, u32, P(u64), P(u32), P(P(sa_observation)), P(C.c_void_p)]),
+    "sa_batch_result_size": (u32, [C.c_void_p]),
+    "sa_batch_result_ready": (C.c_int, [C.c_void_p]),
+    "sa_batch_result_get": (C.c_int, [C.c_void_p, P(u64), P(sa_sort_track), u32, P(u32)]),
+    "sa_batch_result_free": (None, [C.c_void_p]),
     "sa_tracker_idle_tracks": (C.c_int, [C.c_void_p, u64, P(sa_sort_track), u32, P(u32)]),
     "sa_tracker_skip_epochs": (C.c_int, [C.c_void_p, u64, u64]),
     "sa_tracker_current_epoch": (C.c_int, [C.c_void_p, u64, P(u64)]),

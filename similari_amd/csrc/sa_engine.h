@@ -325,6 +325,17 @@ struct BankArgs {
   float minimal_area, q_collect, own_collect;
 };
 hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams& p, hipStream_t st, hipEvent_t done = nullptr, int part = 0);
+// The upkeep of EVERY scene of a request set in one launch per half (Batch*::predict: 64 scenes are two dispatches, not 128): the
+// per-scene arguments travel as an array in the bank's arena (they ride in the set's one upload), blockIdx.y selects the scene.
+// part 1 = the Kalman halves (+ the row copies out of a caller's device block), 2 = the bank halves.  max_blocks = the largest
+// per-scene block count of that half (sa_apply_set_blocks).
+struct ApplyScene {
+  ApplyArgs a;
+  BankArgs b;
+};
+static inline uint32_t sa_apply_set_blocks(uint32_t n, bool copies, int part) { return part == 2 ? n : (n + 3u) / 4u + (copies ? n : 0u); }
+hipError_t sa_launch_apply_set(const ApplyScene* scenes, uint32_t n_scenes, uint32_t max_blocks, uint32_t K, const SaParams& p, hipStream_t st,
+                               hipEvent_t done, int part);
 // oriented boxes after sa_launch_apply: the host's libm cos / sin of a refreshed row's angle -> its polygon
 struct SaPolyFix {
   uint32_t row, pad;

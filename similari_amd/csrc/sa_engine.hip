@@ -50,6 +50,8 @@ struct SceneTable {
   DevBuf spare[SA_TABLE_ARRAYS];                   // sa_tracks_remove compacts the table into these and swaps (no allocation per call)
   HostBuf h_index;                                 // ... the kept rows' old indices (mapped pinned memory the gather kernel reads in place)
   void* d_index = nullptr;
+  uint64_t index_drain = ~0ull;                    // sa_engine::drain_count when the last gather that reads h_index was queued (~0: none): the
+                                                   // buffer may be rewritten once the engine has been drained since
   DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
   DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
   std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
@@ -87,11 +89,15 @@ struct Slot {  // one scene of a request set
   void* d_out = nullptr;  // device view of h_out
   uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
+  bool poly_pending = false;   // sa_tracks_apply_collect_slot has run: the polygons of refreshed ORIENTED rows are still to be queued (sa_tracks_apply_collect_end)
   bool fused_pending = false;  // sa_batch_run_apply has queued the upkeep of this slot behind its association; sa_tracks_apply_collect finishes the host side
   uint64_t fused_id_base = 0;  // ... ids of the tracks that start: fused_id_base + 1 + (per candidate ? candidate index : rank among the new ones)
   int fused_per_candidate = 0;
   uint32_t fused_T0 = 0;       // rows of the scene's table when the upkeep was queued
   bool apply_pending = false;  // sa_tracks_apply_begin has queued the upkeep of this slot; sa_tracks_apply_end (or the next entry point that needs the table) finishes it
+  bool fill_pending = false;   // sa_batch_add_deferred laid the slot out; sa_batch_fill (any thread) has yet to copy the caller's arrays in
+  sa_detections pend_d{};      // ... the caller's arrays
+  const float* const* pend_rows = nullptr;
   bool prepped = true;     // the frame-preparation blocks ran with the frame (false: a lean frame left them out; ensure_prepped runs them on demand)
   bool needs_init = true;  // e_cnt / u / parent were (re)allocated, or a run may have died half-way: k_slot_init before the next frame
 };
@@ -124,6 +130,8 @@ struct Bank {
                                         // upkeep kernels run behind it — sa_batch_fetch waits for the event only, so that the caller's own
                                         // bookkeeping overlaps them
   bool want_prep = false;               // the upkeep follows on the stream (sa_batch_run_apply): its feature-bank step reads what the preparation blocks write
+  bool want_apply = false;              // sa_batch_run_apply: bank_upload appends the set's ApplyScene array to the arena (behind the descriptors: the same DMA)
+  size_t apply_off = 0;                 // ... where it went
   // SA_FLAG_GRAPH: the per-frame launches captured once into a hipGraph (re-captured when the launch geometry changes)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -166,8 +174,10 @@ struct sa_engine {
   bool eu_mfma_ok = false;              // euclidean engines: the expansion is usable at this feature length (eu_rho < 1/3)
   float eu_rho = 0.f;
   std::string err;
+  std::mutex err_mu;                 // (sa_batch_fill / sa_tracks_apply_collect_slot run on several threads: fail() serialises its writes)
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
+  uint64_t drain_count = 0;          // how often the engine has been found drained (engine_idle): "has X retired?" = "was there a drain since X was queued?"
   uint64_t busy_seq = 0;             // counts the enqueues since the engine was created (SA_BUSY): "nothing was queued since event X" is a comparison
   // The LAST thing queued carried a completion event of its own (the upkeep's last dispatch, the gather of sa_tracks_remove): draining the
   // engine is then one event wait — a stream synchronisation costs a marker packet's trip through the command processor (~10 us) even
@@ -211,7 +221,7 @@ int fail(sa_engine* e, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (e) e->err = buf;
+  if (e) { std::lock_guard<std::mutex> lk(e->err_mu); e->err = buf; }
   else g_create_error = buf;
   return code;
 }
@@ -274,6 +284,7 @@ int engine_sync(sa_engine* e) {
   return engine_idle(e);
 }
 int engine_idle(sa_engine* e) {
+  ++e->drain_count;
   for (auto& g : e->garbage) hipFree(g.p);
   e->garbage.clear();
   e->synced = true;
@@ -584,6 +595,39 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   }
 }
 
+// The arguments of a slot's upkeep step (sa_upkeep.hip): Kalman half `a`, feature-bank half `b` (visual engines).  new_row / new_ids:
+// device-visible arrays — table row and id of every candidate that starts a track — or both nullptr: drawn on the device from
+// s->fused_* (sa_batch_run_apply).  part: 0 = both halves in one launch, 1 / 2 = the halves as launches of their own, Kalman first — the
+// rows a registered device block is read in place for then leave the caller's memory with the Kalman dispatch (ApplyArgs::copy_src,
+// into s->feat_raw, which the caller has reserved) and the bank half reads the slot's copy.
+void fill_apply_args(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids, int part, ApplyArgs& a, BankArgs& b, bool frame_known = true) {
+  SceneTable* sc = s->scene;
+  const uint32_t n = s->N;
+  a = ApplyArgs{};
+  b = BankArgs{};
+  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = new_row;
+  a.new_ids = new_ids; a.n = n; a.epoch = s->epoch;
+  a.T0 = s->fused_T0; a.id_base = s->fused_id_base; a.id_per_candidate = s->fused_per_candidate;
+  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
+  a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
+  const bool in_place = e->visual && s->has_feats && e->D == e->Dp && s->feats_device && s->p_feat_raw == (void*)s->feats_device;
+  if (part != 0 && in_place && n) { a.copy_src = (const float*)s->feats_device; a.copy_dst = (float*)s->feat_raw.p; a.copy_row_floats = e->D; }
+  if (!e->visual) return;
+  b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.T0 = a.T0; b.n = n; b.K = e->K; b.Dp = e->Dp;
+  b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? ((part != 0 && in_place) ? s->feat_raw.p : s->p_feat_raw) : s->feat.p) : nullptr;
+  // (rows that need no padding: the frame may have run lean — the step then forms the norms of the rows it stores itself, bit for bit what
+  // the preparation block would have written; padded rows: the preparation blocks rode in the frame, sa_batch_run_apply / ensure_prepped.
+  // frame_known = false: the arguments are built BEFORE the frame's launches are chosen — s->prepped still describes the slot's previous frame)
+  b.c_fnorm = (e->D != e->Dp || (frame_known && s->prepped)) ? (const float*)s->fnorm.p : nullptr;
+  b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
+  b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
+  b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
+  b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
+  b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p;
+  b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
+  b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
+}
+
 // Brings a bank's request set onto the device through stream `st`: the scene inputs appended to the staging arena (once per
 // set: a replayed frame uploads nothing), the features a caller keeps in pinned blocks of its own (DMA'd in place), and the
 // descriptor array, which is appended to the arena so that it travels in the same DMA; a run that finds inputs and descriptors
@@ -593,7 +637,11 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
   const uint32_t ns = b->n_slots;
   const size_t dbytes = (size_t)ns * sizeof(SceneDev);
   const size_t desc_off = align_up(b->used, 256);
-  const size_t total = desc_off + dbytes;
+  // (sa_batch_run_apply: the set's ApplyScene array behind the descriptors — one upload for everything the set's launches read)
+  const size_t abytes = b->want_apply ? (size_t)ns * sizeof(ApplyScene) : 0;
+  const size_t apply_off = abytes ? desc_off + align_up(dbytes, 256) : desc_off + dbytes;
+  const size_t total = apply_off + abytes;
+  const size_t tail_bytes = total - desc_off;   // descriptors (+ padding + upkeep arguments)
   void* before = b->d_arena.p;
   TRY(dev_ensure(e, b->d_arena, total));
   if (b->d_arena.p != before) { b->uploaded = false; b->desc_last.clear(); }
@@ -605,14 +653,19 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
     if (s->feats_device) s->p_feat_raw = ((uintptr_t)s->feats_device & 15u) ? s->feat_raw.p : (void*)s->feats_device;
     else s->p_feat_raw = s->feats_inplace ? s->feat_raw.p : (void*)(dbase + s->o_feat);
   }
-  std::vector<uint8_t> build(dbytes);
+  std::vector<uint8_t> build(tail_bytes, 0);
   SceneDev* bd = (SceneDev*)build.data();
   for (uint32_t i = 0; i < ns; ++i) fill_scene_dev(e, b, b->slots[i], &bd[i]);
-  const bool same_descs = b->desc_off == desc_off && b->desc_last.size() == dbytes && dbytes && std::memcmp(b->desc_last.data(), build.data(), dbytes) == 0;
+  if (abytes) {
+    ApplyScene* as = (ApplyScene*)(build.data() + (apply_off - desc_off));
+    for (uint32_t i = 0; i < ns; ++i) fill_apply_args(e, b->slots[i], nullptr, nullptr, e->visual ? 1 : 0, as[i].a, as[i].b, false);
+  }
+  b->apply_off = apply_off;
+  const bool same_descs = b->desc_off == desc_off && b->desc_last.size() == tail_bytes && tail_bytes && std::memcmp(b->desc_last.data(), build.data(), tail_bytes) == 0;
   if (b->uploaded && same_descs) return SA_OK;
   if (may_be_busy && !e->synced && !only_gather_in_flight(e)) TRY(engine_sync(e));
   uint8_t* h = (uint8_t*)b->h_arena.p;
-  std::memcpy(h + desc_off, build.data(), dbytes);
+  std::memcpy(h + desc_off, build.data(), tail_bytes);
   b->desc_off = desc_off;
   b->desc_last.swap(build);
   if (!b->uploaded) {
@@ -649,7 +702,7 @@ int bank_upload(sa_engine* e, Bank* b, hipStream_t st, bool may_be_busy, hipEven
     TRY(flush(true));
     b->uploaded = true;
   } else {
-    HIPCHK(e, hipMemcpyAsync(dbase + desc_off, h + desc_off, dbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(dbase + desc_off, h + desc_off, tail_bytes, hipMemcpyHostToDevice, st));
   }
   SA_BUSY(e);
   return SA_OK;
@@ -756,6 +809,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
   uint32_t maxN = 0, maxT = 0;
   for (uint32_t i = 0; i < ns; ++i) {
     Slot* s = b->slots[i];
+    if (s->fill_pending) return fail(e, SA_ERR_STATE, "slot %u was added with sa_batch_add_deferred and never filled (sa_batch_fill)", i);
     s->T = s->scene->T;  // tracks may have been upserted since sa_batch_add
     maxN = s->N > maxN ? s->N : maxN;
     maxT = s->T > maxT ? s->T : maxT;
@@ -1208,24 +1262,24 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
     if (!find_slot(sc, ids[i], &at)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[i]);
     drop[at] = 1;
   }
-  // (the index buffer of the previous call must have been consumed: calls on one engine are serial and the gather is short — only a
-  // second removal queued right behind the first would find it in flight)
-  if (!e->synced) TRY(engine_sync(e));
+  // No drain: the gather is ordered on the compute stream behind whatever still reads or writes the table, and the arrays it fills are the
+  // ones the previous gather of this scene read — also behind it.  The one thing the HOST writes is this scene's index buffer: it must not
+  // be rewritten while an earlier gather of the SAME scene may still be reading it (two removals on one scene with no drain between them;
+  // removals on different scenes — a batch tracker evicting from several of its scenes in one predict() — chain freely).
+  if (sc->index_drain == e->drain_count && !e->synced) TRY(engine_sync(e));
   {
     void* before = sc->h_index.p;
+    if ((size_t)(sc->T ? sc->T : 1) * 4 > sc->h_index.cap && !e->synced) TRY(engine_sync(e));   // (the block is about to be replaced)
     TRY(host_ensure(e, sc->h_index, (size_t)(sc->T ? sc->T : 1) * 4));
     if (sc->h_index.p != before || !sc->d_index) HIPCHK(e, hipHostGetDevicePointer(&sc->d_index, sc->h_index.p, 0));
   }
+  const bool was_idle = e->synced || only_gather_in_flight(e);
+  // first pass: the kept rows' old indices only — the host's id list is compacted AFTER the launch has been accepted (a failure half-way
+  // leaves the table as it was)
   uint32_t* keep = (uint32_t*)sc->h_index.p;
   uint32_t nT = 0;
-  sc->full.resize(sc->T, 0);
   for (uint32_t s = 0; s < sc->T; ++s)
-    if (!drop[s]) {
-      keep[nT] = s;
-      sc->ids[nT] = sc->ids[s];
-      sc->full[nT] = sc->full[s];
-      ++nT;
-    }
+    if (!drop[s]) keep[nT++] = s;
   if (nT) {
     const uint32_t K = e->K;
     DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
@@ -1245,9 +1299,13 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
       return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
     for (uint32_t k = 0; k < na; ++k) std::swap(*arrs[k], sc->spare[k]);   // (the old arrays are next call's spares: nothing queued reads them after the gather)
     SA_BUSY(e);
+    sc->index_drain = e->drain_count;
     if (e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
-    e->gather_seq = e->busy_seq;   // (the engine was drained right before this launch: nothing else is in flight)
+    // (nothing but gathers in flight since the last drain: staging the next request set need not wait, only_gather_in_flight)
+    e->gather_seq = was_idle ? e->busy_seq : 0;
   }
+  sc->full.resize(sc->T, 0);
+  for (uint32_t r = 0; r < nT; ++r) { sc->ids[r] = sc->ids[keep[r]]; sc->full[r] = sc->full[keep[r]]; }
   sc->T = nT;
   sc->ids.resize(nT);
   sc->full.resize(nT);
@@ -1366,8 +1424,35 @@ static bool in_device_block(const void* p, size_t bytes, int* device) {
 
 // Appends one scene of a request set to bank `b`: host work only — the boxes (with libm's cos / sin of their angles), the optional
 // per-detection arrays and the features are laid out in the bank's pinned staging arena; bank_upload moves the arena in one DMA.
+// The copy half of bank_add: the caller's arrays into the slot's block of the pinned arena.  Touches nothing but that block (and, on a bad
+// box, the engine's error string under its mutex): slots of one set may be filled by different threads at once.
+static int slot_fill(sa_engine* e, Bank* b, Slot* s, bool check) {
+  const sa_detections* d = &s->pend_d;
+  const float* const* feat_rows = s->pend_rows;
+  const uint32_t N = s->N, D = e->D;
+  s->fill_pending = false;
+  if (!N) return SA_OK;
+  if (check)
+    for (uint32_t i = 0; i < N; ++i) TRY(check_box(e, d->boxes[i], "detections.boxes", i));
+  uint8_t* h = (uint8_t*)b->h_arena.p;
+  fill_raw((BoxRaw*)(h + s->o_raw), d->boxes, N);
+  if (s->has_quality) std::memcpy(h + s->o_q, d->feat_quality, (size_t)N * 4);
+  if (s->has_own) std::memcpy(h + s->o_own, d->own_area, (size_t)N * 4);
+  if (s->has_fpresent) std::memcpy(h + s->o_fp, d->feat_present, N);
+  if (s->has_feats && !s->feats_inplace && !s->feats_device) {
+    float* dst0 = (float*)(h + s->o_feat);
+    if (feat_rows) {
+      for (uint32_t i = 0; i < N; ++i) {
+        float* dst = dst0 + (size_t)i * D;
+        if (feat_rows[i]) std::memcpy(dst, feat_rows[i], (size_t)D * 4);
+        else std::memset(dst, 0, (size_t)D * 4);
+      }
+    } else std::memcpy(dst0, d->feats, (size_t)N * D * 4);
+  }
+  return SA_OK;
+}
 static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
-                    uint32_t* out_slot) {
+                    uint32_t* out_slot, bool defer = false) {
   const uint32_t N = d->n;
   for (uint32_t i = 0; i < b->n_slots; ++i)
     if (b->slots[i]->scene->scene_id == scene_id)
@@ -1409,28 +1494,14 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   s->o_feat = align_up(s->o_fp + N, 4096);
   const size_t end = s->o_feat + ((s->has_feats && !s->feats_inplace && !s->feats_device) ? fbytes : 0);
   TRY(arena_reserve(e, b, end + 256));
-  uint8_t* h = (uint8_t*)b->h_arena.p;
-  if (N) {
-    fill_raw((BoxRaw*)(h + s->o_raw), d->boxes, N);
-    if (s->has_quality) std::memcpy(h + s->o_q, d->feat_quality, (size_t)N * 4);
-    if (s->has_own) std::memcpy(h + s->o_own, d->own_area, (size_t)N * 4);
-    if (s->has_fpresent) std::memcpy(h + s->o_fp, d->feat_present, N);
-    if (s->has_feats && !s->feats_inplace && !s->feats_device) {
-      float* dst0 = (float*)(h + s->o_feat);
-      if (feat_rows) {
-        for (uint32_t i = 0; i < N; ++i) {
-          float* dst = dst0 + (size_t)i * D;
-          if (feat_rows[i]) std::memcpy(dst, feat_rows[i], (size_t)D * 4);
-          else std::memset(dst, 0, (size_t)D * 4);
-        }
-      } else std::memcpy(dst0, d->feats, fbytes);
-    }
-  }
+  s->pend_d = *d;
+  s->pend_rows = feat_rows;
+  s->fill_pending = true;
   b->used = end;
   b->uploaded = false;
   if (out_slot) *out_slot = b->n_slots;
   b->n_slots++;
-  return SA_OK;
+  return defer ? SA_OK : slot_fill(e, b, s, false);
 }
 
 // sa_batch_add with the feature rows given one pointer per detection (nullptr = no feature) instead of one N x D block: the
@@ -1443,6 +1514,23 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
   if (N && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
   for (uint32_t i = 0; i < N; ++i) TRY(check_box(e, d->boxes[i], "detections.boxes", i));
   return bank_add(e, e->B, scene_id, epoch, d, feat_rows, out_slot);
+}
+
+// Batch*::predict stages dozens of scenes per call: the layout of a request set is serial bookkeeping (offsets in one arena), the copies
+// are not — sa_batch_add_deferred lays a scene out and remembers the caller's arrays, sa_batch_fill(slot) validates the boxes and copies
+// (libm's sincos of oriented boxes included); fills of DIFFERENT slots may run on different threads at once, but not beside an add.
+int sa_batch_add_deferred(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows, uint32_t* out_slot) {
+  if (!e || !d) return fail(e, SA_ERR_BAD_ARG, "sa_batch_add_deferred: null argument");
+  if (d->n && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
+  return bank_add(e, e->B, scene_id, epoch, d, feat_rows, out_slot, true);
+}
+int sa_batch_fill(sa_engine* e, uint32_t slot) {
+  if (!e) return SA_ERR_BAD_ARG;
+  Bank* b = e->B;
+  if (slot >= b->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, b->n_slots);
+  Slot* s = b->slots[slot];
+  if (!s->fill_pending) return SA_OK;
+  return slot_fill(e, b, s, true);
 }
 
 int sa_batch_run(sa_engine* e) {
@@ -1493,6 +1581,29 @@ int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
     if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
   } else if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
   std::memcpy(out_cols, (const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16, (size_t)s->N * 4);
+  return SA_OK;
+}
+
+// sa_batch_fetch + sa_batch_fetch_cols without the copies: the slot's results where the assignment tail wrote them (mapped pinned
+// memory), valid until the next sa_batch_begin / sa_pipe_stage that recycles the bank.  Waits for the association like sa_batch_fetch;
+// after sa_batch_run_apply that wait is one event, and the call may be made for different slots from different threads.
+int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id, const uint8_t** out_voting_type, const int32_t** out_cols) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_batch_results"));
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!s->ran && !s->fused_pending) return fail(e, SA_ERR_STATE, "sa_batch_results before sa_batch_run");
+  if (e->B->assoc_event) {
+    hipError_t we = hipEventSynchronize(e->B->ev_done);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+  } else if (!e->synced) TRY(engine_sync(e));
+  const uint8_t* h = (const uint8_t*)s->h_out.p;
+  const size_t n1 = s->N ? s->N : 1, st_off = (n1 * 9 + 7) & ~(size_t)7;
+  if (s->N && ((const uint32_t*)(h + st_off))[1])
+    return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the frame's results are not valid");
+  if (out_track_id) *out_track_id = (const uint64_t*)h;
+  if (out_voting_type) *out_voting_type = h + n1 * 8;
+  if (out_cols) *out_cols = (const int32_t*)(h + st_off + 16);
   return SA_OK;
 }
 
@@ -1650,50 +1761,29 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
 // bookkeeping there); whatever needs the finished table first — the next request set, an upsert, a tap — finishes a pending one.
 static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted);
 static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted);
+static int polygon_fixups(sa_engine* e, Slot* s);
 static int finish_applies(sa_engine* e) {
   while (!e->applying.empty()) TRY(apply_finish(e, e->applying.back(), nullptr));
   for (Bank& bk : e->banks)
-    for (uint32_t i = 0; i < bk.n_slots; ++i)
+    for (uint32_t i = 0; i < bk.n_slots; ++i) {
       if (bk.slots[i]->fused_pending) TRY(fused_collect(e, bk.slots[i], nullptr, nullptr));
+      else if (bk.slots[i]->poly_pending) { bk.slots[i]->poly_pending = false; TRY(polygon_fixups(e, bk.slots[i])); }
+    }
   return SA_OK;
 }
-// Queues the upkeep kernels of slot `s` (Kalman step + table rows, feature-bank policy) on the compute stream.  new_row / new_ids: device-visible
-// arrays — table row and id of every candidate that starts a track (SA_NONE / 0 elsewhere).
-static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids, hipEvent_t done = nullptr, int part = 0) {  // (both nullptr: drawn on the device from s->fused_*; part: sa_launch_apply)
-  SceneTable* sc = s->scene;
+// Queues the upkeep kernels of slot `s` (Kalman step + table rows, feature-bank policy: one launch) on the compute stream.  new_row / new_ids:
+// device-visible arrays — table row and id of every candidate that starts a track (SA_NONE / 0 elsewhere).
+static int apply_launch(sa_engine* e, Slot* s, const uint32_t* new_row, const uint64_t* new_ids) {
   const uint32_t n = s->N;
   {
     void* before = s->h_pred.p;
     TRY(host_ensure(e, s->h_pred, (size_t)n * sizeof(sa_box)));
     if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
   }
-  hipStream_t st = e->stream;
-  ApplyArgs a{};
-  a.c_raw = (const BoxRaw*)s->p_raw; a.win_col = (const int32_t*)s->win_col.p; a.new_row = new_row;
-  a.new_ids = new_ids; a.n = n; a.epoch = s->epoch;
-  a.T0 = s->fused_T0; a.id_base = s->fused_id_base; a.id_per_candidate = s->fused_per_candidate;
-  a.kf = (float*)sc->kf.p; a.geo = (sa_geo*)sc->geo.p; a.ext = (sa_ext*)sc->ext.p; a.verts = (double*)sc->verts.p; a.t_epoch = (uint64_t*)sc->epoch.p;
-  a.t_ids = (uint64_t*)sc->tids.p; a.maha = (float*)sc->maha.p; a.out_pred = (sa_box*)s->d_pred;
-  // queued behind the association, Kalman dispatch first: the rows a registered device block is read in place for leave the caller's
-  // memory with that dispatch (ApplyArgs::copy_src); the bank dispatch reads the slot's copy
-  const bool in_place = e->visual && s->has_feats && e->D == e->Dp && s->feats_device && s->p_feat_raw == (void*)s->feats_device;
-  if (part == 1 && in_place) {
-    TRY(dev_ensure(e, s->feat_raw, (size_t)n * e->D * 4));
-    a.copy_src = (const float*)s->feats_device; a.copy_dst = (float*)s->feat_raw.p; a.copy_row_floats = e->D;
-  }
-  BankArgs b{};
-  if (e->visual) {
-    b.c_raw = a.c_raw; b.win_col = a.win_col; b.new_row = a.new_row; b.T0 = a.T0; b.n = n; b.K = e->K; b.Dp = e->Dp;
-    b.c_feat = s->has_feats ? (const float*)(e->D == e->Dp ? ((part == 2 && in_place) ? s->feat_raw.p : s->p_feat_raw) : s->feat.p) : nullptr; b.c_fnorm = s->prepped ? (const float*)s->fnorm.p : nullptr;   // (a lean frame: D == Dp, the step forms the norms of the rows it stores)
-    b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
-    b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
-    b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
-    b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
-    b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p;
-    b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
-    b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
-  }
-  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, st, done, part));
+  ApplyArgs a;
+  BankArgs b;
+  fill_apply_args(e, s, new_row, new_ids, 0, a, b);
+  HIPCHK(e, sa_launch_apply(a, e->visual ? &b : nullptr, e->P, e->stream, nullptr, 0));
   SA_BUSY(e);
   return SA_OK;
 }
@@ -1819,26 +1909,23 @@ static int apply_finish(sa_engine* e, Slot* s, sa_box* out_predicted) {
 // batch_api.rs:102-106) — the device can draw them itself: k_apply_ids turns the winners into (row, id) of every new track and the
 // Kalman / feature-bank kernels run right behind the assignment tail on the same stream.  The host learns everything in ONE wait and
 // replays the (trivial) id arithmetic for its own copy of the table.
-static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
-  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;  // (trace hook: where the collect spends its time)
-  const auto tc0 = std::chrono::steady_clock::now();
-  HIPCHK(e, hipSetDevice(e->device));
+// (1) the wait: the set's Kalman dispatch has retired — the predicted boxes and the table's rows are out (VisualSORT: the feature banks may
+// still be moving, the engine stays busy)
+static int fused_wait(sa_engine* e, Bank* ob) {
+  if (ob && ob->kf_event) {
+    hipError_t we = hipEventSynchronize(ob->ev_kf);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+  } else if (ob && ob->apply_event) {
+    hipError_t we = hipEventSynchronize(ob->ev_apply);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    if (e->busy_seq == ob->apply_seq && !e->copy_dirty) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
+  } else TRY(engine_sync(e));
+  return SA_OK;
+}
+// (2) the host side of one slot's table: replays the id arithmetic of the kernels, validates the winners.  Touches the slot and its scene only
+// (and the error string, under its mutex): different slots may be collected by different threads at once.
+static int fused_collect_host(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
   s->fused_pending = false;
-  {
-    Bank* ob = nullptr;   // the bank the slot belongs to: its last upkeep dispatch carries ev_apply
-    for (Bank& bk : e->banks)
-      for (uint32_t i = 0; i < bk.n_slots; ++i)
-        if (bk.slots[i] == s) ob = &bk;
-    if (ob && ob->kf_event) {   // (the predicted boxes and the table's rows are out; the feature banks may still be moving: the engine stays busy)
-      hipError_t we = hipEventSynchronize(ob->ev_kf);
-      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
-    } else if (ob && ob->apply_event) {
-      hipError_t we = hipEventSynchronize(ob->ev_apply);
-      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
-      if (e->busy_seq == ob->apply_seq && !e->copy_dirty) TRY(engine_idle(e));  // (that dispatch was the last thing queued on either stream: drained, without a marker packet)
-    } else TRY(engine_sync(e));
-  }
-  const auto tc1 = std::chrono::steady_clock::now();
   SceneTable* sc = s->scene;
   const uint32_t n = s->N, T0 = s->fused_T0;
   if (!n) return SA_OK;
@@ -1855,7 +1942,9 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
       const uint64_t id = s->fused_id_base + 1ull + (s->fused_per_candidate ? (uint64_t)i : (uint64_t)r);
       h_row[i] = T0 + r;
       ++r;
-      if (find_slot(sc, id, nullptr)) bad = fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)id);
+      // (ascending tables — every tracker of the reference — take ids above their last one without a search)
+      if (!(sc->ascending && (sc->ids.empty() || id > sc->ids.back())) && find_slot(sc, id, nullptr))
+        bad = fail(e, SA_ERR_BAD_ARG, "new id %llu already exists in the scene", (unsigned long long)id);
       append_id(sc, id);
       if (out_ids) out_ids[i] = id;
     } else {
@@ -1872,14 +1961,23 @@ static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_p
   sc->full.resize(sc->T, 1);
   s->ran = false;  // the table the slot ran against is gone
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
-  if (bad != SA_OK) return bad;
-  const auto tc2 = std::chrono::steady_clock::now();
-  const int prc = polygon_fixups(e, s);
-  if (trace) {
-    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    fprintf(stderr, "[sa_collect] sync %.1f  table %.1f  polygons %.1f us\n", us(tc0, tc1), us(tc1, tc2), us(tc2, std::chrono::steady_clock::now()));
-  }
-  return prc;
+  s->poly_pending = bad == SA_OK;   // (3) polygon_fixups: a launch — left to the thread that owns the engine's stream
+  return bad;
+}
+static Bank* bank_of_slot(sa_engine* e, const Slot* s) {
+  for (Bank& bk : e->banks)
+    for (uint32_t i = 0; i < bk.n_slots; ++i)
+      if (bk.slots[i] == s) return &bk;
+  return nullptr;
+}
+static int fused_collect(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
+  HIPCHK(e, hipSetDevice(e->device));
+  s->fused_pending = false;
+  TRY(fused_wait(e, bank_of_slot(e, s)));
+  TRY(fused_collect_host(e, s, out_ids, out_predicted));
+  if (!s->poly_pending) return SA_OK;
+  s->poly_pending = false;
+  return polygon_fixups(e, s);
 }
 
 int sa_tracks_apply_end(sa_engine* e, uint32_t slot, sa_box* out_predicted) {
@@ -1902,59 +2000,67 @@ int sa_tracks_apply(sa_engine* e, uint32_t slot, const uint64_t* new_ids, sa_box
 }
 
 int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candidate) {
-  if (!e || !id_base) return fail(e, SA_ERR_BAD_ARG, "sa_batch_run_apply: null argument");
+  if (!e) return SA_ERR_BAD_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   TRY(finish_applies(e));
   if (e->B_ticket) return fail(e, SA_ERR_STATE, "sa_batch_run_apply works on a synchronous batch (sa_batch_begin / sa_batch_add), not on a waited ticket");
   Bank* b = e->B;
-  // every scene's table with room for as many new tracks as it has candidates — BEFORE the descriptors are built (a table that grows moves)
+  if (!b->n_slots) return SA_OK;   // (an empty request set: nothing to run, nothing to apply — id_base may be NULL)
+  if (!id_base) return fail(e, SA_ERR_BAD_ARG, "sa_batch_run_apply: null argument");
+  // every scene's table with room for as many new tracks as it has candidates, the mapped block its predicted boxes land in, the buffer its
+  // in-place feature rows are copied to — BEFORE the descriptors and the upkeep arguments are built (a table that grows moves)
+  uint32_t kf_blocks = 0, bank_blocks = 0;
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     Slot* s = b->slots[i];
     SceneTable* sc = s->scene;
     sc->full.resize(sc->T, 0);
     TRY(scene_reserve(e, sc, sc->T + s->N));
+    s->fused_T0 = sc->T;
+    s->fused_id_base = id_base[i];
+    s->fused_per_candidate = id_per_candidate ? 1 : 0;
+    if (!s->N) continue;
+    void* before = s->h_pred.p;
+    TRY(host_ensure(e, s->h_pred, (size_t)s->N * sizeof(sa_box)));
+    if (s->h_pred.p != before || !s->d_pred) HIPCHK(e, hipHostGetDevicePointer(&s->d_pred, s->h_pred.p, 0));
+    const bool in_place = e->visual && s->has_feats && e->D == e->Dp && s->feats_device && !((uintptr_t)s->feats_device & 15u);
+    if (in_place) TRY(dev_ensure(e, s->feat_raw, (size_t)s->N * e->D * 4));
+    kf_blocks = std::max(kf_blocks, sa_apply_set_blocks(s->N, in_place, 1));
+    bank_blocks = std::max(bank_blocks, sa_apply_set_blocks(s->N, false, 2));
   }
   b->want_prep = e->D != e->Dp;   // the feature-bank step reads the candidates' PADDED rows: the preparation blocks ride in this frame (rows that
                                   // need no padding are read where they were uploaded, their norms formed by the step itself: the frame stays lean)
-  int rc = SA_OK;
-  if (b->n_slots) {
-    // (run_pipeline, with the end of the ASSOCIATION marked on the stream: the frame's last dispatch carries ev_done as its completion
-    // signal, so that sa_batch_fetch can hand out the winners while the upkeep kernels queued below are still running)
-    uint32_t maxN = 0, maxT = 0;
-    bool rides = false;
-    rc = bank_prepare(e, b, &maxN, &maxT);
-    if (rc == SA_OK) rc = bank_upload(e, b, e->stream, true);
-    if (rc == SA_OK) rc = bank_launch(e, b, maxN, maxT, b->ev_done, &rides);
-    if (rc == SA_OK && !rides) { if (hipEventRecord(b->ev_done, e->stream) != hipSuccess) rc = fail(e, SA_ERR_HIP, "hipEventRecord failed"); }
-    b->assoc_event = rc == SA_OK;
-  }
+  b->want_apply = true;           // (bank_upload appends the scenes' upkeep arguments to the set's one upload)
+  // (run_pipeline, with the end of the ASSOCIATION marked on the stream: the frame's last dispatch carries ev_done as its completion
+  // signal, so that sa_batch_fetch can hand out the winners while the upkeep kernels queued below are still running)
+  uint32_t maxN = 0, maxT = 0;
+  bool rides = false;
+  int rc = bank_prepare(e, b, &maxN, &maxT);
+  if (rc == SA_OK) rc = bank_upload(e, b, e->stream, true);
+  if (rc == SA_OK) rc = bank_launch(e, b, maxN, maxT, b->ev_done, &rides);
+  if (rc == SA_OK && !rides) { if (hipEventRecord(b->ev_done, e->stream) != hipSuccess) rc = fail(e, SA_ERR_HIP, "hipEventRecord failed"); }
+  b->assoc_event = rc == SA_OK;
   b->want_prep = false;
+  b->want_apply = false;
   if (rc != SA_OK) return rc;
-  // VisualSORT: every scene's Kalman dispatch first, then the feature-bank dispatches — the predicted boxes (all a caller of
-  // sa_tracks_apply_collect needs from the device) are out when the LAST Kalman dispatch retires (ev_kf), the banks (10+ us of row
-  // moves at 1000 x 3 x 512 floats) run on behind them; whatever touches the engine next is ordered behind them on the stream, or
-  // waits for ev_apply.  SORT: one dispatch per scene.
-  const int parts = e->visual ? 2 : 1;
-  for (int part = 1; part <= parts; ++part)
-    for (uint32_t i = 0; i < b->n_slots; ++i) {
-      Slot* s = b->slots[i];
-      const uint32_t n = s->N;
-      if (!n) continue;
-      if (part == 1) {
-        s->fused_T0 = s->scene->T;
-        s->fused_id_base = id_base[i];
-        s->fused_per_candidate = id_per_candidate ? 1 : 0;
-      }
-      // rows and ids of the tracks that start: drawn inside the kernels, from the winners; the set's LAST upkeep dispatch signals ev_apply
-      bool last = true;
-      for (uint32_t j = i + 1; j < b->n_slots; ++j) last = last && b->slots[j]->N == 0;
-      const bool final_part = part == parts;
-      hipEvent_t ev = !last ? nullptr : (final_part ? b->ev_apply : b->ev_kf);
-      TRY(apply_launch(e, s, nullptr, nullptr, ev, e->visual ? part : 0));
-      if (last && final_part) { b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq; }
-      if (last && !final_part) b->kf_event = true;
-      s->fused_pending = true;
-    }
+  if (!kf_blocks) return SA_OK;   // (no scene brought a detection)
+  // The upkeep of the WHOLE set: one launch for every scene's Kalman step (rows and ids of the tracks that start are drawn inside the
+  // kernel, from the winners) and, VisualSORT, one for every scene's feature bank behind it — Batch*::predict over 64 scenes queues two
+  // dispatches, not 128.  The predicted boxes (all a caller of sa_tracks_apply_collect needs from the device) are out when the Kalman
+  // dispatch retires (ev_kf); the banks (10+ us of row moves at 1000 x 3 x 512 floats) run on behind it; whatever touches the engine
+  // next is ordered behind them on the stream, or waits for ev_apply.
+  const ApplyScene* as = (const ApplyScene*)((const uint8_t*)b->d_arena.p + b->apply_off);
+  if (hipError_t le = sa_launch_apply_set(as, b->n_slots, kf_blocks, e->K, e->P, e->stream, e->visual ? b->ev_kf : b->ev_apply, 1); le != hipSuccess)
+    return fail(e, SA_ERR_HIP, "upkeep launch failed: %s", hipGetErrorString(le));
+  SA_BUSY(e);
+  if (e->visual) {
+    b->kf_event = true;
+    if (hipError_t le = sa_launch_apply_set(as, b->n_slots, bank_blocks, e->K, e->P, e->stream, b->ev_apply, 2); le != hipSuccess)
+      return fail(e, SA_ERR_HIP, "upkeep launch failed: %s", hipGetErrorString(le));
+    SA_BUSY(e);
+  }
+  b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq;
+  for (uint32_t i = 0; i < b->n_slots; ++i)
+    if (b->slots[i]->N) b->slots[i]->fused_pending = true;
   return SA_OK;
 }
 
@@ -1968,6 +2074,41 @@ int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, 
     return fail(e, SA_ERR_STATE, "sa_tracks_apply_collect without sa_batch_run_apply (or collected already)");
   }
   return fused_collect(e, s, out_new_ids, out_predicted);
+}
+
+// sa_tracks_apply_collect for a whole request set, in three steps, so that the per-scene host work can be spread over threads
+// (Batch*::predict, 64 scenes): _begin waits ONCE for the set's Kalman dispatch; _slot does one scene's host side (ids of the tracks that
+// started, predicted boxes) and may run for DIFFERENT slots on different threads at once; _end (the calling thread again) queues the
+// polygons of refreshed oriented rows.  Any entry point that needs the finished table completes what is left.
+int sa_tracks_apply_collect_begin(sa_engine* e) {
+  if (!e) return SA_ERR_BAD_ARG;
+  TRY(bound_bank_ok(e, "sa_tracks_apply_collect_begin"));
+  HIPCHK(e, hipSetDevice(e->device));
+  bool any = false;
+  for (uint32_t i = 0; i < e->B->n_slots; ++i) any = any || e->B->slots[i]->fused_pending;
+  if (!any) return SA_OK;
+  return fused_wait(e, e->B);
+}
+int sa_tracks_apply_collect_slot(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted) {
+  if (!e) return SA_ERR_BAD_ARG;
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!s->fused_pending) {
+    if (!s->N) return SA_OK;
+    return fail(e, SA_ERR_STATE, "sa_tracks_apply_collect_slot without sa_batch_run_apply (or collected already)");
+  }
+  return fused_collect_host(e, s, out_new_ids, out_predicted);
+}
+int sa_tracks_apply_collect_end(sa_engine* e) {
+  if (!e) return SA_ERR_BAD_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  for (uint32_t i = 0; i < e->B->n_slots; ++i) {
+    Slot* s = e->B->slots[i];
+    if (!s->poly_pending) continue;
+    s->poly_pending = false;
+    TRY(polygon_fixups(e, s));
+  }
+  return SA_OK;
 }
 
 int sa_tracks_get_state(sa_engine* e, uint64_t scene_id, uint64_t id, float* mean10, float* cov100, float* quality, uint8_t* present,

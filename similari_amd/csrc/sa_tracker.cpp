@@ -4,25 +4,35 @@
 //   Sort::predict_with_scene          src/trackers/sort/simple_api.rs:110-196
 //   VisualSort::predict_with_scene    src/trackers/visual_sort/simple_api.rs:99-230
 //   Batch*::predict / voting_thread   src/trackers/sort/batch_api.rs:68-153,222-290
+//   PredictionBatchResult             src/trackers/batch.rs:24-38
 //   SortMetric / VisualMetric::optimize (Kalman step, history, feature bank)   sort/metric.rs:79-105,
 //                                     visual_sort/metric.rs:129-154,297-374
 //   TrackerAPI (epochs, waste)        src/trackers/tracker_api.rs, epoch_db.rs
 // The Kalman step is written against the filter's structure (motion = I + shift, update matrix = [I 0]); skipping
 // the multiplications by the constant 0/1 entries leaves every f32 result unchanged (kalman_2d_box.rs:58-148).
+//
+// A request set of several scenes (Batch*::predict) is worked on scene by scene by a small pool of threads (sa_pool.h) â€” the
+// reference's voting_shards (sort/batch_api.rs:197-207) â€” and on the device by ONE set of launches: the association of every scene
+// (grid.z = scene), one Kalman dispatch and one feature-bank dispatch for all of them (sa_batch_run_apply).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <chrono>
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../../include/similari_tracker.h"
 #include "sa_kalman.h"
+#include "sa_pool.h"
 
 namespace {
 
@@ -77,7 +87,32 @@ struct Track {  // (what a frame's bookkeeping touches first; the filter state â
   KF kf;
 };
 
+// One scene's share of the store.  Scenes never share a track (compatible() is false across scene ids, sort.rs:251), so everything a
+// frame's bookkeeping touches belongs to exactly one scene â€” which is what lets the scenes of a request set be worked on side by side.
+struct SceneState {
+  uint64_t id = 0, epoch = 0;   // EpochDb: the scene's current epoch (0 = never seen)
+  // the scene's tracks in the order of the engine's table for that scene: rows are appended in creation order (ids ascend) and removals
+  // close the gaps on both sides, so the winner the engine reports as a COLUMN (sa_batch_results) is rows[column] â€” no lookup by id on
+  // the per-candidate path
+  std::vector<Track*> rows;
+  // Eviction.  A track whose last update lies more than max_idle_epochs behind its scene's epoch fails compatible() (sort.rs:250-270) for
+  // every later frame â€” epochs only grow â€” but the reference keeps it in the store until the next auto_waste (every 100th predict by
+  // default), and so would the engine's table: at 5 % churn a 1000-object VisualSORT loop associates against 6 700 rows instead of
+  // 1 200.  The facade therefore takes such tracks out of the ENGINE's table as soon as they are 64 and a sixteenth of it (sa_tracks_remove:
+  // one gather launch, queued without a drain), and keeps them here â€” idle_tracks / wasted see them as before.  (What is gone with the
+  // row is the Kalman state of a device-upkeep tracker: sa_tracker_track_state answers SA_ERR_NOT_FOUND for an evicted track.)
+  std::vector<uint64_t> row_epoch;   // last_updated_epoch of `rows`, in the same order (the scan's input)
+  std::vector<Track*> evicted;       // out of the engine's table, not wasted yet
+};
+
+struct ResultState;
+
 }  // namespace
+
+// PredictionBatchResult  trackers/batch.rs:19-38
+struct sa_batch_result {
+  std::shared_ptr<ResultState> st;
+};
 
 struct sa_tracker {
   sa_tracker_options o{};
@@ -86,36 +121,34 @@ struct sa_tracker {
   sa_engine* eng = nullptr;
   std::string err;
   uint64_t track_id = 0;
-  std::map<uint64_t, uint64_t> epochs;            // scene -> current epoch
-  std::unordered_map<uint64_t, Track> store;      // main store (node-based: a Track's address is stable while it lives)
-  // scene -> its tracks in the order of the engine's table for that scene: rows are appended in creation order (ids ascend) and
-  // removals close the gaps on both sides, so the winner the engine reports as a COLUMN (sa_batch_fetch_cols) is rows[column] â€”
-  // no lookup by id on the per-candidate path
-  std::map<uint64_t, std::vector<Track*>> by_scene;
-  // Eviction.  A track whose last update lies more than max_idle_epochs behind its scene's epoch fails compatible() (sort.rs:250-270) for
-  // every later frame â€” epochs only grow â€” but the reference keeps it in the store until the next auto_waste (every 100th predict by
-  // default), and so would the engine's table: at 5 % churn a 1000-object VisualSORT loop associates against 6 700 rows instead of
-  // 1 200.  The facade therefore takes such tracks out of the ENGINE's table as soon as they are 64 and a sixteenth of it (sa_tracks_remove:
-  // one gather launch), and keeps them in its own store â€” idle_tracks / wasted see them as before.
-  std::map<uint64_t, std::vector<uint64_t>> row_epoch;   // scene -> last_updated_epoch of by_scene's rows, in the same order (the scan's input)
-  std::map<uint64_t, std::vector<Track*>> evicted;       // scene -> tracks out of the engine's table, still in `store`
+  std::map<uint64_t, SceneState> scenes;   // node-based: a SceneState's address is stable
+  uint64_t n_active = 0;                   // tracks in the main store (sum of active_shard_stats)
   std::vector<Track> wasted_store;
   uint32_t waste_counter = 0;
-  // predict()'s per-scene work arrays, kept between calls: a frame allocates nothing once the arrays have grown to its size
+  // predict()'s per-scene work arrays, kept between calls: a frame allocates nothing once the arrays have grown to its size.  Everything
+  // the work AFTER the launches reads of the caller's observations is copied here (boxes, custom ids): the reference takes its request by
+  // value, and so a caller of sa_tracker_predict_batch_begin may reuse its arrays as soon as that call has returned.
   struct SceneScratch {
-    std::vector<sa_box> cboxes, dev_pred;      // the candidates' boxes after their own Kalman no-op step ; the device's predicted boxes
+    SceneState* st = nullptr;
+    uint32_t n = 0, slot = 0, n_new = 0;
+    uint64_t epoch = 0, id_base = 0;
+    int rc = SA_OK;
+    std::string err;
+    std::vector<sa_box> cboxes, oboxes, dev_pred;  // the candidates' boxes after their own Kalman no-op step ; as observed ; the device's predicted boxes
+    std::vector<int64_t> ccustom;
+    std::vector<uint8_t> chas_custom;
     std::vector<float> cq, cown, shares;
     std::vector<const float*> cfeat;           // one pointer per detection: the engine gathers the rows itself ...
-    std::vector<uint8_t> cpres, votes;
+    std::vector<uint8_t> cpres, votes, merged;
     std::vector<uint64_t> winners, tids, new_ids;
     std::vector<int32_t> wcols;
     std::vector<Track*> trps;
+    sa_detections det{};
     uint8_t contiguous = 0;                    // ... unless they already ARE one N x D block (then: no gather at all)
   };
   std::vector<SceneScratch> scratch[2];     // two sets, used in turn: the set of the previous predict() may still hold deferred work
   int cur_set = 0;
-  std::vector<uint64_t> sc_epoch, sc_id_base, sc_touched;
-  std::vector<sa_scene_request> sc_req;
+  std::vector<uint64_t> sc_touched;
   // Deferred bookkeeping (device upkeep queued behind the association: the fused path).  What a predict() RETURNS needs, per continued
   // track, one cache line of its record (id, length, epoch, custom id, vote); the rest of the reference's merge â€” the history deques
   // (sort.rs:160-176) and the observation policy (visual_sort/metric.rs:129-154) â€” only has to be in place before anything READS it:
@@ -125,10 +158,37 @@ struct sa_tracker {
   bool pending = false;
   int pending_set = 0;
   uint32_t pending_scenes = 0;
-  std::vector<uint32_t> pending_counts;
+  // the per-scene jobs of a request set (created with the first set of more than one scene)
+  std::unique_ptr<SaPool> pool;
+  // sa_tracker_predict_batch_begin: the work behind the launches (waiting, merges, results) runs on this thread, so that the caller gets
+  // its handle back while the GPU is still busy â€” the reference's voting threads.  One request set at a time: every entry point first
+  // waits for the set in flight (the reference's "busy monitor", sort/batch_api.rs:233-241).
+  std::thread driver;
+  std::mutex dmu;
+  std::condition_variable dcv;
+  bool d_work = false, d_stop = false;
+  std::atomic<bool> d_busy{false};
+  struct Flight {   // the request set between its launches and its last result
+    uint32_t n_scenes = 0;
+    int set = 0;
+    std::vector<sa_sort_track*> out;
+    std::shared_ptr<ResultState> res;   // null: a synchronous predict (the caller's arrays)
+  } flight;
 };
 
 namespace {
+
+struct ResultState {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint64_t> scene_ids;
+  std::vector<std::vector<sa_sort_track>> tracks;
+  std::deque<uint32_t> ready_q;   // scenes whose tracks are final, in the order they became so
+  uint32_t taken = 0;
+  int rc = SA_OK;                 // first error of the request set
+  std::string err;
+  bool finished = false;
+};
 
 int tfail(sa_tracker* t, int code, const char* fmt, ...) {
   char buf[512];
@@ -160,22 +220,6 @@ sa_sort_track to_sort_track_with(const sa_tracker_options& o, const Track& tr, c
   s.observed_bbox = observed;
   s.scene_id = tr.scene;
   s.length = tr.length;
-  s.voting_type = (o.visual && tr.voting >= 0) ? tr.voting : SA_VOTE_POSITIONAL;
-  s.has_custom_object_id = tr.has_custom ? 1 : 0;
-  s.custom_object_id = tr.custom;
-  return s;
-}
-
-sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
-  sa_sort_track s;
-  std::memset(&s, 0, sizeof s);
-  s.id = tr.id;
-  s.epoch = tr.epoch;
-  const BoxPair& last = tr.boxes.back();
-  s.predicted_bbox = last.predicted;
-  s.observed_bbox = last.observed;
-  s.scene_id = tr.scene;
-  s.length = tr.length;
   // Sort: always Positional (sort/simple_api.rs:260) ; VisualSort: attrs.voting_type.unwrap_or(Positional)
   s.voting_type = (o.visual && tr.voting >= 0) ? tr.voting : SA_VOTE_POSITIONAL;
   s.has_custom_object_id = tr.has_custom ? 1 : 0;
@@ -183,53 +227,94 @@ sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
   return s;
 }
 
+sa_sort_track to_sort_track(const sa_tracker_options& o, const Track& tr) {
+  const BoxPair& last = tr.boxes.back();
+  return to_sort_track_with(o, tr, last.observed, last.predicted);
+}
+
+SceneState& scene_of(sa_tracker* t, uint64_t scene) {
+  SceneState& s = t->scenes[scene];
+  s.id = scene;
+  return s;
+}
 uint64_t current_epoch(sa_tracker* t, uint64_t scene) {
-  auto it = t->epochs.find(scene);
-  return it == t->epochs.end() ? 0 : it->second;
+  auto it = t->scenes.find(scene);
+  return it == t->scenes.end() ? 0 : it->second.epoch;
+}
+// a stored track by id: rows ascend by id (binary search), evicted ones are few
+Track* find_track(sa_tracker* t, uint64_t id, SceneState** where = nullptr) {
+  for (auto& kv : t->scenes) {
+    SceneState& S = kv.second;
+    auto it = std::lower_bound(S.rows.begin(), S.rows.end(), id, [](const Track* a, uint64_t v) { return a->id < v; });
+    Track* hit = (it != S.rows.end() && (*it)->id == id) ? *it : nullptr;
+    if (!hit)   // (tables whose ids ever arrived out of order: none of the facade's own, but cheap to be safe)
+      for (Track* tr : S.rows)
+        if (tr->id == id) { hit = tr; break; }
+    if (!hit)
+      for (Track* tr : S.evicted)
+        if (tr->id == id) { hit = tr; break; }
+    if (hit) { if (where) *where = &S; return hit; }
+  }
+  return nullptr;
+}
+
+void run_jobs(sa_tracker* t, uint32_t n, const std::function<void(uint32_t)>& fn) {
+  if (n > 1 && !t->pool) {
+    uint32_t w = t->o.workers > 0 ? (uint32_t)t->o.workers : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4u));
+    t->pool.reset(new SaPool(w > 1 ? w - 1 : 0));   // (the calling thread is a worker too)
+  }
+  if (n > 1 && t->pool) t->pool->run(n, fn);
+  else
+    for (uint32_t i = 0; i < n; ++i) fn(i);
 }
 
 // get_main_store_wasted + auto_waste  tracker_api.rs:68-88 ; baked(): epoch_db.rs:52-66
 int auto_waste(sa_tracker* t) {
-  std::map<uint64_t, std::vector<uint64_t>> gone;
-  for (auto& kv : t->store) {
-    const Track& tr = kv.second;
-    if (tr.epoch + t->o.max_idle_epochs < current_epoch(t, tr.scene)) gone[tr.scene].push_back(tr.id);
-  }
-  for (auto& kv : gone) {
-    std::sort(kv.second.begin(), kv.second.end());
-    std::vector<uint64_t> resident;   // those the engine's table still holds (the others were evicted from it earlier)
-    for (uint64_t id : kv.second)
-      if (t->store[id].in_engine) resident.push_back(id);
-    int rc = resident.empty() ? SA_OK : sa_tracks_remove(t->eng, kv.first, (uint32_t)resident.size(), resident.data());
+  for (auto& kv : t->scenes) {
+    SceneState& S = kv.second;
+    std::vector<uint64_t> gone, resident;   // resident: those the engine's table still holds (the others were evicted from it earlier)
+    for (const auto* list : {&S.rows, &S.evicted})
+      for (const Track* tr : *list)
+        if (tr->epoch + t->o.max_idle_epochs < S.epoch) { gone.push_back(tr->id); if (tr->in_engine) resident.push_back(tr->id); }
+    if (gone.empty()) continue;
+    std::sort(gone.begin(), gone.end());
+    std::sort(resident.begin(), resident.end());
+    int rc = resident.empty() ? SA_OK : sa_tracks_remove(t->eng, S.id, (uint32_t)resident.size(), resident.data());
     if (rc != SA_OK) return tfail(t, rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
-    auto& rows = t->by_scene[kv.first];
-    auto& eps = t->row_epoch[kv.first];
+    auto is_gone = [&](const Track* tr) { return std::binary_search(gone.begin(), gone.end(), tr->id); };
+    std::vector<Track*> dead;
     size_t w = 0;
-    for (size_t r = 0; r < rows.size(); ++r)
-      if (!std::binary_search(kv.second.begin(), kv.second.end(), rows[r]->id)) { rows[w] = rows[r]; eps[w] = eps[r]; ++w; }
-    rows.resize(w);
-    eps.resize(w);
-    auto& ev = t->evicted[kv.first];
-    ev.erase(std::remove_if(ev.begin(), ev.end(), [&](const Track* tr) { return std::binary_search(kv.second.begin(), kv.second.end(), tr->id); }), ev.end());
-    for (uint64_t id : kv.second) {
-      t->wasted_store.push_back(std::move(t->store[id]));
-      t->store.erase(id);
+    for (size_t r = 0; r < S.rows.size(); ++r) {
+      if (is_gone(S.rows[r])) dead.push_back(S.rows[r]);
+      else { S.rows[w] = S.rows[r]; S.row_epoch[w] = S.row_epoch[r]; ++w; }
+    }
+    S.rows.resize(w);
+    S.row_epoch.resize(w);
+    for (Track* tr : S.evicted)
+      if (is_gone(tr)) dead.push_back(tr);
+    S.evicted.erase(std::remove_if(S.evicted.begin(), S.evicted.end(), is_gone), S.evicted.end());
+    std::sort(dead.begin(), dead.end(), [](const Track* a, const Track* b) { return a->id < b->id; });
+    for (Track* tr : dead) {
+      t->wasted_store.push_back(std::move(*tr));
+      delete tr;
+      --t->n_active;
     }
   }
   return SA_OK;
 }
 
-// Pushes the rows of `ids` (tracks of one scene that were created or merged this frame) to the engine.
-int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<uint64_t>& ids) {
-  if (ids.empty()) return SA_OK;
-  const uint32_t n = (uint32_t)ids.size(), K = t->o.visual ? t->o.visual_max_observations : 1, D = t->o.feature_len;
+// Pushes the rows of `trs` (tracks of one scene that were created or merged this frame) to the engine.
+int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<Track*>& trs) {
+  if (trs.empty()) return SA_OK;
+  const uint32_t n = (uint32_t)trs.size(), K = t->o.visual ? t->o.visual_max_observations : 1, D = t->o.feature_len;
   std::vector<sa_box> boxes(n);
-  std::vector<uint64_t> epochs(n);
+  std::vector<uint64_t> epochs(n), ids(n);
   std::vector<float> mean(n * 5), cov(n * 25), feats;
   std::vector<uint8_t> present;
   if (t->o.visual) { feats.assign((size_t)n * K * D, 0.0f); present.assign((size_t)n * K, 0); }
   for (uint32_t i = 0; i < n; ++i) {
-    const Track& tr = t->store[ids[i]];
+    const Track& tr = *trs[i];
+    ids[i] = tr.id;
     boxes[i] = tr.boxes.back().predicted;
     epochs[i] = tr.epoch;
     for (int a = 0; a < 5; ++a) {
@@ -289,63 +374,397 @@ inline void merge_heavy(const sa_tracker_options& o, Track& tr, const sa_tracker
   }
 }
 
-// Runs what the previous predict() deferred (sa_tracker::pending).  Idempotent; every entry point that reads a track's history or
-// observations calls it first.
+// Runs what the previous predict() deferred (sa_tracker::pending), one job per scene of that set.  Idempotent; every entry point that
+// reads a track's history or observations calls it first.
 void flush_pending(sa_tracker* t) {
   if (!t->pending) return;
   t->pending = false;
   const std::vector<sa_tracker::SceneScratch>& ss = t->scratch[t->pending_set];
-  for (uint32_t s = 0; s < t->pending_scenes; ++s) {
+  run_jobs(t, t->pending_scenes, [&](uint32_t s) {
     const sa_tracker::SceneScratch& W = ss[s];
-    const uint32_t n = t->pending_counts[s];
-    for (uint32_t i = 0; i < n; ++i)
-      if (W.winners[i] != 0) merge_heavy(t->o, *W.trps[i], W, i);
+    for (uint32_t i = 0; i < W.n; ++i)
+      if (W.merged[i]) merge_heavy(t->o, *W.trps[i], W, i);
+  });
+}
+
+// The set in flight (sa_tracker_predict_batch_begin) has delivered its last scene: every entry point waits for that first.
+void wait_outstanding(sa_tracker* t) {
+  if (!t->d_busy.load(std::memory_order_acquire)) return;
+  std::unique_lock<std::mutex> lk(t->dmu);
+  t->dcv.wait(lk, [&] { return !t->d_busy.load(std::memory_order_acquire); });
+}
+
+using clk = std::chrono::steady_clock;
+inline double us_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+
+// One scene's observations into its work arrays: validation (the reference's assert!s), the candidates' boxes, the optional arrays of a
+// VisualSORT observation, whether the feature rows form one block.  Reads the caller's memory, writes nothing but W.
+int assemble_scene(const sa_tracker_options& o, sa_tracker::SceneScratch& W, uint64_t scene_id, uint32_t n, const sa_observation* obs) {
+  const uint32_t D = o.feature_len;
+  W.n = n;
+  W.rc = SA_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    const sa_box& bb = obs[i].bbox;
+    if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f)) {
+      char buf[128];
+      snprintf(buf, sizeof buf, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_id);
+      W.err = buf;
+      return W.rc = SA_ERR_BAD_ARG;
+    }
+  }
+  W.cboxes.resize(n);
+  W.oboxes.resize(n);
+  W.ccustom.resize(n);
+  W.chas_custom.resize(n);
+  if (o.visual) { W.cfeat.resize(n); W.cq.resize(n); W.cown.resize(n); W.cpres.resize(n); }
+  // The throw-away candidate track of a detection (simple_api.rs:125-145) is never materialised: its box goes into the request, the
+  // rest of it (custom id, feature pointer) is kept beside it for the moment a track takes it over.
+  // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from, kalman_prediction.rs:13-32)
+  // is the identity on the box: zero velocity, zero innovation, so the new mean is the observation plus (+-0) * gain.  All that
+  // changes is TryFrom<KalmanState>: an angle of exactly 0.0 reads back as None (kalman.rs:82-86).  The 10 x 10 filter arithmetic
+  // (about 1 us per detection on the host) is therefore only run for the candidates that become tracks and need the state;
+  // the tests compare every box with the oracle, which does run the filter.
+  const float* block = nullptr;  // where row 0 of an N x D block would lie, if the features form one
+  bool one_block = o.visual && n > 0, all_present = true;
+  const std::vector<float>& shares = W.shares;
+  for (uint32_t i = 0; i < n; ++i) {
+    const sa_observation& ob = obs[i];
+    W.oboxes[i] = ob.bbox;
+    sa_box& c = W.cboxes[i];
+    c = ob.bbox;
+    c.angle = ob.bbox.has_angle ? ob.bbox.angle : 0.0f;
+    c.has_angle = (ob.bbox.has_angle && ob.bbox.angle != 0.0f) ? 1 : 0;
+    c.reserved = 0;
+    W.chas_custom[i] = ob.has_custom_object_id != 0;
+    W.ccustom[i] = ob.custom_object_id;
+    if (o.visual) {
+      const bool has_own = ob.own_area == ob.own_area || !shares.empty();
+      const float own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
+      const bool has_feat = ob.feature != nullptr;
+      W.cq[i] = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
+      W.cown[i] = has_own ? own : NAN;
+      W.cpres[i] = has_feat ? 1 : 0;
+      W.cfeat[i] = ob.feature;
+      all_present = all_present && has_feat;
+      if (has_feat) {
+        if (!block) block = ob.feature - (size_t)i * D;
+        one_block = one_block && ob.feature == block + (size_t)i * D;
+      }
+    }
+  }
+  sa_detections& d = W.det;
+  std::memset(&d, 0, sizeof d);
+  d.n = n;
+  d.boxes = W.cboxes.data();
+  W.contiguous = 0;
+  if (o.visual) {
+    d.feat_present = W.cpres.data();
+    d.feat_quality = W.cq.data();
+    d.own_area = W.cown.data();
+    // The observations' features as ONE block (a producer that writes its N x D output contiguously â€” a ReID head's output buffer,
+    // host or device): handed over as such â€” read in place when the block is pinned (sa_host_alloc) or registered device memory
+    // (sa_device_block_register), one memcpy otherwise â€” instead of one gather per row.  Rows of detections without a feature are
+    // never dereferenced by the host (flagged absent).  Only when every row lies inside a block the engine knows: rows of
+    // absent detections may otherwise be unmapped memory.
+    if (one_block && block && all_present) {
+      W.contiguous = 1;
+      d.feats = block;
+    }
+  }
+  return SA_OK;
+}
+
+// A candidate that starts a track (simple_api.rs:167-187).  Under device upkeep the filter state is born on the GPU and the feature
+// vectors live in the device bank only.
+Track* start_track(const sa_tracker_options& o, const sa_tracker::SceneScratch& W, uint32_t i, uint64_t id, uint64_t scene, const float* feature) {
+  Track* trp = new Track();
+  Track& tr = *trp;
+  tr.id = id; tr.scene = scene; tr.epoch = W.epoch;
+  tr.has_custom = W.chas_custom[i] != 0; tr.custom = W.ccustom[i];
+  tr.has_state = true;
+  if (!o.device_upkeep) { bool hs = false; make_prediction(o.kalman_position_weight, o.kalman_velocity_weight, hs, tr.kf, W.oboxes[i]); }
+  tr.length = 0;
+  update_history(o, tr, W.oboxes[i], W.cboxes[i]);
+  if (o.visual) {
+    const bool has_feat = W.cpres[i] != 0, has_own = W.cown[i] == W.cown[i];
+    tr.obs.reserve(o.visual_max_observations + 1);
+    tr.obs.emplace_back();                         // is_merge = false: the feature is kept as is
+    Obs& nb = tr.obs.back();
+    nb.quality = W.cq[i]; nb.has_own = has_own; nb.own = has_own ? W.cown[i] : 0.0f; nb.has_feat = has_feat;
+    if (!o.device_upkeep && has_feat) nb.feat.assign(feature, feature + o.feature_len);
+    tr.feat_count = has_feat ? 1 : 0;
+  }
+  return trp;
+}
+
+// the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
+Track* winner_row(SceneState& S, size_t rows_before, int32_t col, uint64_t dest, uint64_t epoch) {
+  if (col >= 0 && (size_t)col < rows_before && S.rows[col]->id == dest) { S.row_epoch[col] = epoch; return S.rows[col]; }
+  for (size_t r = 0; r < rows_before; ++r)
+    if (S.rows[r]->id == dest) { S.row_epoch[r] = epoch; return S.rows[r]; }
+  return nullptr;
+}
+
+// eviction (see SceneState::row_epoch): tracks of the set's scenes that no frame from now on can match leave the engine's table.  Removals
+// on different scenes are queued one behind the other, no drain in between.
+int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint32_t n_scenes) {
+  const sa_tracker_options& o = t->o;
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    SceneState& S = *ss[s].st;
+    const uint64_t cur = ss[s].epoch;
+    size_t expired = 0;
+    for (uint64_t ep : S.row_epoch) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
+    // (a removal is one gather launch; a row left in the table costs the frames until auto_waste ~1/64 us each: it pays from about 64 rows on)
+    if (expired < 64 || expired * 16 < S.rows.size()) continue;
+    std::vector<uint64_t> out_ids;
+    out_ids.reserve(expired);
+    for (size_t r = 0; r < S.rows.size(); ++r)
+      if (S.row_epoch[r] + o.max_idle_epochs < cur) out_ids.push_back(S.rows[r]->id);
+    int rce = sa_tracks_remove(t->eng, S.id, (uint32_t)out_ids.size(), out_ids.data());
+    if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
+    size_t w = 0;   // (the engine's table no longer holds them: now the facade's side)
+    for (size_t r = 0; r < S.rows.size(); ++r) {
+      if (S.row_epoch[r] + o.max_idle_epochs < cur) { S.rows[r]->in_engine = false; S.evicted.push_back(S.rows[r]); }
+      else { S.rows[w] = S.rows[r]; S.row_epoch[w] = S.row_epoch[r]; ++w; }
+    }
+    S.rows.resize(w);
+    S.row_epoch.resize(w);
+  }
+  return SA_OK;
+}
+
+// ---- the part of a predict() BEHIND its launches (device upkeep queued behind the association) -----------------------------
+// 1. the previous set's deferred bookkeeping, while this set's association is on the device
+// 2. per scene, side by side: the winners (one wait for the association's completion event), ids, the tracks that start, the light half
+//    of the merges
+// 3. one wait for the set's Kalman dispatch, then per scene: the host side of the engine's table, the predicted boxes, the caller's tracks
+// A scene whose tracks are final is handed to the result handle at once (PredictionBatchResult::get, trackers/batch.rs:29-33).
+int complete_flight(sa_tracker* t) {
+  const sa_tracker_options& o = t->o;
+  sa_tracker::Flight& F = t->flight;
+  std::vector<sa_tracker::SceneScratch>& ss = t->scratch[F.set];
+  const uint32_t n_scenes = F.n_scenes;
+  static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
+  const auto t0 = clk::now();
+  flush_pending(t);
+  const auto t1 = clk::now();
+  run_jobs(t, n_scenes, [&](uint32_t s) {
+    sa_tracker::SceneScratch& W = ss[s];
+    SceneState& S = *W.st;
+    const uint32_t n = W.n;
+    W.n_new = 0;
+    const uint64_t* win = nullptr;
+    const uint8_t* votes = nullptr;
+    const int32_t* wcols = nullptr;
+    int rc = sa_batch_results(t->eng, W.slot, &win, &votes, &wcols);
+    if (rc != SA_OK) { W.rc = rc; W.err = std::string("association: ") + sa_last_error(t->eng); return; }
+    W.trps.resize(n);
+    W.merged.resize(n);
+    const size_t rows_before = S.rows.size();  // the table the engine voted against: columns refer to these rows
+    uint64_t drawn = W.id_base;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint64_t dest = win[i];
+      Track* trp;
+      if (dest == 0) {
+        // Batch*: an id per candidate (batch_api.rs:102-106); Sort / VisualSort: a counter over the tracks that start (simple_api.rs:165-187)
+        const uint64_t id = o.batch_ids ? W.id_base + 1 + i : ++drawn;
+        trp = start_track(o, W, i, id, S.id, nullptr);
+        S.rows.push_back(trp);
+        S.row_epoch.push_back(W.epoch);
+        W.merged[i] = 0;
+        ++W.n_new;
+      } else {
+        trp = winner_row(S, rows_before, wcols[i], dest, W.epoch);
+        if (!trp) { W.rc = SA_ERR_STATE; W.err = "engine returned an unknown track id"; return; }
+        Track& tr = *trp;
+        // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215 (the rest of the merge â€” history, observation policy â€” is
+        // deferred: merge_heavy / flush_pending)
+        tr.epoch = W.epoch;
+        tr.has_custom = W.chas_custom[i] != 0; tr.custom = W.ccustom[i];
+        if (o.visual) tr.voting = votes[i];
+        tr.length += 1;
+        W.merged[i] = 1;
+      }
+      W.trps[i] = trp;
+    }
+  });
+  const auto t2 = clk::now();
+  int rc = SA_OK;
+  std::string first_err;
+  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
+    if (ss[s].rc != SA_OK) { rc = ss[s].rc; first_err = ss[s].err; }
+  if (rc == SA_OK) {
+    rc = sa_tracks_apply_collect_begin(t->eng);
+    if (rc != SA_OK) first_err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng);
+  }
+  const auto t3 = clk::now();
+  if (rc == SA_OK) {
+    run_jobs(t, n_scenes, [&](uint32_t s) {
+      sa_tracker::SceneScratch& W = ss[s];
+      const uint32_t n = W.n;
+      W.dev_pred.resize(n);
+      int rcs = sa_tracks_apply_collect_slot(t->eng, W.slot, nullptr, W.dev_pred.data());
+      if (rcs != SA_OK) { W.rc = rcs; W.err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng); return; }
+      sa_sort_track* out = F.out[s];
+      for (uint32_t i = 0; i < n; ++i)
+        out[i] = W.merged[i] ? to_sort_track_with(o, *W.trps[i], W.cboxes[i], W.dev_pred[i]) : to_sort_track(o, *W.trps[i]);
+      if (F.res) {   // the scene's tracks are final: hand them over
+        std::lock_guard<std::mutex> lk(F.res->mu);
+        F.res->ready_q.push_back(s);
+        F.res->cv.notify_all();
+      }
+    });
+    for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
+      if (ss[s].rc != SA_OK) { rc = ss[s].rc; first_err = ss[s].err; }
+  }
+  if (rc == SA_OK) {
+    rc = sa_tracks_apply_collect_end(t->eng);
+    if (rc != SA_OK) first_err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng);
+  }
+  uint64_t started = 0;
+  for (uint32_t s = 0; s < n_scenes; ++s) started += ss[s].n_new;
+  t->n_active += started;
+  if (!o.batch_ids) t->track_id += started;
+  if (rc == SA_OK) {
+    t->pending = true;
+    t->pending_set = F.set;
+    t->pending_scenes = n_scenes;
+  } else t->err = first_err;
+  if (trace)
+    fprintf(stderr, "[sa_tracker] behind the launches: deferred %.1f  winners + merges %.1f  wait for the Kalman dispatch %.1f  tables + results %.1f us\n",
+            us_between(t0, t1), us_between(t1, t2), us_between(t2, t3), us_between(t3, clk::now()));
+  if (F.res) {
+    std::lock_guard<std::mutex> lk(F.res->mu);
+    F.res->rc = rc;
+    F.res->err = first_err;
+    F.res->finished = true;
+    F.res->cv.notify_all();
+  }
+  return rc;
+}
+
+void driver_loop(sa_tracker* t) {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(t->dmu);
+      t->dcv.wait(lk, [&] { return t->d_work || t->d_stop; });
+      if (t->d_stop) return;
+      t->d_work = false;
+    }
+    complete_flight(t);
+    {
+      std::lock_guard<std::mutex> lk(t->dmu);
+      t->flight.res.reset();
+      t->d_busy.store(false, std::memory_order_release);
+    }
+    t->dcv.notify_all();
   }
 }
 
-int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
-                   const sa_observation* const* obs, sa_sort_track* const* out) {
+// ---- predict, the fused path: device upkeep with ids the device can draw itself ---------------------------------------------
+// Up to the launches on the calling thread; what follows (complete_flight) on the calling thread too (res == nullptr: the caller's arrays
+// are filled when this returns) or on the tracker's driver thread (sa_tracker_predict_batch_begin: the handle delivers scene by scene).
+int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                  sa_sort_track* const* out, const std::shared_ptr<ResultState>& res) {
   const sa_tracker_options& o = t->o;
-  const float pw = o.kalman_position_weight, vw = o.kalman_velocity_weight;
-  const uint32_t D = o.feature_len;
-  for (uint32_t s = 0; s < n_scenes; ++s)
-    for (uint32_t s2 = 0; s2 < s; ++s2)
-      if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
-  // SA_TRACKER_TRACE=1: where a predict() spends its time, in microseconds on stderr
   static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
-  using clk = std::chrono::steady_clock;
   const auto t_entry = clk::now();
-  // auto waste (simple_api.rs:115-120)
-  if (t->waste_counter == 0) {
-    flush_pending(t);   // (wasted tracks are read out with their histories)
-    int rc = auto_waste(t);
-    if (rc != SA_OK) return rc;
-    t->waste_counter = o.auto_waste_periodicity;
-  } else t->waste_counter -= 1;
-
-  // (the other scratch set may hold the previous frame's deferred bookkeeping: it is run below, while this frame's association is on the device)
+  // (the other scratch set may hold the previous frame's deferred bookkeeping: it is run behind the launches, while this frame's association is on the device)
   const int set = t->pending ? (t->pending_set ^ 1) : t->cur_set;
   t->cur_set = set;
   if (t->scratch[set].size() < n_scenes) t->scratch[set].resize(n_scenes);
-  t->sc_epoch.resize(n_scenes);
-  t->sc_req.resize(n_scenes);
   std::vector<sa_tracker::SceneScratch>& ss = t->scratch[set];
-  std::vector<uint64_t>& epoch = t->sc_epoch;
-  std::vector<sa_scene_request>& req = t->sc_req;
+  // exclusively_owned_areas_normalized_shares over the frame's observed boxes, when either own-area gate is armed
+  // (visual_sort/simple_api.rs:111-127) â€” on the GPU (sa_own_areas).  A share the caller supplies takes precedence.
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    std::vector<float>& shares = ss[s].shares;
+    shares.clear();
+    const uint32_t n = counts[s];
+    if (!(o.visual && n && o.visual_minimal_own_area_percentage_collect + o.visual_minimal_own_area_percentage_use > 0.0f)) continue;
+    bool any_missing = false;
+    for (uint32_t i = 0; i < n; ++i) any_missing = any_missing || obs[s][i].own_area != obs[s][i].own_area;
+    if (!any_missing) continue;
+    std::vector<sa_box> frame(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      frame[i] = obs[s][i].bbox;
+      if (!(frame[i].aspect > 0.0f) || !(frame[i].height > 0.0f) || !(frame[i].confidence >= 0.0f && frame[i].confidence <= 1.0f))
+        return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
+    }
+    shares.resize(n);
+    int rc = sa_own_areas(t->eng, n, frame.data(), shares.data());
+    if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
+  }
+  run_jobs(t, n_scenes, [&](uint32_t s) { assemble_scene(o, ss[s], scene_ids[s], counts[s], obs[s]); });
+  for (uint32_t s = 0; s < n_scenes; ++s)
+    if (ss[s].rc != SA_OK) return tfail(t, ss[s].rc, "%s", ss[s].err.c_str());
+  uint64_t next = t->track_id;
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    SceneState& S = scene_of(t, scene_ids[s]);
+    ss[s].st = &S;
+    ss[s].epoch = ++S.epoch;   // next_epoch  epoch_db.rs:35-49
+    ss[s].id_base = next;      // (batch ids: one per candidate; a single scene: its own counter)
+    next += counts[s];
+  }
+  if (o.batch_ids) t->track_id = next;
+  int rc = evict_expired(t, ss, n_scenes);
+  if (rc != SA_OK) return rc;
+  const auto t_built = clk::now();
+  // ---- the hot path: foreign_track_distances + voting.winners, on the GPU, with the upkeep of every scene queued right BEHIND the
+  // association (sa_batch_run_apply) â€” the ids of the tracks that start are a function of the winners alone (a counter, in candidate
+  // order), so the device draws them itself
+  rc = sa_batch_begin(t->eng);
+  for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
+    rc = sa_batch_add_deferred(t->eng, scene_ids[s], ss[s].epoch, &ss[s].det, (o.visual && !ss[s].contiguous) ? ss[s].cfeat.data() : nullptr, &ss[s].slot);
+  if (rc == SA_OK) {
+    run_jobs(t, n_scenes, [&](uint32_t s) { ss[s].rc = sa_batch_fill(t->eng, ss[s].slot); });
+    for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) rc = ss[s].rc;
+  }
+  const auto t_staged = clk::now();
+  if (rc == SA_OK) {
+    std::vector<uint64_t> id_base(n_scenes);
+    for (uint32_t s = 0; s < n_scenes; ++s) id_base[s] = ss[s].id_base;
+    rc = sa_batch_run_apply(t->eng, id_base.data(), o.batch_ids ? 1 : 0);
+  }
+  if (rc != SA_OK) { flush_pending(t); return tfail(t, rc, "association: %s", sa_last_error(t->eng)); }
+  if (trace)
+    fprintf(stderr, "[sa_tracker] up to the launches: assemble %.1f  stage %.1f  enqueue %.1f us\n", us_between(t_entry, t_built),
+            us_between(t_built, t_staged), us_between(t_staged, clk::now()));
+  sa_tracker::Flight& F = t->flight;
+  F.n_scenes = n_scenes;
+  F.set = set;
+  F.out.assign(out, out + n_scenes);
+  F.res = res;
+  if (!res) return complete_flight(t);
+  if (!t->driver.joinable()) t->driver = std::thread(driver_loop, t);
+  {
+    std::lock_guard<std::mutex> lk(t->dmu);
+    t->d_busy.store(true, std::memory_order_release);
+    t->d_work = true;
+  }
+  t->dcv.notify_all();
+  return SA_OK;
+}
+
+// ---- predict, the general path: host upkeep (sa_tracks_upsert of the refreshed rows), or device upkeep with Sort / VisualSort id rules
+// over several scenes (one id per NEW track across scenes makes a scene's first id depend on the previous scenes' winners: two phases)
+int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                    sa_sort_track* const* out) {
+  const sa_tracker_options& o = t->o;
+  const float pw = o.kalman_position_weight, vw = o.kalman_velocity_weight;
+  const uint32_t D = o.feature_len;
+  flush_pending(t);
+  const int set = t->cur_set;
+  if (t->scratch[set].size() < n_scenes) t->scratch[set].resize(n_scenes);
+  std::vector<sa_tracker::SceneScratch>& ss = t->scratch[set];
   for (uint32_t s = 0; s < n_scenes; ++s) {
     const uint32_t n = counts[s];
     sa_tracker::SceneScratch& W = ss[s];
-    epoch[s] = ++t->epochs[scene_ids[s]];  // next_epoch  epoch_db.rs:35-49
-    W.cboxes.resize(n);
-    if (o.visual) { W.cfeat.resize(n); W.cq.resize(n); W.cown.resize(n); W.cpres.resize(n); }
     for (uint32_t i = 0; i < n; ++i) {
       const sa_box& bb = obs[s][i].bbox;
       if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f))
         return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
     }
-    // exclusively_owned_areas_normalized_shares over the frame's observed boxes, when either own-area gate is armed
-    // (visual_sort/simple_api.rs:111-127) â€” on the GPU (sa_own_areas).  A share the caller supplies takes precedence.
-    std::vector<float>& shares = W.shares;
+    std::vector<float>& shares = W.shares;   // (see predict_fused)
     shares.clear();
     if (o.visual && n && o.visual_minimal_own_area_percentage_collect + o.visual_minimal_own_area_percentage_use > 0.0f) {
       bool any_missing = false;
@@ -358,262 +777,144 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
         if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
       }
     }
-    // The throw-away candidate track of a detection (simple_api.rs:125-145) is never materialised: its box goes into the request, the
-    // rest of it (custom id, feature pointer) is read from the caller's observation when a track takes it over.
-    // The candidate's own Kalman step (initiate -> predict -> update with the box it was initiated from, kalman_prediction.rs:13-32)
-    // is the identity on the box: zero velocity, zero innovation, so the new mean is the observation plus (+-0) * gain.  All that
-    // changes is TryFrom<KalmanState>: an angle of exactly 0.0 reads back as None (kalman.rs:82-86).  The 10 x 10 filter arithmetic
-    // (about 1 us per detection on the host) is therefore only run for the candidates that become tracks and need the state
-    // (below); the tests compare every box with the oracle, which does run the filter.
-    const float* block = nullptr;  // where row 0 of an N x D block would lie, if the features form one
-    bool one_block = o.visual && n > 0, all_present = true;
-    sa_box* cb = W.cboxes.data();
-    for (uint32_t i = 0; i < n; ++i) {
-      const sa_observation& ob = obs[s][i];
-      sa_box& c = cb[i];
-      c = ob.bbox;
-      c.angle = ob.bbox.has_angle ? ob.bbox.angle : 0.0f;
-      c.has_angle = (ob.bbox.has_angle && ob.bbox.angle != 0.0f) ? 1 : 0;
-      c.reserved = 0;
-      if (o.visual) {
-        const bool has_own = ob.own_area == ob.own_area || !shares.empty();
-        const float own = ob.own_area == ob.own_area ? ob.own_area : (shares.empty() ? 0.0f : shares[i]);
-        const bool has_feat = ob.feature != nullptr;
-        W.cq[i] = ob.feature_quality == ob.feature_quality ? ob.feature_quality : 1.0f;
-        W.cown[i] = has_own ? own : NAN;
-        W.cpres[i] = has_feat ? 1 : 0;
-        W.cfeat[i] = ob.feature;
-        all_present = all_present && has_feat;
-        if (has_feat) {
-          if (!block) block = ob.feature - (size_t)i * D;
-          one_block = one_block && ob.feature == block + (size_t)i * D;
-        }
-      }
-    }
-    W.winners.resize(n);
-    W.votes.resize(n);
-    W.wcols.resize(n);
-    sa_scene_request& r = req[s];
-    std::memset(&r, 0, sizeof r);
-    r.scene_id = scene_ids[s];
-    r.epoch = epoch[s];
-    r.detections.n = n;
-    r.detections.boxes = W.cboxes.data();
-    W.contiguous = 0;
-    if (o.visual) {
-      r.detections.feat_present = W.cpres.data();
-      r.detections.feat_quality = W.cq.data();
-      r.detections.own_area = W.cown.data();
-      // The observations' features as ONE block (a producer that writes its N x D output contiguously â€” a ReID head's output buffer,
-      // host or device): handed over as such â€” read in place when the block is pinned (sa_host_alloc) or registered device memory
-      // (sa_device_block_register), one memcpy otherwise â€” instead of one gather per row.  Rows of detections without a feature are
-      // never dereferenced by the host (flagged absent).  Only when every row lies inside a block the engine knows: rows of
-      // absent detections may otherwise be unmapped memory.
-      if (one_block && block && all_present) {
-        W.contiguous = 1;
-        r.detections.feats = block;
-      }
-    }
+    int rc = assemble_scene(o, W, scene_ids[s], n, obs[s]);
+    if (rc != SA_OK) return tfail(t, rc, "%s", W.err.c_str());
   }
-  // eviction (see sa_tracker::row_epoch): tracks of these scenes that no frame from now on can match leave the engine's table
   for (uint32_t s = 0; s < n_scenes; ++s) {
-    auto& rows = t->by_scene[scene_ids[s]];
-    auto& eps = t->row_epoch[scene_ids[s]];
-    const uint64_t cur = epoch[s];
-    size_t expired = 0;
-    for (uint64_t ep : eps) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
-    // (a removal is a drain + one gather launch, ~20 us; a row left in the table costs the frames until auto_waste ~1/64 us each: it pays
-    // from about 64 rows on â€” with 16 a batch tracker of 8 x 500 objects spent 78 us per predict() removing a few rows from four scenes)
-    if (expired < 64 || expired * 16 < rows.size()) continue;
-    std::vector<uint64_t> out_ids;
-    out_ids.reserve(expired);
-    auto& ev = t->evicted[scene_ids[s]];
-    size_t w = 0;
-    for (size_t r = 0; r < rows.size(); ++r) {
-      if (eps[r] + o.max_idle_epochs < cur) { out_ids.push_back(rows[r]->id); rows[r]->in_engine = false; ev.push_back(rows[r]); }
-      else { rows[w] = rows[r]; eps[w] = eps[r]; ++w; }
-    }
-    rows.resize(w);
-    eps.resize(w);
-    int rce = sa_tracks_remove(t->eng, scene_ids[s], (uint32_t)out_ids.size(), out_ids.data());
-    if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
+    SceneState& S = scene_of(t, scene_ids[s]);
+    ss[s].st = &S;
+    ss[s].epoch = ++S.epoch;
   }
-  const auto t_built = clk::now();
-  double us_apply = 0.0, us_new = 0.0;
-  uint32_t n_new_tracks = 0;
-  // ---- the hot path: foreign_track_distances + voting.winners, on the GPU ----
-  int rc = sa_batch_begin(t->eng);
-  const auto t_begun = clk::now();
+  int rc = evict_expired(t, ss, n_scenes);
+  if (rc != SA_OK) return rc;
+  rc = sa_batch_begin(t->eng);
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
-    rc = ss[s].contiguous ? sa_batch_add(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, nullptr)
-                          : sa_batch_add_rows(t->eng, req[s].scene_id, req[s].epoch, &req[s].detections, o.visual ? ss[s].cfeat.data() : nullptr, nullptr);
-  const auto t_added = clk::now();
-  // Device upkeep: the Kalman step, the table refresh and the feature-bank policy of every scene are queued right BEHIND the association
-  // on the device (sa_batch_run_apply) â€” the ids of the tracks that start are a function of the winners alone (a counter, in candidate
-  // order), so the device draws them itself and this thread waits once, for everything.  (Several scenes under Sort / VisualSort id
-  // rules â€” one id per NEW track across scenes â€” would make a scene's first id depend on the previous scenes' winners: two phases then.)
-  const bool fused = o.device_upkeep && (o.batch_ids || n_scenes == 1);
-  if (rc == SA_OK && fused) {
-    std::vector<uint64_t>& id_base = t->sc_id_base;
-    id_base.resize(n_scenes);
-    uint64_t next = t->track_id;
-    for (uint32_t s = 0; s < n_scenes; ++s) { id_base[s] = next; next += counts[s]; }   // (batch ids: one per candidate; a single scene: its own counter)
-    rc = sa_batch_run_apply(t->eng, id_base.data(), o.batch_ids ? 1 : 0);
-  } else
+    rc = ss[s].contiguous ? sa_batch_add(t->eng, scene_ids[s], ss[s].epoch, &ss[s].det, &ss[s].slot)
+                          : sa_batch_add_rows(t->eng, scene_ids[s], ss[s].epoch, &ss[s].det, o.visual ? ss[s].cfeat.data() : nullptr, &ss[s].slot);
   if (rc == SA_OK) rc = sa_batch_run(t->eng);
-  const auto t_run = clk::now();
-  flush_pending(t);   // the previous frame's deferred bookkeeping: while this frame's kernels run (or, on an error path, before the return)
-  if (rc == SA_OK && !fused) rc = sa_batch_sync(t->eng);  // (fused: sa_batch_fetch waits for the END OF THE ASSOCIATION only â€” the upkeep kernels
-                                                          // queued behind it run while this thread does its bookkeeping below)
+  if (rc == SA_OK) rc = sa_batch_sync(t->eng);
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) {
-    rc = sa_batch_fetch(t->eng, s, ss[s].winners.data(), ss[s].votes.data());
-    if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, s, ss[s].wcols.data());
+    sa_tracker::SceneScratch& W = ss[s];
+    W.winners.resize(W.n); W.votes.resize(W.n); W.wcols.resize(W.n);
+    rc = sa_batch_fetch(t->eng, W.slot, W.winners.data(), W.votes.data());
+    if (rc == SA_OK) rc = sa_batch_fetch_cols(t->eng, W.slot, W.wcols.data());
   }
   if (rc != SA_OK) return tfail(t, rc, "association: %s", sa_last_error(t->eng));
-  const auto t_assoc = clk::now();
 
   // ids first, scene by scene in the order the reference draws them; with device upkeep the Kalman step, table refresh and
   // feature-bank policy of every scene are QUEUED right away (sa_tracks_apply_begin) â€” they run while this thread does the
   // per-track bookkeeping that does not need their result; the predicted boxes are collected afterwards (sa_tracks_apply_end)
-  std::vector<uint64_t>& touched = t->sc_touched;
   for (uint32_t s = 0; s < n_scenes; ++s) {
-    const uint32_t n = counts[s];
     sa_tracker::SceneScratch& W = ss[s];
+    const uint32_t n = W.n;
     W.tids.resize(n);
     W.new_ids.resize(n);
-    const uint64_t* win = W.winners.data();
     for (uint32_t i = 0; i < n; ++i) {
-      const uint64_t dest = win[i];
+      const uint64_t dest = W.winners[i];
       uint64_t drawn = 0;
       if (o.batch_ids) drawn = ++t->track_id;          // Batch*: an id per candidate (batch_api.rs:102-106)
       if (dest == 0) { W.tids[i] = o.batch_ids ? drawn : ++t->track_id; W.new_ids[i] = W.tids[i]; }
       else { W.tids[i] = dest; W.new_ids[i] = 0; }
     }
-    if (o.device_upkeep && !fused) {
-      const auto ta = clk::now();
-      rc = sa_tracks_apply_begin(t->eng, s, W.new_ids.data());
+    if (o.device_upkeep) {
+      rc = sa_tracks_apply_begin(t->eng, W.slot, W.new_ids.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
-      us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
     }
   }
+  std::vector<Track*> touched;
   for (uint32_t s = 0; s < n_scenes; ++s) {
-    const uint64_t scene = scene_ids[s];
-    const uint32_t n = counts[s];
     sa_tracker::SceneScratch& W = ss[s];
+    SceneState& S = *W.st;
+    const uint32_t n = W.n;
     touched.clear();
     W.trps.resize(n);
-    std::vector<Track*>& rows = t->by_scene[scene];
-    std::vector<uint64_t>& eps = t->row_epoch[scene];
-    const size_t rows_before = rows.size();  // the table the engine voted against: columns refer to these rows
+    W.merged.assign(n, 0);
+    const size_t rows_before = S.rows.size();  // the table the engine voted against: columns refer to these rows
     for (uint32_t i = 0; i < n; ++i) {
-      const sa_observation& ob = obs[s][i];
       const sa_box& cbox = W.cboxes[i];
       const uint64_t dest = W.winners[i];
-      const bool c_has_feat = o.visual && W.cpres[i] != 0;
-      const float c_quality = o.visual ? W.cq[i] : 1.0f;
-      const bool c_has_own = o.visual && W.cown[i] == W.cown[i];
-      const float c_own = c_has_own ? W.cown[i] : 0.0f;
       Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        const auto tn0 = trace ? clk::now() : clk::time_point();
-        ++n_new_tracks;
-        Track& tr = t->store[W.tids[i]];
-        trp = &tr;
-        tr.id = W.tids[i]; tr.scene = scene; tr.epoch = epoch[s];
-        tr.has_custom = ob.has_custom_object_id != 0; tr.custom = ob.custom_object_id;
-        tr.has_state = true;
-        if (!o.device_upkeep) { bool hs = false; make_prediction(pw, vw, hs, tr.kf, ob.bbox); }  // with device upkeep the state is born on the GPU
-        tr.length = 0;
-        update_history(o, tr, ob.bbox, cbox);
-        if (o.visual) {
-          tr.obs.reserve(o.visual_max_observations + 1);
-          tr.obs.emplace_back();                         // is_merge = false: the feature is kept as is
-          Obs& nb = tr.obs.back();
-          nb.quality = c_quality; nb.has_own = c_has_own; nb.own = c_own; nb.has_feat = c_has_feat;
-          if (!o.device_upkeep && c_has_feat) nb.feat.assign(ob.feature, ob.feature + D);  // device upkeep: the vectors live in the device bank only
-          tr.feat_count = c_has_feat ? 1 : 0;
-        }
-        rows.push_back(trp);
-        eps.push_back(epoch[s]);
-        if (trace) us_new += std::chrono::duration<double, std::micro>(clk::now() - tn0).count();
+        trp = start_track(o, W, i, W.tids[i], S.id, o.visual ? W.cfeat[i] : nullptr);
+        S.rows.push_back(trp);
+        S.row_epoch.push_back(W.epoch);
+        ++t->n_active;
       } else {
-        // the winner as a column of the table the engine voted against = a row of `rows` (checked; by id if the orders ever disagree)
-        const int32_t col = W.wcols[i];
-        if (col >= 0 && (size_t)col < rows_before && rows[col]->id == dest) { trp = rows[col]; eps[col] = epoch[s]; }
-        else {
-          auto it = t->store.find(dest);
-          if (it == t->store.end()) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
-          trp = &it->second;
-          for (size_t r = 0; r < rows.size(); ++r)
-            if (rows[r] == trp) { eps[r] = epoch[s]; break; }
-        }
+        trp = winner_row(S, rows_before, W.wcols[i], dest, W.epoch);
+        if (!trp) return tfail(t, SA_ERR_STATE, "engine returned unknown track id %llu", (unsigned long long)dest);
         Track& tr = *trp;
         // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215
-        tr.epoch = epoch[s];
-        tr.has_custom = ob.has_custom_object_id != 0; tr.custom = ob.custom_object_id;
+        tr.epoch = W.epoch;
+        tr.has_custom = W.chas_custom[i] != 0; tr.custom = W.ccustom[i];
         if (o.visual) tr.voting = W.votes[i];
         // optimize(is_merge = true): Kalman predict + update with the candidate's box, history (device upkeep: once the boxes are back)
         if (!o.device_upkeep) update_history(o, tr, cbox, make_prediction(pw, vw, tr.has_state, tr.kf, cbox));
-        if (fused) tr.length += 1;   // (the rest of the merge â€” history, observation policy â€” is deferred: merge_heavy / flush_pending)
-        else if (o.visual) {
+        if (o.visual) {
           Obs nw;
-          nw.quality = c_quality; nw.has_own = c_has_own; nw.own = c_own; nw.has_feat = c_has_feat;
+          nw.quality = W.cq[i];
+          nw.has_own = W.cown[i] == W.cown[i];
+          nw.own = nw.has_own ? W.cown[i] : 0.0f;
+          nw.has_feat = W.cpres[i] != 0;
           if (!feature_can_be_used(o, cbox, nw.quality, o.visual_minimal_quality_collect, nw.has_own, nw.own,
                                    o.visual_minimal_own_area_percentage_collect))
             nw.has_feat = false;
-          if (!o.device_upkeep && nw.has_feat) nw.feat.assign(ob.feature, ob.feature + D);
+          if (!o.device_upkeep && nw.has_feat) nw.feat.assign(W.cfeat[i], W.cfeat[i] + D);
           // (with device upkeep: the bookkeeping only â€” the same policy moves the feature rows inside the device bank, sa_upkeep.hip)
           optimize_observations(tr.obs, std::move(nw), o.visual_max_observations);
           tr.feat_count = 0;
           for (auto& so : tr.obs) tr.feat_count += so.has_feat ? 1u : 0u;
         }
+        W.merged[i] = 1;
       }
       W.trps[i] = trp;
       if (!o.device_upkeep) {
-        touched.push_back(W.tids[i]);
+        touched.push_back(trp);
         out[s][i] = to_sort_track(o, *trp);
       }
     }
     if (o.device_upkeep) continue;
-    rc = sync_engine(t, scene, touched);
+    rc = sync_engine(t, S.id, touched);
     if (rc != SA_OK) return rc;
   }
   if (o.device_upkeep)
     for (uint32_t s = 0; s < n_scenes; ++s) {
-      const uint32_t n = counts[s];
       sa_tracker::SceneScratch& W = ss[s];
+      const uint32_t n = W.n;
       W.dev_pred.resize(n);
-      const auto ta = clk::now();
-      rc = fused ? sa_tracks_apply_collect(t->eng, s, nullptr, W.dev_pred.data()) : sa_tracks_apply_end(t->eng, s, W.dev_pred.data());
+      rc = sa_tracks_apply_end(t->eng, W.slot, W.dev_pred.data());
       if (rc != SA_OK) return tfail(t, rc, "sa_tracks_apply: %s", sa_last_error(t->eng));
-      us_apply += std::chrono::duration<double, std::micro>(clk::now() - ta).count();
-      if (fused) {
-        for (uint32_t i = 0; i < n; ++i)
-          out[s][i] = W.winners[i] != 0 ? to_sort_track_with(o, *W.trps[i], W.cboxes[i], W.dev_pred[i]) : to_sort_track(o, *W.trps[i]);
-        continue;
-      }
       for (uint32_t i = 0; i < n; ++i) {
         Track& tr = *W.trps[i];
-        if (W.winners[i] != 0) update_history(o, tr, W.cboxes[i], W.dev_pred[i]);
+        if (W.merged[i]) update_history(o, tr, W.cboxes[i], W.dev_pred[i]);
         out[s][i] = to_sort_track(o, tr);
       }
     }
-  if (fused) {
-    t->pending = true;
-    t->pending_set = set;
-    t->pending_scenes = n_scenes;
-    t->pending_counts.assign(counts, counts + n_scenes);
-  }
-  if (trace) {
-    const auto t_end = clk::now();
-    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    fprintf(stderr, "[sa_tracker] assemble %.1f  associate %.1f (begin %.1f stage %.1f enqueue %.1f wait+fetch %.1f)  apply %.1f  bookkeeping %.1f us\n",
-            us(t_entry, t_built), us(t_built, t_assoc), us(t_built, t_begun), us(t_begun, t_added), us(t_added, t_run), us(t_run, t_assoc), us_apply,
-            us(t_assoc, t_end) - us_apply);
-    fprintf(stderr, "[sa_newtracks] %u tracks started in %.1f us (with the trace's own clock reads)\n", n_new_tracks, us_new);
-  }
   return SA_OK;
+}
+
+int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                   const sa_observation* const* obs, sa_sort_track* const* out, const std::shared_ptr<ResultState>& res = nullptr) {
+  const sa_tracker_options& o = t->o;
+  wait_outstanding(t);
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    if (counts[s] && (!obs[s] || !out[s])) return tfail(t, SA_ERR_BAD_ARG, "scene %llu: null observations / output", (unsigned long long)scene_ids[s]);
+    for (uint32_t s2 = 0; s2 < s; ++s2)
+      if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
+  }
+  // auto waste (simple_api.rs:115-120)
+  if (t->waste_counter == 0) {
+    flush_pending(t);   // (wasted tracks are read out with their histories)
+    int rc = auto_waste(t);
+    if (rc != SA_OK) return rc;
+    t->waste_counter = o.auto_waste_periodicity;
+  } else t->waste_counter -= 1;
+  if (!n_scenes) { flush_pending(t); return SA_OK; }
+  // Device upkeep queued right behind the association (sa_batch_run_apply) whenever the ids of the tracks that start are a function of one
+  // scene's winners alone: Batch* id rules (an id per candidate), or a single scene.
+  const bool fused = o.device_upkeep && (o.batch_ids || n_scenes == 1);
+  if (fused) return predict_fused(t, n_scenes, scene_ids, counts, obs, out, res);
+  return predict_general(t, n_scenes, scene_ids, counts, obs, out);
 }
 
 }  // namespace
@@ -657,6 +958,7 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
   if (o->history_length == 0) return tfail(nullptr, SA_ERR_BAD_ARG, "bbox_history must be > 0 (sort/simple_api.rs:51)");
   if (o->visual && (o->feature_len == 0 || o->visual_max_observations == 0))
     return tfail(nullptr, SA_ERR_BAD_ARG, "VisualSort needs feature_len and visual_max_observations");
+  if (o->workers < 0 || o->workers > 256) return tfail(nullptr, SA_ERR_BAD_ARG, "workers must lie in [0, 256] (0 = the facade's own choice)");
   sa_tracker* t = new sa_tracker();
   t->o = *o;
   t->cons_delta.assign(o->constraint_epoch_delta, o->constraint_epoch_delta + o->n_constraints);
@@ -699,7 +1001,21 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
 
 void sa_tracker_destroy(sa_tracker* t) {
   if (!t) return;
+  wait_outstanding(t);
+  if (t->driver.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(t->dmu);
+      t->d_stop = true;
+    }
+    t->dcv.notify_all();
+    t->driver.join();
+  }
+  t->pool.reset();
   if (t->eng) sa_engine_destroy(t->eng);
+  for (auto& kv : t->scenes) {
+    for (Track* tr : kv.second.rows) delete tr;
+    for (Track* tr : kv.second.evicted) delete tr;
+  }
   delete t;
 }
 
@@ -716,41 +1032,98 @@ int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* s
   return predict_scenes(t, n_scenes, scene_ids, counts, obs, out);
 }
 
+// Batch*::predict(PredictionBatchRequest) -> PredictionBatchResult  (sort/batch_api.rs:222-290, trackers/batch.rs:19-38)
+int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
+                                   const sa_observation* const* obs, sa_batch_result** out_result) {
+  if (!t || !out_result || (n_scenes && (!scene_ids || !counts || !obs))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict_batch_begin: null argument");
+  *out_result = nullptr;
+  wait_outstanding(t);
+  auto st = std::make_shared<ResultState>();
+  st->scene_ids.assign(scene_ids, scene_ids + n_scenes);
+  st->tracks.resize(n_scenes);
+  std::vector<sa_sort_track*> outs(n_scenes);
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    st->tracks[s].resize(counts[s]);
+    outs[s] = st->tracks[s].data();
+  }
+  const bool fused = t->o.device_upkeep && (t->o.batch_ids || n_scenes == 1) && n_scenes;
+  int rc = predict_scenes(t, n_scenes, scene_ids, counts, obs, outs.data(), fused ? st : nullptr);
+  if (rc != SA_OK) return rc;
+  if (!fused) {   // everything happened inside the call: every scene is ready
+    std::lock_guard<std::mutex> lk(st->mu);
+    for (uint32_t s = 0; s < n_scenes; ++s) st->ready_q.push_back(s);
+    st->finished = true;
+  }
+  sa_batch_result* r = new sa_batch_result();
+  r->st = st;
+  *out_result = r;
+  return SA_OK;
+}
+
+uint32_t sa_batch_result_size(const sa_batch_result* r) { return r ? (uint32_t)r->st->scene_ids.size() : 0; }
+
+int sa_batch_result_ready(sa_batch_result* r) {
+  if (!r) return 0;
+  std::lock_guard<std::mutex> lk(r->st->mu);
+  return (!r->st->ready_q.empty() || (r->st->finished && r->st->rc != SA_OK)) ? 1 : 0;
+}
+
+int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
+  if (!r || !out_n) return SA_ERR_BAD_ARG;
+  ResultState& st = *r->st;
+  std::unique_lock<std::mutex> lk(st.mu);
+  if (st.taken >= st.scene_ids.size()) return SA_ERR_STATE;   // every scene has been taken (the reference's recv() would block for ever)
+  st.cv.wait(lk, [&] { return !st.ready_q.empty() || st.finished; });
+  if (st.ready_q.empty()) { g_err = st.err; return st.rc != SA_OK ? st.rc : SA_ERR_STATE; }
+  const uint32_t s = st.ready_q.front();
+  const uint32_t n = (uint32_t)st.tracks[s].size();
+  if (out_scene_id) *out_scene_id = st.scene_ids[s];
+  *out_n = n;
+  if (n && (!out || cap < n)) return SA_ERR_BAD_ARG;   // (nothing taken: call again with room for *out_n tracks)
+  if (n) std::memcpy(out, st.tracks[s].data(), (size_t)n * sizeof(sa_sort_track));
+  st.ready_q.pop_front();
+  ++st.taken;
+  return SA_OK;
+}
+
+void sa_batch_result_free(sa_batch_result* r) { delete r; }
+
 int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_idle_tracks: null argument");
+  wait_outstanding(t);
   flush_pending(t);
   // IdleLookup  sort.rs:213-228: same scene and last_updated_epoch != current epoch
   uint32_t n = 0;
-  for (const auto* m : {&t->by_scene, &t->evicted}) {   // (evicted tracks are idle tracks like any other until they are wasted)
-    auto it = m->find(scene_id);
-    if (it == m->end()) continue;
-    for (const Track* trp : it->second) {
-      const Track& tr = *trp;
-      if (tr.epoch != current_epoch(t, scene_id)) {
-        if (out && n < cap) out[n] = to_sort_track(t->o, tr);
-        ++n;
-      }
-    }
-  }
+  auto it = t->scenes.find(scene_id);
+  if (it != t->scenes.end())
+    for (const auto* list : {&it->second.rows, &it->second.evicted})   // (evicted tracks are idle tracks like any other until they are wasted)
+      for (const Track* trp : *list)
+        if (trp->epoch != it->second.epoch) {
+          if (out && n < cap) out[n] = to_sort_track(t->o, *trp);
+          ++n;
+        }
   *out_n = n;
   return SA_OK;
 }
 
 int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n) {
   if (!t) return SA_ERR_BAD_ARG;
+  wait_outstanding(t);
   flush_pending(t);
-  t->epochs[scene_id] += n;  // skip_epochs_for_scene  epoch_db.rs:11-20
-  return auto_waste(t);      // tracker_api.rs:48-51
+  scene_of(t, scene_id).epoch += n;  // skip_epochs_for_scene  epoch_db.rs:11-20
+  return auto_waste(t);              // tracker_api.rs:48-51
 }
 
 int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out) {
   if (!t || !out) return SA_ERR_BAD_ARG;
+  wait_outstanding(t);
   *out = current_epoch(t, scene_id);
   return SA_OK;
 }
 
 int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_wasted: null argument");
+  wait_outstanding(t);
   flush_pending(t);
   int rc = auto_waste(t);
   if (rc != SA_OK) return rc;
@@ -764,35 +1137,41 @@ int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t*
 
 int sa_tracker_clear_wasted(sa_tracker* t) {
   if (!t) return SA_ERR_BAD_ARG;
+  wait_outstanding(t);
   t->wasted_store.clear();
   return SA_OK;
 }
 
 int sa_tracker_active_tracks(sa_tracker* t, uint64_t* out_n) {
   if (!t || !out_n) return SA_ERR_BAD_ARG;
-  *out_n = t->store.size();
+  wait_outstanding(t);
+  *out_n = t->n_active;
   return SA_OK;
 }
 
 int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, float* cov100) {
   if (!t) return SA_ERR_BAD_ARG;
-  auto it = t->store.find(track_id);
-  if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  wait_outstanding(t);
+  Track* tr = find_track(t, track_id);
+  if (!tr) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
   if (t->o.device_upkeep) {  // the state lives on the device
-    int rc = sa_tracks_get_state(t->eng, it->second.scene, track_id, mean10, cov100, nullptr, nullptr, nullptr);
+    if (!tr->in_engine)
+      return tfail(t, SA_ERR_NOT_FOUND, "track %llu has been idle for more than max_idle_epochs: its row (and filter state) has left the device", (unsigned long long)track_id);
+    int rc = sa_tracks_get_state(t->eng, tr->scene, track_id, mean10, cov100, nullptr, nullptr, nullptr);
     return rc == SA_OK ? SA_OK : tfail(t, rc, "sa_tracks_get_state: %s", sa_last_error(t->eng));
   }
-  if (mean10) std::memcpy(mean10, it->second.kf.mean, sizeof it->second.kf.mean);
-  if (cov100) std::memcpy(cov100, it->second.kf.cov, sizeof it->second.kf.cov);
+  if (mean10) std::memcpy(mean10, tr->kf.mean, sizeof tr->kf.mean);
+  if (cov100) std::memcpy(cov100, tr->kf.cov, sizeof tr->kf.cov);
   return SA_OK;
 }
 
 int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]) {
   if (!t || !out4) return SA_ERR_BAD_ARG;
+  wait_outstanding(t);
   flush_pending(t);
-  auto it = t->store.find(track_id);
-  if (it == t->store.end()) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
-  const Track& tr = it->second;
+  const Track* trp = find_track(t, track_id);
+  if (!trp) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  const Track& tr = *trp;
   out4[0] = tr.feat_count;
   out4[1] = t->o.visual ? tr.obs.size() : 1;
   out4[2] = tr.boxes.size();

@@ -346,6 +346,43 @@ hipError_t sa_launch_apply(const ApplyArgs& a, const BankArgs* b, const SaParams
   return hipGetLastError();
 }
 
+// ---- the same two halves for a whole request set: blockIdx.y = scene, the scene's arguments read from the set's array (wave-uniform
+// address: scalar loads).  Scenes of different sizes share the grid; a block beyond its scene's count leaves at once.
+__global__ __launch_bounds__(256) void k_apply_kalman_set(const ApplyScene* __restrict__ scenes, SaParams p) {
+  __shared__ KfLds s_kf[4];
+  const ApplyArgs a = scenes[blockIdx.y].a;
+  const uint32_t kfb = (a.n + 3u) / 4u;
+  if (blockIdx.x < kfb) { kalman_block(a, p, blockIdx.x, s_kf); return; }
+  const uint32_t i = blockIdx.x - kfb;
+  if (!a.copy_src || i >= a.n) return;
+  const float4* src = (const float4*)(a.copy_src + (size_t)i * a.copy_row_floats);
+  float4* dst = (float4*)(a.copy_dst + (size_t)i * a.copy_row_floats);
+  for (uint32_t x = threadIdx.x; x < a.copy_row_floats / 4u; x += 256u) dst[x] = src[x];
+}
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_apply_bank_set(const ApplyScene* __restrict__ scenes) {
+  __shared__ BankLds s_bank;
+  const BankArgs b = scenes[blockIdx.y].b;
+  bank_block<KMAX>(b, blockIdx.x, s_bank);
+}
+hipError_t sa_launch_apply_set(const ApplyScene* scenes, uint32_t n_scenes, uint32_t max_blocks, uint32_t K, const SaParams& p, hipStream_t st,
+                               hipEvent_t done, int part) {
+  if (!n_scenes || !max_blocks) return hipSuccess;
+  const dim3 grid(max_blocks, n_scenes), block(256);
+#define SA_SET_LAUNCH(kern, ...)                                                                     \
+  do {                                                                                               \
+    if (done) hipExtLaunchKernelGGL(kern, grid, block, 0, st, nullptr, done, 0, __VA_ARGS__);        \
+    else hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                                  \
+  } while (0)
+  if (part == 2) {
+    if (K <= 4) SA_SET_LAUNCH(k_apply_bank_set<4>, scenes);
+    else if (K <= 8) SA_SET_LAUNCH(k_apply_bank_set<8>, scenes);
+    else SA_SET_LAUNCH(k_apply_bank_set<SA_MAX_BANK>, scenes);
+  } else SA_SET_LAUNCH(k_apply_kalman_set, scenes, p);
+#undef SA_SET_LAUNCH
+  return hipGetLastError();
+}
+
 // =====================================================================================================
 // Non-maximum suppression (src/utils/nms.rs:32-72) on the clip machinery of the positional tiles.
 // The host filters and rank-sorts the boxes (O(N log N), and it owns libm's cos/sin); the O(N^2) part runs here:

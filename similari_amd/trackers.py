@@ -248,6 +248,18 @@ class _Tracker:
         self._chk(self.lib.sa_tracker_predict_batch(self.h, len(scenes), ids, counts, pa, po))
         return {s: [SortTrack.from_c(outs[k][i]) for i in range(len(batch.scenes[s]))] for k, s in enumerate(scenes)}
 
+    def predict_batch_async(self, batch: "PredictionBatchRequest") -> "PredictionBatchResult":
+        """Batch*::predict as the reference shapes it: returns once the request set is on the device; the handle delivers scene by scene."""
+        scenes = list(batch.scenes.keys())
+        keep = []
+        arrs = [self._obs_array(batch.scenes[s], keep) for s in scenes]
+        ids = (C.c_uint64 * max(1, len(scenes)))(*scenes)
+        counts = (C.c_uint32 * max(1, len(scenes)))(*[len(batch.scenes[s]) for s in scenes])
+        pa = (C.POINTER(abi.sa_observation) * max(1, len(scenes)))(*[C.cast(a, C.POINTER(abi.sa_observation)) for a in arrs])
+        h = C.c_void_p()
+        self._chk(self.lib.sa_tracker_predict_batch_begin(self.h, len(scenes), ids, counts, pa, C.byref(h)))
+        return PredictionBatchResult(self, h, max([len(batch.scenes[s]) for s in scenes] + [1]), keep)
+
     def idle_tracks_with_scene(self, scene_id: int):
         n = C.c_uint32()
         self._chk(self.lib.sa_tracker_idle_tracks(self.h, scene_id, None, 0, C.byref(n)))
@@ -306,7 +318,7 @@ class _Tracker:
 
 
 def sort_options(bbox_history, max_idle_epochs, method, min_confidence, constraints, pw, vw, batch=False, device=-1,
-                 device_upkeep=False):
+                 device_upkeep=False, workers=0):
     keep = abi.Keep()
     o = abi.sa_tracker_options()
     o.struct_size = C.sizeof(abi.sa_tracker_options)
@@ -328,12 +340,13 @@ def sort_options(bbox_history, max_idle_epochs, method, min_confidence, constrai
     o.kalman_position_weight = pw
     o.kalman_velocity_weight = vw
     o.device_upkeep = 1 if device_upkeep else 0
+    o.workers = workers
     return o, keep
 
 
-def visual_options(opts: VisualSortOptions, feature_len: int, batch=False, device=-1, device_upkeep=False):
+def visual_options(opts: VisualSortOptions, feature_len: int, batch=False, device=-1, device_upkeep=False, workers=0):
     o, keep = sort_options(opts._kept_history_length, opts._max_idle_epochs, opts._positional_metric,
-                           opts._positional_min_confidence, opts._constraints, opts._pw, opts._vw, batch, device, device_upkeep)
+                           opts._positional_min_confidence, opts._constraints, opts._pw, opts._vw, batch, device, device_upkeep, workers)
     o.visual = 1
     o.visual_kind = opts._visual_metric.kind
     o.visual_threshold = opts._visual_metric.threshold
@@ -355,11 +368,11 @@ class Sort(_Tracker):
 
     def __init__(self, shards=1, bbox_history=1, max_idle_epochs=5, method=None, min_confidence=0.05,
                  spatio_temporal_constraints=None, kalman_position_weight=1.0 / 20.0, kalman_velocity_weight=1.0 / 160.0,
-                 device=-1, _batch=False, device_upkeep=False):
+                 device=-1, _batch=False, device_upkeep=False, workers=0):
         assert bbox_history > 0
         o, keep = sort_options(bbox_history, max_idle_epochs, method or PositionalMetricType.iou(0.3), min_confidence,
                                spatio_temporal_constraints, kalman_position_weight, kalman_velocity_weight, _batch, device,
-                               device_upkeep)
+                               device_upkeep, workers)
         super().__init__(o, keep)
 
 
@@ -367,9 +380,41 @@ class VisualSort(_Tracker):
     """VisualSort::new(shards, &VisualSortOptions); `feature_len` fixes the engine's feature dimension."""
 
     def __init__(self, shards=1, opts: Optional[VisualSortOptions] = None, feature_len: int = 0, device=-1, _batch=False,
-                 device_upkeep=False):
-        o, keep = visual_options(opts or VisualSortOptions(), feature_len, _batch, device, device_upkeep)
+                 device_upkeep=False, workers=0):
+        o, keep = visual_options(opts or VisualSortOptions(), feature_len, _batch, device, device_upkeep, workers)
         super().__init__(o, keep)
+
+
+class PredictionBatchResult:
+    """trackers/batch.rs:19-38: ready() / get() -> (scene_id, [SortTrack]) / batch_size()."""
+
+    def __init__(self, tracker, handle, cap, keep):
+        self._t, self._h, self._cap, self._keep = tracker, handle, cap, keep
+
+    def batch_size(self) -> int:
+        return self._t.lib.sa_batch_result_size(self._h)
+
+    def ready(self) -> bool:
+        return bool(self._t.lib.sa_batch_result_ready(self._h))
+
+    def get(self):
+        out = (abi.sa_sort_track * self._cap)()
+        sid, n = C.c_uint64(), C.c_uint32()
+        rc = self._t.lib.sa_batch_result_get(self._h, C.byref(sid), out, self._cap, C.byref(n))
+        if rc != abi.SA_OK:
+            raise TrackerError(f"sa_batch_result_get failed ({rc}): {self._t.lib.sa_tracker_last_error(None).decode()}")
+        return sid.value, [SortTrack.from_c(out[i]) for i in range(n.value)]
+
+    def close(self):
+        if self._h:
+            self._t.lib.sa_batch_result_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PredictionBatchRequest:
@@ -383,17 +428,20 @@ class PredictionBatchRequest:
 
 
 class BatchSort(Sort):
-    def __init__(self, distance_shards=1, voting_shards=1, **kw):
-        super().__init__(shards=distance_shards, _batch=True, **kw)
+    """BatchSort::new(distance_shards, voting_shards, ...): `voting_shards` = the threads that work on the scenes of a request set
+    (0 = the facade's choice); `distance_shards` is accepted for signature compatibility (the distances are the GPU's)."""
+
+    def __init__(self, distance_shards=1, voting_shards=0, **kw):
+        super().__init__(shards=distance_shards, _batch=True, workers=voting_shards, **kw)
 
     def predict(self, batch: PredictionBatchRequest):
         return self.predict_batch(batch)
 
 
 class BatchVisualSort(VisualSort):
-    def __init__(self, distance_shards=1, voting_shards=1, opts=None, feature_len=0, device=-1, device_upkeep=False):
+    def __init__(self, distance_shards=1, voting_shards=0, opts=None, feature_len=0, device=-1, device_upkeep=False):
         super().__init__(shards=distance_shards, opts=opts, feature_len=feature_len, device=device, _batch=True,
-                         device_upkeep=device_upkeep)
+                         device_upkeep=device_upkeep, workers=voting_shards)
 
     def predict(self, batch: PredictionBatchRequest):
         return self.predict_batch(batch)

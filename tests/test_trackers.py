@@ -623,3 +623,193 @@ def test_caller_may_overwrite_its_device_feature_block_once_predict_has_returned
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "devblock_overwrite_child.py")
     r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OVERWRITE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- Batch*::predict over several scenes: one set of launches, the scenes' host work side by side ----------------------------------
+def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25), frames=8, d=64, bank=3, async_handle=False):
+    """BatchVisualSort over several scenes of different sizes (visual_sort/batch_api.rs:213-317): every frame's tracks of every scene
+    against the oracle tracker; with async_handle the request goes through sa_tracker_predict_batch_begin and the scenes are taken from
+    the PredictionBatchResult handle in whatever order they finish."""
+    rng = np.random.default_rng(seed)
+    opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
+            .positional_metric(IoU(0.3)).visual_minimal_track_length(2).visual_minimal_area(500.0)
+            .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(bank).visual_min_votes(1))
+    g = make(backend, "visual", opts=opts, feature_len=d, batch=True)
+    o = make("oracle", "visual", opts=opts, feature_len=d, batch=True)
+    try:
+        ident = {s: synth.reid_identities(rng, n, d) for s, n in zip(scenes, sizes)}
+        world = {s: synth.dense_boxes(rng, n, (900.0, 700.0)) for s, n in zip(scenes, sizes)}
+        saw_visual = False
+        for f in range(frames):
+            req = TR.PredictionBatchRequest()
+            for s, n in zip(scenes, sizes):
+                if f == 3 and s == scenes[1]:
+                    continue                        # a scene sits a frame out: its epoch stays, its tracks idle
+                world[s] = synth.jitter_boxes(rng, world[s], 2.0)
+                keep = rng.permutation(n)[rng.uniform(size=n) > 0.1]
+                feats = synth.observe(rng, ident[s][keep], 0.01)
+                for k, (bx, ft) in enumerate(zip(boxes_to_u2d(world[s][keep]), feats)):
+                    q = float(rng.uniform(0.2, 1.0))
+                    req.add(s, TR.VisualSortObservation(None if k % 7 == 3 else ft, None if k % 5 == 0 else q, bx, k if k % 2 else None))
+            ro = o.predict_batch(req)
+            if async_handle:
+                h = g.predict_batch_async(req)
+                assert h.batch_size() == len(req.scenes)
+                rg = {}
+                for _ in range(h.batch_size()):
+                    sid, tracks = h.get()
+                    assert sid not in rg
+                    rg[sid] = tracks
+                with pytest.raises(TR.TrackerError):
+                    h.get()                         # every scene has been taken
+                h.close()
+            else:
+                rg = g.predict_batch(req)
+            assert sorted(rg) == sorted(ro)
+            for s in rg:
+                assert_tracks_equal(rg[s], ro[s])
+                saw_visual = saw_visual or any(x.voting_type == TR.VotingType.Visual for x in rg[s])
+                for x in rg[s][:5]:
+                    assert g.track_info(x.id) == o.track_info(x.id)
+            if f % 3 == 2:
+                for s in scenes:
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id),
+                                        sorted(o.idle_tracks_with_scene(s), key=lambda x: x.id))
+        assert saw_visual
+        assert g.active_tracks() == o.active_tracks()
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+@UPKEEP
+def test_batch_visual_sort_three_scenes_match_oracle(backend):
+    run_batch_visual_scenes(backend, seed=61)
+
+
+@pytest.mark.gpu
+def test_batch_visual_sort_single_observation_scenes_match_oracle():
+    """bank depth 1: the fused first phase votes itself, three scenes in one launch."""
+    run_batch_visual_scenes("gpu_dev", seed=63, bank=1, sizes=(70, 33, 90))
+
+
+@pytest.mark.gpu
+@UPKEEP
+def test_batch_result_handle_delivers_every_scene(backend):
+    """sa_tracker_predict_batch_begin -> PredictionBatchResult (trackers/batch.rs:19-38): batch_size(), get() once per scene in completion
+    order, the same tracks as the synchronous call's (both against the oracle tracker)."""
+    run_batch_visual_scenes(backend, seed=67, async_handle=True, frames=6)
+
+
+@pytest.mark.gpu
+def test_batch_result_handle_survives_the_next_call_and_reused_request_arrays():
+    """The request is taken by value: the caller's observation arrays are overwritten right after _begin returns, the next predict() is
+    issued before the handle has been read (it waits for the set in flight — the reference's busy monitor), and the handle still
+    delivers the first request's tracks."""
+    rng = np.random.default_rng(71)
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
+    g, o = make("gpu_dev", "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        scenes, n = (1, 2, 3, 5, 8), 50
+        world = {s: synth.dense_boxes(rng, n, (900.0, 700.0)) for s in scenes}
+        lib = g.lib
+        for f in range(5):
+            req = TR.PredictionBatchRequest()
+            for s in scenes:
+                world[s] = synth.jitter_boxes(rng, world[s], 2.0)
+                for k, bx in enumerate(boxes_to_u2d(world[s])):
+                    req.add(s, (bx, k if k % 3 == 0 else None))
+            ro = o.predict_batch(req)
+            keep = []
+            arrs = [g._obs_array(req.scenes[s], keep) for s in scenes]
+            ids = (C.c_uint64 * len(scenes))(*scenes)
+            counts = (C.c_uint32 * len(scenes))(*([n] * len(scenes)))
+            pa = (C.POINTER(abi.sa_observation) * len(scenes))(*[C.cast(a, C.POINTER(abi.sa_observation)) for a in arrs])
+            h = C.c_void_p()
+            assert lib.sa_tracker_predict_batch_begin(g.h, len(scenes), ids, counts, pa, C.byref(h)) == 0
+            for a in arrs:                                  # the caller's arrays are its own again
+                C.memset(a, 0xFF, C.sizeof(a))
+            assert g.current_epoch_with_scene(scenes[0]) == f + 1   # (any other entry point waits for the set in flight)
+            assert lib.sa_batch_result_size(h) == len(scenes)
+            got = {}
+            out = (abi.sa_sort_track * n)()
+            sid, cnt = C.c_uint64(), C.c_uint32()
+            small = (abi.sa_sort_track * 1)()
+            assert lib.sa_batch_result_get(h, C.byref(sid), small, 1, C.byref(cnt)) == abi.SA_ERR_BAD_ARG and cnt.value == n   # too small: nothing taken
+            for _ in scenes:
+                assert lib.sa_batch_result_ready(h) == 1    # (the set has finished: the call above waited for it)
+                assert lib.sa_batch_result_get(h, C.byref(sid), out, n, C.byref(cnt)) == 0
+                got[sid.value] = [TR.SortTrack.from_c(out[i]) for i in range(cnt.value)]
+            assert lib.sa_batch_result_ready(h) == 0
+            lib.sa_batch_result_free(h)
+            for s in scenes:
+                assert_tracks_equal(got[s], ro[s])
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+@UPKEEP
+def test_batch_request_without_scenes_is_a_no_op(backend):
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
+    g = make(backend, "sort", **kw)
+    try:
+        assert g.predict_batch(TR.PredictionBatchRequest()) == {}
+        req = TR.PredictionBatchRequest()
+        req.add(3, (TR.Universal2DBox(10.0, 10.0, None, 1.0, 5.0), None))
+        r = g.predict_batch(req)
+        assert len(r[3]) == 1 and r[3][0].length == 1
+        assert g.predict_batch(TR.PredictionBatchRequest()) == {}
+        h = g.predict_batch_async(TR.PredictionBatchRequest())
+        assert h.batch_size() == 0 and not h.ready()
+        h.close()
+        assert g.active_tracks() == 1
+    finally:
+        g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 4], ids=["one_thread", "four_threads"])
+def test_batch_sort_scenes_with_churn_and_eviction_match_oracle(workers):
+    """Five scenes of 220 objects, ~18 % of them replaced every frame: the facade evicts expired rows from SEVERAL scenes' tables inside one
+    predict() (the removals are queued one behind the other), with the scenes' bookkeeping spread over a pool of threads — every frame's
+    tracks of every scene against the oracle tracker."""
+    rng = np.random.default_rng(909)
+    scenes, n = (2, 3, 5, 7, 11), 220
+    o_, keep_ = TR.sort_options(3, 2, IoU(0.3), 0.05, None, 1.0 / 20.0, 1.0 / 160.0, batch=True, device_upkeep=True, workers=workers)
+    g = TR._Tracker(o_, keep_)
+    o = make("oracle", "sort", bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
+    try:
+        pool = n + 14 * 40
+        world = {s: synth.dense_boxes(rng, pool, (2600.0, 1800.0)) for s in scenes}
+        active = {s: np.arange(n) for s in scenes}
+        fresh = {s: n for s in scenes}
+        max_rows = 0
+        for f in range(14):
+            req = TR.PredictionBatchRequest()
+            for s in scenes:
+                world[s] = synth.jitter_boxes(rng, world[s], 1.5)
+                if f:
+                    gone = rng.choice(n, 40, replace=False)
+                    active[s][gone] = np.arange(fresh[s], fresh[s] + 40)
+                    fresh[s] += 40
+                for bx in boxes_to_u2d(world[s][active[s]]):
+                    req.add(s, (bx, None))
+            rg, ro = g.predict_batch(req), o.predict_batch(req)
+            for s in scenes:
+                assert_tracks_equal(rg[s], ro[s])
+                cnt = C.c_uint32()
+                g.lib.sa_tracks_count(g.lib.sa_tracker_engine(g.h), s, C.byref(cnt))
+                max_rows = max(max_rows, int(cnt.value))
+                assert cnt.value < n + 6 * 40
+            if f % 5 == 4:
+                for s in scenes:
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id), sorted(o.idle_tracks_with_scene(s), key=lambda x: x.id))
+        assert max_rows > n
+        assert g.active_tracks() == o.active_tracks()
+        assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+    finally:
+        g.close()
+        o.close()
