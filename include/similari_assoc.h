@@ -174,6 +174,9 @@ typedef struct sa_tracks {
 
 int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t);
 int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids);
+/* sa_tracks_remove on several scenes at once (a batch tracker taking expired tracks out of many of its scenes' tables in one predict()):
+ * ids[i] lists counts[i] tracks of scene scene_ids[i]; one gather launch per dozen scenes; either every table changes or none. */
+int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const uint64_t* const* ids);
 int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n);
 /* Column order of the scene's track table (= column order of every matrix tap below). */
 int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t cap, uint32_t* out_n);

@@ -4,28 +4,31 @@ cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 TAG=${1:-r05_a}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 (rocminfo | grep -E "Marketing Name|Compute Unit" | head -4; nproc) > $O/env.txt 2>&1
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo BUILD FAILED; tail -20 $O/build.log; }
-timeout 900 python -m pytest tests/test_trackers.py tests/test_gpu_pipeline.py -m gpu -q --timeout 300 -p no:cacheprovider --maxfail=15 -rf > $O/pytest_trk.log 2>&1
+timeout 900 python -m pytest tests/test_trackers.py tests/test_gpu_pipeline.py tests/test_gpu_cluster.py -m gpu -q --timeout 300 -p no:cacheprovider --maxfail=15 -rf > $O/pytest_trk.log 2>&1
 echo "trk exit $?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest_trk.log | cut -c1-300 | tail -20
 J=$O/batch_tracker.jsonl; : > $J
 run() { timeout 300 python scripts/bench_batch_tracker.py "$@" >> $J 2>> $O/batch_err.txt || echo "bench_batch_tracker $* failed"; }
 run sort 8 500 0 40 0 sync
 run sort 8 500 0 40 1 sync
 run sort 8 500 0 40 4 sync
-run sort 64 500 0 16 0 sync
-run sort 64 500 0 16 1 sync
-run sort 64 500 0 16 16 sync
-run sort 64 500 0 16 0 async
+run sort 8 500 0 40 8 async
+run sort 64 500 0 30 0 sync
+run sort 64 500 0 30 1 sync
+run sort 64 500 0 30 8 sync
+run sort 64 500 0 30 32 sync
+run sort 64 500 0 30 0 async
 run visual 8 1000 512 24 0 sync device
 run visual 8 1000 512 24 1 sync device
 run visual 8 1000 512 24 0 sync rows
 run visual 8 1000 512 24 0 async device
 cat $J
-SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py sort 64 500 0 12 0 sync 2>&1 | grep sa_tracker | tail -4
-SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py sort 8 500 0 12 0 sync 2>&1 | grep sa_tracker | tail -4
-SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py visual 8 1000 512 12 0 sync device 2>&1 | grep sa_tracker | tail -4
+SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py sort 64 500 0 24 0 sync 2> $O/trace_sort64.txt > /dev/null; grep sa_tracker $O/trace_sort64.txt | tail -16
+SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py sort 8 500 0 24 0 sync 2> $O/trace_sort8.txt > /dev/null; grep sa_tracker $O/trace_sort8.txt | tail -8
+SA_TRACKER_TRACE=1 timeout 120 python scripts/bench_batch_tracker.py visual 8 1000 512 12 0 sync device 2> $O/trace_visual8.txt > /dev/null; grep sa_tracker $O/trace_visual8.txt | tail -4
 scripts/batch_tracker_timeline.sh ${TAG}_s8 sort 8 500 0 40 0 sync > $O/timeline_sort8.txt 2>&1; cat $O/timeline_sort8.txt
-scripts/batch_tracker_timeline.sh ${TAG}_s64 sort 64 500 0 16 0 sync > $O/timeline_sort64.txt 2>&1; cat $O/timeline_sort64.txt
+scripts/batch_tracker_timeline.sh ${TAG}_s64 sort 64 500 0 24 0 sync > $O/timeline_sort64.txt 2>&1; cat $O/timeline_sort64.txt
 scripts/batch_tracker_timeline.sh ${TAG}_v8 visual 8 1000 512 24 0 sync device > $O/timeline_visual8.txt 2>&1; cat $O/timeline_visual8.txt
 SA_BENCH_TRACKER_ONLY="sort,rows,0.0" timeout 200 python scripts/bench_tracker.py 1000 512 30; SA_BENCH_TRACKER_ONLY="visual,device,0.0" timeout 200 python scripts/bench_tracker.py 1000 512 30
 SA_BENCH_TRACKER_ONLY="sort,rows,0.05" timeout 200 python scripts/bench_tracker.py 1000 512 30; SA_BENCH_TRACKER_ONLY="visual,device,0.05" timeout 200 python scripts/bench_tracker.py 1000 512 30
 echo DONE
+g++ -O2 -std=c++17 -pthread scripts/micro/pool_bench.cpp -o /tmp/pool_bench && /tmp/pool_bench

@@ -248,6 +248,13 @@ struct SaGatherTable {
   const uint32_t* index;   // [rows] device-visible (mapped pinned memory)
 };
 hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st, hipEvent_t done = nullptr);
+// ... of several scenes in one launch (blockIdx.y = scene; the arguments travel by value: 12 x 256 bytes fit a dispatch's 4 KB)
+#define SA_GATHER_SET 12
+struct SaGatherTables {
+  SaGatherTable t[SA_GATHER_SET];
+  uint32_t n;
+};
+hipError_t sa_launch_gather_tables(const SaGatherTables& g, hipStream_t st, hipEvent_t done = nullptr);
 
 // first launch of a frame: positional tiles + frame-preparation blocks
 // prep: 1 = positional tiles + preparation blocks, 0 = positional tiles only (a lean frame on the one-workgroup tail), 2 = preparation

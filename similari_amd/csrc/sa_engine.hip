@@ -1249,13 +1249,9 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
 // into a spare of the same capacity by ONE gather launch on the compute stream and swapped in — no allocation, no host copy of table
 // data, no synchronisation (whatever reads the table next is ordered behind the launch); the kept rows' old indices travel through a
 // mapped pinned buffer the kernel reads in place; ascending ids need no hash map (find_slot).
-int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
-  if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove: null argument");
-  TRY(finish_applies(e));
-  SceneTable* sc = get_scene(e, scene_id, false);
-  if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
-  if (!n) return SA_OK;
-  HIPCHK(e, hipSetDevice(e->device));
+// (1) everything but the launch: which rows stay (their old indices into the scene's mapped index buffer), the spare arrays, the gather's
+// arguments.  Nothing of the table has changed when this fails.
+static int remove_prepare(sa_engine* e, SceneTable* sc, uint32_t n, const uint64_t* ids, SaGatherTable* g, uint32_t* out_rows) {
   std::vector<uint8_t> drop(sc->T, 0);
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t at;
@@ -1273,44 +1269,92 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
     TRY(host_ensure(e, sc->h_index, (size_t)(sc->T ? sc->T : 1) * 4));
     if (sc->h_index.p != before || !sc->d_index) HIPCHK(e, hipHostGetDevicePointer(&sc->d_index, sc->h_index.p, 0));
   }
-  const bool was_idle = e->synced || only_gather_in_flight(e);
-  // first pass: the kept rows' old indices only — the host's id list is compacted AFTER the launch has been accepted (a failure half-way
-  // leaves the table as it was)
   uint32_t* keep = (uint32_t*)sc->h_index.p;
   uint32_t nT = 0;
   for (uint32_t s = 0; s < sc->T; ++s)
     if (!drop[s]) keep[nT++] = s;
-  if (nT) {
-    const uint32_t K = e->K;
-    DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
-    const uint32_t rowb[SA_TABLE_ARRAYS] = {(uint32_t)sizeof(sa_geo), (uint32_t)sizeof(sa_ext), 64u, 8u, 80u, 8u, 440u, K * e->Dp * 4u, K * 4u, K, 4u, K * 4u};
-    const uint32_t na = e->visual ? SA_TABLE_ARRAYS : 7u;
-    SaGatherTable g{};
-    g.n_arrays = na; g.rows = nT; g.index = (const uint32_t*)sc->d_index;
-    for (uint32_t k = 0; k < na; ++k) {
-      if (sc->spare[k].cap < arrs[k]->cap || !sc->spare[k].p) {
-        if (sc->spare[k].p) e->garbage.push_back({sc->spare[k].p, e->next_ticket});
-        sc->spare[k] = DevBuf{};
-        TRY(dev_ensure(e, sc->spare[k], arrs[k]->cap));
-      }
-      g.src[k] = arrs[k]->p; g.dst[k] = sc->spare[k].p; g.row_bytes[k] = rowb[k];
+  *out_rows = nT;
+  *g = SaGatherTable{};
+  if (!nT) return SA_OK;
+  const uint32_t K = e->K;
+  DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
+  const uint32_t rowb[SA_TABLE_ARRAYS] = {(uint32_t)sizeof(sa_geo), (uint32_t)sizeof(sa_ext), 64u, 8u, 80u, 8u, 440u, K * e->Dp * 4u, K * 4u, K, 4u, K * 4u};
+  const uint32_t na = e->visual ? SA_TABLE_ARRAYS : 7u;
+  g->n_arrays = na; g->rows = nT; g->index = (const uint32_t*)sc->d_index;
+  for (uint32_t k = 0; k < na; ++k) {
+    if (sc->spare[k].cap < arrs[k]->cap || !sc->spare[k].p) {
+      if (sc->spare[k].p) e->garbage.push_back({sc->spare[k].p, e->next_ticket});
+      sc->spare[k] = DevBuf{};
+      TRY(dev_ensure(e, sc->spare[k], arrs[k]->cap));
     }
-    if (sa_launch_gather_table(g, e->stream, e->ev_misc) != hipSuccess)
-      return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
-    for (uint32_t k = 0; k < na; ++k) std::swap(*arrs[k], sc->spare[k]);   // (the old arrays are next call's spares: nothing queued reads them after the gather)
-    SA_BUSY(e);
-    sc->index_drain = e->drain_count;
-    if (e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
-    // (nothing but gathers in flight since the last drain: staging the next request set need not wait, only_gather_in_flight)
-    e->gather_seq = was_idle ? e->busy_seq : 0;
+    g->src[k] = arrs[k]->p; g->dst[k] = sc->spare[k].p; g->row_bytes[k] = rowb[k];
   }
+  return SA_OK;
+}
+// (2) the gather has been queued: the compacted arrays become the table, the host's id list follows
+static void remove_commit(sa_engine* e, SceneTable* sc, uint32_t nT) {
+  if (nT) {
+    DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
+    const uint32_t na = e->visual ? SA_TABLE_ARRAYS : 7u;
+    for (uint32_t k = 0; k < na; ++k) std::swap(*arrs[k], sc->spare[k]);   // (the old arrays are next call's spares: nothing queued reads them after the gather)
+    sc->index_drain = e->drain_count;
+  }
+  const uint32_t* keep = (const uint32_t*)sc->h_index.p;
   sc->full.resize(sc->T, 0);
   for (uint32_t r = 0; r < nT; ++r) { sc->ids[r] = sc->ids[keep[r]]; sc->full[r] = sc->full[keep[r]]; }
   sc->T = nT;
   sc->ids.resize(nT);
   sc->full.resize(nT);
   sc->map_built = false;   // (tables whose ids are not ascending rebuild their map on the next lookup)
+}
+int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const uint64_t* const* ids) {
+  if (!e || (n_scenes && (!scene_ids || !counts || !ids))) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove_many: null argument");
+  TRY(finish_applies(e));
+  std::vector<SceneTable*> scs;
+  for (uint32_t i = 0; i < n_scenes; ++i) {
+    if (!counts[i]) continue;
+    if (!ids[i]) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove_many: null id list");
+    SceneTable* sc = get_scene(e, scene_ids[i], false);
+    if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_ids[i]);
+    for (SceneTable* other : scs)
+      if (other == sc) return fail(e, SA_ERR_BAD_ARG, "scene %llu appears twice in one call", (unsigned long long)scene_ids[i]);
+    scs.push_back(sc);
+  }
+  if (scs.empty()) return SA_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  std::vector<SaGatherTable> gs(scs.size());
+  std::vector<uint32_t> rows(scs.size(), 0);
+  size_t k = 0;
+  for (uint32_t i = 0; i < n_scenes; ++i) {   // first every scene's host side: a failure here leaves every table as it was
+    if (!counts[i]) continue;
+    TRY(remove_prepare(e, scs[k], counts[i], ids[i], &gs[k], &rows[k]));
+    ++k;
+  }
+  const bool was_idle = e->synced || only_gather_in_flight(e);
+  bool launched = false;
+  SaGatherTables set{};
+  for (k = 0; k < scs.size(); ++k) {   // ... then the gathers, SA_GATHER_SET scenes per launch (their arguments travel by value)
+    if (rows[k]) set.t[set.n++] = gs[k];
+    const bool last = k + 1 == scs.size();
+    if (set.n == SA_GATHER_SET || (last && set.n)) {
+      if (sa_launch_gather_tables(set, e->stream, last ? e->ev_misc : nullptr) != hipSuccess)
+        return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
+      SA_BUSY(e);
+      launched = true;
+      if (last && e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
+      set.n = 0;
+    }
+  }
+  // (nothing but gathers in flight since the last drain: staging the next request set need not wait, only_gather_in_flight)
+  if (launched) e->gather_seq = was_idle ? e->busy_seq : 0;
+  for (k = 0; k < scs.size(); ++k) remove_commit(e, scs[k], rows[k]);
   return SA_OK;
+}
+int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
+  if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove: null argument");
+  if (!get_scene(e, scene_id, false)) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
+  if (!n) return finish_applies(e);
+  return sa_tracks_remove_many(e, 1, &scene_id, &n, &ids);
 }
 
 int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n) {

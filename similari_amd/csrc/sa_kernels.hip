@@ -120,6 +120,36 @@ __global__ __launch_bounds__(256) void k_gather_table(SaGatherTable g) {
     }
   }
 }
+__device__ __forceinline__ void gather_table_row(const SaGatherTable& g, uint32_t row) {
+  const uint32_t from = g.index[row];
+  for (uint32_t a = 0; a < g.n_arrays; ++a) {
+    const uint32_t rb = g.row_bytes[a];
+    const uint8_t* s = (const uint8_t*)g.src[a] + (size_t)from * rb;
+    uint8_t* d = (uint8_t*)g.dst[a] + (size_t)row * rb;
+    if ((rb & 15u) == 0) {
+      for (uint32_t k = threadIdx.x; k < rb / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k];
+    } else if ((rb & 3u) == 0) {
+      for (uint32_t k = threadIdx.x; k < rb / 4; k += 256) ((uint32_t*)d)[k] = ((const uint32_t*)s)[k];
+    } else {
+      for (uint32_t k = threadIdx.x; k < rb; k += 256) d[k] = s[k];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_gather_tables(SaGatherTables set) {
+  const SaGatherTable& g = set.t[blockIdx.y];
+  if (blockIdx.x >= g.rows) return;
+  gather_table_row(g, blockIdx.x);
+}
+hipError_t sa_launch_gather_tables(const SaGatherTables& set, hipStream_t st, hipEvent_t done) {
+  if (!set.n) return hipSuccess;
+  if (set.n == 1) return sa_launch_gather_table(set.t[0], st, done);
+  uint32_t rows = 0;
+  for (uint32_t i = 0; i < set.n; ++i) rows = set.t[i].rows > rows ? set.t[i].rows : rows;
+  if (!rows) return hipSuccess;
+  if (done) hipExtLaunchKernelGGL(k_gather_tables, dim3(rows, set.n), dim3(256), 0, st, nullptr, done, 0, set);
+  else hipLaunchKernelGGL(k_gather_tables, dim3(rows, set.n), dim3(256), 0, st, set);
+  return hipGetLastError();
+}
 hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st, hipEvent_t done) {
   if (!g.rows || !g.n_arrays) return hipSuccess;
   if (done) hipExtLaunchKernelGGL(k_gather_table, dim3(g.rows), dim3(256), 0, st, nullptr, done, 0, g);   // (carries its own completion signal)

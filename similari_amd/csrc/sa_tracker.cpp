@@ -142,6 +142,7 @@ struct sa_tracker {
     std::vector<uint8_t> cpres, votes, merged;
     std::vector<uint64_t> winners, tids, new_ids;
     std::vector<int32_t> wcols;
+    std::vector<uint64_t> evict_ids;           // rows of the scene's table that no later frame can match (scan_expired)
     std::vector<Track*> trps;
     sa_detections det{};
     uint8_t contiguous = 0;                    // ... unless they already ARE one N x D block (then: no gather at all)
@@ -505,24 +506,40 @@ Track* winner_row(SceneState& S, size_t rows_before, int32_t col, uint64_t dest,
   return nullptr;
 }
 
-// eviction (see SceneState::row_epoch): tracks of the set's scenes that no frame from now on can match leave the engine's table.  Removals
-// on different scenes are queued one behind the other, no drain in between.
+// eviction (see SceneState::row_epoch): tracks of the set's scenes that no frame from now on can match leave the engine's table.
+// The scan is per scene (it rides in the scene's assemble job); the removals of every scene of the set are ONE call — one gather launch
+// per dozen scenes, no drain.
+void scan_expired(const sa_tracker_options& o, sa_tracker::SceneScratch& W) {
+  W.evict_ids.clear();
+  const SceneState& S = *W.st;
+  const uint64_t cur = W.epoch;
+  size_t expired = 0;
+  for (uint64_t ep : S.row_epoch) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
+  // (a removal is a gather of the whole table; a row left in it costs the frames until auto_waste ~1/64 us each: it pays from about 64 rows on)
+  if (expired < 64 || expired * 16 < S.rows.size()) return;
+  W.evict_ids.reserve(expired);
+  for (size_t r = 0; r < S.rows.size(); ++r)
+    if (S.row_epoch[r] + o.max_idle_epochs < cur) W.evict_ids.push_back(S.rows[r]->id);
+}
 int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint32_t n_scenes) {
   const sa_tracker_options& o = t->o;
+  std::vector<uint64_t> scene_ids;
+  std::vector<uint32_t> counts;
+  std::vector<const uint64_t*> lists;
   for (uint32_t s = 0; s < n_scenes; ++s) {
+    if (ss[s].evict_ids.empty()) continue;
+    scene_ids.push_back(ss[s].st->id);
+    counts.push_back((uint32_t)ss[s].evict_ids.size());
+    lists.push_back(ss[s].evict_ids.data());
+  }
+  if (scene_ids.empty()) return SA_OK;
+  int rce = sa_tracks_remove_many(t->eng, (uint32_t)scene_ids.size(), scene_ids.data(), counts.data(), lists.data());
+  if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
+  for (uint32_t s = 0; s < n_scenes; ++s) {   // (the engine's tables no longer hold them: now the facade's side)
+    if (ss[s].evict_ids.empty()) continue;
     SceneState& S = *ss[s].st;
     const uint64_t cur = ss[s].epoch;
-    size_t expired = 0;
-    for (uint64_t ep : S.row_epoch) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
-    // (a removal is one gather launch; a row left in the table costs the frames until auto_waste ~1/64 us each: it pays from about 64 rows on)
-    if (expired < 64 || expired * 16 < S.rows.size()) continue;
-    std::vector<uint64_t> out_ids;
-    out_ids.reserve(expired);
-    for (size_t r = 0; r < S.rows.size(); ++r)
-      if (S.row_epoch[r] + o.max_idle_epochs < cur) out_ids.push_back(S.rows[r]->id);
-    int rce = sa_tracks_remove(t->eng, S.id, (uint32_t)out_ids.size(), out_ids.data());
-    if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
-    size_t w = 0;   // (the engine's table no longer holds them: now the facade's side)
+    size_t w = 0;
     for (size_t r = 0; r < S.rows.size(); ++r) {
       if (S.row_epoch[r] + o.max_idle_epochs < cur) { S.rows[r]->in_engine = false; S.evicted.push_back(S.rows[r]); }
       else { S.rows[w] = S.rows[r]; S.row_epoch[w] = S.row_epoch[r]; ++w; }
@@ -694,17 +711,20 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
     int rc = sa_own_areas(t->eng, n, frame.data(), shares.data());
     if (rc != SA_OK) return tfail(t, rc, "%s", sa_last_error(t->eng));
   }
-  run_jobs(t, n_scenes, [&](uint32_t s) { assemble_scene(o, ss[s], scene_ids[s], counts[s], obs[s]); });
-  for (uint32_t s = 0; s < n_scenes; ++s)
-    if (ss[s].rc != SA_OK) return tfail(t, ss[s].rc, "%s", ss[s].err.c_str());
   uint64_t next = t->track_id;
   for (uint32_t s = 0; s < n_scenes; ++s) {
     SceneState& S = scene_of(t, scene_ids[s]);
     ss[s].st = &S;
-    ss[s].epoch = ++S.epoch;   // next_epoch  epoch_db.rs:35-49
+    ss[s].epoch = S.epoch + 1; // next_epoch  epoch_db.rs:35-49 (committed once the request has passed validation)
     ss[s].id_base = next;      // (batch ids: one per candidate; a single scene: its own counter)
     next += counts[s];
   }
+  run_jobs(t, n_scenes, [&](uint32_t s) {
+    if (assemble_scene(o, ss[s], scene_ids[s], counts[s], obs[s]) == SA_OK) scan_expired(o, ss[s]);
+  });
+  for (uint32_t s = 0; s < n_scenes; ++s)
+    if (ss[s].rc != SA_OK) return tfail(t, ss[s].rc, "%s", ss[s].err.c_str());
+  for (uint32_t s = 0; s < n_scenes; ++s) ss[s].st->epoch = ss[s].epoch;
   if (o.batch_ids) t->track_id = next;
   int rc = evict_expired(t, ss, n_scenes);
   if (rc != SA_OK) return rc;
@@ -784,6 +804,7 @@ int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids,
     SceneState& S = scene_of(t, scene_ids[s]);
     ss[s].st = &S;
     ss[s].epoch = ++S.epoch;
+    scan_expired(o, ss[s]);
   }
   int rc = evict_expired(t, ss, n_scenes);
   if (rc != SA_OK) return rc;

@@ -632,7 +632,7 @@ def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25)
     the PredictionBatchResult handle in whatever order they finish."""
     rng = np.random.default_rng(seed)
     opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
-            .positional_metric(IoU(0.3)).visual_minimal_track_length(2).visual_minimal_area(500.0)
+            .positional_metric(IoU(0.3)).visual_minimal_track_length(min(2, bank)).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(bank).visual_min_votes(1))
     g = make(backend, "visual", opts=opts, feature_len=d, batch=True)
     o = make("oracle", "visual", opts=opts, feature_len=d, batch=True)
