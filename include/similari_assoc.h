@@ -177,6 +177,13 @@ int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t
 /* sa_tracks_remove on several scenes at once (a batch tracker taking expired tracks out of many of its scenes' tables in one predict()):
  * ids[i] lists counts[i] tracks of scene scene_ids[i]; one gather launch per dozen scenes; either every table changes or none. */
 int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const uint64_t* const* ids);
+/* The same in two steps, so that the per-scene host work can run on several threads: sa_tracks_remove_stage works out which rows of ONE
+ * scene's table stay (different scenes may be staged by different threads at once; SA_ERR_STATE: this scene needs the serial call —
+ * an upkeep step is still to be collected, or the engine would have to be drained first — and nothing has changed);
+ * sa_tracks_remove_commit, on the calling thread, queues the gathers of every staged scene (sa_tracks_remove_many commits what is staged
+ * along with its own scenes).  Nothing else may be called on the engine between a stage and its commit. */
+int sa_tracks_remove_stage(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids);
+int sa_tracks_remove_commit(sa_engine* e);
 int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n);
 /* Column order of the scene's track table (= column order of every matrix tap below). */
 int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t cap, uint32_t* out_n);

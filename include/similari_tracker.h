@@ -88,7 +88,9 @@ typedef struct sa_tracker_options {
   int32_t device_upkeep;                /* 1 = Kalman step, table refresh and feature-bank policy run on the GPU (sa_tracks_apply):
                                            no per-frame upload of boxes / Kalman state / features; 0 = host upkeep + sa_tracks_upsert */
   int32_t workers;                      /* threads working on the scenes of one request set (Batch*: the reference's voting_shards,
-                                           sort/batch_api.rs:197-207), the calling thread included; 0 = the facade's choice, 1 = none */
+                                           sort/batch_api.rs:197-207), the calling thread included; 0 = the facade's choice, 1 = none.
+                                           n > 1: bound to the CPUs next to the one the first batch call runs on (a scene's records stay in
+                                           one cache complex); -n: n threads left to the scheduler */
 } sa_tracker_options;
 
 typedef struct sa_tracker sa_tracker;

@@ -365,6 +365,8 @@ PROTOTYPES = {
     "sa_tracks_upsert": (C.c_int, [ENGINE, u64, P(sa_tracks)]),
     "sa_tracks_remove": (C.c_int, [ENGINE, u64, u32, P(u64)]),
     "sa_tracks_remove_many": (C.c_int, [ENGINE, u32, P(u64), P(u32), P(P(u64))]),
+    "sa_tracks_remove_stage": (C.c_int, [ENGINE, u64, u32, P(u64)]),
+    "sa_tracks_remove_commit": (C.c_int, [ENGINE]),
     "sa_tracks_count": (C.c_int, [ENGINE, u64, P(u32)]),
     "sa_tracks_order": (C.c_int, [ENGINE, u64, P(u64), u32, P(u32)]),
     "sa_associate": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u64), P(C.c_uint8)]),

@@ -5,6 +5,7 @@
 #include "sa_kalman.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -37,7 +38,7 @@ struct HostBuf {  // pinned
   size_t cap = 0;
 };
 
-struct SceneTable {
+struct alignas(128) SceneTable {   // (aligned: the tracker facade works on different scenes from different threads, sa_tracks_apply_collect_slot)
   uint64_t scene_id = 0;
   uint32_t T = 0, cap = 0;
   std::vector<uint64_t> ids;                       // slot -> id
@@ -50,6 +51,9 @@ struct SceneTable {
   DevBuf spare[SA_TABLE_ARRAYS];                   // sa_tracks_remove compacts the table into these and swaps (no allocation per call)
   HostBuf h_index;                                 // ... the kept rows' old indices (mapped pinned memory the gather kernel reads in place)
   void* d_index = nullptr;
+  uint64_t in_set = 0;                             // stamp of the request set the scene was last added to (bank_add)
+  bool staged = false;                             // sa_tracks_remove_stage has filled h_index; sa_tracks_remove_commit queues the gather
+  uint32_t staged_rows = 0;                        // ... rows that stay
   uint64_t index_drain = ~0ull;                    // sa_engine::drain_count when the last gather that reads h_index was queued (~0: none): the
                                                    // buffer may be rewritten once the engine has been drained since
   DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
@@ -59,7 +63,7 @@ struct SceneTable {
                                    // reported itself ill-conditioned for the matrix-core expansion (sa_config.euclid_backoff_frames)
 };
 
-struct Slot {  // one scene of a request set
+struct alignas(128) Slot {  // one scene of a request set (aligned: see SceneTable)
   SceneTable* scene = nullptr;
   uint64_t epoch = 0;
   uint32_t N = 0, T = 0;
@@ -87,6 +91,7 @@ struct Slot {  // one scene of a request set
   void *d_pred = nullptr, *d_apply = nullptr, *d_fix = nullptr;  // device views of the three
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
+  uint32_t N_res = 0, T_res = 0;  // extents the slot's buffers are reserved for (slot_reserve)
   uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
   bool poly_pending = false;   // sa_tracks_apply_collect_slot has run: the polygons of refreshed ORIENTED rows are still to be queued (sa_tracks_apply_collect_end)
@@ -112,6 +117,7 @@ struct Slot {  // one scene of a request set
 struct Bank {
   std::vector<Slot*> slots;  // pool; the first n_slots are live
   uint32_t n_slots = 0;
+  uint64_t set_stamp = ~0ull; // unique per request set (bank_clear draws a new one)
   HostBuf h_arena;
   void* h_arena_dev = nullptr;  // the pinned arena as the device sees it
   DevBuf d_arena;
@@ -129,6 +135,7 @@ struct Bank {
   bool assoc_event = false;             // sa_batch_run_apply: ev_done marks the end of the ASSOCIATION (the frame's last dispatch carries it); the
                                         // upkeep kernels run behind it — sa_batch_fetch waits for the event only, so that the caller's own
                                         // bookkeeping overlaps them
+  std::atomic<bool> assoc_waited{false};// ... and has been waited for (sa_batch_results from several threads: one trip into the runtime, not one per slot)
   bool want_prep = false;               // the upkeep follows on the stream (sa_batch_run_apply): its feature-bank step reads what the preparation blocks write
   bool want_apply = false;              // sa_batch_run_apply: bank_upload appends the set's ApplyScene array to the arena (behind the descriptors: the same DMA)
   size_t apply_off = 0;                 // ... where it went
@@ -174,6 +181,7 @@ struct sa_engine {
   bool eu_mfma_ok = false;              // euclidean engines: the expansion is usable at this feature length (eu_rho < 1/3)
   float eu_rho = 0.f;
   std::string err;
+  std::atomic<uint32_t> n_staged{0}; // scenes between sa_tracks_remove_stage and sa_tracks_remove_commit
   std::mutex err_mu;                 // (sa_batch_fill / sa_tracks_apply_collect_slot run on several threads: fail() serialises its writes)
   std::unordered_map<uint64_t, SceneTable*> scenes;
   bool synced = true;
@@ -460,7 +468,12 @@ int arena_reserve(sa_engine* e, Bank* b, size_t bytes) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
 int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
-  const size_t n = N ? N : 1, t = T ? T : 1, K = e->K, Dp = e->Dp ? e->Dp : 32;
+  // Reserved extents: a tracker's table breathes (tracks start, idle ones are evicted) and most of a slot's buffers are sized N x T —
+  // sizing them by the frame would reallocate a few of them (hipMalloc, slot init, later hipFree) every time T sets a new record.  The
+  // first frame and every record reserve half as much again, in steps of 256.
+  if (N > s->N_res) s->N_res = (N + N / 2 + 255u) & ~255u;
+  if (T > s->T_res) s->T_res = (T + T / 2 + 255u) & ~255u;
+  const size_t n = s->N_res ? s->N_res : 1, t = s->T_res ? s->T_res : 1, K = e->K, Dp = e->Dp ? e->Dp : 32;
   const size_t CT = (t + 63) / 64, RT = (n + 63) / 64;
   TRY(dev_ensure(e, s->geo, n * sizeof(sa_geo)));
   TRY(dev_ensure(e, s->verts, n * 8 * sizeof(double)));
@@ -1249,32 +1262,64 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
 // into a spare of the same capacity by ONE gather launch on the compute stream and swapped in — no allocation, no host copy of table
 // data, no synchronisation (whatever reads the table next is ordered behind the launch); the kept rows' old indices travel through a
 // mapped pinned buffer the kernel reads in place; ascending ids need no hash map (find_slot).
-// (1) everything but the launch: which rows stay (their old indices into the scene's mapped index buffer), the spare arrays, the gather's
-// arguments.  Nothing of the table has changed when this fails.
-static int remove_prepare(sa_engine* e, SceneTable* sc, uint32_t n, const uint64_t* ids, SaGatherTable* g, uint32_t* out_rows) {
-  std::vector<uint8_t> drop(sc->T, 0);
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t at;
-    if (!find_slot(sc, ids[i], &at)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[i]);
-    drop[at] = 1;
-  }
+// sa_tracks_remove in three steps.
+// (1) stage: which rows stay — their old indices into the scene's mapped index buffer.  Touches the scene only: different scenes may be
+// staged by different threads at once (may_sync = false: where the engine would have to be drained first — the index buffer may still be
+// read by an earlier gather of the same scene, or has to grow — the call answers SA_ERR_STATE and nothing has changed).
+static int remove_stage(sa_engine* e, SceneTable* sc, uint32_t n, const uint64_t* ids, bool may_sync) {
   // No drain: the gather is ordered on the compute stream behind whatever still reads or writes the table, and the arrays it fills are the
   // ones the previous gather of this scene read — also behind it.  The one thing the HOST writes is this scene's index buffer: it must not
   // be rewritten while an earlier gather of the SAME scene may still be reading it (two removals on one scene with no drain between them;
   // removals on different scenes — a batch tracker evicting from several of its scenes in one predict() — chain freely).
-  if (sc->index_drain == e->drain_count && !e->synced) TRY(engine_sync(e));
-  {
+  if (sc->index_drain == e->drain_count && !e->synced) {
+    if (!may_sync) return SA_ERR_STATE;
+    TRY(engine_sync(e));
+  }
+  const size_t need = (size_t)std::max<uint32_t>(sc->cap, sc->T ? sc->T : 1) * 4;   // (for the table's capacity: grows with the table, not per call)
+  if (need > sc->h_index.cap || !sc->h_index.p || !sc->d_index) {
+    if (!e->synced) {
+      if (!may_sync) return SA_ERR_STATE;
+      TRY(engine_sync(e));   // (the block is about to be replaced)
+    }
     void* before = sc->h_index.p;
-    if ((size_t)(sc->T ? sc->T : 1) * 4 > sc->h_index.cap && !e->synced) TRY(engine_sync(e));   // (the block is about to be replaced)
-    TRY(host_ensure(e, sc->h_index, (size_t)(sc->T ? sc->T : 1) * 4));
+    TRY(host_ensure(e, sc->h_index, need));
     if (sc->h_index.p != before || !sc->d_index) HIPCHK(e, hipHostGetDevicePointer(&sc->d_index, sc->h_index.p, 0));
   }
   uint32_t* keep = (uint32_t*)sc->h_index.p;
   uint32_t nT = 0;
-  for (uint32_t s = 0; s < sc->T; ++s)
-    if (!drop[s]) keep[nT++] = s;
-  *out_rows = nT;
+  bool walked = false;
+  if (sc->ascending) {   // ascending table, ascending list (every tracker of the reference): one walk over both
+    bool asc = true;
+    for (uint32_t i = 1; i < n && asc; ++i) asc = ids[i] > ids[i - 1];
+    if (asc) {
+      uint32_t j = 0;
+      for (uint32_t r = 0; r < sc->T; ++r) {
+        if (j < n && sc->ids[r] == ids[j]) { ++j; continue; }
+        keep[nT++] = r;
+      }
+      if (j != n) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[j]);
+      walked = true;
+    }
+  }
+  if (!walked) {
+    std::vector<uint8_t> drop(sc->T, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+      uint32_t at;
+      if (!find_slot(sc, ids[i], &at)) return fail(e, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)ids[i]);
+      drop[at] = 1;
+    }
+    for (uint32_t r = 0; r < sc->T; ++r)
+      if (!drop[r]) keep[nT++] = r;
+  }
+  sc->staged = true;
+  sc->staged_rows = nT;
+  e->n_staged.fetch_add(1, std::memory_order_relaxed);
+  return SA_OK;
+}
+// (2) the gather's arguments (the spare arrays exist from here on)
+static int remove_build(sa_engine* e, SceneTable* sc, SaGatherTable* g) {
   *g = SaGatherTable{};
+  const uint32_t nT = sc->staged_rows;
   if (!nT) return SA_OK;
   const uint32_t K = e->K;
   DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
@@ -1291,8 +1336,10 @@ static int remove_prepare(sa_engine* e, SceneTable* sc, uint32_t n, const uint64
   }
   return SA_OK;
 }
-// (2) the gather has been queued: the compacted arrays become the table, the host's id list follows
-static void remove_commit(sa_engine* e, SceneTable* sc, uint32_t nT) {
+// (3) the gather has been queued: the compacted arrays become the table, the host's id list follows
+static void remove_commit(sa_engine* e, SceneTable* sc) {
+  const uint32_t nT = sc->staged_rows;
+  sc->staged = false;
   if (nT) {
     DevBuf* arrs[SA_TABLE_ARRAYS] = {&sc->geo, &sc->ext, &sc->verts, &sc->epoch, &sc->maha, &sc->tids, &sc->kf, &sc->feat, &sc->fnorm, &sc->fpresent, &sc->fcount, &sc->fquality};
     const uint32_t na = e->visual ? SA_TABLE_ARRAYS : 7u;
@@ -1307,6 +1354,58 @@ static void remove_commit(sa_engine* e, SceneTable* sc, uint32_t nT) {
   sc->full.resize(nT);
   sc->map_built = false;   // (tables whose ids are not ascending rebuild their map on the next lookup)
 }
+static bool upkeep_pending(const sa_engine* e) {
+  if (!e->applying.empty()) return true;
+  for (const Bank& bk : e->banks)
+    for (uint32_t i = 0; i < bk.n_slots; ++i)
+      if (bk.slots[i]->fused_pending || bk.slots[i]->poly_pending) return true;
+  return false;
+}
+int sa_tracks_remove_stage(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
+  if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove_stage: null argument");
+  if (upkeep_pending(e)) return SA_ERR_STATE;   // (an upkeep step has yet to be collected: the serial sa_tracks_remove_many finishes it first)
+  SceneTable* sc = get_scene(e, scene_id, false);
+  if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
+  if (sc->staged) return fail(e, SA_ERR_STATE, "scene %llu has a removal staged already", (unsigned long long)scene_id);
+  if (!n) return SA_OK;
+  return remove_stage(e, sc, n, ids, false);
+}
+int sa_tracks_remove_commit(sa_engine* e) {
+  if (!e) return SA_ERR_BAD_ARG;
+  if (!e->n_staged.load(std::memory_order_relaxed)) return SA_OK;
+  e->n_staged.store(0, std::memory_order_relaxed);
+  std::vector<SceneTable*> scs;
+  for (auto& kv : e->scenes)
+    if (kv.second->staged) scs.push_back(kv.second);
+  if (scs.empty()) return SA_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  std::vector<SaGatherTable> gs(scs.size());
+  for (size_t k = 0; k < scs.size(); ++k) {
+    int rc = remove_build(e, scs[k], &gs[k]);
+    if (rc != SA_OK) { for (SceneTable* sc : scs) sc->staged = false; return rc; }   // (nothing has been queued: every table is as it was)
+  }
+  const bool was_idle = e->synced || only_gather_in_flight(e);
+  bool launched = false;
+  SaGatherTables set{};
+  for (size_t k = 0; k < scs.size(); ++k) {   // the gathers, SA_GATHER_SET scenes per launch (their arguments travel by value)
+    if (gs[k].rows) set.t[set.n++] = gs[k];
+    const bool last = k + 1 == scs.size();
+    if (set.n == SA_GATHER_SET || (last && set.n)) {
+      if (sa_launch_gather_tables(set, e->stream, last ? e->ev_misc : nullptr) != hipSuccess) {
+        for (SceneTable* sc : scs) sc->staged = false;
+        return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
+      }
+      SA_BUSY(e);
+      launched = true;
+      if (last && e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
+      set.n = 0;
+    }
+  }
+  // (nothing but gathers in flight since the last drain: staging the next request set need not wait, only_gather_in_flight)
+  if (launched) e->gather_seq = was_idle ? e->busy_seq : 0;
+  for (SceneTable* sc : scs) remove_commit(e, sc);
+  return SA_OK;
+}
 int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const uint64_t* const* ids) {
   if (!e || (n_scenes && (!scene_ids || !counts || !ids))) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove_many: null argument");
   TRY(finish_applies(e));
@@ -1320,35 +1419,15 @@ int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene
       if (other == sc) return fail(e, SA_ERR_BAD_ARG, "scene %llu appears twice in one call", (unsigned long long)scene_ids[i]);
     scs.push_back(sc);
   }
-  if (scs.empty()) return SA_OK;
   HIPCHK(e, hipSetDevice(e->device));
-  std::vector<SaGatherTable> gs(scs.size());
-  std::vector<uint32_t> rows(scs.size(), 0);
   size_t k = 0;
-  for (uint32_t i = 0; i < n_scenes; ++i) {   // first every scene's host side: a failure here leaves every table as it was
+  for (uint32_t i = 0; i < n_scenes; ++i) {   // every scene's host side first: a failure here leaves every table as it was
     if (!counts[i]) continue;
-    TRY(remove_prepare(e, scs[k], counts[i], ids[i], &gs[k], &rows[k]));
+    int rc = scs[k]->staged ? SA_OK : remove_stage(e, scs[k], counts[i], ids[i], true);
+    if (rc != SA_OK) { for (SceneTable* sc : scs) sc->staged = false; return rc; }
     ++k;
   }
-  const bool was_idle = e->synced || only_gather_in_flight(e);
-  bool launched = false;
-  SaGatherTables set{};
-  for (k = 0; k < scs.size(); ++k) {   // ... then the gathers, SA_GATHER_SET scenes per launch (their arguments travel by value)
-    if (rows[k]) set.t[set.n++] = gs[k];
-    const bool last = k + 1 == scs.size();
-    if (set.n == SA_GATHER_SET || (last && set.n)) {
-      if (sa_launch_gather_tables(set, e->stream, last ? e->ev_misc : nullptr) != hipSuccess)
-        return fail(e, SA_ERR_HIP, "sa_tracks_remove: gather launch failed: %s", hipGetErrorString(hipGetLastError()));
-      SA_BUSY(e);
-      launched = true;
-      if (last && e->ev_misc) { e->tail_ev = e->ev_misc; e->tail_seq = e->busy_seq; }
-      set.n = 0;
-    }
-  }
-  // (nothing but gathers in flight since the last drain: staging the next request set need not wait, only_gather_in_flight)
-  if (launched) e->gather_seq = was_idle ? e->busy_seq : 0;
-  for (k = 0; k < scs.size(); ++k) remove_commit(e, scs[k], rows[k]);
-  return SA_OK;
+  return sa_tracks_remove_commit(e);
 }
 int sa_tracks_remove(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
   if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove: null argument");
@@ -1375,8 +1454,11 @@ int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t
 }
 
 // ---- batches ------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_set_stamp{0};
 static void bank_clear(Bank* b) {
+  b->set_stamp = g_set_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
   b->assoc_event = false;
+  b->assoc_waited.store(false, std::memory_order_relaxed);
   b->apply_event = false;
   b->kf_event = false;
   b->n_slots = 0;
@@ -1498,10 +1580,10 @@ static int slot_fill(sa_engine* e, Bank* b, Slot* s, bool check) {
 static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows,
                     uint32_t* out_slot, bool defer = false) {
   const uint32_t N = d->n;
-  for (uint32_t i = 0; i < b->n_slots; ++i)
-    if (b->slots[i]->scene->scene_id == scene_id)
-      return fail(e, SA_ERR_STATE, "scene %llu is already part of this batch", (unsigned long long)scene_id);
   SceneTable* sc = get_scene(e, scene_id, true);
+  // (a scene once per request set: the set's stamp on the scene instead of a walk over the slots — Batch* trackers stage dozens per call)
+  if (sc->in_set == b->set_stamp) return fail(e, SA_ERR_STATE, "scene %llu is already part of this batch", (unsigned long long)scene_id);
+  sc->in_set = b->set_stamp;
   Slot* s = get_slot(b, b->n_slots);
   if (s->ran && s->h_out.p && e->cfg.visual_kind == SA_VIS_EUCLIDEAN) {
     // what the slot's previous frame reported (the bank is idle: that frame has retired)
@@ -1638,8 +1720,11 @@ int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id,
   Slot* s = e->B->slots[slot];
   if (!s->ran && !s->fused_pending) return fail(e, SA_ERR_STATE, "sa_batch_results before sa_batch_run");
   if (e->B->assoc_event) {
-    hipError_t we = hipEventSynchronize(e->B->ev_done);
-    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    if (!e->B->assoc_waited.load(std::memory_order_acquire)) {
+      hipError_t we = hipEventSynchronize(e->B->ev_done);
+      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+      e->B->assoc_waited.store(true, std::memory_order_release);
+    }
   } else if (!e->synced) TRY(engine_sync(e));
   const uint8_t* h = (const uint8_t*)s->h_out.p;
   const size_t n1 = s->N ? s->N : 1, st_off = (n1 * 9 + 7) & ~(size_t)7;
@@ -2005,7 +2090,11 @@ static int fused_collect_host(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* 
   sc->full.resize(sc->T, 1);
   s->ran = false;  // the table the slot ran against is gone
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
-  s->poly_pending = bad == SA_OK;   // (3) polygon_fixups: a launch — left to the thread that owns the engine's stream
+  // (3) polygon_fixups — a launch, left to the thread that owns the engine's stream — only where a refreshed row is oriented
+  bool oriented = false;
+  const sa_box* pb = (const sa_box*)s->h_pred.p;
+  for (uint32_t i = 0; i < n && !oriented; ++i) oriented = pb[i].has_angle && pb[i].angle != 0.0f;
+  s->poly_pending = bad == SA_OK && oriented;
   return bad;
 }
 static Bank* bank_of_slot(sa_engine* e, const Slot* s) {
@@ -2083,6 +2172,7 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
   if (rc == SA_OK) rc = bank_launch(e, b, maxN, maxT, b->ev_done, &rides);
   if (rc == SA_OK && !rides) { if (hipEventRecord(b->ev_done, e->stream) != hipSuccess) rc = fail(e, SA_ERR_HIP, "hipEventRecord failed"); }
   b->assoc_event = rc == SA_OK;
+  b->assoc_waited.store(false, std::memory_order_relaxed);
   b->want_prep = false;
   b->want_apply = false;
   if (rc != SA_OK) return rc;

@@ -25,6 +25,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -56,25 +57,24 @@ struct Obs {  // one stored observation of a VisualSORT track; index 0 carries t
 };
 
 // The last `cap` (observed, predicted) boxes of a track (SortAttributes::observed_boxes / predicted_boxes are VecDeques trimmed to the
-// history length, sort.rs:160-176; the two are always pushed together): ONE fixed ring of pairs â€” no allocation per frame, one heap
-// block per track.
+// history length, sort.rs:160-176; the two are always pushed together): ONE fixed ring of pairs, stored right behind the track's record
+// in its slab cell (TrackSlab) â€” no allocation per frame, none per track.
 struct BoxPair { sa_box observed, predicted; };
 struct Ring {
-  std::vector<BoxPair> v;
-  uint32_t head = 0, count = 0;
-  void push(const sa_box& observed, const sa_box& predicted, uint32_t cap) {
-    if (v.size() != cap) { v.resize(cap); head = 0; count = 0; }
+  BoxPair* v = nullptr;
+  uint32_t cap = 0, head = 0, count = 0;
+  void push(const sa_box& observed, const sa_box& predicted) {
     uint32_t at;
     if (count < cap) { at = head + count++; at = at >= cap ? at - cap : at; }
     else { at = head; head = head + 1 == cap ? 0 : head + 1; }
     v[at].observed = observed;
     v[at].predicted = predicted;
   }
-  const BoxPair& back() const { const uint32_t at = head + count - 1, cap = (uint32_t)v.size(); return v[at >= cap ? at - cap : at]; }
+  const BoxPair& back() const { const uint32_t at = head + count - 1; return v[at >= cap ? at - cap : at]; }
   uint32_t size() const { return count; }
 };
 
-struct Track {  // (what a frame's bookkeeping touches first; the filter state â€” 440 bytes the device owns under device upkeep â€” last)
+struct Track {  // (what a frame's bookkeeping touches first)
   uint64_t id = 0, scene = 0, epoch = 0, length = 0;
   bool has_custom = false;
   int64_t custom = 0;
@@ -84,12 +84,52 @@ struct Track {  // (what a frame's bookkeeping touches first; the filter state â
   uint32_t feat_count = 0;
   Ring boxes;
   std::vector<Obs> obs;
-  KF kf;
+  std::unique_ptr<KF> kf;  // host upkeep only (440 bytes the device owns under device upkeep)
+  Track* next_free = nullptr;
+};
+
+// Where a scene's tracks live: cells of (record + history ring) carved from chunks of 256, recycled through a free list when a track is
+// wasted.  A tracker at 5 % churn starts 1 600 tracks per predict() of 64 x 500 objects; from the process heap that was three allocations
+// each and â€” measured, MI355X box â€” ~300 page faults per call with the heap's growth calls (mprotect: a TLB shoot-down on every thread
+// of the process) in the middle of the scenes' parallel jobs, which ran 3.6 x slower than the same jobs one after the other.
+struct TrackSlab {
+  std::vector<char*> chunks;
+  size_t cell = 0, left = 0;   // bytes per cell ; cells left in the last chunk
+  uint32_t ring_cap = 0;
+  Track* free_list = nullptr;
+  static constexpr size_t kCells = 256;
+  Track* get(uint32_t history) {
+    if (!cell) { ring_cap = history; cell = ((sizeof(Track) + 15) & ~(size_t)15) + (size_t)history * sizeof(BoxPair); cell = (cell + 63) & ~(size_t)63; }
+    char* at;
+    if (free_list) { at = (char*)free_list; free_list = free_list->next_free; }
+    else {
+      if (!left) { chunks.push_back((char*)::operator new(cell * kCells, std::align_val_t(64))); left = kCells; }
+      at = chunks.back() + (kCells - left) * cell;
+      --left;
+    }
+    Track* tr = new (at) Track();
+    tr->boxes.v = (BoxPair*)(at + ((sizeof(Track) + 15) & ~(size_t)15));
+    tr->boxes.cap = ring_cap;
+    return tr;
+  }
+  void put(Track* tr) {
+    tr->~Track();
+    tr->next_free = free_list;   // (the cell is raw memory again: only this link lives in it)
+    free_list = tr;
+  }
+  void release() {
+    for (char* c : chunks) ::operator delete(c, std::align_val_t(64));
+    chunks.clear();
+    free_list = nullptr;
+    left = 0;
+  }
 };
 
 // One scene's share of the store.  Scenes never share a track (compatible() is false across scene ids, sort.rs:251), so everything a
 // frame's bookkeeping touches belongs to exactly one scene â€” which is what lets the scenes of a request set be worked on side by side.
-struct SceneState {
+// (aligned to two cache lines: neighbouring scenes are worked on by different threads, and the vectors' headers below are written â€” a
+// push_back per track that starts â€” while the neighbour's are read)
+struct alignas(128) SceneState {
   uint64_t id = 0, epoch = 0;   // EpochDb: the scene's current epoch (0 = never seen)
   // the scene's tracks in the order of the engine's table for that scene: rows are appended in creation order (ids ascend) and removals
   // close the gaps on both sides, so the winner the engine reports as a COLUMN (sa_batch_results) is rows[column] â€” no lookup by id on
@@ -103,6 +143,7 @@ struct SceneState {
   // row is the Kalman state of a device-upkeep tracker: sa_tracker_track_state answers SA_ERR_NOT_FOUND for an evicted track.)
   std::vector<uint64_t> row_epoch;   // last_updated_epoch of `rows`, in the same order (the scan's input)
   std::vector<Track*> evicted;       // out of the engine's table, not wasted yet
+  TrackSlab slab;
 };
 
 struct ResultState;
@@ -123,17 +164,18 @@ struct sa_tracker {
   uint64_t track_id = 0;
   std::map<uint64_t, SceneState> scenes;   // node-based: a SceneState's address is stable
   uint64_t n_active = 0;                   // tracks in the main store (sum of active_shard_stats)
-  std::vector<Track> wasted_store;
+  std::vector<sa_sort_track> wasted_store;   // (what wasted() hands out of a wasted track: its SortTrack)
   uint32_t waste_counter = 0;
   // predict()'s per-scene work arrays, kept between calls: a frame allocates nothing once the arrays have grown to its size.  Everything
   // the work AFTER the launches reads of the caller's observations is copied here (boxes, custom ids): the reference takes its request by
   // value, and so a caller of sa_tracker_predict_batch_begin may reuse its arrays as soon as that call has returned.
-  struct SceneScratch {
+  struct alignas(128) SceneScratch {   // (one thread per scene: see SceneState)
     SceneState* st = nullptr;
     uint32_t n = 0, slot = 0, n_new = 0;
     uint64_t epoch = 0, id_base = 0;
     int rc = SA_OK;
     std::string err;
+    double job_us[4] = {0, 0, 0, 0};   // (SA_TRACKER_TRACE)
     std::vector<sa_box> cboxes, oboxes, dev_pred;  // the candidates' boxes after their own Kalman no-op step ; as observed ; the device's predicted boxes
     std::vector<int64_t> ccustom;
     std::vector<uint8_t> chas_custom;
@@ -143,6 +185,7 @@ struct sa_tracker {
     std::vector<uint64_t> winners, tids, new_ids;
     std::vector<int32_t> wcols;
     std::vector<uint64_t> evict_ids;           // rows of the scene's table that no later frame can match (scan_expired)
+    int evict_rc = SA_OK;                      // ... staged in the engine by the scene's own job (sa_tracks_remove_stage)
     std::vector<Track*> trps;
     sa_detections det{};
     uint8_t contiguous = 0;                    // ... unless they already ARE one N x D block (then: no gather at all)
@@ -208,7 +251,7 @@ bool feature_can_be_used(const sa_tracker_options& o, const sa_box& b, float q, 
 
 void update_history(const sa_tracker_options& o, Track& tr, const sa_box& observed, const sa_box& predicted) {
   tr.length += 1;                                     // sort.rs:160-176, track_attributes.rs:60-78
-  tr.boxes.push(observed, predicted, o.history_length);
+  tr.boxes.push(observed, predicted);
 }
 
 // What to_sort_track would read from a track whose history had just taken (observed, predicted) â€” without the history
@@ -261,8 +304,10 @@ Track* find_track(sa_tracker* t, uint64_t id, SceneState** where = nullptr) {
 
 void run_jobs(sa_tracker* t, uint32_t n, const std::function<void(uint32_t)>& fn) {
   if (n > 1 && !t->pool) {
-    uint32_t w = t->o.workers > 0 ? (uint32_t)t->o.workers : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4u));
-    t->pool.reset(new SaPool(w > 1 ? w - 1 : 0));   // (the calling thread is a worker too)
+    // workers: n > 0 = n threads bound to the CPUs next to the caller's (sa_pool.h), n < 0 = |n| threads left to the scheduler, 0 = the facade's choice
+    const int32_t ow = t->o.workers;
+    uint32_t w = ow ? (uint32_t)(ow < 0 ? -ow : ow) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4u));
+    t->pool.reset(new SaPool(w > 1 ? w - 1 : 0, ow >= 0));   // (the calling thread is a worker too)
   }
   if (n > 1 && t->pool) t->pool->run(n, fn);
   else
@@ -296,8 +341,8 @@ int auto_waste(sa_tracker* t) {
     S.evicted.erase(std::remove_if(S.evicted.begin(), S.evicted.end(), is_gone), S.evicted.end());
     std::sort(dead.begin(), dead.end(), [](const Track* a, const Track* b) { return a->id < b->id; });
     for (Track* tr : dead) {
-      t->wasted_store.push_back(std::move(*tr));
-      delete tr;
+      t->wasted_store.push_back(to_sort_track(t->o, *tr));
+      S.slab.put(tr);
       --t->n_active;
     }
   }
@@ -319,8 +364,8 @@ int sync_engine(sa_tracker* t, uint64_t scene, const std::vector<Track*>& trs) {
     boxes[i] = tr.boxes.back().predicted;
     epochs[i] = tr.epoch;
     for (int a = 0; a < 5; ++a) {
-      mean[i * 5 + a] = tr.kf.mean[a];
-      for (int b = 0; b < 5; ++b) cov[i * 25 + a * 5 + b] = tr.kf.cov[a * 10 + b];
+      mean[i * 5 + a] = tr.kf->mean[a];
+      for (int b = 0; b < 5; ++b) cov[i * 25 + a * 5 + b] = tr.kf->cov[a * 10 + b];
     }
     if (t->o.visual)
       for (uint32_t k = 0; k < tr.obs.size() && k < K; ++k)
@@ -360,7 +405,7 @@ void optimize_observations(std::vector<Obs>& obs, Obs&& nw, uint32_t max_observa
 // The heavy half of a continued track's merge under device upkeep: history (the boxes are the candidate's and the device's prediction)
 // and, for VisualSort, the observation policy on the bookkeeping records (the feature rows move inside the device bank, sa_upkeep.hip).
 inline void merge_heavy(const sa_tracker_options& o, Track& tr, const sa_tracker::SceneScratch& W, uint32_t i) {
-  tr.boxes.push(W.cboxes[i], W.dev_pred[i], o.history_length);
+  tr.boxes.push(W.cboxes[i], W.dev_pred[i]);
   if (o.visual) {
     Obs nw;
     nw.quality = W.cq[i];
@@ -396,6 +441,8 @@ void wait_outstanding(sa_tracker* t) {
 }
 
 using clk = std::chrono::steady_clock;
+#include <sys/resource.h>
+inline long minor_faults() { struct rusage ru; getrusage(RUSAGE_SELF, &ru); return ru.ru_minflt; }
 inline double us_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 
 // One scene's observations into its work arrays: validation (the reference's assert!s), the candidates' boxes, the optional arrays of a
@@ -477,13 +524,13 @@ int assemble_scene(const sa_tracker_options& o, sa_tracker::SceneScratch& W, uin
 
 // A candidate that starts a track (simple_api.rs:167-187).  Under device upkeep the filter state is born on the GPU and the feature
 // vectors live in the device bank only.
-Track* start_track(const sa_tracker_options& o, const sa_tracker::SceneScratch& W, uint32_t i, uint64_t id, uint64_t scene, const float* feature) {
-  Track* trp = new Track();
+Track* start_track(const sa_tracker_options& o, SceneState& S, const sa_tracker::SceneScratch& W, uint32_t i, uint64_t id, const float* feature) {
+  Track* trp = S.slab.get(o.history_length);
   Track& tr = *trp;
-  tr.id = id; tr.scene = scene; tr.epoch = W.epoch;
+  tr.id = id; tr.scene = S.id; tr.epoch = W.epoch;
   tr.has_custom = W.chas_custom[i] != 0; tr.custom = W.ccustom[i];
   tr.has_state = true;
-  if (!o.device_upkeep) { bool hs = false; make_prediction(o.kalman_position_weight, o.kalman_velocity_weight, hs, tr.kf, W.oboxes[i]); }
+  if (!o.device_upkeep) { bool hs = false; tr.kf.reset(new KF()); make_prediction(o.kalman_position_weight, o.kalman_velocity_weight, hs, *tr.kf, W.oboxes[i]); }
   tr.length = 0;
   update_history(o, tr, W.oboxes[i], W.cboxes[i]);
   if (o.visual) {
@@ -521,32 +568,42 @@ void scan_expired(const sa_tracker_options& o, sa_tracker::SceneScratch& W) {
   for (size_t r = 0; r < S.rows.size(); ++r)
     if (S.row_epoch[r] + o.max_idle_epochs < cur) W.evict_ids.push_back(S.rows[r]->id);
 }
-int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint32_t n_scenes) {
-  const sa_tracker_options& o = t->o;
+// the facade's side of a scene's eviction, once the engine's table has let the rows go
+void evict_commit(const sa_tracker_options& o, sa_tracker::SceneScratch& W) {
+  if (W.evict_ids.empty()) return;
+  SceneState& S = *W.st;
+  const uint64_t cur = W.epoch;
+  size_t w = 0;
+  for (size_t r = 0; r < S.rows.size(); ++r) {
+    if (S.row_epoch[r] + o.max_idle_epochs < cur) { S.rows[r]->in_engine = false; S.evicted.push_back(S.rows[r]); }
+    else { S.rows[w] = S.rows[r]; S.row_epoch[w] = S.row_epoch[r]; ++w; }
+  }
+  S.rows.resize(w);
+  S.row_epoch.resize(w);
+  W.evict_ids.clear();
+}
+// staged: the scenes' jobs have staged their removals themselves (sa_tracks_remove_stage; W.evict_rc == SA_ERR_STATE: that scene has to go
+// through the serial call); commit_rows: also do the facade's side here (else: the caller does it, in the scenes' next jobs)
+int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint32_t n_scenes, bool staged, bool commit_rows) {
   std::vector<uint64_t> scene_ids;
   std::vector<uint32_t> counts;
   std::vector<const uint64_t*> lists;
+  bool any = false;
   for (uint32_t s = 0; s < n_scenes; ++s) {
     if (ss[s].evict_ids.empty()) continue;
+    any = true;
+    if (staged && ss[s].evict_rc == SA_OK) continue;
+    if (staged && ss[s].evict_rc != SA_ERR_STATE) return tfail(t, ss[s].evict_rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
     scene_ids.push_back(ss[s].st->id);
     counts.push_back((uint32_t)ss[s].evict_ids.size());
     lists.push_back(ss[s].evict_ids.data());
   }
-  if (scene_ids.empty()) return SA_OK;
-  int rce = sa_tracks_remove_many(t->eng, (uint32_t)scene_ids.size(), scene_ids.data(), counts.data(), lists.data());
+  if (!any) return SA_OK;
+  int rce = scene_ids.empty() ? sa_tracks_remove_commit(t->eng)
+                              : sa_tracks_remove_many(t->eng, (uint32_t)scene_ids.size(), scene_ids.data(), counts.data(), lists.data());   // (commits what was staged as well)
   if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
-  for (uint32_t s = 0; s < n_scenes; ++s) {   // (the engine's tables no longer hold them: now the facade's side)
-    if (ss[s].evict_ids.empty()) continue;
-    SceneState& S = *ss[s].st;
-    const uint64_t cur = ss[s].epoch;
-    size_t w = 0;
-    for (size_t r = 0; r < S.rows.size(); ++r) {
-      if (S.row_epoch[r] + o.max_idle_epochs < cur) { S.rows[r]->in_engine = false; S.evicted.push_back(S.rows[r]); }
-      else { S.rows[w] = S.rows[r]; S.row_epoch[w] = S.row_epoch[r]; ++w; }
-    }
-    S.rows.resize(w);
-    S.row_epoch.resize(w);
-  }
+  if (commit_rows)
+    for (uint32_t s = 0; s < n_scenes; ++s) evict_commit(t->o, ss[s]);
   return SA_OK;
 }
 
@@ -563,16 +620,30 @@ int complete_flight(sa_tracker* t) {
   const uint32_t n_scenes = F.n_scenes;
   static const bool trace = getenv("SA_TRACKER_TRACE") != nullptr;
   const auto t0 = clk::now();
+  const long flt0 = trace ? minor_faults() : 0;
   flush_pending(t);
   const auto t1 = clk::now();
+  {  // ONE wait for the association's completion event, here: the jobs below then read the results without a trip into the runtime each
+    const uint64_t* w0 = nullptr;
+    int rc0 = sa_batch_results(t->eng, ss[0].slot, &w0, nullptr, nullptr);
+    if (rc0 != SA_OK) {
+      t->err = std::string("association: ") + sa_last_error(t->eng);
+      if (F.res) { std::lock_guard<std::mutex> lk(F.res->mu); F.res->rc = rc0; F.res->err = t->err; F.res->finished = true; F.res->cv.notify_all(); }
+      return rc0;
+    }
+  }
+  const auto t1w = clk::now();
   run_jobs(t, n_scenes, [&](uint32_t s) {
     sa_tracker::SceneScratch& W = ss[s];
     SceneState& S = *W.st;
     const uint32_t n = W.n;
-    W.n_new = 0;
+    const auto j0 = trace ? clk::now() : clk::time_point();
+    evict_commit(o, W);   // (rows the engine's table let go in front of this set's launches: the columns below refer to the table without them)
+    uint32_t n_new = 0;
     const uint64_t* win = nullptr;
     const uint8_t* votes = nullptr;
     const int32_t* wcols = nullptr;
+    W.n_new = 0;
     int rc = sa_batch_results(t->eng, W.slot, &win, &votes, &wcols);
     if (rc != SA_OK) { W.rc = rc; W.err = std::string("association: ") + sa_last_error(t->eng); return; }
     W.trps.resize(n);
@@ -585,14 +656,14 @@ int complete_flight(sa_tracker* t) {
       if (dest == 0) {
         // Batch*: an id per candidate (batch_api.rs:102-106); Sort / VisualSort: a counter over the tracks that start (simple_api.rs:165-187)
         const uint64_t id = o.batch_ids ? W.id_base + 1 + i : ++drawn;
-        trp = start_track(o, W, i, id, S.id, nullptr);
+        trp = start_track(o, S, W, i, id, nullptr);
         S.rows.push_back(trp);
         S.row_epoch.push_back(W.epoch);
         W.merged[i] = 0;
-        ++W.n_new;
+        ++n_new;
       } else {
         trp = winner_row(S, rows_before, wcols[i], dest, W.epoch);
-        if (!trp) { W.rc = SA_ERR_STATE; W.err = "engine returned an unknown track id"; return; }
+        if (!trp) { W.rc = SA_ERR_STATE; W.err = "engine returned an unknown track id"; W.n_new = n_new; return; }
         Track& tr = *trp;
         // TrackAttributes::merge  sort.rs:272-276 / track_attributes.rs:210-215 (the rest of the merge â€” history, observation policy â€” is
         // deferred: merge_heavy / flush_pending)
@@ -604,6 +675,8 @@ int complete_flight(sa_tracker* t) {
       }
       W.trps[i] = trp;
     }
+    W.n_new = n_new;
+    if (trace) W.job_us[0] = us_between(j0, clk::now());
   });
   const auto t2 = clk::now();
   int rc = SA_OK;
@@ -619,6 +692,7 @@ int complete_flight(sa_tracker* t) {
     run_jobs(t, n_scenes, [&](uint32_t s) {
       sa_tracker::SceneScratch& W = ss[s];
       const uint32_t n = W.n;
+      const auto j0 = trace ? clk::now() : clk::time_point();
       W.dev_pred.resize(n);
       int rcs = sa_tracks_apply_collect_slot(t->eng, W.slot, nullptr, W.dev_pred.data());
       if (rcs != SA_OK) { W.rc = rcs; W.err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng); return; }
@@ -630,6 +704,7 @@ int complete_flight(sa_tracker* t) {
         F.res->ready_q.push_back(s);
         F.res->cv.notify_all();
       }
+      if (trace) W.job_us[1] = us_between(j0, clk::now());
     });
     for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
       if (ss[s].rc != SA_OK) { rc = ss[s].rc; first_err = ss[s].err; }
@@ -647,9 +722,15 @@ int complete_flight(sa_tracker* t) {
     t->pending_set = F.set;
     t->pending_scenes = n_scenes;
   } else t->err = first_err;
-  if (trace)
-    fprintf(stderr, "[sa_tracker] behind the launches: deferred %.1f  winners + merges %.1f  wait for the Kalman dispatch %.1f  tables + results %.1f us\n",
-            us_between(t0, t1), us_between(t1, t2), us_between(t2, t3), us_between(t3, clk::now()));
+  if (trace) {
+    double mx[2] = {0, 0}, sum[2] = {0, 0};
+    for (uint32_t s = 0; s < n_scenes; ++s)
+      for (int k = 0; k < 2; ++k) { mx[k] = std::max(mx[k], ss[s].job_us[k]); sum[k] += ss[s].job_us[k]; }
+    fprintf(stderr, "[sa_tracker] behind the launches: deferred %.1f  wait for the association %.1f  merges %.1f (jobs: longest %.1f, all %.1f)  wait for the Kalman "
+            "dispatch %.1f  tables + results %.1f (jobs: longest %.1f, all %.1f) us  minor faults %.1f\n",
+            us_between(t0, t1), us_between(t1, t1w), us_between(t1w, t2), mx[0], sum[0], us_between(t2, t3), us_between(t3, clk::now()), mx[1], sum[1],
+            (double)(minor_faults() - flt0));
+  }
   if (F.res) {
     std::lock_guard<std::mutex> lk(F.res->mu);
     F.res->rc = rc;
@@ -719,25 +800,43 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
     ss[s].id_base = next;      // (batch ids: one per candidate; a single scene: its own counter)
     next += counts[s];
   }
+  const auto t_pre = clk::now();
   run_jobs(t, n_scenes, [&](uint32_t s) {
-    if (assemble_scene(o, ss[s], scene_ids[s], counts[s], obs[s]) == SA_OK) scan_expired(o, ss[s]);
+    const auto j0 = trace ? clk::now() : clk::time_point();
+    sa_tracker::SceneScratch& W = ss[s];
+    assemble_scene(o, W, scene_ids[s], counts[s], obs[s]);
+    if (trace) W.job_us[2] = us_between(j0, clk::now());
   });
+  const auto t_asm = clk::now();
   for (uint32_t s = 0; s < n_scenes; ++s)
     if (ss[s].rc != SA_OK) return tfail(t, ss[s].rc, "%s", ss[s].err.c_str());
   for (uint32_t s = 0; s < n_scenes; ++s) ss[s].st->epoch = ss[s].epoch;
   if (o.batch_ids) t->track_id = next;
-  int rc = evict_expired(t, ss, n_scenes);
-  if (rc != SA_OK) return rc;
   const auto t_built = clk::now();
   // ---- the hot path: foreign_track_distances + voting.winners, on the GPU, with the upkeep of every scene queued right BEHIND the
   // association (sa_batch_run_apply) â€” the ids of the tracks that start are a function of the winners alone (a counter, in candidate
   // order), so the device draws them itself
-  rc = sa_batch_begin(t->eng);
+  int rc = sa_batch_begin(t->eng);
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
     rc = sa_batch_add_deferred(t->eng, scene_ids[s], ss[s].epoch, &ss[s].det, (o.visual && !ss[s].contiguous) ? ss[s].cfeat.data() : nullptr, &ss[s].slot);
   if (rc == SA_OK) {
-    run_jobs(t, n_scenes, [&](uint32_t s) { ss[s].rc = sa_batch_fill(t->eng, ss[s].slot); });
+    // per scene, side by side: which of its table's rows no later frame can match (staged in the engine: sa_tracks_remove_stage), and the
+    // copy of its detections into the staging arena
+    run_jobs(t, n_scenes, [&](uint32_t s) {
+      sa_tracker::SceneScratch& W = ss[s];
+      scan_expired(o, W);
+      W.evict_rc = W.evict_ids.empty() ? SA_OK : sa_tracks_remove_stage(t->eng, W.st->id, (uint32_t)W.evict_ids.size(), W.evict_ids.data());
+      W.rc = sa_batch_fill(t->eng, W.slot);
+    });
+    // (the gathers of every staged scene: one launch per dozen scenes, in front of the request set's own launches; the facade's side of an
+    // eviction follows in the scene's merge job)
+    const int rce = evict_expired(t, ss, n_scenes, true, false);
     for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) rc = ss[s].rc;
+    if (rce != SA_OK || rc != SA_OK) {
+      if (rce == SA_OK) for (uint32_t s = 0; s < n_scenes; ++s) evict_commit(o, ss[s]);
+      flush_pending(t);
+      return rce != SA_OK ? rce : tfail(t, rc, "association: %s", sa_last_error(t->eng));
+    }
   }
   const auto t_staged = clk::now();
   if (rc == SA_OK) {
@@ -745,10 +844,17 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
     for (uint32_t s = 0; s < n_scenes; ++s) id_base[s] = ss[s].id_base;
     rc = sa_batch_run_apply(t->eng, id_base.data(), o.batch_ids ? 1 : 0);
   }
-  if (rc != SA_OK) { flush_pending(t); return tfail(t, rc, "association: %s", sa_last_error(t->eng)); }
-  if (trace)
-    fprintf(stderr, "[sa_tracker] up to the launches: assemble %.1f  stage %.1f  enqueue %.1f us\n", us_between(t_entry, t_built),
-            us_between(t_built, t_staged), us_between(t_staged, clk::now()));
+  if (rc != SA_OK) {
+    for (uint32_t s = 0; s < n_scenes; ++s) evict_commit(o, ss[s]);
+    flush_pending(t);
+    return tfail(t, rc, "association: %s", sa_last_error(t->eng));
+  }
+  if (trace) {
+    double mx = 0;
+    for (uint32_t s = 0; s < n_scenes; ++s) mx = std::max(mx, ss[s].job_us[2]);
+    fprintf(stderr, "[sa_tracker] up to the launches: before the jobs %.1f  assemble %.1f (longest job %.1f)  epochs %.1f  stage + evict %.1f  enqueue %.1f us\n",
+            us_between(t_entry, t_pre), us_between(t_pre, t_asm), mx, us_between(t_asm, t_built), us_between(t_built, t_staged), us_between(t_staged, clk::now()));
+  }
   sa_tracker::Flight& F = t->flight;
   F.n_scenes = n_scenes;
   F.set = set;
@@ -806,7 +912,7 @@ int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids,
     ss[s].epoch = ++S.epoch;
     scan_expired(o, ss[s]);
   }
-  int rc = evict_expired(t, ss, n_scenes);
+  int rc = evict_expired(t, ss, n_scenes, false, true);
   if (rc != SA_OK) return rc;
   rc = sa_batch_begin(t->eng);
   for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s)
@@ -857,7 +963,7 @@ int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids,
       Track* trp;
       if (dest == 0) {
         // winner == self or none: the candidate becomes a new track (simple_api.rs:167-187)
-        trp = start_track(o, W, i, W.tids[i], S.id, o.visual ? W.cfeat[i] : nullptr);
+        trp = start_track(o, S, W, i, W.tids[i], o.visual ? W.cfeat[i] : nullptr);
         S.rows.push_back(trp);
         S.row_epoch.push_back(W.epoch);
         ++t->n_active;
@@ -870,7 +976,7 @@ int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids,
         tr.has_custom = W.chas_custom[i] != 0; tr.custom = W.ccustom[i];
         if (o.visual) tr.voting = W.votes[i];
         // optimize(is_merge = true): Kalman predict + update with the candidate's box, history (device upkeep: once the boxes are back)
-        if (!o.device_upkeep) update_history(o, tr, cbox, make_prediction(pw, vw, tr.has_state, tr.kf, cbox));
+        if (!o.device_upkeep) update_history(o, tr, cbox, make_prediction(pw, vw, tr.has_state, *tr.kf, cbox));
         if (o.visual) {
           Obs nw;
           nw.quality = W.cq[i];
@@ -979,7 +1085,7 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
   if (o->history_length == 0) return tfail(nullptr, SA_ERR_BAD_ARG, "bbox_history must be > 0 (sort/simple_api.rs:51)");
   if (o->visual && (o->feature_len == 0 || o->visual_max_observations == 0))
     return tfail(nullptr, SA_ERR_BAD_ARG, "VisualSort needs feature_len and visual_max_observations");
-  if (o->workers < 0 || o->workers > 256) return tfail(nullptr, SA_ERR_BAD_ARG, "workers must lie in [0, 256] (0 = the facade's own choice)");
+  if (o->workers < -256 || o->workers > 256) return tfail(nullptr, SA_ERR_BAD_ARG, "workers must lie in [-256, 256] (0 = the facade's own choice)");
   sa_tracker* t = new sa_tracker();
   t->o = *o;
   t->cons_delta.assign(o->constraint_epoch_delta, o->constraint_epoch_delta + o->n_constraints);
@@ -1034,8 +1140,9 @@ void sa_tracker_destroy(sa_tracker* t) {
   t->pool.reset();
   if (t->eng) sa_engine_destroy(t->eng);
   for (auto& kv : t->scenes) {
-    for (Track* tr : kv.second.rows) delete tr;
-    for (Track* tr : kv.second.evicted) delete tr;
+    for (Track* tr : kv.second.rows) kv.second.slab.put(tr);
+    for (Track* tr : kv.second.evicted) kv.second.slab.put(tr);
+    kv.second.slab.release();
   }
   delete t;
 }
@@ -1148,9 +1255,9 @@ int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t*
   flush_pending(t);
   int rc = auto_waste(t);
   if (rc != SA_OK) return rc;
-  std::sort(t->wasted_store.begin(), t->wasted_store.end(), [](const Track& a, const Track& b) { return a.id < b.id; });
+  std::sort(t->wasted_store.begin(), t->wasted_store.end(), [](const sa_sort_track& a, const sa_sort_track& b) { return a.id < b.id; });
   uint32_t n = (uint32_t)t->wasted_store.size();
-  for (uint32_t i = 0; i < n && i < cap && out; ++i) out[i] = to_sort_track(t->o, t->wasted_store[i]);
+  for (uint32_t i = 0; i < n && i < cap && out; ++i) out[i] = t->wasted_store[i];
   *out_n = n;
   if (out && cap >= n) t->wasted_store.clear();  // fetch_tracks removes them from the wasted store
   return SA_OK;
@@ -1181,8 +1288,8 @@ int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, floa
     int rc = sa_tracks_get_state(t->eng, tr->scene, track_id, mean10, cov100, nullptr, nullptr, nullptr);
     return rc == SA_OK ? SA_OK : tfail(t, rc, "sa_tracks_get_state: %s", sa_last_error(t->eng));
   }
-  if (mean10) std::memcpy(mean10, tr->kf.mean, sizeof tr->kf.mean);
-  if (cov100) std::memcpy(cov100, tr->kf.cov, sizeof tr->kf.cov);
+  if (mean10) std::memcpy(mean10, tr->kf->mean, sizeof tr->kf->mean);
+  if (cov100) std::memcpy(cov100, tr->kf->cov, sizeof tr->kf->cov);
   return SA_OK;
 }
 
