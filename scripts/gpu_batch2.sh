@@ -14,10 +14,9 @@ for key in ("up to the launches", "behind the launches"):
         print("   ", key, [round(st.median(c), 1) for c in zip(*rows)])
 PY
 }
-for cfg in "sort 64 500 0 40 8" "sort 64 500 0 40 16" "sort 64 500 0 120 8" "sort 8 500 0 40 8" "sort 8 500 0 40 4" "sort 8 500 0 40 2" "visual 8 1000 512 24 8"; do
+for cfg in "sort 64 500 0 40 0" "sort 64 500 0 40 8" "sort 8 500 0 40 0" "sort 8 500 0 40 4" "visual 8 1000 512 24 0"; do
   echo "== $cfg"
   timeout 200 python scripts/bench_batch_tracker.py $cfg sync device | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   ', d['us_per_predict_median'], d['us_per_predict_min'])"
   SA_TRACKER_TRACE=1 timeout 200 python scripts/bench_batch_tracker.py $cfg sync device 2> $O/tr.txt > /dev/null; agg $O/tr.txt
 done
-timeout 600 python -m pytest tests/test_trackers.py -m gpu -q --timeout 300 -p no:cacheprovider --maxfail=15 -rf 2>&1 | tail -5
 echo DONE

@@ -306,7 +306,7 @@ void run_jobs(sa_tracker* t, uint32_t n, const std::function<void(uint32_t)>& fn
   if (n > 1 && !t->pool) {
     // workers: n > 0 = n threads bound to the CPUs next to the caller's (sa_pool.h), n < 0 = |n| threads left to the scheduler, 0 = the facade's choice
     const int32_t ow = t->o.workers;
-    uint32_t w = ow ? (uint32_t)(ow < 0 ? -ow : ow) : std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4u));
+    uint32_t w = ow ? (uint32_t)(ow < 0 ? -ow : ow) : std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 8u));
     t->pool.reset(new SaPool(w > 1 ? w - 1 : 0, ow >= 0));   // (the calling thread is a worker too)
   }
   if (n > 1 && t->pool) t->pool->run(n, fn);
