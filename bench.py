@@ -474,7 +474,7 @@ def kernel_bytes_model(cfg, scenes, matched_edges):
     return b
 
 
-def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
+def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None, on_results=None, region=None):
     """The reference's predict() ingests host buffers every frame (visual_sort/simple_api.rs:130-170): the same frame through
     sa_pipe_submit / sa_pipe_wait, two request sets in flight, features in a block from sa_host_alloc (DMA'd in place), results
     copied out — H2D and D2H inside the timed region.  feats_on_device: the feature rows lie in device memory already (a ReID model on
@@ -517,6 +517,8 @@ def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
             j = i - (depth - 1)
             if j >= 0:
                 rc |= lib.sa_pipe_wait(h, tk[j % depth], sets[j % depth][1])
+                if on_results is not None:   # (a multi-GPU run whose ranks ingest their own scenes: the step's ids / votes go to the root)
+                    on_results(sets[j % depth][2])
             c = pc()
             host[0] += b - a
             host[1] += c - b
@@ -524,9 +526,12 @@ def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
 
     loop(10)
     host[0] = host[1] = 0.0
-    t0 = time.perf_counter()
-    loop(iters)
-    dt = time.perf_counter() - t0
+    if region is not None:   # (several ranks: barrier + synchronize on both sides, the maximum over the ranks)
+        dt = region(lambda: loop(iters))
+    else:
+        t0 = time.perf_counter()
+        loop(iters)
+        dt = time.perf_counter() - t0
     # the synchronous form for comparison (stage -> DMA -> kernels -> results, nothing overlapped)
     req, res, outs = sets[0]
     for _ in range(5):
@@ -551,6 +556,64 @@ def h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=False, keys=None):
                      if feats_on_device else
                      "sa_pipe_submit / sa_pipe_wait, three request sets in flight (H2D of frame n+1 beside the kernels of frame n, frame n+2 queued), features in a "
                      "sa_host_alloc block, results copied out; synchronous_ms_per_step = sa_associate_batch on the same buffers")}, ids
+
+
+def local_ingest(wname, total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, iters):
+    """--gpus N > 1, `--ingest local`: every rank OWNS the detections of its scenes (scene_id % N: a camera's detector feeds the GPU that owns
+    the camera's scene) — nothing of the request travels between ranks; each step every rank ingests its own share (boxes from host buffers;
+    the feature rows either resident in HBM — a ReID model on the same GPU: `device_features` — or in pinned host blocks: `host_pinned`),
+    runs it, and the ids / vote types go to rank 0 (similari_amd.sharding.ResultGather: one KB-scale gather per step, asynchronous).
+    EXACTLY `iters` steps between barrier + synchronize, the maximum over the ranks; pairs/s over the cells of ALL ranks."""
+    import torch
+
+    from similari_amd import sharding
+    from similari_amd.engine import Engine
+
+    keys = scene_ids_of_rank(total_scenes, world, rank)
+    cfg, scenes, desc = workload(wname, seed=1234, scene_ids=keys)
+    cfg.device = local_rank
+    cfg.flags = 0
+    eng = Engine(cfg)
+    keep = stage(eng, cfg, scenes, keys)
+    visual = cfg.visual_kind != abi.SA_VIS_NONE
+    eng.batch_run()
+    eng.batch_sync()
+    got = [eng.batch_fetch(s, len(sc["det_boxes"])) for s, sc in enumerate(scenes)]
+    cdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    tot = torch.tensor([float(sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)), float(sum(len(s["det_boxes"]) for s in scenes))], dtype=torch.float64, device=cdev)
+    rows_all = [torch.zeros_like(tot) for _ in range(world)]
+    dist.all_gather(rows_all, tot)
+    total_cells = float(sum(float(t[0]) for t in rows_all))
+    rows_per_rank = [int(t[1]) for t in rows_all]
+    out = {"workload": desc, "scenes_total": total_scenes, "ranks": world, "backend": dist.get_backend(), "pairs_per_step": total_cells}
+    for name, ondev in (([("device_features", True)] if visual else []) + [("host_pinned" if visual else "host_boxes", False)]):
+        rg = sharding.ResultGather(max(rows_per_rank) + 16)
+
+        def region(fn):
+            barrier()
+            t0 = time.perf_counter()
+            fn()
+            rg.drain()
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0)
+
+        res, ids = h2d_pipelined(eng, cfg, scenes, iters, feats_on_device=ondev, keys=keys, on_results=rg.push, region=region)
+        rg.drain()
+        same_local = all(np.array_equal(a, g[0]) for a, g in zip(ids, got))
+        mine = np.concatenate([g[0] for g in got]) if got else np.zeros(0, np.uint64)
+        everyone = [None] * world if rank == 0 else None
+        dist.gather_object(mine, everyone, dst=0)      # (verification only, outside the timed region)
+        ok = torch.tensor([1.0 if same_local else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        entry = {"pairs_per_s": total_cells * iters / (1e-3 * res["ms_per_step"] * iters), "ms_per_step": res["ms_per_step"], "steps": iters,
+                 "h2d_bytes_per_step_per_rank": res["h2d_bytes_per_step"], "gathered_bytes_per_step": 9 * sum(rows_per_rank),
+                 "every_rank_matches_its_resident_run": bool(float(ok.item()) == 1.0)}
+        if rank == 0:
+            last = rg.last(rows_per_rank)
+            entry["root_received_every_ranks_answers"] = bool(all(np.array_equal(last[r][0], everyone[r]) for r in range(world)))
+        out[name] = entry
+    eng.close()
+    return out
 
 
 def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400, max_over_ranks=None):
@@ -589,6 +652,9 @@ def main():
     ap.add_argument("--cluster", type=int, default=0, help="single process: also time the workload's scenes through sa_cluster over this many shards (one engine per device; --cluster-devices to place several shards on one GPU)")
     ap.add_argument("--cluster-devices", default="", help="comma-separated HIP ordinals for --cluster (default 0..n-1)")
     ap.add_argument("--gemm-plan", type=int, default=-1, help="pin the contraction's tile plan (sa_config.gemm_plan; tuning / A-B measurements)")
+    ap.add_argument("--ingest", default="both", choices=["local", "scatter", "both"],
+                    help="--gpus N > 1 on a scene set: `local` = every rank ingests the detections of ITS scenes, only ids / votes are gathered (this is `value`); "
+                         "`scatter` = rank 0 packs and scatters the whole request set (value_scatter); default: both")
     ap.add_argument("--scenes", type=int, default=0, help="scene-set workloads (c2b, c2bk3, c3): scenes of the set — in all, split scene_id %% N under --gpus N (default 64 there, 8 at one GPU)")
     args = ap.parse_args()
 
@@ -745,8 +811,14 @@ def main():
     # scene_id % N) this is `value` — total cells / wall time of scatter + per-rank batch + gather, strong scaling — and the per-rank
     # resident replay above becomes value_resident; on the other workloads (every rank replays its own frame: weak scaling) it stays
     # the side object `dispatch`.
+    local = None
+    local_c3 = None
+    if dist is not None and facade is None and fixed_set and args.ingest in ("local", "both"):
+        local = local_ingest(wname, total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, max(args.steps, 30))
+        if wname == "c2b":   # BASELINE's multi-GPU configuration beside the headline one: 64 scenes x 500 x 500 BatchSORT (KB-scale ingest)
+            local_c3 = local_ingest("c3", total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, max(args.steps, 30))
     dispatch = None
-    if dist is not None and facade is None:
+    if dist is not None and facade is None and (args.ingest in ("scatter", "both") or not fixed_set):
         from similari_amd import sharding
         from similari_amd.engine import Engine as _E
 
@@ -913,30 +985,40 @@ def main():
                         "achieved": fl / (kern[pk]["avg_us"] * 1e-6) / 1e12, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": fl / (kern[pk]["avg_us"] * 1e-6) / 1e12 / VALU_F64_PEAK_TFLOPS,
                         "note": "pairs that pass too_far() x the f64 operations Sutherland-Hodgman + shoelace spend on them (counted on a sample by a host restatement)"}
+        lead = None   # N > 1 on a fixed scene set: the ranks ingest their own scenes (features resident in HBM where the workload has any)
+        if local is not None:
+            lead = local.get("device_features") or local.get("host_boxes") or local.get("host_pinned")
         out = {
             "metric": "assoc-pairs/sec (NxM cost+assign) VisualSORT 512-d",
-            "value": (dispatch["pairs_per_s"] if (fixed_set and dispatch) else total_cells * args.steps / dt),
+            "value": (lead["pairs_per_s"] if lead else dispatch["pairs_per_s"] if (fixed_set and dispatch) else total_cells * args.steps / dt),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": (dispatch["ms_per_batch"] if (fixed_set and dispatch) else 1e3 * dt / args.steps),
+            "ms_per_step": (lead["ms_per_step"] if lead else dispatch["ms_per_batch"] if (fixed_set and dispatch) else 1e3 * dt / args.steps),
             "higher_is_better": True,
             "scaling": "strong" if fixed_set else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("synthetic (seeded, SURVEY §8d); a FIXED set of %d scenes split scene_id %% %d: every step rank 0 scatters the request set (RCCL), every rank "
-                     "runs its share (H2D + kernels), one gather — value = total cells / that wall time; value_resident = the per-rank replay with inputs resident in HBM"
+            "data": (("synthetic (seeded, SURVEY §8d); a FIXED set of %d scenes split scene_id %% %d; every rank ingests the detections of ITS scenes each step (boxes from "
+                      "host buffers, feature rows resident in HBM), runs them, ids / votes gathered on rank 0 (RCCL) — value = total cells / that wall time (maximum over "
+                      "ranks); value_h2d = the same with the feature rows in pinned host blocks; value_scatter = rank 0 packs and scatters the whole request set; "
+                      "value_resident = the per-rank replay with inputs resident in HBM" if lead else
+                      "synthetic (seeded, SURVEY §8d); a FIXED set of %d scenes split scene_id %% %d: every step rank 0 scatters the request set (RCCL), every rank "
+                      "runs its share (H2D + kernels), one gather — value = total cells / that wall time; value_resident = the per-rank replay with inputs resident in HBM")
                      % (total_scenes, world)) if fixed_set else "synthetic (seeded, SURVEY §8d), inputs resident in HBM, same frame replayed each step",
             "config": {"workload": desc, "scenes_per_gpu": len(scenes) if scenes else 8, "scenes_total": (total_scenes if fixed_set else world * (len(scenes) if scenes else 8)),
                        "pairs_per_step_per_gpu": cells,
-                       "parallelism": (f"fixed scene set sharded scene_id % {world}: one scatter + one gather per step (RCCL), no collective inside a rank's share"
+                       "parallelism": ((f"fixed scene set sharded scene_id % {world}, every rank ingests its own scenes: one KB-scale gather of ids / votes per step (RCCL), "
+                                        "no collective inside a rank's share" if lead else
+                                        f"fixed scene set sharded scene_id % {world}: one scatter + one gather per step (RCCL), no collective inside a rank's share")
                                        if fixed_set else f"scene-sharded x{world}, no data-path collective")},
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
                               "max_ms_per_step": 1e3 * max(regions) / args.steps, "ms_per_step_slope": 1e3 * step_s},
             "value_resident": total_cells * args.steps / dt,
             "ms_per_step_resident": 1e3 * dt / args.steps,
-            "value_h2d": h2d["pairs_per_s"] if h2d else None,
+            "value_h2d": (local["host_pinned"]["pairs_per_s"] if (local and "host_pinned" in local) else h2d["pairs_per_s"] if h2d else None),
+            "value_scatter": dispatch["pairs_per_s"] if (fixed_set and dispatch) else None,
             "match_accuracy": acc,
             "roofline": roof,
             "kernels": kern,
@@ -962,6 +1044,10 @@ def main():
             out["cluster"] = cluster
         if dispatch is not None:
             out["dispatch"] = dispatch
+        if local is not None:
+            out["ingest_local"] = local
+        if local_c3 is not None:
+            out["c3_batchsort"] = local_c3
         if not args.no_oracle and world == 1 and facade is None:  # the timed run's answer against the oracle's (ids AND vote types)
             ans = oracle_answers(cfg, scenes)
             same = np.concatenate([(g[0] == a[0]) & (g[1] == a[1]) for g, a in zip(got, ans)])

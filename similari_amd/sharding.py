@@ -575,3 +575,76 @@ class ShardedAssociator:
         assert self.rank == self.root
         self.associate(None, shutdown=True)
         self.close()
+
+
+class ResultGather:
+    """The ONLY exchange of a multi-GPU run whose ranks ingest their own scenes (a camera's detector feeds the GPU that owns the camera's
+    scene: `scene_id % world`): every step each rank hands over the ids and vote types of its scenes, the root receives them — KB-scale,
+    `dist.gather` (RCCL over xGMI on the GPU box; gloo in the CPU tests).  Up to `depth` steps are in flight (each with buffers of its own),
+    so the gather of step n rides beside the kernels of step n + 1.  Nothing of the request travels: the reference's fan-out of scenes to
+    voting threads (sort/batch_api.rs:197-207, 278-288) becomes "the scene lives where its detections arrive".
+
+    Wire: ids[rows] (u64) | votes[rows] (u8), rows = this rank's detections in scene order; `capacity_rows` bounds them on every rank."""
+
+    def __init__(self, capacity_rows: int, group=None, root: int = 0, device=None, depth: int = 3):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group, self.root = torch, dist, group, root
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.device, self.cap = device, int(capacity_rows)
+        pin = device.type == "cuda"
+        nb = 9 * self.cap
+        self.h = [torch.zeros(nb, dtype=torch.uint8, pin_memory=pin) for _ in range(depth)]
+        self.d = [torch.zeros(nb, dtype=torch.uint8, device=device) for _ in range(depth)] if pin else self.h
+        self.recv = ([[torch.zeros(nb, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
+                     if self.rank == root else [None] * depth)
+        self.work = [None] * depth
+        self.rows = [0] * depth
+        self.at = 0
+        self.steps = 0
+
+    def push(self, outs):
+        """outs: [(ids u64[n], votes u8[n])] of this rank's scenes, in scene order.  Returns at once; the buffers of the step `depth` pushes
+        ago are waited for first."""
+        k = self.at
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        buf = self.h[k].numpy()
+        o = 0
+        for ids, votes in outs:
+            n = len(ids)
+            if o + n > self.cap:
+                raise ValueError(f"a rank's share holds more than capacity_rows = {self.cap} detections")
+            buf[8 * o: 8 * (o + n)] = np.ascontiguousarray(ids, np.uint64).view(np.uint8)
+            buf[8 * self.cap + o: 8 * self.cap + o + n] = votes
+            o += n
+        self.rows[k] = o
+        if self.d is not self.h:
+            self.d[k].copy_(self.h[k], non_blocking=True)
+        if self.world > 1:
+            self.work[k] = self.dist.gather(self.d[k], self.recv[k], dst=self.root, group=self.group, async_op=True)
+        self.at = (k + 1) % len(self.h)
+        self.steps += 1
+
+    def drain(self):
+        for k in range(len(self.work)):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def last(self, rows_per_rank):
+        """Root, after drain(): the last step's (ids, votes) of every rank — rows_per_rank[r] detections each."""
+        assert self.rank == self.root
+        k = (self.at - 1) % len(self.h)
+        out = []
+        for r in range(self.world):
+            raw = (self.recv[k][r] if self.world > 1 else self.d[k]).cpu().numpy()
+            n = int(rows_per_rank[r])
+            out.append((raw[: 8 * n].view(np.uint64).copy(), raw[8 * self.cap: 8 * self.cap + n].copy()))
+        return out

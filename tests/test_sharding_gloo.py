@@ -427,3 +427,55 @@ def test_share_pack_roundtrip():
         assert sharding.pack_share_into(dst, items, 24, base, 0) == len(ref)
         np.testing.assert_array_equal(dst[: len(ref)], ref)
         assert (dst[len(ref):] == 0xAB).all()
+
+
+# ---- every rank ingests its own scenes: the only exchange is the gather of ids / votes (sharding.ResultGather) --------------------
+def gather_worker(rank: int, port: int, outfile: str):
+    sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import torch.distributed as dist
+
+    from similari_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        rows = [37, 12][rank]                       # the ranks' shares differ in size
+        scenes = [[20, 17], [12]][rank]             # ... and in their number of scenes
+        rg = sharding.ResultGather(capacity_rows=40, depth=3)
+        seen = {}
+        for step in range(7):                       # more steps than buffers: every buffer is reused, each reuse waits for its gather
+            outs, base = [], 1000 * step + 100 * rank
+            for k, n in enumerate(scenes):
+                outs.append((np.arange(base + 10 * k, base + 10 * k + n, dtype=np.uint64), np.full(n, (step + rank + k) % 2, np.uint8)))
+            rg.push(outs)
+            if step in (2, 6):                      # the root may look at any finished step
+                rg.drain()
+                if rank == 0:
+                    last = rg.last([37, 12])
+                    seen[f"s{step}_ids0"], seen[f"s{step}_v0"] = last[0]
+                    seen[f"s{step}_ids1"], seen[f"s{step}_v1"] = last[1]
+        rg.drain()
+        assert rg.steps == 7 and rows == sum(scenes)
+        with pytest.raises(ValueError):
+            rg.push([(np.zeros(41, np.uint64), np.zeros(41, np.uint8))])   # a share beyond the agreed capacity is refused locally
+        if rank == 0:
+            np.savez(outfile, **seen)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_result_gather_delivers_every_ranks_answers_to_the_root(tmp_path):
+    """Local ingest (bench.py --gpus N --ingest local): no request travels; per step one asynchronous gather of ids | votes.  World 2 on
+    gloo: shares of different sizes, more steps than buffers in flight, the root reads the step it drained."""
+    import torch.multiprocessing as mp
+
+    outfile = str(tmp_path / "gathered.npz")
+    mp.spawn(gather_worker, args=(free_port(), outfile), nprocs=WORLD, join=True)
+    got = dict(np.load(outfile))
+    for step in (2, 6):
+        for rank, scenes in ((0, [20, 17]), (1, [12])):
+            base = 1000 * step + 100 * rank
+            ids = np.concatenate([np.arange(base + 10 * k, base + 10 * k + n, dtype=np.uint64) for k, n in enumerate(scenes)])
+            votes = np.concatenate([np.full(n, (step + rank + k) % 2, np.uint8) for k, n in enumerate(scenes)])
+            np.testing.assert_array_equal(got[f"s{step}_ids{rank}"], ids)
+            np.testing.assert_array_equal(got[f"s{step}_v{rank}"], votes)
