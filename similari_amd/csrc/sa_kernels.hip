@@ -1657,9 +1657,9 @@ __device__ __forceinline__ void dense_solve_component(const SceneDev& S, uint32_
 //   (Mahalanobis engines, whose gains do not fit the middle tier's 32-bit cells: components of up to 8 rows, 12 columns and 24
 //   usable edges are gathered by the root's lane into a private block of LDS — a pool of SL_POOL per workgroup —, solved there by
 //   the serial sa_assign_component and scattered back; the rest goes to the big queue.)
-//   All workgroups of the scene — the row workgroups and the helper workgroups launched behind them, which do nothing else — serve
-//   the queues: workgroup b the mid-sized entries b, b + G, ... as they land, then, once every row workgroup has said it is through
-//   with its rows, the big ones by ticket.  No third launch, and a crowd's dozens of knots are solved side by side.
+//   The helper workgroups launched behind the scene's row workgroups serve the queues: helper b the mid-sized entries b, b + G, ... as
+//   they land, then, once every row workgroup has said it is through with its rows, the big ones by ticket.  No third launch, and a
+//   crowd's dozens of knots are solved side by side.  (Row workgroups never wait: forward progress does not depend on residency.)
 // Per-row duals / matches and per-column matches / predecessors of the dense solver: dynamic LDS when 12 N + 8 T bytes fit
 // (LDS_STATE), else the scene's arrays in HBM — the workgroup's own L1 keeps them coherent between its waves.
 #define SL_POOL 40
@@ -1922,7 +1922,18 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     // 10 us at C4; everything else the takers read was written by earlier launches)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add((uint32_t*)(S.stats + SA_QW_DONE), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // FORWARD PROGRESS: a row workgroup never waits — it leaves here.  Everything below waits for "every row workgroup of the scene has
+    // reported", and the only workgroups that wait are the HELPERS launched behind the scene's row workgroups: on every XCD a helper is
+    // dispatched after the row workgroups of its scene that share the XCD (workgroups are handed out in index order), and those never
+    // block, so the report count always gets there — whatever the device's residency: a frame of 10^5 detections, a CU mask, a
+    // partitioned device, another kernel (the ReID model that fills the registered feature block) holding most of the CUs.  Before,
+    // the row workgroups themselves served the queues behind the same wait, which needed ALL of them resident at once: a frame
+    // beyond that (or a masked device) ran into the bounded wait and failed.  Served by helpers alone the queues lose 4 of 128
+    // wavefronts at 1000 detections.
+    SOLVE_STAMP(5);
+    return;
   }
+  const uint32_t helper = blockIdx.x - row_wgs, n_helpers = gridDim.x - row_wgs;   // (the launcher always adds helpers: launch_solve)
   // Middle tier first, AS THE ENTRIES ARRIVE: the first wavefront of every workgroup serves its entries of the mid-sized queue the
   // moment they have landed (k_assign_label left SA_NONE in every slot) — a crowd's knots are being solved while the slowest row
   // workgroup is still on its pairs (in-kernel timeline of a tracker loop's crowd frame: the last row workgroup was through 11 us after
@@ -1939,11 +1950,11 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t nref = 0;
     if (wv < ML_WAVES) {
-      // No tickets: workgroup b serves the entries b, b + (workgroups), ... of the queue — entries are numbered in the order they were
-      // pushed, workgroups in the order they were dispatched, so the first knots go to the workgroups that are through first, and a
+      // No tickets: helper b serves the entries b, b + (helpers), ... of the queue — entries are numbered in the order they were
+      // pushed, workgroups in the order they were dispatched, so the first knots go to the workgroups that are there first, and a
       // frame WITHOUT a mid-sized component (most tracking frames) leaves here at the price of the old wait: one poll of its slot and of
       // the report count, then the slot again + the big queue's length once every row workgroup has reported.
-      uint32_t k = blockIdx.x;
+      uint32_t k = helper;
       while (nref < NT / ML_WAVES) {  // (a full refusal list: this wavefront serves no more — its later entries would be lost, so it is sized for every row it could get)
         if (k >= N) break;  // (at most one mid-sized component per row)
         uint32_t ent = SA_NONE;
@@ -1962,7 +1973,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
           __builtin_amdgcn_s_sleep(2);
           if (spin + 1u == (1u << 22)) S.out_stats[1] = 1u;   // gave up: a row workgroup that never reported (a partitioned or shared device?)
         }
-        k += gridDim.x;
+        k += n_helpers;
         if (ent == SA_NONE) break;
         ++took_mid;
         const uint32_t root = ent & 0xffffffu, R = ent >> 24;
@@ -2027,7 +2038,7 @@ __global__ __launch_bounds__(NT) void k_assign_solve(const SceneDev* __restrict_
     for (uint32_t i = 0; i < nf; ++i) dense_one(s_fail[w2 * (NT / ML_WAVES) + i]);
   }
   if (leftover)
-    for (uint32_t k = s_resume; k < N; k += gridDim.x) {   // (every row workgroup has reported: the slots are final)
+    for (uint32_t k = s_resume; k < N; k += n_helpers) {   // (every row workgroup has reported: the slots are final)
       const uint32_t ent = __hip_atomic_load((uint32_t*)S.dq + N + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ent == SA_NONE) break;
       dense_one(ent & 0xffffffu);
@@ -2148,7 +2159,10 @@ static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, u
   // fewer per scene in a wide batch
   const uint32_t rows = cdiv(maxN, NT);
   const uint32_t want = ns >= 16 ? 16u : ns >= 4 ? 32u : 128u;
-  const dim3 grid(rows > want ? rows : want, 1, ns);
+  // (the row workgroups leave once their rows are through — they never wait, see the kernel — so every scene gets helpers of its own:
+  // what is left of `want`, at least half of it)
+  const uint32_t helpers = want > rows + want / 2 ? want - rows : want / 2;
+  const dim3 grid(rows + helpers, 1, ns);
   const uint32_t rw = rows | (no_mid ? 0x80000000u : 0u) | (words ? 0x40000000u : 0u);  // (bit 31: no middle tier; bit 30: re-arm the vote words)
   if (vis && in_lds) return launch_solve_one<true, NT, CPT, true>(grid, rw, lds, st, scenes);
   if (vis) return launch_solve_one<true, NT, CPT, false>(grid, rw, lds, st, scenes);
