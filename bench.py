@@ -236,13 +236,17 @@ def pmc_traffic(workload: str, kernel: str):
     scripts/pmc_traffic.sh on the GPU box: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as the gfx950 guide says).
     Counters cannot be read from inside this process; None when no pass exists for this workload."""
     best = None
-    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json")):
+    files = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
+    newest_round = files[-1].name.split("_")[0] if files else None
+    for f in files:
         try:
             d = json.loads(f.read_text())["workloads"].get(workload, {}).get(kernel)
         except Exception:
             d = None
         if d:
-            best = (d["hbm_bytes"], f.name)
+            # (a pass of an EARLIER round than the newest committed one says nothing about this tree's launch — tile orders and kernels
+            # change between rounds: it is reported, but labelled as stale)
+            best = (d["hbm_bytes"], f.name, f.name.split("_")[0] != newest_round)
     return best
 
 
@@ -966,6 +970,8 @@ def main():
             tr = pmc_traffic(args.workload, dom)
             if tr:
                 roof["traffic"], roof["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH + WRITE bytes per launch)"
+                if tr[2]:
+                    roof["traffic_stale"] = "measured in an earlier round than the newest committed PMC pass: not this tree's launch"
             if dom in models:
                 roof["algorithmic"] = models[dom][1] / per_step(dom)
                 roof["algorithmic_unit"] = "flop per launch" if models[dom][0] in ("mfma", "valu") else "bytes per launch"

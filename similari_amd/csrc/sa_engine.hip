@@ -1671,6 +1671,11 @@ int sa_batch_sync(sa_engine* e) {
   return engine_sync(e);
 }
 
+// (a wait of the assignment tail ran out: whatever the frame left half-way — queues, the dense solver's matrix — is re-established
+// before the bank's slots run again)
+static void bank_mark_dirty(Bank* b) {
+  for (uint32_t i = 0; i < b->n_slots; ++i) b->slots[i]->needs_init = true;
+}
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_batch_fetch"));
@@ -1686,7 +1691,7 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
     // (k_assign_solve's waits for the scene's row workgroups are bounded: a wait that ran out — the launch's workgroups were not all
     // resident, e.g. a partitioned or heavily shared device — leaves a mark instead of a hung queue)
     const uint32_t* st4 = (const uint32_t*)(h + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
-    if (s->N && st4[1]) return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the frame's results are not valid");
+    if (s->N && st4[1]) { bank_mark_dirty(e->B); return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the frame's results are not valid"); }
   }
   if (out_track_id) std::memcpy(out_track_id, h, (size_t)s->N * 8);
   if (out_voting_type) std::memcpy(out_voting_type, h + (size_t)s->N * 8, s->N);
@@ -1728,8 +1733,10 @@ int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id,
   } else if (!e->synced) TRY(engine_sync(e));
   const uint8_t* h = (const uint8_t*)s->h_out.p;
   const size_t n1 = s->N ? s->N : 1, st_off = (n1 * 9 + 7) & ~(size_t)7;
-  if (s->N && ((const uint32_t*)(h + st_off))[1])
+  if (s->N && ((const uint32_t*)(h + st_off))[1]) {
+    bank_mark_dirty(e->B);
     return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the frame's results are not valid");
+  }
   if (out_track_id) *out_track_id = (const uint64_t*)h;
   if (out_voting_type) *out_voting_type = h + n1 * 8;
   if (out_cols) *out_cols = (const int32_t*)(h + st_off + 16);
@@ -1860,7 +1867,8 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     const Slot* s = b->slots[i];
     const uint8_t* h = (const uint8_t*)s->h_out.p;
-    if (s->N && ((const uint32_t*)(h + (((size_t)s->N * 9 + 7) & ~(size_t)7)))[1])   // (see sa_batch_fetch)
+    if (s->N && ((const uint32_t*)(h + (((size_t)s->N * 9 + 7) & ~(size_t)7)))[1]) bank_mark_dirty(b);   // (see sa_batch_fetch)
+    if (s->N && ((const uint32_t*)(h + (((size_t)s->N * 9 + 7) & ~(size_t)7)))[1])
       return fail(e, SA_ERR_HIP, "the assignment tail gave up waiting for its row workgroups: the results of ticket %llu are not valid", (unsigned long long)ticket);
     if (res[i].out_track_id) std::memcpy(res[i].out_track_id, h, (size_t)s->N * 8);
     if (res[i].out_voting_type) std::memcpy(res[i].out_voting_type, h + (size_t)s->N * 8, s->N);

@@ -66,12 +66,16 @@ struct XcdOrder { uint32_t chunk, W; };
 static inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool row_major = false) {
   XcdOrder o;
   const uint32_t tiles = gx * gy;
-  if (row_major) { o.chunk = tiles; o.W = 0; return o; }  // the default: W = 0 -> workgroup b is tile b, row by row
+  if (row_major || tiles >= (1u << 24)) { o.chunk = tiles; o.W = 0; return o; }  // the default: W = 0 -> workgroup b is tile b, row by row
   o.chunk = (tiles + 7u) / 8u;
   uint32_t w = 1;
   while ((w + 1) * (w + 1) <= o.chunk) ++w;   // ~ sqrt(chunk): square-ish blocks
   o.W = w < gx ? w : gx;
   if (o.W == 0) o.W = 1;
+  // (the kernels take the pair packed as chunk << 8 | W: any band width is a valid one — 255 at most; a grid beyond 2^24 chunks — half
+  // a million tracks against as many detections — falls back to the row-by-row numbering, which the launchers handle with W = 0)
+  if (o.W > 255u) o.W = 255u;
+  if (o.chunk >= (1u << 24)) { o.chunk = tiles; o.W = 0; }
   return o;
 }
 __device__ __forceinline__ bool xcd_tile(uint32_t b, uint32_t gx, uint32_t gy, uint32_t chunk, uint32_t W, uint32_t* bx, uint32_t* by) {

@@ -13,9 +13,6 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -42,38 +39,6 @@ class SaPool {
     std::vector<int> cpus;
     int at = -1;
 #if defined(__linux__)
-    const char* mode = getenv("SA_POOL_AFFINITY");   // experiment hook: "node" = every worker anywhere on the caller's NUMA node
-    if (pin && mode && !strcmp(mode, "node")) {
-      const int here = sched_getcpu();
-      cpu_set_t set;
-      CPU_ZERO(&set);
-      int found = 0;
-      for (int node = 0; node < 16 && !found; ++node) {
-        char path[96];
-        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-        FILE* f = fopen(path, "r");
-        if (!f) break;
-        char buf[512] = {0};
-        if (fgets(buf, sizeof buf, f)) {
-          cpu_set_t ns;
-          CPU_ZERO(&ns);
-          bool mine = false;
-          for (char* p = buf; *p;) {
-            int a = (int)strtol(p, &p, 10), b = a;
-            if (*p == '-') b = (int)strtol(p + 1, &p, 10);
-            for (int c = a; c <= b; ++c) { CPU_SET(c, &ns); mine = mine || c == here; }
-            while (*p == ',' || *p == '\n') ++p;
-          }
-          if (mine) { set = ns; found = 1; }
-        }
-        fclose(f);
-      }
-      for (uint32_t w = 0; w < workers; ++w) {
-        th_.emplace_back([this, w] { loop(w); });
-        if (found) pthread_setaffinity_np(th_.back().native_handle(), sizeof set, &set);
-      }
-      return;
-    }
     if (pin) {
       cpu_set_t allowed;
       CPU_ZERO(&allowed);

@@ -491,3 +491,132 @@ def test_a_recycled_ticket_is_refused_not_misread():
         assert eng.tap_dims(0)[0] == len(scs[3]["det_boxes"])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("visual", [False, True])
+def test_request_set_staged_collected_and_evicted_on_several_threads(visual):
+    """The entry points Batch*::predict spreads over threads, straight through the C ABI: sa_batch_add_deferred + sa_batch_fill (slots
+    filled from a thread pool), sa_batch_results (zero-copy views), sa_tracks_apply_collect_begin / _slot / _end (slots collected from a
+    thread pool), sa_tracks_remove_stage / _commit and sa_tracks_remove_many (several scenes' tables compacted by ONE launch) — against
+    a second engine driven through the serial entry points (sa_batch_add, sa_batch_fetch, sa_tracks_apply_collect, sa_tracks_remove):
+    same winners, ids, predicted boxes and tables, frame after frame."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(131 + visual)
+    d, S = 64, 14                                            # (14 scenes: the gathers of one removal go out as two launches of 12 + 2)
+    cfg = (visual_cfg(d, k=2, visual_minimal_quality_collect=0.4) if visual else abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5))
+    u64p, u8p, i32p, boxp = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(abi.sa_box)
+    scenes = [3 + 5 * s for s in range(S)]
+    world = {sc: synth.dense_boxes(rng, 30 + sc % 7, (800.0, 600.0), oriented=(sc % 4 == 0)) for sc in scenes}
+    ident = {sc: synth.reid_identities(rng, 120, d) for sc in scenes}
+    a, b = Engine(cfg), Engine(cfg)
+    pool = ThreadPoolExecutor(max_workers=6)
+    try:
+        nxt_id = [0, 0]
+        for f in range(5):
+            items = []
+            for sc in scenes:
+                world[sc] = np.concatenate([synth.jitter_boxes(rng, world[sc], 1.5, angle_sigma=0.02 if sc % 4 == 0 else 0.0),
+                                            synth.dense_boxes(rng, 2, (800.0, 600.0), oriented=(sc % 4 == 0))])
+                n = len(world[sc])
+                kw = dict(feats=synth.observe(rng, ident[sc][:n]), feat_quality=rng.uniform(0.2, 1.0, n).astype(np.float32)) if visual else {}
+                items.append((sc, f + 1, abi.make_detections(world[sc], **kw)))
+            bases = []
+            for e_i in (0, 1):
+                acc, bs = nxt_id[e_i], []
+                for sc, ep, det in items:
+                    bs.append(acc)
+                    acc += det.n
+                bases.append(np.array(bs, np.uint64))
+            # serial reference on engine a
+            a.batch_begin()
+            slots_a = [a.batch_add(sc, ep, det) for sc, ep, det in items]
+            a._chk(a.lib.sa_batch_run_apply(a.h, bases[0].ctypes.data_as(u64p), 1))
+            a.batch_sync()
+            ref = []
+            for sl, (sc, ep, det) in zip(slots_a, items):
+                ids, votes = a.batch_fetch(sl, det.n)
+                cols = np.zeros(det.n, np.int32)
+                a._chk(a.lib.sa_batch_fetch_cols(a.h, sl, cols.ctypes.data_as(i32p)))
+                nid, pred = np.zeros(det.n, np.uint64), np.zeros(det.n, abi.BOX_DTYPE)
+                a._chk(a.lib.sa_tracks_apply_collect(a.h, sl, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp)))
+                ref.append((ids, votes, cols, nid, pred))
+            # engine b: deferred adds, fills / collects on the pool
+            b.batch_begin()
+            slots_b = []
+            for sc, ep, det in items:
+                sl = C.c_uint32()
+                b._chk(b.lib.sa_batch_add_deferred(b.h, sc, ep, C.byref(det), None, C.byref(sl)))
+                slots_b.append(sl.value)
+            if f == 1:   # a slot that was never filled is refused by the run, and the set is still usable once it is
+                rc = b.lib.sa_batch_run_apply(b.h, bases[1].ctypes.data_as(u64p), 1)
+                assert rc == abi.SA_ERR_STATE and b"sa_batch_fill" in b.lib.sa_last_error(b.h)
+            assert all(rc == 0 for rc in pool.map(lambda sl: b.lib.sa_batch_fill(b.h, sl), slots_b))
+            b._chk(b.lib.sa_batch_run_apply(b.h, bases[1].ctypes.data_as(u64p), 1))
+
+            def view(sl_n):
+                sl, n = sl_n
+                pi, pv, pc = u64p(), u8p(), i32p()
+                rc = b.lib.sa_batch_results(b.h, sl, C.byref(pi), C.byref(pv), C.byref(pc))
+                assert rc == 0, b.lib.sa_last_error(b.h)
+                return (np.ctypeslib.as_array(pi, (n,)).copy(), np.ctypeslib.as_array(pv, (n,)).copy(), np.ctypeslib.as_array(pc, (n,)).copy()) if n else \
+                       (np.zeros(0, np.uint64), np.zeros(0, np.uint8), np.zeros(0, np.int32))
+            views = list(pool.map(view, [(sl, det.n) for sl, (_, _, det) in zip(slots_b, items)]))
+            b._chk(b.lib.sa_tracks_apply_collect_begin(b.h))
+
+            def collect(sl_n):
+                sl, n = sl_n
+                nid, pred = np.zeros(n, np.uint64), np.zeros(n, abi.BOX_DTYPE)
+                rc = b.lib.sa_tracks_apply_collect_slot(b.h, sl, nid.ctypes.data_as(u64p), C.cast(pred.ctypes.data, boxp))
+                assert rc == 0, b.lib.sa_last_error(b.h)
+                return nid, pred
+            got = list(pool.map(collect, [(sl, det.n) for sl, (_, _, det) in zip(slots_b, items)]))
+            b._chk(b.lib.sa_tracks_apply_collect_end(b.h))
+            for k, ((ids, votes, cols, nid, pred), (vi, vv, vc), (nid_b, pred_b)) in enumerate(zip(ref, views, got)):
+                np.testing.assert_array_equal(vi, ids, err_msg=f"frame {f} slot {k}")
+                np.testing.assert_array_equal(vv, votes)
+                np.testing.assert_array_equal(vc, cols)
+                np.testing.assert_array_equal(nid_b, nid)
+                np.testing.assert_array_equal(pred_b.view(np.uint8), pred.view(np.uint8))
+            for e_i in (0, 1):
+                nxt_id[e_i] += sum(det.n for _, _, det in items)
+            # every other frame: the tracks that did not continue leave the tables of ALL scenes — one call on b (staged on the pool where
+            # the scene allows it), one call per scene on a
+            if f % 2 == 1:
+                lists = []
+                for sc in scenes:
+                    order = a.order(sc)
+                    gone = order[: max(1, len(order) // 4)]
+                    lists.append(np.ascontiguousarray(gone, np.uint64))
+                    a._chk(a.lib.sa_tracks_remove(a.h, sc, len(gone), gone.ctypes.data_as(u64p)))
+                if f == 1:
+                    b.batch_sync()   # (a drained engine: every scene can be staged off the calling thread)
+                    rcs = list(pool.map(lambda k: b.lib.sa_tracks_remove_stage(b.h, scenes[k], len(lists[k]), lists[k].ctypes.data_as(u64p)), range(S)))
+                    assert all(rc == abi.SA_OK for rc in rcs), rcs
+                    rest = []
+                else:
+                    rest = list(range(S))
+                if rest:
+                    sid = np.array([scenes[k] for k in rest], np.uint64)
+                    cnt = np.array([len(lists[k]) for k in rest], np.uint32)
+                    ptrs = (u64p * len(rest))(*[lists[k].ctypes.data_as(u64p) for k in rest])
+                    b._chk(b.lib.sa_tracks_remove_many(b.h, len(rest), sid.ctypes.data_as(u64p), cnt.ctypes.data_as(C.POINTER(C.c_uint32)), ptrs))
+                else:
+                    b._chk(b.lib.sa_tracks_remove_commit(b.h))
+            for sc in scenes:
+                np.testing.assert_array_equal(b.order(sc), a.order(sc), err_msg=f"frame {f} scene {sc}")
+                np.testing.assert_array_equal(b.tap_track_polygons(sc).view(np.uint64), a.tap_track_polygons(sc).view(np.uint64))
+        # a scene listed twice, an unknown id: refused, and nothing has changed
+        two = np.array([scenes[0], scenes[0]], np.uint64)
+        one = np.ascontiguousarray(a.order(scenes[0])[:1], np.uint64)
+        ptr2 = (u64p * 2)(one.ctypes.data_as(u64p), one.ctypes.data_as(u64p))
+        assert b.lib.sa_tracks_remove_many(b.h, 2, two.ctypes.data_as(u64p), np.array([1, 1], np.uint32).ctypes.data_as(C.POINTER(C.c_uint32)), ptr2) == abi.SA_ERR_BAD_ARG
+        bad = np.array([2 ** 60], np.uint64)
+        assert b.lib.sa_tracks_remove_stage(b.h, scenes[1], 1, bad.ctypes.data_as(u64p)) == abi.SA_ERR_NOT_FOUND
+        b._chk(b.lib.sa_tracks_remove_commit(b.h))
+        for sc in scenes:
+            np.testing.assert_array_equal(b.order(sc), a.order(sc))
+    finally:
+        pool.shutdown(wait=True)
+        a.close()
+        b.close()
