@@ -4,7 +4,7 @@
 # tracker loop, and — last, because they rebuild the library with the trace hooks — the in-kernel timelines.
 #   scripts/profile_round.sh <tag>        outputs under gpurun_out/<tag>/ — copy what is to be judged into profiles/
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-TAG=${1:-r04_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+TAG=${1:-r05_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 # 1. kernel stats: the DEFAULT command first (the driver's line), then the other workloads
@@ -25,7 +25,7 @@ timeout 300 python bench.py --flags 32 --no-cpu-baseline > $O/bench_c2_separate.
 timeout 300 python bench.py --flags 32768 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2_row_tiles.json 2> $O/bench_c2_row_tiles.err
 timeout 300 python bench.py --workload c2b --gemm-plan 1 --steps 50 --warmup 5 --profile-iters 10 --no-cpu-baseline --no-oracle --no-h2d > $O/bench_c2b_fused64.json 2> $O/bench_c2b_fused64.err
 # 3. HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes); C2 also with its tiles row by row (SA_FLAG_ROW_TILES)
-for w in c2 c2b c5 c4; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
+for w in c2 c2b c5 c4 c2e c2t c2k3; do bash scripts/pmc_traffic.sh $w ${TAG}_$w > $O/pmc_traffic_$w.log 2>&1; cp gpurun_out/pmc_${TAG}_$w/summary.json $O/pmc_traffic_$w.json 2>/dev/null; done
 SA_BENCH_FLAGS=32768 bash scripts/pmc_traffic.sh c2 ${TAG}_c2row > $O/pmc_traffic_c2_row_tiles.log 2>&1; cp gpurun_out/pmc_${TAG}_c2row/summary.json $O/pmc_traffic_c2_row_tiles.json 2>/dev/null
 # 4. MFMA utilisation of the contraction (C2 default line, c2b and C5)
 for w in c2 c2b c5; do
@@ -53,6 +53,19 @@ done
 # 5. the tracker loop (plain and churned) and where a predict() spends its time
 timeout 600 python scripts/bench_tracker.py 1000 512 30 > $O/tracker_loop.jsonl 2> $O/tracker_loop.err; cat $O/tracker_loop.jsonl
 bash scripts/tracker_trace.sh "visual,device,0.0" "visual,pinned,0.0" "sort,rows,0.0" "visual,device,0.05" "sort,rows,0.05" > $O/tracker_breakdown.txt 2>&1; cat $O/tracker_breakdown.txt
+# 5b. Batch*::predict through the facade: per call, per phase, device timelines (scripts/gpu_batch.sh without its tests)
+J=$O/batch_tracker.jsonl; : > $J
+brun() { timeout 300 python scripts/bench_batch_tracker.py "$@" >> $J 2>> $O/batch_err.txt || echo "bench_batch_tracker $* failed"; }
+brun sort 8 500 0 60 0 sync; brun sort 8 500 0 60 1 sync; brun sort 8 500 0 60 0 async
+brun sort 64 500 0 60 0 sync; brun sort 64 500 0 60 1 sync; brun sort 64 500 0 60 8 sync; brun sort 64 500 0 60 0 async
+brun visual 8 1000 512 24 0 sync device; brun visual 8 1000 512 24 1 sync device; brun visual 8 1000 512 24 0 sync rows; brun visual 8 1000 512 24 0 async device
+cat $J
+scripts/batch_tracker_timeline.sh ${TAG}_s8 sort 8 500 0 40 0 sync > $O/batch_tracker_timeline_sort8.txt 2>&1
+scripts/batch_tracker_timeline.sh ${TAG}_s64 sort 64 500 0 24 0 sync > $O/batch_tracker_timeline_sort64.txt 2>&1
+scripts/batch_tracker_timeline.sh ${TAG}_v8 visual 8 1000 512 24 0 sync device > $O/batch_tracker_timeline_visual8.txt 2>&1
+tail -n 8 $O/batch_tracker_timeline_*.txt
+# 5c. the giant components: where a search step's time goes (k_assign_solve's timeline; rebuilds with -DSA_TAIL_TRACE)
+bash scripts/solve_trace.sh giant bigcrowd sdt > $O/solve_trace.txt 2>&1; tail -30 $O/solve_trace.txt
 # 6. in-kernel timelines (rebuilds the library with -DSA_POS_TRACE -DSA_GEMM_TRACE) + the launch floor
 bash scripts/gpu_trace.sh ${TAG}_trace "c4 c3 c1" "c2 c2t" > $O/trace.log 2>&1; cp gpurun_out/${TAG}_trace/*.txt $O/ 2>/dev/null; tail -45 $O/trace.log
 echo DONE
