@@ -5,12 +5,15 @@ A step = one pass of the hot path (pair pre-filter + cost matrices + quantise + 
   N = 1 (default): BASELINE C2, one scene-frame whose inputs are already resident in HBM (value = value_resident; value_h2d = the
       same frame ingested from host buffers every step).
   N > 1: scenes are independent (compatible() is false across scene ids, sort.rs:251), so the path shards by scene.  The default
-      workload becomes its batched form: a FIXED set of 64 scenes of the C2 frame split scene_id % N (strong scaling); a step = rank 0
-      scatters the request set (RCCL), every rank runs its share, one gather — `value` = total cells / that wall time.  The per-rank
-      replay with resident inputs stays beside it as value_resident.  Workloads that are one frame (c4, c5, ...) are replicated per
-      rank instead ("weak", no data-path collective) and carry the scatter / gather pass as the side object `dispatch`.
+      workload becomes its batched form: a FIXED set of 64 scenes of the C2 frame split scene_id % N (strong scaling).  `value` = local
+      ingest: every rank owns the detections of ITS scenes — a step = each rank stages its boxes (feature rows resident in HBM), runs
+      its share, and the ids / vote types are gathered on rank 0 (RCCL), total cells / wall time, maximum over ranks.  Beside it:
+      value_h2d (feature rows in pinned host blocks), value_scatter (rank 0 packs and scatters the whole request set: one ingest
+      point), value_resident (the per-rank replay), and BASELINE's multi-GPU configuration as `c3_batchsort`.  Workloads that are one
+      frame (c4, c5, ...) are replicated per rank instead ("weak", no data-path collective) and carry the scatter / gather pass as the
+      side object `dispatch`.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2b|c2t|c3|c4|c5|...] [--scenes S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2b|c2t|c3|c4|c5|...] [--scenes S] [--ingest local|scatter|both]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
