@@ -119,8 +119,9 @@ typedef struct sa_config {
 
 #define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */
 /* First phase of a VisualSORT frame.  By default the engine puts the contraction's tiles, the positional tiles and the preparation
- * blocks into ONE heterogeneous launch whenever that applies (cosine, frames of at most 1024 detections that run as 64x64 tiles,
- * feature length a multiple of 32) — one dependent launch less per frame — and otherwise runs them as two launches. */
+ * blocks into ONE heterogeneous launch whenever that applies (cosine, or euclidean through the matrix-core expansion; frames of any
+ * size whose contraction runs as 64x64 tiles — up to two tiles per compute unit, or banks of 2..8 observations through whole-track
+ * tiles; feature length a multiple of 32) — one dependent launch less per frame — and otherwise runs them as two launches. */
 #define SA_FLAG_FUSED_FRAME 0x10u     /* ask for the heterogeneous launch explicitly (same as the default) */
 #define SA_FLAG_SEPARATE_FRAME 0x20u  /* always two launches: the contraction runs as a kernel of its own (per-kernel measurements) */
 #define SA_FLAG_GRAPH 0x8u          /* capture the per-frame launches into a hipGraph and replay it while the staged set is unchanged */

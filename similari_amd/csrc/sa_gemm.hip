@@ -60,7 +60,9 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // MEASURED (round 4, SA_FLAG_XCD_TILES; profiles/r04_*): FETCH_SIZE of the C2 launch 19.1 -> 15.3 MB, the frame no faster (20.42 against
 // 20.48 us; the launch itself 17.6 against 16.5 us between its own timestamps), c2b's stand-alone contraction 92.3 -> 91.0 us, C5's
 // 634 -> 657 us (bands of 12 x 128 tracks x 16 KB overflow the 4 MB L2 that a row-by-row walk keeps one candidate panel in): the HBM
-// traffic is not what bounds these launches (1.1 TB/s at C5), so the order stays row by row and this one is an option.
+// traffic is not what bounds these launches (1.1 TB/s at C5).  Since round 4 the FUSED first phase numbers its contraction tiles this way
+// by default (the same speed on every workload that takes it, a fifth fewer L2 fills; SA_FLAG_ROW_TILES: row by row); the stand-alone
+// contraction stays row by row (SA_FLAG_XCD_TILES: this order there too).
 // b in [0, 8 chunk) -> tile number t = (b % 8) chunk + b / 8 (t >= tiles: an idle workgroup); t -> (row, column).
 struct XcdOrder { uint32_t chunk, W; };
 static inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool row_major = false) {
