@@ -821,9 +821,10 @@ def main():
     local = None
     local_c3 = None
     if dist is not None and facade is None and fixed_set and args.ingest in ("local", "both"):
-        local = local_ingest(wname, total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, max(args.steps, 30))
+        # (EXACTLY K steps between the barriers, as for every timed region of this file)
+        local = local_ingest(wname, total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, args.steps)
         if wname == "c2b":   # BASELINE's multi-GPU configuration beside the headline one: 64 scenes x 500 x 500 BatchSORT (KB-scale ingest)
-            local_c3 = local_ingest("c3", total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, max(args.steps, 30))
+            local_c3 = local_ingest("c3", total_scenes, world, rank, local_rank, dist, barrier, max_over_ranks, args.steps)
     dispatch = None
     if dist is not None and facade is None and (args.ingest in ("scatter", "both") or not fixed_set):
         from similari_amd import sharding

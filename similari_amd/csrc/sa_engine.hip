@@ -260,6 +260,9 @@ int dev_ensure(sa_engine* e, DevBuf& b, size_t bytes, bool keep = false) {
 }
 int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return SA_OK;
+  // (a (re)allocation may come from a thread of the caller's pool — sa_tracks_apply_collect_slot, sa_tracks_remove_stage —, whose current
+  // device is not necessarily the engine's: the mapping belongs to the engine's device)
+  if (e && hipSetDevice(e->device) != hipSuccess) (void)hipGetLastError();
   if (b.p) hipHostFree(b.p);
   b.p = nullptr;
   b.cap = 0;
