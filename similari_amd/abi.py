@@ -450,6 +450,46 @@ PROTOTYPES = {
 }
 
 
+def hip_runtimes_mapped() -> list[str]:
+    """Paths of the libamdhip64 images mapped into this process (one is healthy; two runtimes in one process do not see each other's
+    devices, streams or pointers)."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                path = ln.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64" in path and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def share_torchs_hip_runtime() -> str | None:
+    """ONE HIP runtime per process.  A PyTorch-ROCm wheel ships a libamdhip64 of its own and its libraries ask for it by FILE name
+    ("libamdhip64.so"), this library asks for the SONAME ("libamdhip64.so.7"): with torch loaded first the loader hands torch's copy to
+    both; with this library loaded first it takes /opt/rocm's and torch then loads its own beside it — and the second runtime to start
+    finds the devices taken ("No HIP GPUs are available"), let alone shares a registered feature buffer or a stream with the first.  So,
+    before libsimilari_assoc.so is loaded and when no HIP runtime is mapped yet, the copy a torch installed in this interpreter would
+    bring is loaded up front (found through the import machinery, torch itself is NOT imported) — either order then runs on one
+    runtime.  SA_HIP_RUNTIME=system keeps the system's runtime (a process that never starts torch's GPU side)."""
+    if os.environ.get("SA_HIP_RUNTIME", "") == "system" or hip_runtimes_mapped():
+        return None
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if not cand.exists():
+        return None
+    C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    return str(cand)
+
+
 def load_library(path: os.PathLike | None = None) -> C.CDLL:
     """Load libsimilari_assoc.so and attach prototypes. Fails loudly when it is not built."""
     p = Path(path) if path else LIB_PATH
@@ -458,6 +498,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
             f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback."
         )
+    share_torchs_hip_runtime()
     lib = C.CDLL(str(p))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift

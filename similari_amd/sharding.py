@@ -586,11 +586,13 @@ class ResultGather:
 
     Wire: ids[rows] (u64) | votes[rows] (u8), rows = this rank's detections in scene order; `capacity_rows` bounds them on every rank."""
 
-    def __init__(self, capacity_rows: int, group=None, root: int = 0, device=None, depth: int = 3):
+    def __init__(self, capacity_rows: int, group=None, root: int = 0, device=None, depth: int = 3, loopback: bool = False):
+        """loopback: issue the gather in a group of ONE rank as well (a test of the backend's path on a single GPU)."""
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist, self.group, self.root = torch, dist, group, root
+        self.loopback = bool(loopback)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -602,6 +604,9 @@ class ResultGather:
         self.recv = ([[torch.zeros(nb, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
                      if self.rank == root else [None] * depth)
         self.work = [None] * depth
+        # (GPU backends: Work.wait() orders STREAMS, not the host — the host may only rewrite a pinned staging row once the copy that
+        # read it has actually run: an event behind every copy, synchronised before the row's next use)
+        self.copied = [torch.cuda.Event() for _ in range(depth)] if pin else None
         self.rows = [0] * depth
         self.at = 0
         self.steps = 0
@@ -613,6 +618,8 @@ class ResultGather:
         if self.work[k] is not None:
             self.work[k].wait()
             self.work[k] = None
+            if self.copied is not None:
+                self.copied[k].synchronize()
         buf = self.h[k].numpy()
         o = 0
         for ids, votes in outs:
@@ -625,7 +632,8 @@ class ResultGather:
         self.rows[k] = o
         if self.d is not self.h:
             self.d[k].copy_(self.h[k], non_blocking=True)
-        if self.world > 1:
+            self.copied[k].record()
+        if self.world > 1 or self.loopback:
             self.work[k] = self.dist.gather(self.d[k], self.recv[k], dst=self.root, group=self.group, async_op=True)
         self.at = (k + 1) % len(self.h)
         self.steps += 1
@@ -644,7 +652,7 @@ class ResultGather:
         k = (self.at - 1) % len(self.h)
         out = []
         for r in range(self.world):
-            raw = (self.recv[k][r] if self.world > 1 else self.d[k]).cpu().numpy()
+            raw = (self.recv[k][r] if self.world > 1 or self.loopback else self.d[k]).cpu().numpy()
             n = int(rows_per_rank[r])
             out.append((raw[: 8 * n].view(np.uint64).copy(), raw[8 * self.cap: 8 * self.cap + n].copy()))
         return out

@@ -113,3 +113,19 @@ def test_every_prototype_of_the_python_binding_is_declared_in_a_header():
     bound = set(abi.PROTOTYPES)
     decl = set(declared("similari_assoc.h")) | set(declared("similari_tracker.h"))
     assert bound == decl, (sorted(bound - decl), sorted(decl - bound))
+
+
+@pytest.mark.parametrize("order", ["engine_first", "torch_first"])
+def test_one_hip_runtime_in_the_process_whichever_is_loaded_first(order):
+    """abi.load_library and PyTorch-ROCm end up on ONE libamdhip64 image in either order (abi.share_torchs_hip_runtime: a second runtime
+    in the process would start without devices — "No HIP GPUs are available" — and could not read the first one's feature buffers)."""
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    first, second = ("lib = abi.load_library()", "import torch") if order == "engine_first" else ("import torch", "lib = abi.load_library()")
+    code = f"from similari_amd import abi\n{first}\n{second}\nm = abi.hip_runtimes_mapped()\nprint(len(m), m)"
+    root = str(Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[0] == "1", r.stdout

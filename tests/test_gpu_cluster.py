@@ -144,6 +144,34 @@ def test_sharded_batch_tracker_over_the_hip_batch_sort():
         ora.close()
 
 
+def test_result_gather_over_rccl_in_a_group_of_one():
+    """similari_amd.sharding.ResultGather on its GPU path — pinned staging rows, the copy to device rows on torch's stream, an asynchronous
+    `dist.gather` over RCCL, rows reused `depth` pushes later — in an RCCL group of this one rank (loopback=True makes the gather happen);
+    more pushes than rows in flight, every step's payload distinct, the last one read back at the root."""
+    import torch
+
+    dist = _init_single_rank_group()
+    torch.cuda.set_device(0)
+    g = dist.new_group(ranks=[0], backend="nccl")
+    try:
+        rg = sharding.ResultGather(300, group=g, loopback=True, depth=3)
+        assert rg.device.type == "cuda" and rg.copied is not None
+        rng = np.random.default_rng(93)
+        sent = None
+        for step in range(11):
+            outs = [(rng.integers(0, 2**63, n, dtype=np.uint64), rng.integers(0, 2, n).astype(np.uint8)) for n in (120, 0, 77, 100)]
+            rg.push(outs)
+            sent = outs
+        rg.drain()
+        (ids, votes), = rg.last([297])
+        np.testing.assert_array_equal(ids, np.concatenate([o[0] for o in sent]))
+        np.testing.assert_array_equal(votes, np.concatenate([o[1] for o in sent]))
+        with pytest.raises(ValueError):
+            rg.push([(np.zeros(301, np.uint64), np.zeros(301, np.uint8))])
+    finally:
+        dist.destroy_process_group(g)
+
+
 @pytest.mark.parametrize("workload", ["c3", "c2"])
 def test_bench_under_torchrun_takes_the_rccl_branch(workload):
     """bench.py the way the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), here with ONE rank
