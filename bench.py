@@ -687,8 +687,14 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU, each on its own share of the host's cores (pinned staging rows and pool threads on the rank's socket,
+        # no two ranks' workers on one core): similari_amd.sharding.cpu_share
+        from similari_amd import sharding as _sh
+
+        rank_cpus = _sh.bind_rank_to_cpu_share(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     else:
         dist = None
+        rank_cpus = []
         torch.cuda.set_device(local_rank)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -1054,6 +1060,8 @@ def main():
             out["cluster"] = cluster
         if dispatch is not None:
             out["dispatch"] = dispatch
+        if world > 1:
+            out["cpus_of_rank0"] = len(rank_cpus)   # (0: the process was left where the launcher put it)
         if local is not None:
             out["ingest_local"] = local
         if local_c3 is not None:

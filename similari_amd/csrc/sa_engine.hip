@@ -258,6 +258,11 @@ int dev_ensure(sa_engine* e, DevBuf& b, size_t bytes, bool keep = false) {
   b.cap = ncap;
   return SA_OK;
 }
+// Entry points that a thread of the caller's pool may run (the facade's scene jobs, its result driver) or that only wait / copy: the
+// thread's current device is whatever its creator left (device 0 on a fresh thread), the engine's resources live on e->device.
+static inline void bind_device(sa_engine* e) {
+  if (hipSetDevice(e->device) != hipSuccess) (void)hipGetLastError();
+}
 int host_ensure(sa_engine* e, HostBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return SA_OK;
   // (a (re)allocation may come from a thread of the caller's pool — sa_tracks_apply_collect_slot, sa_tracks_remove_stage —, whose current
@@ -1366,6 +1371,7 @@ static bool upkeep_pending(const sa_engine* e) {
 }
 int sa_tracks_remove_stage(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids) {
   if (!e || (n && !ids)) return fail(e, SA_ERR_BAD_ARG, "sa_tracks_remove_stage: null argument");
+  bind_device(e);
   if (upkeep_pending(e)) return SA_ERR_STATE;   // (an upkeep step has yet to be collected: the serial sa_tracks_remove_many finishes it first)
   SceneTable* sc = get_scene(e, scene_id, false);
   if (!sc) return fail(e, SA_ERR_NOT_FOUND, "unknown scene %llu", (unsigned long long)scene_id);
@@ -1642,6 +1648,7 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
   const uint32_t N = d->n;
   if (N && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
   for (uint32_t i = 0; i < N; ++i) TRY(check_box(e, d->boxes[i], "detections.boxes", i));
+  bind_device(e);
   return bank_add(e, e->B, scene_id, epoch, d, feat_rows, out_slot);
 }
 
@@ -1651,10 +1658,12 @@ int sa_batch_add_rows(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_
 int sa_batch_add_deferred(sa_engine* e, uint64_t scene_id, uint64_t epoch, const sa_detections* d, const float* const* feat_rows, uint32_t* out_slot) {
   if (!e || !d) return fail(e, SA_ERR_BAD_ARG, "sa_batch_add_deferred: null argument");
   if (d->n && !d->boxes) return fail(e, SA_ERR_BAD_ARG, "detections.boxes is null");
+  bind_device(e);
   return bank_add(e, e->B, scene_id, epoch, d, feat_rows, out_slot, true);
 }
 int sa_batch_fill(sa_engine* e, uint32_t slot) {
   if (!e) return SA_ERR_BAD_ARG;
+  bind_device(e);
   Bank* b = e->B;
   if (slot >= b->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, b->n_slots);
   Slot* s = b->slots[slot];
@@ -1682,6 +1691,7 @@ static void bank_mark_dirty(Bank* b) {
 int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t* out_voting_type) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_batch_fetch"));
+  bind_device(e);
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch before sa_batch_run");
@@ -1705,6 +1715,7 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
 int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_batch_fetch_cols"));
+  bind_device(e);
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!out_cols && s->N) return fail(e, SA_ERR_BAD_ARG, "sa_batch_fetch_cols: null argument");
@@ -1724,6 +1735,7 @@ int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
 int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id, const uint8_t** out_voting_type, const int32_t** out_cols) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_batch_results"));
+  bind_device(e);
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->ran && !s->fused_pending) return fail(e, SA_ERR_STATE, "sa_batch_results before sa_batch_run");
@@ -1858,6 +1870,7 @@ int sa_pipe_submit(sa_engine* e, uint32_t n_scenes, const sa_scene_request* req,
 
 int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
   if (!e) return SA_ERR_BAD_ARG;
+  bind_device(e);
   Bank* b = bank_of_ticket(e, ticket);
   if (!b || (b->state != 2 && b->state != 3))
     return fail(e, SA_ERR_STATE, "ticket %llu has not been launched (or is unknown)", (unsigned long long)ticket);
@@ -2236,6 +2249,7 @@ int sa_tracks_apply_collect_begin(sa_engine* e) {
 }
 int sa_tracks_apply_collect_slot(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted) {
   if (!e) return SA_ERR_BAD_ARG;
+  bind_device(e);
   if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
   Slot* s = e->B->slots[slot];
   if (!s->fused_pending) {

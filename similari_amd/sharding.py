@@ -576,6 +576,60 @@ class ShardedAssociator:
         self.associate(None, shutdown=True)
         self.close()
 
+def cpu_share(local_rank: int, local_world: int, allowed=None, siblings_of=None):
+    """The CPUs of rank `local_rank` of `local_world` processes on one host: the host's PHYSICAL cores (a core = its hardware threads, read
+    from /sys/devices/system/cpu/cpuN/topology), in (package, first thread) order, are dealt out in contiguous runs — low ranks on the
+    first socket, high ranks on the last, the way the GPUs of an 8-GPU node hang off the sockets — and a rank gets every hardware thread of
+    its cores that the process may run on.  Without this the ranks' threads land wherever the scheduler likes: a rank's pinned staging
+    rows on the far socket's memory, and the facade's pool workers (sa_pool.h binds them to the CPUs next to the caller's INSIDE the
+    process's allowed set) of two ranks on the same cores.  Returns a sorted list (empty: leave the process alone)."""
+    import os
+
+    if allowed is None:
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    if local_world <= 1 or not allowed:
+        return []
+    if siblings_of is None:
+        def siblings_of(c):
+            pkg, sib = 0, [c]
+            try:
+                base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+                with open(base + "physical_package_id") as f:
+                    pkg = int(f.read())
+                with open(base + "thread_siblings_list") as f:
+                    sib = []
+                    for part in f.read().strip().split(","):
+                        lo, _, hi = part.partition("-")
+                        sib.extend(range(int(lo), int(hi or lo) + 1))
+            except (OSError, ValueError):
+                pass
+            return pkg, sib
+    ok = set(allowed)
+    cores = {}
+    for c in allowed:
+        pkg, sib = siblings_of(c)
+        sib = tuple(sorted(x for x in sib if x in ok)) or (c,)
+        cores.setdefault((pkg, sib[0]), sib)
+    order = [cores[k] for k in sorted(cores)]
+    if len(order) < local_world:
+        return []
+    lo = (len(order) * local_rank) // local_world
+    hi = (len(order) * (local_rank + 1)) // local_world
+    return sorted(c for sib in order[lo:hi] for c in sib)
+
+
+def bind_rank_to_cpu_share(local_rank: int, local_world: int):
+    """os.sched_setaffinity to cpu_share(); never fatal (a container may forbid it).  Returns the CPUs bound to, or []."""
+    import os
+
+    try:
+        cpus = cpu_share(local_rank, local_world)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError, AttributeError):
+        return []
+
 
 class ResultGather:
     """The ONLY exchange of a multi-GPU run whose ranks ingest their own scenes (a camera's detector feeds the GPU that owns the camera's

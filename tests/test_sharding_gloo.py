@@ -479,3 +479,22 @@ def test_result_gather_delivers_every_ranks_answers_to_the_root(tmp_path):
             votes = np.concatenate([np.full(n, (step + rank + k) % 2, np.uint8) for k, n in enumerate(scenes)])
             np.testing.assert_array_equal(got[f"s{step}_ids{rank}"], ids)
             np.testing.assert_array_equal(got[f"s{step}_v{rank}"], votes)
+
+
+def test_cpu_share_deals_whole_cores_out_socket_by_socket():
+    """sharding.cpu_share: two sockets x four cores x two hardware threads (threads c and c + 8 share a core), four ranks: every rank gets
+    two whole cores of one socket, no CPU twice, nothing left over; CPUs outside the process's allowed set are never handed out."""
+    from similari_amd import sharding
+
+    def sib(c):
+        core = c % 8
+        return (0 if core < 4 else 1), [core, core + 8]
+
+    shares = [sharding.cpu_share(r, 4, allowed=list(range(16)), siblings_of=sib) for r in range(4)]
+    assert shares == [[0, 1, 8, 9], [2, 3, 10, 11], [4, 5, 12, 13], [6, 7, 14, 15]]
+    allowed = [1, 2, 3, 5, 9, 10, 13]                      # a cpuset that cut cores in half
+    shares = [sharding.cpu_share(r, 2, allowed=allowed, siblings_of=sib) for r in range(2)]
+    assert sorted(c for s in shares for c in s) == allowed and not set(shares[0]) & set(shares[1])
+    assert shares == [[1, 2, 9, 10], [3, 5, 13]]                  # four cores left, two each, hardware threads kept together
+    assert sharding.cpu_share(0, 1, allowed=allowed, siblings_of=sib) == []          # one rank: left alone
+    assert sharding.cpu_share(0, 8, allowed=[0, 8], siblings_of=sib) == []           # fewer cores than ranks: left alone
