@@ -140,6 +140,9 @@ typedef struct sa_config {
                                            a launch of its own — measured: c2b no faster, C5 4 % slower (the fused first phase uses that order by default:
                                            C2 20.0 -> 16.1 MB of L2 fills per launch at the same speed); A/B measurements */
 #define SA_FLAG_ROW_TILES 0x8000u       /* the contraction's tiles row by row everywhere, the fused first phase included; A/B measurements */
+#define SA_FLAG_SIGNAL_COMPLETION 0x10000u /* the host always waits for the completion SIGNAL of a frame's last dispatch; by default, where that dispatch is the
+                                             one-workgroup tail, each scene's workgroup stores a completion WORD behind its results (mapped host memory) and
+                                             the host polls it: a dispatch that carries a signal holds the next dispatch of its queue back by ~4.6 us */
 #define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,

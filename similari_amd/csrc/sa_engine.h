@@ -134,6 +134,8 @@ struct SceneDev {
                              // table order finds the winner without a hash lookup per candidate)
   uint32_t SA_G* stats;      // [8] device words: [1] [3] [4] [5] the general tail's list top / queue length / ticket / row workgroups done; [0] = 1 when the frame was ill-conditioned for the euclidean expansion
   uint32_t SA_G* out_stats;  // [4] the same, moved next to the results (mapped host memory) and re-armed by the assignment tail
+  unsigned long long SA_G* out_done;  // one word on a cache line of its own behind the results (mapped host memory): the one-workgroup tail
+                                      // stores its launch's sequence number here once every result of the scene has left (k_assign_small, done_seq)
   int64_t SA_G* quant;  // optional N x T tap
   // SA_FLAG_TAP (parity tests): what the timed launches themselves produced, copied out by the assignment tail before it re-arms /
   // consumes it — the vote words as the first phase left them and the edge counts of the positional tiles (the edge records stay in
@@ -279,8 +281,11 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t
 // them into verdicts, the solver re-arms them); stage 5 = the whole tail in ONE workgroup per scene (requires maxN, maxT <= SA_SMALL_N;
 // 8: with vote words)
 #define SA_SMALL_N 1024
+// done_seq != 0 (stages 5 / 8): every scene's workgroup reports the end of its results itself, by storing done_seq to SceneDev::out_done —
+// the host polls that word instead of waiting for a completion signal of the dispatch (a dispatch that carries one holds the NEXT
+// dispatch of its queue back by ~4.6 us on this stack: scripts/gpu_ab_timeline.sh, NOTES section 0a)
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
-                            const SaParams& p, hipStream_t st, int stage);
+                            const SaParams& p, hipStream_t st, int stage, uint64_t done_seq = 0);
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                hipStream_t st);
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).

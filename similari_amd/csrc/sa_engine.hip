@@ -91,6 +91,7 @@ struct alignas(128) Slot {  // one scene of a request set (aligned: see SceneTab
   void *d_pred = nullptr, *d_apply = nullptr, *d_fix = nullptr;  // device views of the three
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
+  size_t done_off = 0;    // where the slot's completion word lies in h_out (slot_reserve)
   uint32_t N_res = 0, T_res = 0;  // extents the slot's buffers are reserved for (slot_reserve)
   uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
@@ -135,6 +136,8 @@ struct Bank {
   bool assoc_event = false;             // sa_batch_run_apply: ev_done marks the end of the ASSOCIATION (the frame's last dispatch carries it); the
                                         // upkeep kernels run behind it — sa_batch_fetch waits for the event only, so that the caller's own
                                         // bookkeeping overlaps them
+  uint64_t done_seq = 0;                // != 0: the set's last launch reports by completion WORDS (k_assign_small stores this number behind every scene's
+                                        // results; the host polls: wait_done), ev_done is NOT recorded for it
   std::atomic<bool> assoc_waited{false};// ... and has been waited for (sa_batch_results from several threads: one trip into the runtime, not one per slot)
   bool want_prep = false;               // the upkeep follows on the stream (sa_batch_run_apply): its feature-bank step reads what the preparation blocks write
   bool want_apply = false;              // sa_batch_run_apply: bank_upload appends the set's ApplyScene array to the arena (behind the descriptors: the same DMA)
@@ -190,6 +193,7 @@ struct sa_engine {
   // The LAST thing queued carried a completion event of its own (the upkeep's last dispatch, the gather of sa_tracks_remove): draining the
   // engine is then one event wait — a stream synchronisation costs a marker packet's trip through the command processor (~10 us) even
   // when the queue has long been idle.  Valid while busy_seq == tail_seq.
+  uint64_t done_counter = 0;   // sequence numbers of the launches that report by completion words (Bank::done_seq)
   hipEvent_t tail_ev = nullptr;
   uint64_t tail_seq = 0;
   hipEvent_t ev_misc = nullptr;      // (the event sa_tracks_remove's gather carries)
@@ -475,6 +479,8 @@ int arena_reserve(sa_engine* e, Bank* b, size_t bytes) {
 }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
+// where a slot's completion word lies in its mapped result block (n = the slot's detections, at least 1)
+static inline size_t done_word_off(size_t n) { return (n * 13 + 48 + 127) & ~(size_t)127; }
 int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   // Reserved extents: a tracker's table breathes (tracks start, idle ones are evicted) and most of a slot's buffers are sized N x T —
   // sizing them by the frame would reallocate a few of them (hipMalloc, slot init, later hipFree) every time T sets a new record.  The
@@ -558,8 +564,15 @@ int slot_reserve(sa_engine* e, Slot* s, uint32_t N, uint32_t T) {
   if (e->cfg.flags & SA_FLAG_TAP) TRY(dev_ensure(e, s->tap, (n * 8 + t * 8) * (e->K > 1 && e->K <= SA_CLS_MAXK ? e->K : 1) + n * 4));
   {
     void* before = s->h_out.p;
-    TRY(host_ensure(e, s->h_out, n * 13 + 48));  // ids[n] | votes[n] | (8-byte aligned) stats[4] | winning columns[n]
+    // ids[n] | votes[n] | (8-byte aligned) stats[4] | winning columns[n] | (on a 128-byte line of its own) the completion word
+    // (the word sits behind the RESERVED extent: it moves only when that grows, and is cleared wherever it lands — what a slot's
+    // earlier launches stored there are older sequence numbers, never the one a later launch is waited for with)
+    TRY(host_ensure(e, s->h_out, done_word_off(n) + 128));
     if (s->h_out.p != before || !s->d_out) HIPCHK(e, hipHostGetDevicePointer(&s->d_out, s->h_out.p, 0));
+    if (s->h_out.p != before || s->done_off != done_word_off(n)) {
+      s->done_off = done_word_off(n);
+      __atomic_store_n((uint64_t*)((uint8_t*)s->h_out.p + s->done_off), 0ull, __ATOMIC_RELEASE);
+    }
   }
   return SA_OK;
 }
@@ -607,6 +620,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   d->stats = (decltype(d->stats))(s->stats.p);
   d->out_stats = (decltype(d->out_stats))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7));
   d->out_win = (decltype(d->out_win))((uint8_t*)s->d_out + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16);
+  d->out_done = (decltype(d->out_done))((uint8_t*)s->d_out + s->done_off);
   if (s->tap.p) {  // SA_FLAG_TAP: [N] row words | [T] column words | [N] edge counts (sizes as slot_reserve laid them out)
     const size_t n = s->N ? s->N : 1, t = s->T ? s->T : 1;
     const size_t wk = bk->words == 3 ? e->K : 1;  // class words: K per candidate / track
@@ -802,10 +816,21 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // being profiled (the launch then stamps the profile's events) or captured into a graph (the caller does not ask then)
   const bool attach = done && maxN && !e->profile;
   hipError_t le;
+  b->done_seq = 0;
   if (small_tail) {
     ProfScope ps(e, KID_ASSIGN_SMALL);
-    if (attach) sa_done_event = done;
-    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5);
+    // the caller wants to know when the results are in: every scene's workgroup says so itself, in a word behind its results that the
+    // host polls (wait_done) — the dispatch carries no completion signal and the next dispatch of the queue (the upkeep step, the next
+    // frame of a pipelined loop) starts ~4.6 us earlier; SA_FLAG_SIGNAL_COMPLETION: the signal
+#ifdef SA_FORCE_SIGNAL_COMPLETION   /* (A/B builds: scripts/gpu_ab.sh) */
+    const bool by_words = false;
+#else
+    const bool by_words = attach && !(e->cfg.flags & SA_FLAG_SIGNAL_COMPLETION);
+#endif
+    if (by_words) b->done_seq = ++e->done_counter;
+    else if (attach) sa_done_event = done;
+    le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 8 : 5, b->done_seq);
+    if (le != hipSuccess) b->done_seq = 0;
   } else {
     // (with vote words the label kernel also turns them into the verdicts the solver honours, and the solver re-arms them).
     // Measured and dropped (round 4): the label step as the FIRST PHASE of the solver's launch, its row workgroups meeting at a counter
@@ -816,7 +841,7 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
     if (attach) sa_done_event = done;
     le = sa_launch_assign(ds, ns, maxN, maxT, P, st, words ? 4 : 3);
   }
-  if (done_attached) *done_attached = attach && sa_done_event == nullptr;  // taken by the launch
+  if (done_attached) *done_attached = (attach && sa_done_event == nullptr) || b->done_seq != 0;  // taken by the launch (or replaced by the completion words)
   sa_done_event = nullptr;  // never left behind for another launch of this thread, whatever happened
   HIPCHK(e, le);
   return SA_OK;
@@ -887,6 +912,7 @@ int bank_prepare(sa_engine* e, Bank* b, uint32_t* maxN_out, uint32_t* maxT_out, 
 
 int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t done = nullptr, bool* done_attached = nullptr) {
   const uint32_t ns = b->n_slots;
+  b->done_seq = 0;
   SA_BUSY(e);
   const SceneDev* ds = (const SceneDev*)((const uint8_t*)b->d_arena.p + b->desc_off);
   hipStream_t st = e->stream;
@@ -941,6 +967,48 @@ int bank_launch(sa_engine* e, Bank* b, uint32_t maxN, uint32_t maxT, hipEvent_t 
   // per launch, replays of a captured graph included: what the frame's launches did (not) prepare
   for (uint32_t i = 0; i < ns; ++i) { b->slots[i]->ran = true; b->slots[i]->prepped = b->frame_with_prep; }
   return SA_OK;
+}
+
+// The end of a request set's association, as its last launch reports it: completion words (Bank::done_seq — every scene's workgroup of
+// the one-workgroup tail stores the launch's sequence number behind its results; polled here) or the completion signal of the dispatch
+// (ev_done).  The poll looks at the stream now and then: a queue that has run dry without the words (a fault inside the launch) must not
+// hang the caller.
+int wait_done(sa_engine* e, Bank* b) {
+  if (!b->done_seq) {
+    hipError_t we = hipEventSynchronize(b->ev_done);
+    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    return SA_OK;
+  }
+  const uint64_t want = b->done_seq;
+  uint32_t next = 0;   // slots [0, next) have reported
+  auto all_in = [&]() {
+    for (; next < b->n_slots; ++next) {
+      const Slot* s = b->slots[next];
+      if (__atomic_load_n((const uint64_t*)((const uint8_t*)s->h_out.p + s->done_off), __ATOMIC_ACQUIRE) != want) return false;
+    }
+    return true;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  auto next_look = t0 + std::chrono::milliseconds(5);   // (a frame is there within microseconds: the runtime is not touched on the way)
+  for (uint32_t spin = 1;; ++spin) {
+    if (all_in()) return SA_OK;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((spin & 1023u) != 0) continue;
+    const auto now = std::chrono::steady_clock::now();
+    if (now < next_look) continue;
+    next_look = now + std::chrono::milliseconds(5);
+    const hipError_t q = hipStreamQuery(e->stream);
+    if (q == hipSuccess) {   // everything queued has retired: the words are there, or never will be
+      if (all_in()) return SA_OK;
+      return fail(e, SA_ERR_HIP, "the assignment tail retired without reporting the results of slot %u", next);
+    }
+    (void)hipGetLastError();
+    if (q != hipErrorNotReady) return fail(e, SA_ERR_HIP, "the request set's launches failed: %s", hipGetErrorString(q));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+      return fail(e, SA_ERR_HIP, "no completion word from slot %u within 30 s", next);
+  }
 }
 
 int run_pipeline(sa_engine* e) {
@@ -1467,6 +1535,7 @@ static std::atomic<uint64_t> g_set_stamp{0};
 static void bank_clear(Bank* b) {
   b->set_stamp = g_set_stamp.fetch_add(1, std::memory_order_relaxed) + 1;
   b->assoc_event = false;
+  b->done_seq = 0;
   b->assoc_waited.store(false, std::memory_order_relaxed);
   b->apply_event = false;
   b->kf_event = false;
@@ -1696,8 +1765,7 @@ int sa_batch_fetch(sa_engine* e, uint32_t slot, uint64_t* out_track_id, uint8_t*
   Slot* s = e->B->slots[slot];
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch before sa_batch_run");
   if (e->B->assoc_event) {  // (the upkeep queued behind the association is still running: the winners are in)
-    hipError_t we = hipEventSynchronize(e->B->ev_done);
-    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    TRY(wait_done(e, e->B));
   } else if (!e->synced) TRY(engine_sync(e));
   const uint8_t* h = (const uint8_t*)s->h_out.p;
   {
@@ -1722,8 +1790,7 @@ int sa_batch_fetch_cols(sa_engine* e, uint32_t slot, int32_t* out_cols) {
   if (!s->N) return SA_OK;
   if (!s->ran) return fail(e, SA_ERR_STATE, "sa_batch_fetch_cols before sa_batch_run");
   if (e->B->assoc_event) {
-    hipError_t we = hipEventSynchronize(e->B->ev_done);
-    if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+    TRY(wait_done(e, e->B));
   } else if (!e->synced && !e->B_ticket) TRY(engine_sync(e));
   std::memcpy(out_cols, (const uint8_t*)s->h_out.p + (((size_t)(s->N ? s->N : 1) * 9 + 7) & ~(size_t)7) + 16, (size_t)s->N * 4);
   return SA_OK;
@@ -1741,8 +1808,7 @@ int sa_batch_results(sa_engine* e, uint32_t slot, const uint64_t** out_track_id,
   if (!s->ran && !s->fused_pending) return fail(e, SA_ERR_STATE, "sa_batch_results before sa_batch_run");
   if (e->B->assoc_event) {
     if (!e->B->assoc_waited.load(std::memory_order_acquire)) {
-      hipError_t we = hipEventSynchronize(e->B->ev_done);
-      if (we != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
+      TRY(wait_done(e, e->B));
       e->B->assoc_waited.store(true, std::memory_order_release);
     }
   } else if (!e->synced) TRY(engine_sync(e));
@@ -1876,10 +1942,7 @@ int sa_pipe_wait(sa_engine* e, uint64_t ticket, const sa_scene_result* res) {
     return fail(e, SA_ERR_STATE, "ticket %llu has not been launched (or is unknown)", (unsigned long long)ticket);
   if (b->n_slots && !res) return fail(e, SA_ERR_BAD_ARG, "sa_pipe_wait: null result array");
   TRY(finish_applies(e));  // (slot numbers are about to mean THIS ticket's scenes: a pending sa_tracks_apply_end could no longer name its slot)
-  if (b->state == 2) {
-    hipError_t s = hipEventSynchronize(b->ev_done);
-    if (s != hipSuccess) return fail(e, SA_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(s));
-  }
+  if (b->state == 2) TRY(wait_done(e, b));
   for (uint32_t i = 0; i < b->n_slots; ++i) {
     const Slot* s = b->slots[i];
     const uint8_t* h = (const uint8_t*)s->h_out.p;

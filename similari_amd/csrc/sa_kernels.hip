@@ -616,11 +616,40 @@ __device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmc
 #define SA_DENSE_NT 256
 #define SA_DENSE_MIN_ROOTS 8u
 #define SA_DENSE_MIN_COLS 128u
+// The end of a scene's results, reported by the workgroup itself (done_seq != 0): every wave, when it has issued its last result, waits
+// for its stores to be acknowledged (s_waitcnt vmcnt(0); the results are SYSTEM-scope stores — SA_OUT in k_assign_small —, acknowledged
+// from the host's side of the link: a system-scope release per workgroup instead, i.e. an L2 write-back each, cost a 64-scene set
+// 25 us) and counts itself in LDS; the wave that completes the count stores the launch's sequence number to the scene's completion word
+// (a cache line of its own in the same block) — every result was acknowledged before that store was issued.  The host polls the word.
+// Waves leave k_assign_small at three places; each of them reports.
+__device__ __forceinline__ void sa_report_done(const SceneDev& S, uint64_t done_seq, uint32_t* s_done) {
+  if (!done_seq) return;
+  // (a workgroup-scope release alone is NOT that wait: the waves of a workgroup share their CU's memory pipeline, so the compiler
+  // emits no s_waitcnt for it — measured: the word overtook the results)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt untouched): this wave's stores have been acknowledged
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    const uint32_t before = atomicAdd(s_done, 1u);
+    if (before + 1u == blockDim.x / WAVE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (the count seen: the other waves' acknowledgements are behind us)
+      __hip_atomic_store(S.out_done, (unsigned long long)done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 template <bool VISUAL, bool WORDS, int G>
-__global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes) {
+__global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes, uint64_t done_seq) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
+  __shared__ uint32_t s_done;   // waves that have reported (sa_report_done)
+  // a result on its way to the host's mapped block: with completion words as a SYSTEM-scope store — such a store is acknowledged when it
+  // has reached the host's memory, a plain one when the L2 has taken it (measured: behind plain stores the completion word overtook the
+  // results it announces, s_waitcnt vmcnt(0) or not); otherwise plain (the dispatch's own end-of-kernel release covers it)
+#define SA_OUT(ptr, val)                                                                                             \
+  do {                                                                                                               \
+    if (done_seq) __hip_atomic_store((ptr), (std::remove_cv_t<std::remove_reference_t<decltype(*(ptr))>>)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    else *(ptr) = (val);                                                                                             \
+  } while (0)
   __shared__ uint32_t s_head[SA_SMALL_N];  // per component root: the rows that lost their greedy bid (pushed in any order)
   __shared__ uint32_t s_next[SA_SMALL_N];
   __shared__ int64_t s_u[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
@@ -648,9 +677,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
-    S.out_stats[0] = S.stats[0];
-    S.out_stats[1] = 0u;   // (k_assign_solve: a bounded wait ran out — the host refuses the frame's results)
+    SA_OUT(S.out_stats + 0, S.stats[0]);
+    SA_OUT(S.out_stats + 1, 0u);   // (k_assign_solve: a bounded wait ran out — the host refuses the frame's results)
     S.stats[0] = 0u;
+    s_done = 0u;           // (barriers follow before any wave can leave)
   }
   __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
   __shared__ uint32_t s_bt[WORDS ? SA_SMALL_N : 1];     // candidate -> its best column (SA_NONE: no group at all)
@@ -819,11 +849,12 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       uint8_t vt = SA_VOTE_NONE;
       const int32_t vw = vw0;
       if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
-      S.out_track_id[q] = id;
-      S.out_vote[q] = vt;
+      SA_OUT(S.out_track_id + q, id);
+      SA_OUT(S.out_vote + q, vt);
       S.win_col[q] = vw >= 0 ? vw : -1;
-      S.out_win[q] = vw >= 0 ? vw : -1;
+      SA_OUT(S.out_win + q, vw >= 0 ? vw : -1);
     }
+    sa_report_done(S, done_seq, &s_done);
     return;
   }
   TAIL_STAMP(1);
@@ -1003,15 +1034,15 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
         win = c;
       }
     }
-    S.out_track_id[q] = id;
-    S.out_vote[q] = vt;
+    SA_OUT(S.out_track_id + q, id);
+    SA_OUT(S.out_vote + q, vt);
     S.win_col[q] = win;
-    S.out_win[q] = win;
+    SA_OUT(S.out_win + q, win);
   }
   if (nd) {
     // The dense solver runs on SA_DENSE_NT threads (one wave per SIMD: a search step is a chain of dependent instructions, more
     // waves per SIMD only stretch it): the other waves are done — a barrier waits for the surviving waves only.
-    if (q >= SA_DENSE_NT) return;
+    if (q >= SA_DENSE_NT) { sa_report_done(S, done_seq, &s_done); return; }
     uint32_t rtop = s_ctr[3];
     for (uint32_t k = 0; k < nd; ++k) {
       const uint32_t root = s_queue[SA_SMALL_N - 1u - k];
@@ -1067,10 +1098,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
         if (s_lab[row] != root) continue;
         const int32_t c = s_rmatch[row];
-        S.out_track_id[row] = c >= 0 ? S.t_ids[c] : 0ull;
-        S.out_vote[row] = c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE;
+        SA_OUT(S.out_track_id + row, c >= 0 ? S.t_ids[c] : 0ull);
+        SA_OUT(S.out_vote + row, c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE);
         S.win_col[row] = c;
-        S.out_win[row] = c;
+        SA_OUT(S.out_win + row, c);
         int64_t SA_G* drow = S.dense + (size_t)row * T;
         const uint32_t cnt = s_ecnt[row];
         if (pool) {
@@ -1091,8 +1122,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       __syncthreads();
     }
   }
+  sa_report_done(S, done_seq, &s_done);
   TAIL_STAMP(7);
 }
+#undef SA_OUT
 
 // General tail, kernel 1 of 2: every participating row finds its component (root = minimum vertex, always a row) and
 // pushes itself onto that root's list — S.label[root] is the list head, S.next_row the links.  No O(N^2) scan for "the
@@ -2170,7 +2203,7 @@ static hipError_t launch_solve(bool vis, bool in_lds, bool no_mid, bool words, u
   return launch_solve_one<false, NT, CPT, false>(grid, rw, lds, st, scenes);
 }
 hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, const SaParams& p,
-                            hipStream_t st, int stage) {
+                            hipStream_t st, int stage, uint64_t done_seq) {
   if (!maxN) return hipSuccess;
   switch (stage) {
     case 1: SA_LAUNCH(k_assign_label<false>, dim3(cdiv(maxN, 256), 1, ns), dim3(256), 0, st, scenes); break;
@@ -2194,9 +2227,9 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     }
     default:
       sa_tail_trace_hook(st, ns);
-      if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
-      else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes);
+      if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
       break;
   }
   return hipGetLastError();

@@ -75,6 +75,7 @@ def test_batch_time_replays_the_staged_set():
         eng.close()
 
 
+@pytest.mark.paths("signal_completion")   # (the completion SIGNAL of the last dispatch instead of the scenes' completion words)
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned_block"])
 def test_pipelined_tickets_match_the_synchronous_path(pinned):
     """A stream of different frames through sa_pipe_submit / sa_pipe_wait with two (then three) tickets in flight: every frame's answer equals
@@ -185,6 +186,7 @@ def test_apply_in_two_halves_matches_the_single_call():
         b.close()
 
 
+@pytest.mark.paths("signal_completion")   # (the completion SIGNAL of the last dispatch instead of the scenes' completion words)
 def test_pipelined_tracker_loop_with_device_upkeep():
     """stage(n+1); wait(n); apply(n); launch(n+1): the H2D of the next frame overlaps the current frame's kernels, and the track
     table the next frame meets is the one sa_tracks_apply left (new tracks appended, Kalman steps taken).  Same ids, frame by
@@ -312,6 +314,7 @@ def test_oriented_boxes_between_apply_begin_and_end_meet_the_next_launch_with_th
         b.close()
 
 
+@pytest.mark.paths("signal_completion")   # (the completion SIGNAL of the last dispatch instead of the scenes' completion words)
 @pytest.mark.parametrize("per_candidate", [0, 1])
 @pytest.mark.parametrize("visual", [False, True])
 def test_upkeep_queued_behind_the_association_equals_the_two_phase_upkeep(visual, per_candidate):
@@ -493,6 +496,7 @@ def test_a_recycled_ticket_is_refused_not_misread():
         eng.close()
 
 
+@pytest.mark.paths("signal_completion")   # (the completion SIGNAL of the last dispatch instead of the scenes' completion words)
 @pytest.mark.parametrize("visual", [False, True])
 def test_request_set_staged_collected_and_evicted_on_several_threads(visual):
     """The entry points Batch*::predict spreads over threads, straight through the C ABI: sa_batch_add_deferred + sa_batch_fill (slots
