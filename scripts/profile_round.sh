@@ -64,6 +64,9 @@ scripts/batch_tracker_timeline.sh ${TAG}_s8 sort 8 500 0 40 0 sync > $O/batch_tr
 scripts/batch_tracker_timeline.sh ${TAG}_s64 sort 64 500 0 24 0 sync > $O/batch_tracker_timeline_sort64.txt 2>&1
 scripts/batch_tracker_timeline.sh ${TAG}_v8 visual 8 1000 512 24 0 sync device > $O/batch_tracker_timeline_visual8.txt 2>&1
 tail -n 8 $O/batch_tracker_timeline_*.txt
+bash scripts/tracker_timeline.sh "visual,device,0.0" > $O/tracker_timeline_visual.txt 2>&1; bash scripts/tracker_timeline.sh "sort,None,0.0" > $O/tracker_timeline_sort.txt 2>&1
+tail -n 7 $O/tracker_timeline_*.txt
+[ -n "$SA_PROFILE_SKIP_TRACES" ] && { echo "DONE (without the in-kernel timelines)"; exit 0; }
 # 5c. the giant components: where a search step's time goes (k_assign_solve's timeline; rebuilds with -DSA_TAIL_TRACE)
 bash scripts/solve_trace.sh giant bigcrowd sdt > $O/solve_trace.txt 2>&1; tail -30 $O/solve_trace.txt
 # 6. in-kernel timelines (rebuilds the library with -DSA_POS_TRACE -DSA_GEMM_TRACE) + the launch floor
