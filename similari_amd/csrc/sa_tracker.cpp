@@ -212,6 +212,7 @@ struct sa_tracker {
   std::condition_variable dcv;
   bool d_work = false, d_stop = false;
   std::atomic<bool> d_busy{false};
+  std::atomic<uint32_t> d_posted{0};   // request sets handed to the driver so far (the driver looks at this word for a while before it sleeps)
   struct Flight {   // the request set between its launches and its last result
     uint32_t n_scenes = 0;
     int set = 0;
@@ -228,7 +229,8 @@ struct ResultState {
   std::vector<uint64_t> scene_ids;
   std::vector<std::vector<sa_sort_track>> tracks;
   std::deque<uint32_t> ready_q;   // scenes whose tracks are final, in the order they became so
-  uint32_t taken = 0;
+  std::atomic<uint32_t> n_ready{0};   // scenes pushed so far | bit 31: finished (what get() looks at before it takes the lock and sleeps)
+  std::atomic<uint32_t> taken{0};   // (written under the lock)
   int rc = SA_OK;                 // first error of the request set
   std::string err;
   bool finished = false;
@@ -628,7 +630,7 @@ int complete_flight(sa_tracker* t) {
     int rc0 = sa_batch_results(t->eng, ss[0].slot, &w0, nullptr, nullptr);
     if (rc0 != SA_OK) {
       t->err = std::string("association: ") + sa_last_error(t->eng);
-      if (F.res) { std::lock_guard<std::mutex> lk(F.res->mu); F.res->rc = rc0; F.res->err = t->err; F.res->finished = true; F.res->cv.notify_all(); }
+      if (F.res) { std::lock_guard<std::mutex> lk(F.res->mu); F.res->rc = rc0; F.res->err = t->err; F.res->finished = true; F.res->n_ready.fetch_or(0x80000000u, std::memory_order_release); F.res->cv.notify_all(); }
       return rc0;
     }
   }
@@ -702,6 +704,7 @@ int complete_flight(sa_tracker* t) {
       if (F.res) {   // the scene's tracks are final: hand them over
         std::lock_guard<std::mutex> lk(F.res->mu);
         F.res->ready_q.push_back(s);
+        F.res->n_ready.fetch_add(1, std::memory_order_release);
         F.res->cv.notify_all();
       }
       if (trace) W.job_us[1] = us_between(j0, clk::now());
@@ -736,18 +739,28 @@ int complete_flight(sa_tracker* t) {
     F.res->rc = rc;
     F.res->err = first_err;
     F.res->finished = true;
+    F.res->n_ready.fetch_or(0x80000000u, std::memory_order_release);
     F.res->cv.notify_all();
   }
   return rc;
 }
 
+// A tracker loop calls _begin back to back: the driver finds the next set within microseconds of the last one — it looks at the posting
+// counter for a while (no futex round trip: ~50 us on this host when the thread had gone to sleep) before it waits on the condition variable.
 void driver_loop(sa_tracker* t) {
+  uint32_t seen = 0;
   for (;;) {
     {
+      const auto t0 = clk::now();
+      for (uint32_t spin = 1; t->d_posted.load(std::memory_order_acquire) == seen; ++spin) {
+        SA_POOL_PAUSE();
+        if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(300)) break;
+      }
       std::unique_lock<std::mutex> lk(t->dmu);
       t->dcv.wait(lk, [&] { return t->d_work || t->d_stop; });
       if (t->d_stop) return;
       t->d_work = false;
+      seen = t->d_posted.load(std::memory_order_acquire);
     }
     complete_flight(t);
     {
@@ -861,11 +874,35 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
   F.out.assign(out, out + n_scenes);
   F.res = res;
   if (!res) return complete_flight(t);
-  if (!t->driver.joinable()) t->driver = std::thread(driver_loop, t);
+  if (!t->driver.joinable()) {
+    t->driver = std::thread(driver_loop, t);
+#if defined(__linux__)
+    // next to the caller and the pool's workers (sa_pool.h: worker w on the (w + 1)-th CPU after the creating thread's): the driver runs
+    // the calling thread's share of the jobs behind the launches — the scenes' records should not cross a socket for it
+    if (o.workers >= 0) {
+      cpu_set_t allowed;
+      CPU_ZERO(&allowed);
+      const int here = sched_getcpu();
+      std::vector<int> cpus;
+      int at = -1;
+      if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+          if (CPU_ISSET(c, &allowed)) { if (c == here) at = (int)cpus.size(); cpus.push_back(c); }
+      const size_t behind = t->pool ? t->pool->threads() : 1;   // (the caller + the workers)
+      if (at >= 0 && cpus.size() > behind + 1) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[((size_t)at + behind) % cpus.size()], &set);
+        pthread_setaffinity_np(t->driver.native_handle(), sizeof set, &set);
+      }
+    }
+#endif
+  }
   {
     std::lock_guard<std::mutex> lk(t->dmu);
     t->d_busy.store(true, std::memory_order_release);
     t->d_work = true;
+    t->d_posted.fetch_add(1, std::memory_order_release);
   }
   t->dcv.notify_all();
   return SA_OK;
@@ -1181,6 +1218,7 @@ int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint6
     std::lock_guard<std::mutex> lk(st->mu);
     for (uint32_t s = 0; s < n_scenes; ++s) st->ready_q.push_back(s);
     st->finished = true;
+    st->n_ready.store(n_scenes | 0x80000000u, std::memory_order_release);
   }
   sa_batch_result* r = new sa_batch_result();
   r->st = st;
@@ -1199,6 +1237,18 @@ int sa_batch_result_ready(sa_batch_result* r) {
 int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!r || !out_n) return SA_ERR_BAD_ARG;
   ResultState& st = *r->st;
+  {
+    // (the next scene is usually microseconds away: look at the delivery counter for a while before the lock and the futex; `taken` is only
+    // written by get() — by this thread, or by another caller thread under the lock, in which case the wait below sorts it out)
+    const uint32_t have = st.taken;
+    const auto t0 = clk::now();
+    for (uint32_t spin = 1;; ++spin) {
+      const uint32_t v = st.n_ready.load(std::memory_order_acquire);
+      if ((v & 0x7fffffffu) > have || (v & 0x80000000u)) break;
+      SA_POOL_PAUSE();
+      if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(500)) break;
+    }
+  }
   std::unique_lock<std::mutex> lk(st.mu);
   if (st.taken >= st.scene_ids.size()) return SA_ERR_STATE;   // every scene has been taken (the reference's recv() would block for ever)
   st.cv.wait(lk, [&] { return !st.ready_q.empty() || st.finished; });
