@@ -114,6 +114,7 @@ int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* s
  * trackers/batch.rs:19-38:
  *   sa_batch_result_size   batch_size(): scenes in the request set
  *   sa_batch_result_ready  ready(): 1 when sa_batch_result_get would not block
+ *   sa_batch_result_take   get() as the reference has it: the next finished scene's tracks handed over in place (no copy)
  *   sa_batch_result_get    get(): the next finished scene — its id, its tracks in candidate order (cap < *out_n: SA_ERR_BAD_ARG, nothing is
  *                          taken, *out_n says how many there are); blocks until one is there; SA_ERR_STATE once every scene was taken
  * The request is taken by value like the reference's: the observation arrays (and feature rows in host memory) may be reused as soon as
@@ -127,6 +128,10 @@ int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint6
 uint32_t sa_batch_result_size(const sa_batch_result* r);
 int sa_batch_result_ready(sa_batch_result* r);
 int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
+/* get() without the copy (the reference's get() MOVES a scene's Vec<SortTrack> out of the channel): *out_tracks points at the scene's
+ * tracks inside the handle, valid until sa_batch_result_free.  (64 scenes x 500 tracks are 2.3 MB: copied out one scene at a time they
+ * cost a C++ host 140 us of a 390 us call, scripts/micro/batch_handle_bench.cpp.) */
+int sa_batch_result_take(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** out_tracks, uint32_t* out_n);
 void sa_batch_result_free(sa_batch_result* r);
 
 int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);

@@ -1,0 +1,79 @@
+// BatchSort::predict through the C ABI from a C++ host (no Python between the calls): the synchronous call against the result handle
+// (sa_tracker_predict_batch_begin + one sa_batch_result_get per scene).  S scenes x n objects on a jittered grid, 5 % of the objects
+// replaced every frame, device upkeep.
+//   g++ -O2 -std=c++17 -I include scripts/micro/batch_handle_bench.cpp -L similari_amd/lib -lsimilari_assoc -Wl,-rpath,$PWD/similari_amd/lib -o /tmp/batch_handle_bench
+//   /tmp/batch_handle_bench [scenes] [objects] [frames]
+#include "similari_tracker.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+using clk = std::chrono::steady_clock;
+static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+int main(int argc, char** argv) {
+  const uint32_t S = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 500, frames = argc > 3 ? atoi(argv[3]) : 60;
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> u(0.f, 1.f);
+  const uint32_t side = (uint32_t)std::ceil(std::sqrt((double)n));
+  auto fresh = [&](sa_box& b, uint32_t k) {
+    b = sa_box{};
+    b.xc = 60.f * (k % side) + 20.f * u(rng); b.yc = 60.f * (k / side) + 20.f * u(rng);
+    b.aspect = 0.5f + 0.2f * u(rng); b.height = 30.f + 10.f * u(rng); b.confidence = 0.9f;
+  };
+  std::vector<std::vector<sa_box>> world(S, std::vector<sa_box>(n));
+  for (auto& w : world) for (uint32_t k = 0; k < n; ++k) fresh(w[k], k);
+  double med[3] = {0, 0, 0}, first[1] = {0}, ret[1] = {0};
+  for (int mode = 0; mode < 3; ++mode) {   // 0 = synchronous, 1 = handle + get (a copy per scene), 2 = handle + take (in place)
+    sa_tracker_options o;
+    sa_tracker_options_default(&o, 0);
+    o.history_length = 3; o.max_idle_epochs = 3; o.batch_ids = 1; o.device_upkeep = 1;
+    sa_tracker* t = nullptr;
+    if (sa_tracker_create(&o, &t) != 0) { printf("create failed: %s\n", sa_tracker_last_error(nullptr)); return 1; }
+    std::vector<std::vector<sa_observation>> obs(S, std::vector<sa_observation>(n));
+    std::vector<std::vector<sa_sort_track>> out(S, std::vector<sa_sort_track>(n));
+    std::vector<uint64_t> ids(S);
+    std::vector<uint32_t> counts(S, n);
+    std::vector<const sa_observation*> po(S);
+    std::vector<sa_sort_track*> pt(S);
+    for (uint32_t s = 0; s < S; ++s) { ids[s] = s; po[s] = obs[s].data(); pt[s] = out[s].data(); }
+    std::vector<double> tt, tf, tr;
+    for (uint32_t f = 0; f < frames; ++f) {
+      for (uint32_t s = 0; s < S; ++s)
+        for (uint32_t k = 0; k < n; ++k) {
+          sa_box& b = world[s][k];
+          if (u(rng) < 0.05f) fresh(b, k); else { b.xc += u(rng) - 0.5f; b.yc += u(rng) - 0.5f; }
+          sa_observation& ob = obs[s][k];
+          ob = sa_observation{};
+          ob.bbox = b; ob.feature_quality = std::nanf(""); ob.own_area = std::nanf("");
+        }
+      const auto t0 = clk::now();
+      if (mode == 0) {
+        if (sa_tracker_predict_batch(t, S, ids.data(), counts.data(), po.data(), pt.data()) != 0) { printf("predict failed: %s\n", sa_tracker_last_error(t)); return 1; }
+        tt.push_back(us(t0, clk::now()));
+      } else {
+        sa_batch_result* r = nullptr;
+        if (sa_tracker_predict_batch_begin(t, S, ids.data(), counts.data(), po.data(), &r) != 0) { printf("begin failed: %s\n", sa_tracker_last_error(t)); return 1; }
+        const auto t1 = clk::now();
+        for (uint32_t k = 0; k < S; ++k) {
+          uint64_t sid; uint32_t cnt;
+          const sa_sort_track* view = nullptr;
+          if ((mode == 1 ? sa_batch_result_get(r, &sid, out[0].data(), n, &cnt) : sa_batch_result_take(r, &sid, &view, &cnt)) != 0) { printf("get failed\n"); return 1; }
+          if (k == 0) tf.push_back(us(t0, clk::now()));
+        }
+        tt.push_back(us(t0, clk::now()));
+        tr.push_back(us(t0, t1));
+        sa_batch_result_free(r);
+      }
+    }
+    auto median = [](std::vector<double> v) { v.erase(v.begin(), v.begin() + std::min<size_t>(5, v.size() - 1)); std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    med[mode] = median(tt);
+    if (mode == 2) { first[0] = median(tf); ret[0] = median(tr); }
+    sa_tracker_destroy(t);
+  }
+  printf("{\"host\": \"C++\", \"tracker\": \"BatchSort\", \"scenes\": %u, \"objects_per_scene\": %u, \"us_per_predict_sync\": %.1f, \"us_per_predict_through_the_handle_get\": %.1f, "
+         "\"us_per_predict_through_the_handle_take\": %.1f, \"us_until_begin_returns\": %.1f, \"us_until_first_scene\": %.1f}\n", S, n, med[0], med[1], med[2], ret[0], first[0]);
+  return 0;
+}

@@ -438,6 +438,7 @@ PROTOTYPES = {
     "sa_batch_result_size": (u32, [C.c_void_p]),
     "sa_batch_result_ready": (C.c_int, [C.c_void_p]),
     "sa_batch_result_get": (C.c_int, [C.c_void_p, P(u64), P(sa_sort_track), u32, P(u32)]),
+    "sa_batch_result_take": (C.c_int, [C.c_void_p, P(u64), P(P(sa_sort_track)), P(u32)]),
     "sa_batch_result_free": (None, [C.c_void_p]),
     "sa_tracker_idle_tracks": (C.c_int, [C.c_void_p, u64, P(sa_sort_track), u32, P(u32)]),
     "sa_tracker_skip_epochs": (C.c_int, [C.c_void_p, u64, u64]),

@@ -148,6 +148,33 @@ struct alignas(128) SceneState {
 
 struct ResultState;
 
+// The tracks of a request set on their way through a result handle lie in ONE block per set, and the blocks go round: a handle that is
+// freed gives its block back, the next _begin takes it (64 scenes x 500 tracks are 2.3 MB: from the heap that was an mmap, its page
+// faults and a memset per call — the call returned after 204 us where the synchronous one has launched after 135).  Shared by the tracker
+// and its handles: whichever goes last frees it.
+struct TrackBlocks {
+  std::mutex mu;
+  struct Block { std::unique_ptr<sa_sort_track[]> p; size_t cap = 0; };
+  std::vector<Block> spare;
+  Block take(size_t n) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < spare.size(); ++i)
+        if (spare[i].cap >= n) { Block b = std::move(spare[i]); spare.erase(spare.begin() + (long)i); return b; }
+      if (!spare.empty()) spare.pop_back();   // (too small for this tracker's sets: let it go)
+    }
+    Block b;
+    b.cap = n + n / 4 + 64;
+    b.p.reset(new sa_sort_track[b.cap]);   // (default-initialised: every track of a delivered scene is written before it is handed out)
+    return b;
+  }
+  void give(Block&& b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (spare.size() < 4) spare.push_back(std::move(b));
+  }
+};
+
 }  // namespace
 
 // PredictionBatchResult  trackers/batch.rs:19-38
@@ -207,6 +234,7 @@ struct sa_tracker {
   // sa_tracker_predict_batch_begin: the work behind the launches (waiting, merges, results) runs on this thread, so that the caller gets
   // its handle back while the GPU is still busy — the reference's voting threads.  One request set at a time: every entry point first
   // waits for the set in flight (the reference's "busy monitor", sort/batch_api.rs:233-241).
+  std::shared_ptr<TrackBlocks> blocks = std::make_shared<TrackBlocks>();   // (the result handles' storage)
   std::thread driver;
   std::mutex dmu;
   std::condition_variable dcv;
@@ -227,7 +255,10 @@ struct ResultState {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<uint64_t> scene_ids;
-  std::vector<std::vector<sa_sort_track>> tracks;
+  std::shared_ptr<TrackBlocks> blocks;     // where `store` came from and goes back to
+  TrackBlocks::Block store;                // the set's tracks, scene after scene
+  std::vector<size_t> off;                 // [scenes + 1] a scene's first track in `store`
+  ~ResultState() { if (blocks) blocks->give(std::move(store)); }
   std::deque<uint32_t> ready_q;   // scenes whose tracks are final, in the order they became so
   std::atomic<uint32_t> n_ready{0};   // scenes pushed so far | bit 31: finished (what get() looks at before it takes the lock and sleeps)
   std::atomic<uint32_t> taken{0};   // (written under the lock)
@@ -1205,12 +1236,12 @@ int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint6
   wait_outstanding(t);
   auto st = std::make_shared<ResultState>();
   st->scene_ids.assign(scene_ids, scene_ids + n_scenes);
-  st->tracks.resize(n_scenes);
+  st->off.resize((size_t)n_scenes + 1, 0);
+  for (uint32_t s = 0; s < n_scenes; ++s) st->off[s + 1] = st->off[s] + counts[s];
+  st->blocks = t->blocks;
+  st->store = t->blocks->take(st->off[n_scenes] ? st->off[n_scenes] : 1);
   std::vector<sa_sort_track*> outs(n_scenes);
-  for (uint32_t s = 0; s < n_scenes; ++s) {
-    st->tracks[s].resize(counts[s]);
-    outs[s] = st->tracks[s].data();
-  }
+  for (uint32_t s = 0; s < n_scenes; ++s) outs[s] = st->store.p.get() + st->off[s];
   const bool fused = t->o.device_upkeep && (t->o.batch_ids || n_scenes == 1) && n_scenes;
   int rc = predict_scenes(t, n_scenes, scene_ids, counts, obs, outs.data(), fused ? st : nullptr);
   if (rc != SA_OK) return rc;
@@ -1234,8 +1265,9 @@ int sa_batch_result_ready(sa_batch_result* r) {
   return (!r->st->ready_q.empty() || (r->st->finished && r->st->rc != SA_OK)) ? 1 : 0;
 }
 
-int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
-  if (!r || !out_n) return SA_ERR_BAD_ARG;
+// The next finished scene of the handle: waits for one (the delivery counter first, then the lock and the condition variable), takes it
+// off the queue unless `cap` says the caller's array is too short.  The scene's tracks lie in the handle's block until it is freed.
+static int result_next(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** tracks, uint32_t* out_n, bool bounded, uint32_t cap) {
   ResultState& st = *r->st;
   {
     // (the next scene is usually microseconds away: look at the delivery counter for a while before the lock and the futex; `taken` is only
@@ -1254,14 +1286,28 @@ int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_trac
   st.cv.wait(lk, [&] { return !st.ready_q.empty() || st.finished; });
   if (st.ready_q.empty()) { g_err = st.err; return st.rc != SA_OK ? st.rc : SA_ERR_STATE; }
   const uint32_t s = st.ready_q.front();
-  const uint32_t n = (uint32_t)st.tracks[s].size();
+  const uint32_t n = (uint32_t)(st.off[s + 1] - st.off[s]);
   if (out_scene_id) *out_scene_id = st.scene_ids[s];
   *out_n = n;
-  if (n && (!out || cap < n)) return SA_ERR_BAD_ARG;   // (nothing taken: call again with room for *out_n tracks)
-  if (n) std::memcpy(out, st.tracks[s].data(), (size_t)n * sizeof(sa_sort_track));
+  if (bounded && n && cap < n) return SA_ERR_BAD_ARG;   // (nothing taken: call again with room for *out_n tracks)
+  *tracks = st.store.p.get() + st.off[s];
   st.ready_q.pop_front();
   ++st.taken;
   return SA_OK;
+}
+
+int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
+  if (!r || !out_n) return SA_ERR_BAD_ARG;
+  const sa_sort_track* src = nullptr;
+  int rc = result_next(r, out_scene_id, &src, out_n, true, out ? cap : 0);
+  if (rc != SA_OK) return rc;
+  if (*out_n) std::memcpy(out, src, (size_t)*out_n * sizeof(sa_sort_track));   // (outside the handle's lock: the scenes' jobs deliver under it)
+  return SA_OK;
+}
+
+int sa_batch_result_take(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** out_tracks, uint32_t* out_n) {
+  if (!r || !out_tracks || !out_n) return SA_ERR_BAD_ARG;
+  return result_next(r, out_scene_id, out_tracks, out_n, false, 0);
 }
 
 void sa_batch_result_free(sa_batch_result* r) { delete r; }

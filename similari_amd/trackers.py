@@ -398,7 +398,18 @@ class PredictionBatchResult:
         return bool(self._t.lib.sa_batch_result_ready(self._h))
 
     def get(self):
-        out = (abi.sa_sort_track * self._cap)()
+        """The next finished scene: (scene id, its tracks).  Through sa_batch_result_take — the tracks are read where the handle holds
+        them (the reference's get() moves the scene's Vec out of the channel; sa_batch_result_get is the copying form for C callers)."""
+        ptr = C.POINTER(abi.sa_sort_track)()
+        sid, n = C.c_uint64(), C.c_uint32()
+        rc = self._t.lib.sa_batch_result_take(self._h, C.byref(sid), C.byref(ptr), C.byref(n))
+        if rc != abi.SA_OK:
+            raise TrackerError(f"sa_batch_result_take failed ({rc}): {self._t.lib.sa_tracker_last_error(None).decode()}")
+        return sid.value, [SortTrack.from_c(ptr[i]) for i in range(n.value)]
+
+    def get_copy(self):
+        """The same through sa_batch_result_get (the scene's tracks copied into an array of the caller's)."""
+        out = (abi.sa_sort_track * max(1, self._cap))()
         sid, n = C.c_uint64(), C.c_uint32()
         rc = self._t.lib.sa_batch_result_get(self._h, C.byref(sid), out, self._cap, C.byref(n))
         if rc != abi.SA_OK:
