@@ -281,6 +281,10 @@ int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, 
  * dozens of scenes): _begin waits ONCE for the set's upkeep (one Kalman dispatch for every scene of the set); _slot does one scene's host
  * side and may run for DIFFERENT slots on different threads at once; _end, on the calling thread again, queues what is left (the
  * polygons of refreshed oriented rows). */
+/* The host side of one scene's table for the queued upkeep step (the ids of the tracks that start; the winners checked) needs the
+ * association's results only: with those in (sa_batch_results) it may be done per slot, on any thread, WHILE the Kalman dispatch runs —
+ * sa_tracks_apply_collect_slot then only hands out the predicted boxes.  Optional: the _slot call does it when nobody has. */
+int sa_tracks_apply_collect_table(sa_engine* e, uint32_t slot, uint64_t* out_new_ids);
 int sa_tracks_apply_collect_begin(sa_engine* e);
 int sa_tracks_apply_collect_slot(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, sa_box* out_predicted);
 int sa_tracks_apply_collect_end(sa_engine* e);

@@ -403,6 +403,7 @@ PROTOTYPES = {
     "sa_tracks_apply_collect": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
     "sa_tracks_apply_collect_begin": (C.c_int, [ENGINE]),
     "sa_tracks_apply_collect_slot": (C.c_int, [ENGINE, u32, P(u64), P(sa_box)]),
+    "sa_tracks_apply_collect_table": (C.c_int, [ENGINE, u32, P(u64)]),
     "sa_tracks_apply_collect_end": (C.c_int, [ENGINE]),
     "sa_tracks_get_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float)]),
     "sa_tracks_set_state": (C.c_int, [ENGINE, u64, u64, P(C.c_float), P(C.c_float), P(C.c_float)]),

@@ -92,6 +92,8 @@ struct alignas(128) Slot {  // one scene of a request set (aligned: see SceneTab
   HostBuf h_out;    // ids[N] then votes[N]: mapped pinned memory the finalisation writes directly (no D2H copy)
   void* d_out = nullptr;  // device view of h_out
   size_t done_off = 0;    // where the slot's completion word lies in h_out (slot_reserve)
+  bool table_collected = false;   // sa_tracks_apply_collect_table has done the host side of the scene's table for the queued upkeep step
+  int table_bad = 0;              // ... and what it found (SA_OK or the error the collect reports)
   uint32_t N_res = 0, T_res = 0;  // extents the slot's buffers are reserved for (slot_reserve)
   uint32_t vb_n = 0, vb_t = 0;  // rows / columns the vote-word block (vote_best) is laid out for: row words | column words | row class words | column class words
   bool ran = false;
@@ -2140,15 +2142,18 @@ static int fused_wait(sa_engine* e, Bank* ob) {
 }
 // (2) the host side of one slot's table: replays the id arithmetic of the kernels, validates the winners.  Touches the slot and its scene only
 // (and the error string, under its mutex): different slots may be collected by different threads at once.
-static int fused_collect_host(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
-  s->fused_pending = false;
+// (2a) the table: needs the association's winners only — may run while the Kalman dispatch is still on the device
+static int fused_collect_table(sa_engine* e, Slot* s, uint64_t* out_ids) {
+  if (s->table_collected) return s->table_bad;
+  s->table_collected = true;
+  s->table_bad = SA_OK;
   SceneTable* sc = s->scene;
   const uint32_t n = s->N, T0 = s->fused_T0;
   if (!n) return SA_OK;
   const uint64_t* winners = (const uint64_t*)s->h_out.p;
   const int32_t* wcol = (const int32_t*)((const uint8_t*)s->h_out.p + (((size_t)n * 9 + 7) & ~(size_t)7) + 16);
-  if (sc->T != T0) return fail(e, SA_ERR_STATE, "the scene's track table changed while its upkeep was queued");
-  TRY(host_ensure(e, s->h_apply, (size_t)n * 4));
+  if (sc->T != T0) return s->table_bad = fail(e, SA_ERR_STATE, "the scene's track table changed while its upkeep was queued");
+  if (int rc = host_ensure(e, s->h_apply, (size_t)n * 4); rc != SA_OK) return s->table_bad = rc;
   uint32_t* h_row = (uint32_t*)s->h_apply.p;
   sc->full.resize(T0, 0);
   uint32_t r = 0;
@@ -2176,6 +2181,17 @@ static int fused_collect_host(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* 
   sc->T = T0 + r;
   sc->full.resize(sc->T, 1);
   s->ran = false;  // the table the slot ran against is gone
+  s->table_bad = bad;
+  return bad;
+}
+// (2b) what the Kalman dispatch left: the predicted boxes, and whether refreshed rows need their oriented polygons
+static int fused_collect_host(sa_engine* e, Slot* s, uint64_t* out_ids, sa_box* out_predicted) {
+  s->fused_pending = false;
+  const uint32_t n = s->N;
+  if (!n) return SA_OK;
+  const bool had = s->table_collected;
+  int bad = fused_collect_table(e, s, out_ids);
+  if (had) bad = s->table_bad;   // (collected earlier, by sa_tracks_apply_collect_table: its verdict stands; the new ids went out there)
   if (out_predicted) std::memcpy(out_predicted, s->h_pred.p, (size_t)n * sizeof(sa_box));
   // (3) polygon_fixups — a launch, left to the thread that owns the engine's stream — only where a refreshed row is oriented
   bool oriented = false;
@@ -2280,8 +2296,10 @@ int sa_batch_run_apply(sa_engine* e, const uint64_t* id_base, int id_per_candida
     SA_BUSY(e);
   }
   b->apply_event = true; b->apply_seq = e->busy_seq; e->tail_ev = b->ev_apply; e->tail_seq = e->busy_seq;
-  for (uint32_t i = 0; i < b->n_slots; ++i)
+  for (uint32_t i = 0; i < b->n_slots; ++i) {
+    b->slots[i]->table_collected = false;
     if (b->slots[i]->N) b->slots[i]->fused_pending = true;
+  }
   return SA_OK;
 }
 
@@ -2301,6 +2319,24 @@ int sa_tracks_apply_collect(sa_engine* e, uint32_t slot, uint64_t* out_new_ids, 
 // (Batch*::predict, 64 scenes): _begin waits ONCE for the set's Kalman dispatch; _slot does one scene's host side (ids of the tracks that
 // started, predicted boxes) and may run for DIFFERENT slots on different threads at once; _end (the calling thread again) queues the
 // polygons of refreshed oriented rows.  Any entry point that needs the finished table completes what is left.
+// The host side of ONE scene's table for the upkeep step that sa_batch_run_apply queued — the ids of the tracks that start, the rows
+// they take, the checks of the winners — which needs nothing but the association's results: a caller that has them (sa_batch_results)
+// may do this while the Kalman dispatch is still running, per slot, on any thread; sa_tracks_apply_collect_slot then only hands out the boxes.
+int sa_tracks_apply_collect_table(sa_engine* e, uint32_t slot, uint64_t* out_new_ids) {
+  if (!e) return SA_ERR_BAD_ARG;
+  bind_device(e);
+  if (slot >= e->B->n_slots) return fail(e, SA_ERR_BAD_ARG, "slot %u out of range (%u staged)", slot, e->B->n_slots);
+  Slot* s = e->B->slots[slot];
+  if (!s->fused_pending) {
+    if (!s->N) return SA_OK;
+    return fail(e, SA_ERR_STATE, "sa_tracks_apply_collect_table without sa_batch_run_apply (or collected already)");
+  }
+  if (e->B->assoc_event && !e->B->assoc_waited.load(std::memory_order_acquire)) {
+    TRY(wait_done(e, e->B));
+    e->B->assoc_waited.store(true, std::memory_order_release);
+  }
+  return fused_collect_table(e, s, out_new_ids);
+}
 int sa_tracks_apply_collect_begin(sa_engine* e) {
   if (!e) return SA_ERR_BAD_ARG;
   TRY(bound_bank_ok(e, "sa_tracks_apply_collect_begin"));

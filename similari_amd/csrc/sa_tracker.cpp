@@ -709,6 +709,14 @@ int complete_flight(sa_tracker* t) {
       W.trps[i] = trp;
     }
     W.n_new = n_new;
+    // what of the scene's results does not wait for the Kalman dispatch — the engine's side of the table (ids of the tracks that start,
+    // the winners checked) and every field of the caller's tracks but the predicted box of a continued one — is done here, while that
+    // dispatch is on the device; the second set of jobs, behind the wait, only fills the boxes in
+    rc = sa_tracks_apply_collect_table(t->eng, W.slot, nullptr);
+    if (rc != SA_OK) { W.rc = rc; W.err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng); return; }
+    sa_sort_track* out = F.out[s];
+    for (uint32_t i = 0; i < n; ++i)
+      out[i] = W.merged[i] ? to_sort_track_with(o, *W.trps[i], W.cboxes[i], W.cboxes[i]) : to_sort_track(o, *W.trps[i]);
     if (trace) W.job_us[0] = us_between(j0, clk::now());
   });
   const auto t2 = clk::now();
@@ -731,7 +739,7 @@ int complete_flight(sa_tracker* t) {
       if (rcs != SA_OK) { W.rc = rcs; W.err = std::string("sa_tracks_apply: ") + sa_last_error(t->eng); return; }
       sa_sort_track* out = F.out[s];
       for (uint32_t i = 0; i < n; ++i)
-        out[i] = W.merged[i] ? to_sort_track_with(o, *W.trps[i], W.cboxes[i], W.dev_pred[i]) : to_sort_track(o, *W.trps[i]);
+        if (W.merged[i]) out[i].predicted_bbox = W.dev_pred[i];
       if (F.res) {   // the scene's tracks are final: hand them over
         std::lock_guard<std::mutex> lk(F.res->mu);
         F.res->ready_q.push_back(s);
