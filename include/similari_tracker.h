@@ -130,7 +130,7 @@ int sa_batch_result_ready(sa_batch_result* r);
 int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n);
 /* get() without the copy (the reference's get() MOVES a scene's Vec<SortTrack> out of the channel): *out_tracks points at the scene's
  * tracks inside the handle, valid until sa_batch_result_free.  (64 scenes x 500 tracks are 2.3 MB: copied out one scene at a time they
- * cost a C++ host 140 us of a 390 us call, scripts/micro/batch_handle_bench.cpp.) */
+ * cost a C++ host 100 us of a 450 us call, scripts/micro/batch_handle_bench.cpp.) */
 int sa_batch_result_take(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** out_tracks, uint32_t* out_n);
 void sa_batch_result_free(sa_batch_result* r);
 

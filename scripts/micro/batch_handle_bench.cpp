@@ -1,8 +1,8 @@
 // BatchSort::predict through the C ABI from a C++ host (no Python between the calls): the synchronous call against the result handle
-// (sa_tracker_predict_batch_begin + one sa_batch_result_get per scene).  S scenes x n objects on a jittered grid, 5 % of the objects
-// replaced every frame, device upkeep.
+// (sa_tracker_predict_batch_begin + one sa_batch_result_get / _take per scene).  S scenes x n objects of the world scripts/bench_batch_tracker.py
+// uses (dense random boxes, jittered every frame; [churn]: that fraction of the objects replaced every frame), device upkeep.
 //   g++ -O2 -std=c++17 -I include scripts/micro/batch_handle_bench.cpp -L similari_amd/lib -lsimilari_assoc -Wl,-rpath,$PWD/similari_amd/lib -o /tmp/batch_handle_bench
-//   /tmp/batch_handle_bench [scenes] [objects] [frames]
+//   /tmp/batch_handle_bench [scenes] [objects] [frames] [churn]
 #include "similari_tracker.h"
 #include <algorithm>
 #include <chrono>
@@ -15,13 +15,16 @@ using clk = std::chrono::steady_clock;
 static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 int main(int argc, char** argv) {
   const uint32_t S = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 500, frames = argc > 3 ? atoi(argv[3]) : 60;
+  const float churn = argc > 4 ? (float)atof(argv[4]) : 0.0f;
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> u(0.f, 1.f);
-  const uint32_t side = (uint32_t)std::ceil(std::sqrt((double)n));
-  auto fresh = [&](sa_box& b, uint32_t k) {
+  std::normal_distribution<float> g(0.f, 2.f);
+  // the world of scripts/bench_batch_tracker.py (similari_amd/synth.py: dense_boxes / jitter_boxes): centres uniform over 1920 x 1080,
+  // height U(40, 200), aspect U(0.3, 0.6), confidence U(0.3, 1); every frame centre + N(0, 2 px), size x (1 +- 0.001)
+  auto fresh = [&](sa_box& b, uint32_t) {
     b = sa_box{};
-    b.xc = 60.f * (k % side) + 20.f * u(rng); b.yc = 60.f * (k / side) + 20.f * u(rng);
-    b.aspect = 0.5f + 0.2f * u(rng); b.height = 30.f + 10.f * u(rng); b.confidence = 0.9f;
+    b.xc = 1920.f * u(rng); b.yc = 1080.f * u(rng);
+    b.aspect = 0.3f + 0.3f * u(rng); b.height = 40.f + 160.f * u(rng); b.confidence = 0.3f + 0.7f * u(rng);
   };
   std::vector<std::vector<sa_box>> world(S, std::vector<sa_box>(n));
   for (auto& w : world) for (uint32_t k = 0; k < n; ++k) fresh(w[k], k);
@@ -44,7 +47,11 @@ int main(int argc, char** argv) {
       for (uint32_t s = 0; s < S; ++s)
         for (uint32_t k = 0; k < n; ++k) {
           sa_box& b = world[s][k];
-          if (u(rng) < 0.05f) fresh(b, k); else { b.xc += u(rng) - 0.5f; b.yc += u(rng) - 0.5f; }
+          if (churn > 0.f && u(rng) < churn) fresh(b, k);
+          else {
+            b.xc += g(rng); b.yc += g(rng);
+            b.height *= 1.0f + 0.002f * (u(rng) - 0.5f); b.aspect *= 1.0f + 0.002f * (u(rng) - 0.5f); b.confidence = 0.3f + 0.7f * u(rng);
+          }
           sa_observation& ob = obs[s][k];
           ob = sa_observation{};
           ob.bbox = b; ob.feature_quality = std::nanf(""); ob.own_area = std::nanf("");
@@ -73,7 +80,7 @@ int main(int argc, char** argv) {
     if (mode == 2) { first[0] = median(tf); ret[0] = median(tr); }
     sa_tracker_destroy(t);
   }
-  printf("{\"host\": \"C++\", \"tracker\": \"BatchSort\", \"scenes\": %u, \"objects_per_scene\": %u, \"us_per_predict_sync\": %.1f, \"us_per_predict_through_the_handle_get\": %.1f, "
-         "\"us_per_predict_through_the_handle_take\": %.1f, \"us_until_begin_returns\": %.1f, \"us_until_first_scene\": %.1f}\n", S, n, med[0], med[1], med[2], ret[0], first[0]);
+  printf("{\"host\": \"C++\", \"tracker\": \"BatchSort\", \"scenes\": %u, \"objects_per_scene\": %u, \"churn_per_frame\": %.2f, \"us_per_predict_sync\": %.1f, \"us_per_predict_through_the_handle_get\": %.1f, "
+         "\"us_per_predict_through_the_handle_take\": %.1f, \"us_until_begin_returns\": %.1f, \"us_until_first_scene\": %.1f}\n", S, n, (double)churn, med[0], med[1], med[2], ret[0], first[0]);
   return 0;
 }
