@@ -74,6 +74,7 @@ if dev is not None:
     torch.cuda.synchronize()
 times, t_begin, t_first = [], [], []
 sid, cnt = C.c_uint64(), C.c_uint32()
+view = C.POINTER(abi.sa_sort_track)()
 for (arrs, outs, ids, counts, pa, po) in calls:
     t0 = time.perf_counter()
     if mode == "async":
@@ -82,7 +83,7 @@ for (arrs, outs, ids, counts, pa, po) in calls:
         t1 = time.perf_counter()
         assert rc == 0, lib.sa_tracker_last_error(trk.h)
         for k in range(S):
-            rc = lib.sa_batch_result_get(h, C.byref(sid), outs[0], n, C.byref(cnt))
+            rc = lib.sa_batch_result_take(h, C.byref(sid), C.byref(view), C.byref(cnt))   # (in place: the reference's get() moves the scene's Vec)
             if k == 0:
                 t2 = time.perf_counter()
             assert rc == 0

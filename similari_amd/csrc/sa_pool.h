@@ -9,6 +9,7 @@
 // hundred microseconds after a run (a tracker loop calls predict() back to back: the next run finds them awake) and then sleep on a
 // condition variable.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -31,30 +32,44 @@
 
 class SaPool {
  public:
-  // pin: worker w is bound to the (w + 1)-th CPU after the creating thread's, among the CPUs that thread may run on — its neighbours in
-  // the same socket and cache complex on the usual numbering.  Measured on the 2 x 64-core host of the MI355X box (64 scenes x 500 objects,
+  // pin: worker w is bound to the (w + 1)-th CPU after the creating thread's that no other pool of the process holds, among the CPUs that
+  // thread may run on — its neighbours in the same socket and cache complex on the usual numbering.  Measured on the 2 x 64-core host of the MI355X box (64 scenes x 500 objects,
   // 8 threads): left to the scheduler the workers land on the other socket and a merge job runs at 300 ns per object, every record a
   // remote miss; next to the caller at 7.
   explicit SaPool(uint32_t workers, bool pin = true) : acks_(workers ? new Ack[workers] : nullptr), nw_(workers) {
-    std::vector<int> cpus;
-    int at = -1;
 #if defined(__linux__)
-    if (pin) {
+    if (pin && workers) {
+      // the CPUs the creating thread may run on, from its own onwards; the first workers + 1 of them that no other pool of this process
+      // has taken (two trackers created by one thread would otherwise bind their workers to the SAME CPUs: a worker still spinning after
+      // its tracker's run and a worker of the other tracker's run on one CPU take turns by the scheduler's tick — milliseconds)
       cpu_set_t allowed;
       CPU_ZERO(&allowed);
       const int here = sched_getcpu();
+      std::vector<int> cpus;
+      int at = -1;
       if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
         for (int c = 0; c < CPU_SETSIZE; ++c)
           if (CPU_ISSET(c, &allowed)) { if (c == here) at = (int)cpus.size(); cpus.push_back(c); }
+      if (at >= 0) {
+        std::lock_guard<std::mutex> lk(claims_mu());
+        std::vector<int>& taken = claims();
+        for (size_t k = 1; k < cpus.size() && mine_.size() < (size_t)workers + 1; ++k) {
+          const int c = cpus[((size_t)at + k) % cpus.size()];
+          if (std::find(taken.begin(), taken.end(), c) == taken.end()) mine_.push_back(c);
+        }
+        if (mine_.size() == (size_t)workers + 1) taken.insert(taken.end(), mine_.begin(), mine_.end());
+        else mine_.clear();   // (not enough free CPUs: this pool is left to the scheduler)
+      }
+      if (!mine_.empty()) next_cpu_ = mine_.back();   // (behind the workers: kept for a companion thread of the owner's, next_cpu())
     }
 #endif
     for (uint32_t w = 0; w < workers; ++w) {
       th_.emplace_back([this, w] { loop(w); });
 #if defined(__linux__)
-      if (at >= 0 && cpus.size() > workers) {
+      if (!mine_.empty()) {
         cpu_set_t set;
         CPU_ZERO(&set);
-        CPU_SET(cpus[((size_t)at + 1 + w) % cpus.size()], &set);
+        CPU_SET(mine_[w], &set);
         pthread_setaffinity_np(th_.back().native_handle(), sizeof set, &set);
       }
 #endif
@@ -69,8 +84,22 @@ class SaPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
     delete[] acks_;
+    if (!mine_.empty()) {
+      std::lock_guard<std::mutex> lk(claims_mu());
+      std::vector<int>& taken = claims();
+      for (int c : mine_) {
+        auto it = std::find(taken.begin(), taken.end(), c);
+        if (it != taken.end()) taken.erase(it);
+      }
+    }
   }
   uint32_t threads() const { return nw_ + 1; }
+  // The CPU right behind the pinned workers' (-1: the pool is not pinned): where a companion thread of the owner belongs — chosen HERE,
+  // from the same list and the same position the workers were placed by (a thread that looks up "the CPUs next to the caller" by itself,
+  // later, starts from wherever the caller runs THEN and can land on a worker's CPU: two spinning threads on one CPU take turns by the
+  // scheduler's tick, milliseconds at a time).
+  int next_cpu() const { return next_cpu_; }
+  const std::vector<int>& claimed_cpus() const { return mine_; }   // (the workers', then next_cpu(); empty: not pinned)
 
   // fn(i) for i in [0, n): job i on thread i % threads().  One run at a time (the facade's entry points are serial).
   // No lock on the way: the run is published by one store (the workers spin on that word), every worker answers with one store to a
@@ -128,6 +157,10 @@ class SaPool {
   std::vector<std::thread> th_;
   Ack* acks_;
   uint32_t nw_;
+  int next_cpu_ = -1;
+  std::vector<int> mine_;   // the CPUs this pool has claimed: its workers', then next_cpu()
+  static std::mutex& claims_mu() { static std::mutex m; return m; }
+  static std::vector<int>& claims() { static std::vector<int> v; return v; }   // CPUs claimed by the pools of this process
   std::mutex mu_;
   std::condition_variable cv_;
   alignas(64) std::atomic<uint64_t> gen_{0};

@@ -916,24 +916,15 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
   if (!t->driver.joinable()) {
     t->driver = std::thread(driver_loop, t);
 #if defined(__linux__)
-    // next to the caller and the pool's workers (sa_pool.h: worker w on the (w + 1)-th CPU after the creating thread's): the driver runs
-    // the calling thread's share of the jobs behind the launches — the scenes' records should not cross a socket for it
-    if (o.workers >= 0) {
-      cpu_set_t allowed;
-      CPU_ZERO(&allowed);
-      const int here = sched_getcpu();
-      std::vector<int> cpus;
-      int at = -1;
-      if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
-        for (int c = 0; c < CPU_SETSIZE; ++c)
-          if (CPU_ISSET(c, &allowed)) { if (c == here) at = (int)cpus.size(); cpus.push_back(c); }
-      const size_t behind = t->pool ? t->pool->threads() : 1;   // (the caller + the workers)
-      if (at >= 0 && cpus.size() > behind + 1) {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        CPU_SET(cpus[((size_t)at + behind) % cpus.size()], &set);
-        pthread_setaffinity_np(t->driver.native_handle(), sizeof set, &set);
-      }
+    // behind the pool's workers (SaPool::next_cpu: the same list and position they were placed by): the driver runs the calling thread's
+    // share of the jobs behind the launches — the scenes' records should not cross a socket for it.  Without a pinned pool it is left
+    // to the scheduler.
+    const int cpu = t->pool ? t->pool->next_cpu() : -1;
+    if (cpu >= 0) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET(cpu, &set);
+      pthread_setaffinity_np(t->driver.native_handle(), sizeof set, &set);
     }
 #endif
   }
