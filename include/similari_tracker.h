@@ -89,8 +89,8 @@ typedef struct sa_tracker_options {
                                            no per-frame upload of boxes / Kalman state / features; 0 = host upkeep + sa_tracks_upsert */
   int32_t workers;                      /* threads working on the scenes of one request set (Batch*: the reference's voting_shards,
                                            sort/batch_api.rs:197-207), the calling thread included; 0 = the facade's choice, 1 = none.
-                                           n > 1: bound to the CPUs next to the one the first batch call runs on (a scene's records stay in
-                                           one cache complex); -n: n threads left to the scheduler */
+                                           n > 1: bound to the CPUs next to the one the first batch call runs on that no other tracker of
+                                           the process holds (a scene's records stay in one cache complex); -n: n threads left to the scheduler */
 } sa_tracker_options;
 
 typedef struct sa_tracker sa_tracker;
