@@ -136,6 +136,46 @@ def test_pipelined_tickets_match_the_synchronous_path(pinned):
         eng.close()
 
 
+def test_completion_words_never_arrive_before_the_results_they_announce():
+    """A long pipelined run (three tickets in flight, request sets of one to four scenes of every size from 3 to ~400 detections, each
+    frame different): the host takes a ticket's results the moment its scenes' completion words show the launch's sequence number —
+    every id and vote type must be what the synchronous path answers for the same request (computed beforehand on a second engine).
+    A word that overtook its results would hand out the previous occupant of the result block."""
+    rng = np.random.default_rng(79)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5)
+    scenes = {s: synth.sort_scene(rng, 420, 420, canvas=(1400.0, 900.0), pos_sigma=3.0) for s in range(4)}
+    a, b = Engine(cfg), Engine(cfg)
+    try:
+        for eng in (a, b):
+            for s, sc in scenes.items():
+                upsert_scene(eng, s, sc, False)
+        sets = []
+        for f in range(2000):
+            items = []
+            for s in rng.permutation(4)[: 1 + f % 4]:
+                sc = scenes[int(s)]
+                n = int(rng.integers(3, len(sc["det_boxes"])))
+                p = rng.permutation(len(sc["det_boxes"]))[:n]
+                items.append((int(s), 1, abi.make_detections(sc["det_boxes"][p])))
+            want = [b.associate(s, 1, det) for s, _, det in items]
+            sets.append((items, Engine.make_requests(items), want))
+        depth = 3
+        tickets = [None] * len(sets)
+        for f in range(len(sets) + depth - 1):
+            if f < len(sets):
+                tickets[f] = a.pipe_submit(sets[f][1][0])
+            j = f - (depth - 1)
+            if j >= 0:
+                items, (req, res, outs), want = sets[j]
+                a.pipe_wait(tickets[j], res)
+                for k, ((ids, votes), (wi, wv)) in enumerate(zip(outs, want)):
+                    np.testing.assert_array_equal(ids, wi, err_msg=f"request set {j}, scene {k}")
+                    np.testing.assert_array_equal(votes, wv)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_apply_in_two_halves_matches_the_single_call():
     """sa_tracks_apply_begin / _end (the tracker facade's form: its own bookkeeping runs between the two) on oriented boxes against
     sa_tracks_apply on a second engine, six frames: same predicted boxes, same tables and polygons.  On odd frames the second half is
