@@ -703,6 +703,52 @@ def test_batch_result_handle_delivers_every_scene(backend):
 
 
 @pytest.mark.gpu
+def test_long_batch_run_device_upkeep_against_host_upkeep():
+    """400 frames of BatchSort over five scenes with missed detections, false positives and departures — the fused path (association with
+    the upkeep queued behind it, completion words, the table side of the collect ahead of the Kalman wait, staged evictions, every third
+    frame through the result handle) against the facade's host-upkeep path frame by frame: same tracks, same idle and wasted sets.  (Both
+    are compared with the oracle tracker on short sequences above; this one is about the thousandth frame.)"""
+    rng = np.random.default_rng(83)
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
+    g, h = make("gpu_dev", "sort", **kw), make("gpu", "sort", **kw)
+    try:
+        scenes = (2, 3, 5, 7, 11)
+        world = {s: synth.dense_boxes(rng, 70 + 10 * k, (1100.0, 800.0)) for k, s in enumerate(scenes)}
+        for f in range(400):
+            req = TR.PredictionBatchRequest()
+            for s in scenes:
+                world[s] = synth.jitter_boxes(rng, world[s], 2.0)
+                keep = rng.uniform(size=len(world[s])) > 0.1
+                extra = synth.dense_boxes(rng, int(rng.integers(0, 5)), (1100.0, 800.0))
+                det = np.concatenate([world[s][keep], extra])
+                det = det[rng.permutation(len(det))]
+                for i, bx in enumerate(boxes_to_u2d(det)):
+                    req.add(s, (bx, i if i % 4 == 0 else None))
+                if f % 50 == 49:                                  # a few objects leave, as many arrive
+                    world[s] = np.concatenate([world[s][3:], synth.dense_boxes(rng, 3, (1100.0, 800.0))])
+            if f % 3 == 2:
+                res = g.predict_batch_async(req)
+                rg = {}
+                for _ in range(res.batch_size()):
+                    sid, tracks = res.get()
+                    rg[sid] = tracks
+                res.close()
+            else:
+                rg = g.predict_batch(req)
+            rh = h.predict_batch(req)
+            for s in scenes:
+                assert_tracks_equal(rg[s], rh[s])
+            if f % 40 == 39:
+                assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in h.wasted())
+                for s in scenes:
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id), sorted(h.idle_tracks_with_scene(s), key=lambda x: x.id))
+        assert g.active_tracks() == h.active_tracks()
+    finally:
+        g.close()
+        h.close()
+
+
+@pytest.mark.gpu
 def test_batch_result_handle_survives_the_next_call_and_reused_request_arrays():
     """The request is taken by value: the caller's observation arrays are overwritten right after _begin returns, the next predict() is
     issued before the handle has been read (it waits for the set in flight — the reference's busy monitor), and the handle still
