@@ -626,7 +626,7 @@ def test_caller_may_overwrite_its_device_feature_block_once_predict_has_returned
 
 
 # ---- Batch*::predict over several scenes: one set of launches, the scenes' host work side by side ----------------------------------
-def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25), frames=8, d=64, bank=3, async_handle=False):
+def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25), frames=8, d=64, bank=3, async_handle=False, reference="oracle"):
     """BatchVisualSort over several scenes of different sizes (visual_sort/batch_api.rs:213-317): every frame's tracks of every scene
     against the oracle tracker; with async_handle the request goes through sa_tracker_predict_batch_begin and the scenes are taken from
     the PredictionBatchResult handle in whatever order they finish."""
@@ -635,7 +635,7 @@ def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25)
             .positional_metric(IoU(0.3)).visual_minimal_track_length(min(2, bank)).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(bank).visual_min_votes(1))
     g = make(backend, "visual", opts=opts, feature_len=d, batch=True)
-    o = make("oracle", "visual", opts=opts, feature_len=d, batch=True)
+    o = make(reference, "visual", opts=opts, feature_len=d, batch=True)   # (the oracle tracker, or the facade's other upkeep path)
     try:
         ident = {s: synth.reid_identities(rng, n, d) for s, n in zip(scenes, sizes)}
         world = {s: synth.dense_boxes(rng, n, (900.0, 700.0)) for s, n in zip(scenes, sizes)}
@@ -686,6 +686,14 @@ def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25)
 @UPKEEP
 def test_batch_visual_sort_three_scenes_match_oracle(backend):
     run_batch_visual_scenes(backend, seed=61)
+
+
+@pytest.mark.gpu
+def test_long_batch_visual_run_device_upkeep_against_host_upkeep():
+    """150 frames of BatchVisualSort over three scenes through the result handle: the fused device-upkeep path (Kalman and feature banks
+    on the GPU, completion words, the collect's table side ahead of the Kalman wait) against the facade's host-upkeep path, frame by frame
+    — tracks, vote types, observation counts, idle sets."""
+    run_batch_visual_scenes("gpu_dev", seed=89, frames=150, async_handle=True, reference="gpu")
 
 
 @pytest.mark.gpu
