@@ -7,6 +7,16 @@
 #include "../../include/similari_assoc.h"
 #include "sa_device.h"
 
+// Fragment order of a [rows][Dp] f32 matrix (rows padded to a multiple of 32; Dp a multiple of 32): blocks of 32 rows x 8 k, each one
+// contiguous kilobyte laid out [k / 4][row][k % 4] — exactly what the 64 lanes of a wave hold as the operand of four consecutive
+// v_mfma_f32_32x32x2_f32 (lane l: row l & 31, k-slot l >> 5, four consecutive k), so a wave-load is ONE contiguous dwordx4 per lane: 8
+// full cache lines instead of 32 B out of each of 32.  The engine keeps the track bank in this order NEXT TO the row-major bank
+// (SceneDev::t_ffrag; every kernel that writes bank rows writes both), for the k-split contraction (sa_gemm.hip: gemm_mainloop_ks).
+__host__ __device__ __forceinline__ size_t sa_frag_index(uint32_t r, uint32_t k, uint32_t Dp) {
+  return ((size_t)(r >> 5) * (Dp >> 3) + (k >> 3)) * 256u + ((k >> 2) & 1u) * 128u + (r & 31u) * 4u + (k & 3u);
+}
+static inline size_t sa_frag_bytes(size_t rows, uint32_t Dp) { return (rows + 31u) / 32u * 32u * (size_t)Dp * 4u; }
+
 // Device-visible description of one scene of the current batch (blockIdx.z selects it).
 // HBM layout (all row-major, structure-of-arrays; T tracks, K bank slots, Dp = feature length padded to 32):
 //   t_geo[T] 16 B | t_verts[T][8] f64 | t_epoch[T] | t_maha[T][20] (mean5 + packed Cholesky L15)
@@ -61,6 +71,7 @@ struct SceneDev {
   const uint64_t SA_G* t_epoch;
   const float SA_G* t_maha;
   const float SA_G* t_feat;
+  const float SA_G* t_ffrag;  // the same bank in FRAGMENT order (sa_frag_index): what the k-split contraction's wave-loads read
   const float SA_G* t_fnorm;
   const uint8_t SA_G* t_fpresent;
   const uint32_t SA_G* t_fcount;
@@ -188,6 +199,8 @@ struct SaParams {
   uint32_t force_general;       // SA_FLAG_GENERAL_TAIL: the many-workgroup assignment tail (and the launches that feed it) whatever the frame size
   uint32_t row_major_tiles;     // order of the contraction's tiles: 1 = the default (stand-alone contraction row by row, fused first phase XCD-aware),
                                 // 0 = XCD-aware everywhere (SA_FLAG_XCD_TILES), 2 = row by row everywhere (SA_FLAG_ROW_TILES); sa_gemm.hip
+  uint32_t ks_yield;            // k-split loop of the fused first phase: the matrix waves sleep 64 cycles after every ks_yield-th k-step (0: never)
+  uint32_t staged_loop;         // SA_FLAG_STAGED_LOOP: the fused first phase's contraction tiles on the LDS-staged main loop (row-major bank)
   int32_t gemm_plan;            // sa_config.gemm_plan - 1: the contraction's tile plan pinned (tuning / tests), -1 = tile_plan()'s own choice
 };
 
@@ -230,7 +243,7 @@ hipError_t sa_launch_prep_tracks(const PrepTrackArgs& a, const SaParams& p, hipS
 // and stores the squared norm; `present` (or nullptr) zeroes absent rows.
 hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                   const uint32_t* slots, const uint8_t* present, float* dst, float* norms,
-                                  uint8_t* dst_present, uint32_t* fcount, hipStream_t st);
+                                  uint8_t* dst_present, uint32_t* fcount, hipStream_t st, float* dst_frag = nullptr);
 // one launch of the ingest kernel moves up to SA_COPY_SEGS pinned-host -> HBM segments (device-visible source addresses)
 #define SA_COPY_SEGS 12
 struct SaCopySegs {
@@ -248,6 +261,10 @@ struct SaGatherTable {
   uint32_t row_bytes[SA_TABLE_ARRAYS];
   uint32_t n_arrays, rows;
   const uint32_t* index;   // [rows] device-visible (mapped pinned memory)
+  // the feature bank's fragment-order twin follows the rows of array `frag_array` (row-major source -> the twin, in place: nothing
+  // reads the twin while the gather runs); frag = nullptr: no bank
+  float* frag;
+  uint32_t frag_array, frag_K, frag_Dp;
 };
 hipError_t sa_launch_gather_table(const SaGatherTable& g, hipStream_t st, hipEvent_t done = nullptr);
 // ... of several scenes in one launch (blockIdx.y = scene; the arguments travel by value: 12 x 256 bytes fit a dispatch's 4 KB)
@@ -288,6 +305,7 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t n_scenes, uint32_t 
                             const SaParams& p, hipStream_t st, int stage, uint64_t done_seq = 0);
 hipError_t sa_launch_quant_tap(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                                hipStream_t st);
+hipError_t sa_launch_frag_reorder(const float* src, uint32_t rows, uint32_t dp, float* dst, hipStream_t st);
 // Standalone contraction for sa_feature_distance_matrix: out[n][t] = cosine / euclid distance (no gating).
 hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, const float* b, const float* bn,
                                      uint32_t n, uint32_t t, uint32_t dp, float* out, hipStream_t st, int32_t plan_override = -1);
@@ -330,6 +348,7 @@ struct BankArgs {
   const float* c_quality;
   const float* c_own;
   float* t_feat;
+  float* t_ffrag;            // the bank's fragment-order twin (every row written to t_feat is written here too)
   float* t_fnorm;
   uint8_t* t_fpresent;
   float* t_fquality;

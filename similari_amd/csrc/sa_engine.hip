@@ -57,6 +57,8 @@ struct alignas(128) SceneTable {   // (aligned: the tracker facade works on diff
   uint64_t index_drain = ~0ull;                    // sa_engine::drain_count when the last gather that reads h_index was queued (~0: none): the
                                                    // buffer may be rewritten once the engine has been drained since
   DevBuf geo, ext, verts, epoch, maha, feat, fnorm, fpresent, fcount, tids;
+  DevBuf ffrag;                    // the feature bank once more, in FRAGMENT order (sa_frag_index): every kernel that writes rows of `feat`
+                                   // writes this twin too; the k-split contraction's wave-loads read it
   DevBuf kf, fquality;             // device-side upkeep: Kalman mean(10) + cov(100) per track, feature quality per bank slot
   std::vector<uint8_t> full;       // slot -> the device holds a full Kalman state for it (sa_tracks_apply / sa_tracks_set_state)
   uint32_t eu_valu_left = 0;       // euclidean engines: frames of THIS scene still to run on the vector-pipe kernel after one of its frames
@@ -423,6 +425,7 @@ int scene_reserve(sa_engine* e, SceneTable* s, uint32_t need) {
   TRY(dev_ensure(e, s->kf, (size_t)ncap * 110 * sizeof(float), true));
   if (e->visual) {
     TRY(dev_ensure(e, s->feat, (size_t)ncap * KDp * sizeof(float), true));
+    TRY(dev_ensure(e, s->ffrag, sa_frag_bytes((size_t)ncap * e->K, e->Dp), true));   // (blocks of 32 rows, rows ascending: growth appends)
     TRY(dev_ensure(e, s->fnorm, (size_t)ncap * e->K * sizeof(float), true));
     TRY(dev_ensure(e, s->fpresent, (size_t)ncap * e->K, true));
     TRY(dev_ensure(e, s->fcount, (size_t)ncap * 4, true));
@@ -594,7 +597,7 @@ void fill_scene_dev(sa_engine* e, const Bank* bk, Slot* s, SceneDev* d) {
   if (bk->words == 3) d->nkeys = ((s->N + 63) / 64) * ((s->T + 64 / e->K - 1) / (64 / e->K));  // whole-track tiles: floor(64 / K) tracks each
   d->epoch = s->epoch;
   d->t_geo = (decltype(d->t_geo))(sc->geo.p); d->t_ext = (decltype(d->t_ext))(sc->ext.p); d->t_verts = (decltype(d->t_verts))(sc->verts.p); d->t_epoch = (decltype(d->t_epoch))(sc->epoch.p);
-  d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
+  d->t_maha = (decltype(d->t_maha))(sc->maha.p); d->t_feat = (decltype(d->t_feat))(sc->feat.p); d->t_ffrag = (decltype(d->t_ffrag))(sc->ffrag.p); d->t_fnorm = (decltype(d->t_fnorm))(sc->fnorm.p);
   d->t_fpresent = (decltype(d->t_fpresent))(sc->fpresent.p); d->t_fcount = (decltype(d->t_fcount))(sc->fcount.p); d->t_ids = (decltype(d->t_ids))(sc->tids.p);
   d->c_raw = (decltype(d->c_raw))(s->p_raw); d->c_quality = (decltype(d->c_quality))(s->p_quality); d->c_own = (decltype(d->c_own))(s->p_own);
   d->c_fpresent_in = (decltype(d->c_fpresent_in))(s->p_fpresent); d->c_feat_raw = (decltype(d->c_feat_raw))(s->p_feat_raw);
@@ -659,7 +662,7 @@ void fill_apply_args(sa_engine* e, Slot* s, const uint32_t* new_row, const uint6
   b.c_fpresent_in = s->has_fpresent ? (const uint8_t*)s->p_fpresent : nullptr;
   b.c_quality = s->has_quality ? (const float*)s->p_quality : nullptr;
   b.c_own = s->has_own ? (const float*)s->p_own : nullptr;
-  b.t_feat = (float*)sc->feat.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
+  b.t_feat = (float*)sc->feat.p; b.t_ffrag = (float*)sc->ffrag.p; b.t_fnorm = (float*)sc->fnorm.p; b.t_fpresent = (uint8_t*)sc->fpresent.p;
   b.t_fquality = (float*)sc->fquality.p; b.t_fcount = (uint32_t*)sc->fcount.p;
   b.minimal_area = e->cfg.visual_minimal_area; b.q_collect = e->cfg.visual_minimal_quality_collect;
   b.own_collect = e->cfg.visual_minimal_own_area_percentage_collect;
@@ -1143,6 +1146,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.vote_words = 0;  // set per frame by enqueue_frame
   P.force_general = (cfg->flags & SA_FLAG_GENERAL_TAIL) ? 1u : 0u;
   P.gemm_plan = cfg->gemm_plan > 0 ? cfg->gemm_plan - 1 : -1;
+  P.staged_loop = (cfg->flags & SA_FLAG_STAGED_LOOP) ? 1u : 0u;
   P.row_major_tiles = (cfg->flags & SA_FLAG_XCD_TILES) ? 0u : ((cfg->flags & SA_FLAG_ROW_TILES) ? 2u : 1u);
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
@@ -1189,7 +1193,7 @@ void sa_engine_destroy(sa_engine* e) {
   for (auto& g : e->garbage) hipFree(g.p);
   for (auto& kv : e->scenes) {
     SceneTable* s = kv.second;
-    for (DevBuf* b : {&s->geo, &s->ext, &s->verts, &s->epoch, &s->maha, &s->feat, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
+    for (DevBuf* b : {&s->geo, &s->ext, &s->verts, &s->epoch, &s->maha, &s->feat, &s->ffrag, &s->fnorm, &s->fpresent, &s->fcount, &s->tids, &s->kf, &s->fquality}) free_dev(*b);
     for (DevBuf& b : s->spare) free_dev(b);
     free_host(s->h_index);
     delete s;
@@ -1329,7 +1333,7 @@ int sa_tracks_upsert(sa_engine* e, uint64_t scene_id, const sa_tracks* t) {
     }
     HIPCHK(e, sa_launch_pad_features(have_feats ? (const float*)e->up_feats.p : nullptr, n * K, D, e->Dp, K,
                                      (const uint32_t*)e->up_slots.p, (const uint8_t*)e->up_present.p, (float*)sc->feat.p,
-                                     (float*)sc->fnorm.p, (uint8_t*)sc->fpresent.p, (uint32_t*)sc->fcount.p, st));
+                                     (float*)sc->fnorm.p, (uint8_t*)sc->fpresent.p, (uint32_t*)sc->fcount.p, st, (float*)sc->ffrag.p));
   }
   SA_BUSY(e);
   return engine_sync(e);
@@ -1412,6 +1416,7 @@ static int remove_build(sa_engine* e, SceneTable* sc, SaGatherTable* g) {
     }
     g->src[k] = arrs[k]->p; g->dst[k] = sc->spare[k].p; g->row_bytes[k] = rowb[k];
   }
+  if (e->visual) { g->frag = (float*)sc->ffrag.p; g->frag_array = 7u; g->frag_K = K; g->frag_Dp = e->Dp; }  // (array 7 = the bank)
   return SA_OK;
 }
 // (3) the gather has been queued: the compacted arrays become the table, the host's id list follows
@@ -2810,6 +2815,19 @@ int sa_feature_distance_matrix(sa_engine* e, int32_t kind, uint32_t n, uint32_t 
         hipMemcpyAsync(rb.p, b, (size_t)t * d * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "H2D copy failed"); break; }
     if (sa_launch_pad_features((const float*)ra.p, n, d, d8, 1, nullptr, nullptr, (float*)pa.p, (float*)na.p, nullptr, nullptr, st) != hipSuccess ||
         sa_launch_pad_features((const float*)rb.p, t, d, d8, 1, nullptr, nullptr, (float*)pb.p, (float*)nb.p, nullptr, nullptr, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "pad launch failed"); break; }
+    // the k-split plans 10 / 12 read the B operand in fragment order (sa_gemm.hip: sa_frag_index)
+    if (kind == SA_VIS_COSINE && (e->P.gemm_plan == 10 || e->P.gemm_plan == 12 || (e->P.gemm_plan >= 15 && e->P.gemm_plan <= 17))) {
+      if (dev_ensure(e, rb, (size_t)((t + 31u) / 32u * 32u) * d8 * 4) != SA_OK) { rc = SA_ERR_HIP; break; }
+      if (sa_launch_frag_reorder((const float*)pb.p, t, d8, (float*)rb.p, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "reorder launch failed"); break; }
+      std::swap(pb, rb);
+    }
+    if (kind == SA_VIS_COSINE && (e->P.gemm_plan == 13 || e->P.gemm_plan == 14)) {  // both operands in fragment order
+      if (dev_ensure(e, rb, (size_t)((t + 31u) / 32u * 32u) * d8 * 4) != SA_OK || dev_ensure(e, ra, (size_t)((n + 63u) / 64u * 64u) * d8 * 4) != SA_OK) { rc = SA_ERR_HIP; break; }
+      if (sa_launch_frag_reorder((const float*)pb.p, t, d8, (float*)rb.p, st) != hipSuccess ||
+          sa_launch_frag_reorder((const float*)pa.p, n, d8, (float*)ra.p, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "reorder launch failed"); break; }
+      std::swap(pb, rb);
+      std::swap(pa, ra);
+    }
     // one warm-up launch, then `iters` timed launches of the contraction kernel alone
     if (sa_launch_distance_matrix(kind, (const float*)pa.p, (const float*)na.p, (const float*)pb.p, (const float*)nb.p, n, t, d8, (float*)o.p, st, e->P.gemm_plan) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "kernel launch failed"); break; }
     hipEventRecord(e->ev_t0, st);

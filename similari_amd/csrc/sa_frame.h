@@ -22,20 +22,23 @@ __device__ __forceinline__ void prep_box_common(const BoxRaw& r, sa_geo* geo, do
 // One wave per feature row: zero-pad D -> Dp (Feature::from_vec, track/utils.rs:45-71; the extra zero lanes
 // add +0.0 to every sum), scatter, squared norm (the per-pair norms of distance.rs:36-44 hoisted to once
 // per vector).
+// (fr / frow: the destination's fragment-order twin and the row's index in it — the track bank, sa_frag_index — or nullptr)
 __device__ __forceinline__ void pad_feature_row(const float* s, float* d, uint32_t D, uint32_t Dp,
-                                                bool pres, uint32_t lane, float* norm_out) {
+                                                bool pres, uint32_t lane, float* norm_out, float* fr = nullptr, uint32_t frow = 0) {
   float acc = 0.0f;
   const bool alias = d == s;  // D == Dp: the uploaded rows ARE the padded rows (the engine points c_feat at them): norms only
   if (pres && (D & 3u) == 0 && ((uintptr_t)s & 15u) == 0) {
     for (uint32_t k = lane * 4; k < Dp; k += WAVE * 4) {
       float4 x = k < D ? *(const float4*)(s + k) : float4{0.f, 0.f, 0.f, 0.f};
       if (!alias) *(float4*)(d + k) = x;
+      if (fr) *(float4*)(fr + sa_frag_index(frow, k, Dp)) = x;   // four consecutive k of a row are contiguous in fragment order too
       acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     }
   } else {
     for (uint32_t k = lane; k < Dp; k += WAVE) {
       float x = (pres && k < D) ? s[k] : 0.0f;
       if (!alias || !pres) d[k] = x;  // a row without a feature is zeroed in place (nothing reads its uploaded content)
+      if (fr) fr[sa_frag_index(frow, k, Dp)] = x;
       acc += x * x;
     }
   }

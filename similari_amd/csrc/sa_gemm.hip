@@ -438,6 +438,214 @@ __device__ __forceinline__ void gemm_mainloop_ring(gfloat_p A, gfloat_p B, uint3
   SA_STAMP(tr, 2);
 }
 
+// (fragment order: sa_engine.h, sa_frag_index)
+__global__ void k_frag_reorder(const float* __restrict__ src, uint32_t rows, uint32_t Dp, float* __restrict__ dst) {
+  // one thread per 16-byte piece of the destination; rows past the end repeat the last row (never stored by the consumers)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)((rows + 31u) / 32u * 32u) * Dp / 4u;
+  if (i >= total) return;
+  const uint32_t lane = (uint32_t)(i & 63u);
+  const size_t blk = i >> 6;
+  const uint32_t kb = (uint32_t)(blk % (Dp >> 3)), rb = (uint32_t)(blk / (Dp >> 3));
+  uint32_t r = rb * 32u + (lane & 31u);
+  r = r < rows ? r : rows - 1;
+  ((f32x4*)dst)[i] = *(const f32x4*)(src + (size_t)r * Dp + kb * 8u + (lane >> 5) * 4u);
+}
+hipError_t sa_launch_frag_reorder(const float* src, uint32_t rows, uint32_t dp, float* dst, hipStream_t st) {
+  const size_t total = (size_t)((rows + 31u) / 32u * 32u) * dp / 4u;
+  hipLaunchKernelGGL(k_frag_reorder, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src, rows, dp, dst);
+  return hipGetLastError();
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sa_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sa_static_for<I + 1, N>(f); }
+}
+
+// k-split main loop of the 64 x 64 tile (KS): NO LDS stage and NO barrier between the first load and the last matrix instruction.
+// A lone wave per SIMD pays ~25 matrix-pipe cycles for every LDS or memory instruction it issues (scripts/micro/mfma_side_mix.hip);
+// the staged loop above issues 16 of them per 16 matrix instructions (8 ds_read_b128, 4 ds_write_b128, 4 global loads).  Here wave
+// (wm, kg) owns tile rows wm 32 .. +31, ALL 64 tile columns, and every second 8-deep k-step (kg = its parity): a 32 x 64 wave tile of
+// two independent accumulators whose operands come straight from memory into registers — per k-step one dwordx4 of A (its 32 rows,
+// row-major: 32 B out of 32 lines) and two of B (row-major likewise, or BFRAG: the fragment-order copy of the bank, one contiguous
+// kilobyte each) for 8 matrix instructions: 6 side instructions per 16 instead of 16.  NBUF register buffers: the loads of step
+// j + NBUF - 1 are issued under the matrix instructions of step j.  The two k-halves of a 32 x 32 quadrant meet through LDS once, at
+// the end (each wave ships the quadrant it does not keep: 4 KB): wave (wm, x) leaves with rows wm 32.., columns x 32.. in the
+// standard 32 x 32 accumulator layout — what the epilogues of this file expect from wave (wm, wn = x).
+// NORM: *nsq = the squared norm of row wm 32 + lr of A (both lane halves, both k-halves), complete.
+template <int NBUF, bool NORM, bool BFRAG, bool AFRAG = false>
+__device__ __forceinline__ void gemm_mainloop_ks(gfloat_p A, gfloat_p B, uint32_t M, uint32_t Ncols, uint32_t Dp, uint32_t m0,
+                                                 uint32_t n0, float* lds, f32x16& out, uint64_t* tr = nullptr, float* nsq = nullptr,
+                                                 uint32_t yield_every = 0) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) & 3u;
+  const uint32_t wm = w4 >> 1, kg = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  // Buffer loads: a resource descriptor per operand (base = the tile's first row, range = what is left of the matrix behind it), a
+  // 32-bit byte offset per lane (constant), and the position along k in the instruction's SCALAR offset — no vector arithmetic and no
+  // 64-bit address in the loop, and rows past the matrix edge need no clamp: they are out of range and read as zero.
+  const uint32_t Mp = AFRAG ? (M + 31u) / 32u * 32u : M, Np = BFRAG ? (Ncols + 31u) / 32u * 32u : Ncols;
+  const uint32_t nb0 = BFRAG ? (n0 & ~31u) : n0;
+  auto left = [&](uint32_t rows) { const uint64_t b = (uint64_t)rows * Dp * 4u; return (uint32_t)(b < 0xffffffffull ? b : 0xffffffffull); };
+  const __amdgpu_buffer_rsrc_t RA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * Dp), 0, (int)left(Mp - m0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t RB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)nb0 * Dp), 0, (int)left(Np - nb0), 0x00020000);
+  const uint32_t oa = AFRAG ? (wm * 32u * Dp + lane * 4u) * 4u : ((wm * 32u + lr) * Dp + lh * 4u) * 4u;  // (m0 is a multiple of 64)
+  uint32_t ob[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    // (fragment order: the tile's first column need not start a block of 32 rows — the whole-track tiles of deeper banks start anywhere;
+    // a wave-load then covers two runs of a kilobyte instead of one)
+    const uint32_t rr = (n0 - nb0) + n * 32u + lr;
+    ob[n] = BFRAG ? ((rr >> 5) * (Dp >> 3) * 256u + lh * 128u + (rr & 31u) * 4u) * 4u : ((n * 32u + lr) * Dp + lh * 4u) * 4u;
+  }
+  const uint32_t mine = Dp >> 4;  // k-steps of this wave: global step s = 2 j + kg (Dp is a multiple of 32)
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  f32x4 fa[NBUF], fb[NBUF][2];
+  float ns = 0.f;
+  auto load = [&](auto buf_tag, uint32_t j) {  // (a step past the end reads the next rows' bytes or zeros: never multiplied)
+    constexpr int buf = decltype(buf_tag)::value;
+    const uint32_t s = 2u * j + kg;
+    fa[buf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, (int)oa, (int)(s * (AFRAG ? 1024u : 32u)), 0));
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      fb[buf][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RB, (int)ob[n], (int)(s * (BFRAG ? 1024u : 32u)), 0));
+  };
+  auto compute = [&](auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][e], fb[buf][0][e], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][e], fb[buf][1][e], acc1, 0, 0, 0);
+    }
+    if constexpr (NORM) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ns += fa[buf][e] * fa[buf][e];
+    }
+  };
+  auto step = [&](auto b_tag, uint32_t j) {  // step j on buffer b; the loads of step j + NBUF - 1 go to the buffer step j - 1 has just left
+    constexpr int b = decltype(b_tag)::value;
+    load(std::integral_constant<int, (b + NBUF - 1) % NBUF>{}, j + NBUF - 1);
+    compute(b_tag);
+    // three loads spread over the step: a matrix instruction has to be presented well before the pipe is free for it, so only a few
+    // cycles of other instructions fit between two of them for nothing
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    if (yield_every && (j % yield_every) == 0) __builtin_amdgcn_s_sleep(1);
+  };
+  // prologue: steps 0 .. NBUF-2 in flight
+  // (in STEP order, pinned: the wait in front of a step's first matrix instruction counts the loads issued after that step's own, and
+  // the loop header's count is the smaller of the two ways in — a prologue that issues buffer 0 last would drain every trip)
+  sa_static_for<0, NBUF - 1>([&](auto b) { load(b, (uint32_t)decltype(b)::value); __builtin_amdgcn_sched_barrier(0); });
+  SA_STAMP(tr, 1);
+  uint32_t j = 0;
+  for (; j + NBUF <= mine; j += NBUF) sa_static_for<0, NBUF>([&](auto b) { step(b, j + decltype(b)::value); });
+  const uint32_t rem = mine - j;
+  sa_static_for<0, NBUF>([&](auto b) { if ((uint32_t)decltype(b)::value < rem) step(b, j + decltype(b)::value); });
+  SA_STAMP(tr, 2);
+  // the two k-halves of every quadrant meet: wave (wm, x) keeps columns x 32 .. and ships the other accumulator to wave (wm, 1 - x)
+  f32x4* red = (f32x4*)lds;                 // [4 waves][4][64 lanes] f32x4 = 16 KB
+  float* rn = lds + 4 * 4 * 64 * 4;         // [4 waves][32] squared-norm halves
+  if (kg == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w4 * 4 + g) * 64 + lane] = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w4 * 4 + g) * 64 + lane] = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+  }
+  if constexpr (NORM) {
+    ns += __shfl_xor(ns, 32);
+    if (lh == 0) rn[w4 * 32 + lr] = ns;
+  }
+  __syncthreads();
+  const uint32_t pw = w4 ^ 1u;
+  // (a + b is the same f32 whichever wave adds: both orders give the k-half 0 + k-half 1 sum)
+  if (kg == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = red[(pw * 4 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[4 * g + c] = acc0[4 * g + c] + o[c];
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = red[(pw * 4 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[4 * g + c] = o[c] + acc1[4 * g + c];
+    }
+  }
+  if constexpr (NORM) *nsq = rn[(wm * 2) * 32 + lr] + rn[(wm * 2 + 1) * 32 + lr];
+  __syncthreads();  // the epilogue reuses this LDS
+}
+
+// The same idea for the wider tiles (128x128, 64x128, 128x64: 2 x 2 waves, each a (BM/2) x (BN/2) wave tile over the WHOLE k range): operands
+// straight from memory — A row-major, B from the bank's fragment-order twin — TM + TN buffer loads per 8-deep k-step for 4 TM TN matrix
+// instructions, no LDS stage, no barrier, no reduction.  The two waves of a wave row (column) load the same A (B) fragments: twice the
+// L1 traffic of the staged loop, none of its LDS instructions.
+template <int BM, int BN, int NBUF>
+__device__ __forceinline__ void gemm_mainloop_direct(gfloat_p A, gfloat_p B, uint32_t M, uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0,
+                                                     f32x16 (&acc)[BM / 64][BN / 64], uint64_t* tr = nullptr) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) & 3u;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  const uint32_t Np = (Ncols + 31u) / 32u * 32u, nb0 = n0 & ~31u;
+  auto left = [&](uint32_t rows) { const uint64_t b = (uint64_t)rows * Dp * 4u; return (uint32_t)(b < 0xffffffffull ? b : 0xffffffffull); };
+  const __amdgpu_buffer_rsrc_t RA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * Dp), 0, (int)left(M - m0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t RB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)nb0 * Dp), 0, (int)left(Np - nb0), 0x00020000);
+  uint32_t oa[TM], ob[TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) oa[m] = ((wm * (BM / 2) + m * 32u + lr) * Dp + lh * 4u) * 4u;
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    const uint32_t rr = (n0 - nb0) + wn * (BN / 2) + n * 32u + lr;
+    ob[n] = ((rr >> 5) * (Dp >> 3) * 256u + lh * 128u + (rr & 31u) * 4u) * 4u;
+  }
+  const uint32_t steps = Dp >> 3;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  f32x4 fa[NBUF][TM], fb[NBUF][TN];
+  auto load = [&](auto buf_tag, uint32_t s) {
+    constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) fa[buf][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, (int)oa[m], (int)(s * 32u), 0));
+#pragma unroll
+    for (int n = 0; n < TN; ++n) fb[buf][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RB, (int)ob[n], (int)(s * 1024u), 0));
+  };
+  auto step = [&](auto b_tag, uint32_t s) {
+    constexpr int b = decltype(b_tag)::value;
+    load(std::integral_constant<int, (b + NBUF - 1) % NBUF>{}, s + NBUF - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[b][m][e], fb[b][n][e], acc[m][n], 0, 0, 0);
+    // the step's loads spread evenly over its 4 TM TN matrix instructions
+    constexpr int NM = 4 * TM * TN, NL = TM + TN, GAP = NM / NL;
+    sa_static_for<0, NL>([&](auto i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, decltype(i)::value == 0 ? 1 : GAP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    });
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - 1 - (NL - 1) * GAP, 0);
+  };
+  sa_static_for<0, NBUF - 1>([&](auto b) { load(b, (uint32_t)decltype(b)::value); __builtin_amdgcn_sched_barrier(0); });
+  SA_STAMP(tr, 1);
+  uint32_t s = 0;
+  for (; s + NBUF <= steps; s += NBUF) sa_static_for<0, NBUF>([&](auto b) { step(b, s + decltype(b)::value); });
+  const uint32_t rem = steps - s;
+  sa_static_for<0, NBUF>([&](auto b) { if ((uint32_t)decltype(b)::value < rem) step(b, s + decltype(b)::value); });
+  SA_STAMP(tr, 2);
+}
+
 // k-group reductions (64x64 tile only: one 32x32 accumulator per wave).  Every group parks its 16 partial
 // sums per lane in LDS as red[group][reg][thread] (conflict-free: consecutive lanes, consecutive words).
 //  * kgroup_reduce_spread: group g then owns registers [g*16/KG, (g+1)*16/KG) of every wave tile and sums them
@@ -565,9 +773,24 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // DIFFERENT weights round to the same f32 difference from max_dist the reference would fall back on the index order; they
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
+// LDS floats a contraction tile needs.  KGT: 1 / 2 / 4 = staged loop with that many k-groups (two stages each), 0 = ring (three stages),
+// 9 = k-split loop (64 x 64: the quadrant exchange), 15 = direct loop (wider tiles: no LDS in the main loop) — and, for every loop, what the
+// fused epilogue lays out in the same buffer afterwards: row operands, PART / EU: column minima + a 64-row key tile, EU: flag words + list.
+constexpr uint32_t gemm_lds_floats(int BM, int BN, int KGT, bool PART, bool EU) {
+  const int KG = (KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1;
+  const uint32_t loop = KGT == 15 ? 0u : KGT == 9 ? 4u * 4u * 64u * 4u + 4u * 32u : (uint32_t)((KGT ? KG * 2 : 3) * (BM + BN) * BK);
+  const uint32_t epi = (uint32_t)((6 + KG) * BM + 2 * BN + ((PART || EU) ? 64 * (BN + 4) : 0) + (EU ? 64 * (BN / 32) + 256 : 0));
+  uint32_t m = loop > epi ? loop : epi;
+  // the direct loop's 64 x 128 tile (85 VGPRs: four blocks per CU by registers) is held to THREE blocks per CU by its LDS footprint: measured at
+  // C5 (5000 x 2000 x 4096), four resident tiles 714 us, three 631, two 655 (the staged loop: 657) — a fourth tile's operand streams thrash the L1
+  if (KGT == 15 && BM == 64 && BN == 128 && m < 12288u) m = 12288u;
+  return (m + 63u) & ~63u;
+}
 template <int BM, int BN, int KGT, bool RAW, bool PART, bool EU = false>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
-  constexpr int KG = KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
+  constexpr bool KSPLIT = KGT == 9;      // KGT == 9: the k-split main loop (gemm_mainloop_ks: the bank read in fragment order, no LDS stage)
+  constexpr bool DIRECT = KGT == 15;     // KGT == 15: the direct main loop of the wider tiles (gemm_mainloop_direct)
+  constexpr int KG = (KSPLIT || DIRECT) ? 1 : KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
   const uint32_t N = S.N, TK = S.TK, K = S.K;
@@ -577,7 +800,8 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   static_assert(!RAW || (TM == 1 && TN == 1 && KGT != 0), "raw mode: 64x64 tiles with k-groups");
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
+  static_assert(!KSPLIT || (TM == 1 && TN == 1), "k-split: 64x64 tiles");
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = (KSPLIT || DIRECT) ? 0u : tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
   // dependent loads that used to sit, fully exposed, between the last MFMA and the first store: ~2 us of a 18 us kernel at
@@ -635,7 +859,9 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 
   f32x16 acc[TM][TN];
   float nsq = 0.f;
-  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
+  if constexpr (KSPLIT) gemm_mainloop_ks<4, RAW, true>((gfloat_p)(RAW ? S.c_feat_raw : (const float SA_G*)S.c_feat), (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc[0][0], tr, &nsq, RAW ? p.ks_yield : 0u);
+  else if constexpr (DIRECT) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)S.c_feat, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, acc, tr);
+  else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
   else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
 
@@ -655,7 +881,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   uint32_t* s_flag = (uint32_t*)(lds + (6 + KG) * BM + 2 * BN + 64 * KS);  // [64][FW] EU: cells of the current 64-row pass to recompute directly
   constexpr uint32_t FL_CAP = 255;                                         // EU: the same cells as a list (a tracking frame has a handful per tile); [FL_CAP] = their count
   uint32_t* s_flist = s_flag + 64 * FW;
-  static_assert(!EU || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 64 * (BN / 32) + 256) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "flag words and list must fit the stages");
+  static_assert(!EU || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4) + 64 * (BN / 32) + 256) <= gemm_lds_floats(BM, BN, KGT, PART, EU), "flag words and list must fit the tile's LDS");
   if constexpr (EU) {
     for (uint32_t i = tid; i < 64u * FW; i += blockDim.x) s_flag[i] = 0u;
     if (tid == 0) s_flist[FL_CAP] = 0u;
@@ -669,7 +895,8 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   }
   if constexpr (RAW) {
     // the two halves of a row's k values sit in lanes lr and lr + 32; the waves wn = 0 / 1 of a group hold the same rows
-    nsq += __shfl_xor(nsq, 32);
+    // (k-split: the main loop has already folded lane halves and k-halves)
+    if constexpr (!KSPLIT) nsq += __shfl_xor(nsq, 32);
     if (wn == 0 && lh == 0) s_np[kg * BM + wm * 32 + lr] = nsq;
   }
   __syncthreads();
@@ -689,7 +916,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   // the two lane halves by one exchange, the waves stacked on each other by a 64-bit LDS minimum.  (A first version reduced every
   // accumulator register across the wave with DPP + ballot: 30 instructions per cell, 10.7 k cycles of epilogue for the
   // one-k-group tile where each lane holds 16 cells.)
-  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4)) <= (KGT ? KG * 2 : 3) * (BM + BN) * BK, "key tile must fit the stages");
+  static_assert(!PART || ((6 + KG) * BM + 2 * BN + 64 * (BN + 4)) <= gemm_lds_floats(BM, BN, KGT, PART, EU), "key tile must fit the tile's LDS");
   auto rows_to_partials = [&](uint32_t m) {
     __syncthreads();  // the key tile (and, in the last pass, the column minima) complete
     const uint32_t nthr = blockDim.x, TPR = nthr >> 6, CPT = BN / TPR;  // threads per row, columns per thread
@@ -918,7 +1145,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
 // The tiles stay as many and as independent as before (three per CU in flight at C2's size — a version that kept one 64 x 64 tile of
 // (candidate, track) pairs per workgroup and ran the main loop K times lost exactly that: 44.7 us against 38.6 for the first phase).
 // RAW rows only (the fused launch); EU: the flagged cells are recomputed directly as in euclid_fixup, into the LDS tile.
-template <bool EU>
+template <bool EU, bool KSL = false>
 __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
   constexpr int BM = 64, BN = 64, R = 16, G = 4;
   const uint32_t N = S.N, T = S.T, K = S.K, TK = S.TK;
@@ -965,7 +1192,8 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
   }
   f32x16 acc[1][1];
   float nsq = 0.f;
-  gemm_mainloop<BM, BN, 1, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, nullptr, &nsq);
+  if constexpr (KSL) gemm_mainloop_ks<4, true, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc[0][0], nullptr, &nsq);
+  else gemm_mainloop<BM, BN, 1, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, nullptr, &nsq);
   float* s_na = lds;                      // [BM]
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
   float* s_np = lds + 6 * BM;             // [BM] squared norms of the candidates' rows (raw mode)
@@ -985,7 +1213,7 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
   for (uint32_t i = tid; i < 64u * K; i += blockDim.x) s_rc[i] = ~0ull;
   if (tid < used) s_cc[tid] = ~0ull;
   if (tid < (uint32_t)BM) s_g[tid] = pre_g;
-  nsq += __shfl_xor(nsq, 32);
+  if constexpr (!KSL) nsq += __shfl_xor(nsq, 32);
   if (wn == 0 && lh == 0) s_np[wm * 32 + lr] = nsq;
   __syncthreads();
   if (tid < (uint32_t)BM) s_na[tid] = pre_us != 0.f ? s_np[tid] : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
@@ -1094,10 +1322,9 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
 // (Tile order: row by row.  An XCD-aware band order — each XCD's L2 keeping one set of candidate panels — was measured at C5 with bands
 // of 1, 2 and 4 tile rows: no difference, the 114 MB working set sits in the 256 MB Infinity Cache and the fabric keeps up.)
 template <int BM, int BN, int KGT, bool PART = false, bool EU = false>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
+__global__ __launch_bounds__(256 * ((KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1), (KGT == 15 && BM == 128 && BN == 128) ? 2 : 1) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                                           uint32_t xo_) {
-  constexpr int KG = KGT ? KGT : 1;
-  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats(BM, BN, KGT, PART, EU)];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   uint32_t bx, by;  // XCD-aware tile order (xcd_order): a 1-D grid of 8 chunk workgroups per scene
   if (!xcd_tile(blockIdx.x, gx, gy, xo_ >> 8, xo_ & 255u, &bx, &by)) return;
@@ -1108,7 +1335,7 @@ template <int BM, int BN, int KGT, bool PART, bool EU>
 static void launch_cosine(uint32_t maxTK, uint32_t maxN, uint32_t ns, hipStream_t st, const SceneDev* scenes, const SaParams& p) {
   const uint32_t gx = cdiv(maxTK, BN), gy = cdiv(maxN, BM);
   const XcdOrder xo = xcd_order(gx, gy, p.row_major_tiles != 0);
-  SA_LAUNCH((k_visual_cosine<BM, BN, KGT, PART, EU>), dim3(xo.W ? 8u * xo.chunk : xo.chunk, 1, ns), dim3(256 * (KGT ? KGT : 1)), 0, st, scenes, p, gx, gy, (xo.chunk << 8) | xo.W);
+  SA_LAUNCH((k_visual_cosine<BM, BN, KGT, PART, EU>), dim3(xo.W ? 8u * xo.chunk : xo.chunk, 1, ns), dim3(256 * ((KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1)), 0, st, scenes, p, gx, gy, (xo.chunk << 8) | xo.W);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1119,7 +1346,7 @@ static void launch_cosine(uint32_t maxTK, uint32_t maxN, uint32_t ns, hipStream_
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
-template <int KG, bool PART, bool EU = false, bool KP = false>
+template <int KG, bool PART, bool EU = false, bool KP = false, bool KSL = false>
 __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py, uint32_t nprep_, uint32_t xo_) {
   // nprep_: preparation blocks of the launch; bit 31: they run their RESET half only, bit 30: the positional tiles also feed the
@@ -1127,6 +1354,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   const uint32_t nprep = nprep_ & 0x3fffffffu;
   const bool prep_light = (nprep_ >> 31) != 0, uni = ((nprep_ >> 30) & 1u) != 0;
   __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
+  static_assert(gemm_lds_floats(64, 64, KSL ? 9 : KG, PART, EU) <= KG * 2 * (64 + 64) * BK, "the contraction tile must fit the launch's LDS");
   using FusedPos = PosSmem<2, 64>;  // the wide, proof-filtered positional tile of this launch (sa_frame.h)
   static_assert(sizeof(FusedPos) <= sizeof(float) * 2 * 128 * BK, "the positional tile must fit one k-group's stages");
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -1140,8 +1368,8 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   if (b < (xW ? 8u * xchunk : xchunk)) {
     uint32_t tbx, tby;
     if (!xcd_tile(b, gx, gy, xchunk, xW, &tbx, &tby)) return;
-    if constexpr (KP) visual_ktile<EU>(S, p, tbx, tby, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
-    else visual_cosine_tile<64, 64, KG, true, PART, EU>(S, p, tbx, tby, lds);
+    if constexpr (KP) visual_ktile<EU, KSL>(S, p, tbx, tby, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
+    else visual_cosine_tile<64, 64, KSL ? 9 : KG, true, PART, EU>(S, p, tbx, tby, lds);
     return;
   }
   b -= xW ? 8u * xchunk : xchunk;
@@ -1397,18 +1625,23 @@ __global__ __launch_bounds__(EU_THREADS) void k_visual_euclid(const SceneDev* __
 
 // ---- standalone distance matrix (sa_feature_distance_matrix): no gating, plain d ----
 template <int BM, int BN, int KGT>
-__global__ __launch_bounds__(256 * (KGT ? KGT : 1)) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
+__global__ __launch_bounds__(256 * (KGT >= 9 ? 1 : KGT ? KGT : 1)) void k_cosine_matrix(const float* __restrict__ A, const float* __restrict__ an,
                                                             const float* __restrict__ B, const float* __restrict__ bn,
                                                             uint32_t M, uint32_t Ncols, uint32_t Dp, float* __restrict__ out) {
   const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int KG = KGT ? KGT : 1;
+  // KGT >= 9: the k-split main loop (gemm_mainloop_ks): 9 / 10 = B row-major / in fragment order, four register buffers; 11 / 12 = six
+  constexpr bool KS = KGT >= 9 && KGT != 15;   // 15: the direct loop of the wider tiles (gemm_mainloop_direct)
+  constexpr int KG = KGT >= 9 ? 1 : KGT ? KGT : 1;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
-  __shared__ __attribute__((aligned(16))) float lds[(KGT ? KG * 2 : 3) * (BM + BN) * BK];
+  static_assert(!KS || (TM == 1 && TN == 1), "k-split only with the 64x64 tile");
+  __shared__ __attribute__((aligned(16))) float lds[KGT == 15 ? 64 : (KGT ? KG * 2 : 3) * (BM + BN) * BK];
   f32x16 acc[TM][TN];
-  if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
+  if constexpr (KGT == 15) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, acc, tr);
+  else if constexpr (KS) gemm_mainloop_ks<(KGT == 11 || KGT == 12 || KGT == 14 ? 6 : 4), false, (KGT == 10 || KGT >= 12), (KGT >= 13)>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc[0][0], tr);
+  else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
@@ -1547,8 +1780,8 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
   if (visual_kind == SA_VIS_EUCLIDEAN && !eu_mfma) { *bm = EU_BM; *bn = EU_BN; return; }  // k_visual_euclid's block tile (vis_max_key slots)
   if ((visual_kind != SA_VIS_COSINE && visual_kind != SA_VIS_EUCLIDEAN) || !maxN || !maxTK) return;
   switch (tile_plan(maxN, maxTK, ns, Dp, plan_override)) {
-    case 0: case 8: *bm = 128; *bn = 128; break;
-    case 5: *bm = 64; *bn = 128; break;
+    case 0: case 8: case 15: *bm = 128; *bn = 128; break;
+    case 5: case 16: *bm = 64; *bn = 128; break;
     case 6: *bm = 128; *bn = 64; break;
     default: break;
   }
@@ -1567,7 +1800,7 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
   const int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
   // every plan of the 64 x 64 family: the launch runs one-k-group 64 x 64 tiles whatever the stand-alone kernel would do (frames of
   // several rounds of tiles — deeper banks: 1000 x 5000 columns at five observations per track — gain as well: 107.2 -> 102.5 us)
-  if (plan == 1 || plan == 2 || plan == 4 || plan == 7) return true;
+  if (plan == 1 || plan == 2 || plan == 4 || plan == 7 || plan == 9) return true;
   // deeper banks with class words: the whole-track tiles (64 x 64) replace THREE launches of the other family's path (positional
   // tiles, the contraction on wider tiles, k_bestfit_tile) — C2's frame with two observations per track: 42.9 us there.  (Only
   // with class words: the matrix mode's per-tile slots are laid out by the engine for the plan's own tile grid.)
@@ -1578,7 +1811,11 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
   return p.gemm_plan < 0 && p.vote_words && K == 1 && (size_t)cdiv(maxN, 64) * cdiv(maxTK, 64) * ns <= 512;
 }
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
-                                  const SaParams& p, hipStream_t st, bool partials, int prep, bool kpass, bool general_tail) {
+                                  const SaParams& p_in, hipStream_t st, bool partials, int prep, bool kpass, bool general_tail) {
+  static const int env_yield = getenv("SA_KS_YIELD") ? atoi(getenv("SA_KS_YIELD")) : -1;   // (experiment knob)
+  SaParams p_ = p_in;
+  if (env_yield >= 0) p_.ks_yield = (uint32_t)env_yield;
+  const SaParams& p = p_;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;
   const uint32_t maxTK = maxT * K;
@@ -1600,19 +1837,33 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // against 22.7 (raising the contraction's wave priority changes nothing).
   const dim3 grid(n_gemm + px * py + prep_blocks, 1, ns);
   const uint32_t np = prep_blocks | (prep == 3 ? 0x80000000u : 0u) | (general_tail ? 0x40000000u : 0u);
+  // the contraction tiles' main loop: k-split over the bank's fragment-order twin by default, the LDS-staged loop with SA_FLAG_STAGED_LOOP
+#define SA_FV(PART_, EU_, KP_) do { if (p.staged_loop) SA_LAUNCH((k_frame_visual<1, PART_, EU_, KP_, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_); \
+                                    else SA_LAUNCH((k_frame_visual<1, PART_, EU_, KP_, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_); } while (0)
   if (kpass) {
-    if (eu) SA_LAUNCH((k_frame_visual<1, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
-    else SA_LAUNCH((k_frame_visual<1, false, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+    if (eu) SA_FV(false, true, true);
+    else SA_FV(false, false, true);
     return hipGetLastError();
   }
   if (eu) {
-    if (partials) SA_LAUNCH((k_frame_visual<1, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
-    else SA_LAUNCH((k_frame_visual<1, false, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
-  } else if (partials) SA_LAUNCH((k_frame_visual<1, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
-  else SA_LAUNCH((k_frame_visual<1, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+    if (partials) SA_FV(true, true, false);
+    else SA_FV(false, true, false);
+  } else if (partials) SA_FV(true, false, false);
+  else SA_FV(false, false, false);
+#undef SA_FV
   return hipGetLastError();
 }
 
+// The stand-alone contraction.  Plans (sa_config.gemm_plan - 1 pins one): 0 / 5 / 6 = 128x128 / 64x128 / 128x64 on the LDS-staged loop, 1 / 2 / 4 =
+// 64x64 with that many k-groups, 7 / 8 = ring variants; 9 = 64x64 on the k-split loop, 15 / 16 = 128x128 / 64x128 on the direct loop (both read
+// the bank's fragment-order twin: gemm_mainloop_ks / gemm_mainloop_direct).  tile_plan() chooses among the tile SIZES; unless a plan is pinned or
+// SA_FLAG_STAGED_LOOP is set, 128x128 / 64x128 / 64x64 then run the direct / k-split loops (measured on the stand-alone contraction, 4096 x 2048 x
+// 512: 93.6 -> 74.6 us; 2000 x 5000 x 4096: 732 -> 661; 1000 x 1000 x 512: 15.0 -> 12.9; 128x64 stays staged: two row-major gathers per
+// fragment-order load are what the direct loop is worst at).
+static inline int loop_plan(int plan, const SaParams& p) {
+  if (p.gemm_plan >= 0 || p.staged_loop) return plan;
+  return plan == 0 ? 15 : plan == 5 ? 16 : (plan == 1 || plan == 2) ? 9 : plan;
+}
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
                             hipStream_t st, bool partials) {
   if (!maxN || !maxTK) return hipSuccess;
@@ -1620,20 +1871,25 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma) {
     // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
     int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
-    plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6) ? plan : 1;
-#define SA_EU_LAUNCH(BM_, BN_, PART_) launch_cosine<BM_, BN_, 1, PART_, true>(maxTK, maxN, ns, st, scenes, p)
+    plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6 || plan == 9 || plan == 15 || plan == 16) ? plan : 1;
+    plan = loop_plan(plan, p);
+#define SA_EU_LAUNCH(BM_, BN_, KGT_) do { if (partials) launch_cosine<BM_, BN_, KGT_, true, true>(maxTK, maxN, ns, st, scenes, p); \
+                                          else launch_cosine<BM_, BN_, KGT_, false, true>(maxTK, maxN, ns, st, scenes, p); } while (0)
     switch (plan) {
-      case 0: if (partials) SA_EU_LAUNCH(128, 128, true); else SA_EU_LAUNCH(128, 128, false); break;
-      case 5: if (partials) SA_EU_LAUNCH(64, 128, true); else SA_EU_LAUNCH(64, 128, false); break;
-      case 6: if (partials) SA_EU_LAUNCH(128, 64, true); else SA_EU_LAUNCH(128, 64, false); break;
-      default: if (partials) SA_EU_LAUNCH(64, 64, true); else SA_EU_LAUNCH(64, 64, false); break;
+      case 0: SA_EU_LAUNCH(128, 128, 1); break;
+      case 5: SA_EU_LAUNCH(64, 128, 1); break;
+      case 6: SA_EU_LAUNCH(128, 64, 1); break;
+      case 9: SA_EU_LAUNCH(64, 64, 9); break;
+      case 15: SA_EU_LAUNCH(128, 128, 15); break;
+      case 16: SA_EU_LAUNCH(64, 128, 15); break;
+      default: SA_EU_LAUNCH(64, 64, 1); break;
     }
 #undef SA_EU_LAUNCH
     return hipGetLastError();
   }
   if (p.visual_kind == SA_VIS_COSINE) {
     const uint32_t Dp = p.Dp;  // one feature length per engine
-    int plan = tile_plan(maxN, maxTK, ns, Dp, p.gemm_plan);
+    int plan = loop_plan(tile_plan(maxN, maxTK, ns, Dp, p.gemm_plan), p);
     if (partials) {
       plan = plan == 4 ? 2 : plan == 7 ? 1 : plan == 8 ? 0 : plan;
       switch (plan) {
@@ -1641,6 +1897,9 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
         case 5: launch_cosine<64, 128, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         case 6: launch_cosine<128, 64, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         case 2: launch_cosine<64, 64, 2, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 9: launch_cosine<64, 64, 9, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 15: launch_cosine<128, 128, 15, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 16: launch_cosine<64, 128, 15, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         default: launch_cosine<64, 64, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
       }
       return hipGetLastError();
@@ -1653,6 +1912,9 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       case 6: launch_cosine<128, 64, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       case 4: launch_cosine<64, 64, 4, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       case 2: launch_cosine<64, 64, 2, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 9: launch_cosine<64, 64, 9, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 15: launch_cosine<128, 128, 15, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 16: launch_cosine<64, 128, 15, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       default: launch_cosine<64, 64, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
     }
   } else {
@@ -1674,6 +1936,16 @@ hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, 
       case 6: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 4: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 4>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(1024), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 2: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 2>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(512), 0, st, a, an, b, bn, n, t, dp, out); break;
+      // k-split plans (b = the bank in fragment order for 10 / 12: sa_launch_frag_reorder)
+      case 9: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 9>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 10: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 10>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 11: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 11>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 12: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 12>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 15: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 16: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 17: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 15>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 13: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 13>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 14: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 14>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
     }
   } else {

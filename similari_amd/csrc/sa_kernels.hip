@@ -26,14 +26,15 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // =====================================================================================================
 __global__ void k_pad_features(const float* __restrict__ src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                const uint32_t* __restrict__ slots, const uint8_t* __restrict__ present,
-                               float* __restrict__ dst, float* __restrict__ norms, uint8_t* __restrict__ dst_present) {
+                               float* __restrict__ dst, float* __restrict__ norms, uint8_t* __restrict__ dst_present,
+                               float* __restrict__ dst_frag) {
   uint32_t row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   uint32_t lane = threadIdx.x % WAVE;
   if (row >= rows) return;
   uint32_t drow = slots ? slots[row / K] * K + row % K : row;
   bool pres = present ? present[row] != 0 : true;
   float nrm;
-  pad_feature_row(src + (size_t)row * D, dst + (size_t)drow * Dp, D, Dp, pres && src, lane, &nrm);
+  pad_feature_row(src + (size_t)row * D, dst + (size_t)drow * Dp, D, Dp, pres && src, lane, &nrm, dst_frag, drow);
   if (lane == 0) {
     norms[drow] = nrm;
     if (dst_present) dst_present[drow] = pres ? 1 : 0;
@@ -103,23 +104,6 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, uint8_t* __restri
 }
 
 // sa_tracks_remove: row r of every array of a scene's track table := its old row index[r], all arrays in ONE launch (one block per kept row)
-__global__ __launch_bounds__(256) void k_gather_table(SaGatherTable g) {
-  const uint32_t row = blockIdx.x;
-  if (row >= g.rows) return;
-  const uint32_t from = g.index[row];
-  for (uint32_t a = 0; a < g.n_arrays; ++a) {
-    const uint32_t rb = g.row_bytes[a];
-    const uint8_t* s = (const uint8_t*)g.src[a] + (size_t)from * rb;
-    uint8_t* d = (uint8_t*)g.dst[a] + (size_t)row * rb;
-    if ((rb & 15u) == 0) {
-      for (uint32_t k = threadIdx.x; k < rb / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k];
-    } else if ((rb & 3u) == 0) {
-      for (uint32_t k = threadIdx.x; k < rb / 4; k += 256) ((uint32_t*)d)[k] = ((const uint32_t*)s)[k];
-    } else {
-      for (uint32_t k = threadIdx.x; k < rb; k += 256) d[k] = s[k];
-    }
-  }
-}
 __device__ __forceinline__ void gather_table_row(const SaGatherTable& g, uint32_t row) {
   const uint32_t from = g.index[row];
   for (uint32_t a = 0; a < g.n_arrays; ++a) {
@@ -133,7 +117,19 @@ __device__ __forceinline__ void gather_table_row(const SaGatherTable& g, uint32_
     } else {
       for (uint32_t k = threadIdx.x; k < rb; k += 256) d[k] = s[k];
     }
+    if (g.frag && a == g.frag_array) {
+      // the bank's fragment-order twin: the row's K observations, 16 bytes (four consecutive k) per store, from the row-major SOURCE
+      const uint32_t q = g.frag_Dp >> 2;  // 16-byte pieces per observation
+      for (uint32_t k = threadIdx.x; k < g.frag_K * q; k += 256) {
+        const uint32_t ob = k / q, kk = (k % q) * 4u;
+        *(uint4*)(g.frag + sa_frag_index(row * g.frag_K + ob, kk, g.frag_Dp)) = ((const uint4*)s)[k];
+      }
+    }
   }
+}
+__global__ __launch_bounds__(256) void k_gather_table(SaGatherTable g) {
+  if (blockIdx.x >= g.rows) return;
+  gather_table_row(g, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_gather_tables(SaGatherTables set) {
   const SaGatherTable& g = set.t[blockIdx.y];
@@ -2089,10 +2085,10 @@ hipError_t sa_launch_prep_tracks(const PrepTrackArgs& a, const SaParams& p, hipS
 }
 hipError_t sa_launch_pad_features(const float* src, uint32_t rows, uint32_t D, uint32_t Dp, uint32_t K,
                                   const uint32_t* slots, const uint8_t* present, float* dst, float* norms,
-                                  uint8_t* dst_present, uint32_t* fcount, hipStream_t st) {
+                                  uint8_t* dst_present, uint32_t* fcount, hipStream_t st, float* dst_frag) {
   if (!rows) return hipSuccess;
   hipLaunchKernelGGL(k_pad_features, dim3(cdiv(rows, 4)), dim3(256), 0, st, src, rows, D, Dp, K, slots, present, dst,
-                     norms, dst_present);
+                     norms, dst_present, dst_frag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (fcount && slots) {

@@ -284,6 +284,7 @@ __device__ __forceinline__ void bank_block(const BankArgs& a, uint32_t i, BankLd
         for (int j = 0; j < KMAX; ++j) out = src == (uint32_t)j ? v[j] : out;
       }
       bank[(size_t)k * Dp + x] = out;
+      if (a.t_ffrag) a.t_ffrag[sa_frag_index(row * K + (uint32_t)k, x, Dp)] = out;   // the bank's fragment-order twin
     }
   }
   if (tid == 0) {
