@@ -145,6 +145,8 @@ typedef struct sa_config {
                                              the host polls it: a dispatch that carries a signal holds the next dispatch of its queue back by ~4.6 us */
 #define SA_FLAG_STAGED_LOOP 0x20000u    /* the fused first phase's contraction tiles run the LDS-staged main loop over the row-major bank (the round-5 loop) instead of
                                            the k-split loop over the bank's fragment-order twin; A/B measurements and parity tests */
+#define SA_FLAG_NO_YIELD 0x40000u       /* the fused first phase's matrix waves never nap between k-steps (by default one-observation cosine frames hand the positional
+                                           tiles' waves 64 cycles of the vector port per k-step); A/B measurements */
 #define SA_FLAG_BESTFIT_TILE 0x2000u    /* the weight matrix + k_bestfit_tile also where the contraction could vote itself (exact reference weights for deeper banks) */
 
 /* Fill *cfg with the reference's defaults: IoU(0.3) (sort.rs:31), min confidence 0.05 (sort/metric.rs:11), no visual part,

@@ -47,6 +47,7 @@ SA_FLAG_XCD_TILES = 0x4000
 SA_FLAG_ROW_TILES = 0x8000
 SA_FLAG_SIGNAL_COMPLETION = 0x10000
 SA_FLAG_STAGED_LOOP = 0x20000
+SA_FLAG_NO_YIELD = 0x40000
 
 # Path switches OR-ed into every config make_config builds (tests: the `sa_path` fixture of tests/conftest.py sends whole parity tests
 # through the engine's other paths in the same process) and a tile-plan override for the same purpose.

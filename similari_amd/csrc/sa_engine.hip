@@ -1147,6 +1147,7 @@ int sa_engine_create(const sa_config* cfg, sa_engine** out) {
   P.force_general = (cfg->flags & SA_FLAG_GENERAL_TAIL) ? 1u : 0u;
   P.gemm_plan = cfg->gemm_plan > 0 ? cfg->gemm_plan - 1 : -1;
   P.staged_loop = (cfg->flags & SA_FLAG_STAGED_LOOP) ? 1u : 0u;
+  P.no_yield = (cfg->flags & SA_FLAG_NO_YIELD) ? 1u : 0u;
   P.row_major_tiles = (cfg->flags & SA_FLAG_XCD_TILES) ? 0u : ((cfg->flags & SA_FLAG_ROW_TILES) ? 2u : 1u);
   P.Dp = e->Dp;
   P.cons.n = cfg->n_constraints;
@@ -1606,6 +1607,8 @@ static bool in_pinned_block(const void* p, size_t bytes, const void** dev = null
     }
   return false;
 }
+
+bool sa_in_pinned_host_block(const void* p, size_t bytes) { return p && in_pinned_block(p, bytes); }   // (the tracker facade, sa_tracker.cpp)
 
 // ---- device blocks the caller's own producers write detection features into (sa_device_block_register) ----
 struct DevBlock { const char* base; size_t bytes; int device; };

@@ -533,6 +533,7 @@ __device__ __forceinline__ void gemm_mainloop_ks(gfloat_p A, gfloat_p B, uint32_
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    // (the fused launch: the waves of the positional tiles on this SIMD issue nothing while this wave presents matrix instructions)
     if (yield_every && (j % yield_every) == 0) __builtin_amdgcn_s_sleep(1);
   };
   // prologue: steps 0 .. NBUF-2 in flight
@@ -1812,9 +1813,13 @@ bool sa_frame_visual_ok(uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, u
 }
 hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxT, uint32_t K, uint32_t D,
                                   const SaParams& p_in, hipStream_t st, bool partials, int prep, bool kpass, bool general_tail) {
-  static const int env_yield = getenv("SA_KS_YIELD") ? atoi(getenv("SA_KS_YIELD")) : -1;   // (experiment knob)
+  // The matrix waves of a one-observation cosine frame sleep 64 cycles after every k-step (SA_FLAG_NO_YIELD: never): while a wave presents
+  // matrix instructions back to back, the positional tiles' waves on its SIMD issue no vector instruction at all (NOTES), and with the
+  // k-split loop the contraction's tile retires ~3-6 k cycles BEFORE the positional tiles that end the launch — 32 naps hand them ~2 k
+  // cycles of the port at the same cost to the tile that can afford it: C2 first phase -1.5 .. -5 % over three visits (c2n -1.5 %); euclidean
+  // frames (a longer epilogue: +2.5 %) and deeper banks (several matrix waves per SIMD: no difference) do not take it.
   SaParams p_ = p_in;
-  if (env_yield >= 0) p_.ks_yield = (uint32_t)env_yield;
+  p_.ks_yield = (p_in.no_yield || kpass || (p_in.visual_kind == SA_VIS_EUCLIDEAN && p_in.eu_mfma)) ? 0u : 1u;
   const SaParams& p = p_;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;

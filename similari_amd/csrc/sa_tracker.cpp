@@ -35,6 +35,8 @@
 #include "sa_kalman.h"
 #include "sa_pool.h"
 
+extern "C" bool sa_in_pinned_host_block(const void* p, size_t bytes);   // sa_engine.hip: inside a block from sa_host_alloc?
+
 namespace {
 
 thread_local std::string g_err;
@@ -857,6 +859,12 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
     const auto j0 = trace ? clk::now() : clk::time_point();
     sa_tracker::SceneScratch& W = ss[s];
     assemble_scene(o, W, scene_ids[s], counts[s], obs[s]);
+    // _begin hands the request back to the caller as soon as the launches are queued, and the ingest pulls a PINNED block's rows over the
+    // link asynchronously: a caller that refills its block for the next frame would race it.  The handle's contract ("the request may be
+    // reused once _begin returns") therefore costs such a block its in-place read: its rows are copied into the staging arena during the
+    // call like any other host rows.  (Registered DEVICE blocks stay in place: the Kalman dispatch moves their rows into engine memory
+    // before anything of the frame is handed out.)
+    if (res && W.contiguous && sa_in_pinned_host_block(W.det.feats, (size_t)W.n * o.feature_len * sizeof(float))) { W.contiguous = 0; W.det.feats = nullptr; }
     if (trace) W.job_us[2] = us_between(j0, clk::now());
   });
   const auto t_asm = clk::now();

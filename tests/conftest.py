@@ -26,7 +26,7 @@ def _path_flags():
     return {"default": 0, "general": abi.SA_FLAG_GENERAL_TAIL, "never_lean": abi.SA_FLAG_NEVER_LEAN, "bestfit_tile": abi.SA_FLAG_BESTFIT_TILE,
             "separate_resolve": abi.SA_FLAG_SEPARATE_RESOLVE, "euclid_valu": abi.SA_FLAG_EUCLID_VALU, "euclid_mfma": abi.SA_FLAG_EUCLID_MFMA,
             "row_tiles": abi.SA_FLAG_ROW_TILES, "xcd_tiles": abi.SA_FLAG_XCD_TILES, "signal_completion": abi.SA_FLAG_SIGNAL_COMPLETION,
-            "staged_loop": abi.SA_FLAG_STAGED_LOOP}
+            "staged_loop": abi.SA_FLAG_STAGED_LOOP, "no_yield": abi.SA_FLAG_NO_YIELD}
 
 
 def pytest_generate_tests(metafunc):

@@ -164,6 +164,47 @@ def test_maha_cells_bit_identical():
     assert hits > 200
 
 
+def test_maha_cells_off_diagonal_covariances_bit_identical():
+    """The same cell on covariances with real off-diagonal mass (the filter's own stay diagonal: the inner loops of the Cholesky and of
+    the forward substitution multiply zeros in the test above), and on ones whose pivot fails: NaN on both sides."""
+    rng = np.random.default_rng(55)
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.1)
+    n = 400
+    tracks = random_boxes(rng, n)
+    hits = nans = 0
+    for i in range(n):
+        tb = tracks[i : i + 1].copy()
+        tb["confidence"] = 1.0
+        h = float(tb["height"][0])
+        m5 = np.array([tb["xc"][0], tb["yc"][0], 0.0, tb["aspect"][0], h], np.float32)
+        g = rng.standard_normal((5, 7))
+        r = g @ g.T
+        d = np.sqrt(np.diag(r))
+        r = np.eye(5) + rng.uniform(0.2, 0.95) * (r / d[:, None] / d[None, :] - np.eye(5))
+        sd = np.sqrt(np.array([(h / 20) ** 2 * 3, (h / 20) ** 2 * 3, 1e-2, 1e-2, (h / 20) ** 2 * 3]) * rng.uniform(0.3, 3.0, 5))
+        c = (sd[:, None] * r * sd[None, :]).astype(np.float32)
+        c = np.triu(c) + np.triu(c, 1).T
+        if i % 25 == 7:
+            c[int(rng.integers(0, 5))] *= np.float32(-50.0)   # not positive definite any more (and not symmetric): some pivot fails
+        c25 = np.ascontiguousarray(c.ravel())
+        cand = tb.copy()
+        cand["xc"] += np.float32(rng.normal(0, 3))
+        cand["yc"] += np.float32(rng.normal(0, 3))
+        cand["confidence"] = np.float32(rng.uniform(0, 1))
+        ov, ev = C.c_float(), C.c_float()
+        r_o = OL.or_positional_metric(C.byref(cfg), O.box_ptr(cand), O.box_ptr(tb), O.fptr(m5), O.fptr(c25), C.byref(ov))
+        r_e = E.emu_positional_cell(C.byref(cfg), O.box_ptr(cand), 0, O.box_ptr(tb), 0, O.fptr(m5), O.fptr(c25), C.byref(ev), None)
+        assert r_o == r_e
+        if r_o:
+            hits += 1
+            if np.isnan(ov.value):
+                nans += 1
+                assert np.isnan(ev.value)
+            else:
+                assert np.float32(ov.value).tobytes() == np.float32(ev.value).tobytes(), (i, ov.value, ev.value)
+    assert hits > 300 and nans >= 3
+
+
 def test_float_key_roundtrip_and_order():
     vals = np.array([-3.5, -1.0, -0.0, 0.0, 1e-30, 0.5, 1.0, 2.0, 3.4e38], np.float32)
     keys = [E.emu_f32_key(float(v)) for v in vals]

@@ -532,6 +532,125 @@ def test_sort_maha_parity():
     assert (ids != 0).sum() > 100
 
 
+def random_spd(rng, diag, corr=0.7):
+    """A symmetric positive definite matrix with the given diagonal and real off-diagonal mass: D^1/2 R D^1/2, R a random correlation
+    matrix whose off-diagonal entries reach +-corr (f32, symmetric bit for bit)."""
+    n = len(diag)
+    g = rng.standard_normal((n, n + 2))
+    r = g @ g.T
+    d = np.sqrt(np.diag(r))
+    r = r / d[:, None] / d[None, :]
+    r = np.eye(n) + corr * (r - np.eye(n))
+    sd = np.sqrt(np.asarray(diag, np.float64))
+    c = (sd[:, None] * r * sd[None, :]).astype(np.float32)
+    return np.triu(c) + np.triu(c, 1).T
+
+
+@pytest.mark.paths("general", "never_lean")
+def test_sort_maha_off_diagonal_covariances():
+    """The 5 x 5 Cholesky + forward substitution behind every Mahalanobis cell (kalman_2d_box.rs:150-170) on covariances WITH
+    off-diagonal mass — the reference's own filter keeps them diagonal, so every other test multiplies zeros in the inner
+    loops of sa_maha_prepare / sa_maha_cell, but sa_tracks_upsert accepts any kf_cov: cells bit-identical to or_positional_metric; a
+    covariance whose pivot is not positive poisons its track's cells with NaN on both sides (the reference panics there)."""
+    rng = np.random.default_rng(211)
+    sc = synth.sort_scene(rng, 180, 200, canvas=(1500.0, 900.0))
+    boxes, m5, c25 = kf_states(rng, sc["track_boxes"])
+    c25 = c25.copy()
+    for i in range(len(c25)):
+        base = c25[i].reshape(5, 5)
+        c25[i] = random_spd(rng, np.diag(base) * rng.uniform(0.5, 4.0, 5), corr=rng.uniform(0.2, 0.9)).ravel()
+    off = c25.reshape(-1, 5, 5) - np.stack([np.diag(np.diag(c.reshape(5, 5))) for c in c25])
+    assert (np.abs(off) > 0).mean() > 0.7
+    for i in (5, 77, 140):
+        c25[i] = (-1.0e6 * np.eye(5, dtype=np.float32)).ravel()      # a non-positive first pivot
+    c25[33] = random_spd(rng, np.full(5, 4.0), corr=0.5).ravel()
+    c25[33].reshape(5, 5)[2, 2] = -1.0e4                             # ... and one that fails at the third
+    sc["det_boxes"] = synth.jitter_boxes(rng, boxes, 2.0)[rng.permutation(180)]
+    sc["det_boxes"] = np.concatenate([sc["det_boxes"], synth.dense_boxes(rng, 20, (1500.0, 900.0))])
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.05, max_idle_epochs=5)
+    ids, ref = check_sort(cfg, sc, kf=(boxes, m5, c25), require_ids=False)
+    assert (ids != 0).sum() > 60
+    # the poisoned tracks: their whole column is NaN wherever the pair passes too_far (checked against the oracle above), and nobody wins them
+    bad = sc["track_ids"][[5, 77, 140, 33]]
+    assert not np.isin(ids, bad).any()
+
+
+def test_device_upkeep_steps_full_covariances_like_the_oracle():
+    """sa_tracks_set_state with full 10 x 10 covariances carrying position-position AND position-velocity cross terms, one
+    association, the device-side Kalman step (sa_tracks_apply: predict + update, kalman_2d_box.rs:122-148 / 186-232), then the next
+    frame's Mahalanobis cells: bit-identical to the oracle's filter stepped on the same states."""
+    L = O.lib()
+    rng = np.random.default_rng(212)
+    n = 60
+    sc = synth.sort_scene(rng, n, n, canvas=(900.0, 700.0))
+    ids0 = sc["track_ids"]
+    boxes, m5, _ = kf_states(rng, sc["track_boxes"])
+    mean = np.zeros((n, 10), np.float32)
+    cov = np.zeros((n, 100), np.float32)
+    for i in range(n):
+        mean[i, :5] = m5[i]
+        mean[i, 5:] = rng.normal(0, 0.5, 5).astype(np.float32)
+        h = float(m5[i, 4])
+        d = np.array([(h / 20) ** 2 * 4] * 2 + [1e-3, 1e-3, (h / 20) ** 2 * 4] + [(h / 160) ** 2 * 8] * 2 + [1e-5, 1e-5, (h / 160) ** 2 * 8])
+        cov[i] = random_spd(rng, d, corr=0.6).ravel()
+    cfg = abi.make_config(positional="maha", positional_min_confidence=0.05, max_idle_epochs=5)
+    det1 = synth.jitter_boxes(rng, boxes, 1.5)
+    det2 = synth.jitter_boxes(rng, det1, 1.5)
+    fp, u64p, bp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(abi.sa_box)
+    eng = Engine(cfg)
+    try:
+        tr = abi.make_tracks(ids0, boxes, sc["track_epochs"], kf_mean=mean[:, :5].copy(), kf_cov=cov.reshape(n, 10, 10)[:, :5, :5].reshape(n, 25).copy())
+        eng.upsert(0, tr)
+        for i, tid in enumerate(ids0):
+            assert eng.lib.sa_tracks_set_state(eng.h, 0, int(tid), mean[i].ctypes.data_as(fp), cov[i].ctypes.data_as(fp), None) == 0
+        ids1, _ = eng.associate(0, 1, abi.make_detections(det1))
+        ref1 = O.associate(cfg, tr, 1, abi.make_detections(det1))
+        pos1 = eng.tap_positional()
+        m1 = ~np.isnan(pos1)
+        np.testing.assert_array_equal(np.isnan(pos1), np.isnan(ref1["positional"]))
+        np.testing.assert_array_equal(pos1.view(np.uint32)[m1], ref1["positional"].view(np.uint32)[m1])
+        assert (ids1 != 0).sum() > n // 2
+        new_ids = np.where(ids1 == 0, 5000 + np.arange(n), 0).astype(np.uint64)
+        pred = np.zeros(n, abi.BOX_DTYPE)
+        assert eng.lib.sa_tracks_apply(eng.h, 0, new_ids.ctypes.data_as(u64p), C.cast(pred.ctypes.data, bp)) == 0, eng.lib.sa_last_error(eng.h)
+        # the oracle's filter on the same states: winners step (predict + update with their detection), the others stay, new tracks start
+        row = {int(t): k for k, t in enumerate(ids0)}
+        t_ids, t_boxes, t_ep = list(ids0), boxes.copy(), np.asarray(sc["track_epochs"], np.uint64).copy()
+        t_mean, t_cov = mean.copy(), cov.copy()
+        add_ids, add_boxes, add_mean, add_cov = [], [], [], []
+        for i in range(n):
+            sb = np.zeros(1, abi.BOX_DTYPE)
+            ob = det1[i : i + 1].copy()
+            if ids1[i]:
+                k = row[int(ids1[i])]
+                L.or_make_prediction(PW, VW, 1, O.fptr(t_mean[k]), O.fptr(t_cov[k]), O.box_ptr(ob), O.box_ptr(sb))
+                t_boxes[k] = sb[0]
+                t_ep[k] = 1
+                for f in ("xc", "yc", "aspect", "height"):
+                    assert pred[i][f] == sb[0][f], (i, f)
+            else:
+                m, c = np.zeros(10, np.float32), np.zeros(100, np.float32)
+                L.or_make_prediction(PW, VW, 0, O.fptr(m), O.fptr(c), O.box_ptr(ob), O.box_ptr(sb))
+                add_ids.append(int(new_ids[i])); add_boxes.append(sb[0]); add_mean.append(m); add_cov.append(c)
+        all_ids = np.array(t_ids + add_ids, np.uint64)
+        all_boxes = np.concatenate([t_boxes, np.array(add_boxes, abi.BOX_DTYPE)]) if add_ids else t_boxes
+        all_ep = np.concatenate([t_ep, np.ones(len(add_ids), np.uint64)])
+        all_mean = np.concatenate([t_mean, np.array(add_mean, np.float32).reshape(-1, 10)])
+        all_cov = np.concatenate([t_cov, np.array(add_cov, np.float32).reshape(-1, 100)])
+        t2 = len(all_ids)
+        tr2 = abi.make_tracks(all_ids, all_boxes, all_ep, kf_mean=all_mean[:, :5].copy(),
+                              kf_cov=all_cov.reshape(t2, 10, 10)[:, :5, :5].reshape(t2, 25).copy())
+        ids2, _ = eng.associate(0, 2, abi.make_detections(det2))
+        ref2 = O.associate(cfg, tr2, 2, abi.make_detections(det2))
+        pos2 = eng.tap_positional()
+        np.testing.assert_array_equal(np.isnan(pos2), np.isnan(ref2["positional"]))
+        m2 = ~np.isnan(pos2)
+        assert m2.sum() > n
+        np.testing.assert_array_equal(pos2.view(np.uint32)[m2], ref2["positional"].view(np.uint32)[m2])
+    finally:
+        eng.close()
+
+
 def test_sort_maha_oriented_parity():
     rng = np.random.default_rng(22)
     sc = synth.sort_scene(rng, 90, 90, canvas=(900.0, 900.0), oriented=True)
@@ -614,7 +733,7 @@ def check_visual(cfg, sc, tol_abs=1e-5, tol_rel=0.0, **kw):
     return ids, votes, ref
 
 
-@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve", "row_tiles", "xcd_tiles")
+@pytest.mark.paths("general", "never_lean", "bestfit_tile", "separate_resolve", "row_tiles", "xcd_tiles", "staged_loop", "no_yield")
 @pytest.mark.parametrize("fused", [abi.SA_FLAG_SEPARATE_FRAME, abi.SA_FLAG_FUSED_FRAME, 0], ids=["separate_launches", "fused_frame_launch", "default"])
 @pytest.mark.parametrize("k", [1, 3])
 @pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 100), (129, 257, 36), (300, 280, 64)])
@@ -647,7 +766,7 @@ def test_visual_cosine_more_than_1024_detections():
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 50
 
 
-@pytest.mark.paths("euclid_valu", "euclid_mfma")
+@pytest.mark.paths("euclid_valu", "euclid_mfma", "staged_loop")
 def test_visual_euclid_parity():
     rng = np.random.default_rng(77)
     sc = synth.visual_scene(rng, 120, 140, 256, 3, canvas=(1500.0, 900.0), new_fraction=0.1)
@@ -1351,7 +1470,7 @@ def _full_size_visual(cfg, sc, shards=32):
     return ids, votes, pos, vis, ref
 
 
-@pytest.mark.paths("row_tiles")
+@pytest.mark.paths("row_tiles", "staged_loop", "no_yield")
 def test_full_size_c2_against_the_oracle():
     """BASELINE C2 (1000 x 1000 x 512-d cosine + IoU): IoU cells and the quantised matrix bit for bit, every cosine weight within
     1e-5, ids and vote types identical."""
@@ -1474,7 +1593,7 @@ def test_full_size_batched_c2_against_the_oracle(k):
         eng.close()
 
 
-@pytest.mark.paths("euclid_valu", "euclid_mfma")
+@pytest.mark.paths("euclid_valu", "euclid_mfma", "staged_loop")
 def test_full_size_c2_euclidean_against_the_oracle():
     """The C2 frame under the reference's DEFAULT visual metric: every euclidean distance within 1e-5 relative."""
     sc = synth.visual_scene(np.random.default_rng(6), 1000, 1000, 512, 1)
@@ -1593,7 +1712,7 @@ def hard_margin_scene_bank(rng, metric, pairs=500, d=512, k=3, gap=(1e-4, 4e-4))
                 det_boxes=dboxes, det_feats=det.astype(np.float32)[perm].copy(), det_quality=np.full(n, 0.9, np.float32))
 
 
-@pytest.mark.paths("bestfit_tile")
+@pytest.mark.paths("bestfit_tile", "staged_loop")
 @pytest.mark.parametrize("visual", ["cosine", "euclidean"])
 def test_full_size_c2_bank_of_three_hard_margins_against_the_oracle(visual):
     """C2 size, three observations per track, runner-up GROUPS within 4e-4 of the winners (hard_margin_scene_bank): ids and vote types of

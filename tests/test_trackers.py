@@ -689,11 +689,17 @@ def test_batch_visual_sort_three_scenes_match_oracle(backend):
 
 
 @pytest.mark.gpu
-def test_long_batch_visual_run_device_upkeep_against_host_upkeep():
+def test_long_batch_visual_run_device_upkeep_against_the_oracle_tracker():
     """150 frames of BatchVisualSort over three scenes through the result handle: the fused device-upkeep path (Kalman and feature banks
-    on the GPU, completion words, the collect's table side ahead of the Kalman wait) against the facade's host-upkeep path, frame by frame
-    — tracks, vote types, observation counts, idle sets."""
-    run_batch_visual_scenes("gpu_dev", seed=89, frames=150, async_handle=True, reference="gpu")
+    on the GPU — row-major bank and its fragment-order twin —, completion words, the collect's table side ahead of the Kalman wait)
+    against the ORACLE tracker, every frame — tracks, vote types, observation counts, idle sets."""
+    run_batch_visual_scenes("gpu_dev", seed=89, frames=150, async_handle=True, reference="oracle")
+
+
+@pytest.mark.gpu
+def test_batch_visual_run_device_upkeep_against_host_upkeep():
+    """... and 40 frames of the same against the facade's own host-upkeep path (two implementations of the same upkeep side by side)."""
+    run_batch_visual_scenes("gpu_dev", seed=90, frames=40, async_handle=True, reference="gpu")
 
 
 @pytest.mark.gpu
@@ -711,14 +717,14 @@ def test_batch_result_handle_delivers_every_scene(backend):
 
 
 @pytest.mark.gpu
-def test_long_batch_run_device_upkeep_against_host_upkeep():
+def test_long_batch_run_device_upkeep_against_the_oracle_tracker_and_host_upkeep():
     """400 frames of BatchSort over five scenes with missed detections, false positives and departures — the fused path (association with
     the upkeep queued behind it, completion words, the table side of the collect ahead of the Kalman wait, staged evictions, every third
-    frame through the result handle) against the facade's host-upkeep path frame by frame: same tracks, same idle and wasted sets.  (Both
-    are compared with the oracle tracker on short sequences above; this one is about the thousandth frame.)"""
+    frame through the result handle) against the ORACLE tracker AND the facade's host-upkeep path, every frame: same tracks, same idle and
+    wasted sets."""
     rng = np.random.default_rng(83)
     kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
-    g, h = make("gpu_dev", "sort", **kw), make("gpu", "sort", **kw)
+    g, h, o = make("gpu_dev", "sort", **kw), make("gpu", "sort", **kw), make("oracle", "sort", **kw)
     try:
         scenes = (2, 3, 5, 7, 11)
         world = {s: synth.dense_boxes(rng, 70 + 10 * k, (1100.0, 800.0)) for k, s in enumerate(scenes)}
@@ -744,16 +750,22 @@ def test_long_batch_run_device_upkeep_against_host_upkeep():
             else:
                 rg = g.predict_batch(req)
             rh = h.predict_batch(req)
+            ro = o.predict_batch(req)
             for s in scenes:
+                assert_tracks_equal(rg[s], ro[s])
                 assert_tracks_equal(rg[s], rh[s])
             if f % 40 == 39:
-                assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in h.wasted())
+                wo = sorted(x.id for x in o.wasted())
+                assert sorted(x.id for x in g.wasted()) == wo and sorted(x.id for x in h.wasted()) == wo
                 for s in scenes:
-                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id), sorted(h.idle_tracks_with_scene(s), key=lambda x: x.id))
-        assert g.active_tracks() == h.active_tracks()
+                    io = sorted(o.idle_tracks_with_scene(s), key=lambda x: x.id)
+                    assert_tracks_equal(sorted(g.idle_tracks_with_scene(s), key=lambda x: x.id), io)
+                    assert_tracks_equal(sorted(h.idle_tracks_with_scene(s), key=lambda x: x.id), io)
+        assert g.active_tracks() == h.active_tracks() == o.active_tracks()
     finally:
         g.close()
         h.close()
+        o.close()
 
 
 @pytest.mark.gpu
