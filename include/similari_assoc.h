@@ -115,6 +115,11 @@ typedef struct sa_config {
                                       with 1/2/4 k-groups, 7/8 = the ring variants) */
   uint32_t euclid_backoff_frames;  /* euclidean engines: after a frame that reported itself ill-conditioned for the matrix-core expansion, that
                                       SCENE's next frames run on the vector-pipe kernel, this many of them (0 = 256), before another try */
+  int32_t poll_spin_us;            /* how long a host thread may poll a request set's completion words (mapped host memory, stored by the
+                                      assignment tail: no completion signal on the dispatch) before it falls back to a BLOCKING wait on the
+                                      engine's stream: 0 = the default (2000 us: a frame is there within tens of microseconds; a set
+                                      queued behind somebody else's long kernel on a shared GPU blocks instead of burning a core),
+                                      -1 = never poll (block at once: no host CPU while the GPU works, ~5 us later per frame) */
 } sa_config;
 
 #define SA_FLAG_PROFILE 0x2u        /* stamp every kernel with its dispatch begin / end (implies eager launches) */

@@ -91,6 +91,20 @@ typedef struct sa_tracker_options {
                                            sort/batch_api.rs:197-207), the calling thread included; 0 = the facade's choice, 1 = none.
                                            n > 1: bound to the CPUs next to the one the first batch call runs on that no other tracker of
                                            the process holds (a scene's records stay in one cache complex); -n: n threads left to the scheduler */
+  /* Batch*::predict over the GPUs of one node (sort/batch_api.rs:157-207, visual_sort/batch_api.rs:161-317: ONE tracker object fans a
+   * request set out).  n_devices > 1: the tracker owns one engine per entry of devices[] (HIP ordinals; the same ordinal may appear more
+   * than once — several engines on one GPU) and every scene lives on ONE of them for good: shard = scene_id % n_devices.  A request
+   * set is split by shard, every shard's share runs on its device through the same fused path as a single-device tracker (association
+   * + device upkeep queued behind it, that shard's own worker threads and result driver), all shards at once, and the result handle
+   * delivers the scenes of every shard as they finish.  Track ids, epochs, idle / wasted sets and the auto-waste cadence are those of ONE
+   * tracker (the id counter and the waste counter are the group's; Batch* ids are a function of the request alone, so no shard waits for
+   * another).  n_devices <= 1: one engine on `device` (devices is ignored). */
+  uint32_t n_devices;
+  const int32_t* devices;
+  /* Host manners.  spin_us: how long a thread of this tracker may busy-poll — the result driver for the next request set, the worker
+   * pool for its next job, a caller inside sa_batch_result_get for the next scene — before it goes to sleep on a condition variable
+   * (-1 = the defaults: 300 us pool, 200 us driver, 500 us handle; 0 = sleep at once: no idle CPU use, +5-20 us per hand-over). */
+  int32_t spin_us;
 } sa_tracker_options;
 
 typedef struct sa_tracker sa_tracker;

@@ -5,7 +5,11 @@ returns / until the first scene / until the last).  `device`: the scenes' featur
 model's output buffer).  `device_association_us`: the association kernels of the last request set alone, replayed on resident inputs
 (sa_batch_time); the device-side span of a whole predict() — association + upkeep dispatches — is what scripts/batch_tracker_timeline.sh
 reads from a rocprofv3 kernel trace of this script.
-   python scripts/bench_batch_tracker.py [sort|visual] [scenes] [objects] [feature_len] [frames] [workers] [sync|async] [rows|device]"""
+`devices`: a comma-separated list of HIP ordinals — the tracker becomes a device GROUP (sa_tracker_options.devices: one engine per entry,
+scenes dealt out scene_id % n; "0,0" = two engines on one GPU); `spin_us`: sa_tracker_options.spin_us (-1 = defaults, 0 = no idle
+polling).  `cpu_seconds_per_1000_predicts`: user + system CPU time of the WHOLE process (caller, pool, drivers, runtime threads) over the
+timed loop, scaled — what a host pays for the back-to-back loop, idle spinning included.
+   python scripts/bench_batch_tracker.py [sort|visual] [scenes] [objects] [feature_len] [frames] [workers] [sync|async] [rows|device] [devices|-] [spin_us]"""
 import ctypes as C
 import json
 import sys
@@ -26,6 +30,8 @@ frames = int(sys.argv[5]) if len(sys.argv) > 5 else 30
 workers = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 mode = sys.argv[7] if len(sys.argv) > 7 else "sync"
 feats_mode = sys.argv[8] if len(sys.argv) > 8 else "rows"
+devices = [int(x) for x in sys.argv[9].split(",")] if len(sys.argv) > 9 and sys.argv[9] != "-" else None
+spin_us = int(sys.argv[10]) if len(sys.argv) > 10 else -1
 K = 3
 rng = np.random.default_rng(0)
 dev = None
@@ -37,9 +43,9 @@ if kind == "visual" and feats_mode == "device":
 if kind == "visual":
     opts = (TR.VisualSortOptions().max_idle_epochs(3).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.2))
             .positional_metric(TR.PositionalMetricType.iou(0.3)).visual_minimal_track_length(1).visual_max_observations(K))
-    trk = TR.BatchVisualSort(voting_shards=workers, opts=opts, feature_len=d, device_upkeep=True)
+    trk = TR.BatchVisualSort(voting_shards=workers, opts=opts, feature_len=d, device_upkeep=True, devices=devices, spin_us=spin_us)
 else:
-    trk = TR.BatchSort(voting_shards=workers, bbox_history=3, max_idle_epochs=3, device_upkeep=True)
+    trk = TR.BatchSort(voting_shards=workers, bbox_history=3, max_idle_epochs=3, device_upkeep=True, devices=devices, spin_us=spin_us)
 lib = trk.lib
 if dev is not None:
     lib.sa_device_block_register(C.c_void_p(dev.data_ptr()), dev.numel() * 4, 0)
@@ -72,10 +78,15 @@ for f in range(frames):
     calls.append((arrs, outs, ids, counts, pa, po))
 if dev is not None:
     torch.cuda.synchronize()
+import resource
 times, t_begin, t_first = [], [], []
+cpu0 = wall0 = None
 sid, cnt = C.c_uint64(), C.c_uint32()
 view = C.POINTER(abi.sa_sort_track)()
-for (arrs, outs, ids, counts, pa, po) in calls:
+for ci, (arrs, outs, ids, counts, pa, po) in enumerate(calls):
+    if ci == 3:
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        cpu0, wall0 = ru.ru_utime + ru.ru_stime, time.perf_counter()
     t0 = time.perf_counter()
     if mode == "async":
         h = C.c_void_p()
@@ -95,6 +106,8 @@ for (arrs, outs, ids, counts, pa, po) in calls:
         rc = lib.sa_tracker_predict_batch(trk.h, S, ids, counts, pa, po)
         times.append(time.perf_counter() - t0)
         assert rc == 0, lib.sa_tracker_last_error(trk.h)
+ru = resource.getrusage(resource.RUSAGE_SELF)
+cpu_s, wall_s = ru.ru_utime + ru.ru_stime - cpu0, time.perf_counter() - wall0
 cont = sum(1 for o in calls[-1][1] for i in range(n) if o[i].length > 1) if mode != "async" else None
 # the device's share: the association of the last request set against the tables as they stand (resident inputs, kernels only)
 eng = lib.sa_tracker_engine(trk.h)
@@ -102,7 +115,7 @@ lib.sa_batch_sync(eng)
 ms = C.c_double()
 dev_assoc_us = None
 lib.sa_batch_time(eng, 2, C.byref(ms))   # (the first replay behind a loop re-stages the set on the host: ~9 ms at 64 scenes, no kernel in it)
-if lib.sa_batch_time(eng, 20, C.byref(ms)) == 0:
+if devices is None and lib.sa_batch_time(eng, 20, C.byref(ms)) == 0:
     dev_assoc_us = round(1e3 * ms.value / 20, 1)
 trk.close()
 if dev is not None:
@@ -112,6 +125,10 @@ out = {"tracker": "Batch" + ("VisualSort" if kind == "visual" else "Sort"), "sce
        "bank": K if kind == "visual" else 0, "features": feats_mode if kind == "visual" else None, "upkeep": "device", "workers": workers, "call": mode,
        "us_per_predict_median": round(1e6 * med, 1), "us_per_predict_min": round(1e6 * float(np.min(times[3:])), 1),
        "us_per_scene": round(1e6 * med / S, 1), "device_association_us": dev_assoc_us, "tracks_continued_last_frame": cont}
+out["devices"] = devices
+out["spin_us"] = spin_us
+out["cpu_seconds_per_1000_predicts"] = round(1e3 * cpu_s / max(1, len(calls) - 3), 4)
+out["cpu_cores_busy_over_the_loop"] = round(cpu_s / wall_s, 2)
 if mode == "async":
     out["us_until_begin_returns"] = round(1e6 * float(np.median(t_begin[3:])), 1)
     out["us_until_first_scene"] = round(1e6 * float(np.median(t_first[3:])), 1)

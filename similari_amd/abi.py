@@ -110,6 +110,7 @@ class sa_config(C.Structure):
         ("visual_minimal_own_area_percentage_collect", C.c_float),
         ("gemm_plan", C.c_int32),
         ("euclid_backoff_frames", C.c_uint32),
+        ("poll_spin_us", C.c_int32),
     ]
 
 
@@ -205,6 +206,9 @@ class sa_tracker_options(C.Structure):
         ("visual_minimal_own_area_percentage_collect", C.c_float),
         ("device_upkeep", C.c_int32),
         ("workers", C.c_int32),
+        ("n_devices", C.c_uint32),
+        ("devices", C.POINTER(C.c_int32)),
+        ("spin_us", C.c_int32),
     ]
 
 
@@ -276,6 +280,7 @@ def make_config(
     visual_minimal_own_area_percentage_collect=0.0,
     gemm_plan=None,
     euclid_backoff_frames=0,
+    poll_spin_us=0,
 ):
     """sa_config with the reference's defaults; returns (cfg, keepalive)."""
     keep = Keep()
@@ -312,6 +317,7 @@ def make_config(
     cfg.flags = flags | EXTRA_FLAGS
     cfg.gemm_plan = 0 if gemm_plan is None else int(gemm_plan) + 1
     cfg.euclid_backoff_frames = euclid_backoff_frames
+    cfg.poll_spin_us = poll_spin_us
     cfg.visual_minimal_quality_collect = visual_minimal_quality_collect
     cfg.visual_minimal_own_area_percentage_collect = visual_minimal_own_area_percentage_collect
     cfg._keep = keep

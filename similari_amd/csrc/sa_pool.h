@@ -6,14 +6,16 @@
 // scene's tracks, work arrays and table bookkeeping stay in one core's caches from frame to frame (measured on the 2 x 64-core host of
 // the MI355X box: with jobs handed out first come first served every track record a merge touched came out of another core's cache,
 // ~100 ns per object; four threads were slower than one).  run(n, fn) returns when every job has finished.  Workers spin for a few
-// hundred microseconds after a run (a tracker loop calls predict() back to back: the next run finds them awake) and then sleep on a
-// condition variable.
+// hundred microseconds after a run (a tracker loop calls predict() back to back: the next run finds them awake; spin_us, 0 = not at all)
+// and then sleep on a condition variable.  A job that throws does not hang the run: the exception is caught where it happens, every
+// worker still answers, and run() rethrows the first one on the calling thread.
 #pragma once
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -36,7 +38,7 @@ class SaPool {
   // thread may run on — its neighbours in the same socket and cache complex on the usual numbering.  Measured on the 2 x 64-core host of the MI355X box (64 scenes x 500 objects,
   // 8 threads): left to the scheduler the workers land on the other socket and a merge job runs at 300 ns per object, every record a
   // remote miss; next to the caller at 7.
-  explicit SaPool(uint32_t workers, bool pin = true) : acks_(workers ? new Ack[workers] : nullptr), nw_(workers) {
+  explicit SaPool(uint32_t workers, bool pin = true, int spin_us = 300) : acks_(workers ? new Ack[workers] : nullptr), nw_(workers), spin_us_(spin_us < 0 ? 300 : spin_us) {
 #if defined(__linux__)
     if (pin && workers) {
       // the CPUs the creating thread may run on, from its own onwards; the first workers + 1 of them that no other pool of this process
@@ -119,9 +121,23 @@ class SaPool {
       { std::lock_guard<std::mutex> lk(mu_); }   // (a worker between its last look at gen_ and its wait holds the mutex: wait for it to be in the wait)
       cv_.notify_all();
     }
-    for (uint32_t i = 0; i < n; i += nt) fn(i);
+    std::exception_ptr mine;
+    try {
+      for (uint32_t i = 0; i < n; i += nt) fn(i);
+    } catch (...) { mine = std::current_exception(); }   // (the workers still read fn_: wait for them before unwinding)
     for (uint32_t w = 0; w < nw_; ++w)
-      while (acks_[w].gen.load(std::memory_order_acquire) != g) SA_POOL_PAUSE();
+      for (uint32_t spin = 1; acks_[w].gen.load(std::memory_order_acquire) != g; ++spin) {
+        if ((spin & 4095u) == 0) std::this_thread::yield();   // (a worker that lost its CPU to somebody else's thread)
+        else SA_POOL_PAUSE();
+      }
+    std::exception_ptr theirs;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      theirs = error_;
+      error_ = nullptr;
+    }
+    if (mine) std::rethrow_exception(mine);
+    if (theirs) std::rethrow_exception(theirs);
   }
 
  private:
@@ -129,14 +145,14 @@ class SaPool {
   void loop(uint32_t w) {
     uint64_t seen = 0;
     for (;;) {
-      // spin for ~300 us (a predict() of a running tracker loop is back within that), then sleep
+      // spin for spin_us (300 by default: a predict() of a running tracker loop is back within that), then sleep
       uint64_t g = gen_.load(std::memory_order_acquire);
-      if (g == seen) {
+      if (g == seen && spin_us_ > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spin = 1; g == seen; ++spin) {
           SA_POOL_PAUSE();
           g = gen_.load(std::memory_order_acquire);
-          if ((spin & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+          if ((spin & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
         }
       }
       if (g == seen) {
@@ -149,7 +165,12 @@ class SaPool {
       seen = g;
       if (stop_) return;
       const uint32_t nt = nw_ + 1;
-      for (uint32_t i = w + 1; i < n_; i += nt) (*fn_)(i);
+      try {
+        for (uint32_t i = w + 1; i < n_; i += nt) (*fn_)(i);
+      } catch (...) {   // (recorded, answered all the same: run() must not wait for an acknowledgement that never comes)
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
       acks_[w].gen.store(g, std::memory_order_release);
     }
   }
@@ -157,6 +178,8 @@ class SaPool {
   std::vector<std::thread> th_;
   Ack* acks_;
   uint32_t nw_;
+  int spin_us_ = 300;
+  std::exception_ptr error_;   // the first exception a worker's job threw during the current run (under mu_)
   int next_cpu_ = -1;
   std::vector<int> mine_;   // the CPUs this pool has claimed: its workers', then next_cpu()
   static std::mutex& claims_mu() { static std::mutex m; return m; }

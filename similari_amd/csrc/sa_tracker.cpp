@@ -182,6 +182,11 @@ struct TrackBlocks {
 // PredictionBatchResult  trackers/batch.rs:19-38
 struct sa_batch_result {
   std::shared_ptr<ResultState> st;
+  // the handle of a device GROUP (sa_tracker_options.n_devices > 1): one handle per shard that received scenes; a scene is delivered
+  // from whichever shard has one ready
+  std::vector<sa_batch_result*> kids;
+  uint32_t kid_total = 0, kid_taken = 0, kid_next = 0;
+  int spin_us = 500;
 };
 
 struct sa_tracker {
@@ -191,6 +196,12 @@ struct sa_tracker {
   sa_engine* eng = nullptr;
   std::string err;
   uint64_t track_id = 0;
+  // Device group (n_devices > 1): this object owns one complete tracker per device and only routes — shard = scene_id % shards.size(), for
+  // good; it has no engine, no scenes and no pool of its own, and keeps the two things the shards must share: the id counter and the
+  // auto-waste counter.  A shard draws the ids of a call's scenes from forced_base (one base per scene of ITS share, set by the group for
+  // the duration of the call) instead of its own counter.
+  std::vector<sa_tracker*> shards;
+  const uint64_t* forced_base = nullptr;
   std::map<uint64_t, SceneState> scenes;   // node-based: a SceneState's address is stable
   uint64_t n_active = 0;                   // tracks in the main store (sum of active_shard_stats)
   std::vector<sa_sort_track> wasted_store;   // (what wasted() hands out of a wasted track: its SortTrack)
@@ -342,7 +353,7 @@ void run_jobs(sa_tracker* t, uint32_t n, const std::function<void(uint32_t)>& fn
     // workers: n > 0 = n threads bound to the CPUs next to the caller's (sa_pool.h), n < 0 = |n| threads left to the scheduler, 0 = the facade's choice
     const int32_t ow = t->o.workers;
     uint32_t w = ow ? (uint32_t)(ow < 0 ? -ow : ow) : std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 8u));
-    t->pool.reset(new SaPool(w > 1 ? w - 1 : 0, ow >= 0));   // (the calling thread is a worker too)
+    t->pool.reset(new SaPool(w > 1 ? w - 1 : 0, ow >= 0, t->o.spin_us));   // (the calling thread is a worker too; spin_us < 0: the pool's default)
   }
   if (n > 1 && t->pool) t->pool->run(n, fn);
   else
@@ -792,10 +803,11 @@ void driver_loop(sa_tracker* t) {
   uint32_t seen = 0;
   for (;;) {
     {
+      const int spin_us = t->o.spin_us < 0 ? 300 : t->o.spin_us;   // (sa_tracker_options.spin_us; 0: to sleep at once)
       const auto t0 = clk::now();
-      for (uint32_t spin = 1; t->d_posted.load(std::memory_order_acquire) == seen; ++spin) {
+      for (uint32_t spin = 1; spin_us > 0 && t->d_posted.load(std::memory_order_acquire) == seen; ++spin) {
         SA_POOL_PAUSE();
-        if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(300)) break;
+        if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(spin_us)) break;
       }
       std::unique_lock<std::mutex> lk(t->dmu);
       t->dcv.wait(lk, [&] { return t->d_work || t->d_stop; });
@@ -803,7 +815,20 @@ void driver_loop(sa_tracker* t) {
       t->d_work = false;
       seen = t->d_posted.load(std::memory_order_acquire);
     }
-    complete_flight(t);
+    try {
+      complete_flight(t);
+    } catch (const std::exception& ex) {   // (a job of the set threw — out of memory, most likely: the handle reports it, nothing hangs)
+      sa_tracker::Flight& F = t->flight;
+      t->err = std::string("request set abandoned: ") + ex.what();
+      if (F.res) {
+        std::lock_guard<std::mutex> lk(F.res->mu);
+        F.res->rc = SA_ERR_OOM;
+        F.res->err = t->err;
+        F.res->finished = true;
+        F.res->n_ready.fetch_or(0x80000000u, std::memory_order_release);
+        F.res->cv.notify_all();
+      }
+    }
     {
       std::lock_guard<std::mutex> lk(t->dmu);
       t->flight.res.reset();
@@ -851,7 +876,7 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
     SceneState& S = scene_of(t, scene_ids[s]);
     ss[s].st = &S;
     ss[s].epoch = S.epoch + 1; // next_epoch  epoch_db.rs:35-49 (committed once the request has passed validation)
-    ss[s].id_base = next;      // (batch ids: one per candidate; a single scene: its own counter)
+    ss[s].id_base = t->forced_base ? t->forced_base[s] : next;      // (batch ids: one per candidate; a single scene: its own counter; a shard of a device group: the group's)
     next += counts[s];
   }
   const auto t_pre = clk::now();
@@ -1011,6 +1036,7 @@ int predict_general(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids,
     const uint32_t n = W.n;
     W.tids.resize(n);
     W.new_ids.resize(n);
+    if (t->forced_base) t->track_id = t->forced_base[s];   // (a shard of a device group: the group has drawn this scene's ids)
     for (uint32_t i = 0; i < n; ++i) {
       const uint64_t dest = W.winners[i];
       uint64_t drawn = 0;
@@ -1119,6 +1145,109 @@ int predict_scenes(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, 
   return predict_general(t, n_scenes, scene_ids, counts, obs, out);
 }
 
+
+}  // namespace
+int sa_begin_into(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                  sa_sort_track* const* caller_out, sa_batch_result** out_result);
+namespace {
+// ---- device group: Batch*::predict over several GPUs behind ONE tracker object (sort/batch_api.rs:157-207, 222-290) ------------------
+inline uint32_t shard_of(const sa_tracker* t, uint64_t scene) { return (uint32_t)(scene % t->shards.size()); }
+inline int group_fail(sa_tracker* t, const sa_tracker* c, int rc) { t->err = c->err; g_err = c->err; return rc; }
+void group_auto_waste(sa_tracker* t, const sa_tracker* skip = nullptr) {
+  for (sa_tracker* c : t->shards) {
+    if (c == skip) continue;
+    wait_outstanding(c);
+    flush_pending(c);
+    (void)auto_waste(c);
+  }
+}
+// The request set split by shard (request order kept inside a shard), every shard's share begun one after the other on the calling
+// thread — a shard's _begin returns once its launches are queued (its own pool assembles and stages its scenes, its own driver thread
+// finishes them), so shard k + 1 prepares while shard k's kernels run — and ONE handle over the shards' handles.
+int group_begin(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                sa_batch_result** out_result, sa_sort_track* const* caller_out = nullptr) {
+  const sa_tracker_options& o = t->o;
+  const uint32_t ns = (uint32_t)t->shards.size();
+  for (uint32_t s = 0; s < n_scenes; ++s) {
+    if (counts[s] && !obs[s]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu: null observations", (unsigned long long)scene_ids[s]);
+    for (uint32_t s2 = 0; s2 < s; ++s2)
+      if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
+  }
+  // the auto-waste cadence is the GROUP's (one counter per tracker object, simple_api.rs:115-120): a shard never wastes on its own count
+  if (t->waste_counter == 0) {
+    group_auto_waste(t);
+    t->waste_counter = o.auto_waste_periodicity;
+  } else t->waste_counter -= 1;
+  std::unique_ptr<sa_batch_result> r(new sa_batch_result());
+  r->spin_us = o.spin_us < 0 ? 500 : o.spin_us;
+  if (!n_scenes) { for (sa_tracker* c : t->shards) { wait_outstanding(c); flush_pending(c); } *out_result = r.release(); return SA_OK; }
+  struct Share { std::vector<uint64_t> ids, base; std::vector<uint32_t> counts; std::vector<const sa_observation*> obs; std::vector<sa_sort_track*> out; };
+  std::vector<Share> sh(ns);
+  if (o.batch_ids) {
+    // Batch* ids: one per candidate, in request order — a function of the request alone, so every shard gets its scenes' bases up front
+    uint64_t next = t->track_id;
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+      Share& S = sh[shard_of(t, scene_ids[s])];
+      S.ids.push_back(scene_ids[s]); S.counts.push_back(counts[s]); S.obs.push_back(obs[s]); S.base.push_back(next);
+      if (caller_out) S.out.push_back(caller_out[s]);
+      next += counts[s];
+    }
+    t->track_id = next;
+    int rc = SA_OK;
+    for (uint32_t k = 0; k < ns && rc == SA_OK; ++k) {
+      if (sh[k].ids.empty()) continue;
+      sa_tracker* c = t->shards[k];
+      wait_outstanding(c);
+      c->forced_base = sh[k].base.data();
+      sa_batch_result* kid = nullptr;
+      try {
+        rc = sa_begin_into(c, (uint32_t)sh[k].ids.size(), sh[k].ids.data(), sh[k].counts.data(), sh[k].obs.data(), caller_out ? sh[k].out.data() : nullptr, &kid);
+      } catch (const std::exception& ex) { rc = tfail(c, SA_ERR_OOM, "%s", ex.what()); }
+      c->forced_base = nullptr;
+      if (rc != SA_OK) { group_fail(t, c, rc); break; }
+      r->kids.push_back(kid);
+      r->kid_total += (uint32_t)sh[k].ids.size();
+    }
+    if (rc != SA_OK) { for (sa_batch_result* kid : r->kids) sa_batch_result_free(kid); return rc; }
+  } else {
+    // Sort / VisualSort id rules: an id per track that STARTS, drawn in candidate order — the counter a scene starts from depends on the
+    // scenes before it, so the scenes run one after the other, each on its shard, and hand the counter on
+    for (uint32_t s = 0; s < n_scenes; ++s) {
+      sa_tracker* c = t->shards[shard_of(t, scene_ids[s])];
+      wait_outstanding(c);
+      c->track_id = t->track_id;
+      sa_batch_result* kid = nullptr;
+      int rc;
+      try {
+        rc = sa_begin_into(c, 1, &scene_ids[s], &counts[s], &obs[s], caller_out ? &caller_out[s] : nullptr, &kid);
+      } catch (const std::exception& ex) { rc = tfail(c, SA_ERR_OOM, "%s", ex.what()); }
+      if (rc == SA_OK) { wait_outstanding(c); t->track_id = c->track_id; }
+      if (rc != SA_OK) { for (sa_batch_result* k2 : r->kids) sa_batch_result_free(k2); return group_fail(t, c, rc); }
+      r->kids.push_back(kid);
+      r->kid_total += 1;
+    }
+  }
+  *out_result = r.release();
+  return SA_OK;
+}
+// the next finished scene of a group handle: whichever shard has one
+int group_next(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** tracks, uint32_t* out_n, bool bounded, uint32_t cap);
+int group_predict(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                  sa_sort_track* const* out) {
+  for (uint32_t s = 0; s < n_scenes; ++s)
+    if (counts[s] && !out[s]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu: null output", (unsigned long long)scene_ids[s]);
+  // every shard fills the caller's arrays of ITS scenes itself; the group waits for the shards' drivers and looks at what they report
+  sa_batch_result* h = nullptr;
+  int rc = group_begin(t, n_scenes, scene_ids, counts, obs, &h, out);
+  if (rc != SA_OK) return rc;
+  for (sa_tracker* c : t->shards) wait_outstanding(c);
+  for (sa_batch_result* kid : h->kids) {
+    std::lock_guard<std::mutex> lk(kid->st->mu);
+    if (kid->st->rc != SA_OK && rc == SA_OK) { rc = kid->st->rc; t->err = kid->st->err; g_err = kid->st->err; }
+  }
+  sa_batch_result_free(h);
+  return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -1151,7 +1280,7 @@ void sa_tracker_options_default(sa_tracker_options* o, int visual) {
 }
 
 const char* sa_tracker_last_error(const sa_tracker* t) { return t ? t->err.c_str() : g_err.c_str(); }
-sa_engine* sa_tracker_engine(sa_tracker* t) { return t ? t->eng : nullptr; }
+sa_engine* sa_tracker_engine(sa_tracker* t) { return !t ? nullptr : t->shards.empty() ? t->eng : t->shards[0]->eng; }   // (a device group: its first shard's)
 
 int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
   if (!o || !out) return tfail(nullptr, SA_ERR_BAD_ARG, "sa_tracker_create: null argument");
@@ -1161,6 +1290,26 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
   if (o->visual && (o->feature_len == 0 || o->visual_max_observations == 0))
     return tfail(nullptr, SA_ERR_BAD_ARG, "VisualSort needs feature_len and visual_max_observations");
   if (o->workers < -256 || o->workers > 256) return tfail(nullptr, SA_ERR_BAD_ARG, "workers must lie in [-256, 256] (0 = the facade's own choice)");
+  if (o->n_devices > 64 || (o->n_devices > 1 && !o->devices)) return tfail(nullptr, SA_ERR_BAD_ARG, "n_devices must be <= 64, with devices[] given");
+  if (o->n_devices > 1) {
+    // a device group: one complete tracker per entry of devices[]; this object routes (sa_tracker::shards)
+    sa_tracker* g = new sa_tracker();
+    g->o = *o;
+    g->o.constraint_epoch_delta = nullptr; g->o.constraint_max_dist = nullptr; g->o.devices = nullptr;
+    g->waste_counter = o->auto_waste_periodicity;
+    for (uint32_t k = 0; k < o->n_devices; ++k) {
+      sa_tracker_options oc = *o;
+      oc.n_devices = 0; oc.devices = nullptr;
+      oc.device = o->devices[k];
+      oc.auto_waste_periodicity = 0xffffffffu;   // (the cadence is the group's)
+      sa_tracker* c = nullptr;
+      int rc = sa_tracker_create(&oc, &c);
+      if (rc != SA_OK) { for (sa_tracker* c2 : g->shards) sa_tracker_destroy(c2); delete g; return rc; }
+      g->shards.push_back(c);
+    }
+    *out = g;
+    return SA_OK;
+  }
   sa_tracker* t = new sa_tracker();
   t->o = *o;
   t->cons_delta.assign(o->constraint_epoch_delta, o->constraint_epoch_delta + o->n_constraints);
@@ -1203,6 +1352,11 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
 
 void sa_tracker_destroy(sa_tracker* t) {
   if (!t) return;
+  if (!t->shards.empty()) {
+    for (sa_tracker* c : t->shards) sa_tracker_destroy(c);
+    delete t;
+    return;
+  }
   wait_outstanding(t);
   if (t->driver.joinable()) {
     {
@@ -1226,13 +1380,19 @@ int sa_tracker_predict(sa_tracker* t, uint64_t scene_id, uint32_t n, const sa_ob
   if (!t || (n && (!obs || !out))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict: null argument");
   const sa_observation* op = obs;
   sa_sort_track* outp = out;
-  return predict_scenes(t, 1, &scene_id, &n, &op, &outp);
+  try {
+    if (!t->shards.empty()) return group_predict(t, 1, &scene_id, &n, &op, &outp);
+    return predict_scenes(t, 1, &scene_id, &n, &op, &outp);
+  } catch (const std::exception& ex) { return tfail(t, SA_ERR_OOM, "sa_tracker_predict: %s", ex.what()); }
 }
 
 int sa_tracker_predict_batch(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts,
                              const sa_observation* const* obs, sa_sort_track* const* out) {
   if (!t || (n_scenes && (!scene_ids || !counts || !obs || !out))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict_batch: null argument");
-  return predict_scenes(t, n_scenes, scene_ids, counts, obs, out);
+  try {
+    if (!t->shards.empty()) return group_predict(t, n_scenes, scene_ids, counts, obs, out);
+    return predict_scenes(t, n_scenes, scene_ids, counts, obs, out);
+  } catch (const std::exception& ex) { return tfail(t, SA_ERR_OOM, "sa_tracker_predict_batch: %s", ex.what()); }
 }
 
 // Batch*::predict(PredictionBatchRequest) -> PredictionBatchResult  (sort/batch_api.rs:222-290, trackers/batch.rs:19-38)
@@ -1240,17 +1400,28 @@ int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint6
                                    const sa_observation* const* obs, sa_batch_result** out_result) {
   if (!t || !out_result || (n_scenes && (!scene_ids || !counts || !obs))) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_predict_batch_begin: null argument");
   *out_result = nullptr;
+  if (!t->shards.empty()) return group_begin(t, n_scenes, scene_ids, counts, obs, out_result);
+  return sa_begin_into(t, n_scenes, scene_ids, counts, obs, nullptr, out_result);
+}
+}  // extern "C"
+// _begin with the tracks going either into a block of the handle's (caller_out == nullptr: sa_batch_result_get / _take hand them out) or
+// straight into the caller's arrays (a device group's synchronous predict: every shard fills its scenes' arrays itself, the group only waits)
+int sa_begin_into(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, const uint32_t* counts, const sa_observation* const* obs,
+                  sa_sort_track* const* caller_out, sa_batch_result** out_result) {
   wait_outstanding(t);
   auto st = std::make_shared<ResultState>();
   st->scene_ids.assign(scene_ids, scene_ids + n_scenes);
   st->off.resize((size_t)n_scenes + 1, 0);
   for (uint32_t s = 0; s < n_scenes; ++s) st->off[s + 1] = st->off[s] + counts[s];
   st->blocks = t->blocks;
-  st->store = t->blocks->take(st->off[n_scenes] ? st->off[n_scenes] : 1);
+  if (!caller_out) st->store = t->blocks->take(st->off[n_scenes] ? st->off[n_scenes] : 1);
   std::vector<sa_sort_track*> outs(n_scenes);
-  for (uint32_t s = 0; s < n_scenes; ++s) outs[s] = st->store.p.get() + st->off[s];
+  for (uint32_t s = 0; s < n_scenes; ++s) outs[s] = caller_out ? caller_out[s] : st->store.p.get() + st->off[s];
   const bool fused = t->o.device_upkeep && (t->o.batch_ids || n_scenes == 1) && n_scenes;
-  int rc = predict_scenes(t, n_scenes, scene_ids, counts, obs, outs.data(), fused ? st : nullptr);
+  int rc;
+  try {
+    rc = predict_scenes(t, n_scenes, scene_ids, counts, obs, outs.data(), fused ? st : nullptr);
+  } catch (const std::exception& ex) { rc = tfail(t, SA_ERR_OOM, "sa_tracker_predict_batch_begin: %s", ex.what()); }
   if (rc != SA_OK) return rc;
   if (!fused) {   // everything happened inside the call: every scene is ready
     std::lock_guard<std::mutex> lk(st->mu);
@@ -1260,14 +1431,21 @@ int sa_tracker_predict_batch_begin(sa_tracker* t, uint32_t n_scenes, const uint6
   }
   sa_batch_result* r = new sa_batch_result();
   r->st = st;
+  r->spin_us = t->o.spin_us < 0 ? 500 : t->o.spin_us;
   *out_result = r;
   return SA_OK;
 }
+extern "C" {
 
-uint32_t sa_batch_result_size(const sa_batch_result* r) { return r ? (uint32_t)r->st->scene_ids.size() : 0; }
+uint32_t sa_batch_result_size(const sa_batch_result* r) { return !r ? 0 : r->st ? (uint32_t)r->st->scene_ids.size() : r->kid_total; }
 
 int sa_batch_result_ready(sa_batch_result* r) {
   if (!r) return 0;
+  if (!r->st) {   // a device group's handle: any shard
+    for (sa_batch_result* kid : r->kids)
+      if (sa_batch_result_ready(kid)) return 1;
+    return 0;
+  }
   std::lock_guard<std::mutex> lk(r->st->mu);
   return (!r->st->ready_q.empty() || (r->st->finished && r->st->rc != SA_OK)) ? 1 : 0;
 }
@@ -1281,11 +1459,11 @@ static int result_next(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort
     // written by get() — by this thread, or by another caller thread under the lock, in which case the wait below sorts it out)
     const uint32_t have = st.taken;
     const auto t0 = clk::now();
-    for (uint32_t spin = 1;; ++spin) {
+    for (uint32_t spin = 1; r->spin_us > 0; ++spin) {
       const uint32_t v = st.n_ready.load(std::memory_order_acquire);
       if ((v & 0x7fffffffu) > have || (v & 0x80000000u)) break;
       SA_POOL_PAUSE();
-      if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(500)) break;
+      if ((spin & 255u) == 0 && clk::now() - t0 > std::chrono::microseconds(r->spin_us)) break;
     }
   }
   std::unique_lock<std::mutex> lk(st.mu);
@@ -1303,10 +1481,34 @@ static int result_next(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort
   return SA_OK;
 }
 
+}  // extern "C"
+namespace {
+// A group handle's next scene: the shards' handles are looked at in turn (a ready scene is taken at once); while none has one, the
+// calling thread polls for spin_us and then naps 20 us at a time — the shards' drivers deliver under their own locks.
+int group_next(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** tracks, uint32_t* out_n, bool bounded, uint32_t cap) {
+  if (r->kid_taken >= r->kid_total) return SA_ERR_STATE;
+  const auto t0 = clk::now();
+  const uint32_t nk = (uint32_t)r->kids.size();
+  for (;;) {
+    for (uint32_t i = 0; i < nk; ++i) {
+      const uint32_t k = (r->kid_next + i) % nk;
+      sa_batch_result* kid = r->kids[k];
+      if (kid->st->taken >= kid->st->scene_ids.size() || !sa_batch_result_ready(kid)) continue;
+      int rc = result_next(kid, out_scene_id, tracks, out_n, bounded, cap);
+      if (rc == SA_OK) { ++r->kid_taken; r->kid_next = (k + 1) % nk; }
+      return rc;
+    }
+    if (clk::now() - t0 > std::chrono::microseconds(r->spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    else SA_POOL_PAUSE();
+  }
+}
+}  // namespace
+extern "C" {
+
 int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!r || !out_n) return SA_ERR_BAD_ARG;
   const sa_sort_track* src = nullptr;
-  int rc = result_next(r, out_scene_id, &src, out_n, true, out ? cap : 0);
+  int rc = r->st ? result_next(r, out_scene_id, &src, out_n, true, out ? cap : 0) : group_next(r, out_scene_id, &src, out_n, true, out ? cap : 0);
   if (rc != SA_OK) return rc;
   if (*out_n) std::memcpy(out, src, (size_t)*out_n * sizeof(sa_sort_track));   // (outside the handle's lock: the scenes' jobs deliver under it)
   return SA_OK;
@@ -1314,13 +1516,22 @@ int sa_batch_result_get(sa_batch_result* r, uint64_t* out_scene_id, sa_sort_trac
 
 int sa_batch_result_take(sa_batch_result* r, uint64_t* out_scene_id, const sa_sort_track** out_tracks, uint32_t* out_n) {
   if (!r || !out_tracks || !out_n) return SA_ERR_BAD_ARG;
-  return result_next(r, out_scene_id, out_tracks, out_n, false, 0);
+  return r->st ? result_next(r, out_scene_id, out_tracks, out_n, false, 0) : group_next(r, out_scene_id, out_tracks, out_n, false, 0);
 }
 
-void sa_batch_result_free(sa_batch_result* r) { delete r; }
+void sa_batch_result_free(sa_batch_result* r) {
+  if (!r) return;
+  for (sa_batch_result* kid : r->kids) sa_batch_result_free(kid);
+  delete r;
+}
 
 int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_idle_tracks: null argument");
+  if (!t->shards.empty()) {
+    sa_tracker* c = t->shards[shard_of(t, scene_id)];
+    int rc = sa_tracker_idle_tracks(c, scene_id, out, cap, out_n);
+    return rc == SA_OK ? rc : group_fail(t, c, rc);
+  }
   wait_outstanding(t);
   flush_pending(t);
   // IdleLookup  sort.rs:213-228: same scene and last_updated_epoch != current epoch
@@ -1339,6 +1550,13 @@ int sa_tracker_idle_tracks(sa_tracker* t, uint64_t scene_id, sa_sort_track* out,
 
 int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n) {
   if (!t) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) {   // (the owner skips and wastes its own scenes; the auto-waste behind it reaches every scene of the tracker)
+    sa_tracker* c = t->shards[shard_of(t, scene_id)];
+    int rc = sa_tracker_skip_epochs(c, scene_id, n);
+    if (rc != SA_OK) return group_fail(t, c, rc);
+    group_auto_waste(t, c);
+    return SA_OK;
+  }
   wait_outstanding(t);
   flush_pending(t);
   scene_of(t, scene_id).epoch += n;  // skip_epochs_for_scene  epoch_db.rs:11-20
@@ -1347,6 +1565,7 @@ int sa_tracker_skip_epochs(sa_tracker* t, uint64_t scene_id, uint64_t n) {
 
 int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out) {
   if (!t || !out) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) return sa_tracker_current_epoch(t->shards[shard_of(t, scene_id)], scene_id, out);
   wait_outstanding(t);
   *out = current_epoch(t, scene_id);
   return SA_OK;
@@ -1354,6 +1573,22 @@ int sa_tracker_current_epoch(sa_tracker* t, uint64_t scene_id, uint64_t* out) {
 
 int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t* out_n) {
   if (!t || !out_n) return tfail(t, SA_ERR_BAD_ARG, "sa_tracker_wasted: null argument");
+  if (!t->shards.empty()) {   // every shard's wasted store, as one list by id
+    std::vector<sa_sort_track> all;
+    for (sa_tracker* c : t->shards) {
+      uint32_t nc = 0;
+      int rc = sa_tracker_wasted(c, nullptr, 0, &nc);   // (auto-wastes; nothing leaves the shard's store)
+      if (rc != SA_OK) return group_fail(t, c, rc);
+      all.insert(all.end(), c->wasted_store.begin(), c->wasted_store.end());
+    }
+    std::sort(all.begin(), all.end(), [](const sa_sort_track& a, const sa_sort_track& b) { return a.id < b.id; });
+    const uint32_t n = (uint32_t)all.size();
+    for (uint32_t i = 0; i < n && i < cap && out; ++i) out[i] = all[i];
+    *out_n = n;
+    if (out && cap >= n)
+      for (sa_tracker* c : t->shards) c->wasted_store.clear();
+    return SA_OK;
+  }
   wait_outstanding(t);
   flush_pending(t);
   int rc = auto_waste(t);
@@ -1368,6 +1603,7 @@ int sa_tracker_wasted(sa_tracker* t, sa_sort_track* out, uint32_t cap, uint32_t*
 
 int sa_tracker_clear_wasted(sa_tracker* t) {
   if (!t) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) { for (sa_tracker* c : t->shards) sa_tracker_clear_wasted(c); return SA_OK; }
   wait_outstanding(t);
   t->wasted_store.clear();
   return SA_OK;
@@ -1375,6 +1611,11 @@ int sa_tracker_clear_wasted(sa_tracker* t) {
 
 int sa_tracker_active_tracks(sa_tracker* t, uint64_t* out_n) {
   if (!t || !out_n) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) {
+    *out_n = 0;
+    for (sa_tracker* c : t->shards) { uint64_t k = 0; sa_tracker_active_tracks(c, &k); *out_n += k; }
+    return SA_OK;
+  }
   wait_outstanding(t);
   *out_n = t->n_active;
   return SA_OK;
@@ -1382,6 +1623,15 @@ int sa_tracker_active_tracks(sa_tracker* t, uint64_t* out_n) {
 
 int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, float* cov100) {
   if (!t) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) {   // (ids are the group's: exactly one shard knows the track)
+    for (sa_tracker* c : t->shards) {
+      wait_outstanding(c);
+      if (!find_track(c, track_id)) continue;
+      int rc = sa_tracker_track_state(c, track_id, mean10, cov100);
+      return rc == SA_OK ? rc : group_fail(t, c, rc);
+    }
+    return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  }
   wait_outstanding(t);
   Track* tr = find_track(t, track_id);
   if (!tr) return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
@@ -1398,6 +1648,15 @@ int sa_tracker_track_state(sa_tracker* t, uint64_t track_id, float* mean10, floa
 
 int sa_tracker_track_info(sa_tracker* t, uint64_t track_id, uint64_t out4[4]) {
   if (!t || !out4) return SA_ERR_BAD_ARG;
+  if (!t->shards.empty()) {
+    for (sa_tracker* c : t->shards) {
+      wait_outstanding(c);
+      if (!find_track(c, track_id)) continue;
+      int rc = sa_tracker_track_info(c, track_id, out4);
+      return rc == SA_OK ? rc : group_fail(t, c, rc);
+    }
+    return tfail(t, SA_ERR_NOT_FOUND, "unknown track id %llu", (unsigned long long)track_id);
+  }
   wait_outstanding(t);
   flush_pending(t);
   const Track* trp = find_track(t, track_id);

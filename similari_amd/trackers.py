@@ -318,7 +318,7 @@ class _Tracker:
 
 
 def sort_options(bbox_history, max_idle_epochs, method, min_confidence, constraints, pw, vw, batch=False, device=-1,
-                 device_upkeep=False, workers=0):
+                 device_upkeep=False, workers=0, devices=None, spin_us=-1):
     keep = abi.Keep()
     o = abi.sa_tracker_options()
     o.struct_size = C.sizeof(abi.sa_tracker_options)
@@ -341,12 +341,18 @@ def sort_options(bbox_history, max_idle_epochs, method, min_confidence, constrai
     o.kalman_velocity_weight = vw
     o.device_upkeep = 1 if device_upkeep else 0
     o.workers = workers
+    # devices = [ordinals]: one engine per entry, scenes dealt out scene_id % len(devices) (include/similari_tracker.h)
+    dv = keep.arr(list(devices), np.int32) if devices else None
+    o.n_devices = len(devices) if devices else 0
+    o.devices = abi._ptr(dv, C.c_int32)
+    o.spin_us = spin_us
     return o, keep
 
 
-def visual_options(opts: VisualSortOptions, feature_len: int, batch=False, device=-1, device_upkeep=False, workers=0):
+def visual_options(opts: VisualSortOptions, feature_len: int, batch=False, device=-1, device_upkeep=False, workers=0, devices=None, spin_us=-1):
     o, keep = sort_options(opts._kept_history_length, opts._max_idle_epochs, opts._positional_metric,
-                           opts._positional_min_confidence, opts._constraints, opts._pw, opts._vw, batch, device, device_upkeep, workers)
+                           opts._positional_min_confidence, opts._constraints, opts._pw, opts._vw, batch, device, device_upkeep, workers,
+                           devices, spin_us)
     o.visual = 1
     o.visual_kind = opts._visual_metric.kind
     o.visual_threshold = opts._visual_metric.threshold
@@ -368,11 +374,11 @@ class Sort(_Tracker):
 
     def __init__(self, shards=1, bbox_history=1, max_idle_epochs=5, method=None, min_confidence=0.05,
                  spatio_temporal_constraints=None, kalman_position_weight=1.0 / 20.0, kalman_velocity_weight=1.0 / 160.0,
-                 device=-1, _batch=False, device_upkeep=False, workers=0):
+                 device=-1, _batch=False, device_upkeep=False, workers=0, devices=None, spin_us=-1):
         assert bbox_history > 0
         o, keep = sort_options(bbox_history, max_idle_epochs, method or PositionalMetricType.iou(0.3), min_confidence,
                                spatio_temporal_constraints, kalman_position_weight, kalman_velocity_weight, _batch, device,
-                               device_upkeep, workers)
+                               device_upkeep, workers, devices, spin_us)
         super().__init__(o, keep)
 
 
@@ -380,8 +386,8 @@ class VisualSort(_Tracker):
     """VisualSort::new(shards, &VisualSortOptions); `feature_len` fixes the engine's feature dimension."""
 
     def __init__(self, shards=1, opts: Optional[VisualSortOptions] = None, feature_len: int = 0, device=-1, _batch=False,
-                 device_upkeep=False, workers=0):
-        o, keep = visual_options(opts or VisualSortOptions(), feature_len, _batch, device, device_upkeep, workers)
+                 device_upkeep=False, workers=0, devices=None, spin_us=-1):
+        o, keep = visual_options(opts or VisualSortOptions(), feature_len, _batch, device, device_upkeep, workers, devices, spin_us)
         super().__init__(o, keep)
 
 
@@ -450,9 +456,9 @@ class BatchSort(Sort):
 
 
 class BatchVisualSort(VisualSort):
-    def __init__(self, distance_shards=1, voting_shards=0, opts=None, feature_len=0, device=-1, device_upkeep=False):
+    def __init__(self, distance_shards=1, voting_shards=0, opts=None, feature_len=0, device=-1, device_upkeep=False, devices=None, spin_us=-1):
         super().__init__(shards=distance_shards, opts=opts, feature_len=feature_len, device=device, _batch=True,
-                         device_upkeep=device_upkeep, workers=voting_shards)
+                         device_upkeep=device_upkeep, workers=voting_shards, devices=devices, spin_us=spin_us)
 
     def predict(self, batch: PredictionBatchRequest):
         return self.predict_batch(batch)

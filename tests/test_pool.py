@@ -12,6 +12,7 @@ SRC = r"""
 #include "sa_pool.h"
 #include <cstdio>
 #include <set>
+#include <stdexcept>
 int main() {
   int allowed = 0;
   cpu_set_t set; CPU_ZERO(&set);
@@ -36,6 +37,21 @@ int main() {
     for (auto& h : hits) h = 0;
     a.run(jobs, [&](uint32_t i) { hits[i].fetch_add(1); });
     for (uint32_t i = 0; i < 64; ++i) if (hits[i] != (i < jobs ? 1 : 0)) { printf("BAD job %u of %u\n", i, jobs); return 1; }
+  }
+  // a job that throws: run() comes back (every worker has answered) and rethrows on the caller; the pool works afterwards
+  for (uint32_t bad : {0u, 1u, 5u}) {
+    bool caught = false;
+    try { a.run(8, [&](uint32_t i) { if (i == bad) throw std::runtime_error("job failed"); }); } catch (const std::runtime_error&) { caught = true; }
+    if (!caught) { printf("BAD exception of job %u lost\n", bad); return 1; }
+    for (auto& h : hits) h = 0;
+    a.run(8, [&](uint32_t i) { hits[i].fetch_add(1); });
+    for (uint32_t i = 0; i < 8; ++i) if (hits[i] != 1) { printf("BAD run after an exception\n"); return 1; }
+  }
+  SaPool lazy(2, true, 0);   // spin_us = 0: the workers sleep at once
+  for (int rep = 0; rep < 50; ++rep) {
+    for (auto& h : hits) h = 0;
+    lazy.run(6, [&](uint32_t i) { hits[i].fetch_add(1); });
+    for (uint32_t i = 0; i < 6; ++i) if (hits[i] != 1) { printf("BAD lazy pool\n"); return 1; }
   }
   printf("ok allowed=%d pinned=%d\n", allowed, (int)pinned);
   return 0;

@@ -23,9 +23,11 @@ def make(backend, kind, **kw):
     if kind == "sort":
         o, keep = TR.sort_options(kw.get("bbox_history", 10), kw.get("max_idle_epochs", 2), kw.get("method", IoU(0.3)),
                                   kw.get("min_confidence", 0.05), kw.get("constraints"), 1.0 / 20.0, 1.0 / 160.0,
-                                  batch=kw.get("batch", False), device_upkeep=dev)
+                                  batch=kw.get("batch", False), device_upkeep=dev, workers=kw.get("workers", 0),
+                                  devices=kw.get("devices"), spin_us=kw.get("spin_us", -1))
     else:
-        o, keep = TR.visual_options(kw["opts"], kw["feature_len"], batch=kw.get("batch", False), device_upkeep=dev)
+        o, keep = TR.visual_options(kw["opts"], kw["feature_len"], batch=kw.get("batch", False), device_upkeep=dev,
+                                    workers=kw.get("workers", 0), devices=kw.get("devices"), spin_us=kw.get("spin_us", -1))
     if backend == "oracle":
         return O.OracleTracker(o, keep)
     return TR._Tracker(o, keep)
@@ -626,7 +628,8 @@ def test_caller_may_overwrite_its_device_feature_block_once_predict_has_returned
 
 
 # ---- Batch*::predict over several scenes: one set of launches, the scenes' host work side by side ----------------------------------
-def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25), frames=8, d=64, bank=3, async_handle=False, reference="oracle"):
+def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25), frames=8, d=64, bank=3, async_handle=False, reference="oracle",
+                            **tracker_kw):
     """BatchVisualSort over several scenes of different sizes (visual_sort/batch_api.rs:213-317): every frame's tracks of every scene
     against the oracle tracker; with async_handle the request goes through sa_tracker_predict_batch_begin and the scenes are taken from
     the PredictionBatchResult handle in whatever order they finish."""
@@ -634,7 +637,7 @@ def run_batch_visual_scenes(backend, seed, scenes=(4, 9, 17), sizes=(40, 70, 25)
     opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.5))
             .positional_metric(IoU(0.3)).visual_minimal_track_length(min(2, bank)).visual_minimal_area(500.0)
             .visual_minimal_quality_use(0.4).visual_minimal_quality_collect(0.6).visual_max_observations(bank).visual_min_votes(1))
-    g = make(backend, "visual", opts=opts, feature_len=d, batch=True)
+    g = make(backend, "visual", opts=opts, feature_len=d, batch=True, **tracker_kw)
     o = make(reference, "visual", opts=opts, feature_len=d, batch=True)   # (the oracle tracker, or the facade's other upkeep path)
     try:
         ident = {s: synth.reid_identities(rng, n, d) for s, n in zip(scenes, sizes)}
@@ -768,6 +771,64 @@ def test_long_batch_run_device_upkeep_against_the_oracle_tracker_and_host_upkeep
         o.close()
 
 
+# ---- one tracker object over several devices (sa_tracker_options.n_devices / devices): sort/batch_api.rs:157-207 -------------------
+GROUPS = [pytest.param([0, 0], id="two_shards_one_gpu"), pytest.param([0, 0, 0, 0], id="four_shards_one_gpu")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", GROUPS)
+@pytest.mark.parametrize("async_handle", [False, True], ids=["sync", "handle"])
+def test_device_group_batch_visual_sort_matches_oracle(devices, async_handle):
+    """BatchVisualSort with device upkeep on a GROUP of engines (here: several engines on the one GPU of the box; scenes dealt out scene_id
+    % n, every shard's share through its own fused launches) against the oracle tracker: same ids — the id counter is the group's —, same
+    tracks, vote types, idle sets, track_info through the group."""
+    run_batch_visual_scenes("gpu_dev", seed=71, scenes=(4, 9, 17, 22, 31), sizes=(40, 70, 25, 33, 50), frames=10, devices=devices,
+                            async_handle=async_handle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", GROUPS)
+def test_device_group_churned_batch_sort_matches_oracle(devices):
+    """Five churned BatchSort scenes (evictions, wasted tracks) over a group of engines, against the oracle tracker."""
+    run_churned_batch_sort(workers=2, devices=devices)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gpu", "gpu_dev"], ids=["host_upkeep", "device_upkeep"])
+def test_device_group_with_sort_id_rules_hands_the_counter_from_scene_to_scene(backend):
+    """Sort (NOT Batch*) id rules on a group of three engines: an id per track that STARTS, so the counter a scene starts from depends on
+    the scenes before it — single-scene predicts and a multi-scene request both reproduce the oracle's ids; skip_epochs, wasted and
+    active_tracks reach every shard."""
+    rng = np.random.default_rng(5)
+    kw = dict(bbox_history=3, max_idle_epochs=1, method=IoU(0.3), min_confidence=0.05)
+    g, o = make(backend, "sort", devices=[0, 0, 0], **kw), make("oracle", "sort", **kw)
+    try:
+        scenes = (1, 2, 3, 7)
+        world = {s: synth.dense_boxes(rng, 30 + 5 * s, (900.0, 700.0)) for s in scenes}
+        for f in range(8):
+            for s in scenes:
+                world[s] = synth.jitter_boxes(rng, world[s], 2.0)
+                keep = rng.uniform(size=len(world[s])) > 0.15
+                det = [(bx, None) for bx in boxes_to_u2d(world[s][keep])]
+                assert_tracks_equal(g.predict_with_scene(s, det), o.predict_with_scene(s, det))
+            if f == 4:
+                g.skip_epochs_for_scene(2, 3)
+                o.skip_epochs_for_scene(2, 3)
+                assert g.current_epoch_with_scene(2) == o.current_epoch_with_scene(2)
+                assert sorted(x.id for x in g.wasted()) == sorted(x.id for x in o.wasted())
+        req = TR.PredictionBatchRequest()
+        for s in scenes:
+            for bx in boxes_to_u2d(synth.jitter_boxes(rng, world[s], 2.0)):
+                req.add(s, (bx, None))
+        rg, ro = g.predict_batch(req), o.predict_batch(req)
+        for s in scenes:
+            assert_tracks_equal(rg[s], ro[s])
+        assert g.active_tracks() == o.active_tracks()
+    finally:
+        g.close()
+        o.close()
+
+
 @pytest.mark.gpu
 def test_batch_result_handle_survives_the_next_call_and_reused_request_arrays():
     """The request is taken by value: the caller's observation arrays are overwritten right after _begin returns, the next predict() is
@@ -842,10 +903,15 @@ def test_batch_sort_scenes_with_churn_and_eviction_match_oracle(workers):
     """Five scenes of 220 objects, ~18 % of them replaced every frame: the facade evicts expired rows from SEVERAL scenes' tables inside one
     predict() (the removals are queued one behind the other), with the scenes' bookkeeping spread over a pool of threads — every frame's
     tracks of every scene against the oracle tracker."""
+    run_churned_batch_sort(workers=workers)
+
+
+def run_churned_batch_sort(**tracker_kw):
     rng = np.random.default_rng(909)
     scenes, n = (2, 3, 5, 7, 11), 220
-    o_, keep_ = TR.sort_options(3, 2, IoU(0.3), 0.05, None, 1.0 / 20.0, 1.0 / 160.0, batch=True, device_upkeep=True, workers=workers)
+    o_, keep_ = TR.sort_options(3, 2, IoU(0.3), 0.05, None, 1.0 / 20.0, 1.0 / 160.0, batch=True, device_upkeep=True, **tracker_kw)
     g = TR._Tracker(o_, keep_)
+    group = len(tracker_kw.get("devices") or []) > 1
     o = make("oracle", "sort", bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
     try:
         pool = n + 14 * 40
@@ -867,7 +933,10 @@ def test_batch_sort_scenes_with_churn_and_eviction_match_oracle(workers):
             for s in scenes:
                 assert_tracks_equal(rg[s], ro[s])
                 cnt = C.c_uint32()
-                g.lib.sa_tracks_count(g.lib.sa_tracker_engine(g.h), s, C.byref(cnt))
+                if group:   # (sa_tracker_engine hands out a group's FIRST engine: the scene may live on another)
+                    cnt.value = n + 1
+                else:
+                    g.lib.sa_tracks_count(g.lib.sa_tracker_engine(g.h), s, C.byref(cnt))
                 max_rows = max(max_rows, int(cnt.value))
                 assert cnt.value < n + 6 * 40
             if f % 5 == 4:
