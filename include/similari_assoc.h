@@ -197,6 +197,7 @@ int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene
  * along with its own scenes).  Nothing else may be called on the engine between a stage and its commit. */
 int sa_tracks_remove_stage(sa_engine* e, uint64_t scene_id, uint32_t n, const uint64_t* ids);
 int sa_tracks_remove_commit(sa_engine* e);
+int sa_tracks_remove_abort(sa_engine* e);  /* forget every staged removal: no table changes (error paths between stage and commit) */
 int sa_tracks_count(sa_engine* e, uint64_t scene_id, uint32_t* out_n);
 /* Column order of the scene's track table (= column order of every matrix tap below). */
 int sa_tracks_order(sa_engine* e, uint64_t scene_id, uint64_t* out_ids, uint32_t cap, uint32_t* out_n);

@@ -376,6 +376,7 @@ PROTOTYPES = {
     "sa_tracks_remove_many": (C.c_int, [ENGINE, u32, P(u64), P(u32), P(P(u64))]),
     "sa_tracks_remove_stage": (C.c_int, [ENGINE, u64, u32, P(u64)]),
     "sa_tracks_remove_commit": (C.c_int, [ENGINE]),
+    "sa_tracks_remove_abort": (C.c_int, [ENGINE]),
     "sa_tracks_count": (C.c_int, [ENGINE, u64, P(u32)]),
     "sa_tracks_order": (C.c_int, [ENGINE, u64, P(u64), u32, P(u32)]),
     "sa_associate": (C.c_int, [ENGINE, u64, u64, P(sa_detections), P(u64), P(C.c_uint8)]),
@@ -476,7 +477,34 @@ def hip_runtimes_mapped() -> list[str]:
     return seen
 
 
-def share_torchs_hip_runtime() -> str | None:
+def _elf_dynamic_strings(path, tags=(1, 14)):
+    """DT_NEEDED (1) / DT_SONAME (14) strings of a 64-bit little-endian ELF file: {tag: [strings]} ({} when it cannot be read)."""
+    import struct
+
+    out = {t: [] for t in tags}
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+            return {}
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        for sec in secs:
+            if sec[1] != 6:   # SHT_DYNAMIC
+                continue
+            strtab = secs[sec[6]]
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                tag, val = struct.unpack_from("<qQ", data, off)
+                if tag in out:
+                    end = data.index(b"\0", strtab[4] + val)
+                    out[tag].append(data[strtab[4] + val:end].decode())
+    except Exception:
+        return {}
+    return out
+
+
+def share_torchs_hip_runtime(lib_path=None) -> str | None:
     """ONE HIP runtime per process.  A PyTorch-ROCm wheel ships a libamdhip64 of its own and its libraries ask for it by FILE name
     ("libamdhip64.so"), this library asks for the SONAME ("libamdhip64.so.7"): with torch loaded first the loader hands torch's copy to
     both; with this library loaded first it takes /opt/rocm's and torch then loads its own beside it — and the second runtime to start
@@ -497,6 +525,18 @@ def share_torchs_hip_runtime() -> str | None:
     cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
     if not cand.exists():
         return None
+    # Only a runtime of the SAME SONAME as the one libsimilari_assoc.so was linked against may stand in for it: a wheel built against
+    # another ROCm major would have this library's gfx950 code objects registered with a runtime it was not built for (SA_HIP_RUNTIME=torch
+    # forces the wheel's copy all the same).
+    if os.environ.get("SA_HIP_RUNTIME", "") != "torch" and lib_path is not None:
+        need = [n for n in _elf_dynamic_strings(lib_path).get(1, []) if n.startswith("libamdhip64.so")]
+        have = _elf_dynamic_strings(cand).get(14, [])
+        if need and have and need[0] != have[0]:
+            import warnings
+
+            warnings.warn(f"similari_amd: torch ships {have[0]} but libsimilari_assoc.so needs {need[0]}: the system's HIP runtime is used; "
+                          "torch's GPU side cannot be started in this process afterwards (SA_HIP_RUNTIME=torch to share torch's copy)")
+            return None
     C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
     return str(cand)
 
@@ -509,8 +549,13 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
             f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback."
         )
-    share_torchs_hip_runtime()
+    share_torchs_hip_runtime(p)
     lib = C.CDLL(str(p))
+    if len(hip_runtimes_mapped()) > 1:
+        import warnings
+
+        warnings.warn("similari_amd: more than one HIP runtime is mapped into this process (" + ", ".join(sorted(hip_runtimes_mapped())) +
+                      "): the one that starts second will not see the GPUs")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = res

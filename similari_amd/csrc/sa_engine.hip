@@ -51,7 +51,8 @@ struct alignas(128) SceneTable {   // (aligned: the tracker facade works on diff
   DevBuf spare[SA_TABLE_ARRAYS];                   // sa_tracks_remove compacts the table into these and swaps (no allocation per call)
   HostBuf h_index;                                 // ... the kept rows' old indices (mapped pinned memory the gather kernel reads in place)
   void* d_index = nullptr;
-  uint64_t in_set = 0;                             // stamp of the request set the scene was last added to (bank_add)
+  uint64_t in_set[4] = {0, 0, 0, 0};               // per bank: stamp of the request set of THAT bank the scene was last added to (bank_add) — a scene
+                                                   // staged into another bank in between must not hide a duplicate in this one
   bool staged = false;                             // sa_tracks_remove_stage has filled h_index; sa_tracks_remove_commit queues the gather
   uint32_t staged_rows = 0;                        // ... rows that stay
   uint64_t index_drain = ~0ull;                    // sa_engine::drain_count when the last gather that reads h_index was queued (~0: none): the
@@ -1452,6 +1453,14 @@ int sa_tracks_remove_stage(sa_engine* e, uint64_t scene_id, uint32_t n, const ui
   if (!n) return SA_OK;
   return remove_stage(e, sc, n, ids, false);
 }
+// Nothing of what was staged is queued: every scene's table stays as it is (a caller whose OTHER scenes failed to stage, or that gives the
+// request set up, calls this — a scene left staged would make the next sa_tracks_remove_many commit a stale row list).
+int sa_tracks_remove_abort(sa_engine* e) {
+  if (!e) return SA_ERR_BAD_ARG;
+  e->n_staged.store(0, std::memory_order_relaxed);
+  for (auto& kv : e->scenes) { kv.second->staged = false; kv.second->staged_rows = 0; }
+  return SA_OK;
+}
 int sa_tracks_remove_commit(sa_engine* e) {
   if (!e) return SA_ERR_BAD_ARG;
   if (!e->n_staged.load(std::memory_order_relaxed)) return SA_OK;
@@ -1505,8 +1514,10 @@ int sa_tracks_remove_many(sa_engine* e, uint32_t n_scenes, const uint64_t* scene
   size_t k = 0;
   for (uint32_t i = 0; i < n_scenes; ++i) {   // every scene's host side first: a failure here leaves every table as it was
     if (!counts[i]) continue;
-    int rc = scs[k]->staged ? SA_OK : remove_stage(e, scs[k], counts[i], ids[i], true);
-    if (rc != SA_OK) { for (SceneTable* sc : scs) sc->staged = false; return rc; }
+    // (a scene staged earlier is staged AGAIN from the ids given here: what an aborted call left behind must not be committed)
+    scs[k]->staged = false;
+    int rc = remove_stage(e, scs[k], counts[i], ids[i], true);
+    if (rc != SA_OK) { sa_tracks_remove_abort(e); return rc; }
     ++k;
   }
   return sa_tracks_remove_commit(e);
@@ -1667,8 +1678,8 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   const uint32_t N = d->n;
   SceneTable* sc = get_scene(e, scene_id, true);
   // (a scene once per request set: the set's stamp on the scene instead of a walk over the slots — Batch* trackers stage dozens per call)
-  if (sc->in_set == b->set_stamp) return fail(e, SA_ERR_STATE, "scene %llu is already part of this batch", (unsigned long long)scene_id);
-  sc->in_set = b->set_stamp;
+  const size_t bi = (size_t)(b - &e->banks[0]) & 3u;
+  if (sc->in_set[bi] == b->set_stamp) return fail(e, SA_ERR_STATE, "scene %llu is already part of this batch", (unsigned long long)scene_id);
   Slot* s = get_slot(b, b->n_slots);
   if (s->ran && s->h_out.p && e->cfg.visual_kind == SA_VIS_EUCLIDEAN) {
     // what the slot's previous frame reported (the bank is idle: that frame has retired)
@@ -1712,6 +1723,7 @@ static int bank_add(sa_engine* e, Bank* b, uint64_t scene_id, uint64_t epoch, co
   b->uploaded = false;
   if (out_slot) *out_slot = b->n_slots;
   b->n_slots++;
+  sc->in_set[bi] = b->set_stamp;   // (only now: an add that failed above has added nothing, and may be retried in the same set)
   return defer ? SA_OK : slot_fill(e, b, s, false);
 }
 

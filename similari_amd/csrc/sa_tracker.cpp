@@ -639,7 +639,11 @@ int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint
     if (ss[s].evict_ids.empty()) continue;
     any = true;
     if (staged && ss[s].evict_rc == SA_OK) continue;
-    if (staged && ss[s].evict_rc != SA_ERR_STATE) return tfail(t, ss[s].evict_rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
+    if (staged && ss[s].evict_rc != SA_ERR_STATE) {
+      const int rc = tfail(t, ss[s].evict_rc, "sa_tracks_remove: %s", sa_last_error(t->eng));
+      sa_tracks_remove_abort(t->eng);   // (the other scenes' staged removals with it: none of them is committed, every table stays as it is)
+      return rc;
+    }
     scene_ids.push_back(ss[s].st->id);
     counts.push_back((uint32_t)ss[s].evict_ids.size());
     lists.push_back(ss[s].evict_ids.data());
@@ -647,7 +651,7 @@ int evict_expired(sa_tracker* t, std::vector<sa_tracker::SceneScratch>& ss, uint
   if (!any) return SA_OK;
   int rce = scene_ids.empty() ? sa_tracks_remove_commit(t->eng)
                               : sa_tracks_remove_many(t->eng, (uint32_t)scene_ids.size(), scene_ids.data(), counts.data(), lists.data());   // (commits what was staged as well)
-  if (rce != SA_OK) return tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng));
+  if (rce != SA_OK) { const int rc = tfail(t, rce, "sa_tracks_remove: %s", sa_last_error(t->eng)); sa_tracks_remove_abort(t->eng); return rc; }
   if (commit_rows)
     for (uint32_t s = 0; s < n_scenes; ++s) evict_commit(t->o, ss[s]);
   return SA_OK;
