@@ -1,4 +1,4 @@
-"""Probe of the k-split main loop (gemm plans 9-12) through sa_feature_distance_matrix: answers against an f64 reference, then
+"""Probe of the k-split main loop (gemm plans 9, 10, 13) through sa_feature_distance_matrix: answers against an f64 reference, then
 microseconds per launch next to the staged plans on the C2 family of shapes."""
 import sys, json
 from pathlib import Path
@@ -7,7 +7,7 @@ import numpy as np
 from similari_amd import abi
 from similari_amd.engine import Engine
 
-plans = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,7,9,10,11,12".split(","))]
+plans = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,7,9,10,13".split(","))]
 rng = np.random.default_rng(0)
 for (n, t, d) in [(300, 333, 512), (129, 70, 96), (64, 64, 32), (1000, 1000, 512)]:
     a = rng.standard_normal((n, d)).astype(np.float32)

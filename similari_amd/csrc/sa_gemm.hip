@@ -1633,7 +1633,8 @@ __global__ __launch_bounds__(256 * (KGT >= 9 ? 1 : KGT ? KGT : 1)) void k_cosine
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
   constexpr int TM = BM / 64, TN = BN / 64;
-  // KGT >= 9: the k-split main loop (gemm_mainloop_ks): 9 / 10 = B row-major / in fragment order, four register buffers; 11 / 12 = six
+  // KGT >= 9: the k-split main loop (gemm_mainloop_ks): 9 / 10 = B row-major / in fragment order, 13 = A in fragment order as well (the
+  // stand-alone matrix entry point's measurement plans: sa_feature_distance_matrix reorders the operands it is asked to)
   constexpr bool KS = KGT >= 9 && KGT != 15;   // 15: the direct loop of the wider tiles (gemm_mainloop_direct)
   constexpr int KG = KGT >= 9 ? 1 : KGT ? KGT : 1;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
@@ -1641,7 +1642,7 @@ __global__ __launch_bounds__(256 * (KGT >= 9 ? 1 : KGT ? KGT : 1)) void k_cosine
   __shared__ __attribute__((aligned(16))) float lds[KGT == 15 ? 64 : (KGT ? KG * 2 : 3) * (BM + BN) * BK];
   f32x16 acc[TM][TN];
   if constexpr (KGT == 15) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, acc, tr);
-  else if constexpr (KS) gemm_mainloop_ks<(KGT == 11 || KGT == 12 || KGT == 14 ? 6 : 4), false, (KGT == 10 || KGT >= 12), (KGT >= 13)>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc[0][0], tr);
+  else if constexpr (KS) gemm_mainloop_ks<4, false, (KGT == 10 || KGT == 13), (KGT == 13)>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc[0][0], tr);
   else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = tid >> 8;
@@ -1941,16 +1942,13 @@ hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, 
       case 6: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 4: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 4>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(1024), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 2: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 2>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(512), 0, st, a, an, b, bn, n, t, dp, out); break;
-      // k-split plans (b = the bank in fragment order for 10 / 12: sa_launch_frag_reorder)
+      // k-split plans (b = the bank in fragment order for 10 / 13: sa_launch_frag_reorder; 13: a as well)
       case 9: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 9>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 10: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 10>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
-      case 11: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 11>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
-      case 12: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 12>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 15: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 16: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 17: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 15>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 13: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 13>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
-      case 14: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 14>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
     }
   } else {
