@@ -8,7 +8,7 @@ TAG=${1:-r05_z}; O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
 (rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6; nproc) > $O/env.txt 2>&1
 # 1. kernel stats: the DEFAULT command first (the driver's line), then the other workloads
-for w in c2 c2b c2t c5 c4 c3 c2k3 sdt; do
+for w in c2 c2b c2t c2e c5 c4 c3 c2k3 sdt; do
   extra="--workload $w --no-cpu-baseline --no-oracle --no-h2d"; [ "$w" = "c2" ] && extra="--no-cpu-baseline --no-oracle --no-h2d"
   steps="--steps 50 --warmup 5"; [ "$w" = "c5" ] && steps="--steps 10 --warmup 2 --profile-iters 5"; [ "$w" = "c2b" ] && steps="--steps 20 --warmup 3 --profile-iters 10"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o bench -- python $OLDPWD/bench.py $steps $extra > $O/prof_$w.log 2>&1)
