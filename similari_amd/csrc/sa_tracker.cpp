@@ -1177,6 +1177,14 @@ int group_begin(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, con
     for (uint32_t s2 = 0; s2 < s; ++s2)
       if (scene_ids[s] == scene_ids[s2]) return tfail(t, SA_ERR_BAD_ARG, "scene %llu appears twice in one batch", (unsigned long long)scene_ids[s]);
   }
+  // every box of the request is checked BEFORE any shard is begun (the reference asserts on its input before it touches the store): a bad
+  // observation in one shard's scene must not leave the other shards a frame ahead
+  for (uint32_t s = 0; s < n_scenes; ++s)
+    for (uint32_t i = 0; i < counts[s]; ++i) {
+      const sa_box& bb = obs[s][i].bbox;
+      if (!(bb.aspect > 0.0f) || !(bb.height > 0.0f) || !(bb.confidence >= 0.0f && bb.confidence <= 1.0f))
+        return tfail(t, SA_ERR_BAD_ARG, "observation %u of scene %llu: bad box", i, (unsigned long long)scene_ids[s]);
+    }
   // the auto-waste cadence is the GROUP's (one counter per tracker object, simple_api.rs:115-120): a shard never wastes on its own count
   if (t->waste_counter == 0) {
     group_auto_waste(t);

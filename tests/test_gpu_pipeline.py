@@ -76,13 +76,16 @@ def test_batch_time_replays_the_staged_set():
 
 
 @pytest.mark.paths("signal_completion")   # (the completion SIGNAL of the last dispatch instead of the scenes' completion words)
+@pytest.mark.parametrize("poll_spin_us", [0, -1, 1], ids=["poll_default", "block_at_once", "poll_1us_then_block"])
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned_block"])
-def test_pipelined_tickets_match_the_synchronous_path(pinned):
+def test_pipelined_tickets_match_the_synchronous_path(pinned, poll_spin_us):
     """A stream of different frames through sa_pipe_submit / sa_pipe_wait with two (then three) tickets in flight: every frame's answer equals
-    the oracle's (and therefore sa_associate's); features from pageable memory or DMA'd in place from sa_host_alloc blocks."""
+    the oracle's (and therefore sa_associate's); features from pageable memory or DMA'd in place from sa_host_alloc blocks.  The wait for a
+    set's completion words polls for sa_config.poll_spin_us and then blocks on the stream: the default, blocking at once (-1), and a 1 us
+    budget that runs out on nearly every frame."""
     rng = np.random.default_rng(73)
     d, n, t = 128, 150, 170
-    cfg = visual_cfg(d)
+    cfg = visual_cfg(d, poll_spin_us=poll_spin_us)
     sc = synth.visual_scene(rng, t, n, d, 1, canvas=(1500.0, 900.0), new_fraction=0.1)
     eng = Engine(cfg)
     blocks = []

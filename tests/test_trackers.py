@@ -830,6 +830,50 @@ def test_device_group_with_sort_id_rules_hands_the_counter_from_scene_to_scene(b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("async_handle", [False, True], ids=["sync", "handle"])
+def test_batch_trackers_with_no_idle_polling_match_the_oracle(async_handle):
+    """Host manners: spin_us = 0 (no thread of the tracker polls while idle: the pool's workers, the result driver and a caller inside
+    get() sleep at once) and workers = -4 (four threads left to the scheduler, no CPU claimed): the three-scene BatchVisualSort sequence
+    and the churned five-scene BatchSort loop against the oracle tracker, as with the defaults."""
+    run_batch_visual_scenes("gpu_dev", seed=73, frames=8, async_handle=async_handle, spin_us=0, workers=-4)
+    run_churned_batch_sort(workers=-4, spin_us=0)
+
+
+@pytest.mark.gpu
+def test_device_group_refuses_a_bad_request_before_any_shard_has_begun():
+    """A bad box in ONE shard's scene fails the whole call and no shard has moved: epochs, ids and track counts are those of a tracker
+    that never saw the request; the next good request gives the oracle's tracks."""
+    rng = np.random.default_rng(9)
+    kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05, batch=True)
+    g, o = make("gpu_dev", "sort", devices=[0, 0], **kw), make("oracle", "sort", **kw)
+    try:
+        world = {s: synth.dense_boxes(rng, 20, (600.0, 400.0)) for s in (2, 3)}
+        def request(bad=False):
+            req = TR.PredictionBatchRequest()
+            for s in (2, 3):
+                for k, bx in enumerate(boxes_to_u2d(world[s])):
+                    if bad and s == 3 and k == 7:
+                        bx = TR.Universal2DBox(bx.xc, bx.yc, None, -1.0, bx.height, bx.confidence)   # aspect <= 0
+                    req.add(s, (bx, None))
+            return req
+        rg, ro = g.predict_batch(request()), o.predict_batch(request())
+        for s in (2, 3):
+            assert_tracks_equal(rg[s], ro[s])
+        with pytest.raises(TR.TrackerError):
+            g.predict_batch(request(bad=True))
+        assert g.active_tracks() == o.active_tracks() == 40
+        assert g.current_epoch_with_scene(2) == o.current_epoch_with_scene(2) == 1
+        for s in (2, 3):
+            world[s] = synth.jitter_boxes(rng, world[s], 1.5)
+        rg, ro = g.predict_batch(request()), o.predict_batch(request())
+        for s in (2, 3):
+            assert_tracks_equal(rg[s], ro[s])
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
 def test_batch_result_handle_survives_the_next_call_and_reused_request_arrays():
     """The request is taken by value: the caller's observation arrays are overwritten right after _begin returns, the next predict() is
     issued before the handle has been read (it waits for the set in flight — the reference's busy monitor), and the handle still
