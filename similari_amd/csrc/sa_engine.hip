@@ -2828,7 +2828,7 @@ int sa_feature_distance_matrix(sa_engine* e, int32_t kind, uint32_t n, uint32_t 
     if (sa_launch_pad_features((const float*)ra.p, n, d, d8, 1, nullptr, nullptr, (float*)pa.p, (float*)na.p, nullptr, nullptr, st) != hipSuccess ||
         sa_launch_pad_features((const float*)rb.p, t, d, d8, 1, nullptr, nullptr, (float*)pb.p, (float*)nb.p, nullptr, nullptr, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "pad launch failed"); break; }
     // the k-split plans 10 / 12 read the B operand in fragment order (sa_gemm.hip: sa_frag_index)
-    if (kind == SA_VIS_COSINE && (e->P.gemm_plan == 10 || (e->P.gemm_plan >= 15 && e->P.gemm_plan <= 17))) {
+    if (kind == SA_VIS_COSINE && (e->P.gemm_plan == 10 || (e->P.gemm_plan >= 15 && e->P.gemm_plan <= 18))) {
       if (dev_ensure(e, rb, (size_t)((t + 31u) / 32u * 32u) * d8 * 4) != SA_OK) { rc = SA_ERR_HIP; break; }
       if (sa_launch_frag_reorder((const float*)pb.p, t, d8, (float*)rb.p, st) != hipSuccess) { rc = fail(e, SA_ERR_HIP, "reorder launch failed"); break; }
       std::swap(pb, rb);

@@ -582,6 +582,81 @@ __device__ __forceinline__ void gemm_mainloop_ks(gfloat_p A, gfloat_p B, uint32_
   __syncthreads();  // the epilogue reuses this LDS
 }
 
+// The k-split loop for the 64 x 128 tile: wave (wm, kg) owns tile rows wm 32 .. +31, ALL 128 columns (four accumulators) and every second
+// 8-deep k-step — one row-major gather of A and four fragment-order loads of B per 16 matrix instructions (the direct loop's 32 x 64 wave
+// tiles: 6 per 16, and every fragment loaded by two waves), nothing loaded twice.  Wave (wm, x) keeps columns x 64 .. +63 and ships its other
+// two accumulators to wave (wm, 1 - x) through LDS (8 KB per wave): it leaves with acc[0][0..1] as the 2 x 2 wave layout of the epilogues has them.
+template <int NBUF>
+__device__ __forceinline__ void gemm_mainloop_ks128(gfloat_p A, gfloat_p B, uint32_t M, uint32_t Ncols, uint32_t Dp, uint32_t m0,
+                                                    uint32_t n0, float* lds, f32x16 (&out)[1][2], uint64_t* tr = nullptr) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) & 3u;
+  const uint32_t wm = w4 >> 1, kg = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  const uint32_t Np = (Ncols + 31u) / 32u * 32u, nb0 = n0 & ~31u;
+  auto left = [&](uint32_t rows) { const uint64_t b = (uint64_t)rows * Dp * 4u; return (uint32_t)(b < 0xffffffffull ? b : 0xffffffffull); };
+  const __amdgpu_buffer_rsrc_t RA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * Dp), 0, (int)left(M - m0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t RB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)nb0 * Dp), 0, (int)left(Np - nb0), 0x00020000);
+  const uint32_t oa = ((wm * 32u + lr) * Dp + lh * 4u) * 4u;
+  uint32_t ob[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const uint32_t rr = (n0 - nb0) + n * 32u + lr;
+    ob[n] = ((rr >> 5) * (Dp >> 3) * 256u + lh * 128u + (rr & 31u) * 4u) * 4u;
+  }
+  const uint32_t mine = Dp >> 4;
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+  f32x4 fa[NBUF], fb[NBUF][4];
+  auto load = [&](auto buf_tag, uint32_t j) {
+    constexpr int buf = decltype(buf_tag)::value;
+    const uint32_t s = 2u * j + kg;
+    fa[buf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, (int)oa, (int)(s * 32u), 0));
+#pragma unroll
+    for (int n = 0; n < 4; ++n) fb[buf][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RB, (int)ob[n], (int)(s * 1024u), 0));
+  };
+  auto step = [&](auto b_tag, uint32_t j) {
+    constexpr int b = decltype(b_tag)::value;
+    load(std::integral_constant<int, (b + NBUF - 1) % NBUF>{}, j + NBUF - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[b][e], fb[b][n][e], acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    sa_static_for<0, 4>([&](auto) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); });
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  };
+  sa_static_for<0, NBUF - 1>([&](auto b) { load(b, (uint32_t)decltype(b)::value); __builtin_amdgcn_sched_barrier(0); });
+  SA_STAMP(tr, 1);
+  uint32_t j = 0;
+  for (; j + NBUF <= mine; j += NBUF) sa_static_for<0, NBUF>([&](auto b) { step(b, j + decltype(b)::value); });
+  const uint32_t rem = mine - j;
+  sa_static_for<0, NBUF>([&](auto b) { if ((uint32_t)decltype(b)::value < rem) step(b, j + decltype(b)::value); });
+  SA_STAMP(tr, 2);
+  f32x4* red = (f32x4*)lds;   // [4 waves][2 accumulators][4][64 lanes] f32x4 = 32 KB
+  auto ship = [&](const f32x16& a, uint32_t slot) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[((w4 * 2u + slot) * 4u + g) * 64u + lane] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+  };
+  if (kg == 0) { ship(acc[2], 0); ship(acc[3], 1); } else { ship(acc[0], 0); ship(acc[1], 1); }
+  __syncthreads();
+  const uint32_t pw = w4 ^ 1u;
+  auto take = [&](const f32x16& mine_, uint32_t slot, f32x16& dst, bool mine_first) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = red[((pw * 2u + slot) * 4u + g) * 64u + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[4 * g + c] = mine_first ? mine_[4 * g + c] + o[c] : o[c] + mine_[4 * g + c];
+    }
+  };
+  // (k-half 0 + k-half 1 whichever wave adds)
+  if (kg == 0) { take(acc[0], 0, out[0][0], true); take(acc[1], 1, out[0][1], true); }
+  else { take(acc[2], 0, out[0][0], false); take(acc[3], 1, out[0][1], false); }
+  __syncthreads();
+}
+
 // The same idea for the wider tiles (128x128, 64x128, 128x64: 2 x 2 waves, each a (BM/2) x (BN/2) wave tile over the WHOLE k range): operands
 // straight from memory — A row-major, B from the bank's fragment-order twin — TM + TN buffer loads per 8-deep k-step for 4 TM TN matrix
 // instructions, no LDS stage, no barrier, no reduction.  The two waves of a wave row (column) load the same A (B) fragments: twice the
@@ -775,11 +850,12 @@ __device__ __forceinline__ float visual_cell(const SaParams& p, float dot, float
 // differ by < 6e-8, four hundred times below the 1e-5 the feature distances themselves are good for.  One launch
 // (k_bestfit_tile) and the write + re-read of the matrix disappear; the parity taps re-run the contraction with PART = false.
 // LDS floats a contraction tile needs.  KGT: 1 / 2 / 4 = staged loop with that many k-groups (two stages each), 0 = ring (three stages),
-// 9 = k-split loop (64 x 64: the quadrant exchange), 15 = direct loop (wider tiles: no LDS in the main loop) — and, for every loop, what the
+// 9 = k-split loop (64 x 64: the quadrant exchange), 15 = direct loop (wider tiles: no LDS in the main loop), 17 = k-split loop of the 64 x 128
+// tile (32 KB exchange) — and, for every loop, what the
 // fused epilogue lays out in the same buffer afterwards: row operands, PART / EU: column minima + a 64-row key tile, EU: flag words + list.
 constexpr uint32_t gemm_lds_floats(int BM, int BN, int KGT, bool PART, bool EU) {
-  const int KG = (KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1;
-  const uint32_t loop = KGT == 15 ? 0u : KGT == 9 ? 4u * 4u * 64u * 4u + 4u * 32u : (uint32_t)((KGT ? KG * 2 : 3) * (BM + BN) * BK);
+  const int KG = (KGT == 9 || KGT == 15 || KGT == 17) ? 1 : KGT ? KGT : 1;
+  const uint32_t loop = KGT == 15 ? 0u : KGT == 17 ? 8192u : KGT == 9 ? 4u * 4u * 64u * 4u + 4u * 32u : (uint32_t)((KGT ? KG * 2 : 3) * (BM + BN) * BK);
   const uint32_t epi = (uint32_t)((6 + KG) * BM + 2 * BN + ((PART || EU) ? 64 * (BN + 4) : 0) + (EU ? 64 * (BN / 32) + 256 : 0));
   uint32_t m = loop > epi ? loop : epi;
   // the direct loop's 64 x 128 tile (85 VGPRs: four blocks per CU by registers) is held to THREE blocks per CU by its LDS footprint: measured at
@@ -791,7 +867,9 @@ template <int BM, int BN, int KGT, bool RAW, bool PART, bool EU = false>
 __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
   constexpr bool KSPLIT = KGT == 9;      // KGT == 9: the k-split main loop (gemm_mainloop_ks: the bank read in fragment order, no LDS stage)
   constexpr bool DIRECT = KGT == 15;     // KGT == 15: the direct main loop of the wider tiles (gemm_mainloop_direct)
-  constexpr int KG = (KSPLIT || DIRECT) ? 1 : KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
+  constexpr bool KS128 = KGT == 17;      // KGT == 17: the k-split main loop of the 64 x 128 tile (gemm_mainloop_ks128)
+  static_assert(!KS128 || (BM == 64 && BN == 128 && !RAW), "k-split 64 x 128");
+  constexpr int KG = (KSPLIT || DIRECT || KS128) ? 1 : KGT ? KGT : 1;  // KGT == 0: ring main loop (one k-group, 3 LDS stages)
   uint64_t* tr = SA_TRACE_PTR();
   SA_STAMP(tr, 0);
   const uint32_t N = S.N, TK = S.TK, K = S.K;
@@ -802,7 +880,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   static_assert(!RAW || (TM == 1 && TN == 1 && KGT != 0), "raw mode: 64x64 tiles with k-groups");
   static_assert(!KSPLIT || (TM == 1 && TN == 1), "k-split: 64x64 tiles");
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = (KSPLIT || DIRECT) ? 0u : tid >> 8;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u, kg = (KSPLIT || DIRECT || KS128) ? 0u : tid >> 8;
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   // The epilogue's per-row / per-column operands are fetched BEFORE the contraction: their L2/HBM latency (a chain of
   // dependent loads that used to sit, fully exposed, between the last MFMA and the first store: ~2 us of a 18 us kernel at
@@ -861,6 +939,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   f32x16 acc[TM][TN];
   float nsq = 0.f;
   if constexpr (KSPLIT) gemm_mainloop_ks<4, RAW, true>((gfloat_p)(RAW ? S.c_feat_raw : (const float SA_G*)S.c_feat), (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc[0][0], tr, &nsq, RAW ? p.ks_yield : 0u);
+  else if constexpr (KS128) gemm_mainloop_ks128<3>((gfloat_p)S.c_feat, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc, tr);
   else if constexpr (DIRECT) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)S.c_feat, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, acc, tr);
   else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
   else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
@@ -1323,7 +1402,7 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
 // (Tile order: row by row.  An XCD-aware band order — each XCD's L2 keeping one set of candidate panels — was measured at C5 with bands
 // of 1, 2 and 4 tile rows: no difference, the 114 MB working set sits in the 256 MB Infinity Cache and the fabric keeps up.)
 template <int BM, int BN, int KGT, bool PART = false, bool EU = false>
-__global__ __launch_bounds__(256 * ((KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1), (KGT == 15 && BM == 128 && BN == 128) ? 2 : 1) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
+__global__ __launch_bounds__(256 * ((KGT == 9 || KGT == 15 || KGT == 17) ? 1 : KGT ? KGT : 1), (KGT == 15 && BM == 128 && BN == 128) ? 2 : 1) void k_visual_cosine(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                                           uint32_t xo_) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats(BM, BN, KGT, PART, EU)];
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -1336,7 +1415,7 @@ template <int BM, int BN, int KGT, bool PART, bool EU>
 static void launch_cosine(uint32_t maxTK, uint32_t maxN, uint32_t ns, hipStream_t st, const SceneDev* scenes, const SaParams& p) {
   const uint32_t gx = cdiv(maxTK, BN), gy = cdiv(maxN, BM);
   const XcdOrder xo = xcd_order(gx, gy, p.row_major_tiles != 0);
-  SA_LAUNCH((k_visual_cosine<BM, BN, KGT, PART, EU>), dim3(xo.W ? 8u * xo.chunk : xo.chunk, 1, ns), dim3(256 * ((KGT == 9 || KGT == 15) ? 1 : KGT ? KGT : 1)), 0, st, scenes, p, gx, gy, (xo.chunk << 8) | xo.W);
+  SA_LAUNCH((k_visual_cosine<BM, BN, KGT, PART, EU>), dim3(xo.W ? 8u * xo.chunk : xo.chunk, 1, ns), dim3(256 * ((KGT == 9 || KGT == 15 || KGT == 17) ? 1 : KGT ? KGT : 1)), 0, st, scenes, p, gx, gy, (xo.chunk << 8) | xo.W);
 }
 
 // The whole first phase of a VisualSORT frame in ONE heterogeneous launch: blockIdx.x <
@@ -1635,13 +1714,14 @@ __global__ __launch_bounds__(256 * (KGT >= 9 ? 1 : KGT ? KGT : 1)) void k_cosine
   constexpr int TM = BM / 64, TN = BN / 64;
   // KGT >= 9: the k-split main loop (gemm_mainloop_ks): 9 / 10 = B row-major / in fragment order, 13 = A in fragment order as well (the
   // stand-alone matrix entry point's measurement plans: sa_feature_distance_matrix reorders the operands it is asked to)
-  constexpr bool KS = KGT >= 9 && KGT != 15;   // 15: the direct loop of the wider tiles (gemm_mainloop_direct)
+  constexpr bool KS = KGT >= 9 && KGT != 15 && KGT != 17;   // 15: the direct loop of the wider tiles (gemm_mainloop_direct); 17: the 64 x 128 tile's k-split loop
   constexpr int KG = KGT >= 9 ? 1 : KGT ? KGT : 1;
   static_assert(KG == 1 || (TM == 1 && TN == 1), "k-groups only with the 64x64 tile");
   static_assert(!KS || (TM == 1 && TN == 1), "k-split only with the 64x64 tile");
-  __shared__ __attribute__((aligned(16))) float lds[KGT == 15 ? 64 : (KGT ? KG * 2 : 3) * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[KGT == 15 ? 64 : KGT == 17 ? 8192 : (KGT ? KG * 2 : 3) * (BM + BN) * BK];
   f32x16 acc[TM][TN];
-  if constexpr (KGT == 15) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, acc, tr);
+  if constexpr (KGT == 17) gemm_mainloop_ks128<3>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
+  else if constexpr (KGT == 15) gemm_mainloop_direct<BM, BN, 4>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, acc, tr);
   else if constexpr (KS) gemm_mainloop_ks<4, false, (KGT == 10 || KGT == 13), (KGT == 13)>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc[0][0], tr);
   else if constexpr (KGT == 0) gemm_mainloop_ring<BM, BN>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)A, (gfloat_p)B, M, Ncols, Dp, m0, n0, lds, acc, tr);
@@ -1783,7 +1863,7 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
   if ((visual_kind != SA_VIS_COSINE && visual_kind != SA_VIS_EUCLIDEAN) || !maxN || !maxTK) return;
   switch (tile_plan(maxN, maxTK, ns, Dp, plan_override)) {
     case 0: case 8: case 15: *bm = 128; *bn = 128; break;
-    case 5: case 16: *bm = 64; *bn = 128; break;
+    case 5: case 16: case 18: *bm = 64; *bn = 128; break;
     case 6: *bm = 128; *bn = 64; break;
     default: break;
   }
@@ -1862,13 +1942,14 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
 
 // The stand-alone contraction.  Plans (sa_config.gemm_plan - 1 pins one): 0 / 5 / 6 = 128x128 / 64x128 / 128x64 on the LDS-staged loop, 1 / 2 / 4 =
 // 64x64 with that many k-groups, 7 / 8 = ring variants; 9 = 64x64 on the k-split loop, 15 / 16 = 128x128 / 64x128 on the direct loop (both read
-// the bank's fragment-order twin: gemm_mainloop_ks / gemm_mainloop_direct).  tile_plan() chooses among the tile SIZES; unless a plan is pinned or
-// SA_FLAG_STAGED_LOOP is set, 128x128 / 64x128 / 64x64 then run the direct / k-split loops (measured on the stand-alone contraction, 4096 x 2048 x
-// 512: 93.6 -> 74.6 us; 2000 x 5000 x 4096: 732 -> 661; 1000 x 1000 x 512: 15.0 -> 12.9; 128x64 stays staged: two row-major gathers per
-// fragment-order load are what the direct loop is worst at).
+// the bank's fragment-order twin: gemm_mainloop_ks / gemm_mainloop_direct), 18 = 64x128 on ITS k-split loop (gemm_mainloop_ks128).  tile_plan()
+// chooses among the tile SIZES; unless a plan is pinned or SA_FLAG_STAGED_LOOP is set, 128x128 / 64x128 / 64x64 then run the direct / k-split /
+// k-split loops (measured on the stand-alone contraction, 4096 x 2048 x 512: 93.6 -> 74.6 us; 1000 x 1000 x 512: 15.0 -> 12.9; C5's frame with the
+// 64x128 tile staged / direct / k-split: 657 / 632-642 / 617-619 us; 128x64 stays staged: two row-major gathers per fragment-order load are what
+// the direct loop is worst at).
 static inline int loop_plan(int plan, const SaParams& p) {
   if (p.gemm_plan >= 0 || p.staged_loop) return plan;
-  return plan == 0 ? 15 : plan == 5 ? 16 : (plan == 1 || plan == 2) ? 9 : plan;
+  return plan == 0 ? 15 : plan == 5 ? 18 : (plan == 1 || plan == 2) ? 9 : plan;
 }
 hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, uint32_t maxTK, const SaParams& p,
                             hipStream_t st, bool partials) {
@@ -1877,7 +1958,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
   if (p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma) {
     // euclidean distances through the contraction: the one-k-group plans of every tile size (the k-group and ring plans are cosine tuning)
     int plan = tile_plan(maxN, maxTK, ns, p.Dp, p.gemm_plan);
-    plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6 || plan == 9 || plan == 15 || plan == 16) ? plan : 1;
+    plan = (plan == 0 || plan == 8) ? 0 : (plan == 5 || plan == 6 || plan == 9 || plan == 15 || plan == 16 || plan == 18) ? plan : 1;
     plan = loop_plan(plan, p);
 #define SA_EU_LAUNCH(BM_, BN_, KGT_) do { if (partials) launch_cosine<BM_, BN_, KGT_, true, true>(maxTK, maxN, ns, st, scenes, p); \
                                           else launch_cosine<BM_, BN_, KGT_, false, true>(maxTK, maxN, ns, st, scenes, p); } while (0)
@@ -1888,6 +1969,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       case 9: SA_EU_LAUNCH(64, 64, 9); break;
       case 15: SA_EU_LAUNCH(128, 128, 15); break;
       case 16: SA_EU_LAUNCH(64, 128, 15); break;
+      case 18: SA_EU_LAUNCH(64, 128, 17); break;
       default: SA_EU_LAUNCH(64, 64, 1); break;
     }
 #undef SA_EU_LAUNCH
@@ -1906,6 +1988,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
         case 9: launch_cosine<64, 64, 9, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         case 15: launch_cosine<128, 128, 15, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         case 16: launch_cosine<64, 128, 15, true, false>(maxTK, maxN, ns, st, scenes, p); break;
+        case 18: launch_cosine<64, 128, 17, true, false>(maxTK, maxN, ns, st, scenes, p); break;
         default: launch_cosine<64, 64, 1, true, false>(maxTK, maxN, ns, st, scenes, p); break;
       }
       return hipGetLastError();
@@ -1921,6 +2004,7 @@ hipError_t sa_launch_visual(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
       case 9: launch_cosine<64, 64, 9, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       case 15: launch_cosine<128, 128, 15, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       case 16: launch_cosine<64, 128, 15, false, false>(maxTK, maxN, ns, st, scenes, p); break;
+      case 18: launch_cosine<64, 128, 17, false, false>(maxTK, maxN, ns, st, scenes, p); break;
       default: launch_cosine<64, 64, 1, false, false>(maxTK, maxN, ns, st, scenes, p); break;
     }
   } else {
@@ -1948,6 +2032,7 @@ hipError_t sa_launch_distance_matrix(int kind, const float* a, const float* an, 
       case 15: hipLaunchKernelGGL((k_cosine_matrix<128, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 16: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 15>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 17: hipLaunchKernelGGL((k_cosine_matrix<128, 64, 15>), dim3(cdiv(t, 64), cdiv(n, 128)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
+      case 18: hipLaunchKernelGGL((k_cosine_matrix<64, 128, 17>), dim3(cdiv(t, 128), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       case 13: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 13>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
       default: hipLaunchKernelGGL((k_cosine_matrix<64, 64, 1>), dim3(cdiv(t, 64), cdiv(n, 64)), dim3(256), 0, st, a, an, b, bn, n, t, dp, out); break;
     }

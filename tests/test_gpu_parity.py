@@ -1092,7 +1092,7 @@ def test_distance_matrix_vs_numpy_f64(kind, n, t, d):
 
 
 @pytest.mark.paths("never_lean", "bestfit_tile", "separate_resolve")
-@pytest.mark.parametrize("plan", [0, 1, 2, 4, 5, 6, 7, 8, 9, 15, 16])
+@pytest.mark.parametrize("plan", [0, 1, 2, 4, 5, 6, 7, 8, 9, 15, 16, 18])
 @pytest.mark.parametrize("n,t,d", [(300, 333, 512), (129, 70, 96)])
 def test_every_tile_plan_of_the_contraction(plan, n, t, d):
     """All six tile plans (128x128, 64x128, 128x64, 64x64 with 1/2/4 k-groups) produce the same cosine matrix, both in the
