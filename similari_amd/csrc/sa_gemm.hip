@@ -586,6 +586,9 @@ __device__ __forceinline__ void gemm_mainloop_ks(gfloat_p A, gfloat_p B, uint32_
 // 8-deep k-step — one row-major gather of A and four fragment-order loads of B per 16 matrix instructions (the direct loop's 32 x 64 wave
 // tiles: 6 per 16, and every fragment loaded by two waves), nothing loaded twice.  Wave (wm, x) keeps columns x 64 .. +63 and ships its other
 // two accumulators to wave (wm, 1 - x) through LDS (8 KB per wave): it leaves with acc[0][0..1] as the 2 x 2 wave layout of the epilogues has them.
+// Two blocks per CU (150 VGPRs + 64 AGPRs as the compiler allots them).  Asked for three waves per SIMD (__launch_bounds__(256, 3): 162
+// registers, nothing spilled) the kernel is SLOWER — C5 645 us per frame against 616, c2b on this tile 119 against 107: like the direct
+// loop's tiles (three resident beat four), fewer co-resident operand streams keep their lines in L1.
 template <int NBUF>
 __device__ __forceinline__ void gemm_mainloop_ks128(gfloat_p A, gfloat_p B, uint32_t M, uint32_t Ncols, uint32_t Dp, uint32_t m0,
                                                     uint32_t n0, float* lds, f32x16 (&out)[1][2], uint64_t* tr = nullptr) {
