@@ -478,27 +478,33 @@ def hip_runtimes_mapped() -> list[str]:
 
 
 def _elf_dynamic_strings(path, tags=(1, 14)):
-    """DT_NEEDED (1) / DT_SONAME (14) strings of a 64-bit little-endian ELF file: {tag: [strings]} ({} when it cannot be read)."""
+    """DT_NEEDED (1) / DT_SONAME (14) strings of a 64-bit little-endian ELF file: {tag: [strings]} ({} when it cannot be read).  Reads the
+    headers, the dynamic section and the string table only (a HIP runtime is tens of megabytes)."""
     import struct
 
     out = {t: [] for t in tags}
     try:
         with open(path, "rb") as f:
-            data = f.read()
-        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
-            return {}
-        shoff, = struct.unpack_from("<Q", data, 0x28)
-        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
-        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
-        for sec in secs:
-            if sec[1] != 6:   # SHT_DYNAMIC
-                continue
-            strtab = secs[sec[6]]
-            for off in range(sec[4], sec[4] + sec[5], 16):
-                tag, val = struct.unpack_from("<qQ", data, off)
-                if tag in out:
-                    end = data.index(b"\0", strtab[4] + val)
-                    out[tag].append(data[strtab[4] + val:end].decode())
+            hdr = f.read(64)
+            if hdr[:4] != b"\x7fELF" or hdr[4] != 2 or hdr[5] != 1:
+                return {}
+            shoff, = struct.unpack_from("<Q", hdr, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", hdr, 0x3A)
+            f.seek(shoff)
+            sh = f.read(shentsize * shnum)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", sh, i * shentsize) for i in range(shnum)]
+            for sec in secs:
+                if sec[1] != 6:   # SHT_DYNAMIC
+                    continue
+                strtab = secs[sec[6]]
+                f.seek(strtab[4])
+                strs = f.read(strtab[5])
+                f.seek(sec[4])
+                dyn = f.read(sec[5])
+                for off in range(0, len(dyn) - 15, 16):
+                    tag, val = struct.unpack_from("<qQ", dyn, off)
+                    if tag in out and val < len(strs):
+                        out[tag].append(strs[val:strs.index(b"\0", val)].decode())
     except Exception:
         return {}
     return out
