@@ -1616,7 +1616,7 @@ static bool in_pinned_block(const void* p, size_t bytes, const void** dev = null
   return false;
 }
 
-bool sa_in_pinned_host_block(const void* p, size_t bytes) { return p && in_pinned_block(p, bytes); }   // (the tracker facade, sa_tracker.cpp)
+__attribute__((visibility("hidden"))) bool sa_in_pinned_host_block(const void* p, size_t bytes) { return p && in_pinned_block(p, bytes); }   // (the tracker facade, sa_tracker.cpp)
 
 // ---- device blocks the caller's own producers write detection features into (sa_device_block_register) ----
 struct DevBlock { const char* base; size_t bytes; int device; };

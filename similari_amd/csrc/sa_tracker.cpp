@@ -35,7 +35,7 @@
 #include "sa_kalman.h"
 #include "sa_pool.h"
 
-extern "C" bool sa_in_pinned_host_block(const void* p, size_t bytes);   // sa_engine.hip: inside a block from sa_host_alloc?
+extern "C" __attribute__((visibility("hidden"))) bool sa_in_pinned_host_block(const void* p, size_t bytes);   // sa_engine.hip: inside a block from sa_host_alloc?
 
 namespace {
 
