@@ -2,7 +2,9 @@
 // (sa_tracker_predict_batch_begin + one sa_batch_result_get / _take per scene).  S scenes x n objects of the world scripts/bench_batch_tracker.py
 // uses (dense random boxes, jittered every frame; [churn]: that fraction of the objects replaced every frame), device upkeep.
 //   g++ -O2 -std=c++17 -I include scripts/micro/batch_handle_bench.cpp -L similari_amd/lib -lsimilari_assoc -Wl,-rpath,$PWD/similari_amd/lib -o /tmp/batch_handle_bench
-//   /tmp/batch_handle_bench [scenes] [objects] [frames] [churn]
+//   /tmp/batch_handle_bench [scenes] [objects] [frames] [churn] [devices]
+// devices: a comma-separated list of HIP ordinals — the tracker becomes a device GROUP (sa_tracker_options.n_devices / devices: one engine per
+// entry, scene_id % n; "0,0" = two engines on one GPU), everything else unchanged: ONE tracker object, ONE handle.
 #include "similari_tracker.h"
 #include <algorithm>
 #include <chrono>
@@ -16,6 +18,9 @@ static double us(clk::time_point a, clk::time_point b) { return std::chrono::dur
 int main(int argc, char** argv) {
   const uint32_t S = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 500, frames = argc > 3 ? atoi(argv[3]) : 60;
   const float churn = argc > 4 ? (float)atof(argv[4]) : 0.0f;
+  std::vector<int32_t> devices;
+  if (argc > 5)
+    for (const char* c = argv[5]; *c;) { devices.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> u(0.f, 1.f);
   std::normal_distribution<float> g(0.f, 2.f);
@@ -33,6 +38,7 @@ int main(int argc, char** argv) {
     sa_tracker_options o;
     sa_tracker_options_default(&o, 0);
     o.history_length = 3; o.max_idle_epochs = 3; o.batch_ids = 1; o.device_upkeep = 1;
+    if (devices.size() > 1) { o.n_devices = (uint32_t)devices.size(); o.devices = devices.data(); }
     sa_tracker* t = nullptr;
     if (sa_tracker_create(&o, &t) != 0) { printf("create failed: %s\n", sa_tracker_last_error(nullptr)); return 1; }
     std::vector<std::vector<sa_observation>> obs(S, std::vector<sa_observation>(n));
@@ -80,7 +86,7 @@ int main(int argc, char** argv) {
     if (mode == 2) { first[0] = median(tf); ret[0] = median(tr); }
     sa_tracker_destroy(t);
   }
-  printf("{\"host\": \"C++\", \"tracker\": \"BatchSort\", \"scenes\": %u, \"objects_per_scene\": %u, \"churn_per_frame\": %.2f, \"us_per_predict_sync\": %.1f, \"us_per_predict_through_the_handle_get\": %.1f, "
-         "\"us_per_predict_through_the_handle_take\": %.1f, \"us_until_begin_returns\": %.1f, \"us_until_first_scene\": %.1f}\n", S, n, (double)churn, med[0], med[1], med[2], ret[0], first[0]);
+  printf("{\"host\": \"C++\", \"tracker\": \"BatchSort\", \"engines\": %u, \"scenes\": %u, \"objects_per_scene\": %u, \"churn_per_frame\": %.2f, \"us_per_predict_sync\": %.1f, \"us_per_predict_through_the_handle_get\": %.1f, "
+         "\"us_per_predict_through_the_handle_take\": %.1f, \"us_until_begin_returns\": %.1f, \"us_until_first_scene\": %.1f}\n", (uint32_t)(devices.size() > 1 ? devices.size() : 1), S, n, (double)churn, med[0], med[1], med[2], ret[0], first[0]);
   return 0;
 }

@@ -1205,20 +1205,36 @@ int group_begin(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, con
       next += counts[s];
     }
     t->track_id = next;
-    int rc = SA_OK;
-    for (uint32_t k = 0; k < ns && rc == SA_OK; ++k) {
-      if (sh[k].ids.empty()) continue;
+    // every shard's share is begun on a thread of its own (the group's pool: shard k on thread k, the calling thread takes shard 0): a begin
+    // is 70-180 us of host work whatever the number of scenes (assemble, stage, evict, four launches), and two of them one after the other
+    // cost a 64 x 500 set 338 us before the last launch where one engine takes 183
+    std::vector<sa_batch_result*> kids(ns, nullptr);
+    std::vector<int> rcs(ns, SA_OK);
+    auto begin_shard = [&](uint32_t k) {
+      if (sh[k].ids.empty()) return;
       sa_tracker* c = t->shards[k];
       wait_outstanding(c);
       c->forced_base = sh[k].base.data();
-      sa_batch_result* kid = nullptr;
       try {
-        rc = sa_begin_into(c, (uint32_t)sh[k].ids.size(), sh[k].ids.data(), sh[k].counts.data(), sh[k].obs.data(), caller_out ? sh[k].out.data() : nullptr, &kid);
-      } catch (const std::exception& ex) { rc = tfail(c, SA_ERR_OOM, "%s", ex.what()); }
+        rcs[k] = sa_begin_into(c, (uint32_t)sh[k].ids.size(), sh[k].ids.data(), sh[k].counts.data(), sh[k].obs.data(), caller_out ? sh[k].out.data() : nullptr, &kids[k]);
+      } catch (const std::exception& ex) { rcs[k] = tfail(c, SA_ERR_OOM, "%s", ex.what()); }
       c->forced_base = nullptr;
-      if (rc != SA_OK) { group_fail(t, c, rc); break; }
-      r->kids.push_back(kid);
-      r->kid_total += (uint32_t)sh[k].ids.size();
+    };
+    uint32_t busy = 0;
+    for (uint32_t k = 0; k < ns; ++k) busy += sh[k].ids.empty() ? 0u : 1u;
+    if (busy > 1) {
+      // The group's own threads neither spin nor bind.  Bound (to the CPUs next to the caller's) they leave a shard's pool, which is created
+      // ON such a thread, one allowed CPU and therefore unbound workers: 64 x 500 over two shards 880-1560 us per call; unbound but spinning
+      // they can sit on the CPU a shard's bound worker is given later, and the two then take turns by the scheduler's tick (8 ms per call
+      // seen once).  Asleep between calls they are placed afresh on an idle CPU at every wake-up, for a futex round trip per call.
+      if (!t->pool) t->pool.reset(new SaPool(ns - 1, false, 0));
+      t->pool->run(ns, begin_shard);
+    } else
+      for (uint32_t k = 0; k < ns; ++k) begin_shard(k);
+    int rc = SA_OK;
+    for (uint32_t k = 0; k < ns; ++k) {
+      if (rcs[k] != SA_OK && rc == SA_OK) { rc = rcs[k]; group_fail(t, t->shards[k], rc); }
+      if (kids[k]) { r->kids.push_back(kids[k]); r->kid_total += (uint32_t)sh[k].ids.size(); }
     }
     if (rc != SA_OK) { for (sa_batch_result* kid : r->kids) sa_batch_result_free(kid); return rc; }
   } else {
@@ -1314,6 +1330,10 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
       oc.n_devices = 0; oc.devices = nullptr;
       oc.device = o->devices[k];
       oc.auto_waste_periodicity = 0xffffffffu;   // (the cadence is the group's)
+      if (oc.workers == 0) {   // the facade's own choice, shared out: the group works on a request set with as many threads as ONE tracker would
+        const uint32_t all = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 8u));
+        oc.workers = (int32_t)std::max(2u, all / o->n_devices);
+      }
       sa_tracker* c = nullptr;
       int rc = sa_tracker_create(&oc, &c);
       if (rc != SA_OK) { for (sa_tracker* c2 : g->shards) sa_tracker_destroy(c2); delete g; return rc; }
@@ -1365,6 +1385,7 @@ int sa_tracker_create(const sa_tracker_options* o, sa_tracker** out) {
 void sa_tracker_destroy(sa_tracker* t) {
   if (!t) return;
   if (!t->shards.empty()) {
+    t->pool.reset();
     for (sa_tracker* c : t->shards) sa_tracker_destroy(c);
     delete t;
     return;
