@@ -98,7 +98,7 @@ typedef struct sa_tracker_options {
    * + device upkeep queued behind it, that shard's own worker threads and result driver), all shards at once, and the result handle
    * delivers the scenes of every shard as they finish.  Track ids, epochs, idle / wasted sets and the auto-waste cadence are those of ONE
    * tracker (the id counter and the waste counter are the group's; Batch* ids are a function of the request alone, so no shard waits for
-   * another).  Feature rows handed over in a registered DEVICE block (sa_device_block_register) must lie on the device of their scene's shard
+   * another).  `workers` is per shard; workers = 0 shares ONE tracker's default thread budget out among the shards.  Feature rows handed over in a registered DEVICE block (sa_device_block_register) must lie on the device of their scene's shard
    * (devices[scene_id % n_devices]): a row on another GPU is refused, not fetched.  n_devices <= 1: one engine on `device` (devices is ignored). */
   uint32_t n_devices;
   const int32_t* devices;
