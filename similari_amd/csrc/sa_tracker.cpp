@@ -1291,6 +1291,7 @@ void sa_tracker_options_default(sa_tracker_options* o, int visual) {
   o->positional_threshold = 0.3f;
   o->kalman_position_weight = 1.0f / 20.0f;
   o->kalman_velocity_weight = 1.0f / 160.0f;
+  o->spin_us = -1;   // the facade's own polling times (0 would mean: no thread of the tracker ever polls)
   if (!visual) {
     o->history_length = 1;
     o->max_idle_epochs = 5;

@@ -52,6 +52,7 @@ def test_struct_sizes_match_the_headers(lib):
     lib.sa_tracker_options_default(C.byref(o), 1)
     assert o.struct_size == C.sizeof(abi.sa_tracker_options)
     assert o.visual_max_observations == 5 and o.visual_minimal_track_length == 3 and o.max_idle_epochs == 2
+    assert o.spin_us == -1 and o.n_devices == 0   # (0 would mean "no thread of the tracker ever polls": the defaults must ask for the facade's own times)
 
 
 def gpu_visible() -> bool:
