@@ -652,7 +652,7 @@ def local_ingest(wname, total_scenes, world, rank, local_rank, dist, barrier, ma
     return out
 
 
-def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400, max_over_ranks=None):
+def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400, max_over_ranks=None, after=None):
     """EXACTLY K steps per timed region, bracketed by barrier + synchronize on both sides; the region is repeated until at least
     min_total_s has been measured (a 20-step region of a 25 us step is 0.5 ms of signal: one region is a noisy sample) and the
     MEDIAN region is reported.  Under several ranks a region's time is the MAX over ranks (max_over_ranks: an all-reduce OUTSIDE the
@@ -667,6 +667,8 @@ def timed_rounds(run_k, barrier, min_total_s=0.5, min_rounds=5, max_rounds=400, 
         run_k()
         barrier()
         dt = time.perf_counter() - t0
+        if after is not None:
+            after()
         if max_over_ranks is not None:
             dt = max_over_ranks(dt)
         times.append(dt)
@@ -754,10 +756,13 @@ def main():
         cells = sum(len(s["det_boxes"]) * len(s["track_boxes"]) for s in scenes)
 
     def barrier():
+        # the contract's bracket: a barrier + torch.cuda.synchronize().  One rank: the synchronize alone (it drains every stream of the
+        # device, the engine's included) — each further runtime call on the idle device is 2.7 us INSIDE the region, 0.13 us per step of a
+        # 20-step region (scripts/region_fixed_cost.py: batch_sync + two synchronizes 20.8 us per step at K = 20, one synchronize 20.3)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def max_over_ranks(x):
         if dist is None:
@@ -769,21 +774,22 @@ def main():
     def run_k():
         for _ in range(args.steps):
             eng.batch_run()
+
+    def after_region():   # (outside the clock: the engine's own view of the drained queue — error codes, replaced buffers)
         eng.batch_sync()
 
     for _ in range(args.warmup):
         eng.batch_run()
     eng.batch_sync()
-    dt, regions = timed_rounds(run_k, barrier, max_over_ranks=max_over_ranks)
+    dt, regions = timed_rounds(run_k, barrier, max_over_ranks=max_over_ranks, after=after_region)
     # the pure per-step time: a region carries a fixed cost (the first launch's latency, the final synchronisation: ~20 us, 5 % of a
     # 20-step region) — regions of 4 K steps give the slope; `value` stays the K-step region, the slope only rescales the
     # instrumented per-kernel durations below
     def run_4k():
         for _ in range(4 * args.steps):
             eng.batch_run()
-        eng.batch_sync()
     if dt < 0.05:
-        dt4, _r4 = timed_rounds(run_4k, barrier, min_total_s=0.2, min_rounds=3, max_rounds=60, max_over_ranks=max_over_ranks)
+        dt4, _r4 = timed_rounds(run_4k, barrier, min_total_s=0.2, min_rounds=3, max_rounds=60, max_over_ranks=max_over_ranks, after=after_region)
         step_s = max(0.0, (dt4 - dt) / (3.0 * args.steps)) or dt / args.steps
     else:
         step_s = dt / args.steps  # a region of 50 ms and more: the fixed cost is below a tenth of a percent

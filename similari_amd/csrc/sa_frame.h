@@ -269,6 +269,9 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   const uint32_t N = S.N, T = S.T;
   const uint32_t i0 = by * POS_TI, j0 = bx * POS_TJ;
   if (i0 >= N || j0 >= T) return;
+#if defined(SA_POS_SKIP) && SA_POS_SKIP >= 4   // (measurement only, scripts/pos_skip_probe.sh: what each phase of a tile costs its launch; the answers are wrong)
+  return;
+#endif
   POS_STAMP(tr, 0);
   [[maybe_unused]] const uint64_t pos_rt0 = POS_RT();
   // LDS comes from the caller (one raw buffer per kernel): in the fused VisualSORT launch the tiles share their kernel's
@@ -347,6 +350,9 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
   }
   __syncthreads();
   uint32_t cnt = s_cnt;
+#if defined(SA_POS_SKIP) && SA_POS_SKIP >= 3
+  cnt = 0;
+#endif
   POS_STAMP(tr, 2);
   POS_NOTE(tr, 6, cnt);
   // (only where it saves a clip round: up to 64 surviving pairs are one round of the four-lane clipper whatever their number)
@@ -388,6 +394,9 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     __syncthreads();
     cnt = sm.cnt2;
   }
+#if defined(SA_POS_SKIP) && SA_POS_SKIP >= 2
+  cnt = 0;
+#endif
   POS_STAMP(tr, 3);
   POS_NOTE(tr, 7, cnt);
   // one surviving cell -> (optionally) the dense matrix, and its edge
@@ -455,6 +464,9 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
         }
       }
     };
+    // (four lanes for every count — half the waves of a 25-pair tile in the clipper — was measured in the fused launch, where vector
+    // issue is what the tiles take from the contraction: C2 first phase 15.2-15.3 us against 15.0, also with the active waves rotated from
+    // tile to tile: what the launch waits for is the tiles' chain, not their instruction count)
     if (cnt <= 32u) clip_pairs(std::integral_constant<uint32_t, 8u>{});
     else clip_pairs(std::integral_constant<uint32_t, 4u>{});
   } else if (tid < POS_WORKERS) {

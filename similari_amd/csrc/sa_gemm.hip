@@ -1041,10 +1041,13 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       auto recompute = [&](uint32_t lrow, uint32_t lc) {
         const uint32_t li = (lrow >> 5) * (BM / 2) + m * 32 + (lrow & 31u), gi = m0 + li, gj = n0 + lc;
         const float SA_G* a = Ab + (size_t)gi * S.Dp;
-        const float SA_G* b = S.t_feat + (size_t)gj * S.Dp;
+        // (k-split / direct loops: the track's row out of the fragment-order twin the tile has just streamed — L2-resident; the row-major
+        // bank is cold there, a trip to memory per flagged cell)
+        constexpr bool TWIN = KSPLIT || DIRECT || KS128;
+        const float SA_G* b = TWIN ? S.t_ffrag + sa_frag_index(gj, 0, S.Dp) : S.t_feat + (size_t)gj * S.Dp;
         float acc2 = 0.f;
         for (uint32_t k = lane * 4u; k < S.Dp; k += 256u) {
-          const f32x4 x = *(const f32x4 SA_G*)(a + k), y = *(const f32x4 SA_G*)(b + k);
+          const f32x4 x = *(const f32x4 SA_G*)(a + k), y = *(const f32x4 SA_G*)(b + (TWIN ? (size_t)(k >> 3) * 256u + ((k >> 2) & 1u) * 128u : (size_t)k));
           const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
           acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
         }
@@ -1107,25 +1110,34 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
     }
     uint32_t ckey = 0xffffffffu, crow = 0;
     const uint32_t cfail = constraint_mask<R>(col[0], [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
+    uint32_t fmask = 0;  // EU: bit i = cell i of this lane goes to the direct recompute
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const uint32_t li = rbase[i >> 2] + (i & 3);
       const uint32_t gi = m0 + li;
       bool flagged;
       const float w = visual_cell<EU>(p, part[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax, &flagged);  // rows / columns past the edge: ok = false
-      if constexpr (EU) {
-        if (flagged && gi < N) {  // BM = 64: the tile row is the pass row
-          atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));
-          const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
-          if (pos < FL_CAP) s_flist[pos] = (li << 8) | lc;
-        }
-      }
+      // (the flagged cells are REGISTERED behind the loop: with the LDS atomics inside it every cell was a basic block of its own and the
+      // lone wave walked 16 dependent chains one after the other — the euclidean cells 6.2 k cycles against the cosine ones' 3.2 k)
+      if constexpr (EU) fmask |= (flagged && gi < N) ? (1u << i) : 0u;
       if constexpr (PART) {
         const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
         s_key[li * KS + lc] = key;
         if (key < ckey) { ckey = key; crow = gi; }  // rows ascend with i: the lowest row wins ties
       } else if (gi < N && gj < TK) {
         S.vis[(size_t)gi * TK + gj] = w;
+      }
+    }
+    if constexpr (EU) {
+      if (__ballot(fmask != 0u) != 0ull) {  // (a tracking frame: about one cell per candidate — most waves skip this)
+        while (fmask) {
+          const uint32_t i = (uint32_t)__builtin_ctz(fmask);
+          fmask &= fmask - 1u;
+          const uint32_t li = wm * 32 + 8u * (kg * (R / 4) + (i >> 2)) + 4u * lh + (i & 3u);  // BM = 64: the tile row is the pass row
+          atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));
+          const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
+          if (pos < FL_CAP) s_flist[pos] = (li << 8) | lc;
+        }
       }
     }
     if constexpr (PART) {
@@ -1310,6 +1322,7 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
   }
   uint32_t kmax = 0;
   const uint32_t cfail = constraint_mask<R>(col, [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
+  uint32_t fmask = 0;
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const uint32_t li = rbase[i >> 2] + (i & 3);
@@ -1317,25 +1330,29 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
     bool flagged;
     float w = visual_cell<EU>(p, acc[0][0][i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col, &kmax, &flagged);
     if (gi >= N) w = __builtin_nanf("");  // (columns past the tile's tracks: col.ok = false)
-    if constexpr (EU) {
-      if (flagged && gi < N) {
+    if constexpr (EU) fmask |= (flagged && gi < N) ? (1u << i) : 0u;   // (registered behind the loop: see visual_cosine_tile)
+    s_w[li * KS + lc] = __float_as_uint(w);
+  }
+  if constexpr (EU) {
+    if (__ballot(fmask != 0u) != 0ull) {
+      while (fmask) {
+        const uint32_t i = (uint32_t)__builtin_ctz(fmask);
+        fmask &= fmask - 1u;
+        const uint32_t li = wm * 32 + 8u * (i >> 2) + 4u * lh + (i & 3u);
         atomicOr(&s_flag[li * FW + (lc >> 5)], 1u << (lc & 31u));
         const uint32_t pos = atomicAdd(&s_flist[FL_CAP], 1u);
         if (pos < FL_CAP) s_flist[pos] = (li << 8) | lc;
       }
     }
-    s_w[li * KS + lc] = __float_as_uint(w);
-  }
-  if constexpr (EU) {
     __syncthreads();  // flag words / list and the weight tile complete
     const uint32_t wave = tid >> 6, nw = blockDim.x >> 6;
     auto recompute = [&](uint32_t li, uint32_t lc2) {
       const uint32_t gi = m0 + li;
       const float SA_G* a = S.c_feat_raw + (size_t)gi * S.Dp;
-      const float SA_G* b = S.t_feat + (size_t)(n0 + lc2) * S.Dp;
+      const float SA_G* b = KSL ? S.t_ffrag + sa_frag_index(n0 + lc2, 0, S.Dp) : S.t_feat + (size_t)(n0 + lc2) * S.Dp;   // (the twin: L2-resident)
       float acc2 = 0.f;
       for (uint32_t kk = lane * 4u; kk < S.Dp; kk += 256u) {
-        const f32x4 x = *(const f32x4 SA_G*)(a + kk), y = *(const f32x4 SA_G*)(b + kk);
+        const f32x4 x = *(const f32x4 SA_G*)(a + kk), y = *(const f32x4 SA_G*)(b + (KSL ? (size_t)(kk >> 3) * 256u + ((kk >> 2) & 1u) * 128u : (size_t)kk));
         const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
         acc2 += d0 * d0; acc2 += d1 * d1; acc2 += d2 * d2; acc2 += d3 * d3;
       }
