@@ -1451,12 +1451,16 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
                                                            uint32_t px, uint32_t py, uint32_t nprep_, uint32_t xo_) {
   // nprep_: preparation blocks of the launch; bit 31: they run their RESET half only, bit 30: the positional tiles also feed the
   // many-workgroup tail (row-major edge lists, row duals, union-find: UNION) — frames beyond the one-workgroup tail's 1024 x 1024
-  const uint32_t nprep = nprep_ & 0x3fffffffu;
-  const bool prep_light = (nprep_ >> 31) != 0, uni = ((nprep_ >> 30) & 1u) != 0;
-  __shared__ __attribute__((aligned(16))) float lds[KG * 2 * (64 + 64) * BK];
-  static_assert(gemm_lds_floats(64, 64, KSL ? 9 : KG, PART, EU) <= KG * 2 * (64 + 64) * BK, "the contraction tile must fit the launch's LDS");
+  // bit 29: the positional tiles are 16 x 256 (launches whose blocks would not all be resident with 16 x 128 tiles: sa_launch_frame_visual)
+  const uint32_t nprep = nprep_ & 0x1fffffffu;
+  const bool prep_light = (nprep_ >> 31) != 0, uni = ((nprep_ >> 30) & 1u) != 0, wide = ((nprep_ >> 29) & 1u) != 0;
   using FusedPos = PosSmem<2, 64>;  // the wide, proof-filtered positional tile of this launch (sa_frame.h)
+  using FusedPosW = PosSmem<4, 64>; // ... and its 16 x 256 form
   static_assert(sizeof(FusedPos) <= sizeof(float) * 2 * 128 * BK, "the positional tile must fit one k-group's stages");
+  constexpr uint32_t POS_LDS = (sizeof(FusedPosW) + 15u) & ~15u;
+  constexpr uint32_t LDSF = (KG * POS_LDS + 3u) / 4u > (uint32_t)(KG * 2 * (64 + 64) * BK) ? (KG * POS_LDS + 3u) / 4u : (uint32_t)(KG * 2 * (64 + 64) * BK);
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];   // (35.6 KB with the 16 x 256 positional tile: four blocks per CU as before)
+  static_assert(gemm_lds_floats(64, 64, KSL ? 9 : KG, PART, EU) <= LDSF, "the contraction tile must fit the launch's LDS");
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   // Contraction tiles first in blockIdx order: the dispatcher hands blocks out in that order, breadth-first over the CUs, so
   // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
@@ -1477,8 +1481,6 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // LDS buffer.  Their barriers are the block's; units pair up barrier for barrier (same kind: same count), and a unit that has
   // nothing to do, or none, simply ends — ended waves do not take part in s_barrier.
   const uint32_t unit = b * KG + (threadIdx.x >> 8), tid = threadIdx.x & 255u;
-  constexpr uint32_t POS_LDS = (sizeof(FusedPos) + 15u) & ~15u;
-  static_assert(KG * POS_LDS <= sizeof(float) * KG * 2 * 128 * BK, "the positional tiles must fit the contraction's LDS");
 #ifdef SA_GEMM_TRACE
   uint64_t* tr2 = g_trace_dev && blockIdx.x < 65536 ? g_trace_dev + 8 * blockIdx.x : nullptr;  // entry / exit of the other kinds
   if (tr2 && threadIdx.x == 0) { tr2[0] = __builtin_amdgcn_s_memtime(); tr2[1] = unit < nprep ? 2 : 1; }
@@ -1487,8 +1489,10 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   // preparation blocks queued behind them started only when the first tiles retired — the last thing to finish in the launch
   if (unit < nprep) frame_prep_block(S, p, unit, tid, prep_light);
   else if (unit - nprep < px * py) {
-    if (uni) positional_tile<false, true, 2, true, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
-    else positional_tile<false, true, 2, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS, tid);
+    unsigned char* pl = (unsigned char*)lds + (threadIdx.x >> 8) * POS_LDS;
+    if (wide) positional_tile<false, true, 4, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, pl, tid);   // (never with the many-workgroup tail's extras)
+    else if (uni) positional_tile<false, true, 2, true, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, pl, tid);
+    else positional_tile<false, true, 2, false, true, 64, true>(S, p, (unit - nprep) % px, (unit - nprep) / px, pl, tid);
   }
 #ifdef SA_GEMM_TRACE
   if (tr2 && threadIdx.x == 0) tr2[5] = __builtin_amdgcn_s_memtime();
@@ -1925,7 +1929,8 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;
   const uint32_t maxTK = maxT * K;
-  const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), px = cdiv(maxT, 128), py = cdiv(maxN, POS_TI);
+  const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), py = cdiv(maxN, POS_TI);
+  uint32_t px = cdiv(maxT, 128);
   // preparation blocks: 1 = all of them (one wave per feature row: N / 4), 3 = the reset half only (one thread per row / column),
   // 0 = none (a lean frame on the one-workgroup tail: nothing on its path reads what they write, enqueue_frame)
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
@@ -1935,6 +1940,12 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // C2 20.3, c2t 36.1 / 36.4, c2k3 46.7 / 46.6, c2d 80.9, c2e 23.4 us either way — for a fifth fewer L2 fills; SA_FLAG_ROW_TILES: row by row)
   const XcdOrder xo = xcd_order(gx, gy, p.row_major_tiles == 2u);
   const uint32_t xo_ = (xo.chunk << 8) | xo.W, n_gemm = xo.W ? 8u * xo.chunk : xo.chunk;
+  // Positional tiles of 16 x 256 where the launch's blocks would not all be resident with 16 x 128 (four blocks per CU: 1024) — deeper
+  // banks, request sets of several scenes: a tile that has to wait for a place starts when the first contraction tiles retire.  Measured,
+  // first phase: c2k3 37.1 -> 35.5 us, c2bk3 262 -> 253, c2d 69.3 -> 68.5.  Not where the tiles also feed the many-workgroup tail (row
+  // duals, union-find: a 16 x 256 tile of THAT kind is a longer chain than two rounds of 16 x 128 — c2t 27.0 -> 29.2 us).
+  const bool wide_pos = !general_tail && (size_t)(n_gemm + px * py + prep_blocks) * ns > 1024u;
+  if (wide_pos) px = cdiv(maxT, 256);
   sa_trace_hook(st, n_gemm + px * py + prep_blocks);
   // One k-group (256-thread blocks, 32 KB of LDS for every kind of block: five blocks per CU).  With two k-groups the
   // contraction alone is faster (15 vs 20 us) but every block of the launch then owns 512 threads and 64 KB — a kernel's LDS is
@@ -1942,7 +1953,7 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // each 512-thread block the latency-bound tiles, which want four or five blocks in flight per CU, queue: 30 us for the launch
   // against 22.7 (raising the contraction's wave priority changes nothing).
   const dim3 grid(n_gemm + px * py + prep_blocks, 1, ns);
-  const uint32_t np = prep_blocks | (prep == 3 ? 0x80000000u : 0u) | (general_tail ? 0x40000000u : 0u);
+  const uint32_t np = prep_blocks | (prep == 3 ? 0x80000000u : 0u) | (general_tail ? 0x40000000u : 0u) | (wide_pos ? 0x20000000u : 0u);
   // the contraction tiles' main loop: k-split over the bank's fragment-order twin by default, the LDS-staged loop with SA_FLAG_STAGED_LOOP
 #define SA_FV(PART_, EU_, KP_) do { if (p.staged_loop) SA_LAUNCH((k_frame_visual<1, PART_, EU_, KP_, false>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_); \
                                     else SA_LAUNCH((k_frame_visual<1, PART_, EU_, KP_, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_); } while (0)
