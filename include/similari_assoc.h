@@ -114,7 +114,9 @@ typedef struct sa_config {
   int32_t gemm_plan;               /* n + 1 pins tile plan n of the contraction (sa_gemm.hip: 0 = 128x128, 5 = 64x128, 6 = 128x64, 1/2/4 = 64x64
                                       with 1/2/4 k-groups, 7/8 = the ring variants — all on the LDS-staged main loop; 9 = 64x64 on the k-split loop,
                                       15 / 16 = 128x128 / 64x128 on the direct loop, 18 = 64x128 on its k-split loop: 9 / 15 / 18 are what the engine
-                                      runs by default, reading the track bank's fragment-order twin) */
+                                      runs by default, reading the track bank's fragment-order twin; 19 = plan 9 with the fused first phase's
+                                      tiles 64x96 wherever that form applies — cosine frames of one observation per track — which the engine
+                                      picks by itself for frames of 1.0 .. 1.5 rounds of 64x64 tiles) */
   uint32_t euclid_backoff_frames;  /* euclidean engines: after a frame that reported itself ill-conditioned for the matrix-core expansion, that
                                       SCENE's next frames run on the vector-pipe kernel, this many of them (0 = 256), before another try */
   int32_t poll_spin_us;            /* how long a host thread may poll a request set's completion words (mapped host memory, stored by the

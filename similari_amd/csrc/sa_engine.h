@@ -200,7 +200,7 @@ struct SaParams {
   uint32_t row_major_tiles;     // order of the contraction's tiles: 1 = the default (stand-alone contraction row by row, fused first phase XCD-aware),
                                 // 0 = XCD-aware everywhere (SA_FLAG_XCD_TILES), 2 = row by row everywhere (SA_FLAG_ROW_TILES); sa_gemm.hip
   uint32_t no_yield;            // SA_FLAG_NO_YIELD
-  uint32_t ks_yield;            // k-split loop of the fused first phase: the matrix waves sleep 64 cycles after every ks_yield-th k-step (0: never)
+  uint32_t ks_yield;            // k-split loops of the fused first phase: the matrix waves nap after every (ks_yield & 255)-th k-step (0: never), (ks_yield >> 8) x 64 cycles (0: 64)
   uint32_t staged_loop;         // SA_FLAG_STAGED_LOOP: the fused first phase's contraction tiles on the LDS-staged main loop (row-major bank)
   int32_t gemm_plan;            // sa_config.gemm_plan - 1: the contraction's tile plan pinned (tuning / tests), -1 = tile_plan()'s own choice
 };

@@ -582,6 +582,127 @@ __device__ __forceinline__ void gemm_mainloop_ks(gfloat_p A, gfloat_p B, uint32_
   __syncthreads();  // the epilogue reuses this LDS
 }
 
+// The k-split loop for a 64 x 96 tile (the fused first phase of frames whose 64 x 64 tiles would be one and a half rounds of the chip:
+// sa_launch_frame_visual): wave (wm, kg) owns tile rows wm 32 .. +31, ALL 96 columns (three accumulators) and every second 8-deep k-step —
+// one gather of A and three fragment-order loads of B per 12 matrix instructions.  Wave (wm, x) leaves with columns x 32 .. +31 in the
+// standard 32 x 32 accumulator (`out`: what wave (wm, wn = x) of a 64 x 64 tile holds) and with HALF of the third column block: accumulator
+// registers 8 x .. 8 x + 7 of columns 64 .. 95 (`out2`; register r <-> tile row wm 32 + acc_row(r, lane half)).  Every cell is
+// (k-half 0) + (k-half 1), each half accumulated over the same k-steps in the same order as gemm_mainloop_ks: the 64 x 64 tiling's bits.
+// LDS: [4 waves][6][64] f32x4 of exchange (24 KB) + [4][32] squared-norm halves.
+constexpr uint32_t SA_KS96_RED = 4u * 6u * 64u * 4u;
+constexpr uint32_t SA_KS96_LDS = SA_KS96_RED + 4u * 32u;
+template <int NBUF, bool NORM>
+__device__ __forceinline__ void gemm_mainloop_ks96(gfloat_p A, gfloat_p B, uint32_t M, uint32_t Ncols, uint32_t Dp, uint32_t m0, uint32_t n0,
+                                                   float* lds, f32x16& out, float (&out2)[8], uint64_t* tr = nullptr, float* nsq = nullptr,
+                                                   uint32_t yield_every = 0) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) & 3u;
+  const uint32_t wm = w4 >> 1, kg = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  const uint32_t Np = (Ncols + 31u) / 32u * 32u;   // (n0 is a multiple of 96: it starts a block of 32 rows of the twin)
+  auto left = [&](uint32_t rows) { const uint64_t b = (uint64_t)rows * Dp * 4u; return (uint32_t)(b < 0xffffffffull ? b : 0xffffffffull); };
+  const __amdgpu_buffer_rsrc_t RA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * Dp), 0, (int)left(M - m0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t RB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * Dp), 0, (int)left(Np - n0), 0x00020000);
+  const uint32_t oa = ((wm * 32u + lr) * Dp + lh * 4u) * 4u;
+  uint32_t ob[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) ob[n] = ((uint32_t)n * (Dp >> 3) * 256u + lh * 128u + lr * 4u) * 4u;
+  const uint32_t mine = Dp >> 4;
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; }
+  f32x4 fa[NBUF], fb[NBUF][3];
+  float ns = 0.f;
+  auto load = [&](auto buf_tag, uint32_t j) {
+    constexpr int buf = decltype(buf_tag)::value;
+    const uint32_t s = 2u * j + kg;
+    fa[buf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, (int)oa, (int)(s * 32u), 0));
+#pragma unroll
+    for (int n = 0; n < 3; ++n) fb[buf][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RB, (int)ob[n], (int)(s * 1024u), 0));
+  };
+  auto compute = [&](auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][e], fb[buf][0][e], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][e], fb[buf][1][e], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][e], fb[buf][2][e], acc2, 0, 0, 0);
+    }
+    if constexpr (NORM) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ns += fa[buf][e] * fa[buf][e];
+    }
+  };
+  auto step = [&](auto b_tag, uint32_t j) {
+    constexpr int b = decltype(b_tag)::value;
+    load(std::integral_constant<int, (b + NBUF - 1) % NBUF>{}, j + NBUF - 1);
+    compute(b_tag);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    if (yield_every) {
+      const uint32_t ev = yield_every & 255u, amt = yield_every >> 8;
+      if ((j % ev) == 0) { if (amt <= 1) __builtin_amdgcn_s_sleep(1); else if (amt == 2) __builtin_amdgcn_s_sleep(2); else if (amt == 3) __builtin_amdgcn_s_sleep(3); else __builtin_amdgcn_s_sleep(4); }   // (yield_every: period | naps of 64 cycles << 8)
+    }
+  };
+  sa_static_for<0, NBUF - 1>([&](auto b) { load(b, (uint32_t)decltype(b)::value); __builtin_amdgcn_sched_barrier(0); });
+  SA_STAMP(tr, 1);
+  uint32_t j = 0;
+  for (; j + NBUF <= mine; j += NBUF) sa_static_for<0, NBUF>([&](auto b) { step(b, j + decltype(b)::value); });
+  const uint32_t rem = mine - j;
+  sa_static_for<0, NBUF>([&](auto b) { if ((uint32_t)decltype(b)::value < rem) step(b, j + decltype(b)::value); });
+  SA_STAMP(tr, 2);
+  f32x4* red = (f32x4*)lds;           // [4 waves][6][64 lanes]
+  float* rn = lds + SA_KS96_RED;      // [4 waves][32]
+  if (kg == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w4 * 6 + g) * 64 + lane] = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) red[(w4 * 6 + 4 + g) * 64 + lane] = f32x4{acc2[8 + 4 * g], acc2[9 + 4 * g], acc2[10 + 4 * g], acc2[11 + 4 * g]};
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w4 * 6 + g) * 64 + lane] = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) red[(w4 * 6 + 4 + g) * 64 + lane] = f32x4{acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
+  }
+  if constexpr (NORM) {
+    ns += __shfl_xor(ns, 32);
+    if (lh == 0) rn[w4 * 32 + lr] = ns;
+  }
+  __syncthreads();
+  const uint32_t pw = w4 ^ 1u;
+  if (kg == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = red[(pw * 6 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[4 * g + c] = acc0[4 * g + c] + o[c];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 o = red[(pw * 6 + 4 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out2[4 * g + c] = acc2[4 * g + c] + o[c];
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = red[(pw * 6 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[4 * g + c] = o[c] + acc1[4 * g + c];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 o = red[(pw * 6 + 4 + g) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out2[4 * g + c] = o[c] + acc2[8 + 4 * g + c];
+    }
+  }
+  if constexpr (NORM) *nsq = rn[(wm * 2) * 32 + lr] + rn[(wm * 2 + 1) * 32 + lr];
+  __syncthreads();  // the epilogue reuses this LDS
+}
+
 // The k-split loop for the 64 x 128 tile: wave (wm, kg) owns tile rows wm 32 .. +31, ALL 128 columns (four accumulators) and every second
 // 8-deep k-step — one row-major gather of A and four fragment-order loads of B per 16 matrix instructions (the direct loop's 32 x 64 wave
 // tiles: 6 per 16, and every fragment loaded by two waves), nothing loaded twice.  Wave (wm, x) keeps columns x 64 .. +63 and ships its other
@@ -1226,6 +1347,168 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   SA_STAMP(tr, 5);
 }
 
+// A 64 x 96 tile of the fused first phase: cosine, one observation per track, the BestFit vote reduced into the vote words (raw candidate
+// rows: see visual_cosine_tile's RAW / PART mode, whose cells, keys and tie rules these are).  For frames whose 64 x 64 tiles would be one and
+// a half rounds of the chip — 1000 detections against 1100 .. 1536 tracks: 272 .. 384 tiles, every CU that gets two of them runs twice as
+// long as the others — 256 tiles of one and a half times the work each leave nothing unbalanced (sa_launch_frame_visual picks the form).
+// Wave (wm, x) evaluates its 32 x 32 block of columns x 32 .. (16 cells per lane) and eight rows' worth of columns 64 .. 95 (8 cells).
+__device__ __forceinline__ void visual_tile96(const SceneDev& S, const SaParams& p, uint32_t bx, uint32_t by, float* lds) {
+  constexpr int BM = 64, BN = 96;
+  uint64_t* tr = SA_TRACE_PTR();
+  SA_STAMP(tr, 0);
+  const uint32_t N = S.N, TK = S.TK, K = S.K;
+  const uint32_t m0 = by * BM, n0 = bx * BN;
+  if (m0 >= N || n0 >= TK) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w4 = (tid >> 6) & 3u;
+  const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
+  // row operands, fetched before the contraction (thread r < 64 holds row r): what frame_prep_block derives for the candidate
+  float pre_us = 0.f;
+  sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  if (tid < (uint32_t)BM && m0 + tid < N) {
+    const uint32_t gi = m0 + tid;
+    const BoxRaw r = sa_ldg(S.c_raw + gi);
+    const sa_box& b = r.box;
+    pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
+    bool usable = false;
+    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
+      const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
+      bool perc_ok = true;
+      if (S.flags & SCN_HAS_OWN) {
+        const float oa = S.c_own[gi];
+        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
+      }
+      usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
+    }
+    pre_us = usable ? 1.f : 0.f;
+  }
+  GemmCols col[2];   // [0]: column x 32 + lr of the tile, [1]: column 64 + lr
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const uint32_t gj = n0 + (n == 0 ? wn * 32u : 64u) + lr;
+    col[n].ok = false;
+    col[n].nb = 0.f;
+    col[n].cmax = -1.0f;
+    col[n].g = sa_geo{0.f, 0.f, 0.f, 0.f};
+    if (gj < TK) {
+      const uint32_t t = gj / K;
+      const float nb = S.t_fnorm[gj];
+      const uint8_t pres = S.t_fpresent[gj];
+      const uint32_t cnt = S.t_fcount[t];
+      const uint64_t te = S.t_epoch[t];
+      col[n].g = sa_ldg(S.t_geo + t);
+      col[n].nb = nb;
+      const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
+      col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
+      for (uint32_t i = 0; i < p.cons.n; ++i)
+        if (p.cons.delta[i] >= delta) { col[n].cmax = p.cons.max_dist[i]; break; }
+    }
+  }
+  f32x16 acc;
+  float acc2[8];
+  float nsq = 0.f;
+  gemm_mainloop_ks96<3, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc, acc2, tr, &nsq, p.ks_yield);
+  SA_STAMP(tr, 3);
+  float* s_na = lds;                      // [BM]
+  sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
+  float* s_np = lds + 6 * BM;             // [BM] squared norms of the candidates' rows
+  unsigned long long* s_ck = (unsigned long long*)(lds + 7 * BM);  // [BN] (weight key << 32) | row, minimum per column
+  constexpr uint32_t KS = BN + 4;
+  uint32_t* s_key = (uint32_t*)(lds + 7 * BM + 2 * BN);            // [64][KS] order-preserving keys of the tile's cells
+  if (tid < (uint32_t)BM) s_g[tid] = pre_g;
+  for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) s_ck[i] = ~0ull;
+  if (wn == 0 && lh == 0) s_np[wm * 32 + lr] = nsq;
+  __syncthreads();
+  if (tid < (uint32_t)BM) s_na[tid] = pre_us != 0.f ? s_np[tid] : __builtin_nanf("");  // the feature_can_be_used gate rides in the norm
+  __syncthreads();
+  uint32_t kmax = 0;
+  // ---- the 32 x 32 block: registers 4g .. 4g+3 = tile rows wm 32 + 8g + 4 lh .. +3 ----
+  {
+    const uint32_t lc = wn * 32 + lr;
+    f32x4 nav[4];
+    uint32_t rbase[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rbase[g] = wm * 32 + 8u * g + 4u * lh;
+      nav[g] = *(const f32x4*)(s_na + rbase[g]);
+    }
+    uint32_t ckey = 0xffffffffu, crow = 0;
+    const uint32_t cfail = constraint_mask<16>(col[0], [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t li = rbase[i >> 2] + (i & 3);
+      const uint32_t gi = m0 + li;
+      bool flagged;
+      const float w = visual_cell<false>(p, acc[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[0], &kmax, &flagged);
+      const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
+      s_key[li * KS + lc] = key;
+      if (key < ckey) { ckey = key; crow = gi; }  // rows ascend with i: the lowest row wins ties
+    }
+    unsigned long long cb = ((unsigned long long)ckey << 32) | crow;
+    const unsigned long long ob = __shfl_xor(cb, 32);
+    cb = ob < cb ? ob : cb;
+    if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);
+  }
+  // ---- this wave's half of columns 64 .. 95: accumulator registers 8 wn .. 8 wn + 7 ----
+  {
+    const uint32_t lc = 64 + lr;
+    f32x4 nav[2];
+    uint32_t rbase[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      rbase[g] = wm * 32 + 8u * (2u * wn + g) + 4u * lh;
+      nav[g] = *(const f32x4*)(s_na + rbase[g]);
+    }
+    uint32_t ckey = 0xffffffffu, crow = 0;
+    const uint32_t cfail = constraint_mask<8>(col[1], [&](int c) { return s_g + rbase[c >> 2] + (c & 3); });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t li = rbase[i >> 2] + (i & 3);
+      const uint32_t gi = m0 + li;
+      bool flagged;
+      const float w = visual_cell<false>(p, acc2[i], nav[i >> 2][i & 3], (cfail >> i) & 1u, col[1], &kmax, &flagged);
+      const uint32_t key = (w == w && gi < N) ? sa_f32_key(w) : 0xffffffffu;
+      s_key[li * KS + lc] = key;
+      if (key < ckey) { ckey = key; crow = gi; }
+    }
+    unsigned long long cb = ((unsigned long long)ckey << 32) | crow;
+    const unsigned long long ob = __shfl_xor(cb, 32);
+    cb = ob < cb ? ob : cb;
+    if (lh == 0 && (uint32_t)(cb >> 32) != 0xffffffffu) atomicMin(&s_ck[lc], cb);   // (the column's other rows: wave (wm, 1 - wn) and the other wave row)
+  }
+  SA_STAMP(tr, 6);
+  __syncthreads();  // the key tile and the column minima complete
+  {
+    // a row's lightest weight over the tile's columns (lowest column on ties): four threads per row, 24 columns each
+    const uint32_t rr = tid >> 2, seg = tid & 3u;
+    const uint32_t* kp = s_key + rr * KS + seg * 24u;
+    uint32_t bk = 0xffffffffu, bc = 0;
+#pragma unroll
+    for (uint32_t c4 = 0; c4 < 24u; c4 += 4) {
+      const uint4 v = *(const uint4*)(kp + c4);
+      if (v.x < bk) { bk = v.x; bc = c4; }
+      if (v.y < bk) { bk = v.y; bc = c4 + 1; }
+      if (v.z < bk) { bk = v.z; bc = c4 + 2; }
+      if (v.w < bk) { bk = v.w; bc = c4 + 3; }
+    }
+    bc += seg * 24u;
+    auto take = [&](uint32_t ok, uint32_t oc) { if (ok < bk || (ok == bk && oc < bc)) { bk = ok; bc = oc; } };
+    take((uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0xB1, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)bc, 0xB1, 0xF, 0xF, true));
+    take((uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0x4E, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)bc, 0x4E, 0xF, 0xF, true));
+    const uint32_t gi = m0 + rr;
+    if (seg == 0 && gi < N && bk != 0xffffffffu)
+      __hip_atomic_fetch_min(S.row_best + gi, ((unsigned long long)bk << 32) | (n0 + bc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SA_STAMP(tr, 7);
+  for (uint32_t i = tid; i < (uint32_t)BN; i += blockDim.x) {
+    const uint32_t gj = n0 + i;
+    if (gj >= TK) continue;
+    const unsigned long long k2 = s_ck[i];
+    if (k2 != ~0ull) __hip_atomic_fetch_min(S.col_best + gj, k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SA_STAMP(tr, 4);
+  SA_STAMP(tr, 5);
+}
+
 // Deeper banks (K = 2 .. SA_CLS_MAXK observations per track) WITHOUT the N x T x K weight matrix and without k_bestfit_tile: the
 // whole-track tile of the fused frame launch.  A 64-column tile of the contraction holds the observations of floor(64 / K) WHOLE
 // tracks (its first column is bank row bx floor(64 / K) K: the B operand stays one contiguous run of rows; the 64 mod K columns left
@@ -1446,8 +1729,8 @@ static void launch_cosine(uint32_t maxTK, uint32_t maxN, uint32_t ns, hipStream_
 // the LDS the MFMA-bound contraction leaves idle on every CU instead of costing two more dependent launches.  Tiles are
 // dispatched in blockIdx order: the contraction's (longest) first.  All kinds share ONE static LDS buffer (a kernel's
 // static LDS is the sum of its arrays: separate arrays would cut the residency to one block per CU and serialise the kinds).
-template <int KG, bool PART, bool EU = false, bool KP = false, bool KSL = false>
-__global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
+template <int KG, bool PART, bool EU = false, bool KP = false, bool KSL = false, bool W96 = false>
+__global__ __launch_bounds__(256 * KG, W96 ? 4 : 1) void k_frame_visual(const SceneDev* __restrict__ scenes, SaParams p, uint32_t gx, uint32_t gy,
                                                            uint32_t px, uint32_t py, uint32_t nprep_, uint32_t xo_) {
   // nprep_: preparation blocks of the launch; bit 31: they run their RESET half only, bit 30: the positional tiles also feed the
   // many-workgroup tail (row-major edge lists, row duals, union-find: UNION) — frames beyond the one-workgroup tail's 1024 x 1024
@@ -1461,6 +1744,7 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   constexpr uint32_t LDSF = (KG * POS_LDS + 3u) / 4u > (uint32_t)(KG * 2 * (64 + 64) * BK) ? (KG * POS_LDS + 3u) / 4u : (uint32_t)(KG * 2 * (64 + 64) * BK);
   __shared__ __attribute__((aligned(16))) float lds[LDSF];   // (35.6 KB with the 16 x 256 positional tile: four blocks per CU as before)
   static_assert(gemm_lds_floats(64, 64, KSL ? 9 : KG, PART, EU) <= LDSF, "the contraction tile must fit the launch's LDS");
+  static_assert(!W96 || (KSL && PART && !EU && !KP && KG == 1 && SA_KS96_LDS <= LDSF && 7 * 64 + 2 * 96 + 64 * 100 <= LDSF), "the 64 x 96 tile: cosine vote-word frames on the k-split loop");
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   // Contraction tiles first in blockIdx order: the dispatcher hands blocks out in that order, breadth-first over the CUs, so
   // every CU starts with (at most) one contraction tile and fills its remaining slots with the other kinds.  Interleaving the
@@ -1472,7 +1756,8 @@ __global__ __launch_bounds__(256 * KG) void k_frame_visual(const SceneDev* __res
   if (b < (xW ? 8u * xchunk : xchunk)) {
     uint32_t tbx, tby;
     if (!xcd_tile(b, gx, gy, xchunk, xW, &tbx, &tby)) return;
-    if constexpr (KP) visual_ktile<EU, KSL>(S, p, tbx, tby, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
+    if constexpr (W96) visual_tile96(S, p, tbx, tby, lds);         // (gx counts tiles of 96 columns here)
+    else if constexpr (KP) visual_ktile<EU, KSL>(S, p, tbx, tby, lds);  // (gx counts tiles of floor(64 / K) whole tracks here)
     else visual_cosine_tile<64, 64, KSL ? 9 : KG, true, PART, EU>(S, p, tbx, tby, lds);
     return;
   }
@@ -1858,6 +2143,7 @@ static inline void sa_trace_hook(hipStream_t, uint32_t) {}
 // Frames that fit in one round of 64x64 tiles split k over 2 or 4 wave groups inside each workgroup so that every SIMD
 // still holds 2-4 waves.
 static inline int tile_plan(uint32_t M, uint32_t Ncols, uint32_t ns, uint32_t Dp, int32_t plan_override = -1) {
+  if (plan_override == 19) return 9;             // (19: the fused first phase's 64 x 96 tiles pinned — everything else sees the 64 x 64 k-split plan)
   if (plan_override >= 0) return plan_override;  // sa_config.gemm_plan: tuning / tests
   struct Cand { int plan, bm, bn; };
   const Cand cands[4] = {{0, 128, 128}, {5, 64, 128}, {6, 128, 64}, {1, 64, 64}};
@@ -1925,11 +2211,26 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   // frames (a longer epilogue: +2.5 %) and deeper banks (several matrix waves per SIMD: no difference) do not take it.
   SaParams p_ = p_in;
   p_.ks_yield = (p_in.no_yield || kpass || (p_in.visual_kind == SA_VIS_EUCLIDEAN && p_in.eu_mfma)) ? 0u : 1u;
+
   const SaParams& p = p_;
   const bool eu = p.visual_kind == SA_VIS_EUCLIDEAN && p.eu_mfma;
   if (!sa_frame_visual_ok(ns, maxN, maxT, K, D, p, kpass)) return hipErrorNotSupported;
   const uint32_t maxTK = maxT * K;
-  const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : cdiv(maxTK, 64), gy = cdiv(maxN, 64), py = cdiv(maxN, POS_TI);
+  const uint32_t gy = cdiv(maxN, 64), py = cdiv(maxN, POS_TI);
+  // Tiles of 64 x 96 where they take fewer rounds of the chip's 256 CUs than 64 x 64 ones cost (one and a half times the work each): the
+  // frames between one and one and a half rounds of 64 x 64 tiles — c2t, 1000 x 1500: 384 tiles, half the CUs with two; 256 of 64 x 96.
+  // Cosine frames that vote through the vote words (visual_tile96); sa_config.gemm_plan = 19 + 1 pins the form (tests).
+  bool w96 = false;
+  if (!kpass && !eu && partials && p.vote_words && K == 1 && !p.staged_loop) {
+    const size_t t64 = (size_t)cdiv(maxTK, 64) * gy * ns, t96 = (size_t)cdiv(maxTK, 96) * gy * ns;
+    w96 = p.gemm_plan == 19 || (p.gemm_plan < 0 && ((t96 + 255) / 256) * 3 < ((t64 + 255) / 256) * 2);
+  }
+  // (their matrix waves nap 128 cycles per k-step of 12 matrix instructions — such a frame brings three positional tiles per CU, which
+  // end the launch: c2t first phase 24.4-25.0 us without naps, 23.9-24.3 with 64 cycles, 22.7-23.1 with 128, 23.0-23.2 with 192, 24.6 with
+  // 256.  As compiled: with the nap's length chosen by a two-way branch instead of the loop's four-way one the 128-cycle form read 24.0 —
+  // the scalar instructions between two k-steps are part of the gap the positional waves get)
+  if (w96 && p_.ks_yield) p_.ks_yield = 1u | (2u << 8);
+  const uint32_t gx = kpass ? cdiv(maxT, 64u / K) : w96 ? cdiv(maxTK, 96) : cdiv(maxTK, 64);
   uint32_t px = cdiv(maxT, 128);
   // preparation blocks: 1 = all of them (one wave per feature row: N / 4), 3 = the reset half only (one thread per row / column),
   // 0 = none (a lean frame on the one-workgroup tail: nothing on its path reads what they write, enqueue_frame)
@@ -1965,7 +2266,8 @@ hipError_t sa_launch_frame_visual(const SceneDev* scenes, uint32_t ns, uint32_t 
   if (eu) {
     if (partials) SA_FV(true, true, false);
     else SA_FV(false, true, false);
-  } else if (partials) SA_FV(true, false, false);
+  } else if (w96) SA_LAUNCH((k_frame_visual<1, true, false, false, true, true>), grid, dim3(256), 0, st, scenes, p, gx, gy, px, py, np, xo_);
+  else if (partials) SA_FV(true, false, false);
   else SA_FV(false, false, false);
 #undef SA_FV
   return hipGetLastError();

@@ -752,6 +752,42 @@ def test_visual_cosine_parity(k, n, t, d, fused):
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 0
 
 
+@pytest.mark.paths("general", "never_lean", "row_tiles", "xcd_tiles", "no_yield")
+@pytest.mark.parametrize("n,t,d", [(150, 170, 512), (70, 33, 96), (129, 257, 64), (300, 280, 64), (64, 96, 32), (65, 97, 32), (5, 3, 32), (200, 700, 32)])
+def test_visual_cosine_parity_on_64x96_tiles(n, t, d):
+    """The fused first phase's 64 x 96 tiles (what frames of 1.0 .. 1.5 rounds of 64 x 64 tiles take: sa_launch_frame_visual), pinned
+    on small frames (gemm_plan 19): ragged edges in both directions, tiles whose third column block is empty or partial, the vote words
+    of the timed launch against the oracle's matrix (check_votes inside visual_run), ids and vote types."""
+    rng = np.random.default_rng(1900 + n + t + d)
+    sc = synth.visual_scene(rng, t, n, d, 1, canvas=(1500.0, 900.0), new_fraction=0.1)
+    pres = sc["track_present"]
+    pres[rng.uniform(size=pres.shape) < 0.15] = 0
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, visual_minimal_quality_use=0.55,
+                          visual_minimal_area=3000.0, positional_min_confidence=0.1, max_idle_epochs=5, gemm_plan=19)
+    ids, votes, ref = check_visual(cfg, sc)
+    if n >= 64:
+        assert (votes == abi.SA_VOTE_VISUAL).sum() > 0
+
+
+def test_visual_cosine_1000_x_1500_takes_the_64x96_tiles_by_itself():
+    """c2t's shape (384 tiles of 64 x 64 = one and a half rounds of the chip: the launch picks 256 tiles of 64 x 96), full size against
+    the oracle; and the same frame with the 64 x 64 tiles pinned (gemm_plan 9): the same ids and vote types."""
+    rng = np.random.default_rng(1501)
+    n, t, d = 1000, 1500, 512
+    sc = synth.visual_scene(rng, t, n, d, 1)
+    out = []
+    for plan in (None, 9):
+        cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                              max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                              max_idle_epochs=5, gemm_plan=plan)
+        ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
+        compare_visual(cfg, ids, votes, pos, vis, ref)
+        out.append((ids.copy(), votes.copy()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_visual_cosine_more_than_1024_detections():
     """N > 1024: the contraction's partials feed the resolve kernel, the positional vote goes through the many-workgroup tail, and
     the first phase is two launches (the heterogeneous launch is for frames of at most 1024 detections)."""
