@@ -774,13 +774,14 @@ int enqueue_frame(sa_engine* e, Bank* b, const SceneDev* ds, uint32_t ns, uint32
   // SA_FLAG_GENERAL_TAIL forces the many-workgroup tail on small frames (tests: both tails must agree with the oracle);
   // SA_FLAG_SEPARATE_RESOLVE keeps the vote's resolve step a launch of its own (no vote words)
   const bool force_general = (e->cfg.flags & SA_FLAG_GENERAL_TAIL) != 0;
-  const bool small_tail = maxN <= SA_SMALL_N && maxT <= SA_SMALL_N && !force_general;
+  const bool small_tail = sa_small_tail_ok(maxN, maxT, b->words) && !force_general;
   // vote words: with one observation per track the contraction's tiles reduce the vote straight into one 64-bit word per
   // candidate and per track (atomic minima, free at tile retirement: scripts/micro/atomic_min.hip), and the one-workgroup
   // tail reads its two words per thread — the resolve launch disappears
   const bool partials = b->partials;
   const bool words = b->words != 0;
   SaParams P = e->P;
+  P.force_general = small_tail ? 0u : 1u;  // (the launches below decide by this, not by the frame's size: the tail's reach depends on the vote's form too)
   P.vote_words = b->words == 1 ? 1u : 0u;  // the cost kernels reduce into the words only when they vote themselves (one observation per track)
   P.eu_mfma = b->eu_mfma ? 1u : 0u;
   P.eu_rho = e->eu_rho;

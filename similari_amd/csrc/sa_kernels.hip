@@ -632,11 +632,16 @@ __device__ __forceinline__ void sa_report_done(const SceneDev& S, uint64_t done_
     }
   }
 }
-template <bool VISUAL, bool WORDS, int G>
+// TC: columns per thread — 1: T <= 1024; 2: T <= 2048 (a tracker loop's table once idle tracks linger: more tracks than detections is its
+// normal state): every per-column array twice as long, the LDS edge pool given up for them (rows that lose their bid walk the HBM lists:
+// rare in tracking frames), no class words (SCN_WORDSK: the host keeps such frames on the many-workgroup tail beyond 1024 tracks).
+template <bool VISUAL, bool WORDS, int G, int TC = 1>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes, uint64_t done_seq) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
+  constexpr uint32_t TCAP = (uint32_t)TC * SA_SMALL_N;   // columns this instantiation holds
+  constexpr int DNT = SA_DENSE_NT * TC;                  // threads of the dense solver: four columns each (eight per thread cost the two-column form spilled registers)
   __shared__ uint32_t s_done;   // waves that have reported (sa_report_done)
   // a result on its way to the host's mapped block: with completion words as a SYSTEM-scope store — such a store is acknowledged when it
   // has reached the host's memory, a plain one when the L2 has taken it (measured: behind plain stores the completion word overtook the
@@ -648,28 +653,28 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   } while (0)
   __shared__ uint32_t s_head[SA_SMALL_N];  // per component root: the rows that lost their greedy bid (pushed in any order)
   __shared__ uint32_t s_next[SA_SMALL_N];
-  __shared__ int64_t s_u[SA_SMALL_N], s_v[SA_SMALL_N], s_dist[SA_SMALL_N];
-  __shared__ int32_t s_rmatch[SA_SMALL_N], s_cmatch[SA_SMALL_N], s_pred[SA_SMALL_N];
-  __shared__ uint32_t s_cstamp[SA_SMALL_N], s_cscan[SA_SMALL_N];
+  __shared__ int64_t s_u[SA_SMALL_N], s_v[TCAP], s_dist[TCAP];
+  __shared__ int32_t s_rmatch[SA_SMALL_N], s_cmatch[TCAP], s_pred[TCAP];
+  __shared__ uint32_t s_cstamp[TCAP], s_cscan[TCAP];
   __shared__ uint32_t s_lab[SA_SMALL_N];     // component root of a row with usable edges
-  __shared__ uint32_t s_cwin[SA_SMALL_N];    // per column: lowest row bidding for it
+  __shared__ uint32_t s_cwin[TCAP];          // per column: lowest row bidding for it
   __shared__ uint32_t s_rcount[SA_SMALL_N];  // per component root: search roots
   __shared__ uint32_t s_ccount[SA_SMALL_N];  // per component root: columns
-  __shared__ uint32_t s_clist[SA_SMALL_N];   // labelled columns of the running searches, one segment per component
+  __shared__ uint32_t s_clist[TCAP];         // labelled columns of the running searches, one segment per component
   __shared__ uint32_t s_rlist[SA_SMALL_N];   // search roots in ascending order, one segment per component
   __shared__ uint32_t s_queue[SA_SMALL_N];   // components waiting for a group
   __shared__ uint32_t s_ctr[8];              // queue length | next queue entry | top of s_clist | top of s_rlist | dense queue length
-  __shared__ unsigned long long s_part[2 * (SA_DENSE_NT / 64)];  // the dense solver's per-wave minima (sa_wg_min_u64)
+  __shared__ unsigned long long s_part[2 * (DNT / 64)];  // the dense solver's per-wave minima (sa_wg_min_u64)
   // The edge lists the positional tiles left behind live in HBM, one strided row per candidate: every access from here on would be
   // a dependent, uncoalesced round trip (the solve is a chain of them).  They are packed ONCE into an LDS pool — an
   // exclusive scan of the row counts gives the offsets — and the row duals, the connected components of the usable graph
   // (rows without a visual verdict) and the solve itself then run out of LDS.  A scene whose lists do not fit (dense
   // Mahalanobis frames, crowds under a low threshold) keeps the HBM lists as the solver's edge storage.
-  constexpr uint32_t POOL = 3072;
-  __shared__ uint32_t s_parent[2 * SA_SMALL_N];
+  constexpr uint32_t POOL = TC == 1 ? 3072 : 0;   // (two columns per thread: the pool's 36 KB are the second half of the column arrays)
+  __shared__ uint32_t s_parent[SA_SMALL_N + TCAP];
   __shared__ uint32_t s_ecnt[SA_SMALL_N], s_eoff[SA_SMALL_N], s_wsum[SA_SMALL_N / WAVE];
-  __shared__ uint32_t s_ecol[POOL];
-  __shared__ int64_t s_egain[POOL];
+  __shared__ uint32_t s_ecol[POOL ? POOL : 1];
+  __shared__ int64_t s_egain[POOL ? POOL : 1];
   TAIL_STAMP(0);
   const uint32_t rawcnt = q < N ? S.e_cnt[q] : 0u;
   if (q == 0) {  // what the first phase raised goes out with the results; re-armed for the next frame
@@ -678,9 +683,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     S.stats[0] = 0u;
     s_done = 0u;           // (barriers follow before any wave can leave)
   }
-  __shared__ uint8_t s_cexcl[WORDS ? SA_SMALL_N : 4];   // excluded_tracks as bytes, for the solver's HBM-list variant
+  __shared__ uint8_t s_cexcl[WORDS ? TCAP : 4];         // excluded_tracks as bytes, for the solver's HBM-list variant
   __shared__ uint32_t s_bt[WORDS ? SA_SMALL_N : 1];     // candidate -> its best column (SA_NONE: no group at all)
-  __shared__ uint32_t s_cq[WORDS ? SA_SMALL_N : 1];     // column -> its best candidate (SA_NONE: no group at all)
+  __shared__ uint32_t s_cq[WORDS ? TCAP : 1];           // column -> its best candidate (SA_NONE: no group at all)
   bool has_verdict;
   int32_t vw0 = -1;
   uint32_t bt = SA_NONE;
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   __shared__ uint32_t s_wmk[WORDS ? SA_SMALL_N / WAVE : 1];
   unsigned long long rcls[WORDS ? SA_CLS_MAXK : 1], ccls[WORDS ? SA_CLS_MAXK : 1];
   bool clsmode = false;
-  if constexpr (WORDS) clsmode = (S.flags & SCN_WORDSK) != 0;
+  if constexpr (WORDS && TC == 1) clsmode = (S.flags & SCN_WORDSK) != 0;
   if constexpr (WORDS) if (clsmode) {
     const uint32_t K = S.K;
     bool any = false;
@@ -741,19 +746,23 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
    if (!clsmode) {
     // (weight key << 32 | index), all ones = no group at all; lowest weight wins, lowest index on ties — k_bestfit_resolve's order
     const unsigned long long rb = q < N ? S.row_best[q] : ~0ull;
-    const unsigned long long cb = q < T ? S.col_best[q] : ~0ull;
+    unsigned long long cb[TC];
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; cb[cc] = j < T ? S.col_best[j] : ~0ull; }
     if (q < N) S.row_best[q] = ~0ull;
-    if (q < T) S.col_best[q] = ~0ull;
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; if (j < T) S.col_best[j] = ~0ull; }
     if (S.tap_row_best) {  // SA_FLAG_TAP: the words as the first phase left them
       if (q < N) S.tap_row_best[q] = rb;
-      if (q < T) S.tap_col_best[q] = cb;
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; if (j < T) S.tap_col_best[j] = cb[cc]; }
     }
     const uint32_t imask = (S.flags & SCN_WORDS10) ? 1023u : 0xffffffffu;  // deeper banks: (inverted weight key << 10) | index, k_bestfit_tile
     bt = rb != ~0ull ? ((uint32_t)rb & imask) : SA_NONE;
-    const uint32_t cq = cb != ~0ull ? ((uint32_t)cb & imask) : SA_NONE;
     has_verdict = bt != SA_NONE;  // feature_winners.contains_key(q)
     s_bt[q] = bt;
-    s_cq[q] = cq;
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) s_cq[q + (uint32_t)cc * SA_SMALL_N] = cb[cc] != ~0ull ? ((uint32_t)cb[cc] & imask) : SA_NONE;
    }
   } else {
     has_verdict = VISUAL && q < N && S.row_has[q];
@@ -791,10 +800,14 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   s_ecnt[q] = mycnt;
   s_head[q] = SA_NONE;
   s_next[q] = SA_NONE;
-  s_parent[q] = q;
-  s_parent[q + SA_SMALL_N] = q + SA_SMALL_N;
-  s_v[q] = 0; s_cmatch[q] = -1; s_cstamp[q] = 0; s_cscan[q] = 0;
-  s_cwin[q] = SA_NONE; s_rcount[q] = 0; s_ccount[q] = 0; s_lab[q] = SA_NONE;
+#pragma unroll
+  for (int cc = 0; cc <= TC; ++cc) s_parent[q + (uint32_t)cc * SA_SMALL_N] = q + (uint32_t)cc * SA_SMALL_N;
+#pragma unroll
+  for (int cc = 0; cc < TC; ++cc) {
+    const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+    s_v[j] = 0; s_cmatch[j] = -1; s_cstamp[j] = 0; s_cscan[j] = 0; s_cwin[j] = SA_NONE;
+  }
+  s_rcount[q] = 0; s_ccount[q] = 0; s_lab[q] = SA_NONE;
   if (q < 8) s_ctr[q] = 0;
   // exclusive scan of mycnt over the 1024 threads: wave scan, then the 16 wave totals
   uint32_t incl = mycnt;
@@ -831,7 +844,8 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   }
   if constexpr (WORDS) {
     if (has_verdict && s_cq[bt] == q) vw0 = (int32_t)bt;  // the candidate that is best in its own best column wins it
-    s_cexcl[q] = q < T && excluded(q);
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; s_cexcl[j] = j < T && excluded(j); }
   }
   uint32_t woff = 0, total = 0;
   for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) {
@@ -930,9 +944,13 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       atomicAdd(&s_rcount[lab], 1u);
     }
   }
-  if (q < T) {
-    const uint32_t r = sa_uf_find(s_parent, N + q);
-    if (r < N) atomicAdd(&s_ccount[r], 1u);  // a column without usable edges is its own root (>= N)
+#pragma unroll
+  for (int cc = 0; cc < TC; ++cc) {
+    const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+    if (j < T) {
+      const uint32_t r = sa_uf_find(s_parent, N + j);
+      if (r < N) atomicAdd(&s_ccount[r], 1u);  // a column without usable edges is its own root (>= N)
+    }
   }
   sa_lds_barrier();
   TAIL_STAMP(3);
@@ -1038,7 +1056,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   if (nd) {
     // The dense solver runs on SA_DENSE_NT threads (one wave per SIMD: a search step is a chain of dependent instructions, more
     // waves per SIMD only stretch it): the other waves are done — a barrier waits for the surviving waves only.
-    if (q >= SA_DENSE_NT) { sa_report_done(S, done_seq, &s_done); return; }
+    if (q >= (uint32_t)DNT) { sa_report_done(S, done_seq, &s_done); return; }
     uint32_t rtop = s_ctr[3];
     for (uint32_t k = 0; k < nd; ++k) {
       const uint32_t root = s_queue[SA_SMALL_N - 1u - k];
@@ -1059,7 +1077,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       if (q == 0) s_ctr[5] = 0;  // the component's heaviest gain (32-bit variant of the solver when it is small enough)
       sa_lds_barrier();
       uint32_t mg = 0;
-      for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
+      for (uint32_t row = q; row < N; row += (uint32_t)DNT) {
         if (s_lab[row] != root) continue;
         const int64_t heaviest = -s_u[row];
         const uint32_t h32 = heaviest > 0x7fffffffll ? 0x7fffffffu : (uint32_t)heaviest;
@@ -1087,11 +1105,11 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
         sa_dense_ws w;
         w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
         w.u = s_u; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.pred = s_pred; w.part = s_part;
-        if (s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN) sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT, true>(w, roots, R);
-        else sa_assign_component_dense<SA_DENSE_NT, SA_SMALL_N / SA_DENSE_NT, false>(w, roots, R);
+        if (s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN) sa_assign_component_dense<DNT, TCAP / DNT, true>(w, roots, R);
+        else sa_assign_component_dense<DNT, TCAP / DNT, false>(w, roots, R);
       }
       // results of the component's rows (none of them holds a visual verdict), and the matrix left clean for the next frame
-      for (uint32_t row = q; row < N; row += SA_DENSE_NT) {
+      for (uint32_t row = q; row < N; row += (uint32_t)DNT) {
         if (s_lab[row] != root) continue;
         const int32_t c = s_rmatch[row];
         SA_OUT(S.out_track_id + row, c >= 0 ? S.t_ids[c] : 0ull);
@@ -2117,7 +2135,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   const bool force_general = p.force_general != 0;
   // wide (16 x 256) positional tiles when the frame still gives at least one block per CU that way
   const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
-  const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_N || force_general;  // the one-workgroup tail builds duals and components itself
+  const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_T || force_general;  // the one-workgroup tail builds duals and components itself (enqueue_frame sets force_general for every frame it sends to the other tail)
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
@@ -2223,7 +2241,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     }
     default:
       sa_tail_trace_hook(st, ns);
-      if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      if (maxT > SA_SMALL_N) {   // two columns per thread (T <= SA_SMALL_T)
+        if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else SA_LAUNCH((k_assign_small<false, false, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      } else if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
       else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
       else SA_LAUNCH((k_assign_small<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
       break;
