@@ -754,6 +754,18 @@ struct sa_mem_plain {
   static SA_COOP_FN void sync() { sa_coop_sync<G>(); }
 };
 #if defined(__HIPCC__)
+// sa_mem_wg (device only): part of the state in HBM, touched by the waves of ONE workgroup (k_assign_small2: a search's labels and
+// distances live there, the duals and matches in LDS) — relaxed workgroup-scope accesses: the waves of a workgroup share their CU's vector
+// memory pipeline and its L1, which takes their accesses in order, so nothing is flushed and nothing is waited for beyond the compiler's order.
+template <int G>
+struct sa_mem_wg {
+  template <class T> static __device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  template <class T> static __device__ __forceinline__ void st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 template <int G>
 struct sa_mem_agent {
   template <class T> static __device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -303,7 +303,8 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t
 // class words (deeper banks: their tail keeps a register set per column) or the 10-bit index words
 #define SA_SMALL_T 2048
 static inline bool sa_small_tail_ok(uint32_t maxN, uint32_t maxT, uint32_t words) {
-  return maxN <= SA_SMALL_N && (maxT <= SA_SMALL_N || (maxT <= SA_SMALL_T && words != 2u && words != 3u));
+  if (maxN <= SA_SMALL_N && maxT <= SA_SMALL_N) return true;
+  return maxN <= SA_SMALL_T && maxT <= SA_SMALL_T && words != 2u && words != 3u;   // (k_assign_small<.., TC = 2> / k_assign_small2)
 }
 // done_seq != 0 (stages 5 / 8): every scene's workgroup reports the end of its results itself, by storing done_seq to SceneDev::out_done —
 // the host polls that word instead of waiting for a completion signal of the dispatch (a dispatch that carries one holds the NEXT

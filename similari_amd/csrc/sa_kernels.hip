@@ -1139,6 +1139,416 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   sa_report_done(S, done_seq, &s_done);
   TAIL_STAMP(7);
 }
+
+// The same tail for frames of up to SA_SMALL_T detections AND tracks (C4: 2000 x 2000 oriented boxes): two rows and two columns per thread.
+// What the 1024-row form keeps in LDS does not fit twice: the edge pool is given up (searches walk the HBM lists: rows that lose their
+// bid are rare in tracking frames), a running search's labels and distances (cstamp / cscan / dist / pred / its column list) live in
+// the scene's HBM arrays (sa_mem_wg: relaxed workgroup-scope accesses — one wave works on a component, on its CU's L1), row lists and
+// labels are 16-bit.  No class words (the host keeps such frames on the many-workgroup tail).  Every decision — bids, roots in ascending
+// order, the solvers — is k_assign_small's: the same ids.
+template <bool VISUAL, bool WORDS, int G>
+__global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __restrict__ scenes, uint64_t done_seq) {
+  const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
+  const uint32_t N = S.N, T = S.T;
+  const uint32_t q = threadIdx.x;
+  constexpr int RC = 2;                       // rows (and columns) per thread: q, q + 1024
+  constexpr uint32_t CAP = (uint32_t)RC * SA_SMALL_N;
+  constexpr int DNT = 512;                    // threads of the dense solver, four columns each
+  constexpr uint32_t NONE16 = 0xffffu;
+  __shared__ uint32_t s_done;
+  __shared__ uint32_t s_head[CAP];            // per component root: the rows that lost their greedy bid
+  __shared__ uint16_t s_next[CAP];
+  __shared__ int64_t s_u[CAP], s_v[CAP];
+  __shared__ int32_t s_rmatch[CAP], s_cmatch[CAP];
+  __shared__ uint16_t s_lab[CAP];             // component root of a row with usable edges (NONE16: none)
+  __shared__ uint32_t s_cwin[CAP];            // per column: lowest row bidding for it
+  __shared__ uint32_t s_rcount[CAP];          // per component root: search roots
+  __shared__ uint32_t s_ccount[CAP];          // per component root: columns
+  __shared__ uint32_t s_rlist[CAP];           // search roots in ascending order, one segment per component
+  __shared__ uint16_t s_queue[CAP];           // components waiting for a group (bottom) / for the dense solver (top)
+  __shared__ uint32_t s_ctr[8];
+  __shared__ unsigned long long s_part[2 * (DNT / 64)];
+  __shared__ uint32_t s_parent[2 * CAP];
+  __shared__ uint32_t s_ecnt[CAP], s_wsum[SA_SMALL_N / WAVE];
+  __shared__ uint8_t s_cexcl[WORDS ? CAP : 4];
+  __shared__ uint32_t s_bt[WORDS ? CAP : 1];
+  __shared__ uint32_t s_cq[WORDS ? CAP : 1];
+  TAIL_STAMP(0);
+  uint32_t rawcnt[RC];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) { const uint32_t row = q + (uint32_t)rr * SA_SMALL_N; rawcnt[rr] = row < N ? S.e_cnt[row] : 0u; }
+  if (q == 0) {
+    SA_OUT(S.out_stats + 0, S.stats[0]);
+    SA_OUT(S.out_stats + 1, 0u);
+    S.stats[0] = 0u;
+    s_done = 0u;
+  }
+  bool has_verdict[RC];
+  int32_t vw0[RC];
+  uint32_t bt[RC];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) { vw0[rr] = -1; bt[rr] = SA_NONE; has_verdict[rr] = false; }
+  if constexpr (WORDS) {
+    unsigned long long rb[RC], cb[RC];
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
+      rb[rr] = i < N ? S.row_best[i] : ~0ull;
+      cb[rr] = i < T ? S.col_best[i] : ~0ull;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
+      if (i < N) S.row_best[i] = ~0ull;
+      if (i < T) S.col_best[i] = ~0ull;
+      if (S.tap_row_best) {
+        if (i < N) S.tap_row_best[i] = rb[rr];
+        if (i < T) S.tap_col_best[i] = cb[rr];
+      }
+      bt[rr] = rb[rr] != ~0ull ? (uint32_t)rb[rr] : SA_NONE;
+      has_verdict[rr] = bt[rr] != SA_NONE;
+      s_bt[i] = bt[rr];
+      s_cq[i] = cb[rr] != ~0ull ? (uint32_t)cb[rr] : SA_NONE;
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+      has_verdict[rr] = VISUAL && row < N && S.row_has[row];
+      vw0[rr] = (VISUAL && row < N) ? S.vis_winner[row] : -1;
+    }
+  }
+  auto excluded = [&](uint32_t j) -> bool {
+    if constexpr (WORDS) {
+      const uint32_t c = s_cq[j];
+      return c != SA_NONE && s_bt[c] == j;
+    } else return S.col_excluded[j] != 0;
+  };
+  uint32_t sj[RC][4];
+  int64_t sg[RC][4];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    const SaEdge SA_G* rp = S.e_edge + (row < N ? row : 0);  // slot-major: edge k of row r at [k * N + r]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = !VISUAL && row < N && (uint32_t)k < T;
+      const SaEdge ed = in ? sa_ldg(rp + (size_t)k * N) : SaEdge{0, 0u, 0u};
+      sj[rr][k] = ed.col;
+      sg[rr][k] = ed.gain;
+    }
+  }
+  uint32_t mycnt[RC];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    if (row < N) S.e_cnt[row] = 0;
+    if (S.tap_ecnt && row < N) S.tap_ecnt[row] = rawcnt[rr];
+    mycnt[rr] = (row < N && !has_verdict[rr]) ? rawcnt[rr] : 0u;
+    s_rmatch[row] = -1;
+    s_ecnt[row] = mycnt[rr];
+    s_head[row] = SA_NONE;
+    s_next[row] = (uint16_t)NONE16;
+    s_rcount[row] = 0; s_ccount[row] = 0; s_lab[row] = (uint16_t)NONE16;
+    // this thread's two columns
+    s_v[row] = 0; s_cmatch[row] = -1; s_cwin[row] = SA_NONE;
+    if (row < T) { S.cstamp[row] = 0u; S.cscan[row] = 0u; }   // (a search's labels: in HBM here — read again only behind the __syncthreads in front of the searches)
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * RC; ++k) s_parent[q + (uint32_t)k * SA_SMALL_N] = q + (uint32_t)k * SA_SMALL_N;
+  if (q < 8) s_ctr[q] = 0;
+  {
+    uint32_t tsum = mycnt[0] + mycnt[1];
+    for (int o = WAVE / 2; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
+    if (q % WAVE == 0) s_wsum[q / WAVE] = tsum;
+  }
+  sa_lds_barrier();
+  if constexpr (WORDS) {
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
+      if (has_verdict[rr] && s_cq[bt[rr]] == i) vw0[rr] = (int32_t)bt[rr];  // the candidate that is best in its own best column wins it
+      s_cexcl[i] = i < T && excluded(i);
+    }
+  }
+  uint32_t total = 0;
+  for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) total += s_wsum[w2];
+  if (total == 0) {  // nothing left for the positional vote
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+      if (row < N) {
+        uint64_t id = 0;
+        uint8_t vt = SA_VOTE_NONE;
+        const int32_t vw = vw0[rr];
+        if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; }
+        SA_OUT(S.out_track_id + row, id);
+        SA_OUT(S.out_vote + row, vt);
+        S.win_col[row] = vw >= 0 ? vw : -1;
+        SA_OUT(S.out_win + row, vw >= 0 ? vw : -1);
+      }
+    }
+    sa_report_done(S, done_seq, &s_done);
+    return;
+  }
+  TAIL_STAMP(1);
+  if (VISUAL) {
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+      const SaEdge SA_G* rp = S.e_edge + (row < N ? row : 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const SaEdge ed = (uint32_t)k < mycnt[rr] ? sa_ldg(rp + (size_t)k * N) : SaEdge{0, 0u, 0u};
+        sj[rr][k] = ed.col;
+        sg[rr][k] = ed.gain;
+      }
+    }
+  }
+  bool sx[RC][4];
+  uint64_t sid[RC][4];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = (uint32_t)k < mycnt[rr];
+      sx[rr][k] = VISUAL && in && excluded(sj[rr][k]);
+      sid[rr][k] = in ? S.t_ids[sj[rr][k]] : 0ull;
+    }
+  uint32_t bcol[RC], usable[RC];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    int64_t maxg = 0;
+    bcol[rr] = SA_NONE;  // the column of the heaviest usable edge, lowest column on ties: this row's bid
+    usable[rr] = 0;
+    if (mycnt[rr]) {
+      const SaEdge SA_G* rp = S.e_edge + row;
+      for (uint32_t e0 = 0; e0 < mycnt[rr]; e0 += 4) {
+        uint32_t jj[4];
+        int64_t gg[4];
+        bool skip[4];
+        if (e0 == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { jj[k] = sj[rr][k]; gg[k] = sg[rr][k]; skip[k] = !((uint32_t)k < mycnt[rr]) || sx[rr][k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool in = e0 + k < mycnt[rr];
+            const SaEdge ed = in ? sa_ldg(rp + (size_t)(e0 + k) * N) : SaEdge{0, 0u, 0u};
+            jj[k] = ed.col;
+            gg[k] = ed.gain;
+            skip[k] = !in;
+          }
+          if (VISUAL) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (!skip[k]) skip[k] = excluded(jj[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (skip[k]) continue;
+          const uint32_t j = jj[k];
+          ++usable[rr];
+          if (gg[k] > maxg || (gg[k] == maxg && j < bcol[rr])) { maxg = gg[k]; bcol[rr] = j; }
+          sa_uf_union(s_parent, row, N + j);
+        }
+      }
+    }
+    s_u[row] = -maxg;
+    if (usable[rr]) atomicMin(&s_cwin[bcol[rr]], row);
+  }
+  sa_lds_barrier();
+  TAIL_STAMP(2);
+  uint32_t lab[RC];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    lab[rr] = SA_NONE;
+    if (usable[rr]) {
+      lab[rr] = sa_uf_find(s_parent, row);
+      s_lab[row] = (uint16_t)lab[rr];
+      if (s_cwin[bcol[rr]] == row) { s_rmatch[row] = (int32_t)bcol[rr]; s_cmatch[bcol[rr]] = (int32_t)row; }
+      else {
+        s_next[row] = (uint16_t)atomicExch(&s_head[lab[rr]], row);
+        atomicAdd(&s_rcount[lab[rr]], 1u);
+      }
+    }
+    if (row < T) {   // (the column `row`)
+      const uint32_t r = sa_uf_find(s_parent, N + row);
+      if (r < N) atomicAdd(&s_ccount[r], 1u);
+    }
+  }
+  sa_lds_barrier();
+  TAIL_STAMP(3);
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    if (lab[rr] == row && s_head[row] != SA_NONE) {
+      // (no LDS pool here: a component with many search roots goes to the dense solver whatever its width)
+      if (s_rcount[row] >= SA_DENSE_MIN_ROOTS) {
+        s_queue[CAP - 1u - atomicAdd(&s_ctr[4], 1u)] = (uint16_t)row;
+        s_ccount[row] |= 0x80000000u;
+      } else s_queue[atomicAdd(&s_ctr[0], 1u)] = (uint16_t)row;
+    }
+  }
+  __syncthreads();   // (also: the zeroed labels in HBM have left this CU's waves before any search reads them)
+  TAIL_STAMP(4);
+  {
+    const uint32_t lane = q % G;
+    const uint32_t nq = s_ctr[0];
+    sa_coop_ws w;
+    w.e_cnt = s_ecnt;
+    w.u = s_u; w.v = s_v; w.rmatch = s_rmatch; w.cmatch = s_cmatch;
+    w.dist = (int64_t*)S.dist; w.pred = (int32_t*)S.pred; w.cstamp = (uint32_t*)S.cstamp; w.cscan = (uint32_t*)S.cscan;
+    for (;;) {
+      uint32_t take[1], seg[2];
+      if (lane == 0) take[0] = atomicAdd(&s_ctr[1], 1u);
+      const uint32_t k = sa_coop_bcast<G>(take);
+      if (k >= nq) break;
+      const uint32_t root = s_queue[k];
+      const uint32_t R = s_rcount[root], C = s_ccount[root];
+      if (lane == 0) { seg[0] = atomicAdd(&s_ctr[2], C); seg[1] = atomicAdd(&s_ctr[3], R); }
+      const uint32_t cbase = sa_coop_bcast<G>(seg), rbase = sa_coop_bcast<G>(seg + 1);
+      uint32_t* roots = s_rlist + rbase;
+      if (R <= (uint32_t)G) {
+        uint32_t cur = s_head[root], mine = SA_NONE;
+        for (uint32_t st = 0; st < R; ++st) {
+          if (st == lane) mine = cur;
+          cur = s_next[cur & (CAP - 1u)];
+        }
+        uint32_t rank = 0;
+        for (uint32_t st = 0; st < R; ++st) {
+          const uint32_t other = __shfl(mine, st, G);
+          rank += other < mine ? 1u : 0u;
+        }
+        if (lane < R) roots[rank] = mine;
+      } else {
+        uint32_t cnt = 0;
+        for (uint32_t r0 = 0; r0 < N; r0 += G) {
+          const uint32_t row = r0 + lane;
+          bool f[1];
+          f[0] = row < N && s_lab[row] == (uint16_t)root && s_rmatch[row] < 0;
+          uint32_t tot;
+          const uint32_t rk = sa_coop_rank<G>(f, lane, &tot);
+          if (f[0]) roots[cnt + rk] = row;
+          cnt += tot;
+        }
+      }
+      sa_coop_sync<G>();
+      w.clist = (uint32_t*)S.cnext + cbase;
+      // slot-major HBM lists: row r starts at record r, consecutive edges are N records apart
+      w.e_col = (const uint32_t*)S.e_edge + 2; w.e_gain = (const int64_t*)S.e_edge; w.ecs = 4 * N; w.egs = 2 * N; w.rcs = 4; w.rgs = 2; w.e_off = nullptr; w.estride = 1;
+      if constexpr (WORDS) w.excluded = s_cexcl;
+      else w.excluded = VISUAL ? (const uint8_t*)S.col_excluded : nullptr;
+      sa_assign_component_coop<G, sa_mem_wg<G>>(w, roots, R);
+    }
+  }
+  TAIL_STAMP(5);
+  sa_lds_barrier();  // rmatch is in LDS
+  TAIL_STAMP(6);
+  const uint32_t nd = s_ctr[4];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+    const bool mine_later = nd && usable[rr] && (s_ccount[lab[rr]] & 0x80000000u);
+    if (row < N && !mine_later) {
+      uint64_t id = 0;
+      uint8_t vt = SA_VOTE_NONE;
+      int32_t win = -1;
+      const int32_t vw = vw0[rr];
+      if (vw >= 0) { id = S.t_ids[vw]; vt = SA_VOTE_VISUAL; win = vw; }
+      else if (!has_verdict[rr]) {
+        const int32_t c = s_rmatch[row];
+        if (c >= 0) {
+          bool found = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((uint32_t)k < mycnt[rr] && sj[rr][k] == (uint32_t)c) { id = sid[rr][k]; found = true; }
+          if (!found) id = S.t_ids[c];
+          vt = SA_VOTE_POSITIONAL;
+          win = c;
+        }
+      }
+      SA_OUT(S.out_track_id + row, id);
+      SA_OUT(S.out_vote + row, vt);
+      S.win_col[row] = win;
+      SA_OUT(S.out_win + row, win);
+    }
+  }
+  if (nd) {
+    if (q >= (uint32_t)DNT) { sa_report_done(S, done_seq, &s_done); return; }
+    uint32_t rtop = s_ctr[3];
+    for (uint32_t k = 0; k < nd; ++k) {
+      const uint32_t root = s_queue[CAP - 1u - k];
+      const uint32_t R = s_rcount[root];
+      uint32_t* roots = s_rlist + rtop;
+      rtop += R;
+      if (q < WAVE) {
+        uint32_t cnt = 0;
+        for (uint32_t r0 = 0; r0 < N; r0 += WAVE) {
+          const uint32_t row = r0 + q;
+          const bool f = row < N && s_lab[row] == (uint16_t)root && s_rmatch[row] < 0;
+          const unsigned long long m = __ballot(f);
+          if (f) roots[cnt + (uint32_t)__popcll(m & ((1ull << q) - 1ull))] = row;
+          cnt += (uint32_t)__popcll(m);
+        }
+      }
+      if (q == 0) s_ctr[5] = 0;
+      sa_lds_barrier();
+      uint32_t mg = 0;
+      for (uint32_t row = q; row < N; row += (uint32_t)DNT) {
+        if (s_lab[row] != (uint16_t)root) continue;
+        const int64_t heaviest = -s_u[row];
+        const uint32_t h32 = heaviest > 0x7fffffffll ? 0x7fffffffu : (uint32_t)heaviest;
+        mg = h32 > mg ? h32 : mg;
+        int64_t SA_G* drow = S.dense + (size_t)row * T;
+        const uint32_t cnt = s_ecnt[row];
+        const SaEdge SA_G* ep = S.e_edge + row;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
+          SaEdge ed[4];
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) ed[k2] = e0 + k2 < cnt ? sa_ldg(ep + (size_t)(e0 + k2) * N) : SaEdge{0, 0u, 0u};
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2)
+            if (e0 + k2 < cnt && !(VISUAL && excluded(ed[k2].col))) drow[ed[k2].col] = ed[k2].gain;
+        }
+      }
+      if (mg) atomicMax(&s_ctr[5], mg);
+      __syncthreads();
+      {
+        sa_dense_ws w;
+        w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
+        w.u = s_u; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.pred = (int32_t*)S.pred; w.part = s_part;
+        if (s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN) sa_assign_component_dense<DNT, CAP / DNT, true>(w, roots, R);
+        else sa_assign_component_dense<DNT, CAP / DNT, false>(w, roots, R);
+      }
+      for (uint32_t row = q; row < N; row += (uint32_t)DNT) {
+        if (s_lab[row] != (uint16_t)root) continue;
+        const int32_t c = s_rmatch[row];
+        SA_OUT(S.out_track_id + row, c >= 0 ? S.t_ids[c] : 0ull);
+        SA_OUT(S.out_vote + row, c >= 0 ? SA_VOTE_POSITIONAL : SA_VOTE_NONE);
+        S.win_col[row] = c;
+        SA_OUT(S.out_win + row, c);
+        int64_t SA_G* drow = S.dense + (size_t)row * T;
+        const uint32_t cnt = s_ecnt[row];
+        const SaEdge SA_G* ep = S.e_edge + row;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 4) {
+          uint32_t cj[4];
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) cj[k2] = e0 + k2 < cnt ? sa_ldg(ep + (size_t)(e0 + k2) * N).col : 0u;
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2)
+            if (e0 + k2 < cnt) drow[cj[k2]] = 0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  sa_report_done(S, done_seq, &s_done);
+  TAIL_STAMP(7);
+}
 #undef SA_OUT
 
 // General tail, kernel 1 of 2: every participating row finds its component (root = minimum vertex, always a row) and
@@ -2135,7 +2545,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   const bool force_general = p.force_general != 0;
   // wide (16 x 256) positional tiles when the frame still gives at least one block per CU that way
   const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
-  const bool uni = maxN > SA_SMALL_N || maxT > SA_SMALL_T || force_general;  // the one-workgroup tail builds duals and components itself (enqueue_frame sets force_general for every frame it sends to the other tail)
+  const bool uni = maxN > SA_SMALL_T || maxT > SA_SMALL_T || force_general;  // the one-workgroup tail builds duals and components itself (enqueue_frame sets force_general for every frame it sends to the other tail)
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
@@ -2241,7 +2651,11 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
     }
     default:
       sa_tail_trace_hook(st, ns);
-      if (maxT > SA_SMALL_N) {   // two columns per thread (T <= SA_SMALL_T)
+      if (maxN > SA_SMALL_N) {   // two rows and two columns per thread (N, T <= SA_SMALL_T)
+        if (stage == 8) SA_LAUNCH((k_assign_small2<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small2<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else SA_LAUNCH((k_assign_small2<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      } else if (maxT > SA_SMALL_N) {   // two columns per thread (T <= SA_SMALL_T)
         if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
         else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
         else SA_LAUNCH((k_assign_small<false, false, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);

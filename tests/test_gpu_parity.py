@@ -245,9 +245,9 @@ def test_random_crowd_frames_beyond_1024_tracks_match_the_oracle():
         canvas = (float(rng.uniform(700, 2600)), float(rng.uniform(600, 1600)))
         thr = float(rng.choice([0.1, 0.15, 0.2, 0.3]))
         sc = synth.sort_scene(rng, t, n, canvas=canvas, pos_sigma=float(rng.uniform(4.0, 14.0)))
-        # (up to 1024 detections x 2048 tracks the default engine takes the ONE-workgroup tail, two columns per thread: those frames run on
-        # both tails)
-        both = n <= 1024 and t <= 2048 and not (abi.EXTRA_FLAGS & abi.SA_FLAG_GENERAL_TAIL)
+        # (up to 2048 detections x 2048 tracks the default engine takes the ONE-workgroup tail — two columns, beyond 1024 detections also two
+        # rows per thread: those frames run on both tails)
+        both = n <= 2048 and t <= 2048 and not (abi.EXTRA_FLAGS & abi.SA_FLAG_GENERAL_TAIL)
         ref = None
         for flags in ((0, abi.SA_FLAG_GENERAL_TAIL) if both else (0,)):
           cfg = abi.make_config(positional="iou", positional_threshold=thr, max_idle_epochs=5, flags=flags)
@@ -1568,6 +1568,33 @@ def test_full_size_more_tracks_than_the_small_tail_holds_against_the_oracle(k):
     ids, votes, pos, vis, ref = _full_size_visual(cfg, sc)
     compare_visual(cfg, ids, votes, pos, vis, ref)
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 10 and (votes == abi.SA_VOTE_VISUAL).sum() > 700
+
+
+def test_c4_shaped_sort_frame_takes_two_launches():
+    """2000 x 2000 oriented SORT (BASELINE C4's shape): positional tiles + the one-workgroup tail with two rows and two columns per thread
+    (k_assign_small2) — two launches, not three; ids against the oracle."""
+    rng = np.random.default_rng(2000)
+    sc = synth.sort_scene(rng, 2000, 2000, canvas=(7000.0, 5000.0), oriented=True)
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
+    if abi.EXTRA_FLAGS:
+        pytest.skip("default path only")
+    tracks = abi.make_tracks(sc["track_ids"], sc["track_boxes"], sc["track_epochs"])
+    det = abi.make_detections(sc["det_boxes"])
+    eng = Engine(cfg)
+    try:
+        eng.upsert(0, tracks)
+        eng.associate(0, 1, det)
+        eng.profile_reset()
+        ids, votes = eng.associate(0, 1, det)
+        prof = eng.profile_read()
+    finally:
+        eng.close()
+    launched = {k for k, (n, _) in prof.items() if n and k != "d2h_results"}
+    assert launched == {"k_frame", "k_assign_small"}, prof
+    ref = O.associate(cfg, tracks, 1, det, want_matrices=False)
+    np.testing.assert_array_equal(ids, ref["track_id"])
+    np.testing.assert_array_equal(votes, ref["voting_type"])
+    assert (ids != 0).sum() > 1500
 
 
 @pytest.mark.parametrize("t,expect", [(1500, {"k_frame_visual", "k_assign_small"}), (2048, {"k_frame_visual", "k_assign_small"}),
