@@ -634,7 +634,7 @@ __device__ __forceinline__ void sa_report_done(const SceneDev& S, uint64_t done_
 }
 // TC: columns per thread — 1: T <= 1024; 2: T <= 2048 (a tracker loop's table once idle tracks linger: more tracks than detections is its
 // normal state): every per-column array twice as long, the LDS edge pool given up for them (rows that lose their bid walk the HBM lists:
-// rare in tracking frames), no class words (SCN_WORDSK: the host keeps such frames on the many-workgroup tail beyond 1024 tracks).
+// rare in tracking frames); class words (SCN_WORDSK) with a register set per column — what keeps them out of k_assign_small2.
 template <bool VISUAL, bool WORDS, int G, int TC = 1>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __restrict__ scenes, uint64_t done_seq) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
@@ -695,9 +695,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   // wins, lowest index among equals — folded from the first phase's per-tile slots by this workgroup (one slot per thread, the
   // wave maxima through LDS at the barrier that is there anyway), then one more barrier for the two tables.
   __shared__ uint32_t s_wmk[WORDS ? SA_SMALL_N / WAVE : 1];
-  unsigned long long rcls[WORDS ? SA_CLS_MAXK : 1], ccls[WORDS ? SA_CLS_MAXK : 1];
+  unsigned long long rcls[WORDS ? SA_CLS_MAXK : 1], ccls[TC][WORDS ? SA_CLS_MAXK : 1];
   bool clsmode = false;
-  if constexpr (WORDS && TC == 1) clsmode = (S.flags & SCN_WORDSK) != 0;
+  if constexpr (WORDS) clsmode = (S.flags & SCN_WORDSK) != 0;
   if constexpr (WORDS) if (clsmode) {
     const uint32_t K = S.K;
     bool any = false;
@@ -710,21 +710,34 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
       // load inside `c < K ? ... : ~0` every class became a scalar branch with its own load + s_waitcnt vmcnt(0) — K round trips
       // to memory one after the other, ~1 us per class
       rcls[c] = S.row_cls[(size_t)(q < N ? q : 0u) * K + (c < K ? c : K - 1u)];
-      ccls[c] = S.col_cls[(size_t)(q < T ? q : 0u) * K + (c < K ? c : K - 1u)];
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) {
+        const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+        ccls[cc][c] = S.col_cls[(size_t)(j < T ? j : 0u) * K + (c < K ? c : K - 1u)];
+      }
     }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
       rcls[c] = (c < K && q < N) ? rcls[c] : ~0ull;
-      ccls[c] = (c < K && q < T) ? ccls[c] : ~0ull;
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) ccls[cc][c] = (c < K && q + (uint32_t)cc * SA_SMALL_N < T) ? ccls[cc][c] : ~0ull;
     }
 #pragma unroll
     for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
       if (rcls[c] != ~0ull) S.row_cls[(size_t)q * K + c] = ~0ull;  // re-armed (most classes of a row are empty: nothing to store)
-      if (ccls[c] != ~0ull) S.col_cls[(size_t)q * K + c] = ~0ull;
+#pragma unroll
+      for (int cc = 0; cc < TC; ++cc) {
+        const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+        if (ccls[cc][c] != ~0ull) S.col_cls[(size_t)j * K + c] = ~0ull;
+      }
       if (S.tap_row_best && c < K) {  // SA_FLAG_TAP: the class words as the first phase left them ([N K] then [T K])
         if (q < N) S.tap_row_best[(size_t)q * K + c] = rcls[c];
-        if (q < T) S.tap_col_best[(size_t)q * K + c] = ccls[c];
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) {
+          const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+          if (j < T) S.tap_col_best[(size_t)j * K + c] = ccls[cc][c];
+        }
       }
       any = any || rcls[c] != ~0ull;
     }
@@ -740,7 +753,8 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     if (q % WAVE == 0) s_wmk[q / WAVE] = mk;
     has_verdict = any;  // feature_winners.contains_key(q)
     s_bt[q] = SA_NONE;  // (rows / columns beyond N / T)
-    s_cq[q] = SA_NONE;
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) s_cq[q + (uint32_t)cc * SA_SMALL_N] = SA_NONE;
   }
   if constexpr (WORDS) {
    if (!clsmode) {
@@ -839,7 +853,8 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
     };
     bt = best_of(rcls);
     s_bt[q] = bt;
-    s_cq[q] = best_of(ccls);
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) s_cq[q + (uint32_t)cc * SA_SMALL_N] = best_of(ccls[cc]);
     sa_lds_barrier();
   }
   if constexpr (WORDS) {

@@ -1597,15 +1597,17 @@ def test_c4_shaped_sort_frame_takes_two_launches():
     assert (ids != 0).sum() > 1500
 
 
-@pytest.mark.parametrize("t,expect", [(1500, {"k_frame_visual", "k_assign_small"}), (2048, {"k_frame_visual", "k_assign_small"}),
-                                      (2100, {"k_frame_visual", "k_assign_label", "k_assign_solve"})])
-def test_launches_of_frames_beyond_1024_tracks(t, expect):
+@pytest.mark.parametrize("t,k,expect", [(1500, 1, {"k_frame_visual", "k_assign_small"}), (2048, 1, {"k_frame_visual", "k_assign_small"}),
+                                        (1500, 3, {"k_frame_visual", "k_assign_small"}),
+                                        (2100, 1, {"k_frame_visual", "k_assign_label", "k_assign_solve"})])
+def test_launches_of_frames_beyond_1024_tracks(t, k, expect):
     """1000 detections against 1025 .. 2048 tracks (a tracker loop's table once idle tracks linger): first phase + the ONE-workgroup tail,
-    two columns per thread — two launches; beyond 2048 tracks: first phase, label, solve.  No stand-alone contraction, no resolve kernel."""
-    rng = np.random.default_rng(1503 + t)
-    sc = synth.visual_scene(rng, t, 1000, 128, 1)
+    two columns per thread — two launches, with vote words (one observation per track) and with class words (three); beyond 2048 tracks:
+    first phase, label, solve.  No stand-alone contraction, no resolve kernel."""
+    rng = np.random.default_rng(1503 + t + k)
+    sc = synth.visual_scene(rng, t, 1000, 128, k)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=128,
-                          max_observations=1, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=1, positional_min_confidence=0.1,
                           max_idle_epochs=5, flags=abi.SA_FLAG_PROFILE)
     if abi.EXTRA_FLAGS:
         pytest.skip("default path only")
