@@ -794,9 +794,10 @@ def test_visual_cosine_1000_x_1500_takes_the_64x96_tiles_by_itself():
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.paths("general", "separate_resolve")
 def test_visual_cosine_more_than_1024_detections():
-    """N > 1024: the contraction's partials feed the resolve kernel, the positional vote goes through the many-workgroup tail, and
-    the first phase is two launches (the heterogeneous launch is for frames of at most 1024 detections)."""
+    """N > 1024 (1100 detections, a fifth of them without a feature, against 900 tracks): the one-workgroup tail with two rows per thread
+    (k_assign_small2) behind the fused first phase — or, by the path markers, its verdict-array form and the many-workgroup tail."""
     rng = np.random.default_rng(1300)
     sc = synth.visual_scene(rng, 900, 1100, 64, 1, canvas=(3000.0, 2000.0), new_fraction=0.15)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=64,
@@ -1472,6 +1473,7 @@ def test_big_visual_frame_with_a_dense_positional_stage():
     assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 100 and (votes == abi.SA_VOTE_VISUAL).sum() > 500
 
 
+@pytest.mark.paths("general", "separate_resolve")   # (default: k_assign_small2 with vote words at K = 1; separate_resolve: its verdict-array form; general: the other tail)
 @pytest.mark.parametrize("visual,k", [("cosine", 1), ("euclidean", 2)])
 def test_visual_frame_whose_positional_stage_is_pairs_and_knots(visual, k):
     """1200 detections x 1500 tracks VisualSORT on the C2 canvas, 40 % of the detections new or below the quality gate: the
