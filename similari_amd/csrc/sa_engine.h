@@ -305,7 +305,8 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t
 #define SA_SMALL_T 2048
 static inline bool sa_small_tail_ok(uint32_t maxN, uint32_t maxT, uint32_t words) {
   if (maxN <= SA_SMALL_N && maxT <= SA_SMALL_N) return true;
-  if (words == 2u || maxT > SA_SMALL_T) return false;
+  if (words == 2u) return false;
+  if (maxT > SA_SMALL_T) return maxN <= SA_SMALL_N && maxT <= 2u * SA_SMALL_T && words != 3u;   // (k_assign_small2<.., 1, 4>: 1024 x 4096)
   return maxN <= SA_SMALL_N || (maxN <= SA_SMALL_T && words != 3u);   // (k_assign_small<.., TC = 2> / k_assign_small2)
 }
 // done_seq != 0 (stages 5 / 8): every scene's workgroup reports the end of its results itself, by storing done_seq to SceneDev::out_done —

@@ -1155,39 +1155,40 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small(const SceneDev* __r
   TAIL_STAMP(7);
 }
 
-// The same tail for frames of up to SA_SMALL_T detections AND tracks (C4: 2000 x 2000 oriented boxes): two rows and two columns per thread.
+// The same tail for wider frames — RC rows and TC columns per thread: 2 x 2 = up to SA_SMALL_T detections AND tracks (C4: 2000 x 2000
+// oriented boxes), 1 x 4 = up to 1024 detections against 4096 tracks (a crowd's tracker loop: `sdt`, 1000 x 2500).
 // What the 1024-row form keeps in LDS does not fit twice: the edge pool is given up (searches walk the HBM lists: rows that lose their
 // bid are rare in tracking frames), a running search's labels and distances (cstamp / cscan / dist / pred / its column list) live in
 // the scene's HBM arrays (sa_mem_wg: relaxed workgroup-scope accesses — one wave works on a component, on its CU's L1), row lists and
 // labels are 16-bit.  No class words (the host keeps such frames on the many-workgroup tail).  Every decision — bids, roots in ascending
 // order, the solvers — is k_assign_small's: the same ids.
-template <bool VISUAL, bool WORDS, int G>
+template <bool VISUAL, bool WORDS, int G, int RC = 2, int TC = 2>
 __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __restrict__ scenes, uint64_t done_seq) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
   const uint32_t N = S.N, T = S.T;
   const uint32_t q = threadIdx.x;
-  constexpr int RC = 2;                       // rows (and columns) per thread: q, q + 1024
-  constexpr uint32_t CAP = (uint32_t)RC * SA_SMALL_N;
-  constexpr int DNT = 512;                    // threads of the dense solver, four columns each
+  constexpr uint32_t RCAP = (uint32_t)RC * SA_SMALL_N, TCAP = (uint32_t)TC * SA_SMALL_N;   // rows / columns per thread: q, q + 1024, ...
+  constexpr int DNT = TC <= 2 ? 512 : 1024;   // threads of the dense solver, four columns each
+  static_assert(RCAP <= 2048u && (RC + TC) <= 5, "16-bit row links; LDS");
   constexpr uint32_t NONE16 = 0xffffu;
   __shared__ uint32_t s_done;
-  __shared__ uint32_t s_head[CAP];            // per component root: the rows that lost their greedy bid
-  __shared__ uint16_t s_next[CAP];
-  __shared__ int64_t s_u[CAP], s_v[CAP];
-  __shared__ int32_t s_rmatch[CAP], s_cmatch[CAP];
-  __shared__ uint16_t s_lab[CAP];             // component root of a row with usable edges (NONE16: none)
-  __shared__ uint32_t s_cwin[CAP];            // per column: lowest row bidding for it
-  __shared__ uint32_t s_rcount[CAP];          // per component root: search roots
-  __shared__ uint32_t s_ccount[CAP];          // per component root: columns
-  __shared__ uint32_t s_rlist[CAP];           // search roots in ascending order, one segment per component
-  __shared__ uint16_t s_queue[CAP];           // components waiting for a group (bottom) / for the dense solver (top)
+  __shared__ uint32_t s_head[RCAP];            // per component root: the rows that lost their greedy bid
+  __shared__ uint16_t s_next[RCAP];
+  __shared__ int64_t s_u[RCAP], s_v[TCAP];
+  __shared__ int32_t s_rmatch[RCAP], s_cmatch[TCAP];
+  __shared__ uint16_t s_lab[RCAP];             // component root of a row with usable edges (NONE16: none)
+  __shared__ uint32_t s_cwin[TCAP];            // per column: lowest row bidding for it
+  __shared__ uint32_t s_rcount[RCAP];          // per component root: search roots
+  __shared__ uint32_t s_ccount[RCAP];          // per component root: columns
+  __shared__ uint32_t s_rlist[RCAP];           // search roots in ascending order, one segment per component
+  __shared__ uint16_t s_queue[RCAP];           // components waiting for a group (bottom) / for the dense solver (top)
   __shared__ uint32_t s_ctr[8];
   __shared__ unsigned long long s_part[2 * (DNT / 64)];
-  __shared__ uint32_t s_parent[2 * CAP];
-  __shared__ uint32_t s_ecnt[CAP], s_wsum[SA_SMALL_N / WAVE];
-  __shared__ uint8_t s_cexcl[WORDS ? CAP : 4];
-  __shared__ uint32_t s_bt[WORDS ? CAP : 1];
-  __shared__ uint32_t s_cq[WORDS ? CAP : 1];
+  __shared__ uint32_t s_parent[RCAP + TCAP];
+  __shared__ uint32_t s_ecnt[RCAP], s_wsum[SA_SMALL_N / WAVE];
+  __shared__ uint8_t s_cexcl[WORDS ? TCAP : 4];
+  __shared__ uint32_t s_bt[WORDS ? RCAP : 1];
+  __shared__ uint32_t s_cq[WORDS ? TCAP : 1];
   TAIL_STAMP(0);
   uint32_t rawcnt[RC];
 #pragma unroll
@@ -1204,26 +1205,26 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
 #pragma unroll
   for (int rr = 0; rr < RC; ++rr) { vw0[rr] = -1; bt[rr] = SA_NONE; has_verdict[rr] = false; }
   if constexpr (WORDS) {
-    unsigned long long rb[RC], cb[RC];
+    unsigned long long rb[RC], cb[TC];
 #pragma unroll
-    for (int rr = 0; rr < RC; ++rr) {
-      const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
-      rb[rr] = i < N ? S.row_best[i] : ~0ull;
-      cb[rr] = i < T ? S.col_best[i] : ~0ull;
-    }
+    for (int rr = 0; rr < RC; ++rr) { const uint32_t i = q + (uint32_t)rr * SA_SMALL_N; rb[rr] = i < N ? S.row_best[i] : ~0ull; }
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; cb[cc] = j < T ? S.col_best[j] : ~0ull; }
 #pragma unroll
     for (int rr = 0; rr < RC; ++rr) {
       const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
       if (i < N) S.row_best[i] = ~0ull;
-      if (i < T) S.col_best[i] = ~0ull;
-      if (S.tap_row_best) {
-        if (i < N) S.tap_row_best[i] = rb[rr];
-        if (i < T) S.tap_col_best[i] = cb[rr];
-      }
+      if (S.tap_row_best && i < N) S.tap_row_best[i] = rb[rr];
       bt[rr] = rb[rr] != ~0ull ? (uint32_t)rb[rr] : SA_NONE;
       has_verdict[rr] = bt[rr] != SA_NONE;
       s_bt[i] = bt[rr];
-      s_cq[i] = cb[rr] != ~0ull ? (uint32_t)cb[rr] : SA_NONE;
+    }
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) {
+      const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+      if (j < T) S.col_best[j] = ~0ull;
+      if (S.tap_row_best && j < T) S.tap_col_best[j] = cb[cc];
+      s_cq[j] = cb[cc] != ~0ull ? (uint32_t)cb[cc] : SA_NONE;
     }
   } else {
 #pragma unroll
@@ -1265,15 +1266,20 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
     s_head[row] = SA_NONE;
     s_next[row] = (uint16_t)NONE16;
     s_rcount[row] = 0; s_ccount[row] = 0; s_lab[row] = (uint16_t)NONE16;
-    // this thread's two columns
-    s_v[row] = 0; s_cmatch[row] = -1; s_cwin[row] = SA_NONE;
-    if (row < T) { S.cstamp[row] = 0u; S.cscan[row] = 0u; }   // (a search's labels: in HBM here — read again only behind the __syncthreads in front of the searches)
   }
 #pragma unroll
-  for (int k = 0; k < 2 * RC; ++k) s_parent[q + (uint32_t)k * SA_SMALL_N] = q + (uint32_t)k * SA_SMALL_N;
+  for (int cc = 0; cc < TC; ++cc) {   // this thread's columns
+    const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+    s_v[j] = 0; s_cmatch[j] = -1; s_cwin[j] = SA_NONE;
+    if (j < T) { S.cstamp[j] = 0u; S.cscan[j] = 0u; }   // (a search's labels: in HBM here — read again only behind the __syncthreads in front of the searches)
+  }
+#pragma unroll
+  for (int k = 0; k < RC + TC; ++k) s_parent[q + (uint32_t)k * SA_SMALL_N] = q + (uint32_t)k * SA_SMALL_N;
   if (q < 8) s_ctr[q] = 0;
   {
-    uint32_t tsum = mycnt[0] + mycnt[1];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) tsum += mycnt[rr];
     for (int o = WAVE / 2; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
     if (q % WAVE == 0) s_wsum[q / WAVE] = tsum;
   }
@@ -1283,8 +1289,9 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
     for (int rr = 0; rr < RC; ++rr) {
       const uint32_t i = q + (uint32_t)rr * SA_SMALL_N;
       if (has_verdict[rr] && s_cq[bt[rr]] == i) vw0[rr] = (int32_t)bt[rr];  // the candidate that is best in its own best column wins it
-      s_cexcl[i] = i < T && excluded(i);
     }
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) { const uint32_t j = q + (uint32_t)cc * SA_SMALL_N; s_cexcl[j] = j < T && excluded(j); }
   }
   uint32_t total = 0;
   for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) total += s_wsum[w2];
@@ -1390,8 +1397,12 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
         atomicAdd(&s_rcount[lab[rr]], 1u);
       }
     }
-    if (row < T) {   // (the column `row`)
-      const uint32_t r = sa_uf_find(s_parent, N + row);
+  }
+#pragma unroll
+  for (int cc = 0; cc < TC; ++cc) {
+    const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+    if (j < T) {
+      const uint32_t r = sa_uf_find(s_parent, N + j);
       if (r < N) atomicAdd(&s_ccount[r], 1u);
     }
   }
@@ -1403,7 +1414,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
     if (lab[rr] == row && s_head[row] != SA_NONE) {
       // (no LDS pool here: a component with many search roots goes to the dense solver whatever its width)
       if (s_rcount[row] >= SA_DENSE_MIN_ROOTS) {
-        s_queue[CAP - 1u - atomicAdd(&s_ctr[4], 1u)] = (uint16_t)row;
+        s_queue[RCAP - 1u - atomicAdd(&s_ctr[4], 1u)] = (uint16_t)row;
         s_ccount[row] |= 0x80000000u;
       } else s_queue[atomicAdd(&s_ctr[0], 1u)] = (uint16_t)row;
     }
@@ -1431,7 +1442,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
         uint32_t cur = s_head[root], mine = SA_NONE;
         for (uint32_t st = 0; st < R; ++st) {
           if (st == lane) mine = cur;
-          cur = s_next[cur & (CAP - 1u)];
+          cur = s_next[cur & (RCAP - 1u)];
         }
         uint32_t rank = 0;
         for (uint32_t st = 0; st < R; ++st) {
@@ -1496,7 +1507,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
     if (q >= (uint32_t)DNT) { sa_report_done(S, done_seq, &s_done); return; }
     uint32_t rtop = s_ctr[3];
     for (uint32_t k = 0; k < nd; ++k) {
-      const uint32_t root = s_queue[CAP - 1u - k];
+      const uint32_t root = s_queue[RCAP - 1u - k];
       const uint32_t R = s_rcount[root];
       uint32_t* roots = s_rlist + rtop;
       rtop += R;
@@ -1536,8 +1547,10 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
         sa_dense_ws w;
         w.gain = (const int64_t*)S.dense; w.ld = T; w.T = T;
         w.u = s_u; w.rmatch = s_rmatch; w.cmatch = s_cmatch; w.pred = (int32_t*)S.pred; w.part = s_part;
-        if (s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN) sa_assign_component_dense<DNT, CAP / DNT, true>(w, roots, R);
-        else sa_assign_component_dense<DNT, CAP / DNT, false>(w, roots, R);
+        bool k32 = false;
+        if constexpr (TCAP <= SA_DENSE_K32_MAXT) k32 = s_ctr[5] <= (uint32_t)SA_DENSE_K32_MAXGAIN;
+        if constexpr (TCAP <= SA_DENSE_K32_MAXT) { if (k32) sa_assign_component_dense<DNT, TCAP / DNT, true>(w, roots, R); }
+        if (!k32) sa_assign_component_dense<DNT, TCAP / DNT, false>(w, roots, R);
       }
       for (uint32_t row = q; row < N; row += (uint32_t)DNT) {
         if (s_lab[row] != (uint16_t)root) continue;
@@ -2560,7 +2573,7 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   const bool force_general = p.force_general != 0;
   // wide (16 x 256) positional tiles when the frame still gives at least one block per CU that way
   const bool wide = (size_t)cdiv(maxT, 256) * cdiv(maxN, POS_TI) * ns >= 256;
-  const bool uni = maxN > SA_SMALL_T || maxT > SA_SMALL_T || force_general;  // the one-workgroup tail builds duals and components itself (enqueue_frame sets force_general for every frame it sends to the other tail)
+  const bool uni = maxN > SA_SMALL_T || maxT > 2u * SA_SMALL_T || force_general;  // the one-workgroup tail builds duals and components itself (enqueue_frame sets force_general for every frame it sends to the other tail)
   const uint32_t gx = maxT ? cdiv(maxT, wide ? 256 : 64) : 1u;
   const uint32_t pos_rows = (maxN && maxT && prep != 2) ? cdiv(maxN, POS_TI) : 0u;
   uint32_t prep_blocks = cdiv(maxN + maxT + 1, 256);
@@ -2670,6 +2683,10 @@ hipError_t sa_launch_assign(const SceneDev* scenes, uint32_t ns, uint32_t maxN, 
         if (stage == 8) SA_LAUNCH((k_assign_small2<true, true, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
         else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small2<true, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
         else SA_LAUNCH((k_assign_small2<false, false, 64>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+      } else if (maxT > SA_SMALL_T) {   // four columns per thread (N <= SA_SMALL_N, T <= 2 SA_SMALL_T)
+        if (stage == 8) SA_LAUNCH((k_assign_small2<true, true, 64, 1, 4>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small2<true, false, 64, 1, 4>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
+        else SA_LAUNCH((k_assign_small2<false, false, 64, 1, 4>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
       } else if (maxT > SA_SMALL_N) {   // two columns per thread (T <= SA_SMALL_T)
         if (stage == 8) SA_LAUNCH((k_assign_small<true, true, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);
         else if (p.visual_kind != SA_VIS_NONE) SA_LAUNCH((k_assign_small<true, false, 64, 2>), dim3(1, 1, ns), dim3(SA_SMALL_N), 0, st, scenes, done_seq);

@@ -247,7 +247,7 @@ def test_random_crowd_frames_beyond_1024_tracks_match_the_oracle():
         sc = synth.sort_scene(rng, t, n, canvas=canvas, pos_sigma=float(rng.uniform(4.0, 14.0)))
         # (up to 2048 detections x 2048 tracks the default engine takes the ONE-workgroup tail — two columns, beyond 1024 detections also two
         # rows per thread: those frames run on both tails)
-        both = n <= 2048 and t <= 2048 and not (abi.EXTRA_FLAGS & abi.SA_FLAG_GENERAL_TAIL)
+        both = ((n <= 2048 and t <= 2048) or (n <= 1024 and t <= 4096)) and not (abi.EXTRA_FLAGS & abi.SA_FLAG_GENERAL_TAIL)
         ref = None
         for flags in ((0, abi.SA_FLAG_GENERAL_TAIL) if both else (0,)):
           cfg = abi.make_config(positional="iou", positional_threshold=thr, max_idle_epochs=5, flags=flags)
@@ -1340,7 +1340,8 @@ def test_one_giant_component_against_the_oracle():
 @pytest.mark.paths("general")
 @pytest.mark.parametrize("sigma", [2.0, 12.0])
 @pytest.mark.parametrize("n,t,canvas", [(1000, 1000, (1920.0, 1080.0)), (1024, 1024, (700.0, 500.0)), (300, 900, (500.0, 400.0)),
-                                        (900, 1800, (1920.0, 1080.0)), (1000, 2048, (900.0, 600.0)), (640, 1100, (400.0, 300.0))])
+                                        (900, 1800, (1920.0, 1080.0)), (1000, 2048, (900.0, 600.0)), (640, 1100, (400.0, 300.0)),
+                                        (1000, 2500, (1920.0, 1080.0)), (700, 4096, (1200.0, 800.0))])
 def test_crowds_against_the_oracle(n, t, canvas, sigma):
     """Plain SORT on crowded frames (the C2 canvas without features, and denser): components of tens to hundreds of rows, pool and
     HBM-list edge storage; with 12 px of jitter dozens to hundreds of rows lose their greedy bid and need real augmenting paths.
@@ -1405,7 +1406,7 @@ def test_middle_tier_refusals_go_to_the_queue():
     assert big_rows.sum() == 240 and (ids[big_rows] != 0).all()
 
 
-@pytest.mark.parametrize("n,t", [(700, 700), (1300, 1200), (700, 1500)])
+@pytest.mark.parametrize("n,t", [(700, 700), (1300, 1200), (700, 1500), (600, 2600)])
 def test_mahalanobis_crowd_takes_the_64_bit_dense_solver(n, t):
     """Mahalanobis gains are 1e8-scale (cost <= 100 / confidence, x 1e6): beyond the 32-bit variant of the dense solver.  A crowd with
     genuine Kalman states on a small canvas — every detection inside the chi-square gate of dozens of tracks: components of hundreds
@@ -1601,11 +1602,15 @@ def test_c4_shaped_sort_frame_takes_two_launches():
 
 @pytest.mark.parametrize("t,k,expect", [(1500, 1, {"k_frame_visual", "k_assign_small"}), (2048, 1, {"k_frame_visual", "k_assign_small"}),
                                         (1500, 3, {"k_frame_visual", "k_assign_small"}),
-                                        (2100, 1, {"k_frame_visual", "k_assign_label", "k_assign_solve"})])
+                                        (2100, 1, {"k_frame_visual", "k_assign_small"}), (3000, 1, {"k_frame_visual", "k_assign_small"}),
+                                        (4096, 1, {"k_frame", "k_visual_cost", "k_assign_small"}),   # (1024 tiles of 64 x 64: the contraction takes 128 x 128 tiles, a launch of its own)
+                                        (2100, 3, {"k_frame_visual", "k_assign_label", "k_assign_solve"}),
+                                        (4200, 1, {"k_frame_visual", "k_assign_label", "k_assign_solve"})])
 def test_launches_of_frames_beyond_1024_tracks(t, k, expect):
     """1000 detections against 1025 .. 2048 tracks (a tracker loop's table once idle tracks linger): first phase + the ONE-workgroup tail,
-    two columns per thread — two launches, with vote words (one observation per track) and with class words (three); beyond 2048 tracks:
-    first phase, label, solve.  No stand-alone contraction, no resolve kernel."""
+    two columns per thread — two launches, with vote words (one observation per track) and with class words (three); up to 4096 tracks
+    with vote words: four columns per thread (k_assign_small2<.., 1, 4>); beyond (class words: beyond 2048): first phase, label, solve.
+    No stand-alone contraction, no resolve kernel."""
     rng = np.random.default_rng(1503 + t + k)
     sc = synth.visual_scene(rng, t, 1000, 128, k)
     cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=128,
