@@ -512,6 +512,53 @@ def test_churned_loop_with_eviction_matches_oracle(kind, backend):
 @pytest.mark.gpu
 @UPKEEP
 @pytest.mark.parametrize("kind", ["sort", "visual"])
+def test_loop_of_more_than_1024_objects_matches_oracle(kind, backend):
+    """1300 objects (SORT) / 1100 objects (VisualSORT, one observation per track) with objects leaving and entering: frames of more than
+    1024 detections against tables that grow towards 2048 rows — the one-workgroup tail with two rows and two columns per thread behind the
+    facade (results, winning columns for the device upkeep, new-track ids), frame by frame the oracle tracker's tracks."""
+    rng = np.random.default_rng(1300 + (kind == "visual"))
+    n, d = (1300, 0) if kind == "sort" else (1100, 32)
+    if kind == "visual":
+        opts = (TR.VisualSortOptions().max_idle_epochs(2).kept_history_length(3).visual_metric(TR.VisualSortMetricType.cosine(0.9))
+                .positional_metric(IoU(0.3)).visual_minimal_track_length(1).visual_max_observations(1).visual_min_votes(1))
+        g, o = make(backend, "visual", opts=opts, feature_len=d), make("oracle", "visual", opts=opts, feature_len=d)
+    else:
+        kw = dict(bbox_history=3, max_idle_epochs=2, method=IoU(0.3), min_confidence=0.05)
+        g, o = make(backend, "sort", **kw), make("oracle", "sort", **kw)
+    try:
+        pool = n + 6 * 120
+        world = synth.dense_boxes(rng, pool, (6000.0, 4500.0))
+        ident = synth.reid_identities(rng, pool, d) if kind == "visual" else None
+        active = np.arange(n)
+        fresh = n
+        rows_seen = []
+        for f in range(6):
+            world = synth.jitter_boxes(rng, world, 1.5)
+            if f:
+                gone = rng.choice(n, 120, replace=False)
+                active[gone] = np.arange(fresh, fresh + 120)
+                fresh += 120
+            boxes = boxes_to_u2d(world[active])
+            if kind == "visual":
+                feats = synth.observe(rng, ident[active], 0.01)
+                items = [TR.VisualSortObservation(feats[k], 0.9, boxes[k], None) for k in range(n)]
+            else:
+                items = [(boxes[k], None) for k in range(n)]
+            rg, ro = g.predict(items), o.predict(items)
+            assert_tracks_equal(rg, ro)
+            cnt = C.c_uint32()
+            g.lib.sa_tracks_count(g.lib.sa_tracker_engine(g.h), 0, C.byref(cnt))
+            rows_seen.append(int(cnt.value))
+        assert g.active_tracks() == o.active_tracks()
+        assert max(rows_seen) > n and max(rows_seen) <= 2048, rows_seen
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.gpu
+@UPKEEP
+@pytest.mark.parametrize("kind", ["sort", "visual"])
 def test_frame_sizes_from_empty_to_hundreds_match_oracle(kind, backend):
     """predict() keeps its work arrays between calls: frames that shrink, grow and vanish (0, 9, 0, 260, 3, ...) must leave nothing of the
     previous frame behind — every frame's tracks against the oracle tracker's."""
