@@ -922,6 +922,26 @@ __device__ __forceinline__ uint32_t constraint_mask(const GemmCols& col, RowGeo 
   }
   return failed;
 }
+// A candidate's row operands in raw-feature mode (the fused first phase: nothing the preparation blocks write may be read): what
+// frame_prep_block derives for it (visual_sort/simple_api.rs:130-170, metric.rs:227-249).  FETCH issues the loads — which of them by the
+// scene's flags alone, none behind a branch on a loaded value — and the values are turned into geometry and the feature_can_be_used gate
+// BEHIND the main loop: with the gate's short-circuit chain in front of it (present? -> quality -> own area) the tile's first wave
+// started its loop a memory round trip late, and the other three waited for it at the exchange.
+struct RawRow { float xc, yc, aspect, height, q, oa; uint32_t fp; };
+__device__ __forceinline__ RawRow raw_row_fetch(const SceneDev& S, uint32_t gi) {
+  RawRow r;
+  const BoxRaw br = sa_ldg(S.c_raw + gi);
+  r.xc = br.box.xc; r.yc = br.box.yc; r.aspect = br.box.aspect; r.height = br.box.height;
+  r.fp = (S.flags & SCN_HAS_FPRESENT) ? (uint32_t)S.c_fpresent_in[gi] : 1u;
+  r.q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
+  r.oa = (S.flags & SCN_HAS_OWN) ? S.c_own[gi] : __builtin_nanf("");
+  return r;
+}
+__device__ __forceinline__ bool raw_row_usable(const SceneDev& S, const SaParams& p, const RawRow& r, sa_geo* g) {
+  g->xc = r.xc; g->yc = r.yc; g->r = sa_radius(r.aspect, r.height); g->hha = r.height * r.height * r.aspect;
+  const bool perc_ok = !(r.oa == r.oa) || r.oa >= p.visual_minimal_own_area_use;
+  return (S.flags & SCN_HAS_FEATS) != 0 && r.fp != 0 && sa_area(r.aspect, r.height) >= p.visual_minimal_area && r.q >= p.visual_minimal_quality_use && perc_ok;
+}
 // EU: distance::euclidean (distance.rs:9-19) on the matrix cores.  sqrt(|a|^2 + |b|^2 - 2 a.b) cancels on near-identical vectors —
 // exactly the true matches — so a cell whose expansion is not trustworthy to 1e-5 relative, d^2 < rho (|a|^2 + |b|^2) with
 // rho = 5e-3 sqrt(Dp) (twice the largest error of the f32 expansion seen over 10^6 pairs, scripts/euclid_error_model.py), is FLAGGED
@@ -1011,26 +1031,13 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   // C2) disappears behind the main loop.  Row operands: thread r < BM holds row r (goes through LDS afterwards).
   float pre_na = 0.f, pre_us = 0.f;
   sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  RawRow pre_raw{0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0u};
   static_assert(BM <= 256, "one thread per tile row");
-  if (tid < (uint32_t)BM && m0 + tid < N) {
+  const bool pre_in = tid < (uint32_t)BM && m0 + tid < N;
+  if (pre_in) {
     const uint32_t gi = m0 + tid;
-    if constexpr (RAW) {
-      // what frame_prep_block derives for this candidate (visual_sort/simple_api.rs:130-170, metric.rs:227-249)
-      const BoxRaw r = sa_ldg(S.c_raw + gi);
-      const sa_box& b = r.box;
-      pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
-      bool usable = false;
-      if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
-        const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
-        bool perc_ok = true;
-        if (S.flags & SCN_HAS_OWN) {
-          const float oa = S.c_own[gi];
-          if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
-        }
-        usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
-      }
-      pre_us = usable ? 1.f : 0.f;
-    } else {
+    if constexpr (RAW) pre_raw = raw_row_fetch(S, gi);   // (loads only: raw_row_usable behind the main loop)
+    else {
       pre_na = S.c_fnorm[gi];
       pre_us = S.c_usable[gi] ? 1.f : 0.f;
       pre_g = sa_ldg(S.c_geo + gi);
@@ -1069,6 +1076,7 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
   else if constexpr (RAW) gemm_mainloop<BM, BN, KG, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr, &nsq);
   else gemm_mainloop<BM, BN, KG>((gfloat_p)S.c_feat, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, tr);
 
+  if constexpr (RAW) { if (pre_in) pre_us = raw_row_usable(S, p, pre_raw, &pre_g) ? 1.f : 0.f; }
   constexpr int R = 16 / KG;
   float part[TM == 1 && TN == 1 ? R : 1];
   if constexpr (TM == 1 && TN == 1) kgroup_reduce_spread<KG>(acc[0][0], lds, part);
@@ -1364,22 +1372,12 @@ __device__ __forceinline__ void visual_tile96(const SceneDev& S, const SaParams&
   // row operands, fetched before the contraction (thread r < 64 holds row r): what frame_prep_block derives for the candidate
   float pre_us = 0.f;
   sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  RawRow pre_raw{0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0u};
+  bool pre_in = false;
   if (tid < (uint32_t)BM && m0 + tid < N) {
     const uint32_t gi = m0 + tid;
-    const BoxRaw r = sa_ldg(S.c_raw + gi);
-    const sa_box& b = r.box;
-    pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
-    bool usable = false;
-    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
-      const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
-      bool perc_ok = true;
-      if (S.flags & SCN_HAS_OWN) {
-        const float oa = S.c_own[gi];
-        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
-      }
-      usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
-    }
-    pre_us = usable ? 1.f : 0.f;
+    pre_raw = raw_row_fetch(S, gi);   // (loads only: raw_row_usable behind the main loop)
+    pre_in = true;
   }
   GemmCols col[2];   // [0]: column x 32 + lr of the tile, [1]: column 64 + lr
 #pragma unroll
@@ -1407,6 +1405,7 @@ __device__ __forceinline__ void visual_tile96(const SceneDev& S, const SaParams&
   float acc2[8];
   float nsq = 0.f;
   gemm_mainloop_ks96<3, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc, acc2, tr, &nsq, p.ks_yield);
+  if (pre_in) pre_us = raw_row_usable(S, p, pre_raw, &pre_g) ? 1.f : 0.f;
   SA_STAMP(tr, 3);
   float* s_na = lds;                      // [BM]
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
@@ -1535,22 +1534,12 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
   const uint32_t wm = w4 >> 1, wn = w4 & 1u, lr = lane & 31u, lh = lane >> 5;
   float pre_us = 0.f;
   sa_geo pre_g{0.f, 0.f, 0.f, 0.f};
+  RawRow pre_raw{0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0u};
+  bool pre_in = false;
   if (tid < (uint32_t)BM && m0 + tid < N) {
     const uint32_t gi = m0 + tid;
-    const BoxRaw r = sa_ldg(S.c_raw + gi);
-    const sa_box& b = r.box;
-    pre_g.xc = b.xc; pre_g.yc = b.yc; pre_g.r = sa_radius(b.aspect, b.height); pre_g.hha = b.height * b.height * b.aspect;
-    bool usable = false;
-    if ((S.flags & SCN_HAS_FEATS) && (!(S.flags & SCN_HAS_FPRESENT) || S.c_fpresent_in[gi])) {
-      const float q = (S.flags & SCN_HAS_QUALITY) ? S.c_quality[gi] : 1.0f;
-      bool perc_ok = true;
-      if (S.flags & SCN_HAS_OWN) {
-        const float oa = S.c_own[gi];
-        if (oa == oa) perc_ok = oa >= p.visual_minimal_own_area_use;
-      }
-      usable = sa_area(b.aspect, b.height) >= p.visual_minimal_area && q >= p.visual_minimal_quality_use && perc_ok;
-    }
-    pre_us = usable ? 1.f : 0.f;
+    pre_raw = raw_row_fetch(S, gi);   // (loads only: raw_row_usable behind the main loop)
+    pre_in = true;
   }
   const uint32_t lc = wn * 32 + lr, gj = n0 + lc;
   GemmCols col;
@@ -1572,6 +1561,7 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
   float nsq = 0.f;
   if constexpr (KSL) gemm_mainloop_ks<4, true, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_ffrag, N, TK, S.Dp, m0, n0, lds, acc[0][0], nullptr, &nsq);
   else gemm_mainloop<BM, BN, 1, true>((gfloat_p)S.c_feat_raw, (gfloat_p)S.t_feat, N, TK, S.Dp, m0, n0, lds, acc, nullptr, &nsq);
+  if (pre_in) pre_us = raw_row_usable(S, p, pre_raw, &pre_g) ? 1.f : 0.f;
   float* s_na = lds;                      // [BM]
   sa_geo* s_g = (sa_geo*)(lds + 2 * BM);  // [BM]
   float* s_np = lds + 6 * BM;             // [BM] squared norms of the candidates' rows (raw mode)
