@@ -300,14 +300,13 @@ hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t
 // 8: with vote words)
 #define SA_SMALL_N 1024
 // ... up to SA_SMALL_T tracks (two columns per thread of that workgroup: k_assign_small<.., TC = 2>), and up to SA_SMALL_T detections as
-// well (k_assign_small2: two rows per thread too) unless the frame votes through class words (deeper banks: a register set of K words per
-// row AND per column) — never with the 10-bit index words
+// well (k_assign_small2: two rows per thread too; or one row and four columns: 1024 x 4096) — never with the 10-bit index words
 #define SA_SMALL_T 2048
 static inline bool sa_small_tail_ok(uint32_t maxN, uint32_t maxT, uint32_t words) {
   if (maxN <= SA_SMALL_N && maxT <= SA_SMALL_N) return true;
   if (words == 2u) return false;
-  if (maxT > SA_SMALL_T) return maxN <= SA_SMALL_N && maxT <= 2u * SA_SMALL_T && words != 3u;   // (k_assign_small2<.., 1, 4>: 1024 x 4096)
-  return maxN <= SA_SMALL_N || (maxN <= SA_SMALL_T && words != 3u);   // (k_assign_small<.., TC = 2> / k_assign_small2)
+  if (maxT > SA_SMALL_T) return maxN <= SA_SMALL_N && maxT <= 2u * SA_SMALL_T;   // (k_assign_small2<.., 1, 4>: 1024 x 4096)
+  return maxN <= SA_SMALL_T;   // (k_assign_small<.., TC = 2> / k_assign_small2)
 }
 // done_seq != 0 (stages 5 / 8): every scene's workgroup reports the end of its results itself, by storing done_seq to SceneDev::out_done —
 // the host polls that word instead of waiting for a completion signal of the dispatch (a dispatch that carries one holds the NEXT

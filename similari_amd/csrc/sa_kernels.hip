@@ -1189,6 +1189,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
   __shared__ uint8_t s_cexcl[WORDS ? TCAP : 4];
   __shared__ uint32_t s_bt[WORDS ? RCAP : 1];
   __shared__ uint32_t s_cq[WORDS ? TCAP : 1];
+  __shared__ uint32_t s_wmk[WORDS ? SA_SMALL_N / WAVE : 1];   // class words: the wave maxima of the first phase's max-key slots
   TAIL_STAMP(0);
   uint32_t rawcnt[RC];
 #pragma unroll
@@ -1204,7 +1205,41 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
   uint32_t bt[RC];
 #pragma unroll
   for (int rr = 0; rr < RC; ++rr) { vw0[rr] = -1; bt[rr] = SA_NONE; has_verdict[rr] = false; }
+  // Class words (SCN_WORDSK: banks of 2..8 observations, k_assign_small has the why): which group wins needs the frame's max_dist, known
+  // behind the first barrier — here the K words of a row / column are read TWICE (whether a row has any group at all now, the winners
+  // behind the barrier, one row or column at a time) instead of being held in registers across it: two rows and two to four columns
+  // per thread would be 48 .. 80 registers of words.
+  bool clsmode = false;
+  if constexpr (WORDS) clsmode = (S.flags & SCN_WORDSK) != 0;
+  if constexpr (WORDS) if (clsmode) {
+    const uint32_t K = S.K;
+    uint32_t mk = q < S.nkeys ? S.vis_max_key[q] : 0u;
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+      bool any = false;
+#pragma unroll
+      for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+        const unsigned long long w = S.row_cls[(size_t)(row < N ? row : 0u) * K + (c < K ? c : K - 1u)];
+        any = any || (c < K && row < N && w != ~0ull);
+      }
+      has_verdict[rr] = any;
+      s_bt[row] = SA_NONE;
+    }
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) s_cq[q + (uint32_t)cc * SA_SMALL_N] = SA_NONE;
+    for (uint32_t i = q + SA_SMALL_N; i < S.nkeys; i += SA_SMALL_N) {
+      const uint32_t v = S.vis_max_key[i];
+      mk = v > mk ? v : mk;
+    }
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+      const uint32_t ok = __shfl_xor(mk, o);
+      mk = ok > mk ? ok : mk;
+    }
+    if (q % WAVE == 0) s_wmk[q / WAVE] = mk;
+  }
   if constexpr (WORDS) {
+   if (!clsmode) {
     unsigned long long rb[RC], cb[TC];
 #pragma unroll
     for (int rr = 0; rr < RC; ++rr) { const uint32_t i = q + (uint32_t)rr * SA_SMALL_N; rb[rr] = i < N ? S.row_best[i] : ~0ull; }
@@ -1226,6 +1261,7 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
       if (S.tap_row_best && j < T) S.tap_col_best[j] = cb[cc];
       s_cq[j] = cb[cc] != ~0ull ? (uint32_t)cb[cc] : SA_NONE;
     }
+   }
   } else {
 #pragma unroll
     for (int rr = 0; rr < RC; ++rr) {
@@ -1284,6 +1320,44 @@ __global__ __launch_bounds__(SA_SMALL_N) void k_assign_small2(const SceneDev* __
     if (q % WAVE == 0) s_wsum[q / WAVE] = tsum;
   }
   sa_lds_barrier();
+  if constexpr (WORDS) if (clsmode) {
+    const uint32_t K = S.K;
+    uint32_t mk = 0;
+#pragma unroll
+    for (uint32_t w2 = 0; w2 < SA_SMALL_N / WAVE; ++w2) mk = s_wmk[w2] > mk ? s_wmk[w2] : mk;
+    const double max_dist = mk ? (double)sa_key_f32(mk) : -1.0;
+    // W = c max_dist - sum, heaviest wins, lowest index among equals (k_assign_small's best_of); the words re-armed, the taps fed
+    auto settle = [&](unsigned long long SA_G* words, unsigned long long SA_G* tap, uint32_t i, bool in) -> uint32_t {
+      unsigned long long cls[SA_CLS_MAXK];
+#pragma unroll
+      for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) cls[c] = words[(size_t)(in ? i : 0u) * K + (c < K ? c : K - 1u)];
+      double bw = 0.0;
+      uint32_t bi = SA_NONE;
+#pragma unroll
+      for (uint32_t c = 0; c < SA_CLS_MAXK; ++c) {
+        const unsigned long long v = (c < K && in) ? cls[c] : ~0ull;
+        if (tap && c < K && in) tap[(size_t)i * K + c] = v;
+        if (v == ~0ull) continue;
+        words[(size_t)i * K + c] = ~0ull;
+        const double w = (double)(c + 1u) * max_dist - (double)sa_key_f32((uint32_t)(v >> 32));
+        const uint32_t idx = (uint32_t)v;
+        if (bi == SA_NONE || w > bw || (w == bw && idx < bi)) { bw = w; bi = idx; }
+      }
+      return bi;
+    };
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const uint32_t row = q + (uint32_t)rr * SA_SMALL_N;
+      bt[rr] = settle(S.row_cls, S.tap_row_best, row, row < N);
+      s_bt[row] = bt[rr];
+    }
+#pragma unroll
+    for (int cc = 0; cc < TC; ++cc) {
+      const uint32_t j = q + (uint32_t)cc * SA_SMALL_N;
+      s_cq[j] = settle(S.col_cls, S.tap_col_best, j, j < T);
+    }
+    sa_lds_barrier();
+  }
   if constexpr (WORDS) {
 #pragma unroll
     for (int rr = 0; rr < RC; ++rr) {

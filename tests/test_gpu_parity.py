@@ -794,6 +794,24 @@ def test_visual_cosine_1000_x_1500_takes_the_64x96_tiles_by_itself():
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.paths("general", "bestfit_tile")
+@pytest.mark.parametrize("n,t,d,k", [(1200, 1500, 64, 3), (900, 2300, 64, 2), (1500, 1100, 32, 5)])
+def test_class_words_beyond_the_small_frames(n, t, d, k):
+    """Banks of 2..5 observations (class words) on frames of more than 1024 detections or more than 2048 tracks: the one-workgroup tail's
+    wider forms read a row's / column's K words twice (k_assign_small2) instead of holding them across the barrier — the timed launch's
+    own votes, ids and vote types against the oracle; by the path markers also on the many-workgroup tail and through the weight matrix."""
+    rng = np.random.default_rng(7000 + n + t + k)
+    sc = synth.visual_scene(rng, t, n, d, k, canvas=(4000.0, 3000.0), new_fraction=0.1)
+    pres = sc["track_present"]
+    pres[rng.uniform(size=pres.shape) < 0.15] = 0
+    cfg = abi.make_config(positional="iou", positional_threshold=0.3, visual="cosine", visual_threshold=0.2, feature_len=d,
+                          max_observations=k, visual_min_votes=1, visual_minimal_track_length=2, visual_minimal_quality_use=0.55,
+                          visual_minimal_area=3000.0, positional_min_confidence=0.1, max_idle_epochs=5)
+    ids, votes, ref = check_visual(cfg, sc)
+    assert (votes == abi.SA_VOTE_VISUAL).sum() > 100
+    assert (votes == abi.SA_VOTE_POSITIONAL).sum() > 0
+
+
 @pytest.mark.paths("general", "separate_resolve")
 def test_visual_cosine_more_than_1024_detections():
     """N > 1024 (1100 detections, a fifth of them without a feature, against 900 tracks): the one-workgroup tail with two rows per thread
@@ -1604,12 +1622,12 @@ def test_c4_shaped_sort_frame_takes_two_launches():
                                         (1500, 3, {"k_frame_visual", "k_assign_small"}),
                                         (2100, 1, {"k_frame_visual", "k_assign_small"}), (3000, 1, {"k_frame_visual", "k_assign_small"}),
                                         (4096, 1, {"k_frame", "k_visual_cost", "k_assign_small"}),   # (1024 tiles of 64 x 64: the contraction takes 128 x 128 tiles, a launch of its own)
-                                        (2100, 3, {"k_frame_visual", "k_assign_label", "k_assign_solve"}),
+                                        (2100, 3, {"k_frame_visual", "k_assign_small"}),   # (class words read twice: k_assign_small2<.., 1, 4>)
                                         (4200, 1, {"k_frame_visual", "k_assign_label", "k_assign_solve"})])
 def test_launches_of_frames_beyond_1024_tracks(t, k, expect):
     """1000 detections against 1025 .. 2048 tracks (a tracker loop's table once idle tracks linger): first phase + the ONE-workgroup tail,
     two columns per thread — two launches, with vote words (one observation per track) and with class words (three); up to 4096 tracks
-    with vote words: four columns per thread (k_assign_small2<.., 1, 4>); beyond (class words: beyond 2048): first phase, label, solve.
+    four columns per thread (k_assign_small2<.., 1, 4>); beyond: first phase, label, solve.
     No stand-alone contraction, no resolve kernel."""
     rng = np.random.default_rng(1503 + t + k)
     sc = synth.visual_scene(rng, t, 1000, 128, k)
