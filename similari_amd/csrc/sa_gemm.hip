@@ -1062,8 +1062,9 @@ __device__ __forceinline__ void visual_cosine_tile(const SceneDev& S, const SaPa
       col[n].nb = nb;
       const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
       col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
-      for (uint32_t i = 0; i < p.cons.n; ++i)
-        if (p.cons.delta[i] >= delta) { col[n].cmax = p.cons.max_dist[i]; break; }
+      // (the FIRST constraint whose window holds the track's age — as a chain of selects from the last one down: a `break` on the loaded
+      // epoch would hold every wave of the tile in front of its main loop for the load)
+      for (uint32_t i = p.cons.n; i-- > 0;) col[n].cmax = p.cons.delta[i] >= delta ? p.cons.max_dist[i] : col[n].cmax;
     }
   }
 
@@ -1397,8 +1398,9 @@ __device__ __forceinline__ void visual_tile96(const SceneDev& S, const SaParams&
       col[n].nb = nb;
       const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
       col[n].ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
-      for (uint32_t i = 0; i < p.cons.n; ++i)
-        if (p.cons.delta[i] >= delta) { col[n].cmax = p.cons.max_dist[i]; break; }
+      // (the FIRST constraint whose window holds the track's age — as a chain of selects from the last one down: a `break` on the loaded
+      // epoch would hold every wave of the tile in front of its main loop for the load)
+      for (uint32_t i = p.cons.n; i-- > 0;) col[n].cmax = p.cons.delta[i] >= delta ? p.cons.max_dist[i] : col[n].cmax;
     }
   }
   f32x16 acc;
@@ -1554,8 +1556,7 @@ __device__ __forceinline__ void visual_ktile(const SceneDev& S, const SaParams& 
     col.nb = nb;
     const uint64_t delta = S.epoch > te ? S.epoch - te : te - S.epoch;
     col.ok = (pres != 0) & (cnt >= p.min_track_len) & (p.max_idle >= delta);
-    for (uint32_t i = 0; i < p.cons.n; ++i)
-      if (p.cons.delta[i] >= delta) { col.cmax = p.cons.max_dist[i]; break; }
+    for (uint32_t i = p.cons.n; i-- > 0;) col.cmax = p.cons.delta[i] >= delta ? p.cons.max_dist[i] : col.cmax;   // (selects, no break: see visual_cosine_tile)
   }
   f32x16 acc[1][1];
   float nsq = 0.f;
