@@ -441,10 +441,11 @@ __device__ __forceinline__ void positional_tile(const SceneDev& S, const SaParam
     // the tile's survivors fit 32 groups (cnt is uniform over the block), EIGHT: a pass over a list of up to eight vertices is then ONE step
     // of the dependent chain instead of two (a quad clipped by a quad: 4 -> at most 8 vertices), and a tile's clip phase is that chain
     auto clip_pairs = [&](auto LTAG) {
-      constexpr uint32_t L = decltype(LTAG)::value, GROUPS = 256u / L;
+      // (the groups' vertex lists are the bulk of the tile's LDS — POS_WORKERS of them: with fewer than 256 / L the surplus groups idle)
+      constexpr uint32_t L = decltype(LTAG)::value, GROUPS = (256u / L) < POS_WORKERS ? (256u / L) : POS_WORKERS;
       const uint32_t grp = tid / L, gl = tid & (L - 1u), gshift = lane & (64u - L);
-      double* ws = s_poly + grp * (4 * SA_POLY_CAP);
-      for (uint32_t sidx = grp; sidx < cnt; sidx += GROUPS) {
+      double* ws = s_poly + (grp < GROUPS ? grp : 0u) * (4 * SA_POLY_CAP);
+      for (uint32_t sidx = grp < GROUPS ? grp : cnt; sidx < cnt; sidx += GROUPS) {
         const uint32_t c = s_list[sidx];
         const uint32_t li = c >> 8, lj = c & 255u;
         const uint32_t i = i0 + li, j = j0 + lj;

@@ -194,12 +194,16 @@ static inline void sa_pos_trace_hook(hipStream_t, uint32_t) {}
 #define SA_POS_TRACE_PTR() nullptr
 #endif
 // The first launch of a frame: blockIdx.y < pos_rows -> a positional tile; the rows above carry the frame-preparation blocks.
-template <int NSUB, bool UNION>
+// PW: groups of clipping lanes whose vertex lists the tile keeps in LDS (the bulk of it: 24 KB at 64).  32 of them make the tile 23.6 KB —
+// six blocks per CU instead of four — at the price of a second clip round for tiles with more than 32 surviving pairs: taken by launches
+// of more than 1024 blocks (sa_launch_frame), where a tile that waits for a place costs more than a round (c2b: 2016 tiles, launch
+// 25.8 -> 22.9 us); C3's 512 tiles, all resident either way, would pay 7.7 -> 9.7.
+template <int NSUB, bool UNION, int PW = 64>
 __global__ __launch_bounds__(256) void k_frame(const SceneDev* __restrict__ scenes, SaParams p, uint32_t pos_rows_) {
   const SceneDev S = scenes[blockIdx.z];  // by value: wave-uniform SGPRs, cannot alias the stores below
-  __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB>)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PosSmem<NSUB, PW>)];
   const uint32_t pos_rows = pos_rows_ & 0x7fffffffu;  // (bit 31: the preparation blocks run their reset half only)
-  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, 64, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x, SA_POS_TRACE_PTR());
+  if (blockIdx.y < pos_rows) positional_tile<false, true, NSUB, UNION, true, PW, true>(S, p, blockIdx.x, blockIdx.y, smem, threadIdx.x, SA_POS_TRACE_PTR());
   else frame_prep_block(S, p, (blockIdx.y - pos_rows) * gridDim.x + blockIdx.x, threadIdx.x, (pos_rows_ >> 31) != 0);
 }
 // Parity taps: the dense f32 cost matrix, no side effects.
@@ -2657,7 +2661,10 @@ hipError_t sa_launch_frame(const SceneDev* scenes, uint32_t ns, uint32_t maxN, u
   const dim3 grid(gx, pos_rows + cdiv(prep_blocks, gx), ns);
   sa_pos_trace_hook(st, grid.x * grid.y * grid.z);
   const uint32_t pr = pos_rows | (prep == 3 ? 0x80000000u : 0u);
-  if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pr);
+  const bool crowded = (size_t)grid.x * grid.y * grid.z > 1024u;   // (more blocks than four per CU hold: the lighter tile, six per CU)
+  if (wide && uni && crowded) SA_LAUNCH((k_frame<4, true, 32>), grid, dim3(256), 0, st, scenes, p, pr);
+  else if (wide && uni) SA_LAUNCH((k_frame<4, true>), grid, dim3(256), 0, st, scenes, p, pr);
+  else if (wide && crowded) SA_LAUNCH((k_frame<4, false, 32>), grid, dim3(256), 0, st, scenes, p, pr);
   else if (wide) SA_LAUNCH((k_frame<4, false>), grid, dim3(256), 0, st, scenes, p, pr);
   else if (uni) SA_LAUNCH((k_frame<1, true>), grid, dim3(256), 0, st, scenes, p, pr);
   else SA_LAUNCH((k_frame<1, false>), grid, dim3(256), 0, st, scenes, p, pr);
