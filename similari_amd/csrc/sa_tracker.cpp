@@ -206,6 +206,7 @@ struct sa_tracker {
   uint64_t n_active = 0;                   // tracks in the main store (sum of active_shard_stats)
   std::vector<sa_sort_track> wasted_store;   // (what wasted() hands out of a wasted track: its SortTrack)
   uint32_t waste_counter = 0;
+  bool evict_wave = false;      // the previous request set evicted: this set's scenes join from 16 expired rows on (scan_expired)
   // predict()'s per-scene work arrays, kept between calls: a frame allocates nothing once the arrays have grown to its size.  Everything
   // the work AFTER the launches reads of the caller's observations is copied here (boxes, custom ids): the reference takes its request by
   // value, and so a caller of sa_tracker_predict_batch_begin may reuse its arrays as soon as that call has returned.
@@ -225,6 +226,7 @@ struct sa_tracker {
     std::vector<uint64_t> winners, tids, new_ids;
     std::vector<int32_t> wcols;
     std::vector<uint64_t> evict_ids;           // rows of the scene's table that no later frame can match (scan_expired)
+    uint32_t n_expired = 0;                    // how many such rows the last scan counted (evicted or not)
     int evict_rc = SA_OK;                      // ... staged in the engine by the scene's own job (sa_tracks_remove_stage)
     std::vector<Track*> trps;
     sa_detections det{};
@@ -602,14 +604,20 @@ Track* winner_row(SceneState& S, size_t rows_before, int32_t col, uint64_t dest,
 // eviction (see SceneState::row_epoch): tracks of the set's scenes that no frame from now on can match leave the engine's table.
 // The scan is per scene (it rides in the scene's assemble job); the removals of every scene of the set are ONE call — one gather launch
 // per dozen scenes, no drain.
-void scan_expired(const sa_tracker_options& o, sa_tracker::SceneScratch& W) {
+// wave: another scene of the tracker evicted in the previous request set — this scene joins from 16 expired rows on.  The gathers of a set's
+// scenes are ONE launch (per dozen scenes) whatever their number, and a set without any eviction skips that launch and its commit
+// altogether (7 us of host work + a dependent launch in front of the association): scenes that reach their 64 rows out of phase made
+// nearly every set of a churned 8-scene loop pay for it; after one wave they evict together, every third set or so.  When a row leaves the
+// engine's table changes no result (it can match nothing any more: the tests hold the facade against the oracle tracker, which never evicts).
+void scan_expired(const sa_tracker_options& o, sa_tracker::SceneScratch& W, bool wave = false) {
   W.evict_ids.clear();
   const SceneState& S = *W.st;
   const uint64_t cur = W.epoch;
   size_t expired = 0;
   for (uint64_t ep : S.row_epoch) expired += ep + o.max_idle_epochs < cur ? 1u : 0u;
   // (a removal is a gather of the whole table; a row left in it costs the frames until auto_waste ~1/64 us each: it pays from about 64 rows on)
-  if (expired < 64 || expired * 16 < S.rows.size()) return;
+  W.n_expired = (uint32_t)expired;
+  if (wave ? expired < 16 : (expired < 64 || expired * 16 < S.rows.size())) return;
   W.evict_ids.reserve(expired);
   for (size_t r = 0; r < S.rows.size(); ++r)
     if (S.row_epoch[r] + o.max_idle_epochs < cur) W.evict_ids.push_back(S.rows[r]->id);
@@ -911,14 +919,22 @@ int predict_fused(sa_tracker* t, uint32_t n_scenes, const uint64_t* scene_ids, c
   if (rc == SA_OK) {
     // per scene, side by side: which of its table's rows no later frame can match (staged in the engine: sa_tracks_remove_stage), and the
     // copy of its detections into the staging arena
+    const bool evict_wave = t->evict_wave && n_scenes > 1;
     run_jobs(t, n_scenes, [&](uint32_t s) {
       sa_tracker::SceneScratch& W = ss[s];
-      scan_expired(o, W);
+      scan_expired(o, W, evict_wave);
       W.evict_rc = W.evict_ids.empty() ? SA_OK : sa_tracks_remove_stage(t->eng, W.st->id, (uint32_t)W.evict_ids.size(), W.evict_ids.data());
       W.rc = sa_batch_fill(t->eng, W.slot);
     });
     // (the gathers of every staged scene: one launch per dozen scenes, in front of the request set's own launches; the facade's side of an
     // eviction follows in the scene's merge job)
+    {   // (the next set is a wave when a scene evicted on its own account in this one, or is about to — 40 expired rows: at a few per
+        // cent of churn its 64 are a set or two away — so that the scenes go together instead of one after the other; a wave set does not
+        // start another)
+      bool soon = false;
+      for (uint32_t s = 0; s < n_scenes; ++s) soon = soon || !ss[s].evict_ids.empty() || ss[s].n_expired >= 40u;
+      t->evict_wave = soon && !evict_wave;
+    }
     const int rce = evict_expired(t, ss, n_scenes, true, false);
     for (uint32_t s = 0; s < n_scenes && rc == SA_OK; ++s) rc = ss[s].rc;
     if (rce != SA_OK || rc != SA_OK) {
