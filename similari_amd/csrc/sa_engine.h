@@ -296,7 +296,7 @@ void sa_visual_tile(int visual_kind, bool eu_mfma, uint32_t maxN, uint32_t maxTK
 hipError_t sa_launch_bestfit(const SceneDev* scenes, uint32_t n_scenes, uint32_t maxN, uint32_t maxT,
                              const SaParams& p, hipStream_t st, int stage);
 // stage 1 label + push, 3 solve + results (2 / 4: the same with the visual vote read from the vote words — the label kernel turns
-// them into verdicts, the solver re-arms them); stage 5 = the whole tail in ONE workgroup per scene (requires maxN, maxT <= SA_SMALL_N;
+// them into verdicts, the solver re-arms them); stage 5 = the whole tail in ONE workgroup per scene (requires sa_small_tail_ok(maxN, maxT, ..);
 // 8: with vote words)
 #define SA_SMALL_N 1024
 // ... up to SA_SMALL_T tracks (two columns per thread of that workgroup: k_assign_small<.., TC = 2>), and up to SA_SMALL_T detections as

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_bestfit_resolve(const SceneDev* __restr
 // rows that already hold a visual decision take no part (feature_winners.contains_key(from), visual_sort/voting.rs:77) and
 // columns won visually are skipped while relaxing (excluded_tracks, :62-71).  A component may therefore be larger than
 // strictly needed — harmless, it is still solved exactly.
-//   N, T <= SA_SMALL_N: k_assign_small — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
+//   N, T <= SA_SMALL_T (or N <= SA_SMALL_N, T <= 2 SA_SMALL_T; sa_small_tail_ok): k_assign_small / k_assign_small2 — ONE workgroup per scene: edges -> LDS, components, greedy start, group-cooperative
 //            shortest augmenting paths for the rows the start left over (duals, matches and per-row minima in LDS), results,
 //   else: k_assign_label (component root per row, rows pushed onto their root's list and counted), k_assign_solve (a component
 //            of one or two rows: from the root thread's registers; up to 64 rows and 256 columns: one wavefront on a renumbered
@@ -609,8 +609,8 @@ __device__ __forceinline__ void sa_lds_barrier() { asm volatile("s_waitcnt lgkmc
 //      loops — nearest labelled column, relax a row's edges — spread over the lanes, minima by lane reductions.
 // A component of hundreds of rows (a crowd under a low IoU threshold) is then a few hundred microseconds of group work instead
 // of seconds of one lane's dependent LDS chain; the usual one- and two-row components never reach step 3.
-// Needs N <= SA_SMALL_N and T <= SA_SMALL_N (launcher): rows, columns and the usable edges (up to POOL of them; more stay in the
-// HBM lists and are read from there) live in LDS.
+// Needs N <= SA_SMALL_N and T <= SA_SMALL_N (launcher; TC = 2: T <= SA_SMALL_T; wider frames: k_assign_small2 below): rows, columns and
+// the usable edges (up to POOL of them; more stay in the HBM lists and are read from there) live in LDS.
 // the dense solver (sa_dense.h): SA_DENSE_NT threads, each owning T / SA_DENSE_NT columns; components with at least SA_DENSE_MIN_ROOTS
 // search roots on at least SA_DENSE_MIN_COLS columns (or whose edge lists stayed in HBM) go to it
 #define SA_DENSE_NT 256
